@@ -1,0 +1,218 @@
+/* theora_hip.h -- C ABI of the MI355X (gfx950) backend for libtheora's per-fragment
+ * reconstruction path.
+ *
+ * This is the boundary a maintainer binds from lib/hip/hipstate.c:
+ * the ten oc_base_opt_vtable slots (lib/state.h:352-370) and the encoder's block
+ * kernels (oc_enc_opt_vtable, lib/encint.h:292-326), plus the frame-scope entry points
+ * a device backend needs where the reference has its MCU loop (lib/decode.c:2858-2962).
+ * Plain C types only; every pointer marked "device" is HBM memory of the current HIP
+ * device, everything else is host memory.  All functions return 0 or a negative TH_E*
+ * code (include/theora/codec.h:77-93); none of them ever falls back to a CPU path.
+ *
+ * Coordinates: everything is in BITSTREAM coordinates (row 0 = bottom row of the
+ * picture, as inside the reference: lib/state.c:622-629).  Device planes are stored
+ * unpadded with a positive pitch; motion-compensated reads clamp their coordinates,
+ * which is bit-identical to the reference's replicated UMV border
+ * (lib/state.c:770-835).
+ */
+#ifndef THEORA_HIP_H
+#define THEORA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes, include/theora/codec.h:77-93 */
+#define THIP_OK 0
+#define THIP_EFAULT (-1)
+#define THIP_EINVAL (-10)
+#define THIP_EIMPL (-23)
+#define THIP_DUPFRAME 1 /* TH_DUPFRAME, codec.h:91 */
+
+/* lib/state.h:170-176 */
+#define THIP_FRAME_GOLD 0
+#define THIP_FRAME_PREV 1
+#define THIP_FRAME_SELF 2
+/* lib/state.h:155-158 */
+#define THIP_INTRA_FRAME 0
+#define THIP_INTER_FRAME 1
+
+#define THIP_MAX_BATCH 8 /* streams per kernel launch; larger batches are chunked */
+
+/* ------------------------------------------------------------------------------------
+ * Stream state: the device side of one oc_theora_state (lib/state.h:380-468):
+ * three resident reference frames, the SELF/PREV/GOLD ring, the per-frame coded map.
+ * ---------------------------------------------------------------------------------- */
+typedef struct thip_state thip_state;
+
+typedef struct thip_plane_geom {
+  int32_t nhfrags, nvfrags; /* oc_fragment_plane, state.h:327-344 */
+  int32_t froffset, nfrags;
+  int32_t width, height; /* pixels */
+  int32_t stride;        /* device pitch in bytes (positive) */
+  int32_t plane_off;     /* byte offset of the plane inside one device frame */
+} thip_plane_geom;
+
+/* Replaces oc_state_init + oc_state_ref_bufs_init (state.c:698, :545) for the device
+   side.  frame_width/height are the coded size (multiples of 16), pixel_fmt is
+   th_pixel_fmt (codec.h: 0=4:2:0, 2=4:2:2, 3=4:4:4). */
+int thip_state_create(thip_state **out, int frame_width, int frame_height, int pixel_fmt);
+void thip_state_free(thip_state *st);
+int thip_state_get_geom(const thip_state *st, thip_plane_geom geom[3], int64_t *nfrags,
+                        int64_t *frame_bytes);
+/* Buffer index (0..2) currently holding THIP_FRAME_*; -1 before the first frame. */
+int thip_state_ref_idx(const thip_state *st, int which);
+/* Force the ring (tests / seeking; mirrors the bookkeeping of decode.c:2947-2962). */
+int thip_state_set_ref_idx(thip_state *st, int gold, int prev, int self);
+/* device pointer of buffer bufi (0..2); planes at +geom[pli].plane_off */
+uint8_t *thip_state_frame_ptr(const thip_state *st, int bufi);
+/* Synchronous copies of one plane of buffer bufi, tightly packed, bitstream row order. */
+int thip_state_read_plane(thip_state *st, int bufi, int pli, uint8_t *host_out);
+int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *host_in);
+/* th_decode_ycbcr_out (decode.c:2988): copies the most recently decoded frame to host
+   planes in DISPLAY order (top row first), dst_stride[pli] bytes per row. */
+int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t dst_stride[3]);
+
+/* ------------------------------------------------------------------------------------
+ * Fragment command stream: what oc_dec_frags_recon_mcu_plane (decode.c:1511-1607)
+ * hands to oc_state_frag_recon / oc_frag_copy_list for one frame, laid out for HBM.
+ *
+ *  cmds     one 8-byte record per CODED fragment, in coded order (state.h:423-426):
+ *             word0 = fragment index (raster, Y then Cb then Cr, state.h:244-269)
+ *             word1 = refi        bits 0-1   THIP_FRAME_* (SELF == intra, state.h:215-217)
+ *                     dc_only     bit  2     last_zzi<2: coefficient [0] already holds
+ *                                            p=(dc*dc_quant+15)>>5   (state.c:967-975)
+ *                     last_zzi    bits 8-14  0..64 (idct.c:301-330 picks its variant on it)
+ *                     mv x, mv y  bits 16-23, 24-31 signed (oc_mv, state.h:232-240)
+ *  coeffs   dequantised int16 coefficients, DC included ((int16)(dc*dc_quant),
+ *           state.c:978).  "Tile" layout chosen by this backend (cf. the per-backend
+ *           dct_fzig_zag table, state.h:374-376): slot i (= position in cmds) lives in
+ *           tile i/64, lane i%64; row r (8 coefficients, natural order) of that block is
+ *           the 16 bytes at  tile*8192 + r*1024 + lane*16.  ceil(ncoded/64) whole tiles.
+ *  uncoded  fragment indices copied PREV->SELF (oc_frag_copy_list, fragment.c:37)
+ * Every fragment of the frame must appear in exactly one of the two lists.
+ * ---------------------------------------------------------------------------------- */
+#define THIP_CMD_REFI_MASK 0x3u
+#define THIP_CMD_DC_ONLY 0x4u
+#define THIP_CMD_LAST_ZZI_SHIFT 8
+#define THIP_CMD_MVX_SHIFT 16
+#define THIP_CMD_MVY_SHIFT 24
+#define THIP_TILE_BLOCKS 64
+#define THIP_TILE_BYTES 8192
+
+typedef struct thip_frame_desc {
+  const uint32_t *cmds;    /* device */
+  const int16_t *coeffs;   /* device */
+  const uint32_t *uncoded; /* device */
+  int32_t ncoded, nuncoded;
+  int32_t frame_type; /* THIP_INTRA_FRAME / THIP_INTER_FRAME */
+  int32_t flimit;     /* loop_filter_limits[qis[0]], 0 = filter off (decode.c:1369-1371) */
+} thip_frame_desc;
+
+/* One frame of each of nstreams independent streams, all inputs resident in HBM:
+   reconstruct coded fragments (oc_state_frag_recon, state.c:959), copy uncoded ones
+   (fragment.c:37), run the in-loop filter over the whole frame (state.c:1055) and rotate
+   each stream's reference ring (decode.c:2790-2794, 2947-2962).  Asynchronous on
+   `stream` (a hipStream_t, or NULL for the library's own stream).
+   results[i] (optional, host) receives 0 or THIP_DUPFRAME per stream. */
+int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, int nstreams,
+                       void *stream, int32_t *results);
+/* Wait for everything submitted on the library's own stream. */
+int thip_synchronize(void);
+
+/* ------------------------------------------------------------------------------------
+ * Host-enqueue form of the same path: the vtable slots as the reference calls them, one
+ * fragment at a time from decode.c:1584 / :1601 / :2882.  They only stage into pinned
+ * memory; thip_frame_flush uploads and launches.
+ * ---------------------------------------------------------------------------------- */
+/* Where th_decode_packetin picks the SELF buffer (decode.c:2790-2794). */
+int thip_frame_begin(thip_state *st, int frame_type);
+/* oc_state_frag_recon slot (state.h:365-366).  refi and mv are what the reference reads
+   from state->frags[fragi].refi and state->frag_mvs[fragi].  Like the reference's iDCT
+   (idct.c:245,276,295) it leaves dct_coeffs[0..63] zeroed. */
+int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_coeffs[128],
+                          int last_zzi, uint16_t dc_quant, int refi, int16_t mv);
+/* oc_frag_copy_list slot (state.h:355-357); frame pointers and offsets are implied. */
+int thip_frag_copy_list(thip_state *st, const ptrdiff_t *fragis, ptrdiff_t nfragis);
+/* oc_loop_filter_init slot (state.h:367): the bounding-value table of state.c:1036. */
+void thip_loop_filter_init(signed char bv[256], int flimit);
+/* oc_state_loop_filter_frag_rows slot (state.h:368): records the request; the filter
+   itself runs over the recorded rows at flush.  Only refi==THIP_FRAME_SELF is valid. */
+int thip_state_loop_filter_frag_rows(thip_state *st, int flimit, int refi, int pli, int fragy0,
+                                     int fragy_end);
+/* Upload, launch, rotate the ring.  Returns 0 or THIP_DUPFRAME. */
+int thip_frame_flush(thip_state *st);
+
+/* ------------------------------------------------------------------------------------
+ * Batched forms of the individual slots (device pointers).  These exist so each vtable
+ * entry can be parity-tested on its own; the frame path above fuses them.
+ * ---------------------------------------------------------------------------------- */
+/* oc_idct8x8 (state.h:364, idct.c:301): n blocks of 64 natural-order coefficients. */
+int thip_idct8x8_batch(int16_t *y, const int16_t *x, const int32_t *last_zzi, int64_t n);
+/* oc_frag_recon_intra / _inter / _inter2 (state.h:358-363; fragment.c:49-80), selected by
+   nsrc = 0 / 1 / 2.  dst_offs/src*_offs are byte offsets of each block's first row. */
+int thip_frag_recon_batch(uint8_t *dst_frame, const uint8_t *src_frame, int ystride, int nsrc,
+                          const int32_t *dst_offs, const int32_t *src1_offs,
+                          const int32_t *src2_offs, const int16_t *residue, int64_t n);
+/* oc_frag_copy_list (fragment.c:37) with explicit frames and offsets. */
+int thip_frag_copy_list_batch(uint8_t *dst_frame, const uint8_t *src_frame, int ystride,
+                              const int32_t *fragis, int64_t nfragis, const int32_t *frag_buf_offs);
+/* oc_state_loop_filter_frag_rows (state.c:1055) on one plane: coded = 1 byte per fragment
+   of that plane (raster), rows [fragy0,fragy_end). */
+int thip_loop_filter_plane(uint8_t *plane, int ystride, int nhfrags, int nvfrags,
+                           const uint8_t *coded, int flimit, int fragy0, int fragy_end);
+
+/* ------------------------------------------------------------------------------------
+ * Encoder block kernels (oc_enc_opt_vtable, encint.h:292-326), batched: element i works on
+ * the 8x8 block at src_plane+src_offs[i] (and ref_plane+ref_offs[i], +ref2_offs[i]).
+ * ---------------------------------------------------------------------------------- */
+enum {
+  THIP_ENC_SAD = 0,         /* oc_enc_frag_sad,         encfrag.c:42  */
+  THIP_ENC_SAD_THRESH = 1,  /* oc_enc_frag_sad_thresh,  encfrag.c:56  */
+  THIP_ENC_SAD2_THRESH = 2, /* oc_enc_frag_sad2_thresh, encfrag.c:71  */
+  THIP_ENC_INTRA_SAD = 3,   /* oc_enc_frag_intra_sad,   encfrag.c:88  */
+  THIP_ENC_SATD = 4,        /* oc_enc_frag_satd,        encfrag.c:317 */
+  THIP_ENC_SATD2 = 5,       /* oc_enc_frag_satd2,       encfrag.c:324 */
+  THIP_ENC_INTRA_SATD = 6,  /* oc_enc_frag_intra_satd,  encfrag.c:331 */
+  THIP_ENC_SSD = 7          /* oc_enc_frag_ssd,         encfrag.c:338 */
+};
+int thip_enc_frag_metric_batch(int op, uint32_t *out, int32_t *dc_out, const uint8_t *src_plane,
+                               const uint8_t *ref_plane, int ystride, const int32_t *src_offs,
+                               const int32_t *ref_offs, const int32_t *ref2_offs,
+                               uint32_t thresh, int64_t n);
+/* oc_enc_frag_border_ssd (encfrag.c:352): per-block 64-bit pixel masks (state.h:285-292). */
+int thip_enc_frag_border_ssd_batch(uint32_t *out, const uint8_t *src_plane,
+                                   const uint8_t *ref_plane, int ystride,
+                                   const int32_t *src_offs, const int32_t *ref_offs,
+                                   const int64_t *masks, int64_t n);
+/* oc_enc_frag_sub / _sub_128 (encfrag.c:21,32): ref_offs==NULL selects sub_128. */
+int thip_enc_frag_sub_batch(int16_t *diff, const uint8_t *src_plane, const uint8_t *ref_plane,
+                            int ystride, const int32_t *src_offs, const int32_t *ref_offs,
+                            int64_t n);
+/* oc_enc_frag_copy2 (encfrag.c:368) */
+int thip_enc_frag_copy2_batch(uint8_t *dst_plane, const uint8_t *src_plane, int ystride,
+                              const int32_t *dst_offs, const int32_t *src1_offs,
+                              const int32_t *src2_offs, int64_t n);
+/* oc_enc_fdct8x8 (fdct.c:128): natural-order int16 in, ZIG-ZAG-ordered int16 out. */
+int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n);
+
+/* ------------------------------------------------------------------------------------
+ * Measurement support for bench.py: HIP-event timing of the kernels of
+ * thip_decode_frames on the stream they run on.
+ * ---------------------------------------------------------------------------------- */
+#define THIP_KERNEL_RECON 0
+#define THIP_KERNEL_LOOPFILTER 1
+#define THIP_NKERNELS 2
+int thip_profile_enable(int on);
+/* Sums since the last reset: launches and milliseconds per kernel (synchronises). */
+int thip_profile_read(int64_t launches[THIP_NKERNELS], double ms[THIP_NKERNELS]);
+int thip_profile_reset(void);
+
+const char *thip_version_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

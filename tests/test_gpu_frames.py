@@ -1,0 +1,114 @@
+"""Frame-level parity on the GPU: thip_decode_frames (recon + copy + loop filter + ring)
+against the oracle's restatement of the reference's MCU loop, bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from theora_amd import synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+PF_420, PF_422, PF_444 = 0, 2, 3
+
+
+@pytest.mark.parametrize("w,h,fmt", [(176, 144, PF_420), (64, 48, PF_444), (80, 112, PF_422),
+                                     (16, 16, PF_420), (336, 16, PF_420), (16, 272, PF_444)])
+@pytest.mark.parametrize("content", ["mixed", "smooth", "dense"])
+def test_sequence_small(hip, w, h, fmt, content):
+    rep = util.run_sequence(hip, w, h, fmt, nframes=12, content=content, seed=w * 7 + h + fmt, kf_interval=5)
+    assert not rep, rep[:3]
+
+
+def test_sequence_720p(hip):
+    rep = util.run_sequence(hip, 1280, 720, PF_420, nframes=6, content="mixed", seed=3, kf_interval=64)
+    assert not rep, rep[:3]
+
+
+def test_sequence_1080p_smooth(hip):
+    rep = util.run_sequence(hip, 1920, 1088, PF_420, nframes=4, content="smooth", seed=4, kf_interval=64)
+    assert not rep, rep[:3]
+
+
+def test_enqueue_path_matches(hip):
+    """The one-fragment-at-a-time vtable slots (thip_state_frag_recon, thip_frag_copy_list,
+    thip_state_loop_filter_frag_rows) driven in the reference's MCU order."""
+    rep = util.run_sequence(hip, 176, 144, PF_420, nframes=7, content="mixed", seed=11, kf_interval=4,
+                            enqueue=True)
+    assert not rep, rep[:3]
+    rep = util.run_sequence(hip, 64, 80, PF_444, nframes=5, content="mixed", seed=12, kf_interval=4,
+                            enqueue=True)
+    assert not rep, rep[:3]
+
+
+def test_start_on_inter_frame_uses_grey_dummy(hip):
+    """decode.c:2757-2762 / :2053-2080: no keyframe yet -> references are 0x80."""
+    w, h = 96, 64
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(5)
+    ost = oracle.State(w, h, PF_420)
+    gst = hip.State(w, h, PF_420)
+    for f in range(3):
+        fr = synth.gen_frame(geom, rng, hip.INTER_FRAME, "mixed")
+        util.oracle_apply(ost, fr)
+        desc, ka = synth.upload_frame(synth.pack_frame(fr))
+        hip.decode_frames([gst], [desc])
+        assert not util.planes_equal(ost, gst)
+
+
+def test_dup_frame_leaves_state_alone(hip):
+    w, h = 64, 64
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(6)
+    ost = oracle.State(w, h, PF_420)
+    gst = hip.State(w, h, PF_420)
+    fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME, "mixed")
+    util.oracle_apply(ost, fr)
+    desc, ka = synth.upload_frame(synth.pack_frame(fr))
+    hip.decode_frames([gst], [desc])
+    before = [gst.ref_idx(k) for k in range(3)]
+    empty = dict(fr)
+    empty.update(frame_type=hip.INTER_FRAME, coded_fragis=np.zeros(0, np.int64), ncoded=[0, 0, 0],
+                 uncoded_fragis=geom.coded_order[::-1].copy(), coeffs=np.zeros((0, 64), np.int16),
+                 last_zzi=np.zeros(0, np.uint8), dc_quant=np.zeros(0, np.uint16))
+    assert util.oracle_apply(ost, empty) == 1
+    desc2, ka2 = synth.upload_frame(synth.pack_frame(empty))
+    assert hip.decode_frames([gst], [desc2]) == [hip.DUPFRAME]
+    assert before == [gst.ref_idx(k) for k in range(3)]
+    assert not util.planes_equal(ost, gst)
+
+
+def test_batched_streams(hip):
+    """More streams than THIP_MAX_BATCH, different sizes, lock-step frames."""
+    sizes = [(64, 48), (176, 144), (32, 32), (128, 96), (64, 48), (48, 80), (96, 96), (160, 64), (64, 64),
+             (32, 112)]
+    geoms = [synth.Geometry(w, h, PF_420) for w, h in sizes]
+    rngs = [np.random.default_rng(100 + i) for i in range(len(sizes))]
+    osts = [oracle.State(w, h, PF_420) for w, h in sizes]
+    gsts = [hip.State(w, h, PF_420) for w, h in sizes]
+    for f in range(5):
+        descs, keep = [], []
+        for i in range(len(sizes)):
+            fr = synth.gen_frame(geoms[i], rngs[i], hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "mixed")
+            util.oracle_apply(osts[i], fr)
+            d, ka = synth.upload_frame(synth.pack_frame(fr))
+            descs.append(d)
+            keep.append(ka)
+        hip.decode_frames(gsts, descs)
+        for i in range(len(sizes)):
+            assert not util.planes_equal(osts[i], gsts[i]), (f, i)
+
+
+def test_ycbcr_out_is_top_down(hip):
+    w, h = 64, 48
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(9)
+    ost = oracle.State(w, h, PF_420)
+    gst = hip.State(w, h, PF_420)
+    fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME, "mixed")
+    util.oracle_apply(ost, fr)
+    desc, ka = synth.upload_frame(synth.pack_frame(fr))
+    hip.decode_frames([gst], [desc])
+    outs = gst.ycbcr_out()
+    for pli in range(3):
+        assert np.array_equal(outs[pli], ost.get_plane(oracle.FRAME_PREV, pli)[::-1])

@@ -1,0 +1,222 @@
+"""Each accel-vtable slot on its own (batched C-ABI form) against the oracle, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def random_blocks(rng, n):
+    """Coefficient blocks over the whole int16 range plus realistic sparse ones."""
+    x = np.zeros((n, 64), np.int16)
+    k = n // 3
+    x[:k] = rng.integers(-32768, 32768, (k, 64))
+    x[k:2 * k] = rng.integers(-600, 600, (k, 64)) * (rng.random((k, 64)) < 0.3)
+    x[2 * k:] = rng.integers(-2000, 2000, (n - 2 * k, 64)) * (rng.random((n - 2 * k, 64)) < 0.08)
+    x[-1] = 32767
+    x[-2] = -32768
+    return x
+
+
+def test_idct8x8_all_last_zzi(hip):
+    rng = np.random.default_rng(0)
+    n = 65 * 300 + 17
+    x = random_blocks(rng, n)
+    lz = (np.arange(n) % 65).astype(np.int32)
+    want = oracle.idct8x8_batch(x, lz)
+    got = hip.idct8x8_batch(dev(x), dev(lz)).cpu().numpy().reshape(-1, 64)
+    assert np.array_equal(want, got)
+    # no last_zzi array == the full transform
+    want = oracle.idct8x8_batch(x, None)
+    got = hip.idct8x8_batch(dev(x), None).cpu().numpy().reshape(-1, 64)
+    assert np.array_equal(want, got)
+
+
+def test_idct_empty_batch(hip):
+    from theora_amd import _lib
+    assert _lib.load().thip_idct8x8_batch(1, 1, None, 0) == 0
+    assert _lib.load().thip_idct8x8_batch(None, None, None, 4) == _lib.EFAULT
+    assert _lib.load().thip_idct8x8_batch(1, 1, None, -1) == _lib.EINVAL
+
+
+def _recon_case(hip, nsrc, seed):
+    from theora_amd import _lib
+    rng = np.random.default_rng(seed)
+    stride, H = 200, 160
+    n = 1500
+    src = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    dst0 = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    res = rng.integers(-400, 400, (n, 64)).astype(np.int16)
+    res[:50] = rng.integers(-32768, 32768, (50, 64))
+    # non-overlapping destination blocks on an 8x8 grid; sources anywhere (unaligned)
+    cells = rng.permutation((H // 8) * (stride // 8))[:n]
+    dst_offs = ((cells // (stride // 8)) * 8 * stride + (cells % (stride // 8)) * 8).astype(np.int32)
+    s1 = (rng.integers(0, H - 9, n) * stride + rng.integers(0, stride - 9, n)).astype(np.int32)
+    dxy = rng.integers(0, 2, (n, 2))
+    s2 = (s1 + dxy[:, 0] * stride + dxy[:, 1]).astype(np.int32)
+    want = dst0.copy()
+    L = oracle.lib()
+    for i in range(n):
+        d = want.ctypes.data + int(dst_offs[i])
+        r = res[i].ctypes.data
+        if nsrc == 0:
+            L.orc_frag_recon_intra(d, stride, r)
+        elif nsrc == 1:
+            L.orc_frag_recon_inter(d, src.ctypes.data + int(s1[i]), stride, r)
+        else:
+            L.orc_frag_recon_inter2(d, src.ctypes.data + int(s1[i]), src.ctypes.data + int(s2[i]), stride, r)
+    d_dst, d_src = dev(dst0), dev(src)
+    rc = _lib.load().thip_frag_recon_batch(d_dst.data_ptr(), d_src.data_ptr(), stride, nsrc,
+                                           dev(dst_offs).data_ptr(), dev(s1).data_ptr(), dev(s2).data_ptr(),
+                                           dev(res).data_ptr(), n)
+    assert rc == 0
+    assert np.array_equal(want, d_dst.cpu().numpy())
+
+
+@pytest.mark.parametrize("nsrc", [0, 1, 2])
+def test_frag_recon_slots(hip, nsrc):
+    _recon_case(hip, nsrc, 20 + nsrc)
+
+
+def test_frag_copy_list(hip):
+    from theora_amd import _lib
+    rng = np.random.default_rng(3)
+    st = oracle.State(176, 144)
+    stride, H = 176, 144
+    src = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    dst0 = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    nh, nv = 22, 18
+    offs = (np.arange(nv)[:, None] * 8 * stride + np.arange(nh)[None, :] * 8).reshape(-1).astype(np.int32)
+    fragis = rng.permutation(nh * nv)[:200].astype(np.int32)
+    want = dst0.copy()
+    for f in fragis:
+        y, x = divmod(int(offs[f]), stride)
+        want[y:y + 8, x:x + 8] = src[y:y + 8, x:x + 8]
+    d_dst = dev(dst0)
+    rc = _lib.load().thip_frag_copy_list_batch(d_dst.data_ptr(), dev(src).data_ptr(), stride,
+                                               dev(fragis).data_ptr(), fragis.size, dev(offs).data_ptr())
+    assert rc == 0
+    assert np.array_equal(want, d_dst.cpu().numpy())
+
+
+@pytest.mark.parametrize("flimit", [1, 2, 4, 15, 63, 127])
+@pytest.mark.parametrize("density", [0.0, 0.1, 0.5, 0.9, 1.0])
+def test_loop_filter_plane(hip, flimit, density):
+    """The cell decomposition against the reference's sequential raster order
+    (state.c:1055-1105) on random pixels and random coded masks, whole plane and row ranges."""
+    from theora_amd import _lib
+    rng = np.random.default_rng(flimit * 10 + int(density * 10))
+    w, h = 176, 144
+    st = oracle.State(w, h)
+    st.set_ref_idx(0, 0, 0)
+    nh, nv = 22, 18
+    for (y0, y1) in [(0, nv), (0, 7), (7, nv), (3, 4)]:
+        pix = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        coded = (rng.random(nh * nv) < density).astype(np.uint8)
+        st.coded[:] = 0
+        st.coded[:nh * nv] = coded
+        st.set_plane(oracle.FRAME_SELF, 0, pix)
+        st.loop_filter_rows(flimit, oracle.FRAME_SELF, 0, y0, y1)
+        want = st.get_plane(oracle.FRAME_SELF, 0)
+        d = dev(pix)
+        rc = _lib.load().thip_loop_filter_plane(d.data_ptr(), w, nh, nv, dev(coded).data_ptr(), flimit, y0, y1)
+        assert rc == 0
+        got = d.cpu().numpy()
+        assert np.array_equal(want, got), (flimit, density, y0, y1, int((want != got).sum()))
+
+
+def test_loop_filter_init_table(hip):
+    from theora_amd import _lib
+    for fl in list(range(0, 20)) + [31, 63, 64, 65, 100, 126, 127]:
+        bv = np.zeros(256, np.int8)
+        _lib.load().thip_loop_filter_init(bv.ctypes.data, fl)
+        assert np.array_equal(bv, oracle.loop_filter_bv(fl)), fl
+
+
+def _enc_planes(rng):
+    stride, H = 256, 128
+    src = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    ref = np.clip(src.astype(np.int32) + rng.integers(-20, 21, (H, stride)), 0, 255).astype(np.uint8)
+    ref[:32] = rng.integers(0, 256, (32, stride))
+    n = 3000
+    so = (rng.integers(0, H - 8, n) * stride + rng.integers(0, stride - 8, n)).astype(np.int32)
+    ro = (rng.integers(0, H - 9, n) * stride + rng.integers(0, stride - 9, n)).astype(np.int32)
+    dxy = rng.integers(0, 2, (n, 2))
+    r2 = (ro + dxy[:, 0] * stride + dxy[:, 1]).astype(np.int32)
+    return stride, src, ref, so, ro, r2
+
+
+@pytest.mark.parametrize("op", ["sad", "sad_thresh", "sad2_thresh", "intra_sad", "satd", "satd2", "intra_satd",
+                                "ssd"])
+def test_enc_metrics(hip, op):
+    rng = np.random.default_rng(sum(map(ord, op)))
+    stride, src, ref, so, ro, r2 = _enc_planes(rng)
+    for thresh in ([0, 300, 2000, 1 << 30] if "thresh" in op else [0]):
+        want, want_dc = oracle.enc_metric_batch(op, src, ref, stride, so, ro, r2, thresh)
+        got, got_dc = hip.enc_metric_batch(op, dev(src), dev(ref), stride, dev(so), dev(ro), dev(r2), thresh)
+        assert np.array_equal(want, got.cpu().numpy().view(np.uint32)), (op, thresh)
+        if "satd" in op:
+            assert np.array_equal(want_dc, got_dc.cpu().numpy()), op
+
+
+def test_enc_fdct(hip):
+    rng = np.random.default_rng(8)
+    n = 20000
+    x = rng.integers(-255, 256, (n, 64)).astype(np.int16)
+    x[:100] = 0
+    x[100:200] = 255
+    x[200:300] = -255
+    x[300:1000] = rng.integers(-8160, 8161, (700, 64))    # beyond the residual range, still defined
+    want = oracle.fdct8x8_batch(x)
+    got = hip.fdct8x8_batch(dev(x)).cpu().numpy().reshape(-1, 64)
+    assert np.array_equal(want, got)
+
+
+def test_enc_sub_copy2_border_ssd(hip):
+    from theora_amd import _lib
+    import torch
+    rng = np.random.default_rng(9)
+    stride, src, ref, so, ro, r2 = _enc_planes(rng)
+    n = so.size
+    L, O = _lib.load(), oracle.lib()
+    d_src, d_ref = dev(src), dev(ref)
+    # sub / sub_128
+    for use_ref in (True, False):
+        want = np.empty((n, 64), np.int16)
+        for i in range(n):
+            if use_ref:
+                O.orc_enc_frag_sub(want[i].ctypes.data, src.ctypes.data + int(so[i]), ref.ctypes.data + int(ro[i]), stride)
+            else:
+                O.orc_enc_frag_sub_128(want[i].ctypes.data, src.ctypes.data + int(so[i]), stride)
+        got = torch.empty((n, 64), dtype=torch.int16, device="cuda")
+        rc = L.thip_enc_frag_sub_batch(got.data_ptr(), d_src.data_ptr(), d_ref.data_ptr(), stride,
+                                       dev(so).data_ptr(), dev(ro).data_ptr() if use_ref else None, n)
+        assert rc == 0 and np.array_equal(want, got.cpu().numpy())
+    # border ssd
+    masks = rng.integers(-2 ** 63, 2 ** 63, n, dtype=np.int64)
+    masks[:4] = [0, -1, 1, 1 << 62]
+    want = np.array([O.orc_enc_frag_border_ssd(src.ctypes.data + int(so[i]), ref.ctypes.data + int(ro[i]), stride,
+                                               int(masks[i])) for i in range(n)], np.uint32)
+    got = torch.empty(n, dtype=torch.int32, device="cuda")
+    rc = L.thip_enc_frag_border_ssd_batch(got.data_ptr(), d_src.data_ptr(), d_ref.data_ptr(), stride,
+                                          dev(so).data_ptr(), dev(ro).data_ptr(), dev(masks).data_ptr(), n)
+    assert rc == 0 and np.array_equal(want, got.cpu().numpy().view(np.uint32))
+    # copy2 into disjoint 8x8 cells
+    H = src.shape[0]
+    cells = rng.permutation((H // 8) * (stride // 8))[:400]
+    do = ((cells // (stride // 8)) * 8 * stride + (cells % (stride // 8)) * 8).astype(np.int32)
+    want = np.zeros_like(src)
+    for i in range(400):
+        O.orc_enc_frag_copy2(want.ctypes.data + int(do[i]), ref.ctypes.data + int(ro[i]), ref.ctypes.data + int(r2[i]), stride)
+    d_dst = dev(np.zeros_like(src))
+    rc = L.thip_enc_frag_copy2_batch(d_dst.data_ptr(), d_ref.data_ptr(), stride, dev(do).data_ptr(),
+                                     dev(ro[:400]).data_ptr(), dev(r2[:400]).data_ptr(), 400)
+    assert rc == 0 and np.array_equal(want, d_dst.cpu().numpy())

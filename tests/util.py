@@ -1,0 +1,94 @@
+"""Shared helpers for the parity tests: drive the oracle and the HIP path with the same
+synthetic command streams."""
+import numpy as np
+
+import oracle
+from theora_amd import synth
+
+
+def oracle_apply(ost, frame):
+    """Feed one synth frame to the oracle state (fills refi/mvs like the front end would)."""
+    ost.refi[:] = frame["refi"]
+    ost.mvs[:] = ((frame["mvx"] & 0xFF) | (frame["mvy"] << 8)).astype(np.int16)
+    return ost.decode_frame(frame["frame_type"], frame["coded_fragis"], frame["ncoded"], frame["coeffs"],
+                            frame["last_zzi"], frame["dc_quant"], frame["uncoded_fragis"], frame["flimit"])
+
+
+def planes_equal(ost, gst, slot=oracle.FRAME_PREV):
+    """Compare the frame both sides just finished (it is PREV after the ring rotation)."""
+    bad = []
+    for pli in range(3):
+        a = ost.get_plane(slot, pli)
+        b = gst.read_plane(gst.ref_idx(slot), pli)
+        if not np.array_equal(a, b):
+            ys, xs = np.nonzero(a != b)
+            bad.append((pli, int((a != b).sum()), int(ys[0]), int(xs[0])))
+    return bad
+
+
+def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, enqueue=False):
+    """Decode nframes synthetic frames on both sides; returns list of mismatch reports."""
+    geom = synth.Geometry(w, h, fmt)
+    rng = np.random.default_rng(seed)
+    ost = oracle.State(w, h, fmt)
+    gst = theora_amd.State(w, h, fmt)
+    reports = []
+    keep = []
+    for f in range(nframes):
+        ftype = theora_amd.INTRA_FRAME if f % kf_interval == 0 else theora_amd.INTER_FRAME
+        fr = synth.gen_frame(geom, rng, ftype, content)
+        rc_o = oracle_apply(ost, fr)
+        if enqueue:
+            rc_g = enqueue_frame(theora_amd, gst, geom, fr)
+        else:
+            desc, ka = synth.upload_frame(synth.pack_frame(fr))
+            keep.append(ka)
+            rc_g = theora_amd.decode_frames([gst], [desc])[0]
+        assert rc_o == rc_g, (f, rc_o, rc_g)
+        assert ost.ref_frame_idx == [gst.ref_idx(k) for k in range(3)], f
+        bad = planes_equal(ost, gst)
+        if bad:
+            reports.append((f, bad))
+    theora_amd.synchronize()
+    return reports
+
+
+def enqueue_frame(theora_amd, gst, geom, fr):
+    """Drive the host-enqueue slots exactly as the reference's MCU loop would
+    (decode.c:2858-2945): per MCU and plane, frag_recon for the coded fragments, one
+    frag_copy_list, then the loop filter with its one-row delays."""
+    gst.frame_begin(fr["frame_type"])
+    coded = np.zeros(geom.nfrags, bool)
+    coded[fr["coded_fragis"]] = True
+    base = np.cumsum([0] + fr["ncoded"])
+    done = [0, 0, 0]
+    buf = np.zeros(128, np.int16)
+    mcu = 4 << geom.vdec
+    stripe, notstart, notdone = 0, 0, 1
+    while notdone:
+        notdone = int(stripe + mcu < geom.nv[0])
+        for pli in range(3):
+            sh = 1 if (pli and geom.vdec) else 0
+            y0 = stripe >> sh
+            y1 = min(geom.nv[pli], y0 + (mcu >> sh))
+            lo = geom.froffset[pli] + y0 * geom.nh[pli]
+            hi = geom.froffset[pli] + y1 * geom.nh[pli]
+            nc = int(coded[lo:hi].sum())
+            for k in range(nc):
+                slot = base[pli] + done[pli] + k
+                fi = int(fr["coded_fragis"][slot])
+                buf[:64] = fr["coeffs"][slot]
+                mv = int((int(fr["mvx"][fi]) & 0xFF) | (int(fr["mvy"][fi]) << 8))
+                mv = (mv + 0x8000) % 0x10000 - 0x8000
+                gst.frag_recon(fi, pli, buf, int(fr["last_zzi"][slot]), int(fr["dc_quant"][slot]),
+                               int(fr["refi"][fi]), mv)
+                assert not buf[:64].any()
+            done[pli] += nc
+            unc = lo + np.nonzero(~coded[lo:hi])[0]
+            if unc.size:
+                gst.frag_copy_list(unc)
+            if fr["flimit"]:
+                gst.loop_filter_frag_rows(fr["flimit"], theora_amd.FRAME_SELF, pli, y0 - notstart, y1 - notdone)
+        notstart = 1
+        stripe += mcu
+    return gst.frame_flush()

@@ -1,0 +1,234 @@
+"""theora_amd -- MI355X (gfx950) backend for libtheora's per-fragment reconstruction path.
+
+The product is the C-ABI library ``libtheora_hip.so`` (include/theora_hip.h, sources in
+theora_amd/csrc/).  This package is the thin Python harness above it used by tests and
+bench.py: ctypes bindings, host-side packing of fragment command streams into the
+backend's HBM layout, and device-buffer plumbing through torch.  It never falls back to a
+CPU implementation.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (DUPFRAME, FRAME_GOLD, FRAME_PREV, FRAME_SELF, INTER_FRAME, INTRA_FRAME,  # noqa: F401
+                   MAX_BATCH, TILE_BLOCKS, TILE_BYTES, FrameDesc, PlaneGeom, TheoraHipError)
+
+PF_420, PF_422, PF_444 = 0, 2, 3
+
+
+def version():
+    return _lib.load().thip_version_string().decode()
+
+
+def _ptr(t):
+    """Device (torch tensor) or host (numpy array) address, or NULL."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    return t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------
+# host-side packing of a frame's fragment command stream (layout of include/theora_hip.h)
+# ---------------------------------------------------------------------------------------
+def cmd_words(fragis, refi, last_zzi, mvx, mvy):
+    """[n,2] uint32 command records; dc_only is derived from last_zzi<2 (state.c:967)."""
+    fragis = np.asarray(fragis, np.uint32)
+    lz = np.asarray(last_zzi, np.uint32)
+    w1 = (np.asarray(refi, np.uint32) & 3) | (lz << 8)
+    w1 |= np.where(lz < 2, np.uint32(_lib.CMD_DC_ONLY), np.uint32(0))
+    w1 |= (np.asarray(mvx, np.int32).astype(np.uint32) & 0xFF) << 16
+    w1 |= (np.asarray(mvy, np.int32).astype(np.uint32) & 0xFF) << 24
+    return np.ascontiguousarray(np.stack([fragis, w1.astype(np.uint32)], axis=1))
+
+
+def dequant_dc(coeffs, last_zzi, dc_quant):
+    """What oc_state_frag_recon does to coefficient 0 before the transform
+    (state.c:967-979): p=(dc*dc_quant+15)>>5 for DC-only blocks, (int16)(dc*dc_quant)
+    otherwise.  coeffs [n,64] int16 with the raw DC in [:,0]; returns a new array."""
+    co = np.array(coeffs, np.int16, copy=True).reshape(-1, 64)
+    dc = co[:, 0].astype(np.int32) * np.asarray(dc_quant, np.int32)
+    lz = np.asarray(last_zzi)
+    co[:, 0] = np.where(lz < 2, (dc + 15) >> 5, dc).astype(np.int16)  # wraps like the C cast
+    co[lz < 2, 1:] = 0
+    return co
+
+
+def pack_tiles(coeffs):
+    """[n,64] natural-order int16 blocks -> the backend's tile layout (int16, flat):
+    block i, row r at tile (i//64), offset r*512 + (i%64)*8 int16s."""
+    co = np.asarray(coeffs, np.int16).reshape(-1, 8, 8)
+    n = co.shape[0]
+    ntiles = (n + TILE_BLOCKS - 1) // TILE_BLOCKS
+    pad = np.zeros((ntiles * TILE_BLOCKS, 8, 8), np.int16)
+    pad[:n] = co
+    # [tile, lane, row, col] -> [tile, row, lane, col]
+    return np.ascontiguousarray(pad.reshape(ntiles, TILE_BLOCKS, 8, 8).transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def unpack_tiles(tiles, n):
+    t = np.asarray(tiles, np.int16).reshape(-1, 8, TILE_BLOCKS, 8).transpose(0, 2, 1, 3)
+    return np.ascontiguousarray(t.reshape(-1, 64)[:n])
+
+
+class State:
+    """Device side of one stream (thip_state): three resident frames + the reference ring."""
+
+    def __init__(self, frame_width, frame_height, pixel_fmt=PF_420):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._L.thip_state_create(C.byref(h), frame_width, frame_height, pixel_fmt),
+                   "thip_state_create")
+        self._h = h
+        geom = (PlaneGeom * 3)()
+        nfrags, fbytes = C.c_int64(), C.c_int64()
+        _lib.check(self._L.thip_state_get_geom(h, geom, C.byref(nfrags), C.byref(fbytes)), "get_geom")
+        self.planes = [dict((f, getattr(g, f)) for f, _ in PlaneGeom._fields_) for g in geom]
+        self.nfrags = nfrags.value
+        self.frame_bytes = fbytes.value
+        self.frame_width, self.frame_height, self.pixel_fmt = frame_width, frame_height, pixel_fmt
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.thip_state_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ref_idx(self, which):
+        return self._L.thip_state_ref_idx(self._h, which)
+
+    def set_ref_idx(self, gold, prev, self_):
+        _lib.check(self._L.thip_state_set_ref_idx(self._h, gold, prev, self_), "set_ref_idx")
+
+    def read_plane(self, bufi, pli):
+        g = self.planes[pli]
+        out = np.empty((g["height"], g["width"]), np.uint8)
+        _lib.check(self._L.thip_state_read_plane(self._h, bufi, pli, out.ctypes.data), "read_plane")
+        return out
+
+    def write_plane(self, bufi, pli, arr):
+        g = self.planes[pli]
+        a = np.ascontiguousarray(arr, np.uint8)
+        assert a.shape == (g["height"], g["width"])
+        _lib.check(self._L.thip_state_write_plane(self._h, bufi, pli, a.ctypes.data), "write_plane")
+
+    def ycbcr_out(self):
+        """th_decode_ycbcr_out: the last decoded frame, display (top-down) row order."""
+        outs = [np.empty((g["height"], g["width"]), np.uint8) for g in self.planes]
+        ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in outs])
+        strides = (C.c_int32 * 3)(*[g["width"] for g in self.planes])
+        _lib.check(self._L.thip_state_ycbcr_out(self._h, ptrs, strides), "ycbcr_out")
+        return outs
+
+    # ---- host-enqueue form: the vtable slots, one fragment at a time --------------------
+    def frame_begin(self, frame_type):
+        _lib.check(self._L.thip_frame_begin(self._h, frame_type), "frame_begin")
+
+    def frag_recon(self, fragi, pli, dct_coeffs, last_zzi, dc_quant, refi, mv):
+        """oc_state_frag_recon slot; dct_coeffs is an int16[128] numpy array (zeroed on return)."""
+        assert dct_coeffs.dtype == np.int16 and dct_coeffs.size >= 128
+        _lib.check(self._L.thip_state_frag_recon(self._h, fragi, pli, dct_coeffs.ctypes.data, last_zzi,
+                                                 dc_quant, refi, mv), "state_frag_recon")
+
+    def frag_copy_list(self, fragis):
+        a = np.ascontiguousarray(fragis, np.int64)
+        _lib.check(self._L.thip_frag_copy_list(self._h, a.ctypes.data, a.size), "frag_copy_list")
+
+    def loop_filter_frag_rows(self, flimit, refi, pli, fragy0, fragy_end):
+        _lib.check(self._L.thip_state_loop_filter_frag_rows(self._h, flimit, refi, pli, fragy0, fragy_end),
+                   "loop_filter_frag_rows")
+
+    def frame_flush(self):
+        return _lib.check(self._L.thip_frame_flush(self._h), "frame_flush")
+
+
+def decode_frames(states, descs, stream=None):
+    """thip_decode_frames over parallel lists of State and FrameDesc; returns per-stream results."""
+    L = _lib.load()
+    n = len(states)
+    assert n == len(descs)
+    hs = (C.c_void_p * n)(*[s.handle for s in states])
+    ds = (FrameDesc * n)(*descs)
+    res = (C.c_int32 * n)()
+    _lib.check(L.thip_decode_frames(hs, ds, n, stream, res), "thip_decode_frames")
+    return list(res)
+
+
+class BatchPlan:
+    """A pre-marshalled thip_decode_frames call (bench.py's timed loop reuses these so the
+    Python/ctypes overhead per step is one foreign call)."""
+
+    def __init__(self, states, descs):
+        self._L = _lib.load()
+        self.n = len(states)
+        self.hs = (C.c_void_p * self.n)(*[s.handle for s in states])
+        self.ds = (FrameDesc * self.n)(*descs)
+        self.res = (C.c_int32 * self.n)()
+
+    def submit(self, stream=None):
+        rc = self._L.thip_decode_frames(self.hs, self.ds, self.n, stream, self.res)
+        if rc < 0:
+            raise TheoraHipError("thip_decode_frames failed: %d" % rc)
+
+
+def synchronize():
+    _lib.check(_lib.load().thip_synchronize(), "thip_synchronize")
+
+
+def make_desc(cmds_dev, coeffs_dev, uncoded_dev, ncoded, nuncoded, frame_type, flimit):
+    return FrameDesc(_ptr(cmds_dev), _ptr(coeffs_dev), _ptr(uncoded_dev), ncoded, nuncoded, frame_type, flimit)
+
+
+def profile_enable(on):
+    _lib.check(_lib.load().thip_profile_enable(int(on)), "profile_enable")
+
+
+def profile_reset():
+    _lib.check(_lib.load().thip_profile_reset(), "profile_reset")
+
+
+def profile_read():
+    n = (C.c_int64 * _lib.NKERNELS)()
+    ms = (C.c_double * _lib.NKERNELS)()
+    _lib.check(_lib.load().thip_profile_read(n, ms), "profile_read")
+    return list(n), list(ms)
+
+
+# ---------------------------------------------------------------------------------------
+# batched single slots (device tensors in, device tensors out)
+# ---------------------------------------------------------------------------------------
+def idct8x8_batch(x_dev, last_zzi_dev=None):
+    import torch
+    y = torch.empty_like(x_dev)
+    n = x_dev.numel() // 64
+    _lib.check(_lib.load().thip_idct8x8_batch(_ptr(y), _ptr(x_dev), _ptr(last_zzi_dev), n), "idct8x8_batch")
+    return y
+
+
+def fdct8x8_batch(x_dev):
+    import torch
+    y = torch.empty_like(x_dev)
+    _lib.check(_lib.load().thip_enc_fdct8x8_batch(_ptr(y), _ptr(x_dev), x_dev.numel() // 64), "fdct8x8_batch")
+    return y
+
+
+def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None, ref2_offs=None, thresh=0):
+    import torch
+    n = src_offs.numel()
+    out = torch.empty(n, dtype=torch.int32, device=src_offs.device)
+    dc = torch.zeros(n, dtype=torch.int32, device=src_offs.device)
+    _lib.check(_lib.load().thip_enc_frag_metric_batch(
+        _lib.ENC_OPS[op], _ptr(out), _ptr(dc), _ptr(src_plane), _ptr(ref_plane), ystride, _ptr(src_offs),
+        _ptr(ref_offs), _ptr(ref2_offs), thresh, n), "enc_frag_metric_batch")
+    return out, dc

@@ -1,0 +1,98 @@
+"""ctypes binding of libtheora_hip.so (include/theora_hip.h).
+
+There is no fallback: if the HIP library has not been built, or a call fails, this
+raises.  Nothing here (or anywhere in theora_amd/) touches oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libtheora_hip.so")
+
+OK, EFAULT, EINVAL, EIMPL, DUPFRAME = 0, -1, -10, -23, 1
+FRAME_GOLD, FRAME_PREV, FRAME_SELF = 0, 1, 2
+INTRA_FRAME, INTER_FRAME = 0, 1
+MAX_BATCH = 8
+TILE_BLOCKS, TILE_BYTES = 64, 8192
+CMD_DC_ONLY = 0x4
+KERNEL_RECON, KERNEL_LOOPFILTER, NKERNELS = 0, 1, 2
+
+ENC_OPS = dict(sad=0, sad_thresh=1, sad2_thresh=2, intra_sad=3, satd=4, satd2=5, intra_satd=6, ssd=7)
+
+
+class PlaneGeom(C.Structure):
+    _fields_ = [("nhfrags", C.c_int32), ("nvfrags", C.c_int32), ("froffset", C.c_int32),
+                ("nfrags", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("stride", C.c_int32), ("plane_off", C.c_int32)]
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("cmds", C.c_void_p), ("coeffs", C.c_void_p), ("uncoded", C.c_void_p),
+                ("ncoded", C.c_int32), ("nuncoded", C.c_int32), ("frame_type", C.c_int32),
+                ("flimit", C.c_int32)]
+
+
+class TheoraHipError(RuntimeError):
+    pass
+
+
+# every symbol include/theora_hip.h declares: (name, restype, argtypes)
+_P, _I, _I64, _U32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
+SYMBOLS = [
+    ("thip_state_create", _I, [C.POINTER(_P), _I, _I, _I]),
+    ("thip_state_free", None, [_P]),
+    ("thip_state_get_geom", _I, [_P, C.POINTER(PlaneGeom), C.POINTER(_I64), C.POINTER(_I64)]),
+    ("thip_state_ref_idx", _I, [_P, _I]),
+    ("thip_state_set_ref_idx", _I, [_P, _I, _I, _I]),
+    ("thip_state_frame_ptr", _P, [_P, _I]),
+    ("thip_state_read_plane", _I, [_P, _I, _I, _P]),
+    ("thip_state_write_plane", _I, [_P, _I, _I, _P]),
+    ("thip_state_ycbcr_out", _I, [_P, C.POINTER(_P), C.POINTER(C.c_int32)]),
+    ("thip_decode_frames", _I, [C.POINTER(_P), C.POINTER(FrameDesc), _I, _P, C.POINTER(C.c_int32)]),
+    ("thip_synchronize", _I, []),
+    ("thip_frame_begin", _I, [_P, _I]),
+    ("thip_state_frag_recon", _I, [_P, C.c_ssize_t, _I, _P, _I, C.c_uint16, _I, C.c_int16]),
+    ("thip_frag_copy_list", _I, [_P, _P, C.c_ssize_t]),
+    ("thip_loop_filter_init", None, [_P, _I]),
+    ("thip_state_loop_filter_frag_rows", _I, [_P, _I, _I, _I, _I, _I]),
+    ("thip_frame_flush", _I, [_P]),
+    ("thip_idct8x8_batch", _I, [_P, _P, _P, _I64]),
+    ("thip_frag_recon_batch", _I, [_P, _P, _I, _I, _P, _P, _P, _P, _I64]),
+    ("thip_frag_copy_list_batch", _I, [_P, _P, _I, _P, _I64, _P]),
+    ("thip_loop_filter_plane", _I, [_P, _I, _I, _I, _P, _I, _I, _I]),
+    ("thip_enc_frag_metric_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _U32, _I64]),
+    ("thip_enc_frag_border_ssd_batch", _I, [_P, _P, _P, _I, _P, _P, _P, _I64]),
+    ("thip_enc_frag_sub_batch", _I, [_P, _P, _P, _I, _P, _P, _I64]),
+    ("thip_enc_frag_copy2_batch", _I, [_P, _P, _I, _P, _P, _P, _I64]),
+    ("thip_enc_fdct8x8_batch", _I, [_P, _P, _I64]),
+    ("thip_profile_enable", _I, [_I]),
+    ("thip_profile_read", _I, [C.POINTER(_I64), C.POINTER(C.c_double)]),
+    ("thip_profile_reset", _I, []),
+    ("thip_version_string", C.c_char_p, []),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library; raises if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise TheoraHipError(
+            "%s not found: build it with `python -m theora_amd.build` (hipcc, gfx950). "
+            "theora_amd has no CPU fallback." % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(L, name)   # AttributeError if the library does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc < 0:
+        raise TheoraHipError("%s failed with TH error %d" % (what, rc))
+    return rc

@@ -1,0 +1,469 @@
+// thip_slots.hip -- batched forms of the individual accel-vtable slots.
+//
+// Decoder side: oc_idct8x8, oc_frag_recon_intra/_inter/_inter2, oc_frag_copy_list,
+// oc_state_loop_filter_frag_rows on one plane (lib/state.h:352-370) -- each exposed on its
+// own so it can be parity-tested against the oracle; the frame path (thip_decode.hip)
+// fuses them.
+// Encoder side: oc_enc_opt_vtable's block kernels (lib/encint.h:292-326): SAD family,
+// SATD family, SSD, sub, copy2 and the forward DCT -- one 8x8 block per lane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/theora_hip.h"
+#include "thip_device.h"
+
+using namespace thip;
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "theora_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
+              __FILE__, __LINE__);                                                       \
+      return THIP_EFAULT;                                                                \
+    }                                                                                    \
+  } while (0)
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// ---------------------------------------------------------------------------------------
+// decoder slots
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_block16(int v[64], const int16_t *p) {
+  const int4 *q = reinterpret_cast<const int4 *>(p);
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int4 w = q[r];
+    const int w4[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      v[r * 8 + 2 * k] = sx16(w4[k]);
+      v[r * 8 + 2 * k + 1] = w4[k] >> 16;
+    }
+  }
+}
+
+__device__ __forceinline__ void store_block16(int16_t *p, const int v[64]) {
+  int4 *q = reinterpret_cast<int4 *>(p);
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    int4 w;
+    w.x = (v[r * 8 + 0] & 0xFFFF) | (v[r * 8 + 1] << 16);
+    w.y = (v[r * 8 + 2] & 0xFFFF) | (v[r * 8 + 3] << 16);
+    w.z = (v[r * 8 + 4] & 0xFFFF) | (v[r * 8 + 5] << 16);
+    w.w = (v[r * 8 + 6] & 0xFFFF) | (v[r * 8 + 7] << 16);
+    q[r] = w;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_idct_batch(int16_t *y, const int16_t *x, const int32_t *last_zzi,
+                                                   int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int v[64];
+  load_block16(v, x + i * 64);
+  idct_mask_by_last_zzi(v, last_zzi ? last_zzi[i] : 64);
+  idct8x8(v);
+  store_block16(y + i * 64, v);
+}
+
+template <int NSRC>
+__global__ __launch_bounds__(256) void k_frag_recon_batch(uint8_t *dst_frame, const uint8_t *src_frame,
+                                                         int ystride, const int32_t *dst_offs,
+                                                         const int32_t *src1_offs, const int32_t *src2_offs,
+                                                         const int16_t *residue, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int v[64];
+  load_block16(v, residue + i * 64);
+  uint8_t *dst = dst_frame + dst_offs[i];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    uint2 pred = make_uint2(0x80808080u, 0x80808080u);   // fragment.c:54
+    if (NSRC >= 1) pred = load_row8(src_frame + src1_offs[i] + (ptrdiff_t)r * ystride);   // fragment.c:64
+    if (NSRC == 2) {                                                                      // fragment.c:76
+      const uint2 b = load_row8(src_frame + src2_offs[i] + (ptrdiff_t)r * ystride);
+      pred.x = avg4_trunc(pred.x, b.x);
+      pred.y = avg4_trunc(pred.y, b.y);
+    }
+    const uint2 o = recon_row(v + r * 8, pred);
+    __builtin_memcpy(dst + (ptrdiff_t)r * ystride, &o, 8);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_frag_copy_list(uint8_t *dst_frame, const uint8_t *src_frame,
+                                                       int ystride, const int32_t *fragis, int64_t n,
+                                                       const int32_t *frag_buf_offs) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const ptrdiff_t off = frag_buf_offs[fragis[i]];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const uint2 t = load_row8(src_frame + off + (ptrdiff_t)r * ystride);
+    __builtin_memcpy(dst_frame + off + (ptrdiff_t)r * ystride, &t, 8);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// encoder block kernels
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_pixels(int p[64], const uint8_t *s, int ystride) {
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const uint2 w = load_row8(s + (ptrdiff_t)r * ystride);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      p[r * 8 + q] = byte_of(w.x, q);
+      p[r * 8 + 4 + q] = byte_of(w.y, q);
+    }
+  }
+}
+
+// 8-point Hadamard butterflies in the reference's output order -- encfrag.c:122-154
+__device__ __forceinline__ void hadamard8(int &a0, int &a1, int &a2, int &a3, int &a4, int &a5, int &a6,
+                                          int &a7) {
+  int t0 = a0 + a4, t4 = a0 - a4, t1 = a1 + a5, t5 = a1 - a5;
+  int t2 = a2 + a6, t6 = a2 - a6, t3 = a3 + a7, t7 = a3 - a7;
+  int r;
+  r = t0; t0 += t2; t2 = r - t2;
+  r = t1; t1 += t3; t3 = r - t3;
+  r = t4; t4 += t6; t6 = r - t6;
+  r = t5; t5 += t7; t7 = r - t7;
+  a0 = t0 + t1; a1 = t0 - t1; a2 = t2 + t3; a3 = t2 - t3;
+  a4 = t4 + t5; a5 = t4 - t5; a6 = t6 + t7; a7 = t6 - t7;
+}
+
+// SATD of a difference block d[64] (row-major): rows first with an int16 store
+// (encfrag.c:147-154), then the other axis, summing |.| without the DC term
+// (encfrag.c:264-315).  *dc = sum of the first-stage DC outputs = sum of all differences.
+__device__ __forceinline__ unsigned satd_of(int d[64], int &dc) {
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    hadamard8(d[r * 8 + 0], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5],
+              d[r * 8 + 6], d[r * 8 + 7]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[r * 8 + k] = sx16(d[r * 8 + k]);
+  }
+  // the reference stores row r's k-th output at buf[k*8+r] and then transforms rows of
+  // buf, i.e. for each k it combines d[r*8+k] over r
+  dc = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) dc += d[r * 8 + 0];
+  unsigned sad = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    int c0 = d[0 * 8 + k], c1 = d[1 * 8 + k], c2 = d[2 * 8 + k], c3 = d[3 * 8 + k];
+    int c4 = d[4 * 8 + k], c5 = d[5 * 8 + k], c6 = d[6 * 8 + k], c7 = d[7 * 8 + k];
+    hadamard8(c0, c1, c2, c3, c4, c5, c6, c7);
+    if (k > 0) sad += abs(c0);
+    sad += abs(c1) + abs(c2) + abs(c3) + abs(c4) + abs(c5) + abs(c6) + abs(c7);
+  }
+  return sad;
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_enc_metric(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane,
+                                                   const uint8_t *ref_plane, int ystride,
+                                                   const int32_t *src_offs, const int32_t *ref_offs,
+                                                   const int32_t *ref2_offs, uint32_t thresh, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int s[64];
+  load_pixels(s, src_plane + src_offs[i], ystride);
+  constexpr bool kHasRef = OP != THIP_ENC_INTRA_SAD && OP != THIP_ENC_INTRA_SATD;
+  constexpr bool kTwo = OP == THIP_ENC_SAD2_THRESH || OP == THIP_ENC_SATD2;
+  int p[64];
+  if (kHasRef) {
+    load_pixels(p, ref_plane + ref_offs[i], ystride);
+    if (kTwo) {
+      int q[64];
+      load_pixels(q, ref_plane + ref2_offs[i], ystride);
+#pragma unroll
+      for (int k = 0; k < 64; k++) p[k] = (p[k] + q[k]) >> 1;   // encfrag.c:79,172
+    }
+  }
+  unsigned v = 0;
+  int dc = 0;
+  if (OP == THIP_ENC_SAD || OP == THIP_ENC_SAD_THRESH || OP == THIP_ENC_SAD2_THRESH) {
+    // row-granular early out of encfrag.c:64,80: rows after the one that crosses the
+    // threshold are not added
+    bool live = true;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      unsigned rs = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) rs += abs(s[r * 8 + k] - p[r * 8 + k]);
+      if (live) v += rs;
+      if (OP != THIP_ENC_SAD && v > thresh) live = false;
+    }
+  } else if (OP == THIP_ENC_INTRA_SAD) {   // encfrag.c:88-107
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 64; k++) sum += s[k];
+    const int mean = (sum + 32) >> 6;
+#pragma unroll
+    for (int k = 0; k < 64; k++) v += abs(s[k] - mean);
+  } else if (OP == THIP_ENC_SSD) {   // encfrag.c:338-350
+#pragma unroll
+    for (int k = 0; k < 64; k++) v += (unsigned)((s[k] - p[k]) * (s[k] - p[k]));
+  } else {   // SATD family, encfrag.c:317-336
+    if (kHasRef) {
+#pragma unroll
+      for (int k = 0; k < 64; k++) s[k] -= p[k];
+    }
+    v = satd_of(s, dc);
+  }
+  out[i] = v;
+  if (dc_out) dc_out[i] = dc;
+}
+
+__global__ __launch_bounds__(256) void k_enc_border_ssd(uint32_t *out, const uint8_t *src_plane,
+                                                       const uint8_t *ref_plane, int ystride,
+                                                       const int32_t *src_offs, const int32_t *ref_offs,
+                                                       const int64_t *masks, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int s[64], p[64];
+  load_pixels(s, src_plane + src_offs[i], ystride);
+  load_pixels(p, ref_plane + ref_offs[i], ystride);
+  const uint64_t m = (uint64_t)masks[i];
+  unsigned v = 0;
+#pragma unroll
+  for (int k = 0; k < 64; k++)
+    if ((m >> k) & 1) v += (unsigned)((s[k] - p[k]) * (s[k] - p[k]));   // encfrag.c:352-366
+  out[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_enc_sub(int16_t *diff, const uint8_t *src_plane,
+                                                const uint8_t *ref_plane, int ystride,
+                                                const int32_t *src_offs, const int32_t *ref_offs, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int s[64];
+  load_pixels(s, src_plane + src_offs[i], ystride);
+  if (ref_offs) {   // encfrag.c:21-30
+    int p[64];
+    load_pixels(p, ref_plane + ref_offs[i], ystride);
+#pragma unroll
+    for (int k = 0; k < 64; k++) s[k] -= p[k];
+  } else {          // encfrag.c:32-40
+#pragma unroll
+    for (int k = 0; k < 64; k++) s[k] -= 128;
+  }
+  store_block16(diff + i * 64, s);
+}
+
+__global__ __launch_bounds__(256) void k_enc_copy2(uint8_t *dst_plane, const uint8_t *src_plane, int ystride,
+                                                  const int32_t *dst_offs, const int32_t *src1_offs,
+                                                  const int32_t *src2_offs, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {   // encfrag.c:368-378
+    const uint2 a = load_row8(src_plane + src1_offs[i] + (ptrdiff_t)r * ystride);
+    const uint2 b = load_row8(src_plane + src2_offs[i] + (ptrdiff_t)r * ystride);
+    const uint2 o = make_uint2(avg4_trunc(a.x, b.x), avg4_trunc(a.y, b.y));
+    __builtin_memcpy(dst_plane + dst_offs[i] + (ptrdiff_t)r * ystride, &o, 8);
+  }
+}
+
+// 1-D forward DCT, in place -- lib/fdct.c:28-120.  Outputs are truncated to int16 by the
+// reference's stores into ogg_int16_t _y[8].
+__device__ __forceinline__ void fdct8(int &x0, int &x1, int &x2, int &x3, int &x4, int &x5, int &x6,
+                                      int &x7) {
+  int t0 = x0 + x7, t7 = x0 - x7, t1 = x1 + x6, t6 = x1 - x6;
+  int t2 = x2 + x5, t5 = x2 - x5, t3 = x3 + x4, t4 = x3 - x4;
+  int r, s, u, v;
+  r = t0 + t3; t3 = t0 - t3; t0 = r;
+  r = t1 + t2; t2 = t1 - t2; t1 = r;
+  r = t6 + t5; t5 = t6 - t5; t6 = r;
+  s = (((27146 * t5 + 0xB500) >> 16) + t5 + (t5 != 0)) >> 1;   // fdct.c:87
+  r = t4 + s; t5 = t4 - s; t4 = r;
+  s = (((27146 * t6 + 0xB500) >> 16) + t6 + (t6 != 0)) >> 1;   // fdct.c:91
+  r = t7 + s; t6 = t7 - s; t7 = r;
+  r = ((27146 * t0 + 0x4000) >> 16) + t0 + (t0 != 0);          // fdct.c:96
+  s = ((27146 * t1 + 0xB500) >> 16) + t1 + (t1 != 0);
+  u = (r + s) >> 1;
+  v = r - u;
+  x0 = sx16(u);
+  x4 = sx16(v);
+  u = ((kC6 * t2 + kC2 * t3 + 0x6CB7) >> 16) + (t3 != 0);      // fdct.c:102
+  s = ((kC6 * u) >> 16) - t2;
+  v = ((s * 21600 + 0x2800) >> 18) + s + (s != 0);
+  x2 = sx16(u);
+  x6 = sx16(v);
+  u = ((kC5 * t6 + kC3 * t5 + 0x0E3D) >> 16) + (t5 != 0);      // fdct.c:108
+  s = t6 - ((kC5 * u) >> 16);
+  v = ((s * 26568 + 0x3400) >> 17) + s + (s != 0);
+  x5 = sx16(u);
+  x3 = sx16(v);
+  u = ((kC7 * t4 + kC1 * t7 + 0x7B1B) >> 16) + (t7 != 0);      // fdct.c:114
+  s = ((kC7 * u) >> 16) - t4;
+  v = ((s * 20539 + 0x3000) >> 20) + s + (s != 0);
+  x1 = sx16(u);
+  x7 = sx16(v);
+}
+
+// natural position of zig-zag index i -- lib/internal.c:27 (first 64 entries)
+__device__ constexpr int kFZigZag[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+__global__ __launch_bounds__(256) void k_enc_fdct(int16_t *y, const int16_t *x, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int w[64];
+  load_block16(w, x + i * 64);
+#pragma unroll
+  for (int k = 0; k < 64; k++) w[k] = sx16(w[k] << 2);        // fdct.c:136
+  w[0] = sx16(w[0] + (w[0] != 0) + 1);                        // fdct.c:139-141
+  w[1] = sx16(w[1] + 1);
+  w[8] = sx16(w[8] - 1);
+  // columns of w -> rows of z (fdct.c:143), then columns of z -> rows of w (fdct.c:145).
+  // In registers: transform each column in place (result element k of column c sits at
+  // [k][c], i.e. z transposed), then each row in place; the final element (r,c) holds
+  // what the reference leaves at w[r*8+c] transposed twice == natural position.
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    fdct8(w[0 * 8 + c], w[1 * 8 + c], w[2 * 8 + c], w[3 * 8 + c], w[4 * 8 + c], w[5 * 8 + c], w[6 * 8 + c],
+          w[7 * 8 + c]);
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    fdct8(w[r * 8 + 0], w[r * 8 + 1], w[r * 8 + 2], w[r * 8 + 3], w[r * 8 + 4], w[r * 8 + 5], w[r * 8 + 6],
+          w[r * 8 + 7]);
+  int o[64];
+#pragma unroll
+  for (int k = 0; k < 64; k++) o[k] = sx16((w[kFZigZag[k]] + 2) >> 2);   // fdct.c:149
+  store_block16(y + i * 64, o);
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int thip_idct8x8_batch(int16_t *y, const int16_t *x, const int32_t *last_zzi, int64_t n) {
+  if (!y || !x) return THIP_EFAULT;
+  if (n < 0) return THIP_EINVAL;
+  if (n == 0) return THIP_OK;
+  hipLaunchKernelGGL(k_idct_batch, grid_for(n), dim3(256), 0, 0, y, x, last_zzi, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
+
+int thip_frag_recon_batch(uint8_t *dst_frame, const uint8_t *src_frame, int ystride, int nsrc,
+                          const int32_t *dst_offs, const int32_t *src1_offs, const int32_t *src2_offs,
+                          const int16_t *residue, int64_t n) {
+  if (!dst_frame || !dst_offs || !residue) return THIP_EFAULT;
+  if (nsrc < 0 || nsrc > 2 || n < 0) return THIP_EINVAL;
+  if ((nsrc >= 1 && (!src_frame || !src1_offs)) || (nsrc == 2 && !src2_offs)) return THIP_EFAULT;
+  if (n == 0) return THIP_OK;
+  if (nsrc == 0)
+    hipLaunchKernelGGL(k_frag_recon_batch<0>, grid_for(n), dim3(256), 0, 0, dst_frame, src_frame, ystride,
+                       dst_offs, src1_offs, src2_offs, residue, n);
+  else if (nsrc == 1)
+    hipLaunchKernelGGL(k_frag_recon_batch<1>, grid_for(n), dim3(256), 0, 0, dst_frame, src_frame, ystride,
+                       dst_offs, src1_offs, src2_offs, residue, n);
+  else
+    hipLaunchKernelGGL(k_frag_recon_batch<2>, grid_for(n), dim3(256), 0, 0, dst_frame, src_frame, ystride,
+                       dst_offs, src1_offs, src2_offs, residue, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
+
+int thip_frag_copy_list_batch(uint8_t *dst_frame, const uint8_t *src_frame, int ystride,
+                              const int32_t *fragis, int64_t nfragis, const int32_t *frag_buf_offs) {
+  if (!dst_frame || !src_frame || !fragis || !frag_buf_offs) return THIP_EFAULT;
+  if (nfragis < 0) return THIP_EINVAL;
+  if (nfragis == 0) return THIP_OK;
+  hipLaunchKernelGGL(k_frag_copy_list, grid_for(nfragis), dim3(256), 0, 0, dst_frame, src_frame, ystride,
+                     fragis, nfragis, frag_buf_offs);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
+
+int thip_enc_frag_metric_batch(int op, uint32_t *out, int32_t *dc_out, const uint8_t *src_plane,
+                               const uint8_t *ref_plane, int ystride, const int32_t *src_offs,
+                               const int32_t *ref_offs, const int32_t *ref2_offs, uint32_t thresh,
+                               int64_t n) {
+  if (!out || !src_plane || !src_offs) return THIP_EFAULT;
+  if (op < 0 || op > THIP_ENC_SSD || n < 0) return THIP_EINVAL;
+  const bool has_ref = op != THIP_ENC_INTRA_SAD && op != THIP_ENC_INTRA_SATD;
+  const bool two = op == THIP_ENC_SAD2_THRESH || op == THIP_ENC_SATD2;
+  if ((has_ref && (!ref_plane || !ref_offs)) || (two && !ref2_offs)) return THIP_EFAULT;
+  if (n == 0) return THIP_OK;
+#define LAUNCH_METRIC(OPC)                                                                              \
+  case OPC:                                                                                             \
+    hipLaunchKernelGGL(k_enc_metric<OPC>, grid_for(n), dim3(256), 0, 0, out, dc_out, src_plane, ref_plane, \
+                       ystride, src_offs, ref_offs, ref2_offs, thresh, n);                              \
+    break;
+  switch (op) {
+    LAUNCH_METRIC(THIP_ENC_SAD)
+    LAUNCH_METRIC(THIP_ENC_SAD_THRESH)
+    LAUNCH_METRIC(THIP_ENC_SAD2_THRESH)
+    LAUNCH_METRIC(THIP_ENC_INTRA_SAD)
+    LAUNCH_METRIC(THIP_ENC_SATD)
+    LAUNCH_METRIC(THIP_ENC_SATD2)
+    LAUNCH_METRIC(THIP_ENC_INTRA_SATD)
+    LAUNCH_METRIC(THIP_ENC_SSD)
+  }
+#undef LAUNCH_METRIC
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
+
+int thip_enc_frag_border_ssd_batch(uint32_t *out, const uint8_t *src_plane, const uint8_t *ref_plane,
+                                   int ystride, const int32_t *src_offs, const int32_t *ref_offs,
+                                   const int64_t *masks, int64_t n) {
+  if (!out || !src_plane || !ref_plane || !src_offs || !ref_offs || !masks) return THIP_EFAULT;
+  if (n < 0) return THIP_EINVAL;
+  if (n == 0) return THIP_OK;
+  hipLaunchKernelGGL(k_enc_border_ssd, grid_for(n), dim3(256), 0, 0, out, src_plane, ref_plane, ystride,
+                     src_offs, ref_offs, masks, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
+
+int thip_enc_frag_sub_batch(int16_t *diff, const uint8_t *src_plane, const uint8_t *ref_plane, int ystride,
+                            const int32_t *src_offs, const int32_t *ref_offs, int64_t n) {
+  if (!diff || !src_plane || !src_offs || (ref_offs && !ref_plane)) return THIP_EFAULT;
+  if (n < 0) return THIP_EINVAL;
+  if (n == 0) return THIP_OK;
+  hipLaunchKernelGGL(k_enc_sub, grid_for(n), dim3(256), 0, 0, diff, src_plane, ref_plane, ystride, src_offs,
+                     ref_offs, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
+
+int thip_enc_frag_copy2_batch(uint8_t *dst_plane, const uint8_t *src_plane, int ystride,
+                              const int32_t *dst_offs, const int32_t *src1_offs, const int32_t *src2_offs,
+                              int64_t n) {
+  if (!dst_plane || !src_plane || !dst_offs || !src1_offs || !src2_offs) return THIP_EFAULT;
+  if (n < 0) return THIP_EINVAL;
+  if (n == 0) return THIP_OK;
+  hipLaunchKernelGGL(k_enc_copy2, grid_for(n), dim3(256), 0, 0, dst_plane, src_plane, ystride, dst_offs,
+                     src1_offs, src2_offs, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
+
+int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n) {
+  if (!y || !x) return THIP_EFAULT;
+  if (n < 0) return THIP_EINVAL;
+  if (n == 0) return THIP_OK;
+  hipLaunchKernelGGL(k_enc_fdct, grid_for(n), dim3(256), 0, 0, y, x, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
+
+}  // extern "C"
