@@ -112,3 +112,20 @@ def test_ycbcr_out_is_top_down(hip):
     outs = gst.ycbcr_out()
     for pli in range(3):
         assert np.array_equal(outs[pli], ost.get_plane(oracle.FRAME_PREV, pli)[::-1])
+
+
+def test_parity_check_has_teeth(hip):
+    """Negative control: a frame decoded with a different loop-filter limit on the GPU side
+    must be reported as a mismatch by the same comparison the other tests rely on."""
+    w, h = 176, 144
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(77)
+    ost = oracle.State(w, h, PF_420)
+    gst = hip.State(w, h, PF_420)
+    fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME, "mixed", flimit=15)
+    util.oracle_apply(ost, fr)
+    wrong = dict(fr)
+    wrong["flimit"] = 14
+    desc, ka = synth.upload_frame(synth.pack_frame(wrong))
+    hip.decode_frames([gst], [desc])
+    assert util.planes_equal(ost, gst), "comparison failed to notice a different filter limit"

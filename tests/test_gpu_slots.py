@@ -9,9 +9,18 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
+_KEEP = []
+
+
 def dev(a):
+    """Host array -> device tensor; the tensor is kept alive until the test module ends so
+    raw data_ptr() values handed to the C ABI stay valid."""
     import torch
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    _KEEP.append(t)
+    if len(_KEEP) > 4096:
+        del _KEEP[:2048]
+    return t
 
 
 def random_blocks(rng, n):
@@ -50,7 +59,7 @@ def test_idct_empty_batch(hip):
 def _recon_case(hip, nsrc, seed):
     from theora_amd import _lib
     rng = np.random.default_rng(seed)
-    stride, H = 200, 160
+    stride, H = 400, 320
     n = 1500
     src = rng.integers(0, 256, (H, stride)).astype(np.uint8)
     dst0 = rng.integers(0, 256, (H, stride)).astype(np.uint8)

@@ -79,6 +79,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP/HSA runtime per process: torch ships its own libamdhip64.so (SONAME
+    # libamdhip64.so.7) and looks it up by the unversioned name, so it must be loaded
+    # BEFORE this library; our DT_NEEDED libamdhip64.so.7 then binds to the copy already in
+    # the process.  The other order loads two runtimes and the second sees no device.
+    import torch  # noqa: F401
     if not os.path.exists(SO_PATH):
         raise TheoraHipError(
             "%s not found: build it with `python -m theora_amd.build` (hipcc, gfx950). "

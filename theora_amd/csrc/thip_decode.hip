@@ -475,14 +475,12 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
   }
   st->nfrags = fro;
   st->frame_bytes = off;
-  for (int b = 0; b < 3; b++) {
-    if (hipMalloc((void **)&st->frames[b], st->frame_bytes) != hipSuccess) {
-      thip_state_free(st);
-      return THIP_EFAULT;
-    }
-  }
-  if (hipMalloc((void **)&st->coded_map, (size_t)st->nfrags) != hipSuccess ||
-      hipMemset(st->coded_map, 0, (size_t)st->nfrags) != hipSuccess) {
+  hipError_t err = hipSuccess;
+  for (int b = 0; b < 3 && err == hipSuccess; b++) err = hipMalloc((void **)&st->frames[b], st->frame_bytes);
+  if (err == hipSuccess) err = hipMalloc((void **)&st->coded_map, (size_t)st->nfrags);
+  if (err == hipSuccess) err = hipMemset(st->coded_map, 0, (size_t)st->nfrags);
+  if (err != hipSuccess) {
+    fprintf(stderr, "theora_hip: thip_state_create: device allocation failed: %s\n", hipGetErrorString(err));
     thip_state_free(st);
     return THIP_EFAULT;
   }
