@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- decode throughput of the MI355X fragment-reconstruction path.
+
+A "step" decodes ONE frame of each of the rank's streams (default: 4 concurrent 4K 4:2:0
+streams per GPU, keyframe interval 64) from fragment command streams already resident in
+HBM: coded-fragment reconstruction (dequantised coefficients -> iDCT -> intra / motion
+compensated predictor -> pixels), uncoded-fragment copy and the in-loop deblocking filter,
+through the C ABI (thip_decode_frames).  Prints ONE JSON line (rank 0).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4k|1080p|720p]
+                  [--content dense|smooth|mixed] [--streams-per-gpu S]
+For N>1 launch with  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+Streams are sharded whole across ranks (no data-path collective); RCCL is used for the
+barriers, the max-over-ranks time and the checksum gather.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SIZES = {"4k": (3840, 2160), "1080p": (1920, 1088), "720p": (1280, 720), "qcif": (176, 144)}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec peak
+KF_INTERVAL = 64
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--size", default="4k", choices=sorted(SIZES))
+    ap.add_argument("--content", default="dense", choices=["dense", "smooth", "mixed"])
+    ap.add_argument("--streams-per-gpu", type=int, default=4)
+    ap.add_argument("--pool", type=int, default=6, help="distinct inter-frame command streams per stream")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of stream 0 the CPU oracle decodes")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import theora_amd
+    from theora_amd import synth
+
+    w, h = SIZES[args.size]
+    S = args.streams_per_gpu
+    geom = synth.Geometry(w, h)
+    # ---- synthetic command streams -> HBM ------------------------------------------------
+    # One seeded pool of frames per rank (numpy generation is the slow part); every stream
+    # gets its OWN device copy of every frame so no two streams share cache lines.
+    rng = np.random.default_rng(12345 + rank)
+    t_gen = time.time()
+    host_frames = [synth.gen_frame(geom, rng, theora_amd.INTRA_FRAME, args.content, flimit=2)]
+    for _ in range(args.pool):
+        host_frames.append(synth.gen_frame(geom, rng, theora_amd.INTER_FRAME, args.content, flimit=2))
+    packed = [synth.pack_frame(f) for f in host_frames]
+    balg = [synth.algorithmic_bytes(geom, f) for f in host_frames]
+    keep, descs = [], []                      # descs[stream][frame]
+    for s in range(S):
+        row = []
+        for p in packed:
+            d, ka = synth.upload_frame(p)
+            keep.append(ka)
+            row.append(d)
+        descs.append(row)
+    t_gen = time.time() - t_gen
+    states = [theora_amd.State(w, h) for _ in range(S)]
+    plans = [theora_amd.BatchPlan(states, [descs[s][j] for s in range(S)]) for j in range(len(packed))]
+
+    def frame_of_step(i):
+        return 0 if i % KF_INTERVAL == 0 else 1 + (i % args.pool)
+
+    def run(nsteps, first=0):
+        for i in range(first, first + nsteps):
+            plans[frame_of_step(i)].submit()
+
+    def sync():
+        theora_amd.synchronize()
+        torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- parity sample + CPU baseline (rank 0, N=1 only) ---------------------------------
+    cpu_baseline, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        ost = oracle.State(w, h)
+        vst = theora_amd.State(w, h)
+        nf = args.cpu_frames
+        t_cpu = 0.0
+        ok = True
+        for i in range(nf):
+            fr = host_frames[frame_of_step(i)]
+            ost.refi[:] = fr["refi"]
+            ost.mvs[:] = ((fr["mvx"] & 0xFF) | (fr["mvy"] << 8)).astype(np.int16)
+            t0 = time.perf_counter()
+            ost.decode_frame(fr["frame_type"], fr["coded_fragis"], fr["ncoded"], fr["coeffs"], fr["last_zzi"],
+                             fr["dc_quant"], fr["uncoded_fragis"], fr["flimit"])
+            t_cpu += time.perf_counter() - t0
+            theora_amd.decode_frames([vst], [descs[0][frame_of_step(i)]])
+        for pli in range(3):
+            a = ost.get_plane(oracle.FRAME_PREV, pli)
+            b = vst.read_plane(vst.ref_idx(theora_amd.FRAME_PREV), pli)
+            ok = ok and bool(np.array_equal(a, b))
+        parity = {"frames": nf, "bit_exact": ok, "checked": "stream 0, frame %d of the sequence, all planes" % (nf - 1)}
+        cpu_baseline = {"value": round(nf / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                        "sample": "%d frames of one %s %s stream through oracle/theora_oracle.c "
+                                  "(scalar C restatement of the reference's C path, gcc -O2)" % (nf, args.size, args.content)}
+        vst.close()
+        ost.close()
+        if not ok:
+            raise SystemExit("bench: GPU output differs from the oracle -- refusing to report a number")
+
+    # ---- timed region ---------------------------------------------------------------------
+    run(args.warmup)
+    sync()
+    profiling = not args.no_profile
+    if profiling:
+        theora_amd.profile_reset()
+        theora_amd.profile_enable(True)
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    run(args.steps, first=args.warmup)
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kms = [0, 0], [0.0, 0.0]
+    if profiling:
+        theora_amd.profile_enable(False)
+        launches, kms = theora_amd.profile_read()
+
+    # checksum of each stream's final frame (all planes): gathered over ranks, printed
+    crcs = []
+    for st in states:
+        c = 0
+        for pli in range(3):
+            c = zlib.crc32(st.read_plane(st.ref_idx(theora_amd.FRAME_PREV), pli).tobytes(), c)
+        crcs.append(c)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        mine = torch.tensor(crcs, dtype=torch.int64, device="cuda")
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        crcs = [int(v) for t in allc for v in t.tolist()]
+        kt = torch.tensor(kms + [float(x) for x in launches], dtype=torch.float64, device="cuda")
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+        kms = [float(kt[0]), float(kt[1])]
+
+    if rank == 0:
+        steps_b_alg = sum(balg[frame_of_step(i)][0] for i in range(args.warmup, args.warmup + args.steps)) * S
+        steps_b_read = sum(balg[frame_of_step(i)][1] for i in range(args.warmup, args.warmup + args.steps)) * S
+        total_frames = args.steps * S * world
+        fps = total_frames / elapsed
+        out = {
+            "metric": "decode frames/sec (%s 4:2:0, bit-exact)" % args.size,
+            "value": round(fps, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i16",
+            "data": "synthetic",
+            "config": {"workload": "%s (%dx%d coded) 4:2:0, %d concurrent streams per GPU, keyframe interval %d, "
+                                   "content class '%s' (seeded fragment command streams resident in HBM), "
+                                   "loop filter on (flimit 2)" % (args.size, w, h, S, KF_INTERVAL, args.content),
+                       "streams_per_gpu": S, "frame_pool": args.pool, "parallelism": "stream-sharded x%d" % world},
+        }
+        if profiling and kms[0] > 0:
+            gbs = steps_b_alg / (kms[0] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_recon", "achieved": round(gbs, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "traffic": None,
+                               "avg_launch_us": round(1e3 * kms[0] / max(launches[0], 1), 3),
+                               "loopfilter_avg_launch_us": round(1e3 * kms[1] / max(launches[1], 1), 3),
+                               "alg_bytes_per_launch": int(steps_b_alg / max(launches[0], 1))}
+        # whole pipeline (recon + loop filter + launch gaps) against the HBM-read roofline of BASELINE.md section 3
+        out["pipeline"] = {"read_roofline_frac": round((steps_b_read / elapsed) / 1e9 / HBM_PEAK_GBS, 4),
+                           "alg_GBps_per_gpu": round(steps_b_alg / elapsed / 1e9, 1)}
+        if cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline
+        if parity:
+            out["parity"] = parity
+        out["stream_crc32"] = ["%08x" % c for c in crcs]
+        out["setup_s"] = round(t_gen, 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
