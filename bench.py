@@ -65,32 +65,36 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     import theora_amd
-    from theora_amd import synth
+    from theora_amd import shard, synth
 
     w, h = SIZES[args.size]
     S = args.streams_per_gpu
     geom = synth.Geometry(w, h)
     # ---- synthetic command streams -> HBM ------------------------------------------------
-    # One seeded pool of frames per rank (numpy generation is the slow part); every stream
-    # gets its OWN device copy of every frame so no two streams share cache lines.
-    rng = np.random.default_rng(12345 + rank)
+    # Every stream has its own seeded content (seed = f(global stream id), so a stream is
+    # the same pictures on whichever GPU it lands) and its own copy in HBM: one keyframe
+    # command stream + `pool` inter-frame command streams, cycled.
     t_gen = time.time()
-    host_frames = [synth.gen_frame(geom, rng, theora_amd.INTRA_FRAME, args.content, flimit=2)]
-    for _ in range(args.pool):
-        host_frames.append(synth.gen_frame(geom, rng, theora_amd.INTER_FRAME, args.content, flimit=2))
-    packed = [synth.pack_frame(f) for f in host_frames]
-    balg = [synth.algorithmic_bytes(geom, f) for f in host_frames]
-    keep, descs = [], []                      # descs[stream][frame]
-    for s in range(S):
+    keep, descs, balg = [], [], []            # descs[stream][frame], balg[stream][frame]
+    host_frames0 = None
+    for gid in shard.stream_ids(rank, world, S):
+        rng = np.random.default_rng(shard.stream_seed(12345, gid))
+        frames = [synth.gen_frame(geom, rng, theora_amd.INTRA_FRAME, args.content, flimit=2)]
+        for _ in range(args.pool):
+            frames.append(synth.gen_frame(geom, rng, theora_amd.INTER_FRAME, args.content, flimit=2))
+        if host_frames0 is None:
+            host_frames0 = frames             # kept for the CPU baseline / parity sample
         row = []
-        for p in packed:
-            d, ka = synth.upload_frame(p)
+        for f in frames:
+            d, ka = synth.upload_frame(synth.pack_frame(f))
             keep.append(ka)
             row.append(d)
         descs.append(row)
+        balg.append([synth.algorithmic_bytes(geom, f) for f in frames])
+    host_frames = host_frames0
     t_gen = time.time() - t_gen
     states = [theora_amd.State(w, h) for _ in range(S)]
-    plans = [theora_amd.BatchPlan(states, [descs[s][j] for s in range(S)]) for j in range(len(packed))]
+    plans = [theora_amd.BatchPlan(states, [descs[s][j] for s in range(S)]) for j in range(args.pool + 1)]
 
     def frame_of_step(i):
         return 0 if i % KF_INTERVAL == 0 else 1 + (i % args.pool)
@@ -104,8 +108,7 @@ def main():
         torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        shard.barrier(world)
 
     # ---- parity sample + CPU baseline (rank 0, N=1 only) ---------------------------------
     cpu_baseline, parity = None, None
@@ -164,21 +167,14 @@ def main():
         for pli in range(3):
             c = zlib.crc32(st.read_plane(st.ref_idx(theora_amd.FRAME_PREV), pli).tobytes(), c)
         crcs.append(c)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        mine = torch.tensor(crcs, dtype=torch.int64, device="cuda")
-        allc = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allc, mine)
-        crcs = [int(v) for t in allc for v in t.tolist()]
-        kt = torch.tensor(kms + [float(x) for x in launches], dtype=torch.float64, device="cuda")
-        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
-        kms = [float(kt[0]), float(kt[1])]
+    dev = torch.device("cuda", local_rank)
+    elapsed, crcs = shard.reduce_results(elapsed, crcs, dev)
+    kms = shard.reduce_max(kms, dev)
 
     if rank == 0:
-        steps_b_alg = sum(balg[frame_of_step(i)][0] for i in range(args.warmup, args.warmup + args.steps)) * S
-        steps_b_read = sum(balg[frame_of_step(i)][1] for i in range(args.warmup, args.warmup + args.steps)) * S
+        rng_steps = range(args.warmup, args.warmup + args.steps)
+        steps_b_alg = sum(balg[s][frame_of_step(i)][0] for i in rng_steps for s in range(S))
+        steps_b_read = sum(balg[s][frame_of_step(i)][1] for i in rng_steps for s in range(S))
         total_frames = args.steps * S * world
         fps = total_frames / elapsed
         out = {

@@ -1,0 +1,227 @@
+"""The CPU oracle against itself, against closed forms, and against the committed golden
+vectors (tests/golden/, produced by tests/golden/make_golden.py from the oracle + the
+spec model).  PARITY UNPINNED: none of this has been compared with a reference binary."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from theora_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_idct_variants_agree_on_consistent_blocks():
+    """idct.c:234-277: the _3 / _10 variants equal the full transform when the ignored
+    coefficients are zero (the fact the GPU kernel relies on)."""
+    rng = np.random.default_rng(1)
+    n = 30000
+    for nz, lz in [(1, 1), (2, 2), (3, 3), (4, 4), (10, 10), (6, 9)]:
+        x = np.zeros((n, 64), np.int16)
+        for z in range(nz):
+            x[:, synth.FZIG_ZAG[z]] = rng.integers(-32768, 32768, n)
+        a = oracle.idct8x8_batch(x, np.full(n, lz, np.int32))
+        b = oracle.idct8x8_batch(x, np.full(n, 64, np.int32))
+        assert np.array_equal(a, b), (nz, lz)
+
+
+def test_idct_variants_ignore_what_the_reference_ignores():
+    rng = np.random.default_rng(2)
+    n = 5000
+    x = rng.integers(-3000, 3000, (n, 64)).astype(np.int16)
+    keep3 = np.zeros(64, bool)
+    keep3[[0, 1, 8]] = True
+    keep10 = np.zeros(64, bool)
+    keep10[[0, 1, 2, 3, 8, 9, 10, 16, 17, 24]] = True
+    for lz, keep in [(0, keep3), (3, keep3), (4, keep10), (10, keep10)]:
+        a = oracle.idct8x8_batch(x, np.full(n, lz, np.int32))
+        b = oracle.idct8x8_batch(np.where(keep, x, 0).astype(np.int16), np.full(n, 64, np.int32))
+        assert np.array_equal(a, b), lz
+
+
+def test_idct_dc_matches_closed_form():
+    """A DC-only block through the transform: ((C4*((C4*dc)>>16))>>16 + 8) >> 4 everywhere."""
+    dc = np.arange(-32768, 32768, 7, dtype=np.int64)
+    x = np.zeros((dc.size, 64), np.int16)
+    x[:, 0] = dc
+    y = oracle.idct8x8_batch(x)
+    t = (46341 * dc) >> 16
+    t = ((t + 32768) % 65536) - 32768
+    t = (46341 * t) >> 16
+    want = (((t + 32768) % 65536 - 32768) + 8) >> 4
+    assert np.array_equal(y, np.repeat(want[:, None], 64, 1).astype(np.int16))
+
+
+def test_idct_is_near_float_idct():
+    """Sanity: the integer transform approximates the orthonormal 2-D iDCT of x/4."""
+    rng = np.random.default_rng(3)
+    x = rng.integers(-500, 500, (2000, 64)).astype(np.int16)
+    y = oracle.idct8x8_batch(x).reshape(-1, 8, 8).astype(np.float64)
+    k = np.arange(8)
+    B = np.cos((2 * k[:, None] + 1) * k[None, :] * np.pi / 16) * np.where(k == 0, np.sqrt(1 / 8), np.sqrt(2 / 8))
+    ref = np.einsum("ik,nkl,jl->nij", B, x.reshape(-1, 8, 8) / 4.0, B)
+    err = np.abs(y - ref)
+    assert err.max() < 3.0 and err.mean() < 0.5      # and the transposed orientation is off by hundreds
+
+
+def test_fdct_idct_round_trip():
+    """fdct.c:74-84 claims the forward transform is built as a near inverse of the iDCT."""
+    rng = np.random.default_rng(4)
+    x = rng.integers(-255, 256, (5000, 64)).astype(np.int16)
+    z = oracle.fdct8x8_batch(x)
+    nat = np.zeros_like(z)
+    nat[:, synth.FZIG_ZAG] = z
+    back = oracle.idct8x8_batch(nat)
+    assert np.abs(back.astype(np.int32) - x).max() <= 2
+
+
+def test_mv_offsets_match_division_rule():
+    """state.c:846-957 (tables) == truncating division plus a sign step on any fraction."""
+    for q in (0, 1):
+        div = 4 if q else 2
+        for v in range(-31, 32):
+            n, o0, o1 = oracle.mv_offsets(1000, q, 0, v, 0)
+            whole = int(v / div)
+            assert o0 == whole
+            if v % div:
+                assert n == 2 and o1 == whole + (1 if v > 0 else -1)
+            else:
+                assert n == 1
+            n, o0, o1 = oracle.mv_offsets(1000, 0, q, 0, v)
+            assert o0 == whole * 1000
+    assert oracle.mv_offsets(-208, 0, 0, -3, 5) == (2, 2 * -208 - 1, 2 * -208 - 1 + -208 - 1)
+
+
+@pytest.mark.parametrize("flimit", [0, 1, 2, 15, 63, 64, 100, 127])
+def test_loop_filter_table_is_lflim(flimit):
+    bv = oracle.loop_filter_bv(flimit).astype(np.int32)
+    R = np.arange(-127, 129)
+    a = np.abs(R)
+    want = np.sign(R) * np.minimum(a, np.maximum(2 * flimit - a, 0))
+    assert np.array_equal(bv, want)
+
+
+def test_sb_order_matches_numpy_geometry():
+    for (w, h, fmt) in [(176, 144, 0), (64, 48, 3), (80, 112, 2), (16, 16, 0), (1280, 720, 0)]:
+        st = oracle.State(w, h, fmt)
+        g = synth.Geometry(w, h, fmt)
+        assert st.nfrags == g.nfrags
+        for p in range(3):
+            assert np.array_equal(st.sb_order(p), g.sb_order(p))
+            assert st.planes[p]["nhfrags"] == g.nh[p] and st.planes[p]["nvfrags"] == g.nv[p]
+        assert sorted(g.coded_order.tolist()) == list(range(g.nfrags))
+
+
+def test_state_rejects_bad_geometry():
+    for (w, h, fmt) in [(170, 144, 0), (176, 100, 0), (176, 144, 1), (0, 16, 0)]:
+        with pytest.raises(ValueError):
+            oracle.State(w, h, fmt)
+
+
+def test_border_fill_equals_clamped_reads():
+    """state.c:770-835: rows first, then caps that copy the padded rows, so every padding
+    pixel equals the picture pixel with both coordinates clamped."""
+    st = oracle.State(64, 48, 0)
+    st.set_ref_idx(0, 0, 0)
+    rng = np.random.default_rng(5)
+    for pli in range(3):
+        g = st.planes[pli]
+        img = rng.integers(0, 256, (g["height"], g["width"])).astype(np.uint8)
+        st.set_plane(oracle.FRAME_SELF, pli, img)
+        # predict each block with every legal vector and compare with a clamped gather
+        res = np.zeros(128, np.int16)
+        for dx in (-31, -16, -1, 0, 15, 31):
+            for dy in (-31, -2, 0, 7, 31):
+                st.set_ref_idx(0, 0, 1)
+                st.refi[:] = oracle.FRAME_PREV
+                st.mvs[:] = np.int16((dx & 0xFF) | (dy << 8))
+                n = st.nfrags
+                cf = np.arange(g["froffset"], g["froffset"] + g["nfrags"])
+                # only the plane under test is coded; the rest uncoded
+                allf = np.arange(n)
+                unc = np.setdiff1d(allf, cf)
+                nc = [0, 0, 0]
+                nc[pli] = cf.size
+                order = st.sb_order(pli)
+                st.decode_frame(oracle.INTER_FRAME, order, nc, np.zeros((cf.size, 64), np.int16),
+                                np.zeros(cf.size, np.uint8), np.ones(cf.size, np.uint16), unc, 0)
+                got = st.get_plane(oracle.FRAME_PREV, pli).astype(np.int32)
+                qx = 4 if (pli and st.hdec) else 2
+                qy = 4 if (pli and st.vdec) else 2
+                mx, my = int(dx / qx), int(dy / qy)
+                mx2 = (1 if dx > 0 else -1) if dx % qx else 0
+                my2 = (1 if dy > 0 else -1) if dy % qy else 0
+                H, W = img.shape
+                yy, xx = np.mgrid[0:H, 0:W]
+                a = img[np.clip(yy + my, 0, H - 1), np.clip(xx + mx, 0, W - 1)].astype(np.int32)
+                if mx2 or my2:
+                    b = img[np.clip(yy + my + my2, 0, H - 1), np.clip(xx + mx + mx2, 0, W - 1)].astype(np.int32)
+                    a = (a + b) >> 1
+                assert np.array_equal(got, a), (pli, dx, dy)
+                st.set_ref_idx(0, 0, 0)
+                st.set_plane(oracle.FRAME_SELF, pli, img)
+
+
+def test_dc_unpredict_simple_cases():
+    st = oracle.State(64, 32, 3)
+    st.coded[:] = 1
+    st.refi[:] = oracle.FRAME_PREV
+    st.dc[:] = 0
+    st.dc[0] = 100
+    st.dc_unpredict()
+    # a single impulse at the first fragment propagates as the predictor of everything after it
+    nh = st.planes[0]["nhfrags"]
+    assert st.dc[0] == 100 and st.dc[1] == 100 and st.dc[nh] == 100
+    assert (st.dc[st.planes[1]["froffset"]:] == 0).all()
+
+
+def test_satd_of_constant_difference():
+    src = np.full((8, 8), 100, np.uint8)
+    ref = np.full((8, 8), 90, np.uint8)
+    v, dc = oracle.enc_metric_batch("satd", src, ref, 8, [0], [0])
+    assert v[0] == 0 and dc[0] == 640
+    v, _ = oracle.enc_metric_batch("sad", src, ref, 8, [0], [0])
+    assert v[0] == 640
+    v, _ = oracle.enc_metric_batch("sad_thresh", src, ref, 8, [0], [0], thresh=100)
+    assert v[0] == 160     # stops after the second row (80, 160 > 100)
+
+
+def test_golden_vectors():
+    """Committed fixtures (inputs + expected outputs); see tests/golden/README.md."""
+    z = np.load(os.path.join(HERE, "golden", "kernels.npz"))
+    assert np.array_equal(oracle.idct8x8_batch(z["idct_x"], z["idct_last_zzi"]), z["idct_y"])
+    assert np.array_equal(oracle.fdct8x8_batch(z["fdct_x"]), z["fdct_y"])
+    for op in ("sad", "satd", "satd2", "intra_satd", "intra_sad", "ssd", "sad2_thresh"):
+        v, dc = oracle.enc_metric_batch(op, z["enc_src"], z["enc_ref"], int(z["enc_stride"]), z["enc_so"],
+                                        z["enc_ro"], z["enc_r2"], int(z["enc_thresh"]))
+        assert np.array_equal(v, z["enc_" + op]), op
+        if "satd" in op:
+            assert np.array_equal(dc, z["enc_" + op + "_dc"]), op
+    st = oracle.State(64, 48, 0)
+    st.set_ref_idx(0, 0, 0)
+    st.coded[:] = 0
+    st.coded[:48] = z["lf_coded"]
+    st.set_plane(oracle.FRAME_SELF, 0, z["lf_in"])
+    st.loop_filter_rows(int(z["lf_flimit"]), oracle.FRAME_SELF, 0, 0, 6)
+    assert np.array_equal(st.get_plane(oracle.FRAME_SELF, 0), z["lf_out"])
+
+
+def test_golden_sequence_digest():
+    """A 10-frame QCIF synthetic sequence: per-frame CRC32 of the decoded planes."""
+    import json
+    import zlib
+    want = json.load(open(os.path.join(HERE, "golden", "qcif_sequence.json")))
+    geom = synth.Geometry(176, 144)
+    rng = np.random.default_rng(want["seed"])
+    st = oracle.State(176, 144)
+    got = []
+    from tests import util
+    for f in range(want["frames"]):
+        fr = synth.gen_frame(geom, rng, 0 if f % want["kf_interval"] == 0 else 1, want["content"])
+        util.oracle_apply(st, fr)
+        c = 0
+        for pli in range(3):
+            c = zlib.crc32(st.get_plane(oracle.FRAME_PREV, pli).tobytes(), c)
+        got.append("%08x" % c)
+    assert got == want["crc32"]

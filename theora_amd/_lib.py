@@ -1,7 +1,7 @@
 """ctypes binding of libtheora_hip.so (include/theora_hip.h).
 
 There is no fallback: if the HIP library has not been built, or a call fails, this
-raises.  Nothing here (or anywhere in theora_amd/) touches oracle/.
+raises.  Nothing here (or anywhere in theora_amd/) touches the CPU checker used by the tests.
 """
 import ctypes as C
 import os

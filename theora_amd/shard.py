@@ -1,0 +1,48 @@
+"""Multi-GPU layout of a batch of independent streams.
+
+Whole streams are sharded across ranks -- stream s lives on rank s // streams_per_gpu --
+and never exchange data: a stream's three reference frames stay on its GPU.  The only
+collectives are control-plane: a barrier around the timed region, MAX of the elapsed time
+and an all-gather of per-stream checksums/counters (RCCL on GPUs, gloo in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def stream_ids(rank, world, streams_per_gpu):
+    """Global stream ids owned by `rank` (weak scaling: the batch grows with the world)."""
+    if not (0 <= rank < world) or streams_per_gpu < 0:
+        raise ValueError("bad rank/world/streams_per_gpu")
+    return list(range(rank * streams_per_gpu, (rank + 1) * streams_per_gpu))
+
+
+def stream_seed(base_seed, stream_id):
+    """Seed of a stream's synthetic content: a function of the GLOBAL stream id only, so a
+    stream decodes to the same pictures wherever it is placed."""
+    return int(base_seed) + 1000003 * int(stream_id)
+
+
+def barrier(world):
+    if world > 1:
+        dist.barrier()
+
+
+def reduce_results(elapsed, per_stream_values, device):
+    """(max elapsed over ranks, values of all streams in global stream order)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(elapsed), [int(v) for v in per_stream_values]
+    world = dist.get_world_size()
+    t = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    mine = torch.tensor([int(v) for v in per_stream_values], dtype=torch.int64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return float(t.item()), [int(v) for p in parts for v in p.tolist()]
+
+
+def reduce_max(values, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
