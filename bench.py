@@ -142,12 +142,9 @@ def main():
             raise SystemExit("bench: GPU output differs from the oracle -- refusing to report a number")
 
     # ---- timed region ---------------------------------------------------------------------
+    # Pass A: exactly K steps, no instrumentation -> `value`.
     run(args.warmup)
     sync()
-    profiling = not args.no_profile
-    if profiling:
-        theora_amd.profile_reset()
-        theora_amd.profile_enable(True)
     barrier()
     sync()
     t0 = time.perf_counter()
@@ -155,8 +152,19 @@ def main():
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    launches, kms = [0, 0], [0.0, 0.0]
+    # Pass B: the same K steps again with every kernel bracketed by HIP events on the
+    # stream it runs on -> per-kernel durations for the roofline.  Kept out of pass A
+    # because four event records per step cost ~15 % of the step.
+    profiling = not args.no_profile
+    launches, kms, elapsed_b = [0, 0], [0.0, 0.0], 0.0
     if profiling:
+        theora_amd.profile_reset()
+        theora_amd.profile_enable(True)
+        sync()
+        t0 = time.perf_counter()
+        run(args.steps, first=args.warmup)       # same frame sequence (the ring state differs, the work does not)
+        sync()
+        elapsed_b = time.perf_counter() - t0
         theora_amd.profile_enable(False)
         launches, kms = theora_amd.profile_read()
 
@@ -202,7 +210,9 @@ def main():
                                "traffic": None,
                                "avg_launch_us": round(1e3 * kms[0] / max(launches[0], 1), 3),
                                "loopfilter_avg_launch_us": round(1e3 * kms[1] / max(launches[1], 1), 3),
-                               "alg_bytes_per_launch": int(steps_b_alg / max(launches[0], 1))}
+                               "alg_bytes_per_launch": int(steps_b_alg / max(launches[0], 1)),
+                               "measured": "HIP events around every launch, separate instrumented pass of the same "
+                                           "%d steps (ms_per_step there: %.5f)" % (args.steps, 1e3 * elapsed_b / args.steps)}
         # whole pipeline (recon + loop filter + launch gaps) against the HBM-read roofline of BASELINE.md section 3
         out["pipeline"] = {"read_roofline_frac": round((steps_b_read / elapsed) / 1e9 / HBM_PEAK_GBS, 4),
                            "alg_GBps_per_gpu": round(steps_b_alg / elapsed / 1e9, 1)}

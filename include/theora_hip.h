@@ -88,9 +88,12 @@ int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t ds
  *                     mv x, mv y  bits 16-23, 24-31 signed (oc_mv, state.h:232-240)
  *  coeffs   dequantised int16 coefficients, DC included ((int16)(dc*dc_quant),
  *           state.c:978).  "Tile" layout chosen by this backend (cf. the per-backend
- *           dct_fzig_zag table, state.h:374-376): slot i (= position in cmds) lives in
- *           tile i/64, lane i%64; row r (8 coefficients, natural order) of that block is
- *           the 16 bytes at  tile*8192 + r*1024 + lane*16.  ceil(ncoded/64) whole tiles.
+ *           dct_fzig_zag table, state.h:374-376, and the transposed tables of
+ *           x86state.c:44-64): slot i (= position in cmds) lives in tile i/64, lane i%64.
+ *           A block is eight 16-byte groups; group q = 2*j+h (j = row pair 0..3, h = column
+ *           half 0..1) sits at  tile*8192 + q*1024 + lane*16  and holds, for columns
+ *           c = 4h..4h+3, the int16 pairs { x[2j][c], x[2j+1][c] } (x natural order,
+ *           row-major).  ceil(ncoded/64) whole tiles.
  *  uncoded  fragment indices copied PREV->SELF (oc_frag_copy_list, fragment.c:37)
  * Every fragment of the frame must appear in exactly one of the two lists.
  * ---------------------------------------------------------------------------------- */

@@ -57,20 +57,22 @@ def dequant_dc(coeffs, last_zzi, dc_quant):
 
 
 def pack_tiles(coeffs):
-    """[n,64] natural-order int16 blocks -> the backend's tile layout (int16, flat):
-    block i, row r at tile (i//64), offset r*512 + (i%64)*8 int16s."""
+    """[n,64] natural-order int16 blocks -> the backend's tile layout (int16, flat); see
+    include/theora_hip.h: group q=2j+h of block i at tile(i//64)*4096 + q*512 + (i%64)*8
+    int16s, holding {x[2j][c], x[2j+1][c]} for c=4h..4h+3."""
     co = np.asarray(coeffs, np.int16).reshape(-1, 8, 8)
     n = co.shape[0]
     ntiles = (n + TILE_BLOCKS - 1) // TILE_BLOCKS
     pad = np.zeros((ntiles * TILE_BLOCKS, 8, 8), np.int16)
     pad[:n] = co
-    # [tile, lane, row, col] -> [tile, row, lane, col]
-    return np.ascontiguousarray(pad.reshape(ntiles, TILE_BLOCKS, 8, 8).transpose(0, 2, 1, 3)).reshape(-1)
+    # [tile, lane, j, half, h, cc] -> [tile, j, h, lane, cc, half]
+    t = pad.reshape(ntiles, TILE_BLOCKS, 4, 2, 2, 4).transpose(0, 2, 4, 1, 5, 3)
+    return np.ascontiguousarray(t).reshape(-1)
 
 
 def unpack_tiles(tiles, n):
-    t = np.asarray(tiles, np.int16).reshape(-1, 8, TILE_BLOCKS, 8).transpose(0, 2, 1, 3)
-    return np.ascontiguousarray(t.reshape(-1, 64)[:n])
+    t = np.asarray(tiles, np.int16).reshape(-1, 4, 2, TILE_BLOCKS, 4, 2).transpose(0, 3, 1, 5, 2, 4)
+    return np.ascontiguousarray(t).reshape(-1, 64)[:n]
 
 
 class State:

@@ -62,6 +62,7 @@ struct StreamK {
   int cell_end0, cell_end1, cell_end2;  // cumulative loop-filter cell counts per plane
   int qpx, qpy;     // chroma axis decimated (quarter-pel chroma vectors)
   int lf_y0[3], lf_y1[3];  // fragment-row range to filter per plane
+  int debug;        // ablation switches for profiling (THIP_DEBUG env), 0 in production
   PlaneK pl[3];
 };
 
@@ -93,11 +94,18 @@ __device__ __forceinline__ void locate_fragment(const StreamK &S, uint32_t fragi
 
 __device__ __forceinline__ void recon_lane(const StreamK &S, uint32_t slot) {
   const bool active = slot < (uint32_t)S.ncoded;
-  // 1. this lane's eight coefficient rows: 16 B per lane per row, 1 KiB per wave per row
+  // 1. this lane's coefficients: four row pairs x two 16-byte halves; every load of the
+  //    wave is 1 KiB contiguous.  P[j*8+c] = { x[2j][c], x[2j+1][c] }.
   const int4 *tp = S.coeffs + ((size_t)(slot >> 6) * 512 + (slot & 63));
-  int4 rows[8];
+  uint32_t P[32];
 #pragma unroll
-  for (int r = 0; r < 8; r++) rows[r] = tp[r * 64];
+  for (int q = 0; q < 8; q++) {
+    const int4 w = (S.debug & 8) ? make_int4((int)slot, q, 3, 4) : tp[q * 64];
+    P[q * 4 + 0] = (uint32_t)w.x;
+    P[q * 4 + 1] = (uint32_t)w.y;
+    P[q * 4 + 2] = (uint32_t)w.z;
+    P[q * 4 + 3] = (uint32_t)w.w;
+  }
   uint2 cmd = make_uint2(0u, 0u);
   if (active) cmd = S.cmds[slot];
   const uint32_t fragi = cmd.x, flags = cmd.y;
@@ -113,7 +121,7 @@ __device__ __forceinline__ void recon_lane(const StreamK &S, uint32_t slot) {
   uint2 pred[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
-  if (active && refi != THIP_FRAME_SELF) {
+  if (active && refi != THIP_FRAME_SELF && !(S.debug & 2)) {
     const uint8_t *ref = (refi == THIP_FRAME_PREV ? S.prev : S.gold) + off;
     const int dx = (int)(int8_t)(flags >> THIP_CMD_MVX_SHIFT);
     const int dy = (int)(int8_t)(flags >> THIP_CMD_MVY_SHIFT);
@@ -125,14 +133,28 @@ __device__ __forceinline__ void recon_lane(const StreamK &S, uint32_t slot) {
     const bool inside = sx + min(mx2, 0) >= 0 && sx + max(mx2, 0) + 8 <= W &&
                         sy + min(my2, 0) >= 0 && sy + max(my2, 0) + 8 <= H;
     if (inside) {
-      const uint8_t *p1 = ref + (ptrdiff_t)sy * stride + sx;
+      // Both samples of a row lie in the 9 bytes starting at xs, i.e. inside one 12-byte
+      // window aligned down to 4: one DWORD-ALIGNED dwordx3 load per source row and byte
+      // funnel shifts, instead of byte-unaligned loads (which the memory pipeline
+      // serialises).  Vertical half-pel needs 9 source rows, not 16.
+      const int xs = sx + min(mx2, 0);
+      const int xw = xs & ~3;
+      const int offA = sx - xw, offB = sx + mx2 - xw;   // 0..4
+      const int ys = sy + min(my2, 0);
+      const int ra = sy - ys, rb = sy + my2 - ys;        // first source row of each sample: 0 or 1
+      const uint8_t *p1 = ref + (ptrdiff_t)ys * stride + xw;
+      Row12 w[9];
 #pragma unroll
-      for (int r = 0; r < 8; r++) pred[r] = load_row8(p1 + (ptrdiff_t)r * stride);
-      if (two) {
-        const uint8_t *p2 = p1 + (ptrdiff_t)my2 * stride + mx2;
+      for (int r = 0; r < 8; r++) w[r] = load_row12(p1 + (ptrdiff_t)r * stride);
+      w[8] = w[7];
+      if (my2 != 0) w[8] = load_row12(p1 + (ptrdiff_t)8 * stride);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-          const uint2 b = load_row8(p2 + (ptrdiff_t)r * stride);
+      for (int r = 0; r < 8; r++) {
+        const Row12 wa = ra ? w[r + 1] : w[r];
+        pred[r] = extract8(wa, offA);
+        if (two) {
+          const Row12 wb = rb ? w[r + 1] : w[r];
+          const uint2 b = extract8(wb, offB);
           pred[r].x = avg4_trunc(pred[r].x, b.x);
           pred[r].y = avg4_trunc(pred[r].y, b.y);
         }
@@ -140,7 +162,7 @@ __device__ __forceinline__ void recon_lane(const StreamK &S, uint32_t slot) {
     } else {
       // the block reaches into the reference's UMV border: clamp every coordinate
       // (== replicated padding, state.c:770-835)
-#pragma unroll
+#pragma unroll 1
       for (int r = 0; r < 8; r++) {
         const int ya = min(max(sy + r, 0), H - 1);
         const int yb = min(max(sy + my2 + r, 0), H - 1);
@@ -155,41 +177,51 @@ __device__ __forceinline__ void recon_lane(const StreamK &S, uint32_t slot) {
           }
           w[c >> 2] |= (uint32_t)v << (8 * (c & 3));
         }
-        pred[r] = make_uint2(w[0], w[1]);
+        // runtime row index: select into the register array without dynamic indexing
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++)
+          if (rr == r) pred[rr] = make_uint2(w[0], w[1]);
       }
     }
   }
 
-  // 3. residual: DC-only shortcut (state.c:967-975) or inverse DCT (idct.c:301)
-  int v[64];
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const int w4[4] = {rows[r].x, rows[r].y, rows[r].z, rows[r].w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      v[r * 8 + 2 * k] = sx16(w4[k]);
-      v[r * 8 + 2 * k + 1] = w4[k] >> 16;
-    }
-  }
-  const int dcp = v[0];
+  // 3. residual: DC-only shortcut (state.c:967-975) or inverse DCT (idct.c:301), packed
+  //    two int16 per register
+  uint32_t Y[32];
+  const uint32_t dcp = (P[0] & 0xFFFFu) * 0x00010001u;   // {p, p}
   // wave-uniform choice of the cheapest transform that covers every lane
   const bool need_any = __any(active && !dc_only);
-  if (need_any) {
-    idct_mask_by_last_zzi(v, last_zzi);
-    if (__any(active && !dc_only && last_zzi > 10)) idct8x8(v);
-    else idct8x8_rows4(v);
+  if (S.debug & 1) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) Y[i] = P[i];
+  } else if (need_any) {
+    pk_mask_by_last_zzi(P, last_zzi);
+    const bool all_zz10 = !__any(active && !dc_only && last_zzi > 10);
+    pk_idct8x8(P, Y, all_zz10);
   }
   if (dc_only || !need_any) {
 #pragma unroll
-    for (int i = 0; i < 64; i++) v[i] = dcp;
+    for (int i = 0; i < 32; i++) Y[i] = dcp;
   }
 
-  // 4. reconstruct and store (8 B per lane per row, rows of one wave are contiguous
-  //    128-B runs in coded order)
-  if (active) {
+  // 4. reconstruct and store (8 B per lane per row)
+  if (active && (S.debug & 4)) {
+    // ablation: keep the values live with one store
+    uint32_t acc = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const uint2 o = pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]),
+                                   as_pk(Y[r * 4 + 3]), pred[r]);
+      acc ^= o.x ^ o.y;
+    }
+    if (acc == 0x12345678u) S.coded_map[fragi] = 2;
+  } else if (active) {
     uint8_t *dst = S.self + off + (ptrdiff_t)y0 * stride + x0;
 #pragma unroll
-    for (int r = 0; r < 8; r++) store_row8(dst + (ptrdiff_t)r * stride, recon_row(v + r * 8, pred[r]));
+    for (int r = 0; r < 8; r++)
+      store_row8(dst + (ptrdiff_t)r * stride,
+                 pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]),
+                              as_pk(Y[r * 4 + 3]), pred[r]));
     S.coded_map[fragi] = 1;
   }
 }
@@ -370,18 +402,31 @@ struct thip_state {
   int enq_ncoded, enq_nuncoded, enq_frame_type, enq_flimit, enq_active;
   int enq_lf_y0[3], enq_lf_y1[3], enq_lf_any;
   int lf_y0[3], lf_y1[3], lf_rows_custom;
+  int lane;             // library-owned HIP stream this state is bound to, -1 until first use
 };
 
 namespace {
 std::mutex g_mu;
-hipStream_t g_stream = nullptr;
+// Library-owned HIP streams ("lanes").  Every thip_state is bound to one lane for life, so
+// the frames of a stream stay ordered; different lanes let one group's loop filter overlap
+// another group's reconstruction (dependent kernels of one group cannot overlap).
+constexpr int kMaxLanes = 4;
+hipStream_t g_lanes[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+int g_nlanes = 0;
+int g_next_lane = 0;
 int g_profile = 0;
+const int g_debug = getenv("THIP_DEBUG") ? atoi(getenv("THIP_DEBUG")) : 0;
 struct EvPair { hipEvent_t a, b; int kernel; };
 std::vector<EvPair> g_events;
 std::vector<hipEvent_t> g_pool;
 
-int ensure_stream() {
-  if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+int ensure_lanes() {
+  if (g_nlanes) return 0;
+  int n = getenv("THIP_LANES") ? atoi(getenv("THIP_LANES")) : 2;
+  if (n < 1) n = 1;
+  if (n > kMaxLanes) n = kMaxLanes;
+  for (int i = 0; i < n; i++) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[i], hipStreamNonBlocking));
+  g_nlanes = n;
   return 0;
 }
 
@@ -476,7 +521,7 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
   st->nfrags = fro;
   st->frame_bytes = off;
   hipError_t err = hipSuccess;
-  for (int b = 0; b < 3 && err == hipSuccess; b++) err = hipMalloc((void **)&st->frames[b], st->frame_bytes);
+  for (int b = 0; b < 3 && err == hipSuccess; b++) err = hipMalloc((void **)&st->frames[b], st->frame_bytes + 256);  /* +256: aligned 12-byte windows may read 3 bytes past a row end */
   if (err == hipSuccess) err = hipMalloc((void **)&st->coded_map, (size_t)st->nfrags);
   if (err == hipSuccess) err = hipMemset(st->coded_map, 0, (size_t)st->nfrags);
   if (err != hipSuccess) {
@@ -486,6 +531,7 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
   }
   st->ref_idx[0] = st->ref_idx[1] = st->ref_idx[2] = -1;   // state.c:658-663
   st->last_decoded = -1;
+  st->lane = -1;
   *out = st;
   return THIP_OK;
 }
@@ -575,7 +621,7 @@ int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t ds
 }
 
 int thip_synchronize(void) {
-  if (g_stream) HIP_TRY(hipStreamSynchronize(g_stream));
+  for (int i = 0; i < g_nlanes; i++) HIP_TRY(hipStreamSynchronize(g_lanes[i]));
   return THIP_OK;
 }
 
@@ -654,6 +700,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     K.nuncoded = d.nuncoded;
     K.nwg_coded = (d.ncoded + 255) / 256;
     K.flimit2 = 2 * d.flimit;
+    K.debug = g_debug;
     K.qpx = st->hdec;
     K.qpy = st->vdec;
     int cells = 0;
@@ -699,16 +746,43 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
   if (!states || !descs) return THIP_EFAULT;
   if (nstreams < 0) return THIP_EINVAL;
   std::lock_guard<std::mutex> lk(g_mu);
-  hipStream_t s = (hipStream_t)stream;
-  if (!s) {
-    int rc = ensure_stream();
-    if (rc) return rc;
-    s = g_stream;
+  if (stream) {   // caller-owned stream: everything in submission order on it
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < nstreams; i += THIP_MAX_BATCH) {
+      const int n = nstreams - i < THIP_MAX_BATCH ? nstreams - i : THIP_MAX_BATCH;
+      int rc = launch_chunk(states + i, descs + i, n, s, results ? results + i : nullptr);
+      if (rc < 0) return rc;
+    }
+    return THIP_OK;
   }
-  for (int i = 0; i < nstreams; i += THIP_MAX_BATCH) {
-    const int n = nstreams - i < THIP_MAX_BATCH ? nstreams - i : THIP_MAX_BATCH;
-    int rc = launch_chunk(states + i, descs + i, n, s, results ? results + i : nullptr);
-    if (rc < 0) return rc;
+  int rc = ensure_lanes();
+  if (rc) return rc;
+  for (int i = 0; i < nstreams; i++) {
+    if (!states[i]) return THIP_EFAULT;
+    if (states[i]->lane < 0) states[i]->lane = g_next_lane++ % g_nlanes;
+  }
+  // group by lane (order inside a lane preserved), launch chunk by chunk
+  for (int lane = 0; lane < g_nlanes; lane++) {
+    thip_state *ls[THIP_MAX_BATCH];
+    thip_frame_desc ld[THIP_MAX_BATCH];
+    int32_t lr[THIP_MAX_BATCH];
+    int li[THIP_MAX_BATCH];
+    int n = 0;
+    for (int i = 0; i <= nstreams; i++) {
+      if (i < nstreams && states[i]->lane == lane) {
+        ls[n] = states[i];
+        ld[n] = descs[i];
+        li[n] = i;
+        n++;
+      }
+      if (n == THIP_MAX_BATCH || (i == nstreams && n > 0)) {
+        rc = launch_chunk(ls, ld, n, g_lanes[lane], lr);
+        if (rc < 0) return rc;
+        if (results)
+          for (int k = 0; k < n; k++) results[li[k]] = lr[k];
+        n = 0;
+      }
+    }
   }
   return THIP_OK;
 }
@@ -775,16 +849,25 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
   uint32_t flags = (uint32_t)refi | ((uint32_t)last_zzi << THIP_CMD_LAST_ZZI_SHIFT) |
                    ((uint32_t)(uint8_t)(mv & 0xFF) << THIP_CMD_MVX_SHIFT) |
                    ((uint32_t)(uint8_t)((mv >> 8) & 0xFF) << THIP_CMD_MVY_SHIFT);
+  // tile layout (theora_hip.h): 16-byte group q = 2*j+h of the block holds, for columns
+  // c = 4h..4h+3, the int16 pairs { x[2j][c], x[2j+1][c] }
   int16_t *tile = st->h_coeffs + (size_t)(slot >> 6) * (THIP_TILE_BYTES / 2) + (size_t)(slot & 63) * 8;
   if (last_zzi < 2) {
     // state.c:967-975: the only rounded dequantisation of the path
     flags |= THIP_CMD_DC_ONLY;
     const int16_t p = (int16_t)((dct_coeffs[0] * (int32_t)dc_quant + 15) >> 5);
-    for (int r = 0; r < 8; r++) memset(tile + (size_t)r * 512, 0, 16);
+    for (int q = 0; q < 8; q++) memset(tile + (size_t)q * 512, 0, 16);
     tile[0] = p;
   } else {
     dct_coeffs[0] = (int16_t)(dct_coeffs[0] * (int)dc_quant);   // state.c:978
-    for (int r = 0; r < 8; r++) memcpy(tile + (size_t)r * 512, dct_coeffs + r * 8, 16);
+    for (int j = 0; j < 4; j++)
+      for (int h = 0; h < 2; h++) {
+        int16_t *g = tile + (size_t)(2 * j + h) * 512;
+        for (int cc = 0; cc < 4; cc++) {
+          g[2 * cc] = dct_coeffs[(2 * j) * 8 + 4 * h + cc];
+          g[2 * cc + 1] = dct_coeffs[(2 * j + 1) * 8 + 4 * h + cc];
+        }
+      }
   }
   memset(dct_coeffs, 0, 64 * sizeof(int16_t));   // idct.c:245,276,295
   st->h_cmds[2 * (size_t)slot] = (uint32_t)fragi;
@@ -836,8 +919,13 @@ int thip_frame_flush(thip_state *st) {
   if (!st) return THIP_EFAULT;
   if (!st->enq_active) return THIP_EINVAL;
   st->enq_active = 0;
-  int rc = ensure_stream();
+  int rc = ensure_lanes();
   if (rc) return rc;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (st->lane < 0) st->lane = g_next_lane++ % g_nlanes;
+  }
+  hipStream_t g_stream = g_lanes[st->lane];
   const size_t ntiles = ((size_t)st->enq_ncoded + THIP_TILE_BLOCKS - 1) / THIP_TILE_BLOCKS;
   if (st->enq_ncoded) {
     HIP_TRY(hipMemcpyAsync(st->d_cmds, st->h_cmds, (size_t)st->enq_ncoded * 8, hipMemcpyHostToDevice, g_stream));

@@ -117,6 +117,30 @@ __device__ __forceinline__ void store_row8(uint8_t *p, uint2 v) {
   *reinterpret_cast<uint2 *>(p) = v;
 }
 
+// 12 bytes of a reference row starting at a 4-byte-aligned address
+struct Row12 {
+  uint32_t a, b, c;
+};
+__device__ __forceinline__ Row12 load_row12(const uint8_t *p) {
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(p);   // p is 4-byte aligned
+  Row12 r;
+  r.a = q[0];
+  r.b = q[1];
+  r.c = q[2];
+  return r;
+}
+// bytes off..off+7 of the window, off in 0..4 (v_alignbyte_b32 funnel shifts)
+__device__ __forceinline__ uint2 extract8(Row12 w, int off) {
+  uint2 o;
+  o.x = __builtin_amdgcn_alignbyte(w.b, w.a, (uint32_t)off);
+  o.y = __builtin_amdgcn_alignbyte(w.c, w.b, (uint32_t)off);
+  if (off == 4) {   // alignbyte only looks at the low two bits of the shift
+    o.x = w.b;
+    o.y = w.c;
+  }
+  return o;
+}
+
 // clamp255(res[k] + pred byte k) for the eight pixels of a row
 __device__ __forceinline__ uint2 recon_row(const int *res, uint2 pred) {
   uint2 o;
@@ -155,6 +179,162 @@ __device__ __forceinline__ int lflim(int R, int L2) {
   const int a = abs(R);
   const int m = min(a, max(L2 - a, 0));
   return R < 0 ? -m : m;
+}
+
+
+// =====================================================================================
+// Packed 16-bit formulation: every 32-bit register carries TWO independent int16 values
+// (two rows in the row pass, two columns in the column pass), the way the reference's
+// SSE2 backend carries eight (lib/x86/sse2idct.c).  All additions may wrap at 16 bits:
+// between two of the reference's (ogg_int16_t) casts only +/- happen, so arithmetic
+// mod 2^16 reaches the same 16-bit results as idct.c's int32 arithmetic.  The only
+// non-linear step, C*x>>16, is done on each half in 32 bits and repacked.
+// =====================================================================================
+typedef short pk16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ pk16 as_pk(uint32_t u) { return __builtin_bit_cast(pk16, u); }
+__device__ __forceinline__ uint32_t as_u32(pk16 p) { return __builtin_bit_cast(uint32_t, p); }
+
+// {C*lo>>16, C*hi>>16}: two 24-bit multiplies and one byte permute that keeps the upper
+// halves of both products (idct.c:35-48 for each half).
+__device__ __forceinline__ pk16 pk_q16(int c, pk16 x) {
+  const int pl = c * (int)x.x;
+  const int ph = c * (int)x.y;
+  return as_pk(__builtin_amdgcn_perm((uint32_t)ph, (uint32_t)pl, 0x07060302u));
+}
+
+// 1-D inverse DCT on eight packed registers, in place -- lib/idct.c:30-81 on both halves.
+__device__ __forceinline__ void pk_idct8(pk16 &x0, pk16 &x1, pk16 &x2, pk16 &x3, pk16 &x4, pk16 &x5,
+                                         pk16 &x6, pk16 &x7) {
+  pk16 t0 = pk_q16(kC4, x0 + x4);
+  pk16 t1 = pk_q16(kC4, x0 - x4);
+  pk16 t2 = pk_q16(kC6, x2) - pk_q16(kC2, x6);
+  pk16 t3 = pk_q16(kC2, x2) + pk_q16(kC6, x6);
+  pk16 t4 = pk_q16(kC7, x1) - pk_q16(kC1, x7);
+  pk16 t5 = pk_q16(kC3, x5) - pk_q16(kC5, x3);
+  pk16 t6 = pk_q16(kC5, x5) + pk_q16(kC3, x3);
+  pk16 t7 = pk_q16(kC1, x1) + pk_q16(kC7, x7);
+  pk16 r;
+  r = t4 + t5; t5 = pk_q16(kC4, t4 - t5); t4 = r;
+  r = t7 + t6; t6 = pk_q16(kC4, t7 - t6); t7 = r;
+  r = t0 + t3; t3 = t0 - t3; t0 = r;
+  r = t1 + t2; t2 = t1 - t2; t1 = r;
+  r = t6 + t5; t5 = t6 - t5; t6 = r;
+  x0 = t0 + t7;
+  x1 = t1 + t6;
+  x2 = t2 + t5;
+  x3 = t3 + t4;
+  x4 = t3 - t4;
+  x5 = t2 - t5;
+  x6 = t1 - t6;
+  x7 = t0 - t7;
+}
+
+// Same transform when inputs 4..7 are zero (lib/idct.c:92-130 on both halves).
+__device__ __forceinline__ void pk_idct8_first4(pk16 &x0, pk16 &x1, pk16 &x2, pk16 &x3, pk16 &x4,
+                                                pk16 &x5, pk16 &x6, pk16 &x7) {
+  pk16 t0 = pk_q16(kC4, x0);
+  pk16 t2 = pk_q16(kC6, x2);
+  pk16 t3 = pk_q16(kC2, x2);
+  pk16 t4 = pk_q16(kC7, x1);
+  pk16 t6 = pk_q16(kC3, x3);
+  pk16 t5 = -pk_q16(kC5, x3);
+  pk16 t7 = pk_q16(kC1, x1);
+  pk16 r;
+  r = t4 + t5; t5 = pk_q16(kC4, t4 - t5); t4 = r;
+  r = t7 + t6; t6 = pk_q16(kC4, t7 - t6); t7 = r;
+  pk16 t1 = t0 + t2;
+  t2 = t0 - t2;
+  r = t0 + t3; t3 = t0 - t3; t0 = r;
+  r = t6 + t5; t5 = t6 - t5; t6 = r;
+  x0 = t0 + t7;
+  x1 = t1 + t6;
+  x2 = t2 + t5;
+  x3 = t3 + t4;
+  x4 = t3 - t4;
+  x5 = t2 - t5;
+  x6 = t1 - t6;
+  x7 = t0 - t7;
+}
+
+// (y+8)>>4 on int16 without the 16-bit overflow of y+8: ((y>>3)+1)>>1  (idct.c:243)
+__device__ __forceinline__ pk16 pk_descale(pk16 y) { return ((y >> 3) + (short)1) >> 1; }
+
+// two predictor bytes (k, k+1 of a packed word) -> two int16
+__device__ __forceinline__ pk16 pk_bytes01(uint32_t w) { return as_pk(__builtin_amdgcn_perm(0u, w, 0x0c010c00u)); }
+__device__ __forceinline__ pk16 pk_bytes23(uint32_t w) { return as_pk(__builtin_amdgcn_perm(0u, w, 0x0c030c02u)); }
+
+// clamp255 of two int16 -> two bytes in bits 0..15 (v_sat_pk_u8_i16)
+__device__ __forceinline__ uint32_t sat_pk_u8(pk16 v) {
+  uint32_t r;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(as_u32(v)));
+  return r;
+}
+
+// One row of 8 pixels: OC_CLAMP255(residue + predictor), fragment.c:54,64,76.  The add
+// saturates at 16 bits so a residue near +32767 still clamps to 255 like the int sum.
+__device__ __forceinline__ uint2 pk_recon_row(pk16 r01, pk16 r23, pk16 r45, pk16 r67, uint2 pred) {
+  const pk16 s01 = __builtin_elementwise_add_sat(r01, pk_bytes01(pred.x));
+  const pk16 s23 = __builtin_elementwise_add_sat(r23, pk_bytes23(pred.x));
+  const pk16 s45 = __builtin_elementwise_add_sat(r45, pk_bytes01(pred.y));
+  const pk16 s67 = __builtin_elementwise_add_sat(r67, pk_bytes23(pred.y));
+  uint2 o;
+  o.x = sat_pk_u8(s01) | (sat_pk_u8(s23) << 16);
+  o.y = sat_pk_u8(s45) | (sat_pk_u8(s67) << 16);
+  return o;
+}
+
+// Block held as P[j][c] = { x[2j][c], x[2j+1][c] } (row pairs): zero what the variant
+// selected by last_zzi does not read (idct.c:327-329, :245, :276).
+__device__ __forceinline__ void pk_mask_by_last_zzi(uint32_t P[32], int last_zzi) {
+  const bool c3 = last_zzi <= 3, c10 = last_zzi <= 10;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int rlo = 2 * j, rhi = 2 * j + 1;
+      const uint32_t m10 = ((rlo + c <= 3) ? 0x0000FFFFu : 0u) | ((rhi + c <= 3) ? 0xFFFF0000u : 0u);
+      const bool lo3 = (rlo == 0 && c <= 1), hi3 = (rhi == 1 && c == 0);
+      const uint32_t m3 = (lo3 ? 0x0000FFFFu : 0u) | (hi3 ? 0xFFFF0000u : 0u);
+      const uint32_t m = c3 ? m3 : (c10 ? m10 : 0xFFFFFFFFu);
+      if (m10 != 0xFFFFFFFFu || m3 != 0xFFFFFFFFu) P[j * 8 + c] &= m;
+    }
+}
+
+// Full 2-D transform.  In: P[j*8+c] = {x[2j][c], x[2j+1][c]}.  Out: Y[r*4+k] =
+// {y[r][2k], y[r][2k+1]} (residue pairs along a row), descaled.  rows4: rows 4..7 of the
+// input are known to be zero for every lane of the wave.
+__device__ __forceinline__ void pk_idct8x8(const uint32_t P[32], uint32_t Y[32], bool rows4) {
+  pk16 R[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) R[i] = as_pk(P[i]);
+  pk_idct8(R[0], R[1], R[2], R[3], R[4], R[5], R[6], R[7]);
+  pk_idct8(R[8], R[9], R[10], R[11], R[12], R[13], R[14], R[15]);
+  if (!rows4) {
+    pk_idct8(R[16], R[17], R[18], R[19], R[20], R[21], R[22], R[23]);
+    pk_idct8(R[24], R[25], R[26], R[27], R[28], R[29], R[30], R[31]);
+  }
+  // 2x2 transposes: row pairs -> column pairs.  Q[r*4+k] = {R[r][2k], R[r][2k+1]}
+  pk16 Q[32];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t a = as_u32(R[j * 8 + 2 * k]), b = as_u32(R[j * 8 + 2 * k + 1]);
+      Q[(2 * j) * 4 + k] = as_pk(__builtin_amdgcn_perm(b, a, 0x05040100u));
+      Q[(2 * j + 1) * 4 + k] = as_pk(__builtin_amdgcn_perm(b, a, 0x07060302u));
+    }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (rows4)
+      pk_idct8_first4(Q[0 * 4 + k], Q[1 * 4 + k], Q[2 * 4 + k], Q[3 * 4 + k], Q[4 * 4 + k], Q[5 * 4 + k],
+                      Q[6 * 4 + k], Q[7 * 4 + k]);
+    else
+      pk_idct8(Q[0 * 4 + k], Q[1 * 4 + k], Q[2 * 4 + k], Q[3 * 4 + k], Q[4 * 4 + k], Q[5 * 4 + k],
+               Q[6 * 4 + k], Q[7 * 4 + k]);
+  }
+#pragma unroll
+  for (int i = 0; i < 32; i++) Y[i] = as_u32(pk_descale(Q[i]));
 }
 
 }  // namespace thip
