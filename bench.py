@@ -86,7 +86,7 @@ def main():
             host_frames0 = frames             # kept for the CPU baseline / parity sample
         row = []
         for f in frames:
-            d, ka = synth.upload_frame(synth.pack_frame(f))
+            d, ka = synth.upload_frame(synth.pack_frame(geom, f))
             keep.append(ka)
             row.append(d)
         descs.append(row)
@@ -205,11 +205,11 @@ def main():
         }
         if profiling and kms[0] > 0:
             gbs = steps_b_alg / (kms[0] * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_recon", "achieved": round(gbs, 1),
+            out["roofline"] = {"bound": "hbm", "kernel": "k_frame", "achieved": round(gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                "traffic": None,
                                "avg_launch_us": round(1e3 * kms[0] / max(launches[0], 1), 3),
-                               "loopfilter_avg_launch_us": round(1e3 * kms[1] / max(launches[1], 1), 3),
+                               "seam_avg_launch_us": round(1e3 * kms[1] / max(launches[1], 1), 3),
                                "alg_bytes_per_launch": int(steps_b_alg / max(launches[0], 1)),
                                "measured": "HIP events around every launch, separate instrumented pass of the same "
                                            "%d steps (ms_per_step there: %.5f)" % (args.steps, 1e3 * elapsed_b / args.steps)}

@@ -76,47 +76,70 @@ int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *hos
 int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t dst_stride[3]);
 
 /* ------------------------------------------------------------------------------------
- * Fragment command stream: what oc_dec_frags_recon_mcu_plane (decode.c:1511-1607)
- * hands to oc_state_frag_recon / oc_frag_copy_list for one frame, laid out for HBM.
- *
- *  cmds     one 8-byte record per CODED fragment, in coded order (state.h:423-426):
- *             word0 = fragment index (raster, Y then Cb then Cr, state.h:244-269)
- *             word1 = refi        bits 0-1   THIP_FRAME_* (SELF == intra, state.h:215-217)
- *                     dc_only     bit  2     last_zzi<2: coefficient [0] already holds
- *                                            p=(dc*dc_quant+15)>>5   (state.c:967-975)
- *                     last_zzi    bits 8-14  0..64 (idct.c:301-330 picks its variant on it)
- *                     mv x, mv y  bits 16-23, 24-31 signed (oc_mv, state.h:232-240)
- *  coeffs   dequantised int16 coefficients, DC included ((int16)(dc*dc_quant),
- *           state.c:978).  "Tile" layout chosen by this backend (cf. the per-backend
- *           dct_fzig_zag table, state.h:374-376, and the transposed tables of
- *           x86state.c:44-64): slot i (= position in cmds) lives in tile i/64, lane i%64.
- *           A block is eight 16-byte groups; group q = 2*j+h (j = row pair 0..3, h = column
- *           half 0..1) sits at  tile*8192 + q*1024 + lane*16  and holds, for columns
- *           c = 4h..4h+3, the int16 pairs { x[2j][c], x[2j+1][c] } (x natural order,
- *           row-major).  ceil(ncoded/64) whole tiles.
- *  uncoded  fragment indices copied PREV->SELF (oc_frag_copy_list, fragment.c:37)
- * Every fragment of the frame must appear in exactly one of the two lists.
+ * Work tiles.  The device walks a frame in the reference's CODED ORDER (state.c:123-190):
+ * a tile is 4 consecutive super blocks of one super-block row of one plane -- 16x4
+ * fragments, 128x32 pixels, one wavefront -- and lane = 16*(super block within the tile) + (position of the
+ * fragment on the 4x4 Hilbert curve, state.c:134-139).  Tiles are numbered plane by plane,
+ * super-block row by super-block row, left to right.  Lanes that fall outside the plane
+ * (ragged right/top edge) exist in the arrays and are ignored.
  * ---------------------------------------------------------------------------------- */
-#define THIP_CMD_REFI_MASK 0x3u
-#define THIP_CMD_DC_ONLY 0x4u
-#define THIP_CMD_LAST_ZZI_SHIFT 8
-#define THIP_CMD_MVX_SHIFT 16
-#define THIP_CMD_MVY_SHIFT 24
-#define THIP_TILE_BLOCKS 64
-#define THIP_TILE_BYTES 8192
+#define THIP_TILE_FRAGS 64
+typedef struct thip_tile_geom {
+  int32_t tiles_x[3], tiles_y[3]; /* tiles across / super-block rows, per plane */
+  int32_t tile_off[3];            /* index of the plane's first tile */
+  int32_t ntiles;
+} thip_tile_geom;
+int thip_state_get_tiles(const thip_state *st, thip_tile_geom *out);
+/* Position (tile*64 + lane) of raster fragment index fragi in the tile-ordered arrays. */
+int64_t thip_state_frag_pos(const thip_state *st, int64_t fragi);
+
+/* ------------------------------------------------------------------------------------
+ * Fragment command stream: what oc_dec_frags_recon_mcu_plane (decode.c:1511-1607) hands to
+ * oc_state_frag_recon / oc_frag_copy_list for one frame, laid out for HBM.
+ *
+ *  frag_info  two 32-bit words per tile position (ntiles*64 positions):
+ *               word0  coded       bit  0     0 = uncoded: copied PREV->SELF (fragment.c:37)
+ *                      refi        bits 1-2   THIP_FRAME_* (SELF == intra, state.h:215-217)
+ *                      dc_only     bit  3     last_zzi<2 (state.c:967-975)
+ *                      last_zzi    bits 8-14  0..64 (idct.c:301-330 picks its variant on it)
+ *                      mv x, mv y  bits 16-23, 24-31 signed (oc_mv, state.h:232-240)
+ *               word1  dc_only blocks: p=(dc*dc_quant+15)>>5 as int16 in bits 0-15
+ *                      (state.c:972); otherwise unused
+ *  coeffs     one 128-byte slot per coded fragment that is NOT dc_only, slots numbered in
+ *             tile/lane order (== the order the reference reconstructs them in).  Slot s
+ *             lives in group-of-64 s/64, lane s%64: the block is eight 16-byte pieces, piece
+ *             q = 2*j+h (j = row pair 0..3, h = column half 0..1) at
+ *             (s/64)*8192 + q*1024 + (s%64)*16, holding for columns c = 4h..4h+3 the int16
+ *             pairs { x[2j][c], x[2j+1][c] } (x = dequantised coefficients, natural order,
+ *             x[0][0] = (int16)(dc*dc_quant), state.c:978).  This is the backend's
+ *             counterpart of the per-backend dct_fzig_zag table (state.h:374-376,
+ *             x86state.c:44-64).  Allocate whole groups of 64 slots.
+ *  tile_slot0 per tile: slot number of its first non-dc_only coded fragment; the kernel
+ *             finds the others with a ballot / prefix count over the tile's lanes.
+ * ---------------------------------------------------------------------------------- */
+#define THIP_INFO_CODED 0x1u
+#define THIP_INFO_REFI_SHIFT 1
+#define THIP_INFO_DC_ONLY 0x8u
+#define THIP_INFO_LAST_ZZI_SHIFT 8
+#define THIP_INFO_MVX_SHIFT 16
+#define THIP_INFO_MVY_SHIFT 24
+#define THIP_SLOT_GROUP 64
+#define THIP_SLOT_GROUP_BYTES 8192
 
 typedef struct thip_frame_desc {
-  const uint32_t *cmds;    /* device */
-  const int16_t *coeffs;   /* device */
-  const uint32_t *uncoded; /* device */
-  int32_t ncoded, nuncoded;
-  int32_t frame_type; /* THIP_INTRA_FRAME / THIP_INTER_FRAME */
-  int32_t flimit;     /* loop_filter_limits[qis[0]], 0 = filter off (decode.c:1369-1371) */
+  const uint32_t *frag_info;  /* device, 2*64*ntiles words */
+  const int16_t *coeffs;      /* device, ceil(nslots/64) groups of 8192 bytes */
+  const uint32_t *tile_slot0; /* device, ntiles words */
+  int32_t nslots;             /* coded fragments carrying coefficients */
+  int32_t ncoded;             /* coded fragments in total; 0 => TH_DUPFRAME (decode.c:2764) */
+  int32_t frame_type;         /* THIP_INTRA_FRAME / THIP_INTER_FRAME */
+  int32_t flimit;             /* loop_filter_limits[qis[0]], 0 = filter off (decode.c:1369-1371) */
 } thip_frame_desc;
 
 /* One frame of each of nstreams independent streams, all inputs resident in HBM:
    reconstruct coded fragments (oc_state_frag_recon, state.c:959), copy uncoded ones
-   (fragment.c:37), run the in-loop filter over the whole frame (state.c:1055) and rotate
+   (fragment.c:37), run the in-loop filter over the whole frame (state.c:1055; fused into
+   the reconstruction kernel except for the cells on strip seams) and rotate
    each stream's reference ring (decode.c:2790-2794, 2947-2962).  Asynchronous on
    `stream` (a hipStream_t, or NULL for the library's own stream).
    results[i] (optional, host) receives 0 or THIP_DUPFRAME per stream. */
@@ -205,8 +228,8 @@ int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n);
  * Measurement support for bench.py: HIP-event timing of the kernels of
  * thip_decode_frames on the stream they run on.
  * ---------------------------------------------------------------------------------- */
-#define THIP_KERNEL_RECON 0
-#define THIP_KERNEL_LOOPFILTER 1
+#define THIP_KERNEL_FRAME 0 /* k_frame: recon + copy + loop filter inside strips */
+#define THIP_KERNEL_SEAM 1  /* k_seam: loop-filter cells on strip seams and frame edges */
 #define THIP_NKERNELS 2
 int thip_profile_enable(int on);
 /* Sums since the last reset: launches and milliseconds per kernel (synchronises). */

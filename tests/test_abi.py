@@ -69,3 +69,20 @@ def test_product_never_imports_oracle():
                     if re.search(r"^\s*(import|from)\s+oracle\b|oracle/|theora_oracle", txt, flags=re.M):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_tile_positions_match_numpy_geometry():
+    """thip_state_frag_pos (host table of the library) == the packer's numpy formula
+    (thip_state_create allocates device frames, hence the gpu mark)."""
+    import theora_amd
+    from theora_amd import synth
+    for (w, h, fmt) in [(176, 144, 0), (80, 112, 2), (64, 48, 3), (1040, 16, 0)]:
+        st = theora_amd.State(w, h, fmt)
+        g = synth.Geometry(w, h, fmt)
+        assert st.ntiles == g.ntiles and st.tile_off == g.tile_off
+        for f in list(range(0, g.nfrags, max(1, g.nfrags // 97))) + [g.nfrags - 1]:
+            assert st.frag_pos(f) == g.frag_pos[f]

@@ -51,7 +51,7 @@ def test_start_on_inter_frame_uses_grey_dummy(hip):
     for f in range(3):
         fr = synth.gen_frame(geom, rng, hip.INTER_FRAME, "mixed")
         util.oracle_apply(ost, fr)
-        desc, ka = synth.upload_frame(synth.pack_frame(fr))
+        desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
         hip.decode_frames([gst], [desc])
         assert not util.planes_equal(ost, gst)
 
@@ -64,7 +64,7 @@ def test_dup_frame_leaves_state_alone(hip):
     gst = hip.State(w, h, PF_420)
     fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME, "mixed")
     util.oracle_apply(ost, fr)
-    desc, ka = synth.upload_frame(synth.pack_frame(fr))
+    desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
     hip.decode_frames([gst], [desc])
     before = [gst.ref_idx(k) for k in range(3)]
     empty = dict(fr)
@@ -72,7 +72,7 @@ def test_dup_frame_leaves_state_alone(hip):
                  uncoded_fragis=geom.coded_order[::-1].copy(), coeffs=np.zeros((0, 64), np.int16),
                  last_zzi=np.zeros(0, np.uint8), dc_quant=np.zeros(0, np.uint16))
     assert util.oracle_apply(ost, empty) == 1
-    desc2, ka2 = synth.upload_frame(synth.pack_frame(empty))
+    desc2, ka2 = synth.upload_frame(synth.pack_frame(geom, empty))
     assert hip.decode_frames([gst], [desc2]) == [hip.DUPFRAME]
     assert before == [gst.ref_idx(k) for k in range(3)]
     assert not util.planes_equal(ost, gst)
@@ -91,7 +91,7 @@ def test_batched_streams(hip):
         for i in range(len(sizes)):
             fr = synth.gen_frame(geoms[i], rngs[i], hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "mixed")
             util.oracle_apply(osts[i], fr)
-            d, ka = synth.upload_frame(synth.pack_frame(fr))
+            d, ka = synth.upload_frame(synth.pack_frame(geoms[i], fr))
             descs.append(d)
             keep.append(ka)
         hip.decode_frames(gsts, descs)
@@ -107,7 +107,7 @@ def test_ycbcr_out_is_top_down(hip):
     gst = hip.State(w, h, PF_420)
     fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME, "mixed")
     util.oracle_apply(ost, fr)
-    desc, ka = synth.upload_frame(synth.pack_frame(fr))
+    desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
     hip.decode_frames([gst], [desc])
     outs = gst.ycbcr_out()
     for pli in range(3):
@@ -126,6 +126,6 @@ def test_parity_check_has_teeth(hip):
     util.oracle_apply(ost, fr)
     wrong = dict(fr)
     wrong["flimit"] = 14
-    desc, ka = synth.upload_frame(synth.pack_frame(wrong))
+    desc, ka = synth.upload_frame(synth.pack_frame(geom, wrong))
     hip.decode_frames([gst], [desc])
     assert util.planes_equal(ost, gst), "comparison failed to notice a different filter limit"

@@ -41,7 +41,7 @@ def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, e
         if enqueue:
             rc_g = enqueue_frame(theora_amd, gst, geom, fr)
         else:
-            desc, ka = synth.upload_frame(synth.pack_frame(fr))
+            desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
             keep.append(ka)
             rc_g = theora_amd.decode_frames([gst], [desc])[0]
         assert rc_o == rc_g, (f, rc_o, rc_g)

@@ -12,7 +12,10 @@ import numpy as np
 
 from . import _lib
 from ._lib import (DUPFRAME, FRAME_GOLD, FRAME_PREV, FRAME_SELF, INTER_FRAME, INTRA_FRAME,  # noqa: F401
-                   MAX_BATCH, TILE_BLOCKS, TILE_BYTES, FrameDesc, PlaneGeom, TheoraHipError)
+                   MAX_BATCH, SLOT_GROUP, SLOT_GROUP_BYTES, TILE_FRAGS, FrameDesc, PlaneGeom, TheoraHipError,
+                   TileGeom)
+
+TILE_BLOCKS = SLOT_GROUP   # slots per coefficient group
 
 PF_420, PF_422, PF_444 = 0, 2, 3
 
@@ -33,15 +36,19 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------
 # host-side packing of a frame's fragment command stream (layout of include/theora_hip.h)
 # ---------------------------------------------------------------------------------------
-def cmd_words(fragis, refi, last_zzi, mvx, mvy):
-    """[n,2] uint32 command records; dc_only is derived from last_zzi<2 (state.c:967)."""
-    fragis = np.asarray(fragis, np.uint32)
+def info_words(npos, pos, refi, last_zzi, mvx, mvy, dc_p):
+    """[npos,2] uint32 frag_info array (include/theora_hip.h): coded fragments at tile
+    positions `pos`; every other position stays 0 (uncoded / outside the plane).  dc_p is the
+    pre-rounded DC value of the DC-only fragments (ignored for the others)."""
+    out = np.zeros((npos, 2), np.uint32)
     lz = np.asarray(last_zzi, np.uint32)
-    w1 = (np.asarray(refi, np.uint32) & 3) | (lz << 8)
-    w1 |= np.where(lz < 2, np.uint32(_lib.CMD_DC_ONLY), np.uint32(0))
-    w1 |= (np.asarray(mvx, np.int32).astype(np.uint32) & 0xFF) << 16
-    w1 |= (np.asarray(mvy, np.int32).astype(np.uint32) & 0xFF) << 24
-    return np.ascontiguousarray(np.stack([fragis, w1.astype(np.uint32)], axis=1))
+    w0 = np.uint32(_lib.INFO_CODED) | ((np.asarray(refi, np.uint32) & 3) << 1) | (lz << 8)
+    w0 |= np.where(lz < 2, np.uint32(_lib.INFO_DC_ONLY), np.uint32(0))
+    w0 |= (np.asarray(mvx, np.int32).astype(np.uint32) & 0xFF) << 16
+    w0 |= (np.asarray(mvy, np.int32).astype(np.uint32) & 0xFF) << 24
+    out[pos, 0] = w0
+    out[pos, 1] = np.where(lz < 2, np.asarray(dc_p, np.int32).astype(np.uint32) & 0xFFFF, 0)
+    return out
 
 
 def dequant_dc(coeffs, last_zzi, dc_quant):
@@ -58,7 +65,7 @@ def dequant_dc(coeffs, last_zzi, dc_quant):
 
 def pack_tiles(coeffs):
     """[n,64] natural-order int16 blocks -> the backend's tile layout (int16, flat); see
-    include/theora_hip.h: group q=2j+h of block i at tile(i//64)*4096 + q*512 + (i%64)*8
+    include/theora_hip.h: group q=2j+h of slot i at group(i//64)*4096 + q*512 + (i%64)*8
     int16s, holding {x[2j][c], x[2j+1][c]} for c=4h..4h+3."""
     co = np.asarray(coeffs, np.int16).reshape(-1, 8, 8)
     n = co.shape[0]
@@ -91,6 +98,13 @@ class State:
         self.nfrags = nfrags.value
         self.frame_bytes = fbytes.value
         self.frame_width, self.frame_height, self.pixel_fmt = frame_width, frame_height, pixel_fmt
+        tg = TileGeom()
+        _lib.check(self._L.thip_state_get_tiles(h, C.byref(tg)), "get_tiles")
+        self.tiles_x, self.tiles_y, self.tile_off = list(tg.tiles_x), list(tg.tiles_y), list(tg.tile_off)
+        self.ntiles = tg.ntiles
+
+    def frag_pos(self, fragi):
+        return self._L.thip_state_frag_pos(self._h, int(fragi))
 
     @property
     def handle(self):
@@ -188,8 +202,8 @@ def synchronize():
     _lib.check(_lib.load().thip_synchronize(), "thip_synchronize")
 
 
-def make_desc(cmds_dev, coeffs_dev, uncoded_dev, ncoded, nuncoded, frame_type, flimit):
-    return FrameDesc(_ptr(cmds_dev), _ptr(coeffs_dev), _ptr(uncoded_dev), ncoded, nuncoded, frame_type, flimit)
+def make_desc(info_dev, coeffs_dev, slot0_dev, nslots, ncoded, frame_type, flimit):
+    return FrameDesc(_ptr(info_dev), _ptr(coeffs_dev), _ptr(slot0_dev), nslots, ncoded, frame_type, flimit)
 
 
 def profile_enable(on):

@@ -13,9 +13,10 @@ OK, EFAULT, EINVAL, EIMPL, DUPFRAME = 0, -1, -10, -23, 1
 FRAME_GOLD, FRAME_PREV, FRAME_SELF = 0, 1, 2
 INTRA_FRAME, INTER_FRAME = 0, 1
 MAX_BATCH = 8
-TILE_BLOCKS, TILE_BYTES = 64, 8192
-CMD_DC_ONLY = 0x4
-KERNEL_RECON, KERNEL_LOOPFILTER, NKERNELS = 0, 1, 2
+TILE_FRAGS = 64
+SLOT_GROUP, SLOT_GROUP_BYTES = 64, 8192
+INFO_CODED, INFO_DC_ONLY = 0x1, 0x8
+KERNEL_FRAME, KERNEL_SEAM, NKERNELS = 0, 1, 2
 
 ENC_OPS = dict(sad=0, sad_thresh=1, sad2_thresh=2, intra_sad=3, satd=4, satd2=5, intra_satd=6, ssd=7)
 
@@ -27,9 +28,14 @@ class PlaneGeom(C.Structure):
 
 
 class FrameDesc(C.Structure):
-    _fields_ = [("cmds", C.c_void_p), ("coeffs", C.c_void_p), ("uncoded", C.c_void_p),
-                ("ncoded", C.c_int32), ("nuncoded", C.c_int32), ("frame_type", C.c_int32),
+    _fields_ = [("frag_info", C.c_void_p), ("coeffs", C.c_void_p), ("tile_slot0", C.c_void_p),
+                ("nslots", C.c_int32), ("ncoded", C.c_int32), ("frame_type", C.c_int32),
                 ("flimit", C.c_int32)]
+
+
+class TileGeom(C.Structure):
+    _fields_ = [("tiles_x", C.c_int32 * 3), ("tiles_y", C.c_int32 * 3), ("tile_off", C.c_int32 * 3),
+                ("ntiles", C.c_int32)]
 
 
 class TheoraHipError(RuntimeError):
@@ -42,6 +48,8 @@ SYMBOLS = [
     ("thip_state_create", _I, [C.POINTER(_P), _I, _I, _I]),
     ("thip_state_free", None, [_P]),
     ("thip_state_get_geom", _I, [_P, C.POINTER(PlaneGeom), C.POINTER(_I64), C.POINTER(_I64)]),
+    ("thip_state_get_tiles", _I, [_P, C.POINTER(TileGeom)]),
+    ("thip_state_frag_pos", _I64, [_P, _I64]),
     ("thip_state_ref_idx", _I, [_P, _I]),
     ("thip_state_set_ref_idx", _I, [_P, _I, _I, _I]),
     ("thip_state_frame_ptr", _P, [_P, _I]),

@@ -1,16 +1,27 @@
 // thip_decode.hip -- frame-scope reconstruction path for gfx950 (MI355X).
 //
-// Kernels (one 8x8 block per lane, 64-wide wavefronts, 256-thread workgroups):
-//   k_recon       K1+K2: coded fragments  -> dequantised coeffs -> iDCT -> predictor -> pixels
-//                        uncoded fragments -> 8x8 copy PREV->SELF          (state.c:959, fragment.c:37)
-//   k_loopfilter  K3:    whole-frame in-loop deblocking, one 8x8 "corner cell" per lane
-//                                                                         (state.c:1055-1105)
-// K4 (UMV border fill, state.c:770-835) does not exist here: device frames are unpadded
-// and motion-compensated reads clamp their coordinates, which is bit-identical.
+// Two kernels per batch of frames (one 8x8 block per lane, wave64, 256-thread workgroups):
 //
-// Host side (C ABI in include/theora_hip.h): stream state = three device frames + ring,
-// batched launch over up to THIP_MAX_BATCH independent streams, pinned staging for the
-// one-fragment-at-a-time vtable slots.
+//   k_frame  A workgroup owns a SEGMENT of a strip: a few consecutive tiles (16 super
+//            blocks = 64x4 fragments = 512x32 pixels each) of one super-block row of one
+//            plane, and walks them left to right.  Per tile: every lane takes one fragment in
+//            coded order (super block by super block, Hilbert inside), finds its coefficient
+//            slot with a ballot/prefix count over the coded mask, runs dequantised
+//            coefficients -> iDCT -> predictor -> pixels (state.c:959, idct.c:301,
+//            fragment.c:49-80) or copies the fragment from PREV (fragment.c:37), and puts the
+//            8x8 result into an LDS image of the tile.  The in-loop filter (state.c:1055)
+//            then runs on that LDS image for every filter cell that lies inside the strip,
+//            and the tile is streamed out to HBM once.
+//   k_seam   The remaining filter cells -- those on the horizontal seams between strips,
+//            on the few vertical seams between segments and on the frame's top/bottom edge
+//            -- directly on the frame in HBM (a quarter of the rows).
+//
+// K4 (UMV border fill, state.c:770-835) does not exist: device frames are unpadded and
+// motion-compensated reads clamp their coordinates, which is bit-identical.
+//
+// Host side (C ABI, include/theora_hip.h): stream state = three device frames + ring,
+// batched launch over up to THIP_MAX_BATCH independent streams per kernel, pinned staging
+// for the one-fragment-at-a-time vtable slots.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -36,33 +47,50 @@ using namespace thip;
   } while (0)
 
 // ---------------------------------------------------------------------------------------
-// kernel arguments
+// geometry shared by host and device
 // ---------------------------------------------------------------------------------------
+// (row, col) of the h-th block on the 4x4 Hilbert curve of a super block, the order of
+// coded_fragis inside a super block (state.c:134-139), two bits per entry.
+constexpr uint32_t kHilbRow = 0u | 0u << 2 | 1u << 4 | 1u << 6 | 2u << 8 | 3u << 10 | 3u << 12 | 2u << 14 |
+                              2u << 16 | 3u << 18 | 3u << 20 | 2u << 22 | 1u << 24 | 1u << 26 | 0u << 28 | 0u << 30;
+constexpr uint32_t kHilbCol = 0u | 1u << 2 | 1u << 4 | 0u << 6 | 0u << 8 | 0u << 10 | 1u << 12 | 1u << 14 |
+                              2u << 16 | 2u << 18 | 3u << 20 | 3u << 22 | 3u << 24 | 2u << 26 | 2u << 28 | 3u << 30;
+// inverse: Hilbert index of (row, col), four bits per entry, entry = row*4+col
+constexpr uint64_t kHilbInv = 0ull | 1ull << 4 | 14ull << 8 | 15ull << 12 |      // row 0
+                              3ull << 16 | 2ull << 20 | 13ull << 24 | 12ull << 28 |   // row 1
+                              4ull << 32 | 7ull << 36 | 8ull << 40 | 11ull << 44 |    // row 2
+                              5ull << 48 | 6ull << 52 | 9ull << 56 | 10ull << 60;     // row 3
+
+__host__ __device__ inline int hilb_row(int h) { return (int)((kHilbRow >> (2 * h)) & 3u); }
+__host__ __device__ inline int hilb_col(int h) { return (int)((kHilbCol >> (2 * h)) & 3u); }
+__host__ __device__ inline int hilb_inv(int r, int c) { return (int)((kHilbInv >> (4 * (r * 4 + c))) & 15ull); }
+
 struct PlaneK {
-  int nh, nv;       // fragments across / down
-  int fro;          // index of the plane's first fragment
-  int stride;       // device pitch
-  int off;          // byte offset of the plane in a frame
-  int ncells_x;     // nh+1 (loop-filter cells across)
-  float rcp_nh;     // 1/nh
-  float rcp_cx;     // 1/(nh+1)
+  int nh, nv;        // fragments across / down
+  int stride;        // device pitch
+  int off;           // byte offset of the plane in a frame
+  int tiles_x;       // tiles across
+  int tile_off;      // index of the plane's first tile
+  int segs_x;        // workgroups (segments) per strip
+  int seam_rows;     // filter-cell rows handled by k_seam
+  int vseams;        // vertical segment seams per strip
+  int vrows;         // interior cell rows that are NOT seam rows (for the vertical seams)
 };
 
 struct StreamK {
-  const uint2 *cmds;
+  const uint2 *info;
   const int4 *coeffs;
-  const uint32_t *uncoded;
+  const uint32_t *tile_slot0;
   uint8_t *self;
   const uint8_t *prev;
   const uint8_t *gold;
-  uint8_t *coded_map;
-  int ncoded, nuncoded;
-  int nwg_coded;    // workgroups of k_recon that do reconstruction; the rest copy
-  int flimit2;      // 2*flimit
-  int cell_end0, cell_end1, cell_end2;  // cumulative loop-filter cell counts per plane
-  int qpx, qpy;     // chroma axis decimated (quarter-pel chroma vectors)
-  int lf_y0[3], lf_y1[3];  // fragment-row range to filter per plane
-  int debug;        // ablation switches for profiling (THIP_DEBUG env), 0 in production
+  int flimit2;            // 2*flimit
+  int qpx, qpy;           // chroma axis decimated (quarter-pel chroma vectors)
+  int seg_tiles;          // tiles per segment
+  int seg_end[3];         // cumulative k_frame workgroup counts per plane
+  int seam_end[3];        // cumulative k_seam cell counts per plane
+  int lf_y0[3], lf_y1[3]; // fragment-row range whose filter operations are applied
+  int debug;              // ablation switches for profiling (THIP_DEBUG env), 0 in production
   PlaneK pl[3];
 };
 
@@ -71,190 +99,7 @@ struct BatchK {
 };
 
 // ---------------------------------------------------------------------------------------
-// K1 + K2
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void locate_fragment(const StreamK &S, uint32_t fragi, int &pli, int &fx,
-                                                int &fy, int &stride, int &off, int &W, int &H) {
-  const bool c1 = fragi >= (uint32_t)S.pl[1].fro;
-  const bool c2 = fragi >= (uint32_t)S.pl[2].fro;
-  pli = (int)c1 + (int)c2;
-  const int nh = c1 ? S.pl[1].nh : S.pl[0].nh;
-  const int nv = c1 ? S.pl[1].nv : S.pl[0].nv;
-  const float rcp = c1 ? S.pl[1].rcp_nh : S.pl[0].rcp_nh;
-  const int fro = c2 ? S.pl[2].fro : (c1 ? S.pl[1].fro : 0);
-  stride = c1 ? S.pl[1].stride : S.pl[0].stride;
-  off = c2 ? S.pl[2].off : (c1 ? S.pl[1].off : S.pl[0].off);
-  uint32_t q, r;
-  divmod_u24(fragi - (uint32_t)fro, (uint32_t)nh, rcp, q, r);
-  fx = (int)r;
-  fy = (int)q;
-  W = nh * 8;
-  H = nv * 8;
-}
-
-__device__ __forceinline__ void recon_lane(const StreamK &S, uint32_t slot) {
-  const bool active = slot < (uint32_t)S.ncoded;
-  // 1. this lane's coefficients: four row pairs x two 16-byte halves; every load of the
-  //    wave is 1 KiB contiguous.  P[j*8+c] = { x[2j][c], x[2j+1][c] }.
-  const int4 *tp = S.coeffs + ((size_t)(slot >> 6) * 512 + (slot & 63));
-  uint32_t P[32];
-#pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const int4 w = (S.debug & 8) ? make_int4((int)slot, q, 3, 4) : tp[q * 64];
-    P[q * 4 + 0] = (uint32_t)w.x;
-    P[q * 4 + 1] = (uint32_t)w.y;
-    P[q * 4 + 2] = (uint32_t)w.z;
-    P[q * 4 + 3] = (uint32_t)w.w;
-  }
-  uint2 cmd = make_uint2(0u, 0u);
-  if (active) cmd = S.cmds[slot];
-  const uint32_t fragi = cmd.x, flags = cmd.y;
-  const int refi = (int)(flags & THIP_CMD_REFI_MASK);
-  const bool dc_only = (flags & THIP_CMD_DC_ONLY) != 0;
-  const int last_zzi = (int)((flags >> THIP_CMD_LAST_ZZI_SHIFT) & 0x7Fu);
-  int pli, fx, fy, stride, off, W, H;
-  locate_fragment(S, fragi, pli, fx, fy, stride, off, W, H);
-  const int x0 = fx * 8, y0 = fy * 8;
-
-  // 2. predictor (fragment.c:49-80): 128, one reference block, or the truncating
-  //    average of two (state.c:986-998)
-  uint2 pred[8];
-#pragma unroll
-  for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
-  if (active && refi != THIP_FRAME_SELF && !(S.debug & 2)) {
-    const uint8_t *ref = (refi == THIP_FRAME_PREV ? S.prev : S.gold) + off;
-    const int dx = (int)(int8_t)(flags >> THIP_CMD_MVX_SHIFT);
-    const int dy = (int)(int8_t)(flags >> THIP_CMD_MVY_SHIFT);
-    int mx, my, mx2, my2;
-    mv_axis(dx, pli != 0 && S.qpx, mx, mx2);
-    mv_axis(dy, pli != 0 && S.qpy, my, my2);
-    const int sx = x0 + mx, sy = y0 + my;
-    const bool two = (mx2 | my2) != 0;
-    const bool inside = sx + min(mx2, 0) >= 0 && sx + max(mx2, 0) + 8 <= W &&
-                        sy + min(my2, 0) >= 0 && sy + max(my2, 0) + 8 <= H;
-    if (inside) {
-      // Both samples of a row lie in the 9 bytes starting at xs, i.e. inside one 12-byte
-      // window aligned down to 4: one DWORD-ALIGNED dwordx3 load per source row and byte
-      // funnel shifts, instead of byte-unaligned loads (which the memory pipeline
-      // serialises).  Vertical half-pel needs 9 source rows, not 16.
-      const int xs = sx + min(mx2, 0);
-      const int xw = xs & ~3;
-      const int offA = sx - xw, offB = sx + mx2 - xw;   // 0..4
-      const int ys = sy + min(my2, 0);
-      const int ra = sy - ys, rb = sy + my2 - ys;        // first source row of each sample: 0 or 1
-      const uint8_t *p1 = ref + (ptrdiff_t)ys * stride + xw;
-      Row12 w[9];
-#pragma unroll
-      for (int r = 0; r < 8; r++) w[r] = load_row12(p1 + (ptrdiff_t)r * stride);
-      w[8] = w[7];
-      if (my2 != 0) w[8] = load_row12(p1 + (ptrdiff_t)8 * stride);
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const Row12 wa = ra ? w[r + 1] : w[r];
-        pred[r] = extract8(wa, offA);
-        if (two) {
-          const Row12 wb = rb ? w[r + 1] : w[r];
-          const uint2 b = extract8(wb, offB);
-          pred[r].x = avg4_trunc(pred[r].x, b.x);
-          pred[r].y = avg4_trunc(pred[r].y, b.y);
-        }
-      }
-    } else {
-      // the block reaches into the reference's UMV border: clamp every coordinate
-      // (== replicated padding, state.c:770-835)
-#pragma unroll 1
-      for (int r = 0; r < 8; r++) {
-        const int ya = min(max(sy + r, 0), H - 1);
-        const int yb = min(max(sy + my2 + r, 0), H - 1);
-        uint32_t w[2] = {0u, 0u};
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          const int xa = min(max(sx + c, 0), W - 1);
-          int v = ref[(ptrdiff_t)ya * stride + xa];
-          if (two) {
-            const int xb = min(max(sx + mx2 + c, 0), W - 1);
-            v = (v + ref[(ptrdiff_t)yb * stride + xb]) >> 1;
-          }
-          w[c >> 2] |= (uint32_t)v << (8 * (c & 3));
-        }
-        // runtime row index: select into the register array without dynamic indexing
-#pragma unroll
-        for (int rr = 0; rr < 8; rr++)
-          if (rr == r) pred[rr] = make_uint2(w[0], w[1]);
-      }
-    }
-  }
-
-  // 3. residual: DC-only shortcut (state.c:967-975) or inverse DCT (idct.c:301), packed
-  //    two int16 per register
-  uint32_t Y[32];
-  const uint32_t dcp = (P[0] & 0xFFFFu) * 0x00010001u;   // {p, p}
-  // wave-uniform choice of the cheapest transform that covers every lane
-  const bool need_any = __any(active && !dc_only);
-  if (S.debug & 1) {
-#pragma unroll
-    for (int i = 0; i < 32; i++) Y[i] = P[i];
-  } else if (need_any) {
-    pk_mask_by_last_zzi(P, last_zzi);
-    const bool all_zz10 = !__any(active && !dc_only && last_zzi > 10);
-    pk_idct8x8(P, Y, all_zz10);
-  }
-  if (dc_only || !need_any) {
-#pragma unroll
-    for (int i = 0; i < 32; i++) Y[i] = dcp;
-  }
-
-  // 4. reconstruct and store (8 B per lane per row)
-  if (active && (S.debug & 4)) {
-    // ablation: keep the values live with one store
-    uint32_t acc = 0;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const uint2 o = pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]),
-                                   as_pk(Y[r * 4 + 3]), pred[r]);
-      acc ^= o.x ^ o.y;
-    }
-    if (acc == 0x12345678u) S.coded_map[fragi] = 2;
-  } else if (active) {
-    uint8_t *dst = S.self + off + (ptrdiff_t)y0 * stride + x0;
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-      store_row8(dst + (ptrdiff_t)r * stride,
-                 pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]),
-                              as_pk(Y[r * 4 + 3]), pred[r]));
-    S.coded_map[fragi] = 1;
-  }
-}
-
-__device__ __forceinline__ void copy_lane(const StreamK &S, uint32_t idx) {
-  if (idx >= (uint32_t)S.nuncoded) return;
-  const uint32_t fragi = S.uncoded[idx];
-  int pli, fx, fy, stride, off, W, H;
-  locate_fragment(S, fragi, pli, fx, fy, stride, off, W, H);
-  const ptrdiff_t o = off + (ptrdiff_t)fy * 8 * stride + fx * 8;
-  uint2 t[8];
-#pragma unroll
-  for (int r = 0; r < 8; r++) t[r] = *reinterpret_cast<const uint2 *>(S.prev + o + (ptrdiff_t)r * stride);
-#pragma unroll
-  for (int r = 0; r < 8; r++) store_row8(S.self + o + (ptrdiff_t)r * stride, t[r]);
-  S.coded_map[fragi] = 0;
-}
-
-__global__ __launch_bounds__(256) void k_recon(const BatchK B) {
-  const StreamK &S = B.s[blockIdx.y];
-  const int b = (int)blockIdx.x;
-  if (b < S.nwg_coded) {
-    const uint32_t slot = (uint32_t)b * 256u + threadIdx.x;
-    // whole waves past the end have no coefficient tile to read
-    if ((slot & ~63u) >= (uint32_t)S.ncoded) return;
-    recon_lane(S, slot);
-  } else {
-    copy_lane(S, (uint32_t)(b - S.nwg_coded) * 256u + threadIdx.x);
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// K3: in-loop deblocking
+// in-loop filter on a register image of one 8x8 "cell"
 // ---------------------------------------------------------------------------------------
 // The reference filters, for every coded fragment in raster order, its left edge, its
 // edge towards the previous fragment row, then its right / next-row edge when that
@@ -266,11 +111,11 @@ __global__ __launch_bounds__(256) void k_recon(const BatchK B) {
 //   Vhi  vertical edge x=8k, fragment row m,   its rows 0..3   (cell rows 4..7)
 //   Hl   horizontal edge y=8m, fragment column k-1, columns 4..7 (cell cols 0..3)
 //   Hr   horizontal edge y=8m, fragment column k,   columns 0..3 (cell cols 4..7)
-// and nothing else reads or writes those pixels, so cells are independent.  Inside a
-// cell the operations run in the reference's order, which depends on which of the four
-// fragments around the corner are coded (a=(k-1,m-1) b=(k,m-1) c=(k-1,m) d=(k,m)):
-//   raster time of an op = (row, column, slot) of the fragment that triggers it, slots
-//   left=0, previous-row=1, right=2, next-row=3.  Sorted, the eight candidates are
+// and nothing else reads or writes those pixels, so cells are independent and tile the
+// plane.  Inside a cell the operations run in the reference's order, which depends on which
+// of the four fragments around the corner are coded (a=(k-1,m-1) b=(k,m-1) c=(k-1,m)
+// d=(k,m)): raster time of an op = (row, column, slot) of the fragment that triggers it,
+// slots left=0, previous-row=1, right=2, next-row=3.  Sorted, the eight candidates are
 //   T1 Vlo by a (!b)   T2 Hl by a (!c)   T3 Vlo by b   T4 Hr by b (!d)
 //   T5 Hl by c         T6 Vhi by c (!d)  T7 Vhi by d   T8 Hr by d
 __device__ __forceinline__ void lf_vert(int P[64], int r0, int L2) {
@@ -292,26 +137,54 @@ __device__ __forceinline__ void lf_horz(int P[64], int c0, int L2) {
   }
 }
 
-__device__ __forceinline__ void loopfilter_cell(uint8_t *plane, int stride, int nh, int nv,
-                                                const uint8_t *cm, int k, int m, int L2, int fy0,
-                                                int fy1) {
-  const bool kin = k >= 1 && k <= nh - 1;  // a vertical edge exists at x=8k
-  const bool min_ = m >= 1 && m <= nv - 1; // a horizontal edge exists at y=8m
-  const bool a = k >= 1 && m >= 1 && cm[(m - 1) * nh + k - 1];
-  const bool b = k <= nh - 1 && m >= 1 && cm[(m - 1) * nh + k];
-  const bool c = k >= 1 && m <= nv - 1 && cm[m * nh + k - 1];
-  const bool d = k <= nh - 1 && m <= nv - 1 && cm[m * nh + k];
+// Which of T1..T8 apply to cell (k,m) of a plane with nh x nv fragments, given the coded
+// flags around the corner and the fragment-row range [fy0,fy1) being filtered.  Bit i-1 of
+// the result = Ti.
+__device__ __forceinline__ uint32_t lf_cell_ops(int k, int m, int nh, int nv, bool a, bool b, bool c, bool d,
+                                                int fy0, int fy1) {
+  const bool kin = k >= 1 && k <= nh - 1;   // a vertical edge exists at x=8k
+  const bool min_ = m >= 1 && m <= nv - 1;  // a horizontal edge exists at y=8m
+  a = a && k >= 1 && m >= 1;
+  b = b && k <= nh - 1 && m >= 1;
+  c = c && k >= 1 && m <= nv - 1;
+  d = d && k <= nh - 1 && m <= nv - 1;
   const bool rlo = (m - 1) >= fy0 && (m - 1) < fy1;  // ops triggered from fragment row m-1
   const bool rhi = m >= fy0 && m < fy1;              // ops triggered from fragment row m
-  const bool t1 = kin && a && !b && rlo;
-  const bool t2 = min_ && k >= 1 && a && !c && rlo;
-  const bool t3 = kin && b && rlo;
-  const bool t4 = min_ && k <= nh - 1 && b && !d && rlo;
-  const bool t5 = min_ && k >= 1 && c && rhi;
-  const bool t6 = kin && c && !d && rhi;
-  const bool t7 = kin && d && rhi;
-  const bool t8 = min_ && k <= nh - 1 && d && rhi;
-  if (!(t1 | t2 | t3 | t4 | t5 | t6 | t7 | t8)) return;
+  uint32_t t = 0;
+  t |= (kin && a && !b && rlo) ? 1u : 0u;
+  t |= (min_ && k >= 1 && a && !c && rlo) ? 2u : 0u;
+  t |= (kin && b && rlo) ? 4u : 0u;
+  t |= (min_ && k <= nh - 1 && b && !d && rlo) ? 8u : 0u;
+  t |= (min_ && k >= 1 && c && rhi) ? 16u : 0u;
+  t |= (kin && c && !d && rhi) ? 32u : 0u;
+  t |= (kin && d && rhi) ? 64u : 0u;
+  t |= (min_ && k <= nh - 1 && d && rhi) ? 128u : 0u;
+  return t;
+}
+
+__device__ __forceinline__ void lf_cell_apply(int P[64], uint32_t t, int L2) {
+  if (__any(t & 1u)) { if (t & 1u) lf_vert(P, 0, L2); }
+  if (__any(t & 2u)) { if (t & 2u) lf_horz(P, 0, L2); }
+  if (__any(t & 4u)) { if (t & 4u) lf_vert(P, 0, L2); }
+  if (__any(t & 8u)) { if (t & 8u) lf_horz(P, 4, L2); }
+  if (__any(t & 16u)) { if (t & 16u) lf_horz(P, 0, L2); }
+  if (__any(t & 32u)) { if (t & 32u) lf_vert(P, 4, L2); }
+  if (__any(t & 64u)) { if (t & 64u) lf_vert(P, 4, L2); }
+  if (__any(t & 128u)) { if (t & 128u) lf_horz(P, 4, L2); }
+}
+
+__device__ __forceinline__ void unpack_row(int *P, uint32_t lo, uint32_t hi) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    P[q] = byte_of(lo, q);
+    P[4 + q] = byte_of(hi, q);
+  }
+}
+
+// A cell directly on a plane in memory (k_seam, thip_loop_filter_plane).
+__device__ __forceinline__ void lf_cell_global(uint8_t *plane, int stride, int nh, int nv, int k, int m,
+                                               uint32_t t, int L2) {
+  if (!t) return;
   const bool lo_ok = k >= 1, hi_ok = k <= nh - 1;
   uint8_t *base = plane + (ptrdiff_t)(8 * m - 4) * stride + (8 * k - 4);
   const int H = nv * 8;
@@ -325,20 +198,9 @@ __device__ __forceinline__ void loopfilter_cell(uint8_t *plane, int stride, int 
       if (lo_ok) lo = p[0];
       if (hi_ok) hi = p[1];
     }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      P[r * 8 + q] = byte_of(lo, q);
-      P[r * 8 + 4 + q] = byte_of(hi, q);
-    }
+    unpack_row(P + r * 8, lo, hi);
   }
-  if (__any(t1)) { if (t1) lf_vert(P, 0, L2); }
-  if (__any(t2)) { if (t2) lf_horz(P, 0, L2); }
-  if (__any(t3)) { if (t3) lf_vert(P, 0, L2); }
-  if (__any(t4)) { if (t4) lf_horz(P, 4, L2); }
-  if (__any(t5)) { if (t5) lf_horz(P, 0, L2); }
-  if (__any(t6)) { if (t6) lf_vert(P, 4, L2); }
-  if (__any(t7)) { if (t7) lf_vert(P, 4, L2); }
-  if (__any(t8)) { if (t8) lf_horz(P, 4, L2); }
+  lf_cell_apply(P, t, L2);
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     const int y = 8 * m - 4 + r;
@@ -350,24 +212,357 @@ __device__ __forceinline__ void loopfilter_cell(uint8_t *plane, int stride, int 
   }
 }
 
-__global__ __launch_bounds__(256) void k_loopfilter(const BatchK B) {
+// ---------------------------------------------------------------------------------------
+// k_frame
+// ---------------------------------------------------------------------------------------
+// Every WAVE is autonomous (no workgroup barriers): it owns a segment -- a run of
+// consecutive tiles (4 super blocks = 16x4 fragments = 128x32 pixels) of one super-block
+// row -- and walks it left to right, software-pipelined: the loads of tile i are in flight
+// while tile i-1 is filtered in LDS and streamed out.
+//
+// LDS image of one tile: 32 rows x (4 carried columns + 128 + slack).  Column cx holds pixel
+// x = tile_x0 - 4 + cx, so filter cell k (pixels 8k-4..8k+3 of the tile) is the
+// 8-byte-aligned group cx = 8k..8k+7.  Two images per wave: tile i is built while tile i-1
+// drains.
+constexpr int kTilePitch = 144;
+constexpr int kTileRows = 32;
+constexpr int kFlagCols = 20;   // [row][0] = last block column of the previous tile, [row][1+bxl]
+
+struct TileLds {
+  uint8_t pix[kTileRows * kTilePitch];
+  uint8_t coded[4 * kFlagCols];
+  uint8_t pad_[16 - (4 * kFlagCols) % 16];
+};
+
+__device__ __forceinline__ void wave_sync() {
+  // LDS traffic between lanes of ONE wave: the hardware executes a wave's DS operations in
+  // order; this only stops the compiler from moving them across the phase boundary.
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// residual of this lane's block as eight rows of packed int16 pairs
+__device__ __forceinline__ void load_slot(const int4 *coeffs, uint32_t slot, uint32_t P[32]) {
+  const int4 *tp = coeffs + ((size_t)(slot >> 6) * 512 + (slot & 63));
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int4 w = tp[q * 64];
+    P[q * 4 + 0] = (uint32_t)w.x;
+    P[q * 4 + 1] = (uint32_t)w.y;
+    P[q * 4 + 2] = (uint32_t)w.z;
+    P[q * 4 + 3] = (uint32_t)w.w;
+  }
+}
+
+// Predictor of an inter block (fragment.c:59-80 with the offsets of state.c:846-957): one
+// reference block or the truncating average of two.  Split in two so the loads can be in
+// flight across other work: *_issue starts them, *_finish turns them into 8 rows of 8 bytes.
+struct PredFetch {
+  Row12 w[9];
+  int offA, offB, ra, rb;
+  bool two, inside;
+};
+
+__device__ __forceinline__ void predictor_issue(PredFetch &F, const uint8_t *ref, int stride, int W, int H,
+                                                int x0, int y0, uint32_t flags, bool qpx, bool qpy,
+                                                uint2 pred[8]) {
+  const int dx = (int)(int8_t)(flags >> THIP_INFO_MVX_SHIFT);
+  const int dy = (int)(int8_t)(flags >> THIP_INFO_MVY_SHIFT);
+  int mx, my, mx2, my2;
+  mv_axis(dx, qpx, mx, mx2);
+  mv_axis(dy, qpy, my, my2);
+  const int sx = x0 + mx, sy = y0 + my;
+  F.two = (mx2 | my2) != 0;
+  F.inside = sx + min(mx2, 0) >= 0 && sx + max(mx2, 0) + 8 <= W && sy + min(my2, 0) >= 0 &&
+             sy + max(my2, 0) + 8 <= H;
+  if (F.inside) {
+    // Both samples of a row lie in the 9 bytes starting at xs, i.e. inside one 12-byte
+    // window aligned down to 4: one dword-aligned dwordx3 load per source row and byte
+    // funnel shifts.  Vertical half-pel needs 9 source rows, not 16.
+    const int xs = sx + min(mx2, 0);
+    const int xw = xs & ~3;
+    F.offA = sx - xw;
+    F.offB = sx + mx2 - xw;   // 0..4
+    const int ys = sy + min(my2, 0);
+    F.ra = sy - ys;
+    F.rb = sy + my2 - ys;     // first source row of each sample: 0 or 1
+    const uint8_t *p1 = ref + (ptrdiff_t)ys * stride + xw;
+#pragma unroll
+    for (int r = 0; r < 8; r++) F.w[r] = load_row12(p1 + (ptrdiff_t)r * stride);
+    F.w[8] = F.w[7];
+    if (my2 != 0) F.w[8] = load_row12(p1 + (ptrdiff_t)8 * stride);
+  } else {
+    // the block reaches into the reference's UMV border: clamp every coordinate
+    // (== replicated padding, state.c:770-835); rare, done on the spot
+#pragma unroll 1
+    for (int r = 0; r < 8; r++) {
+      const int ya = min(max(sy + r, 0), H - 1);
+      const int yb = min(max(sy + my2 + r, 0), H - 1);
+      uint32_t w[2] = {0u, 0u};
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int xa = min(max(sx + c, 0), W - 1);
+        int v = ref[(ptrdiff_t)ya * stride + xa];
+        if (F.two) {
+          const int xb = min(max(sx + mx2 + c, 0), W - 1);
+          v = (v + ref[(ptrdiff_t)yb * stride + xb]) >> 1;
+        }
+        w[c >> 2] |= (uint32_t)v << (8 * (c & 3));
+      }
+#pragma unroll
+      for (int rr = 0; rr < 8; rr++)
+        if (rr == r) pred[rr] = make_uint2(w[0], w[1]);
+    }
+  }
+}
+
+__device__ __forceinline__ void predictor_finish(const PredFetch &F, uint2 pred[8]) {
+  if (!F.inside) return;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const Row12 wa = F.ra ? F.w[r + 1] : F.w[r];
+    pred[r] = extract8(wa, F.offA);
+    if (F.two) {
+      const Row12 wb = F.rb ? F.w[r + 1] : F.w[r];
+      const uint2 b = extract8(wb, F.offB);
+      pred[r].x = avg4_trunc(pred[r].x, b.x);
+      pred[r].y = avg4_trunc(pred[r].y, b.y);
+    }
+  }
+}
+
+// In-loop filter on the cells inside the strip for one finished tile image, then stream
+// the tile out: pixels x0-4 .. x0+3 of every block (the four columns right of the last
+// block wait for the next tile's cell 0, or go out now if the segment ends here).
+__device__ __forceinline__ void filter_and_store(TileLds &T, const StreamK &S, uint8_t *selfp, int lane,
+                                                 int tx, int sby, int nh, int nv, int stride, bool first,
+                                                 bool last, int fy0, int fy1, int hr, int bxl, int by) {
+  const int nbx = min(16, nh - tx * 16);   // valid block columns in this tile
+  if (S.flimit2 != 0 && lane < 51 && !(S.debug & 16)) {
+    // cells (kl, ml): kl = 0..16 across, ml = 1..3 between the strip's block rows
+    const int ml = 1 + lane / 17, kl = lane - (ml - 1) * 17;
+    const int kg = tx * 16 + kl, mg = sby * 4 + ml;
+    // kl == 0: the seam to the previous segment belongs to k_seam (unless it is the frame
+    // edge); kl == nbx: only the plane's right edge is filtered here, otherwise the cell is
+    // the next tile's kl == 0.
+    const bool mine = mg <= nv - 1 && (kl >= 1 || !first || kg == 0) && (kl < nbx || (kl == nbx && kg == nh));
+    if (mine) {
+      const bool a = T.coded[(ml - 1) * kFlagCols + kl] != 0, b = T.coded[(ml - 1) * kFlagCols + kl + 1] != 0;
+      const bool c = T.coded[ml * kFlagCols + kl] != 0, d = T.coded[ml * kFlagCols + kl + 1] != 0;
+      const uint32_t t = lf_cell_ops(kg, mg, nh, nv, a, b, c, d, fy0, fy1);
+      if (t) {
+        uint8_t *cp = T.pix + (ml * 8 - 4) * kTilePitch + kl * 8;
+        int Cc[64];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const uint2 v = *reinterpret_cast<const uint2 *>(cp + r * kTilePitch);
+          unpack_row(Cc + r * 8, v.x, v.y);
+        }
+        lf_cell_apply(Cc, t, S.flimit2);
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          *reinterpret_cast<uint2 *>(cp + r * kTilePitch) =
+              make_uint2(pack4(Cc[r * 8 + 0], Cc[r * 8 + 1], Cc[r * 8 + 2], Cc[r * 8 + 3]),
+                         pack4(Cc[r * 8 + 4], Cc[r * 8 + 5], Cc[r * 8 + 6], Cc[r * 8 + 7]));
+      }
+    }
+  }
+  wave_sync();
+  const int bx = tx * 16 + bxl;
+  if (bx < nh && by < nv && !(S.debug & 4)) {
+    const uint8_t *src = T.pix + (hr * 8) * kTilePitch + bxl * 8;
+    uint8_t *dst = selfp + (ptrdiff_t)(by * 8) * stride + bx * 8 - 4;
+    const bool lo_ok = !(first && bxl == 0);   // left of the segment: not ours
+    const bool tail = last && bxl == nbx - 1;    // segment ends: flush the last 4 px
+    struct __attribute__((packed, aligned(4))) U2 { uint32_t x, y; };
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const uint2 v = *reinterpret_cast<const uint2 *>(src + r * kTilePitch);
+      uint8_t *d = dst + (ptrdiff_t)r * stride;
+      if (lo_ok) {
+        U2 u;
+        u.x = v.x;
+        u.y = v.y;
+        *reinterpret_cast<U2 *>(d) = u;          // 4-byte-aligned dwordx2 store
+      } else {
+        reinterpret_cast<uint32_t *>(d)[1] = v.y;
+      }
+      if (tail) reinterpret_cast<uint32_t *>(d)[2] = *reinterpret_cast<const uint32_t *>(src + r * kTilePitch + 8);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_frame(const BatchK B) {
+  __shared__ __attribute__((aligned(16))) TileLds lds_all[4][2];
   const StreamK &S = B.s[blockIdx.y];
-  const int cell = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (cell >= S.cell_end2 || S.flimit2 == 0) return;
-  const bool c1 = cell >= S.cell_end0, c2 = cell >= S.cell_end1;
-  const int pli = (int)c1 + (int)c2;
-  const int rel = cell - (c2 ? S.cell_end1 : (c1 ? S.cell_end0 : 0));
-  const int nh = c1 ? S.pl[1].nh : S.pl[0].nh;
-  const int nv = c1 ? S.pl[1].nv : S.pl[0].nv;
-  const int stride = c1 ? S.pl[1].stride : S.pl[0].stride;
-  const int off = c2 ? S.pl[2].off : (c1 ? S.pl[1].off : S.pl[0].off);
-  const int fro = c2 ? S.pl[2].fro : (c1 ? S.pl[1].fro : 0);
-  const float rcp = c1 ? S.pl[1].rcp_cx : S.pl[0].rcp_cx;
-  uint32_t m, k;
-  divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), rcp, m, k);
-  const int y0 = pli == 0 ? S.lf_y0[0] : (pli == 1 ? S.lf_y0[1] : S.lf_y0[2]);
-  const int y1 = pli == 0 ? S.lf_y1[0] : (pli == 1 ? S.lf_y1[1] : S.lf_y1[2]);
-  loopfilter_cell(S.self + off, stride, nh, nv, S.coded_map + fro, (int)k, (int)m, S.flimit2, y0, y1);
+  const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+  const int unit = (int)blockIdx.x * 4 + wv;   // this wave's segment
+  if (unit >= S.seg_end[2]) return;             // whole waves leave; no barriers are used below
+  const int pli = (unit >= S.seg_end[0] ? 1 : 0) + (unit >= S.seg_end[1] ? 1 : 0);
+  const PlaneK &G = S.pl[pli];
+  const int rel = unit - (pli == 0 ? 0 : (pli == 1 ? S.seg_end[0] : S.seg_end[1]));
+  const int sby = rel / G.segs_x;
+  const int sg = rel - sby * G.segs_x;
+  const int tx0 = sg * S.seg_tiles;
+  const int tx1 = min(tx0 + S.seg_tiles, G.tiles_x);
+  const int nh = G.nh, nv = G.nv, stride = G.stride;
+  const int W = nh * 8, H = nv * 8;
+  const bool qpx = pli != 0 && S.qpx, qpy = pli != 0 && S.qpy;
+  const int fy0 = pli == 0 ? S.lf_y0[0] : (pli == 1 ? S.lf_y0[1] : S.lf_y0[2]);
+  const int fy1 = pli == 0 ? S.lf_y1[0] : (pli == 1 ? S.lf_y1[1] : S.lf_y1[2]);
+  const int sbl = lane >> 4, h = lane & 15;
+  const int hr = hilb_row(h), hc = hilb_col(h);
+  const int bxl = sbl * 4 + hc;         // block column inside the tile, 0..15
+  const int by = sby * 4 + hr;          // block row in the plane
+  uint8_t *const selfp = S.self + G.off;
+  TileLds *const L = lds_all[wv];
+  const int tile_row0 = G.tile_off + sby * G.tiles_x;
+
+  uint2 info_n = S.info[(size_t)(tile_row0 + tx0) * THIP_TILE_FRAGS + lane];
+  uint32_t slot0_n = S.tile_slot0[tile_row0 + tx0];
+
+  for (int tx = tx0; tx <= tx1; tx++) {
+    const bool cur = tx < tx1;
+    TileLds &T = L[(tx - tx0) & 1];
+    uint32_t P[32];
+    uint2 pred[8];
+    PredFetch F;
+    uint32_t flags = 0, word1 = 0;
+    bool valid = false, coded = false, dc_only = false, has_coeff = false;
+    F.inside = false;
+    // ---- 1. command word, coefficient slot by ballot / prefix count, start the loads ----------
+    if (cur) {
+      const int bx = tx * 16 + bxl;
+      valid = bx < nh && by < nv;
+      flags = valid ? info_n.x : 0u;
+      word1 = info_n.y;
+      coded = (flags & THIP_INFO_CODED) != 0;
+      dc_only = (flags & THIP_INFO_DC_ONLY) != 0;
+      has_coeff = coded && !dc_only;
+      const uint64_t mask = __ballot(has_coeff);
+      const uint32_t slot = slot0_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      if (has_coeff && !(S.debug & 8)) load_slot(S.coeffs, slot, P);
+      else {
+#pragma unroll
+        for (int i = 0; i < 32; i++) P[i] = 0u;
+      }
+      const int refi = (int)((flags >> THIP_INFO_REFI_SHIFT) & 3u);
+      const int x0 = bx * 8, y0 = by * 8;
+#pragma unroll
+      for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);   // intra, fragment.c:54
+      if (valid && !coded) {
+        // uncoded: the fragment is copied from the previous frame (fragment.c:20-47)
+        const uint8_t *p = S.prev + G.off + (ptrdiff_t)y0 * stride + x0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) pred[r] = *reinterpret_cast<const uint2 *>(p + (ptrdiff_t)r * stride);
+      } else if (coded && refi != THIP_FRAME_SELF && !(S.debug & 2)) {
+        const uint8_t *ref = (refi == THIP_FRAME_PREV ? S.prev : S.gold) + G.off;
+        predictor_issue(F, ref, stride, W, H, x0, y0, flags, qpx, qpy, pred);
+      }
+      if (tx + 1 < tx1) {   // command words of the next tile
+        info_n = S.info[(size_t)(tile_row0 + tx + 1) * THIP_TILE_FRAGS + lane];
+        slot0_n = S.tile_slot0[tile_row0 + tx + 1];
+      }
+    }
+    // ---- 2. while those loads fly: filter and stream out the previous tile ---------------------
+    if (tx > tx0)
+      filter_and_store(L[(tx - tx0 + 1) & 1], S, selfp, lane, tx - 1, sby, nh, nv, stride, tx - 1 == tx0,
+                       tx == tx1, fy0, fy1, hr, bxl, by);
+    if (!cur) break;
+    // ---- 3. residual: DC-only shortcut (state.c:967-975) or inverse DCT (idct.c:301) ---------
+    const int last_zzi = (int)((flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
+    uint32_t Y[32];
+    const uint32_t dcp = (word1 & 0xFFFFu) * 0x00010001u;   // {p, p}
+    const bool need_any = __any(has_coeff);
+    if (need_any && !(S.debug & 1)) {
+      pk_mask_by_last_zzi(P, last_zzi);
+      const bool all_zz10 = !__any(has_coeff && last_zzi > 10);
+      pk_idct8x8(P, Y, all_zz10);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 32; i++) Y[i] = P[i];
+    }
+    if (!has_coeff) {
+#pragma unroll
+      for (int i = 0; i < 32; i++) Y[i] = dc_only ? dcp : 0u;
+    }
+    predictor_finish(F, pred);
+    // ---- 4. reconstruct into this tile's LDS image -----------------------------------------------
+    if (valid) {
+      uint8_t *dst = T.pix + (hr * 8) * kTilePitch + 4 + bxl * 8;
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        uint2 o = pred[r];
+        if (coded)
+          o = pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]),
+                           pred[r]);
+        uint32_t *d = reinterpret_cast<uint32_t *>(dst + r * kTilePitch);   // 4-byte aligned
+        d[0] = o.x;
+        d[1] = o.y;
+      }
+    }
+    T.coded[hr * kFlagCols + 1 + bxl] = coded ? 1 : 0;
+    if (lane < 4) T.coded[lane * kFlagCols + 1 + 16] = 0;   // column past the tile: never coded here
+    // carried columns: the last four pixels (and the coded flags) of the previous tile
+    if (tx > tx0) {
+      const TileLds &Q = L[(tx - tx0 + 1) & 1];
+      if (lane < kTileRows)
+        *reinterpret_cast<uint32_t *>(T.pix + lane * kTilePitch) =
+            *reinterpret_cast<const uint32_t *>(Q.pix + lane * kTilePitch + 128);
+      if (lane >= 32 && lane < 36) T.coded[(lane - 32) * kFlagCols] = Q.coded[(lane - 32) * kFlagCols + 16];
+    } else if (lane >= 32 && lane < 36) {
+      T.coded[(lane - 32) * kFlagCols] = 0;
+    }
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_seam: the filter cells k_frame leaves -- seam rows (m % 4 == 0, and m == nv), and on the
+// other interior rows the columns where two segments meet.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool coded_at(const StreamK &S, const PlaneK &G, int bx, int by) {
+  const int pos = (G.tile_off + (by >> 2) * G.tiles_x + (bx >> 4)) * THIP_TILE_FRAGS + ((bx >> 2) & 3) * 16 +
+                  hilb_inv(by & 3, bx & 3);
+  return (S.info[pos].x & THIP_INFO_CODED) != 0;
+}
+
+__global__ __launch_bounds__(256) void k_seam(const BatchK B) {
+  const StreamK &S = B.s[blockIdx.y];
+  const int idx = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (idx >= S.seam_end[2] || S.flimit2 == 0) return;
+  const int pli = (idx >= S.seam_end[0] ? 1 : 0) + (idx >= S.seam_end[1] ? 1 : 0);
+  const PlaneK &G = S.pl[pli];
+  int rel = idx - (pli == 0 ? 0 : (pli == 1 ? S.seam_end[0] : S.seam_end[1]));
+  const int nh = G.nh, nv = G.nv;
+  int k, m;
+  const int hcells = G.seam_rows * (nh + 1);
+  if (rel < hcells) {
+    const int row = rel / (nh + 1);
+    k = rel - row * (nh + 1);
+    m = min(row * 4, nv);   // rows 0,4,8,... and finally nv itself
+  } else {
+    rel -= hcells;
+    const int j = rel / G.vseams;          // j-th interior row that is not a seam row
+    const int s = rel - j * G.vseams;
+    m = (j / 3) * 4 + (j - (j / 3) * 3) + 1;
+    k = (s + 1) * 16 * S.seg_tiles;
+    if (j >= G.vrows) return;
+  }
+  if (S.debug & 64) return;
+  const bool a = k >= 1 && m >= 1 && coded_at(S, G, k - 1, m - 1);
+  const bool b = k <= nh - 1 && m >= 1 && coded_at(S, G, k, m - 1);
+  const bool c = k >= 1 && m <= nv - 1 && coded_at(S, G, k - 1, m);
+  const bool d = k <= nh - 1 && m <= nv - 1 && coded_at(S, G, k, m);
+  if (S.debug & 32) {
+    if (a && b && c && d && k == 12345678) S.self[0] = 1;
+    return;
+  }
+  const int fy0 = pli == 0 ? S.lf_y0[0] : (pli == 1 ? S.lf_y0[1] : S.lf_y0[2]);
+  const int fy1 = pli == 0 ? S.lf_y1[0] : (pli == 1 ? S.lf_y1[1] : S.lf_y1[2]);
+  const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
+  lf_cell_global(S.self + G.off, G.stride, nh, nv, k, m, t, S.flimit2);
 }
 
 // plane-level entry for the slot parity test (thip_loop_filter_plane)
@@ -376,9 +571,14 @@ __global__ __launch_bounds__(256) void k_loopfilter_plane(uint8_t *plane, int st
                                                          float rcp_cx) {
   const int cell = (int)(blockIdx.x * 256u + threadIdx.x);
   if (cell >= (nh + 1) * (nv + 1)) return;
-  uint32_t m, k;
-  divmod_u24((uint32_t)cell, (uint32_t)(nh + 1), rcp_cx, m, k);
-  loopfilter_cell(plane, stride, nh, nv, coded, (int)k, (int)m, L2, fy0, fy1);
+  uint32_t mu, ku;
+  divmod_u24((uint32_t)cell, (uint32_t)(nh + 1), rcp_cx, mu, ku);
+  const int k = (int)ku, m = (int)mu;
+  const bool a = k >= 1 && m >= 1 && coded[(m - 1) * nh + k - 1];
+  const bool b = k <= nh - 1 && m >= 1 && coded[(m - 1) * nh + k];
+  const bool c = k >= 1 && m <= nv - 1 && coded[m * nh + k - 1];
+  const bool d = k <= nh - 1 && m <= nv - 1 && coded[m * nh + k];
+  lf_cell_global(plane, stride, nh, nv, k, m, lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1), L2);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -387,28 +587,29 @@ __global__ __launch_bounds__(256) void k_loopfilter_plane(uint8_t *plane, int st
 struct thip_state {
   int frame_width, frame_height, pixel_fmt, hdec, vdec;
   thip_plane_geom geom[3];
+  thip_tile_geom tiles;
   int64_t nfrags;
   size_t frame_bytes;
   uint8_t *frames[3];   // device
-  uint8_t *coded_map;   // device, nfrags bytes
   int ref_idx[3];       // THIP_FRAME_* -> buffer index
   int last_decoded;     // buffer index of the most recently completed frame, -1 if none
+  int lane;             // library-owned HIP stream this state is bound to, -1 until first use
+  int32_t *frag_pos;    // host: raster fragment index -> tile*256+lane
   // host-enqueue staging (allocated on first use)
   int staging_ready;
-  uint32_t *h_cmds, *d_cmds;
+  uint32_t *h_info, *d_info;
   int16_t *h_coeffs, *d_coeffs;
-  uint32_t *h_uncoded, *d_uncoded;
-  int32_t *frag_xy;     // host table: not needed by the device, kept for validation
-  int enq_ncoded, enq_nuncoded, enq_frame_type, enq_flimit, enq_active;
+  uint32_t *h_slot0, *d_slot0;
+  int32_t *enq_last_lane;   // per tile: last lane that received a slot (arrival-order check)
+  int enq_ncoded, enq_nuncoded, enq_nslots, enq_frame_type, enq_flimit, enq_active, enq_last_tile;
   int enq_lf_y0[3], enq_lf_y1[3], enq_lf_any;
   int lf_y0[3], lf_y1[3], lf_rows_custom;
-  int lane;             // library-owned HIP stream this state is bound to, -1 until first use
 };
 
 namespace {
 std::mutex g_mu;
 // Library-owned HIP streams ("lanes").  Every thip_state is bound to one lane for life, so
-// the frames of a stream stay ordered; different lanes let one group's loop filter overlap
+// the frames of a stream stay ordered; different lanes let one group's seam pass overlap
 // another group's reconstruction (dependent kernels of one group cannot overlap).
 constexpr int kMaxLanes = 4;
 hipStream_t g_lanes[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
@@ -416,6 +617,7 @@ int g_nlanes = 0;
 int g_next_lane = 0;
 int g_profile = 0;
 const int g_debug = getenv("THIP_DEBUG") ? atoi(getenv("THIP_DEBUG")) : 0;
+const int g_seg_tiles = getenv("THIP_SEG_TILES") ? atoi(getenv("THIP_SEG_TILES")) : 4;
 struct EvPair { hipEvent_t a, b; int kernel; };
 std::vector<EvPair> g_events;
 std::vector<hipEvent_t> g_pool;
@@ -462,21 +664,39 @@ struct ScopedTimer {
   }
 };
 
-void fill_plane_k(PlaneK &k, const thip_plane_geom &g) {
-  k.nh = g.nhfrags;
-  k.nv = g.nvfrags;
-  k.fro = g.froffset;
-  k.stride = g.stride;
-  k.off = g.plane_off;
-  k.ncells_x = g.nhfrags + 1;
-  k.rcp_nh = 1.0f / (float)g.nhfrags;
-  k.rcp_cx = 1.0f / (float)(g.nhfrags + 1);
+int seg_tiles() { return g_seg_tiles < 1 ? 1 : (g_seg_tiles > 64 ? 64 : g_seg_tiles); }
+
+// Fills the per-plane kernel geometry; returns k_frame workgroups and k_seam cells.
+void fill_stream_geom(StreamK &K, const thip_state *st) {
+  const int segt = seg_tiles();
+  K.seg_tiles = segt;
+  int wgs = 0, cells = 0;
+  for (int pli = 0; pli < 3; pli++) {
+    const thip_plane_geom &g = st->geom[pli];
+    PlaneK &k = K.pl[pli];
+    k.nh = g.nhfrags;
+    k.nv = g.nvfrags;
+    k.stride = g.stride;
+    k.off = g.plane_off;
+    k.tiles_x = st->tiles.tiles_x[pli];
+    k.tile_off = st->tiles.tile_off[pli];
+    k.segs_x = (k.tiles_x + segt - 1) / segt;
+    // seam rows: m = 0, 4, 8, ... <= nv, plus m = nv when nv is not a multiple of 4
+    k.seam_rows = k.nv / 4 + 1 + ((k.nv & 3) ? 1 : 0);
+    k.vseams = k.segs_x - 1;
+    // interior rows 1..nv-1 that are not multiples of 4
+    k.vrows = (k.nv - 1) - (k.nv - 1) / 4;
+    wgs += st->tiles.tiles_y[pli] * k.segs_x;   // one WAVE per segment
+    K.seg_end[pli] = wgs;
+    cells += k.seam_rows * (k.nh + 1) + k.vseams * k.vrows;
+    K.seam_end[pli] = cells;
+  }
 }
 }  // namespace
 
 extern "C" {
 
-const char *thip_version_string(void) { return "theora_hip 0.1 (gfx950; libtheora 1.2.0 fragment path)"; }
+const char *thip_version_string(void) { return "theora_hip 0.2 (gfx950; libtheora 1.2.0 fragment path)"; }
 
 int thip_state_create(thip_state **out, int frame_width, int frame_height, int pixel_fmt) {
   if (!out) return THIP_EFAULT;
@@ -493,7 +713,7 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
   st->pixel_fmt = pixel_fmt;
   st->hdec = !(pixel_fmt & 1);
   st->vdec = !(pixel_fmt & 2);
-  int64_t fro = 0;
+  int64_t fro = 0, ntiles = 0;
   size_t off = 0;
   for (int pli = 0; pli < 3; pli++) {
     thip_plane_geom &g = st->geom[pli];
@@ -501,10 +721,6 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
     g.nhfrags = pli ? (yh + st->hdec) >> st->hdec : yh;   // state.c:443-449
     g.nvfrags = pli ? (yv + st->vdec) >> st->vdec : yv;
     const int64_t nf = (int64_t)g.nhfrags * g.nvfrags;
-    if (nf >= (1 << 24) || fro + nf >= 0x7FFFFFFFll) {  // divmod_u24 range; 32-bit indices
-      free(st);
-      return THIP_EIMPL;
-    }
     g.froffset = (int32_t)fro;
     g.nfrags = (int32_t)nf;
     fro += nf;
@@ -513,17 +729,36 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
     g.stride = g.width;
     g.plane_off = (int32_t)off;
     off += ((size_t)g.stride * g.height + 255) & ~(size_t)255;
-    if (off >= 0x7FFFFFFFull) {
+    st->tiles.tiles_x[pli] = (g.nhfrags + 15) / 16;
+    st->tiles.tiles_y[pli] = (g.nvfrags + 3) / 4;
+    st->tiles.tile_off[pli] = (int32_t)ntiles;
+    ntiles += (int64_t)st->tiles.tiles_x[pli] * st->tiles.tiles_y[pli];
+    // 32-bit positions and byte offsets on the device (the reference has the same kind of
+    // overflow guard, state.c:476-487, 583-590)
+    if (fro >= (1 << 28) || ntiles * THIP_TILE_FRAGS >= (1ll << 30) || off >= 0x7FFFFFFFull) {
       free(st);
       return THIP_EIMPL;
     }
   }
+  st->tiles.ntiles = (int32_t)ntiles;
   st->nfrags = fro;
   st->frame_bytes = off;
+  st->frag_pos = (int32_t *)malloc(sizeof(int32_t) * (size_t)st->nfrags);
+  if (!st->frag_pos) {
+    free(st);
+    return THIP_EFAULT;
+  }
+  for (int pli = 0; pli < 3; pli++) {
+    const thip_plane_geom &g = st->geom[pli];
+    for (int by = 0; by < g.nvfrags; by++)
+      for (int bx = 0; bx < g.nhfrags; bx++)
+        st->frag_pos[g.froffset + by * g.nhfrags + bx] =
+            (st->tiles.tile_off[pli] + (by >> 2) * st->tiles.tiles_x[pli] + (bx >> 4)) * THIP_TILE_FRAGS +
+            ((bx >> 2) & 3) * 16 + hilb_inv(by & 3, bx & 3);
+  }
   hipError_t err = hipSuccess;
-  for (int b = 0; b < 3 && err == hipSuccess; b++) err = hipMalloc((void **)&st->frames[b], st->frame_bytes + 256);  /* +256: aligned 12-byte windows may read 3 bytes past a row end */
-  if (err == hipSuccess) err = hipMalloc((void **)&st->coded_map, (size_t)st->nfrags);
-  if (err == hipSuccess) err = hipMemset(st->coded_map, 0, (size_t)st->nfrags);
+  // +256: aligned 12-byte predictor windows may read 3 bytes past a row end
+  for (int b = 0; b < 3 && err == hipSuccess; b++) err = hipMalloc((void **)&st->frames[b], st->frame_bytes + 256);
   if (err != hipSuccess) {
     fprintf(stderr, "theora_hip: thip_state_create: device allocation failed: %s\n", hipGetErrorString(err));
     thip_state_free(st);
@@ -541,14 +776,14 @@ void thip_state_free(thip_state *st) {
   (void)hipDeviceSynchronize();
   for (int b = 0; b < 3; b++)
     if (st->frames[b]) (void)hipFree(st->frames[b]);
-  if (st->coded_map) (void)hipFree(st->coded_map);
-  if (st->h_cmds) (void)hipHostFree(st->h_cmds);
+  if (st->h_info) (void)hipHostFree(st->h_info);
   if (st->h_coeffs) (void)hipHostFree(st->h_coeffs);
-  if (st->h_uncoded) (void)hipHostFree(st->h_uncoded);
-  if (st->d_cmds) (void)hipFree(st->d_cmds);
+  if (st->h_slot0) (void)hipHostFree(st->h_slot0);
+  if (st->d_info) (void)hipFree(st->d_info);
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
-  if (st->d_uncoded) (void)hipFree(st->d_uncoded);
-  free(st->frag_xy);
+  if (st->d_slot0) (void)hipFree(st->d_slot0);
+  free(st->enq_last_lane);
+  free(st->frag_pos);
   free(st);
 }
 
@@ -559,6 +794,18 @@ int thip_state_get_geom(const thip_state *st, thip_plane_geom geom[3], int64_t *
   if (nfrags) *nfrags = st->nfrags;
   if (frame_bytes) *frame_bytes = (int64_t)st->frame_bytes;
   return THIP_OK;
+}
+
+int thip_state_get_tiles(const thip_state *st, thip_tile_geom *out) {
+  if (!st || !out) return THIP_EFAULT;
+  *out = st->tiles;
+  return THIP_OK;
+}
+
+int64_t thip_state_frag_pos(const thip_state *st, int64_t fragi) {
+  if (!st) return THIP_EFAULT;
+  if (fragi < 0 || fragi >= st->nfrags) return THIP_EINVAL;
+  return st->frag_pos[fragi];
 }
 
 int thip_state_ref_idx(const thip_state *st, int which) {
@@ -663,16 +910,17 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
                         int32_t *results) {
   BatchK B;
   memset(&B, 0, sizeof(B));
-  int max_wg = 0, max_cells_wg = 0, any_lf = 0, nlive = 0;
+  int max_wg = 0, max_seam_wg = 0, any_lf = 0, nlive = 0;
   int live_state[THIP_MAX_BATCH];
   for (int i = 0; i < n; i++) {
     thip_state *st = states[i];
     const thip_frame_desc &d = descs[i];
     if (!st) return THIP_EFAULT;
-    if (d.ncoded < 0 || d.nuncoded < 0 || (int64_t)d.ncoded + d.nuncoded != st->nfrags) return THIP_EINVAL;
-    if ((d.ncoded && (!d.cmds || !d.coeffs)) || (d.nuncoded && !d.uncoded)) return THIP_EFAULT;
+    if (d.ncoded < 0 || d.nslots < 0 || d.nslots > d.ncoded || d.ncoded > st->nfrags) return THIP_EINVAL;
+    if (d.ncoded && (!d.frag_info || !d.tile_slot0 || (d.nslots && !d.coeffs))) return THIP_EFAULT;
     if (d.flimit < 0 || d.flimit > 127) return THIP_EINVAL;
-    if (d.frame_type == THIP_INTRA_FRAME && d.nuncoded) return THIP_EINVAL;
+    if (d.frame_type != THIP_INTRA_FRAME && d.frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
+    if (d.frame_type == THIP_INTRA_FRAME && d.ncoded != st->nfrags) return THIP_EINVAL;
     // decode.c:2757-2762: an inter frame without references decodes against mid-grey
     if (d.frame_type != THIP_INTRA_FRAME &&
         (st->ref_idx[THIP_FRAME_GOLD] < 0 || st->ref_idx[THIP_FRAME_PREV] < 0)) {
@@ -689,45 +937,37 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     while (bufi == st->ref_idx[THIP_FRAME_GOLD] || bufi == st->ref_idx[THIP_FRAME_PREV]) bufi++;
     st->ref_idx[THIP_FRAME_SELF] = bufi;
     StreamK &K = B.s[nlive];
-    K.cmds = reinterpret_cast<const uint2 *>(d.cmds);
+    K.info = reinterpret_cast<const uint2 *>(d.frag_info);
     K.coeffs = reinterpret_cast<const int4 *>(d.coeffs);
-    K.uncoded = d.uncoded;
+    K.tile_slot0 = d.tile_slot0;
     K.self = st->frames[bufi];
     K.prev = st->ref_idx[THIP_FRAME_PREV] >= 0 ? st->frames[st->ref_idx[THIP_FRAME_PREV]] : st->frames[bufi];
     K.gold = st->ref_idx[THIP_FRAME_GOLD] >= 0 ? st->frames[st->ref_idx[THIP_FRAME_GOLD]] : st->frames[bufi];
-    K.coded_map = st->coded_map;
-    K.ncoded = d.ncoded;
-    K.nuncoded = d.nuncoded;
-    K.nwg_coded = (d.ncoded + 255) / 256;
     K.flimit2 = 2 * d.flimit;
     K.debug = g_debug;
     K.qpx = st->hdec;
     K.qpy = st->vdec;
-    int cells = 0;
+    fill_stream_geom(K, st);
     for (int pli = 0; pli < 3; pli++) {
-      fill_plane_k(K.pl[pli], st->geom[pli]);
-      cells += (st->geom[pli].nhfrags + 1) * (st->geom[pli].nvfrags + 1);
-      (pli == 0 ? K.cell_end0 : pli == 1 ? K.cell_end1 : K.cell_end2) = cells;
       K.lf_y0[pli] = st->lf_rows_custom ? st->lf_y0[pli] : 0;
       K.lf_y1[pli] = st->lf_rows_custom ? st->lf_y1[pli] : st->geom[pli].nvfrags;
     }
-    const int wg = K.nwg_coded + (d.nuncoded + 255) / 256;
-    if (wg > max_wg) max_wg = wg;
+    if ((K.seg_end[2] + 3) / 4 > max_wg) max_wg = (K.seg_end[2] + 3) / 4;
     if (d.flimit) {
       any_lf = 1;
-      const int cwg = (cells + 255) / 256;
-      if (cwg > max_cells_wg) max_cells_wg = cwg;
+      const int swg = (K.seam_end[2] + 255) / 256;
+      if (swg > max_seam_wg) max_seam_wg = swg;
     }
     live_state[nlive++] = i;
   }
   if (!nlive) return THIP_OK;
   {
-    ScopedTimer t(s, THIP_KERNEL_RECON);
-    hipLaunchKernelGGL(k_recon, dim3(max_wg, nlive), dim3(256), 0, s, B);
+    ScopedTimer t(s, THIP_KERNEL_FRAME);
+    hipLaunchKernelGGL(k_frame, dim3(max_wg, nlive), dim3(256), 0, s, B);
   }
   if (any_lf) {
-    ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
-    hipLaunchKernelGGL(k_loopfilter, dim3(max_cells_wg, nlive), dim3(256), 0, s, B);
+    ScopedTimer t(s, THIP_KERNEL_SEAM);
+    hipLaunchKernelGGL(k_seam, dim3(max_seam_wg, nlive), dim3(256), 0, s, B);
   }
   HIP_TRY(hipGetLastError());
   // decode.c:2947-2962
@@ -795,8 +1035,8 @@ int thip_loop_filter_plane(uint8_t *plane, int ystride, int nhfrags, int nvfrags
     return THIP_EINVAL;
   if (flimit == 0) return THIP_OK;
   const int64_t cells = (int64_t)(nhfrags + 1) * (nvfrags + 1);
-  hipLaunchKernelGGL(k_loopfilter_plane, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, plane, ystride, nhfrags, nvfrags,
-                     coded, 2 * flimit, fragy0, fragy_end, 1.0f / (float)(nhfrags + 1));
+  hipLaunchKernelGGL(k_loopfilter_plane, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, plane, ystride,
+                     nhfrags, nvfrags, coded, 2 * flimit, fragy0, fragy_end, 1.0f / (float)(nhfrags + 1));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   return THIP_OK;
@@ -807,14 +1047,16 @@ int thip_loop_filter_plane(uint8_t *plane, int ystride, int nhfrags, int nvfrags
 // ---------------------------------------------------------------------------------------
 static int ensure_staging(thip_state *st) {
   if (st->staging_ready) return THIP_OK;
-  const size_t n = (size_t)st->nfrags;
-  const size_t ntiles = (n + THIP_TILE_BLOCKS - 1) / THIP_TILE_BLOCKS;
-  HIP_TRY(hipHostMalloc((void **)&st->h_cmds, n * 8, hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void **)&st->h_coeffs, ntiles * THIP_TILE_BYTES, hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void **)&st->h_uncoded, n * 4, hipHostMallocDefault));
-  HIP_TRY(hipMalloc((void **)&st->d_cmds, n * 8));
-  HIP_TRY(hipMalloc((void **)&st->d_coeffs, ntiles * THIP_TILE_BYTES));
-  HIP_TRY(hipMalloc((void **)&st->d_uncoded, n * 4));
+  const size_t npos = (size_t)st->tiles.ntiles * THIP_TILE_FRAGS;
+  const size_t ngroups = ((size_t)st->nfrags + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
+  HIP_TRY(hipHostMalloc((void **)&st->h_info, npos * 8, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&st->h_coeffs, ngroups * THIP_SLOT_GROUP_BYTES, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&st->h_slot0, (size_t)st->tiles.ntiles * 4, hipHostMallocDefault));
+  HIP_TRY(hipMalloc((void **)&st->d_info, npos * 8));
+  HIP_TRY(hipMalloc((void **)&st->d_coeffs, ngroups * THIP_SLOT_GROUP_BYTES));
+  HIP_TRY(hipMalloc((void **)&st->d_slot0, (size_t)st->tiles.ntiles * 4));
+  st->enq_last_lane = (int32_t *)malloc(sizeof(int32_t) * (size_t)st->tiles.ntiles);
+  if (!st->enq_last_lane) return THIP_EFAULT;
   st->staging_ready = 1;
   return THIP_OK;
 }
@@ -827,7 +1069,11 @@ int thip_frame_begin(thip_state *st, int frame_type) {
   // the previous frame's upload must have drained before the staging buffers are reused
   rc = thip_synchronize();
   if (rc) return rc;
-  st->enq_ncoded = st->enq_nuncoded = 0;
+  memset(st->h_info, 0, (size_t)st->tiles.ntiles * THIP_TILE_FRAGS * 8);   // everything uncoded
+  memset(st->h_slot0, 0, (size_t)st->tiles.ntiles * 4);
+  for (int t = 0; t < st->tiles.ntiles; t++) st->enq_last_lane[t] = -1;
+  st->enq_ncoded = st->enq_nuncoded = st->enq_nslots = 0;
+  st->enq_last_tile = -1;
   st->enq_frame_type = frame_type;
   st->enq_flimit = 0;
   st->enq_lf_any = 0;
@@ -845,33 +1091,45 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
   if (!st->enq_active || fragi < 0 || fragi >= st->nfrags || pli < 0 || pli > 2 || refi < 0 || refi > 2 ||
       last_zzi < 0 || last_zzi > 64 || (int64_t)st->enq_ncoded + st->enq_nuncoded >= st->nfrags)
     return THIP_EINVAL;
-  const int slot = st->enq_ncoded++;
-  uint32_t flags = (uint32_t)refi | ((uint32_t)last_zzi << THIP_CMD_LAST_ZZI_SHIFT) |
-                   ((uint32_t)(uint8_t)(mv & 0xFF) << THIP_CMD_MVX_SHIFT) |
-                   ((uint32_t)(uint8_t)((mv >> 8) & 0xFF) << THIP_CMD_MVY_SHIFT);
-  // tile layout (theora_hip.h): 16-byte group q = 2*j+h of the block holds, for columns
-  // c = 4h..4h+3, the int16 pairs { x[2j][c], x[2j+1][c] }
-  int16_t *tile = st->h_coeffs + (size_t)(slot >> 6) * (THIP_TILE_BYTES / 2) + (size_t)(slot & 63) * 8;
+  const int32_t pos = st->frag_pos[fragi];
+  if (st->h_info[2 * (size_t)pos] & THIP_INFO_CODED) return THIP_EINVAL;   // fragment enqueued twice
+  uint32_t flags = THIP_INFO_CODED | ((uint32_t)refi << THIP_INFO_REFI_SHIFT) |
+                   ((uint32_t)last_zzi << THIP_INFO_LAST_ZZI_SHIFT) |
+                   ((uint32_t)(uint8_t)(mv & 0xFF) << THIP_INFO_MVX_SHIFT) |
+                   ((uint32_t)(uint8_t)((mv >> 8) & 0xFF) << THIP_INFO_MVY_SHIFT);
+  uint32_t word1 = 0;
   if (last_zzi < 2) {
-    // state.c:967-975: the only rounded dequantisation of the path
-    flags |= THIP_CMD_DC_ONLY;
-    const int16_t p = (int16_t)((dct_coeffs[0] * (int32_t)dc_quant + 15) >> 5);
-    for (int q = 0; q < 8; q++) memset(tile + (size_t)q * 512, 0, 16);
-    tile[0] = p;
+    // state.c:967-975: the only rounded dequantisation of the path; no coefficient slot
+    flags |= THIP_INFO_DC_ONLY;
+    word1 = (uint32_t)(uint16_t)(int16_t)((dct_coeffs[0] * (int32_t)dc_quant + 15) >> 5);
   } else {
+    // Slots are handed out in arrival order, which for the reference's caller is coded
+    // order == tile/lane order (decode.c:1530-1586); the kernel re-derives a lane's slot
+    // from the tile's first slot and a prefix count, so arrival must not jump backwards
+    // inside a tile.
+    const int tile = pos / THIP_TILE_FRAGS, lane = pos % THIP_TILE_FRAGS;
+    if (lane <= st->enq_last_lane[tile]) return THIP_EINVAL;
+    if (st->enq_last_lane[tile] < 0) st->h_slot0[tile] = (uint32_t)st->enq_nslots;
+    else if (st->enq_last_tile != tile) return THIP_EINVAL;   // a tile's slots must be contiguous
+    st->enq_last_lane[tile] = lane;
+    st->enq_last_tile = tile;
+    const int slot = st->enq_nslots++;
     dct_coeffs[0] = (int16_t)(dct_coeffs[0] * (int)dc_quant);   // state.c:978
+    // piece q = 2*j+h of the block: columns c = 4h..4h+3 as pairs { x[2j][c], x[2j+1][c] }
+    int16_t *blk = st->h_coeffs + (size_t)(slot >> 6) * (THIP_SLOT_GROUP_BYTES / 2) + (size_t)(slot & 63) * 8;
     for (int j = 0; j < 4; j++)
-      for (int h = 0; h < 2; h++) {
-        int16_t *g = tile + (size_t)(2 * j + h) * 512;
+      for (int hh = 0; hh < 2; hh++) {
+        int16_t *g = blk + (size_t)(2 * j + hh) * 512;
         for (int cc = 0; cc < 4; cc++) {
-          g[2 * cc] = dct_coeffs[(2 * j) * 8 + 4 * h + cc];
-          g[2 * cc + 1] = dct_coeffs[(2 * j + 1) * 8 + 4 * h + cc];
+          g[2 * cc] = dct_coeffs[(2 * j) * 8 + 4 * hh + cc];
+          g[2 * cc + 1] = dct_coeffs[(2 * j + 1) * 8 + 4 * hh + cc];
         }
       }
   }
   memset(dct_coeffs, 0, 64 * sizeof(int16_t));   // idct.c:245,276,295
-  st->h_cmds[2 * (size_t)slot] = (uint32_t)fragi;
-  st->h_cmds[2 * (size_t)slot + 1] = flags;
+  st->h_info[2 * (size_t)pos] = flags;
+  st->h_info[2 * (size_t)pos + 1] = word1;
+  st->enq_ncoded++;
   return THIP_OK;
 }
 
@@ -881,8 +1139,10 @@ int thip_frag_copy_list(thip_state *st, const ptrdiff_t *fragis, ptrdiff_t nfrag
     return THIP_EINVAL;
   for (ptrdiff_t k = 0; k < nfragis; k++) {
     if (fragis[k] < 0 || fragis[k] >= st->nfrags) return THIP_EINVAL;
-    st->h_uncoded[st->enq_nuncoded++] = (uint32_t)fragis[k];
+    // an uncoded fragment is the default state of its command word; nothing to stage
+    if (st->h_info[2 * (size_t)st->frag_pos[fragis[k]]] & THIP_INFO_CODED) return THIP_EINVAL;
   }
+  st->enq_nuncoded += (int)nfragis;
   return THIP_OK;
 }
 
@@ -919,27 +1179,30 @@ int thip_frame_flush(thip_state *st) {
   if (!st) return THIP_EFAULT;
   if (!st->enq_active) return THIP_EINVAL;
   st->enq_active = 0;
+  // every fragment must have been reconstructed or copied exactly once
+  if (st->enq_ncoded && (int64_t)st->enq_ncoded + st->enq_nuncoded != st->nfrags) return THIP_EINVAL;
   int rc = ensure_lanes();
   if (rc) return rc;
   {
     std::lock_guard<std::mutex> lk(g_mu);
     if (st->lane < 0) st->lane = g_next_lane++ % g_nlanes;
   }
-  hipStream_t g_stream = g_lanes[st->lane];
-  const size_t ntiles = ((size_t)st->enq_ncoded + THIP_TILE_BLOCKS - 1) / THIP_TILE_BLOCKS;
+  hipStream_t s = g_lanes[st->lane];
+  const size_t ngroups = ((size_t)st->enq_nslots + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
   if (st->enq_ncoded) {
-    HIP_TRY(hipMemcpyAsync(st->d_cmds, st->h_cmds, (size_t)st->enq_ncoded * 8, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipMemcpyAsync(st->d_coeffs, st->h_coeffs, ntiles * THIP_TILE_BYTES, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(st->d_info, st->h_info, (size_t)st->tiles.ntiles * THIP_TILE_FRAGS * 8,
+                           hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(st->d_slot0, st->h_slot0, (size_t)st->tiles.ntiles * 4, hipMemcpyHostToDevice, s));
+    if (ngroups)
+      HIP_TRY(hipMemcpyAsync(st->d_coeffs, st->h_coeffs, ngroups * THIP_SLOT_GROUP_BYTES, hipMemcpyHostToDevice, s));
   }
-  if (st->enq_nuncoded)
-    HIP_TRY(hipMemcpyAsync(st->d_uncoded, st->h_uncoded, (size_t)st->enq_nuncoded * 4, hipMemcpyHostToDevice, g_stream));
   thip_frame_desc d;
   memset(&d, 0, sizeof(d));
-  d.cmds = st->d_cmds;
+  d.frag_info = st->d_info;
   d.coeffs = st->d_coeffs;
-  d.uncoded = st->d_uncoded;
+  d.tile_slot0 = st->d_slot0;
+  d.nslots = st->enq_nslots;
   d.ncoded = st->enq_ncoded;
-  d.nuncoded = st->enq_nuncoded;
   d.frame_type = st->enq_frame_type;
   d.flimit = st->enq_lf_any ? st->enq_flimit : 0;
   st->lf_rows_custom = st->enq_lf_any;

@@ -47,6 +47,21 @@ class Geometry:
             sx = 1 if (p == 0 or not self.hdec) else 0
             mb.append((fy >> sy) * self.nhmb + (fx >> sx))
         self.mb_of = np.concatenate(mb)
+        # work tiles of the device (include/theora_hip.h): 4 super blocks of one SB row
+        self.tiles_x = [(self.nh[p] + 15) // 16 for p in range(3)]
+        self.tiles_y = [(self.nv[p] + 3) // 4 for p in range(3)]
+        self.tile_off = [0, self.tiles_x[0] * self.tiles_y[0],
+                         self.tiles_x[0] * self.tiles_y[0] + self.tiles_x[1] * self.tiles_y[1]]
+        self.ntiles = self.tile_off[2] + self.tiles_x[2] * self.tiles_y[2]
+        hinv = np.zeros((4, 4), np.int64)
+        for k, (r, c) in enumerate(_HILBERT_RC):
+            hinv[r, c] = k
+        pos = []
+        for p in range(3):
+            by, bx = np.divmod(np.arange(self.pl_nfrags[p]), self.nh[p])
+            pos.append((self.tile_off[p] + (by >> 2) * self.tiles_x[p] + (bx >> 4)) * 64
+                       + ((bx >> 2) & 3) * 16 + hinv[by & 3, bx & 3])
+        self.frag_pos = np.concatenate(pos)       # raster fragment index -> tile*64+lane
 
     def _sb_order(self, pli):
         nh, nv = self.nh[pli], self.nv[pli]
@@ -167,14 +182,20 @@ def gen_frame(geom, rng, frame_type, content="mixed", flimit=None, global_mv=Non
                 coeffs=coeffs, last_zzi=last_zzi, dc_quant=dc_quant.astype(np.uint16), flimit=flimit)
 
 
-def pack_frame(frame):
+def pack_frame(geom, frame):
     """numpy command stream -> the device layout of include/theora_hip.h (host arrays)."""
-    from . import cmd_words, dequant_dc, pack_tiles
+    from . import dequant_dc, info_words, pack_tiles
     cf = frame["coded_fragis"]
-    cmds = cmd_words(cf, frame["refi"][cf], frame["last_zzi"], frame["mvx"][cf], frame["mvy"][cf])
-    tiles = pack_tiles(dequant_dc(frame["coeffs"], frame["last_zzi"], frame["dc_quant"]))
-    return dict(cmds=cmds, coeffs=tiles, uncoded=frame["uncoded_fragis"].astype(np.uint32),
-                ncoded=int(cf.size), nuncoded=int(frame["uncoded_fragis"].size),
+    pos = geom.frag_pos[cf]
+    assert (np.diff(pos) > 0).all(), "coded order must equal tile/lane order"
+    lz = frame["last_zzi"]
+    co = dequant_dc(frame["coeffs"], lz, frame["dc_quant"])
+    has = lz >= 2
+    info = info_words(geom.ntiles * 64, pos, frame["refi"][cf], lz, frame["mvx"][cf], frame["mvy"][cf], co[:, 0])
+    # first slot of every tile: number of coefficient-carrying fragments in earlier tiles
+    per_tile = np.bincount(pos[has] >> 6, minlength=geom.ntiles)
+    slot0 = np.concatenate([[0], np.cumsum(per_tile)[:-1]]).astype(np.uint32)
+    return dict(info=info, coeffs=pack_tiles(co[has]), slot0=slot0, nslots=int(has.sum()), ncoded=int(cf.size),
                 frame_type=frame["frame_type"], flimit=frame["flimit"])
 
 
@@ -188,12 +209,12 @@ def upload_frame(packed, device="cuda"):
         if a.size == 0:
             return None
         return torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(device)
-    cmds = dev(packed["cmds"].reshape(-1), np.int32)
+    info = dev(packed["info"].reshape(-1), np.int32)
     coeffs = dev(packed["coeffs"], np.int16)
-    unc = dev(packed["uncoded"], np.int32)
-    desc = make_desc(cmds, coeffs, unc, packed["ncoded"], packed["nuncoded"], packed["frame_type"],
+    slot0 = dev(packed["slot0"], np.int32)
+    desc = make_desc(info, coeffs, slot0, packed["nslots"], packed["ncoded"], packed["frame_type"],
                      packed["flimit"])
-    return desc, (cmds, coeffs, unc)
+    return desc, (info, coeffs, slot0)
 
 
 def algorithmic_bytes(geom, frame):
