@@ -138,8 +138,7 @@ typedef struct thip_frame_desc {
 
 /* One frame of each of nstreams independent streams, all inputs resident in HBM:
    reconstruct coded fragments (oc_state_frag_recon, state.c:959), copy uncoded ones
-   (fragment.c:37), run the in-loop filter over the whole frame (state.c:1055; fused into
-   the reconstruction kernel except for the cells on strip seams) and rotate
+   (fragment.c:37), run the in-loop filter over the whole frame (state.c:1055) and rotate
    each stream's reference ring (decode.c:2790-2794, 2947-2962).  Asynchronous on
    `stream` (a hipStream_t, or NULL for the library's own stream).
    results[i] (optional, host) receives 0 or THIP_DUPFRAME per stream. */
@@ -228,8 +227,8 @@ int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n);
  * Measurement support for bench.py: HIP-event timing of the kernels of
  * thip_decode_frames on the stream they run on.
  * ---------------------------------------------------------------------------------- */
-#define THIP_KERNEL_FRAME 0 /* k_frame: recon + copy + loop filter inside strips */
-#define THIP_KERNEL_SEAM 1  /* k_seam: loop-filter cells on strip seams and frame edges */
+#define THIP_KERNEL_RECON 0      /* k_recon: reconstruction + uncoded copy */
+#define THIP_KERNEL_LOOPFILTER 1 /* k_loopfilter: in-loop deblocking */
 #define THIP_NKERNELS 2
 int thip_profile_enable(int on);
 /* Sums since the last reset: launches and milliseconds per kernel (synchronises). */

@@ -16,7 +16,7 @@ MAX_BATCH = 8
 TILE_FRAGS = 64
 SLOT_GROUP, SLOT_GROUP_BYTES = 64, 8192
 INFO_CODED, INFO_DC_ONLY = 0x1, 0x8
-KERNEL_FRAME, KERNEL_SEAM, NKERNELS = 0, 1, 2
+KERNEL_RECON, KERNEL_LOOPFILTER, NKERNELS = 0, 1, 2
 
 ENC_OPS = dict(sad=0, sad_thresh=1, sad2_thresh=2, intra_sad=3, satd=4, satd2=5, intra_satd=6, ssd=7)
 

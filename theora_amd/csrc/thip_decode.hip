@@ -2,19 +2,21 @@
 //
 // Two kernels per batch of frames (one 8x8 block per lane, wave64, 256-thread workgroups):
 //
-//   k_frame  A workgroup owns a SEGMENT of a strip: a few consecutive tiles (16 super
-//            blocks = 64x4 fragments = 512x32 pixels each) of one super-block row of one
-//            plane, and walks them left to right.  Per tile: every lane takes one fragment in
-//            coded order (super block by super block, Hilbert inside), finds its coefficient
-//            slot with a ballot/prefix count over the coded mask, runs dequantised
-//            coefficients -> iDCT -> predictor -> pixels (state.c:959, idct.c:301,
-//            fragment.c:49-80) or copies the fragment from PREV (fragment.c:37), and puts the
-//            8x8 result into an LDS image of the tile.  The in-loop filter (state.c:1055)
-//            then runs on that LDS image for every filter cell that lies inside the strip,
-//            and the tile is streamed out to HBM once.
-//   k_seam   The remaining filter cells -- those on the horizontal seams between strips,
-//            on the few vertical seams between segments and on the frame's top/bottom edge
-//            -- directly on the frame in HBM (a quarter of the rows).
+//   k_recon       K1+K2.  One wave per TILE (4 super blocks = 16x4 fragments = 128x32 pixels),
+//                 lanes in coded order (super block by super block, Hilbert inside).  A lane
+//                 reads its fragment's command word, finds its coefficient slot with a
+//                 ballot / prefix count over the tile's coded mask, and either reconstructs
+//                 (dequantised coefficients -> iDCT -> predictor -> pixels; state.c:959,
+//                 idct.c:301, fragment.c:49-80) or copies the fragment from PREV
+//                 (fragment.c:37).  DC-only fragments carry their value in the command word
+//                 and own no coefficient slot.
+//   k_loopfilter  K3.  Whole-frame in-loop deblocking (state.c:1055-1105), one 8x8 "corner
+//                 cell" per lane; cells are independent, so the pass is fully parallel.
+//
+// A fused variant (reconstruct into an LDS image of a strip, filter there, write once) was
+// built and measured: bit-exact but slower -- these kernels are latency/occupancy bound at
+// the frame sizes involved, so extra in-kernel phases cost more than the saved traffic
+// (DESIGN.md section 5).
 //
 // K4 (UMV border fill, state.c:770-835) does not exist: device frames are unpadded and
 // motion-compensated reads clamp their coordinates, which is bit-identical.
@@ -71,10 +73,8 @@ struct PlaneK {
   int off;           // byte offset of the plane in a frame
   int tiles_x;       // tiles across
   int tile_off;      // index of the plane's first tile
-  int segs_x;        // workgroups (segments) per strip
-  int seam_rows;     // filter-cell rows handled by k_seam
-  int vseams;        // vertical segment seams per strip
-  int vrows;         // interior cell rows that are NOT seam rows (for the vertical seams)
+  int fro;           // raster index of the plane's first fragment
+  float rcp_cx;      // 1/(nh+1)
 };
 
 struct StreamK {
@@ -84,11 +84,11 @@ struct StreamK {
   uint8_t *self;
   const uint8_t *prev;
   const uint8_t *gold;
+  uint8_t *coded_map;     // 1 byte per fragment, raster order: written by k_recon, read by k_loopfilter
   int flimit2;            // 2*flimit
   int qpx, qpy;           // chroma axis decimated (quarter-pel chroma vectors)
-  int seg_tiles;          // tiles per segment
-  int seg_end[3];         // cumulative k_frame workgroup counts per plane
-  int seam_end[3];        // cumulative k_seam cell counts per plane
+  int tile_end[3];        // cumulative tile counts per plane (k_recon: one wave per tile)
+  int cell_end[3];        // cumulative filter-cell counts per plane (k_loopfilter)
   int lf_y0[3], lf_y1[3]; // fragment-row range whose filter operations are applied
   int debug;              // ablation switches for profiling (THIP_DEBUG env), 0 in production
   PlaneK pl[3];
@@ -181,25 +181,39 @@ __device__ __forceinline__ void unpack_row(int *P, uint32_t lo, uint32_t hi) {
   }
 }
 
-// A cell directly on a plane in memory (k_seam, thip_loop_filter_plane).
-__device__ __forceinline__ void lf_cell_global(uint8_t *plane, int stride, int nh, int nv, int k, int m,
-                                               uint32_t t, int L2) {
+// A cell directly on a plane in memory (k_loopfilter, thip_loop_filter_plane).  The pixel
+// loads do not depend on the coded flags, so they are issued first and the flag loads
+// overlap them (one memory latency instead of two); cells without work simply skip the
+// stores.
+struct CellPix {
+  uint32_t lo[8], hi[8];
+};
+__device__ __forceinline__ void lf_cell_load(CellPix &C, const uint8_t *plane, int stride, int nh, int nv, int k,
+                                             int m) {
+  const bool lo_ok = k >= 1, hi_ok = k <= nh - 1;
+  const uint8_t *base = plane + (ptrdiff_t)(8 * m - 4) * stride + (8 * k - 4);
+  const int H = nv * 8;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int y = 8 * m - 4 + r;
+    C.lo[r] = 0;
+    C.hi[r] = 0;
+    if (y >= 0 && y < H) {
+      const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)r * stride);
+      if (lo_ok) C.lo[r] = p[0];
+      if (hi_ok) C.hi[r] = p[1];
+    }
+  }
+}
+__device__ __forceinline__ void lf_cell_finish(const CellPix &C, uint8_t *plane, int stride, int nh, int nv, int k,
+                                               int m, uint32_t t, int L2) {
   if (!t) return;
   const bool lo_ok = k >= 1, hi_ok = k <= nh - 1;
   uint8_t *base = plane + (ptrdiff_t)(8 * m - 4) * stride + (8 * k - 4);
   const int H = nv * 8;
   int P[64];
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const int y = 8 * m - 4 + r;
-    uint32_t lo = 0, hi = 0;
-    if (y >= 0 && y < H) {
-      const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)r * stride);
-      if (lo_ok) lo = p[0];
-      if (hi_ok) hi = p[1];
-    }
-    unpack_row(P + r * 8, lo, hi);
-  }
+  for (int r = 0; r < 8; r++) unpack_row(P + r * 8, C.lo[r], C.hi[r]);
   lf_cell_apply(P, t, L2);
 #pragma unroll
   for (int r = 0; r < 8; r++) {
@@ -213,34 +227,8 @@ __device__ __forceinline__ void lf_cell_global(uint8_t *plane, int stride, int n
 }
 
 // ---------------------------------------------------------------------------------------
-// k_frame
+// k_recon (K1 + K2): one wave per tile, one fragment per lane, in coded order
 // ---------------------------------------------------------------------------------------
-// Every WAVE is autonomous (no workgroup barriers): it owns a segment -- a run of
-// consecutive tiles (4 super blocks = 16x4 fragments = 128x32 pixels) of one super-block
-// row -- and walks it left to right, software-pipelined: the loads of tile i are in flight
-// while tile i-1 is filtered in LDS and streamed out.
-//
-// LDS image of one tile: 32 rows x (4 carried columns + 128 + slack).  Column cx holds pixel
-// x = tile_x0 - 4 + cx, so filter cell k (pixels 8k-4..8k+3 of the tile) is the
-// 8-byte-aligned group cx = 8k..8k+7.  Two images per wave: tile i is built while tile i-1
-// drains.
-constexpr int kTilePitch = 144;
-constexpr int kTileRows = 32;
-constexpr int kFlagCols = 20;   // [row][0] = last block column of the previous tile, [row][1+bxl]
-
-struct TileLds {
-  uint8_t pix[kTileRows * kTilePitch];
-  uint8_t coded[4 * kFlagCols];
-  uint8_t pad_[16 - (4 * kFlagCols) % 16];
-};
-
-__device__ __forceinline__ void wave_sync() {
-  // LDS traffic between lanes of ONE wave: the hardware executes a wave's DS operations in
-  // order; this only stops the compiler from moving them across the phase boundary.
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // residual of this lane's block as eight rows of packed int16 pairs
 __device__ __forceinline__ void load_slot(const int4 *coeffs, uint32_t slot, uint32_t P[32]) {
   const int4 *tp = coeffs + ((size_t)(slot >> 6) * 512 + (slot & 63));
@@ -255,45 +243,47 @@ __device__ __forceinline__ void load_slot(const int4 *coeffs, uint32_t slot, uin
 }
 
 // Predictor of an inter block (fragment.c:59-80 with the offsets of state.c:846-957): one
-// reference block or the truncating average of two.  Split in two so the loads can be in
-// flight across other work: *_issue starts them, *_finish turns them into 8 rows of 8 bytes.
-struct PredFetch {
-  Row12 w[9];
-  int offA, offB, ra, rb;
-  bool two, inside;
-};
-
-__device__ __forceinline__ void predictor_issue(PredFetch &F, const uint8_t *ref, int stride, int W, int H,
-                                                int x0, int y0, uint32_t flags, bool qpx, bool qpy,
-                                                uint2 pred[8]) {
+// reference block or the truncating average of two.
+__device__ __forceinline__ void fetch_predictor(const uint8_t *ref, int stride, int W, int H, int x0, int y0,
+                                                uint32_t flags, bool qpx, bool qpy, uint2 pred[8]) {
   const int dx = (int)(int8_t)(flags >> THIP_INFO_MVX_SHIFT);
   const int dy = (int)(int8_t)(flags >> THIP_INFO_MVY_SHIFT);
   int mx, my, mx2, my2;
   mv_axis(dx, qpx, mx, mx2);
   mv_axis(dy, qpy, my, my2);
   const int sx = x0 + mx, sy = y0 + my;
-  F.two = (mx2 | my2) != 0;
-  F.inside = sx + min(mx2, 0) >= 0 && sx + max(mx2, 0) + 8 <= W && sy + min(my2, 0) >= 0 &&
-             sy + max(my2, 0) + 8 <= H;
-  if (F.inside) {
+  const bool two = (mx2 | my2) != 0;
+  const bool inside = sx + min(mx2, 0) >= 0 && sx + max(mx2, 0) + 8 <= W && sy + min(my2, 0) >= 0 &&
+                      sy + max(my2, 0) + 8 <= H;
+  if (inside) {
     // Both samples of a row lie in the 9 bytes starting at xs, i.e. inside one 12-byte
     // window aligned down to 4: one dword-aligned dwordx3 load per source row and byte
     // funnel shifts.  Vertical half-pel needs 9 source rows, not 16.
     const int xs = sx + min(mx2, 0);
     const int xw = xs & ~3;
-    F.offA = sx - xw;
-    F.offB = sx + mx2 - xw;   // 0..4
+    const int offA = sx - xw, offB = sx + mx2 - xw;  // 0..4
     const int ys = sy + min(my2, 0);
-    F.ra = sy - ys;
-    F.rb = sy + my2 - ys;     // first source row of each sample: 0 or 1
+    const int ra = sy - ys, rb = sy + my2 - ys;      // first source row of each sample: 0 or 1
     const uint8_t *p1 = ref + (ptrdiff_t)ys * stride + xw;
+    Row12 w[9];
 #pragma unroll
-    for (int r = 0; r < 8; r++) F.w[r] = load_row12(p1 + (ptrdiff_t)r * stride);
-    F.w[8] = F.w[7];
-    if (my2 != 0) F.w[8] = load_row12(p1 + (ptrdiff_t)8 * stride);
+    for (int r = 0; r < 8; r++) w[r] = load_row12(p1 + (ptrdiff_t)r * stride);
+    w[8] = w[7];
+    if (my2 != 0) w[8] = load_row12(p1 + (ptrdiff_t)8 * stride);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const Row12 wa = ra ? w[r + 1] : w[r];
+      pred[r] = extract8(wa, offA);
+      if (two) {
+        const Row12 wb = rb ? w[r + 1] : w[r];
+        const uint2 b = extract8(wb, offB);
+        pred[r].x = avg4_trunc(pred[r].x, b.x);
+        pred[r].y = avg4_trunc(pred[r].y, b.y);
+      }
+    }
   } else {
     // the block reaches into the reference's UMV border: clamp every coordinate
-    // (== replicated padding, state.c:770-835); rare, done on the spot
+    // (== replicated padding, state.c:770-835)
 #pragma unroll 1
     for (int r = 0; r < 8; r++) {
       const int ya = min(max(sy + r, 0), H - 1);
@@ -303,7 +293,7 @@ __device__ __forceinline__ void predictor_issue(PredFetch &F, const uint8_t *ref
       for (int c = 0; c < 8; c++) {
         const int xa = min(max(sx + c, 0), W - 1);
         int v = ref[(ptrdiff_t)ya * stride + xa];
-        if (F.two) {
+        if (two) {
           const int xb = min(max(sx + mx2 + c, 0), W - 1);
           v = (v + ref[(ptrdiff_t)yb * stride + xb]) >> 1;
         }
@@ -316,253 +306,124 @@ __device__ __forceinline__ void predictor_issue(PredFetch &F, const uint8_t *ref
   }
 }
 
-__device__ __forceinline__ void predictor_finish(const PredFetch &F, uint2 pred[8]) {
-  if (!F.inside) return;
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const Row12 wa = F.ra ? F.w[r + 1] : F.w[r];
-    pred[r] = extract8(wa, F.offA);
-    if (F.two) {
-      const Row12 wb = F.rb ? F.w[r + 1] : F.w[r];
-      const uint2 b = extract8(wb, F.offB);
-      pred[r].x = avg4_trunc(pred[r].x, b.x);
-      pred[r].y = avg4_trunc(pred[r].y, b.y);
-    }
-  }
-}
-
-// In-loop filter on the cells inside the strip for one finished tile image, then stream
-// the tile out: pixels x0-4 .. x0+3 of every block (the four columns right of the last
-// block wait for the next tile's cell 0, or go out now if the segment ends here).
-__device__ __forceinline__ void filter_and_store(TileLds &T, const StreamK &S, uint8_t *selfp, int lane,
-                                                 int tx, int sby, int nh, int nv, int stride, bool first,
-                                                 bool last, int fy0, int fy1, int hr, int bxl, int by) {
-  const int nbx = min(16, nh - tx * 16);   // valid block columns in this tile
-  if (S.flimit2 != 0 && lane < 51 && !(S.debug & 16)) {
-    // cells (kl, ml): kl = 0..16 across, ml = 1..3 between the strip's block rows
-    const int ml = 1 + lane / 17, kl = lane - (ml - 1) * 17;
-    const int kg = tx * 16 + kl, mg = sby * 4 + ml;
-    // kl == 0: the seam to the previous segment belongs to k_seam (unless it is the frame
-    // edge); kl == nbx: only the plane's right edge is filtered here, otherwise the cell is
-    // the next tile's kl == 0.
-    const bool mine = mg <= nv - 1 && (kl >= 1 || !first || kg == 0) && (kl < nbx || (kl == nbx && kg == nh));
-    if (mine) {
-      const bool a = T.coded[(ml - 1) * kFlagCols + kl] != 0, b = T.coded[(ml - 1) * kFlagCols + kl + 1] != 0;
-      const bool c = T.coded[ml * kFlagCols + kl] != 0, d = T.coded[ml * kFlagCols + kl + 1] != 0;
-      const uint32_t t = lf_cell_ops(kg, mg, nh, nv, a, b, c, d, fy0, fy1);
-      if (t) {
-        uint8_t *cp = T.pix + (ml * 8 - 4) * kTilePitch + kl * 8;
-        int Cc[64];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-          const uint2 v = *reinterpret_cast<const uint2 *>(cp + r * kTilePitch);
-          unpack_row(Cc + r * 8, v.x, v.y);
-        }
-        lf_cell_apply(Cc, t, S.flimit2);
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-          *reinterpret_cast<uint2 *>(cp + r * kTilePitch) =
-              make_uint2(pack4(Cc[r * 8 + 0], Cc[r * 8 + 1], Cc[r * 8 + 2], Cc[r * 8 + 3]),
-                         pack4(Cc[r * 8 + 4], Cc[r * 8 + 5], Cc[r * 8 + 6], Cc[r * 8 + 7]));
-      }
-    }
-  }
-  wave_sync();
-  const int bx = tx * 16 + bxl;
-  if (bx < nh && by < nv && !(S.debug & 4)) {
-    const uint8_t *src = T.pix + (hr * 8) * kTilePitch + bxl * 8;
-    uint8_t *dst = selfp + (ptrdiff_t)(by * 8) * stride + bx * 8 - 4;
-    const bool lo_ok = !(first && bxl == 0);   // left of the segment: not ours
-    const bool tail = last && bxl == nbx - 1;    // segment ends: flush the last 4 px
-    struct __attribute__((packed, aligned(4))) U2 { uint32_t x, y; };
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const uint2 v = *reinterpret_cast<const uint2 *>(src + r * kTilePitch);
-      uint8_t *d = dst + (ptrdiff_t)r * stride;
-      if (lo_ok) {
-        U2 u;
-        u.x = v.x;
-        u.y = v.y;
-        *reinterpret_cast<U2 *>(d) = u;          // 4-byte-aligned dwordx2 store
-      } else {
-        reinterpret_cast<uint32_t *>(d)[1] = v.y;
-      }
-      if (tail) reinterpret_cast<uint32_t *>(d)[2] = *reinterpret_cast<const uint32_t *>(src + r * kTilePitch + 8);
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_frame(const BatchK B) {
-  __shared__ __attribute__((aligned(16))) TileLds lds_all[4][2];
+#ifndef THIP_RECON_WAVES
+#define THIP_RECON_WAVES 4
+#endif
+__global__ __launch_bounds__(256, THIP_RECON_WAVES) void k_recon(const BatchK B) {
   const StreamK &S = B.s[blockIdx.y];
-  const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
-  const int unit = (int)blockIdx.x * 4 + wv;   // this wave's segment
-  if (unit >= S.seg_end[2]) return;             // whole waves leave; no barriers are used below
-  const int pli = (unit >= S.seg_end[0] ? 1 : 0) + (unit >= S.seg_end[1] ? 1 : 0);
+  const int lane = (int)threadIdx.x & 63;
+  const int unit = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);   // this wave's tile, per plane
+  if (unit >= S.tile_end[2]) return;
+  const int pli = (unit >= S.tile_end[0] ? 1 : 0) + (unit >= S.tile_end[1] ? 1 : 0);
   const PlaneK &G = S.pl[pli];
-  const int rel = unit - (pli == 0 ? 0 : (pli == 1 ? S.seg_end[0] : S.seg_end[1]));
-  const int sby = rel / G.segs_x;
-  const int sg = rel - sby * G.segs_x;
-  const int tx0 = sg * S.seg_tiles;
-  const int tx1 = min(tx0 + S.seg_tiles, G.tiles_x);
+  const int rel = unit - (pli == 0 ? 0 : (pli == 1 ? S.tile_end[0] : S.tile_end[1]));
+  const int sby = rel / G.tiles_x;
+  const int tx = rel - sby * G.tiles_x;
   const int nh = G.nh, nv = G.nv, stride = G.stride;
-  const int W = nh * 8, H = nv * 8;
-  const bool qpx = pli != 0 && S.qpx, qpy = pli != 0 && S.qpy;
-  const int fy0 = pli == 0 ? S.lf_y0[0] : (pli == 1 ? S.lf_y0[1] : S.lf_y0[2]);
-  const int fy1 = pli == 0 ? S.lf_y1[0] : (pli == 1 ? S.lf_y1[1] : S.lf_y1[2]);
-  const int sbl = lane >> 4, h = lane & 15;
-  const int hr = hilb_row(h), hc = hilb_col(h);
-  const int bxl = sbl * 4 + hc;         // block column inside the tile, 0..15
-  const int by = sby * 4 + hr;          // block row in the plane
-  uint8_t *const selfp = S.self + G.off;
-  TileLds *const L = lds_all[wv];
-  const int tile_row0 = G.tile_off + sby * G.tiles_x;
+  const int h = lane & 15;
+  const int bx = tx * 16 + (lane >> 4) * 4 + hilb_col(h);
+  const int by = sby * 4 + hilb_row(h);
+  const bool valid = bx < nh && by < nv;
 
-  uint2 info_n = S.info[(size_t)(tile_row0 + tx0) * THIP_TILE_FRAGS + lane];
-  uint32_t slot0_n = S.tile_slot0[tile_row0 + tx0];
+  // ---- 1. command word; coefficient slot by ballot / prefix count over the coded mask -----
+  const uint2 info = S.info[(size_t)unit * THIP_TILE_FRAGS + lane];
+  const uint32_t flags = valid ? info.x : 0u;
+  const bool coded = (flags & THIP_INFO_CODED) != 0;
+  const bool dc_only = (flags & THIP_INFO_DC_ONLY) != 0;
+  const bool has_coeff = coded && !dc_only;
+  const uint64_t mask = __ballot(has_coeff);
+  uint32_t P[32];
+  if (mask != 0 && !(S.debug & 8)) {
+    const uint32_t slot = S.tile_slot0[unit] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (has_coeff) load_slot(S.coeffs, slot, P);
+  }
+  if (!has_coeff) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) P[i] = 0u;
+  }
+  if (!valid) return;   // past the ragged edge of the plane (after the ballot)
+  S.coded_map[G.fro + by * nh + bx] = coded ? 1 : 0;
+  const int refi = (int)((flags >> THIP_INFO_REFI_SHIFT) & 3u);
+  const int last_zzi = (int)((flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
+  const int x0 = bx * 8, y0 = by * 8;
+  uint8_t *dst = S.self + G.off + (ptrdiff_t)y0 * stride + x0;
 
-  for (int tx = tx0; tx <= tx1; tx++) {
-    const bool cur = tx < tx1;
-    TileLds &T = L[(tx - tx0) & 1];
-    uint32_t P[32];
-    uint2 pred[8];
-    PredFetch F;
-    uint32_t flags = 0, word1 = 0;
-    bool valid = false, coded = false, dc_only = false, has_coeff = false;
-    F.inside = false;
-    // ---- 1. command word, coefficient slot by ballot / prefix count, start the loads ----------
-    if (cur) {
-      const int bx = tx * 16 + bxl;
-      valid = bx < nh && by < nv;
-      flags = valid ? info_n.x : 0u;
-      word1 = info_n.y;
-      coded = (flags & THIP_INFO_CODED) != 0;
-      dc_only = (flags & THIP_INFO_DC_ONLY) != 0;
-      has_coeff = coded && !dc_only;
-      const uint64_t mask = __ballot(has_coeff);
-      const uint32_t slot = slot0_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      if (has_coeff && !(S.debug & 8)) load_slot(S.coeffs, slot, P);
-      else {
+  // ---- 2. uncoded: copy from the previous frame (fragment.c:20-47) ------------------------------
+  if (!coded) {
+    const uint8_t *p = S.prev + G.off + (ptrdiff_t)y0 * stride + x0;
+    uint2 t[8];
 #pragma unroll
-        for (int i = 0; i < 32; i++) P[i] = 0u;
-      }
-      const int refi = (int)((flags >> THIP_INFO_REFI_SHIFT) & 3u);
-      const int x0 = bx * 8, y0 = by * 8;
+    for (int r = 0; r < 8; r++) t[r] = *reinterpret_cast<const uint2 *>(p + (ptrdiff_t)r * stride);
 #pragma unroll
-      for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);   // intra, fragment.c:54
-      if (valid && !coded) {
-        // uncoded: the fragment is copied from the previous frame (fragment.c:20-47)
-        const uint8_t *p = S.prev + G.off + (ptrdiff_t)y0 * stride + x0;
+    for (int r = 0; r < 8; r++) store_row8(dst + (ptrdiff_t)r * stride, t[r]);
+    return;
+  }
+
+  // ---- 3. predictor (fragment.c:49-80): 128, one reference block, or the average of two -----
+  uint2 pred[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) pred[r] = *reinterpret_cast<const uint2 *>(p + (ptrdiff_t)r * stride);
-      } else if (coded && refi != THIP_FRAME_SELF && !(S.debug & 2)) {
-        const uint8_t *ref = (refi == THIP_FRAME_PREV ? S.prev : S.gold) + G.off;
-        predictor_issue(F, ref, stride, W, H, x0, y0, flags, qpx, qpy, pred);
-      }
-      if (tx + 1 < tx1) {   // command words of the next tile
-        info_n = S.info[(size_t)(tile_row0 + tx + 1) * THIP_TILE_FRAGS + lane];
-        slot0_n = S.tile_slot0[tile_row0 + tx + 1];
-      }
-    }
-    // ---- 2. while those loads fly: filter and stream out the previous tile ---------------------
-    if (tx > tx0)
-      filter_and_store(L[(tx - tx0 + 1) & 1], S, selfp, lane, tx - 1, sby, nh, nv, stride, tx - 1 == tx0,
-                       tx == tx1, fy0, fy1, hr, bxl, by);
-    if (!cur) break;
-    // ---- 3. residual: DC-only shortcut (state.c:967-975) or inverse DCT (idct.c:301) ---------
-    const int last_zzi = (int)((flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
-    uint32_t Y[32];
-    const uint32_t dcp = (word1 & 0xFFFFu) * 0x00010001u;   // {p, p}
-    const bool need_any = __any(has_coeff);
-    if (need_any && !(S.debug & 1)) {
-      pk_mask_by_last_zzi(P, last_zzi);
-      const bool all_zz10 = !__any(has_coeff && last_zzi > 10);
-      pk_idct8x8(P, Y, all_zz10);
-    } else {
+  for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
+  if (refi != THIP_FRAME_SELF && !(S.debug & 2)) {
+    const uint8_t *ref = (refi == THIP_FRAME_PREV ? S.prev : S.gold) + G.off;
+    fetch_predictor(ref, stride, nh * 8, nv * 8, x0, y0, flags, pli != 0 && S.qpx, pli != 0 && S.qpy, pred);
+  }
+
+  // ---- 4. residual: DC-only shortcut (state.c:967-975) or inverse DCT (idct.c:301) ------------
+  uint32_t Y[32];
+  const uint32_t dcp = (info.y & 0xFFFFu) * 0x00010001u;   // {p, p}
+  const bool need_any = __any(has_coeff);
+  if (need_any && !(S.debug & 1)) {
+    pk_mask_by_last_zzi(P, last_zzi);
+    const bool all_zz10 = !__any(has_coeff && last_zzi > 10);
+    pk_idct8x8(P, Y, all_zz10);
+  } else {
 #pragma unroll
-      for (int i = 0; i < 32; i++) Y[i] = P[i];
-    }
-    if (!has_coeff) {
+    for (int i = 0; i < 32; i++) Y[i] = P[i];
+  }
+  if (dc_only) {
 #pragma unroll
-      for (int i = 0; i < 32; i++) Y[i] = dc_only ? dcp : 0u;
-    }
-    predictor_finish(F, pred);
-    // ---- 4. reconstruct into this tile's LDS image -----------------------------------------------
-    if (valid) {
-      uint8_t *dst = T.pix + (hr * 8) * kTilePitch + 4 + bxl * 8;
+    for (int i = 0; i < 32; i++) Y[i] = dcp;
+  }
+
+  // ---- 5. reconstruct and store (8 aligned bytes per lane per row) --------------------------------
+  if (!(S.debug & 4)) {
 #pragma unroll
-      for (int r = 0; r < 8; r++) {
-        uint2 o = pred[r];
-        if (coded)
-          o = pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]),
-                           pred[r]);
-        uint32_t *d = reinterpret_cast<uint32_t *>(dst + r * kTilePitch);   // 4-byte aligned
-        d[0] = o.x;
-        d[1] = o.y;
-      }
-    }
-    T.coded[hr * kFlagCols + 1 + bxl] = coded ? 1 : 0;
-    if (lane < 4) T.coded[lane * kFlagCols + 1 + 16] = 0;   // column past the tile: never coded here
-    // carried columns: the last four pixels (and the coded flags) of the previous tile
-    if (tx > tx0) {
-      const TileLds &Q = L[(tx - tx0 + 1) & 1];
-      if (lane < kTileRows)
-        *reinterpret_cast<uint32_t *>(T.pix + lane * kTilePitch) =
-            *reinterpret_cast<const uint32_t *>(Q.pix + lane * kTilePitch + 128);
-      if (lane >= 32 && lane < 36) T.coded[(lane - 32) * kFlagCols] = Q.coded[(lane - 32) * kFlagCols + 16];
-    } else if (lane >= 32 && lane < 36) {
-      T.coded[(lane - 32) * kFlagCols] = 0;
-    }
-    wave_sync();
+    for (int r = 0; r < 8; r++)
+      store_row8(dst + (ptrdiff_t)r * stride,
+                 pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]),
+                              pred[r]));
   }
 }
 
 // ---------------------------------------------------------------------------------------
-// k_seam: the filter cells k_frame leaves -- seam rows (m % 4 == 0, and m == nv), and on the
-// other interior rows the columns where two segments meet.
+// k_loopfilter (K3): one filter cell per lane over the whole frame
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ bool coded_at(const StreamK &S, const PlaneK &G, int bx, int by) {
-  const int pos = (G.tile_off + (by >> 2) * G.tiles_x + (bx >> 4)) * THIP_TILE_FRAGS + ((bx >> 2) & 3) * 16 +
-                  hilb_inv(by & 3, bx & 3);
-  return (S.info[pos].x & THIP_INFO_CODED) != 0;
+  return S.coded_map[G.fro + by * G.nh + bx] != 0;
 }
 
-__global__ __launch_bounds__(256) void k_seam(const BatchK B) {
+__global__ __launch_bounds__(256) void k_loopfilter(const BatchK B) {
   const StreamK &S = B.s[blockIdx.y];
   const int idx = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (idx >= S.seam_end[2] || S.flimit2 == 0) return;
-  const int pli = (idx >= S.seam_end[0] ? 1 : 0) + (idx >= S.seam_end[1] ? 1 : 0);
+  if (idx >= S.cell_end[2] || S.flimit2 == 0) return;
+  const int pli = (idx >= S.cell_end[0] ? 1 : 0) + (idx >= S.cell_end[1] ? 1 : 0);
   const PlaneK &G = S.pl[pli];
-  int rel = idx - (pli == 0 ? 0 : (pli == 1 ? S.seam_end[0] : S.seam_end[1]));
+  const int rel = idx - (pli == 0 ? 0 : (pli == 1 ? S.cell_end[0] : S.cell_end[1]));
   const int nh = G.nh, nv = G.nv;
-  int k, m;
-  const int hcells = G.seam_rows * (nh + 1);
-  if (rel < hcells) {
-    const int row = rel / (nh + 1);
-    k = rel - row * (nh + 1);
-    m = min(row * 4, nv);   // rows 0,4,8,... and finally nv itself
-  } else {
-    rel -= hcells;
-    const int j = rel / G.vseams;          // j-th interior row that is not a seam row
-    const int s = rel - j * G.vseams;
-    m = (j / 3) * 4 + (j - (j / 3) * 3) + 1;
-    k = (s + 1) * 16 * S.seg_tiles;
-    if (j >= G.vrows) return;
-  }
-  if (S.debug & 64) return;
+  uint32_t mu, ku;
+  divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
+  const int k = (int)ku, m = (int)mu;
+  CellPix C;
+  lf_cell_load(C, S.self + G.off, G.stride, nh, nv, k, m);
   const bool a = k >= 1 && m >= 1 && coded_at(S, G, k - 1, m - 1);
   const bool b = k <= nh - 1 && m >= 1 && coded_at(S, G, k, m - 1);
   const bool c = k >= 1 && m <= nv - 1 && coded_at(S, G, k - 1, m);
   const bool d = k <= nh - 1 && m <= nv - 1 && coded_at(S, G, k, m);
-  if (S.debug & 32) {
-    if (a && b && c && d && k == 12345678) S.self[0] = 1;
-    return;
-  }
   const int fy0 = pli == 0 ? S.lf_y0[0] : (pli == 1 ? S.lf_y0[1] : S.lf_y0[2]);
   const int fy1 = pli == 0 ? S.lf_y1[0] : (pli == 1 ? S.lf_y1[1] : S.lf_y1[2]);
   const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
-  lf_cell_global(S.self + G.off, G.stride, nh, nv, k, m, t, S.flimit2);
+  lf_cell_finish(C, S.self + G.off, G.stride, nh, nv, k, m, t, S.flimit2);
 }
 
 // plane-level entry for the slot parity test (thip_loop_filter_plane)
@@ -578,7 +439,9 @@ __global__ __launch_bounds__(256) void k_loopfilter_plane(uint8_t *plane, int st
   const bool b = k <= nh - 1 && m >= 1 && coded[(m - 1) * nh + k];
   const bool c = k >= 1 && m <= nv - 1 && coded[m * nh + k - 1];
   const bool d = k <= nh - 1 && m <= nv - 1 && coded[m * nh + k];
-  lf_cell_global(plane, stride, nh, nv, k, m, lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1), L2);
+  CellPix C;
+  lf_cell_load(C, plane, stride, nh, nv, k, m);
+  lf_cell_finish(C, plane, stride, nh, nv, k, m, lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1), L2);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -591,6 +454,7 @@ struct thip_state {
   int64_t nfrags;
   size_t frame_bytes;
   uint8_t *frames[3];   // device
+  uint8_t *coded_map;   // device, nfrags bytes
   int ref_idx[3];       // THIP_FRAME_* -> buffer index
   int last_decoded;     // buffer index of the most recently completed frame, -1 if none
   int lane;             // library-owned HIP stream this state is bound to, -1 until first use
@@ -609,7 +473,7 @@ struct thip_state {
 namespace {
 std::mutex g_mu;
 // Library-owned HIP streams ("lanes").  Every thip_state is bound to one lane for life, so
-// the frames of a stream stay ordered; different lanes let one group's seam pass overlap
+// the frames of a stream stay ordered; different lanes let one group's loop filter overlap
 // another group's reconstruction (dependent kernels of one group cannot overlap).
 constexpr int kMaxLanes = 4;
 hipStream_t g_lanes[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
@@ -617,7 +481,6 @@ int g_nlanes = 0;
 int g_next_lane = 0;
 int g_profile = 0;
 const int g_debug = getenv("THIP_DEBUG") ? atoi(getenv("THIP_DEBUG")) : 0;
-const int g_seg_tiles = getenv("THIP_SEG_TILES") ? atoi(getenv("THIP_SEG_TILES")) : 4;
 struct EvPair { hipEvent_t a, b; int kernel; };
 std::vector<EvPair> g_events;
 std::vector<hipEvent_t> g_pool;
@@ -664,13 +527,9 @@ struct ScopedTimer {
   }
 };
 
-int seg_tiles() { return g_seg_tiles < 1 ? 1 : (g_seg_tiles > 64 ? 64 : g_seg_tiles); }
-
-// Fills the per-plane kernel geometry; returns k_frame workgroups and k_seam cells.
+// Fills the per-plane kernel geometry and the cumulative tile / cell counts.
 void fill_stream_geom(StreamK &K, const thip_state *st) {
-  const int segt = seg_tiles();
-  K.seg_tiles = segt;
-  int wgs = 0, cells = 0;
+  int tiles = 0, cells = 0;
   for (int pli = 0; pli < 3; pli++) {
     const thip_plane_geom &g = st->geom[pli];
     PlaneK &k = K.pl[pli];
@@ -680,16 +539,12 @@ void fill_stream_geom(StreamK &K, const thip_state *st) {
     k.off = g.plane_off;
     k.tiles_x = st->tiles.tiles_x[pli];
     k.tile_off = st->tiles.tile_off[pli];
-    k.segs_x = (k.tiles_x + segt - 1) / segt;
-    // seam rows: m = 0, 4, 8, ... <= nv, plus m = nv when nv is not a multiple of 4
-    k.seam_rows = k.nv / 4 + 1 + ((k.nv & 3) ? 1 : 0);
-    k.vseams = k.segs_x - 1;
-    // interior rows 1..nv-1 that are not multiples of 4
-    k.vrows = (k.nv - 1) - (k.nv - 1) / 4;
-    wgs += st->tiles.tiles_y[pli] * k.segs_x;   // one WAVE per segment
-    K.seg_end[pli] = wgs;
-    cells += k.seam_rows * (k.nh + 1) + k.vseams * k.vrows;
-    K.seam_end[pli] = cells;
+    k.fro = g.froffset;
+    k.rcp_cx = 1.0f / (float)(g.nhfrags + 1);
+    tiles += st->tiles.tiles_x[pli] * st->tiles.tiles_y[pli];
+    K.tile_end[pli] = tiles;
+    cells += (g.nhfrags + 1) * (g.nvfrags + 1);
+    K.cell_end[pli] = cells;
   }
 }
 }  // namespace
@@ -759,6 +614,8 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
   hipError_t err = hipSuccess;
   // +256: aligned 12-byte predictor windows may read 3 bytes past a row end
   for (int b = 0; b < 3 && err == hipSuccess; b++) err = hipMalloc((void **)&st->frames[b], st->frame_bytes + 256);
+  if (err == hipSuccess) err = hipMalloc((void **)&st->coded_map, (size_t)st->nfrags);
+  if (err == hipSuccess) err = hipMemset(st->coded_map, 0, (size_t)st->nfrags);
   if (err != hipSuccess) {
     fprintf(stderr, "theora_hip: thip_state_create: device allocation failed: %s\n", hipGetErrorString(err));
     thip_state_free(st);
@@ -776,6 +633,7 @@ void thip_state_free(thip_state *st) {
   (void)hipDeviceSynchronize();
   for (int b = 0; b < 3; b++)
     if (st->frames[b]) (void)hipFree(st->frames[b]);
+  if (st->coded_map) (void)hipFree(st->coded_map);
   if (st->h_info) (void)hipHostFree(st->h_info);
   if (st->h_coeffs) (void)hipHostFree(st->h_coeffs);
   if (st->h_slot0) (void)hipHostFree(st->h_slot0);
@@ -943,6 +801,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     K.self = st->frames[bufi];
     K.prev = st->ref_idx[THIP_FRAME_PREV] >= 0 ? st->frames[st->ref_idx[THIP_FRAME_PREV]] : st->frames[bufi];
     K.gold = st->ref_idx[THIP_FRAME_GOLD] >= 0 ? st->frames[st->ref_idx[THIP_FRAME_GOLD]] : st->frames[bufi];
+    K.coded_map = st->coded_map;
     K.flimit2 = 2 * d.flimit;
     K.debug = g_debug;
     K.qpx = st->hdec;
@@ -952,22 +811,22 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       K.lf_y0[pli] = st->lf_rows_custom ? st->lf_y0[pli] : 0;
       K.lf_y1[pli] = st->lf_rows_custom ? st->lf_y1[pli] : st->geom[pli].nvfrags;
     }
-    if ((K.seg_end[2] + 3) / 4 > max_wg) max_wg = (K.seg_end[2] + 3) / 4;
+    if ((K.tile_end[2] + 3) / 4 > max_wg) max_wg = (K.tile_end[2] + 3) / 4;
     if (d.flimit) {
       any_lf = 1;
-      const int swg = (K.seam_end[2] + 255) / 256;
+      const int swg = (K.cell_end[2] + 255) / 256;
       if (swg > max_seam_wg) max_seam_wg = swg;
     }
     live_state[nlive++] = i;
   }
   if (!nlive) return THIP_OK;
   {
-    ScopedTimer t(s, THIP_KERNEL_FRAME);
-    hipLaunchKernelGGL(k_frame, dim3(max_wg, nlive), dim3(256), 0, s, B);
+    ScopedTimer t(s, THIP_KERNEL_RECON);
+    hipLaunchKernelGGL(k_recon, dim3(max_wg, nlive), dim3(256), 0, s, B);
   }
   if (any_lf) {
-    ScopedTimer t(s, THIP_KERNEL_SEAM);
-    hipLaunchKernelGGL(k_seam, dim3(max_seam_wg, nlive), dim3(256), 0, s, B);
+    ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
+    hipLaunchKernelGGL(k_loopfilter, dim3(max_seam_wg, nlive), dim3(256), 0, s, B);
   }
   HIP_TRY(hipGetLastError());
   // decode.c:2947-2962
