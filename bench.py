@@ -209,9 +209,20 @@ def main():
         }
         if profiling and kms[0] > 0:
             gbs = steps_b_alg / (kms[0] * 1e-3) / 1e9
+            # HBM bytes per launch from the PMC counters cannot be sampled from inside this
+            # process; they come from the committed rocprofv3 --pmc passes of this very
+            # workload (profiles/r01_pmc_traffic.json), and only when the workload matches.
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                wl = tj["workload"]
+                if (wl["size"], wl["content"], wl["streams_per_launch"]) == (args.size, args.content, S):
+                    traffic = tj["k_recon"]["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"bound": "hbm", "kernel": "k_recon", "achieved": round(gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                               "traffic": None,
+                               "traffic": traffic,
                                "avg_launch_us": round(1e3 * kms[0] / max(launches[0], 1), 3),
                                "loopfilter_avg_launch_us": round(1e3 * kms[1] / max(launches[1], 1), 3),
                                "alg_bytes_per_launch": int(steps_b_alg / max(launches[0], 1)),

@@ -114,7 +114,13 @@ __device__ __forceinline__ uint2 load_row8(const uint8_t *p) {
   return v;
 }
 __device__ __forceinline__ void store_row8(uint8_t *p, uint2 v) {
+#if defined(THIP_NT_STORES)
+  // non-temporal: the pixels are not read again by this kernel
+  __builtin_nontemporal_store(v.x, reinterpret_cast<uint32_t *>(p));
+  __builtin_nontemporal_store(v.y, reinterpret_cast<uint32_t *>(p) + 1);
+#else
   *reinterpret_cast<uint2 *>(p) = v;
+#endif
 }
 
 // 12 bytes of a reference row starting at a 4-byte-aligned address
