@@ -1,0 +1,101 @@
+/* theoradec_hip.h -- libtheora's decoder API (include/theora/codec.h, theoradec.h) served by
+ * the MI355X backend: the same function names, argument meaning and TH_E* return codes, so
+ * a program written against libtheoradec relinks against libtheora_hip.so.
+ *
+ * The structs below restate the PUBLIC layout of the reference's types (they are API
+ * facts: codec.h:144-299, theoradec.h:131-215, libogg's ogg_packet); nothing else of the
+ * reference is reproduced.  The front end behind these calls -- bit reader, header and
+ * frame parsing, Huffman decode, DC un-prediction, token expansion and dequantisation --
+ * is written from the Theora specification (doc/spec/spec.tex); the pixel path is the HIP
+ * backend of theora_hip.h, driven through the accel-vtable slots exactly where
+ * lib/decode.c:2858-2962 drives oc_state_frag_recon / oc_frag_copy_list /
+ * oc_state_loop_filter_frag_rows.
+ *
+ * Not provided (out of scope): post-processing levels > 0, telemetry,
+ * the legacy theora_* API, th_granule_* helpers beyond th_granule_frame, the encoder.
+ */
+#ifndef THEORADEC_HIP_H
+#define THEORADEC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* codec.h:77-93 */
+#define TH_EFAULT (-1)
+#define TH_EINVAL (-10)
+#define TH_ENOTFORMAT (-20)
+#define TH_EBADHEADER (-21)
+#define TH_EVERSION (-22)
+#define TH_EIMPL (-23)
+#define TH_EBADPACKET (-24)
+#define TH_DUPFRAME (1)
+
+typedef enum { TH_CS_UNSPECIFIED, TH_CS_ITU_REC_470M, TH_CS_ITU_REC_470BG, TH_CS_NSPACES } th_colorspace;
+typedef enum { TH_PF_420, TH_PF_RSVD, TH_PF_422, TH_PF_444, TH_PF_NFORMATS } th_pixel_fmt;
+
+typedef struct {
+  int width, height, stride;
+  unsigned char *data;
+} th_img_plane; /* codec.h:144-153 */
+typedef th_img_plane th_ycbcr_buffer[3];
+
+typedef struct { /* codec.h:206-299 */
+  unsigned char version_major, version_minor, version_subminor;
+  uint32_t frame_width, frame_height;
+  uint32_t pic_width, pic_height, pic_x, pic_y;
+  uint32_t fps_numerator, fps_denominator;
+  uint32_t aspect_numerator, aspect_denominator;
+  th_colorspace colorspace;
+  th_pixel_fmt pixel_fmt;
+  int target_bitrate;
+  int quality;
+  int keyframe_granule_shift;
+} th_info;
+
+typedef struct { /* codec.h:326-335 */
+  char **user_comments;
+  int *comment_lengths;
+  int comments;
+  char *vendor;
+} th_comment;
+
+/* libogg's ogg_packet (ogg/ogg.h): only packet, bytes and b_o_s are read here. */
+typedef struct {
+  unsigned char *packet;
+  long bytes;
+  long b_o_s;
+  long e_o_s;
+  int64_t granulepos;
+  int64_t packetno;
+} ogg_packet;
+
+typedef struct th_dec_ctx th_dec_ctx;
+typedef struct th_setup_info th_setup_info;
+
+void th_info_init(th_info *info);   /* info.c */
+void th_info_clear(th_info *info);
+void th_comment_init(th_comment *tc);
+void th_comment_clear(th_comment *tc);
+
+/* theoradec.h:234-322 */
+int th_decode_headerin(th_info *info, th_comment *tc, th_setup_info **setup, ogg_packet *op);
+th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup);
+void th_setup_free(th_setup_info *setup);
+int th_decode_ctl(th_dec_ctx *dec, int req, void *buf, size_t buf_sz);
+int th_decode_packetin(th_dec_ctx *dec, const ogg_packet *op, int64_t *granpos);
+int th_decode_ycbcr_out(th_dec_ctx *dec, th_ycbcr_buffer ycbcr);
+void th_decode_free(th_dec_ctx *dec);
+int64_t th_granule_frame(void *encdec, int64_t granpos);
+
+/* th_decode_ctl requests that are honoured (theoradec.h:40-105) */
+#define TH_DECCTL_GET_PPLEVEL_MAX (1)
+#define TH_DECCTL_SET_PPLEVEL (3)
+#define TH_DECCTL_SET_GRANPOS (5)
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+"""End to end through the th_decode_* API: Theora packets -> the library's own front end
+(bit reader, Huffman, modes, vectors, tokens, DC un-prediction, dequantisation) -> HIP
+reconstruction -> th_decode_ycbcr_out, against the oracle fed with the generator's ground
+truth.  The packets come from tests/streamgen.py (the reference encoder cannot be built
+here and no sample streams exist)."""
+import numpy as np
+import pytest
+
+import oracle
+from tests import streamgen, util
+
+pytestmark = pytest.mark.gpu
+
+
+def run_stream(hip, w, h, fmt, seed, nframes, kf=5):
+    from theora_amd.decoder import Decoder
+    st = streamgen.Stream(w, h, fmt, seed)
+    dec = Decoder(st.header_packets())
+    assert dec.info.frame_width == w and dec.info.frame_height == h and dec.info.pixel_fmt == fmt
+    assert dec.comment.vendor == b"theora-hip streamgen"
+    ost = oracle.State(w, h, fmt)
+    nnew = 0
+    for f in range(nframes):
+        ftype = 0 if f % kf == 0 else 1
+        pkt, truth = st.frame(ftype, density=[0.9, 0.5, 0.15][f % 3])
+        rc, gp = dec.packetin(pkt)
+        if truth["dup"]:
+            assert rc == 1, f
+        else:
+            assert rc == 0, f
+            nnew += 1
+            args = st.oracle_inputs(truth, ost)
+            assert ost.decode_frame(**args) == 0
+        got = dec.ycbcr_out()
+        for pli in range(3):
+            want = ost.get_plane(oracle.FRAME_PREV, pli)[::-1]
+            assert np.array_equal(got[pli], want), (f, pli, int((got[pli] != want).sum()))
+    dec.close()
+    return nnew
+
+
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (336, 32, 0)])
+def test_packets_decode_bit_exact(hip, w, h, fmt):
+    assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9) >= 6
+
+
+def test_empty_packet_is_dup_frame(hip):
+    from theora_amd.decoder import Decoder
+    st = streamgen.Stream(64, 48, 0, seed=5)
+    dec = Decoder(st.header_packets())
+    pkt, truth = st.frame(0)
+    assert dec.packetin(pkt)[0] == 0
+    before = [p.copy() for p in dec.ycbcr_out()]
+    assert dec.packetin(b"")[0] == 1
+    after = dec.ycbcr_out()
+    assert all(np.array_equal(a, b) for a, b in zip(before, after))
+
+
+def test_header_errors(hip):
+    import ctypes as C
+    from theora_amd import _lib
+    from theora_amd.decoder import Decoder, _packet
+    L = _lib.load()
+    st = streamgen.Stream(64, 48, 0, seed=6)
+    hp = st.header_packets()
+    info, tc, setup = _lib.ThInfo(), _lib.ThComment(), C.c_void_p()
+    L.th_info_init(C.byref(info))
+    L.th_comment_init(C.byref(tc))
+    op, k1 = _packet(hp[1], bos=0)
+    assert L.th_decode_headerin(C.byref(info), C.byref(tc), C.byref(setup), C.byref(op)) == -21   # comment before info
+    bad = bytearray(hp[0])
+    bad[3] ^= 0xFF
+    op, k2 = _packet(bytes(bad), bos=1)
+    assert L.th_decode_headerin(C.byref(info), C.byref(tc), C.byref(setup), C.byref(op)) == -20   # not "theora"
+    with pytest.raises(Exception):
+        Decoder([hp[0], hp[2]])

@@ -79,6 +79,46 @@ SYMBOLS = [
     ("thip_version_string", C.c_char_p, []),
 ]
 
+# ---- th_decode_* API (include/theoradec_hip.h) ----------------------------------------------
+class ThInfo(C.Structure):
+    _fields_ = [("version_major", C.c_ubyte), ("version_minor", C.c_ubyte), ("version_subminor", C.c_ubyte),
+                ("frame_width", C.c_uint32), ("frame_height", C.c_uint32), ("pic_width", C.c_uint32),
+                ("pic_height", C.c_uint32), ("pic_x", C.c_uint32), ("pic_y", C.c_uint32),
+                ("fps_numerator", C.c_uint32), ("fps_denominator", C.c_uint32),
+                ("aspect_numerator", C.c_uint32), ("aspect_denominator", C.c_uint32),
+                ("colorspace", C.c_int), ("pixel_fmt", C.c_int), ("target_bitrate", C.c_int),
+                ("quality", C.c_int), ("keyframe_granule_shift", C.c_int)]
+
+
+class ThComment(C.Structure):
+    _fields_ = [("user_comments", C.POINTER(C.c_char_p)), ("comment_lengths", C.POINTER(C.c_int)),
+                ("comments", C.c_int), ("vendor", C.c_char_p)]
+
+
+class OggPacket(C.Structure):
+    _fields_ = [("packet", C.c_void_p), ("bytes", C.c_long), ("b_o_s", C.c_long), ("e_o_s", C.c_long),
+                ("granulepos", C.c_int64), ("packetno", C.c_int64)]
+
+
+class ThImgPlane(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("stride", C.c_int), ("data", C.POINTER(C.c_ubyte))]
+
+
+DEC_SYMBOLS = [
+    ("th_info_init", None, [C.POINTER(ThInfo)]),
+    ("th_info_clear", None, [C.POINTER(ThInfo)]),
+    ("th_comment_init", None, [C.POINTER(ThComment)]),
+    ("th_comment_clear", None, [C.POINTER(ThComment)]),
+    ("th_decode_headerin", _I, [C.POINTER(ThInfo), C.POINTER(ThComment), C.POINTER(_P), C.POINTER(OggPacket)]),
+    ("th_decode_alloc", _P, [C.POINTER(ThInfo), _P]),
+    ("th_setup_free", None, [_P]),
+    ("th_decode_ctl", _I, [_P, _I, _P, C.c_size_t]),
+    ("th_decode_packetin", _I, [_P, C.POINTER(OggPacket), C.POINTER(_I64)]),
+    ("th_decode_ycbcr_out", _I, [_P, C.POINTER(ThImgPlane)]),
+    ("th_decode_free", None, [_P]),
+    ("th_granule_frame", _I64, [_P, _I64]),
+]
+
 _lib = None
 
 
@@ -97,7 +137,7 @@ def load():
             "%s not found: build it with `python -m theora_amd.build` (hipcc, gfx950). "
             "theora_amd has no CPU fallback." % SO_PATH)
     L = C.CDLL(SO_PATH)
-    for name, restype, argtypes in SYMBOLS:
+    for name, restype, argtypes in SYMBOLS + DEC_SYMBOLS:
         fn = getattr(L, name)   # AttributeError if the library does not export it
         fn.restype = restype
         fn.argtypes = argtypes

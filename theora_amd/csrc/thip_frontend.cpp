@@ -1,0 +1,1039 @@
+// thip_frontend.cpp -- host front end of the decoder.
+//
+// Turns Theora packets into calls of the accel-vtable slots implemented by the HIP backend
+// (theora_hip.h): header parsing, frame header, coded-block flags, macro-block modes, motion
+// vectors, block-level qi, DCT token decode, DC un-prediction, token expansion and
+// dequantisation.  Written from the bitstream specification (doc/spec/spec.tex, section
+// numbers cited below); the role it plays is the one lib/decode.c plays in the reference
+// (th_decode_packetin, decode.c:2740-2986), but none of that code is reproduced.  The one
+// structural idea shared with the reference is unpacking the token stream by COUNTS per
+// (plane, zig-zag index) list before expanding per fragment (decode.c:993-1201), because
+// it is what makes a single pass over the packet possible.
+//
+// Exports the th_decode_* API declared in include/theoradec_hip.h.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/theora_hip.h"
+#include "../../include/theoradec_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// bit reader: MSB first, reads past the end return zeros (spec 5.2, "Decoding")
+// ---------------------------------------------------------------------------------------
+struct BitReader {
+  const uint8_t *p;
+  size_t nbits, pos;
+  BitReader(const uint8_t *data, size_t bytes) : p(data), nbits(bytes * 8), pos(0) {}
+  inline uint32_t bit() {
+    uint32_t b = 0;
+    if (pos < nbits) b = (p[pos >> 3] >> (7 - (pos & 7))) & 1u;
+    pos++;
+    return b;
+  }
+  inline uint32_t read(int n) {
+    uint32_t v = 0;
+    while (n-- > 0) v = (v << 1) | bit();
+    return v;
+  }
+  bool overrun() const { return pos > nbits; }
+};
+
+inline int ilog(uint32_t v) {   // number of bits needed to store v (spec 1.4 ilog)
+  int n = 0;
+  while (v) {
+    n++;
+    v >>= 1;
+  }
+  return n;
+}
+
+// zig-zag index -> natural position (spec Figure "zig-zag order")
+const uint8_t kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// (row, col) of the k-th block of a super block in coded (Hilbert) order (spec Figure 2.4)
+const uint8_t kHilbert[16][2] = {{0, 0}, {0, 1}, {1, 1}, {1, 0}, {2, 0}, {3, 0}, {3, 1}, {2, 1},
+                                 {2, 2}, {3, 2}, {3, 3}, {2, 3}, {1, 3}, {1, 2}, {0, 2}, {0, 3}};
+// macro blocks of a super block in coded order: (row, col) in units of macro blocks (spec Figure 2.5)
+const uint8_t kMbOrder[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+
+// Table 7.19: mode alphabets of schemes 1..6
+const uint8_t kModeAlphabets[6][8] = {{3, 4, 2, 0, 1, 5, 6, 7}, {3, 4, 0, 2, 1, 5, 6, 7}, {3, 2, 4, 0, 1, 5, 6, 7},
+                                      {3, 2, 0, 4, 1, 5, 6, 7}, {0, 3, 4, 2, 1, 5, 6, 7}, {0, 5, 3, 4, 2, 1, 6, 7}};
+// reference frame of each coding mode (Table 7.46): 0 intra/self, 1 previous, 2 golden -> THIP_FRAME_*
+const uint8_t kModeRefi[8] = {THIP_FRAME_PREV, THIP_FRAME_SELF, THIP_FRAME_PREV, THIP_FRAME_PREV,
+                              THIP_FRAME_PREV, THIP_FRAME_GOLD, THIP_FRAME_GOLD, THIP_FRAME_PREV};
+enum { MODE_INTER_NOMV = 0, MODE_INTRA = 1, MODE_INTER_MV = 2, MODE_INTER_MV_LAST = 3, MODE_INTER_MV_LAST2 = 4,
+       MODE_GOLDEN_NOMV = 5, MODE_GOLDEN_MV = 6, MODE_INTER_MV_FOUR = 7 };
+
+struct HuffTree {
+  // node i: child[i][b] >= 0 is another node, < 0 is the leaf -(token+1)
+  int16_t child[32][2];
+  int nnodes;
+  int root_leaf;   // a single-leaf tree: token+1, else 0
+};
+
+struct QuantParams {
+  uint8_t lflims[64];
+  uint16_t acscale[64], dcscale[64];
+  int nbms;
+  std::vector<uint8_t> bms;   // nbms*64
+  int nqrs[2][3];
+  int qrsizes[2][3][64];
+  int qrbmis[2][3][65];
+};
+
+struct Tok {
+  int16_t value;   // coefficient value (0 for pure runs / EOB)
+  uint8_t skip;    // zeros before the value
+  uint8_t adv;     // how far the block advances (0 for EOB tokens)
+  uint32_t eob;    // EOB run length, 0 if not an EOB token
+};
+
+}  // namespace
+
+struct th_setup_info {
+  HuffTree huff[80];
+  QuantParams qp;
+};
+
+struct MacroBlock {
+  int32_t luma[4];     // fragment indices in raster order (A,B,C,D), -1 outside the frame
+  int32_t chroma[2][4];
+  int nchroma;         // chroma blocks per plane in this macro block
+};
+
+struct th_dec_ctx {
+  th_info info;
+  th_setup_info setup;
+  thip_state *hip;
+  int nh[3], nv[3], fro[3], nfrags_pl[3];
+  int nfrags;
+  int hdec, vdec;
+  std::vector<int32_t> coded_order;      // all fragments, coded order, planes concatenated
+  std::vector<int32_t> sb_start;         // per super block (all planes): first index in coded_order, +1 sentinel
+  int nsbs;
+  std::vector<MacroBlock> mbs;           // macro blocks in coded order (only those inside the frame)
+  std::vector<uint16_t> dequant;         // [qi][pli][qti][zzi]
+  // per frame
+  std::vector<uint8_t> coded, refi, qii, mbmode_of_frag;
+  std::vector<int8_t> mvx, mvy;
+  std::vector<int16_t> dc;
+  std::vector<uint8_t> sbp, sbf, mbmodes;
+  std::vector<Tok> toks[3][64];
+  uint32_t eob_carry[3][64];
+  int qis[3], nqis, frame_type;
+  int64_t keyframe_num, curframe_num, granpos;
+  int granpos_bias;
+  bool have_frame;
+  std::vector<uint8_t> mirror[3];
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// headers (spec 6.1 - 6.4)
+// ---------------------------------------------------------------------------------------
+int read_common_header(BitReader &br, int expect) {
+  const int type = (int)br.read(8);
+  static const char magic[] = "theora";
+  for (int i = 0; i < 6; i++)
+    if ((char)br.read(8) != magic[i]) return TH_ENOTFORMAT;
+  if (!(type & 0x80)) return TH_ENOTFORMAT;
+  if (type != expect) return TH_EBADHEADER;
+  return 0;
+}
+
+int parse_info(BitReader &br, th_info *info) {   // spec 6.2
+  info->version_major = (uint8_t)br.read(8);
+  info->version_minor = (uint8_t)br.read(8);
+  info->version_subminor = (uint8_t)br.read(8);
+  if (info->version_major != 3 || info->version_minor > 2) return TH_EVERSION;
+  info->frame_width = br.read(16) << 4;
+  info->frame_height = br.read(16) << 4;
+  info->pic_width = br.read(24);
+  info->pic_height = br.read(24);
+  info->pic_x = br.read(8);
+  info->pic_y = br.read(8);
+  info->fps_numerator = br.read(32);
+  info->fps_denominator = br.read(32);
+  if (info->frame_width == 0 || info->frame_height == 0 || info->pic_width + info->pic_x > info->frame_width ||
+      info->pic_height + info->pic_y > info->frame_height || info->fps_numerator == 0 ||
+      info->fps_denominator == 0)
+    return TH_EBADHEADER;
+  // the header counts pic_y from the bottom; the API from the top (decinfo.c:99)
+  info->pic_y = info->frame_height - info->pic_height - info->pic_y;
+  info->aspect_numerator = br.read(24);
+  info->aspect_denominator = br.read(24);
+  info->colorspace = (th_colorspace)br.read(8);
+  info->target_bitrate = (int)br.read(24);
+  info->quality = (int)br.read(6);
+  info->keyframe_granule_shift = (int)br.read(5);
+  info->pixel_fmt = (th_pixel_fmt)br.read(2);
+  if (info->pixel_fmt == TH_PF_RSVD) return TH_EBADHEADER;
+  if (br.read(3) != 0 || br.overrun()) return TH_EBADHEADER;
+  return 0;
+}
+
+uint32_t read_le32(BitReader &br) {   // spec 6.3.1: lengths are little-endian
+  uint32_t v = 0;
+  for (int i = 0; i < 4; i++) v |= br.read(8) << (8 * i);
+  return v;
+}
+
+int parse_comment(BitReader &br, th_comment *tc) {   // spec 6.3
+  uint32_t len = read_le32(br);
+  if (len > br.nbits / 8) return TH_EBADHEADER;
+  tc->vendor = (char *)malloc(len + 1);
+  for (uint32_t i = 0; i < len; i++) tc->vendor[i] = (char)br.read(8);
+  tc->vendor[len] = 0;
+  const uint32_t n = read_le32(br);
+  if (n > br.nbits / 32) return TH_EBADHEADER;
+  tc->comments = (int)n;
+  tc->user_comments = (char **)calloc(n ? n : 1, sizeof(char *));
+  tc->comment_lengths = (int *)calloc(n ? n : 1, sizeof(int));
+  for (uint32_t k = 0; k < n; k++) {
+    len = read_le32(br);
+    if (len > br.nbits / 8) return TH_EBADHEADER;
+    tc->user_comments[k] = (char *)malloc(len + 1);
+    tc->comment_lengths[k] = (int)len;
+    for (uint32_t i = 0; i < len; i++) tc->user_comments[k][i] = (char)br.read(8);
+    tc->user_comments[k][len] = 0;
+  }
+  return br.overrun() ? TH_EBADHEADER : 0;
+}
+
+constexpr int kHuffErr = 1000;   // neither a node index (0..31) nor a leaf code (-32..-1)
+int parse_huff_tree(BitReader &br, HuffTree &t, int depth, int *nleaves) {   // spec 6.4.4
+  if (depth > 32) return kHuffErr;
+  if (br.bit()) {
+    if (++*nleaves > 32) return kHuffErr;
+    return -(int)(br.read(5) + 1);   // leaf
+  }
+  if (t.nnodes >= 32) return kHuffErr;
+  const int me = t.nnodes++;
+  const int c0 = parse_huff_tree(br, t, depth + 1, nleaves);
+  if (c0 == kHuffErr) return kHuffErr;
+  const int c1 = parse_huff_tree(br, t, depth + 1, nleaves);
+  if (c1 == kHuffErr) return kHuffErr;
+  t.child[me][0] = (int16_t)c0;
+  t.child[me][1] = (int16_t)c1;
+  return me;
+}
+
+int parse_setup(BitReader &br, th_setup_info *s) {   // spec 6.4
+  QuantParams &q = s->qp;
+  int nbits = (int)br.read(3);   // 6.4.1 loop filter limits
+  for (int qi = 0; qi < 64; qi++) q.lflims[qi] = (uint8_t)br.read(nbits);
+  nbits = (int)br.read(4) + 1;   // 6.4.2 quantization parameters
+  for (int qi = 0; qi < 64; qi++) q.acscale[qi] = (uint16_t)br.read(nbits);
+  nbits = (int)br.read(4) + 1;
+  for (int qi = 0; qi < 64; qi++) q.dcscale[qi] = (uint16_t)br.read(nbits);
+  q.nbms = (int)br.read(9) + 1;
+  if (q.nbms > 384) return TH_EBADHEADER;
+  q.bms.resize((size_t)q.nbms * 64);
+  for (int i = 0; i < q.nbms * 64; i++) q.bms[i] = (uint8_t)br.read(8);
+  for (int qti = 0; qti < 2; qti++)
+    for (int pli = 0; pli < 3; pli++) {
+      int newqr = 1;
+      if (qti > 0 || pli > 0) newqr = (int)br.bit();
+      if (!newqr) {
+        int rpqr = 0;
+        if (qti > 0) rpqr = (int)br.bit();
+        int qtj, plj;
+        if (rpqr) {
+          qtj = qti - 1;
+          plj = pli;
+        } else {
+          qtj = (3 * qti + pli - 1) / 3;
+          plj = (pli + 2) % 3;
+        }
+        q.nqrs[qti][pli] = q.nqrs[qtj][plj];
+        memcpy(q.qrsizes[qti][pli], q.qrsizes[qtj][plj], sizeof(q.qrsizes[0][0]));
+        memcpy(q.qrbmis[qti][pli], q.qrbmis[qtj][plj], sizeof(q.qrbmis[0][0]));
+      } else {
+        int qri = 0, qi = 0;
+        q.qrbmis[qti][pli][0] = (int)br.read(ilog((uint32_t)q.nbms - 1));
+        if (q.qrbmis[qti][pli][0] >= q.nbms) return TH_EBADHEADER;
+        do {
+          q.qrsizes[qti][pli][qri] = (int)br.read(ilog((uint32_t)(62 - qi))) + 1;
+          qi += q.qrsizes[qti][pli][qri];
+          qri++;
+          q.qrbmis[qti][pli][qri] = (int)br.read(ilog((uint32_t)q.nbms - 1));
+          if (q.qrbmis[qti][pli][qri] >= q.nbms) return TH_EBADHEADER;
+        } while (qi < 63 && qri < 63);
+        if (qi != 63) return TH_EBADHEADER;
+        q.nqrs[qti][pli] = qri;
+      }
+    }
+  for (int hti = 0; hti < 80; hti++) {   // 6.4.4
+    HuffTree &t = s->huff[hti];
+    t.nnodes = 0;
+    t.root_leaf = 0;
+    int nleaves = 0;
+    const int r = parse_huff_tree(br, t, 0, &nleaves);
+    if (r == kHuffErr) return TH_EBADHEADER;
+    if (t.nnodes == 0) t.root_leaf = -r;   // degenerate one-leaf tree: zero-length code
+    else if (r != 0) return TH_EBADHEADER;
+  }
+  return br.overrun() ? TH_EBADHEADER : 0;
+}
+
+// spec 6.4.3 "Computing a Quantization Matrix"; output in ZIG-ZAG order
+void compute_qmat(const QuantParams &q, int qti, int pli, int qi, uint16_t out_zz[64]) {
+  int qri = 0, qistart = 0;
+  while (qri < q.nqrs[qti][pli] - 1 && qi > qistart + q.qrsizes[qti][pli][qri]) {
+    qistart += q.qrsizes[qti][pli][qri];
+    qri++;
+  }
+  const int size = q.qrsizes[qti][pli][qri];
+  const int qiend = qistart + size;
+  const uint8_t *bmi = &q.bms[(size_t)q.qrbmis[qti][pli][qri] * 64];
+  const uint8_t *bmj = &q.bms[(size_t)q.qrbmis[qti][pli][qri + 1] * 64];
+  for (int zzi = 0; zzi < 64; zzi++) {
+    const int ci = kZigZag[zzi];
+    const int bm = (2 * (qiend - qi) * bmi[ci] + 2 * (qi - qistart) * bmj[ci] + size) / (2 * size);
+    const int qmin = ci == 0 ? (qti == 0 ? 16 : 32) : (qti == 0 ? 8 : 16);
+    const int qscale = ci == 0 ? q.dcscale[qi] : q.acscale[qi];
+    int v = (qscale * bm / 100) * 4;
+    if (v > 4096) v = 4096;
+    if (v < qmin) v = qmin;
+    out_zz[zzi] = (uint16_t)v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// run-length coded bit strings (spec 7.2)
+// ---------------------------------------------------------------------------------------
+void read_long_run_bits(BitReader &br, size_t nbits, std::vector<uint8_t> &out) {   // 7.2.1
+  out.assign(nbits, 0);
+  size_t len = 0;
+  if (!nbits) return;
+  uint32_t bit = br.bit();
+  for (;;) {
+    int rstart, rbits;
+    if (!br.bit()) { rstart = 1; rbits = 0; }
+    else if (!br.bit()) { rstart = 2; rbits = 1; }
+    else if (!br.bit()) { rstart = 4; rbits = 1; }
+    else if (!br.bit()) { rstart = 6; rbits = 2; }
+    else if (!br.bit()) { rstart = 10; rbits = 3; }
+    else if (!br.bit()) { rstart = 18; rbits = 4; }
+    else { rstart = 34; rbits = 12; }
+    size_t rlen = (size_t)rstart + br.read(rbits);
+    const bool full = rlen == 4129;
+    if (rlen > nbits - len) rlen = nbits - len;   // invalid stream: clip
+    memset(&out[len], (int)bit, rlen);
+    len += rlen;
+    if (len >= nbits || br.overrun()) return;
+    bit = full ? br.bit() : 1 - bit;
+  }
+}
+
+void read_short_run_bits(BitReader &br, size_t nbits, std::vector<uint8_t> &out) {   // 7.2.2
+  out.assign(nbits, 0);
+  size_t len = 0;
+  if (!nbits) return;
+  uint32_t bit = br.bit();
+  for (;;) {
+    int rstart, rbits;
+    if (!br.bit()) { rstart = 1; rbits = 1; }
+    else if (!br.bit()) { rstart = 3; rbits = 1; }
+    else if (!br.bit()) { rstart = 5; rbits = 1; }
+    else if (!br.bit()) { rstart = 7; rbits = 2; }
+    else if (!br.bit()) { rstart = 11; rbits = 2; }
+    else { rstart = 15; rbits = 4; }
+    size_t rlen = (size_t)rstart + br.read(rbits);
+    if (rlen > nbits - len) rlen = nbits - len;
+    memset(&out[len], (int)bit, rlen);
+    len += rlen;
+    if (len >= nbits || br.overrun()) return;
+    bit = 1 - bit;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// motion vectors (spec 7.5.1)
+// ---------------------------------------------------------------------------------------
+int read_mv_component(BitReader &br, int mvmode) {
+  if (mvmode) {
+    int v = (int)br.read(5);
+    return br.bit() ? -v : v;
+  }
+  const uint32_t p = br.read(3);   // Table 7.23 is a 3-bit prefix + magnitude bits + sign
+  int mag;
+  switch (p) {
+    case 0: return 0;
+    case 1: return 1;
+    case 2: return -1;
+    case 3: mag = 2; break;
+    case 4: mag = 3; break;
+    case 5: mag = 4 + (int)br.read(2); break;
+    case 6: mag = 8 + (int)br.read(3); break;
+    default: mag = 16 + (int)br.read(4); break;
+  }
+  return br.bit() ? -mag : mag;
+}
+
+inline int round_div(int v, int shift) {   // round(v / 2^shift), ties away from zero (spec 7.5.2)
+  const int half = 1 << (shift - 1);
+  return v >= 0 ? (v + half) >> shift : -((-v + half) >> shift);
+}
+
+// ---------------------------------------------------------------------------------------
+// DCT tokens (spec 7.7)
+// ---------------------------------------------------------------------------------------
+inline int read_token(BitReader &br, const HuffTree &t) {
+  if (t.root_leaf) return t.root_leaf - 1;
+  int node = 0;
+  for (;;) {
+    const int c = t.child[node][br.bit()];
+    if (c < 0) return -c - 1;
+    node = c;
+    if (br.overrun()) return 0;
+  }
+}
+
+// Tables 7.33 / 7.38: expands token + extra bits.  For EOB tokens returns the run length in
+// tok.eob (0 extra on token 6 -> "all remaining", signalled as 0xFFFFFFFF).
+inline void decode_token(BitReader &br, int token, Tok &k) {
+  k.value = 0;
+  k.skip = 0;
+  k.adv = 1;
+  k.eob = 0;
+  int sign;
+  switch (token) {
+    case 0: k.eob = 1; k.adv = 0; break;
+    case 1: k.eob = 2; k.adv = 0; break;
+    case 2: k.eob = 3; k.adv = 0; break;
+    case 3: k.eob = 4 + br.read(2); k.adv = 0; break;
+    case 4: k.eob = 8 + br.read(3); k.adv = 0; break;
+    case 5: k.eob = 16 + br.read(4); k.adv = 0; break;
+    case 6: k.eob = br.read(12); if (!k.eob) k.eob = 0xFFFFFFFFu; k.adv = 0; break;
+    case 7: k.adv = (uint8_t)(br.read(3) + 1); k.skip = k.adv; break;    // pure zero runs: value 0
+    case 8: k.adv = (uint8_t)(br.read(6) + 1); k.skip = k.adv; break;
+    case 9: k.value = 1; break;
+    case 10: k.value = -1; break;
+    case 11: k.value = 2; break;
+    case 12: k.value = -2; break;
+    case 13: case 14: case 15: case 16:
+      k.value = (int16_t)(token - 10);
+      if (br.bit()) k.value = (int16_t)-k.value;
+      break;
+    case 17: sign = (int)br.bit(); k.value = (int16_t)(7 + br.read(1)); if (sign) k.value = (int16_t)-k.value; break;
+    case 18: sign = (int)br.bit(); k.value = (int16_t)(9 + br.read(2)); if (sign) k.value = (int16_t)-k.value; break;
+    case 19: sign = (int)br.bit(); k.value = (int16_t)(13 + br.read(3)); if (sign) k.value = (int16_t)-k.value; break;
+    case 20: sign = (int)br.bit(); k.value = (int16_t)(21 + br.read(4)); if (sign) k.value = (int16_t)-k.value; break;
+    case 21: sign = (int)br.bit(); k.value = (int16_t)(37 + br.read(5)); if (sign) k.value = (int16_t)-k.value; break;
+    case 22: sign = (int)br.bit(); k.value = (int16_t)(69 + br.read(9)); if (sign) k.value = (int16_t)-k.value; break;
+    case 23: case 24: case 25: case 26: case 27:
+      k.skip = (uint8_t)(token - 22);
+      k.value = br.bit() ? -1 : 1;
+      k.adv = (uint8_t)(k.skip + 1);
+      break;
+    case 28: sign = (int)br.bit(); k.skip = (uint8_t)(6 + br.read(2)); k.value = sign ? -1 : 1; k.adv = (uint8_t)(k.skip + 1); break;
+    case 29: sign = (int)br.bit(); k.skip = (uint8_t)(10 + br.read(3)); k.value = sign ? -1 : 1; k.adv = (uint8_t)(k.skip + 1); break;
+    case 30:
+      sign = (int)br.bit();
+      k.value = (int16_t)(2 + br.read(1));
+      if (sign) k.value = (int16_t)-k.value;
+      k.skip = 1;
+      k.adv = 2;
+      break;
+    default:   // 31
+      sign = (int)br.bit();
+      k.value = (int16_t)(2 + br.read(1));
+      if (sign) k.value = (int16_t)-k.value;
+      k.skip = (uint8_t)(2 + br.read(1));
+      k.adv = (uint8_t)(k.skip + 1);
+      break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// geometry (spec 2.3 - 2.4): coded order, super blocks, macro blocks
+// ---------------------------------------------------------------------------------------
+void build_geometry(th_dec_ctx *d) {
+  const int fmt = (int)d->info.pixel_fmt;
+  d->hdec = !(fmt & 1);
+  d->vdec = !(fmt & 2);
+  const int yh = (int)d->info.frame_width >> 3, yv = (int)d->info.frame_height >> 3;
+  int fro = 0;
+  for (int p = 0; p < 3; p++) {
+    d->nh[p] = p ? (yh + d->hdec) >> d->hdec : yh;
+    d->nv[p] = p ? (yv + d->vdec) >> d->vdec : yv;
+    d->fro[p] = fro;
+    d->nfrags_pl[p] = d->nh[p] * d->nv[p];
+    fro += d->nfrags_pl[p];
+  }
+  d->nfrags = fro;
+  d->coded_order.clear();
+  d->sb_start.clear();
+  for (int p = 0; p < 3; p++)
+    for (int sby = 0; sby < d->nv[p]; sby += 4)
+      for (int sbx = 0; sbx < d->nh[p]; sbx += 4) {
+        d->sb_start.push_back((int32_t)d->coded_order.size());
+        for (int k = 0; k < 16; k++) {
+          const int by = sby + kHilbert[k][0], bx = sbx + kHilbert[k][1];
+          if (by < d->nv[p] && bx < d->nh[p]) d->coded_order.push_back(d->fro[p] + by * d->nh[p] + bx);
+        }
+      }
+  d->nsbs = (int)d->sb_start.size();
+  d->sb_start.push_back((int32_t)d->coded_order.size());
+  // macro blocks: luma super blocks in raster order, four macro blocks each in coded order
+  d->mbs.clear();
+  for (int sby = 0; sby < yv; sby += 4)
+    for (int sbx = 0; sbx < yh; sbx += 4)
+      for (int k = 0; k < 4; k++) {
+        const int my = sby + 2 * kMbOrder[k][0], mx = sbx + 2 * kMbOrder[k][1];
+        if (my >= yv || mx >= yh) continue;   // frame sizes are multiples of 16: whole MBs only
+        MacroBlock mb;
+        for (int i = 0; i < 2; i++)
+          for (int j = 0; j < 2; j++) mb.luma[i * 2 + j] = (my + i) * yh + mx + j;
+        for (int c = 0; c < 2; c++)
+          for (int i = 0; i < 4; i++) mb.chroma[c][i] = -1;
+        const int cx = mx >> d->hdec, cy = my >> d->vdec;
+        const int ncx = d->hdec ? 1 : 2, ncy = d->vdec ? 1 : 2;
+        mb.nchroma = ncx * ncy;
+        for (int c = 0; c < 2; c++) {
+          // raster order inside the macro block; slot = i*2+j so that 4:4:4 lines up with
+          // luma A,B,C,D and 4:2:2 uses slots 0 (bottom) and 2 (top)
+          for (int i = 0; i < ncy; i++)
+            for (int j = 0; j < ncx; j++)
+              mb.chroma[c][i * 2 + j] = d->fro[1 + c] + (cy + i) * d->nh[1] + cx + j;
+        }
+        d->mbs.push_back(mb);
+      }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// API
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+void th_info_init(th_info *info) {
+  if (!info) return;
+  memset(info, 0, sizeof(*info));
+  info->version_major = 3;
+  info->version_minor = 2;
+  info->version_subminor = 1;
+  info->keyframe_granule_shift = 6;
+}
+void th_info_clear(th_info *info) {
+  if (info) memset(info, 0, sizeof(*info));
+}
+void th_comment_init(th_comment *tc) {
+  if (tc) memset(tc, 0, sizeof(*tc));
+}
+void th_comment_clear(th_comment *tc) {
+  if (!tc) return;
+  for (int i = 0; i < tc->comments; i++) free(tc->user_comments[i]);
+  free(tc->user_comments);
+  free(tc->comment_lengths);
+  free(tc->vendor);
+  memset(tc, 0, sizeof(*tc));
+}
+
+int th_decode_headerin(th_info *info, th_comment *tc, th_setup_info **setup, ogg_packet *op) {
+  if (!op) return TH_EBADHEADER;
+  if (!info) return TH_EFAULT;
+  if (op->bytes <= 0 || !op->packet) return TH_EBADHEADER;
+  // a data packet after all three headers ends header decode (theoradec.h:218-233)
+  if (!(op->packet[0] & 0x80)) {
+    if (info->frame_width && tc && tc->vendor && setup && *setup) return 0;
+    return TH_ENOTFORMAT;
+  }
+  BitReader br(op->packet, (size_t)op->bytes);
+  const int type = op->packet[0];
+  int rc;
+  if (type == 0x80) {
+    if (!op->b_o_s || info->frame_width) return TH_EBADHEADER;
+    if ((rc = read_common_header(br, 0x80)) < 0) return rc;
+    if ((rc = parse_info(br, info)) < 0) {
+      th_info_clear(info);
+      return rc;
+    }
+    return 3;
+  }
+  if (type == 0x81) {
+    if (!tc) return TH_EFAULT;
+    if (!info->frame_width || tc->vendor) return TH_EBADHEADER;
+    if ((rc = read_common_header(br, 0x81)) < 0) return rc;
+    if ((rc = parse_comment(br, tc)) < 0) {
+      th_comment_clear(tc);
+      return rc;
+    }
+    return 2;
+  }
+  if (type == 0x82) {
+    if (!tc || !setup) return TH_EFAULT;
+    if (!info->frame_width || !tc->vendor || *setup) return TH_EBADHEADER;
+    if ((rc = read_common_header(br, 0x82)) < 0) return rc;
+    th_setup_info *s = new th_setup_info();
+    if ((rc = parse_setup(br, s)) < 0) {
+      delete s;
+      return rc;
+    }
+    *setup = s;
+    return 1;
+  }
+  return TH_EBADHEADER;
+}
+
+void th_setup_free(th_setup_info *setup) { delete setup; }
+
+th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup) {
+  if (!info || !setup) return nullptr;
+  if ((info->frame_width & 15) || (info->frame_height & 15) || !info->frame_width || !info->frame_height ||
+      info->pixel_fmt == TH_PF_RSVD || (int)info->pixel_fmt < 0 || (int)info->pixel_fmt > 3)
+    return nullptr;
+  th_dec_ctx *d = new th_dec_ctx();
+  d->info = *info;
+  d->setup = *setup;
+  d->hip = nullptr;
+  if (thip_state_create(&d->hip, (int)info->frame_width, (int)info->frame_height, (int)info->pixel_fmt) < 0) {
+    delete d;
+    return nullptr;
+  }
+  build_geometry(d);
+  d->dequant.resize((size_t)64 * 3 * 2 * 64);
+  for (int qi = 0; qi < 64; qi++)
+    for (int p = 0; p < 3; p++)
+      for (int qti = 0; qti < 2; qti++)
+        compute_qmat(d->setup.qp, qti, p, qi, &d->dequant[(((size_t)qi * 3 + p) * 2 + qti) * 64]);
+  d->coded.assign(d->nfrags, 0);
+  d->refi.assign(d->nfrags, 0);
+  d->qii.assign(d->nfrags, 0);
+  d->mvx.assign(d->nfrags, 0);
+  d->mvy.assign(d->nfrags, 0);
+  d->dc.assign(d->nfrags, 0);
+  d->mbmode_of_frag.assign(d->nfrags, 0);
+  d->mbmodes.assign(d->mbs.size(), 0);
+  d->keyframe_num = d->curframe_num = 0;
+  d->granpos = 0;
+  // streams of bitstream version 3.2.1 and later count frames from 1 (state.c:740-745)
+  d->granpos_bias = (info->version_major > 3 ||
+                     (info->version_major == 3 && (info->version_minor > 2 ||
+                                                   (info->version_minor == 2 && info->version_subminor >= 1))))
+                        ? 1 : 0;
+  d->have_frame = false;
+  for (int p = 0; p < 3; p++) d->mirror[p].assign((size_t)d->nh[p] * 8 * d->nv[p] * 8, 0);
+  return d;
+}
+
+void th_decode_free(th_dec_ctx *d) {
+  if (!d) return;
+  thip_state_free(d->hip);
+  delete d;
+}
+
+int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
+  switch (req) {
+    case TH_DECCTL_GET_PPLEVEL_MAX:
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(int)) return TH_EINVAL;
+      *(int *)buf = 0;   // out-of-loop post-processing is not provided
+      return 0;
+    case TH_DECCTL_SET_PPLEVEL:
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(int)) return TH_EINVAL;
+      return *(int *)buf == 0 ? 0 : TH_EINVAL;
+    case TH_DECCTL_SET_GRANPOS: {
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(int64_t)) return TH_EINVAL;
+      const int64_t g = *(int64_t *)buf;
+      if (g < 0) return TH_EINVAL;
+      d->granpos = g;
+      d->keyframe_num = (g >> d->info.keyframe_granule_shift) - d->granpos_bias;
+      d->curframe_num = d->keyframe_num + (g & (((int64_t)1 << d->info.keyframe_granule_shift) - 1));
+      return 0;
+    }
+    default: return TH_EIMPL;
+  }
+}
+
+int64_t th_granule_frame(void *encdec, int64_t granpos) {
+  th_dec_ctx *d = (th_dec_ctx *)encdec;
+  if (!d || granpos < 0) return -1;
+  const int shift = d->info.keyframe_granule_shift;
+  const int64_t iframe = granpos >> shift;
+  const int64_t pframe = granpos - (iframe << shift);
+  return iframe + pframe - d->granpos_bias;
+}
+
+// One data packet: spec 7.1 - 7.11, ending in the vtable slots of the HIP backend.
+int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
+  if (!d || !op) return TH_EFAULT;
+  const int N = d->nfrags;
+  int ncoded_total = 0;
+  BitReader br(op->packet, op->bytes > 0 ? (size_t)op->bytes : 0);
+  if (op->bytes == 0) {
+    // an empty packet is a dropped frame: an inter frame with no coded blocks (decode.c:2746)
+    d->frame_type = THIP_INTER_FRAME;
+    memset(d->coded.data(), 0, (size_t)N);
+  } else {
+    // ---- 7.1 frame header -------------------------------------------------------------------
+    if (br.bit()) return TH_EBADPACKET;
+    d->frame_type = (int)br.bit();
+    d->nqis = 0;
+    do {
+      d->qis[d->nqis++] = (int)br.read(6);
+    } while (d->nqis < 3 && br.bit());
+    if (d->frame_type == THIP_INTRA_FRAME) {
+      if (br.read(3) != 0) return TH_EIMPL;
+      memset(d->coded.data(), 1, (size_t)N);   // 7.3 step 1
+      ncoded_total = N;
+    } else {
+      // ---- 7.3 coded block flags ---------------------------------------------------------------
+      read_long_run_bits(br, (size_t)d->nsbs, d->sbp);
+      size_t nfull = 0;
+      for (int s = 0; s < d->nsbs; s++) nfull += !d->sbp[s];
+      std::vector<uint8_t> fbits;
+      read_long_run_bits(br, nfull, fbits);
+      d->sbf.assign((size_t)d->nsbs, 0);
+      size_t fi = 0, nblk = 0;
+      for (int s = 0; s < d->nsbs; s++) {
+        if (!d->sbp[s]) d->sbf[s] = fbits[fi++];
+        else nblk += (size_t)(d->sb_start[s + 1] - d->sb_start[s]);
+      }
+      std::vector<uint8_t> bbits;
+      read_short_run_bits(br, nblk, bbits);
+      size_t bi = 0;
+      for (int s = 0; s < d->nsbs; s++)
+        for (int k = d->sb_start[s]; k < d->sb_start[s + 1]; k++) {
+          const uint8_t c = d->sbp[s] ? bbits[bi++] : d->sbf[s];
+          d->coded[d->coded_order[k]] = c;
+          ncoded_total += c;
+        }
+    }
+  }
+  // no reference yet on an inter frame: the backend substitutes mid-grey (decode.c:2757-2762)
+  d->granpos = ((d->keyframe_num + d->granpos_bias) << d->info.keyframe_granule_shift) +
+               (d->curframe_num - d->keyframe_num);
+  if (ncoded_total == 0) {   // decode.c:2764-2772
+    d->curframe_num++;
+    if (granpos) *granpos = d->granpos;
+    return TH_DUPFRAME;
+  }
+  if (d->frame_type == THIP_INTRA_FRAME) {
+    d->keyframe_num = d->curframe_num;
+    d->granpos = ((d->keyframe_num + d->granpos_bias) << d->info.keyframe_granule_shift);
+    memset(d->refi.data(), THIP_FRAME_SELF, (size_t)N);
+    memset(d->mbmode_of_frag.data(), MODE_INTRA, (size_t)N);
+    memset(d->mvx.data(), 0, (size_t)N);
+    memset(d->mvy.data(), 0, (size_t)N);
+  } else {
+    // ---- 7.4 macro block coding modes -----------------------------------------------------------
+    const int mscheme = (int)br.read(3);
+    uint8_t alphabet[8];
+    if (mscheme == 0) {
+      for (int mode = 0; mode < 8; mode++) alphabet[br.read(3)] = (uint8_t)mode;
+    } else if (mscheme != 7) {
+      memcpy(alphabet, kModeAlphabets[mscheme - 1], 8);
+    }
+    for (size_t m = 0; m < d->mbs.size(); m++) {
+      const MacroBlock &mb = d->mbs[m];
+      const bool any = d->coded[mb.luma[0]] | d->coded[mb.luma[1]] | d->coded[mb.luma[2]] | d->coded[mb.luma[3]];
+      int mode = MODE_INTER_NOMV;
+      if (any) {
+        if (mscheme != 7) {
+          int mi = 0;
+          while (mi < 7 && br.bit()) mi++;
+          mode = alphabet[mi];
+        } else {
+          mode = (int)br.read(3);
+        }
+      }
+      d->mbmodes[m] = (uint8_t)mode;
+    }
+    // ---- 7.5 motion vectors ----------------------------------------------------------------------
+    const int mvmode = (int)br.bit();
+    int last1x = 0, last1y = 0, last2x = 0, last2y = 0;
+    for (size_t m = 0; m < d->mbs.size(); m++) {
+      const MacroBlock &mb = d->mbs[m];
+      const int mode = d->mbmodes[m];
+      int mx = 0, my = 0;
+      int lx[4] = {0, 0, 0, 0}, ly[4] = {0, 0, 0, 0};
+      if (mode == MODE_INTER_MV_FOUR) {
+        for (int k = 0; k < 4; k++)
+          if (d->coded[mb.luma[k]]) {
+            lx[k] = read_mv_component(br, mvmode);
+            ly[k] = read_mv_component(br, mvmode);
+            mx = lx[k];
+            my = ly[k];
+          }
+        last2x = last1x; last2y = last1y;
+        last1x = mx; last1y = my;
+      } else if (mode == MODE_GOLDEN_MV) {
+        mx = read_mv_component(br, mvmode);
+        my = read_mv_component(br, mvmode);
+      } else if (mode == MODE_INTER_MV_LAST2) {
+        mx = last2x; my = last2y;
+        last2x = last1x; last2y = last1y;
+        last1x = mx; last1y = my;
+      } else if (mode == MODE_INTER_MV_LAST) {
+        mx = last1x; my = last1y;
+      } else if (mode == MODE_INTER_MV) {
+        mx = read_mv_component(br, mvmode);
+        my = read_mv_component(br, mvmode);
+        last2x = last1x; last2y = last1y;
+        last1x = mx; last1y = my;
+      }
+      const uint8_t refi = kModeRefi[mode];
+      for (int k = 0; k < 4; k++) {
+        const int f = mb.luma[k];
+        d->refi[f] = refi;
+        d->mbmode_of_frag[f] = (uint8_t)mode;
+        d->mvx[f] = (int8_t)(mode == MODE_INTER_MV_FOUR ? lx[k] : mx);
+        d->mvy[f] = (int8_t)(mode == MODE_INTER_MV_FOUR ? ly[k] : my);
+      }
+      for (int c = 0; c < 2; c++)
+        for (int k = 0; k < 4; k++) {
+          const int f = mb.chroma[c][k];
+          if (f < 0) continue;
+          d->refi[f] = refi;
+          d->mbmode_of_frag[f] = (uint8_t)mode;
+          int cxv = mx, cyv = my;
+          if (mode == MODE_INTER_MV_FOUR) {
+            if (d->hdec && d->vdec) {          // 4:2:0: one block, average of four
+              cxv = round_div(lx[0] + lx[1] + lx[2] + lx[3], 2);
+              cyv = round_div(ly[0] + ly[1] + ly[2] + ly[3], 2);
+            } else if (d->hdec) {              // 4:2:2: bottom = A,B ; top = C,D
+              const int a = k == 0 ? 0 : 2;
+              cxv = round_div(lx[a] + lx[a + 1], 1);
+              cyv = round_div(ly[a] + ly[a + 1], 1);
+            } else if (d->vdec) {              // (decimated vertically only) left = A,C ; right = B,D
+              cxv = round_div(lx[k] + lx[k + 2], 1);
+              cyv = round_div(ly[k] + ly[k + 2], 1);
+            } else {                           // 4:4:4
+              cxv = lx[k];
+              cyv = ly[k];
+            }
+          }
+          d->mvx[f] = (int8_t)cxv;
+          d->mvy[f] = (int8_t)cyv;
+        }
+    }
+  }
+  // ---- 7.6 block-level qi ---------------------------------------------------------------------------
+  memset(d->qii.data(), 0, (size_t)N);
+  for (int q = 0; q + 1 < d->nqis; q++) {
+    size_t nb = 0;
+    for (int k = 0; k < N; k++) {
+      const int f = d->coded_order[k];
+      nb += d->coded[f] && d->qii[f] == q;
+    }
+    std::vector<uint8_t> bits;
+    read_long_run_bits(br, nb, bits);
+    size_t bi = 0;
+    for (int k = 0; k < N; k++) {
+      const int f = d->coded_order[k];
+      if (d->coded[f] && d->qii[f] == q) d->qii[f] = (uint8_t)(d->qii[f] + bits[bi++]);
+    }
+  }
+  // ---- 7.7 DCT tokens, unpacked by counts per (plane, index) list -------------------------------------
+  {
+    size_t left[3][64];
+    memset(left, 0, sizeof(left));
+    int cstart[4] = {0, d->nfrags_pl[0], d->nfrags_pl[0] + d->nfrags_pl[1], N};
+    for (int p = 0; p < 3; p++) {
+      size_t n = 0;
+      for (int k = cstart[p]; k < cstart[p + 1]; k++) n += d->coded[d->coded_order[k]];
+      left[p][0] = n;
+      for (int z = 0; z < 64; z++) d->toks[p][z].clear();
+    }
+    memset(d->eob_carry, 0, sizeof(d->eob_carry));
+    uint32_t eobs = 0;
+    int htil = 0, htic = 0;
+    for (int z = 0; z < 64; z++) {
+      if (z < 2) {
+        htil = (int)br.read(4);
+        htic = (int)br.read(4);
+      }
+      const int hg = z == 0 ? 0 : z <= 5 ? 1 : z <= 14 ? 2 : z <= 27 ? 3 : 4;
+      for (int p = 0; p < 3; p++) {
+        size_t n = left[p][z];
+        // an EOB run still open from an earlier list ends the first blocks of this one
+        if (eobs) {
+          const uint32_t take = eobs < n ? eobs : (uint32_t)n;
+          d->eob_carry[p][z] = take;
+          eobs -= take;
+          n -= take;
+        }
+        const HuffTree &tree = d->setup.huff[16 * hg + (p == 0 ? htil : htic)];
+        while (n > 0) {
+          Tok k;
+          decode_token(br, read_token(br, tree), k);
+          if (k.eob) {
+            if (k.eob == 0xFFFFFFFFu) {   // every block still open anywhere ends (7.7.1)
+              size_t all = n;
+              for (int pp = p + 1; pp < 3; pp++) all += left[pp][z];
+              for (int zz = z + 1; zz < 64; zz++)
+                for (int pp = 0; pp < 3; pp++) all += left[pp][zz];
+              k.eob = (uint32_t)all;
+            }
+            const uint32_t take = k.eob < n ? k.eob : (uint32_t)n;
+            eobs = k.eob - take;
+            n -= take;
+            d->toks[p][z].push_back(k);
+          } else {
+            const int nz = z + k.adv;
+            if (nz < 64) left[p][nz]++;
+            n--;
+            d->toks[p][z].push_back(k);
+          }
+          if (br.overrun() && n > 0) {   // truncated packet: close everything that is open
+            Tok e;
+            e.value = 0; e.skip = 0; e.adv = 0; e.eob = (uint32_t)n;
+            d->toks[p][z].push_back(e);
+            n = 0;
+          }
+        }
+      }
+    }
+  }
+  // ---- 7.8 undo DC prediction (the DC token values are the first coefficient of each block) -----------
+  // first pull the DC values out of the zzi == 0 lists, in coded order
+  {
+    int cstart[4] = {0, d->nfrags_pl[0], d->nfrags_pl[0] + d->nfrags_pl[1], N};
+    for (int p = 0; p < 3; p++) {
+      size_t ti = 0;
+      uint32_t run = d->eob_carry[p][0];
+      for (int k = cstart[p]; k < cstart[p + 1]; k++) {
+        const int f = d->coded_order[k];
+        if (!d->coded[f]) continue;
+        int16_t v = 0;
+        if (run) run--;
+        else {
+          const Tok &t = d->toks[p][0][ti];
+          if (t.eob) run = t.eob - 1;
+          else if (t.skip == 0) v = t.value;
+          // the token is consumed again by the expansion below; do not advance past it here
+          ti++;
+        }
+        d->dc[f] = v;
+      }
+    }
+    for (int p = 0; p < 3; p++) {
+      const int nh = d->nh[p], nv = d->nv[p];
+      int last[3] = {0, 0, 0};
+      for (int y = 0; y < nv; y++)
+        for (int x = 0; x < nh; x++) {
+          const int f = d->fro[p] + y * nh + x;
+          if (!d->coded[f]) continue;
+          const int r = d->refi[f];
+          // neighbours that are coded and predicted from the same frame (7.8.1, Table 7.47)
+          int mask = 0, l = 0, ul = 0, u = 0, ur = 0;
+          if (x > 0 && d->coded[f - 1] && d->refi[f - 1] == r) { mask |= 1; l = d->dc[f - 1]; }
+          if (y > 0) {
+            if (x > 0 && d->coded[f - nh - 1] && d->refi[f - nh - 1] == r) { mask |= 2; ul = d->dc[f - nh - 1]; }
+            if (d->coded[f - nh] && d->refi[f - nh] == r) { mask |= 4; u = d->dc[f - nh]; }
+            if (x + 1 < nh && d->coded[f - nh + 1] && d->refi[f - nh + 1] == r) { mask |= 8; ur = d->dc[f - nh + 1]; }
+          }
+          // weights and divisors of Table 7.47, indexed by which neighbours are available
+          static const int8_t W[16][4] = {{0, 0, 0, 0},  {1, 0, 0, 0},   {0, 1, 0, 0},  {1, 0, 0, 0},
+                                          {0, 0, 1, 0},  {1, 0, 1, 0},   {0, 0, 1, 0},  {29, -26, 29, 0},
+                                          {0, 0, 0, 1},  {75, 0, 0, 53}, {0, 1, 0, 1},  {75, 0, 0, 53},
+                                          {0, 0, 1, 0},  {75, 0, 0, 53}, {0, 3, 10, 3}, {29, -26, 29, 0}};
+          static const int16_t D[16] = {1, 1, 1, 1, 1, 2, 1, 32, 1, 128, 2, 128, 1, 128, 16, 32};
+          int pred;
+          if (mask == 0) pred = last[r];
+          else {
+            pred = (W[mask][0] * l + W[mask][1] * ul + W[mask][2] * u + W[mask][3] * ur) / D[mask];
+            if ((mask & 7) == 7) {   // L, UL and U all present: clamp outliers (7.8.1 step 5)
+              if (abs(pred - u) > 128) pred = u;
+              else if (abs(pred - l) > 128) pred = l;
+              else if (abs(pred - ul) > 128) pred = ul;
+            }
+          }
+          d->dc[f] = (int16_t)(d->dc[f] + pred);   // 16-bit wrap
+          last[r] = d->dc[f];
+        }
+    }
+  }
+  // ---- 7.9 reconstruction through the backend's vtable slots -------------------------------------------
+  int rc = thip_frame_begin(d->hip, d->frame_type);
+  if (rc < 0) return TH_EFAULT;
+  const int flimit = d->setup.qp.lflims[d->qis[0]];
+  {
+    alignas(16) int16_t block[128];
+    memset(block, 0, sizeof(block));
+    std::vector<ptrdiff_t> uncoded;
+    int cstart[4] = {0, d->nfrags_pl[0], d->nfrags_pl[0] + d->nfrags_pl[1], N};
+    for (int p = 0; p < 3; p++) {
+      size_t ti[64];
+      uint32_t run[64];
+      for (int z = 0; z < 64; z++) {
+        ti[z] = 0;
+        run[z] = d->eob_carry[p][z];
+      }
+      uncoded.clear();
+      for (int k = cstart[p]; k < cstart[p + 1]; k++) {
+        const int f = d->coded_order[k];
+        if (!d->coded[f]) {
+          uncoded.push_back(f);
+          continue;
+        }
+        const int qti = d->mbmode_of_frag[f] != MODE_INTRA;
+        const uint16_t *acq = &d->dequant[(((size_t)d->qis[d->qii[f]] * 3 + p) * 2 + qti) * 64];
+        const uint16_t dcq = d->dequant[(((size_t)d->qis[0] * 3 + p) * 2 + qti) * 64];
+        int z = 0, last_zzi = 0;
+        while (z < 64) {
+          last_zzi = z;
+          if (run[z]) {   // inside an EOB run at this index
+            run[z]--;
+            break;
+          }
+          if (ti[z] >= d->toks[p][z].size()) break;   // malformed stream
+          const Tok &t = d->toks[p][z][ti[z]++];
+          if (t.eob) {
+            run[z] = t.eob - 1;
+            break;
+          }
+          const int at = z + t.skip;
+          if (t.value != 0 && at < 64) block[kZigZag[at]] = (int16_t)(t.value * (int)acq[at]);   // spec 7.9.2
+          z += t.adv;
+        }
+        block[0] = d->dc[f];   // raw un-predicted DC; the slot dequantises it (state.c:967-979)
+        const int16_t mv = (int16_t)(((int)d->mvx[f] & 0xFF) | ((int)d->mvy[f] * 256));
+        rc = thip_state_frag_recon(d->hip, f, p, block, last_zzi, dcq, d->refi[f], mv);
+        if (rc < 0) return TH_EFAULT;
+      }
+      if (!uncoded.empty() && thip_frag_copy_list(d->hip, uncoded.data(), (ptrdiff_t)uncoded.size()) < 0)
+        return TH_EFAULT;
+      if (flimit && thip_state_loop_filter_frag_rows(d->hip, flimit, THIP_FRAME_SELF, p, 0, d->nv[p]) < 0)
+        return TH_EFAULT;
+    }
+  }
+  rc = thip_frame_flush(d->hip);
+  if (rc < 0) return TH_EFAULT;
+  d->have_frame = true;
+  d->curframe_num++;
+  if (granpos) *granpos = d->granpos;
+  return 0;
+}
+
+int th_decode_ycbcr_out(th_dec_ctx *d, th_ycbcr_buffer ycbcr) {
+  if (!d || !ycbcr) return TH_EFAULT;
+  uint8_t *dst[3];
+  int32_t strides[3];
+  for (int p = 0; p < 3; p++) {
+    dst[p] = d->mirror[p].data();
+    strides[p] = d->nh[p] * 8;
+    ycbcr[p].width = d->nh[p] * 8;
+    ycbcr[p].height = d->nv[p] * 8;
+    ycbcr[p].stride = strides[p];
+    ycbcr[p].data = dst[p];
+  }
+  if (d->have_frame && thip_state_ycbcr_out(d->hip, dst, strides) < 0) return TH_EFAULT;
+  return 0;
+}
+
+}  // extern "C"
