@@ -18,6 +18,19 @@ def test_header_and_binding_agree():
     assert declared_symbols() == sorted(n for n, _, _ in _lib.SYMBOLS)
 
 
+def test_decoder_api_header_and_exports_agree():
+    """include/theoradec_hip.h (the th_decode_* names of theoradec.h:234-322) <-> ctypes
+    binding <-> exported symbols."""
+    from theora_amd import build, _lib
+    text = open(os.path.join(ROOT, "include", "theoradec_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(th_[a-z0-9_]+)\s*\(", text)))
+    assert declared == sorted(n for n, _, _ in _lib.DEC_SYMBOLS)
+    lib = C.CDLL(build.build())
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
 def test_library_exports_every_declared_symbol():
     from theora_amd import build, _lib
     so = build.build()

@@ -74,3 +74,21 @@ def test_header_errors(hip):
     assert L.th_decode_headerin(C.byref(info), C.byref(tc), C.byref(setup), C.byref(op)) == -20   # not "theora"
     with pytest.raises(Exception):
         Decoder([hp[0], hp[2]])
+
+
+def test_corrupted_packet_changes_the_picture(hip):
+    """Negative control for the comparison above: flip one bit in the token area of a
+    keyframe and the decoded picture must differ from the clean decode."""
+    from theora_amd.decoder import Decoder
+    st = streamgen.Stream(64, 48, 0, seed=8)
+    hp = st.header_packets()
+    pkt, truth = st.frame(0)
+    a = Decoder(hp)
+    a.packetin(pkt)
+    clean = a.ycbcr_out()
+    bad = bytearray(pkt)
+    bad[len(bad) // 2] ^= 0x10
+    b = Decoder(hp)
+    b.packetin(bytes(bad))
+    dirty = b.ycbcr_out()
+    assert any(not np.array_equal(x, y) for x, y in zip(clean, dirty))
