@@ -12,6 +12,10 @@ through the C ABI (thip_decode_frames).  Prints ONE JSON line (rank 0).
 For N>1 launch with  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
 Streams are sharded whole across ranks (no data-path collective); RCCL is used for the
 barriers, the max-over-ranks time and the checksum gather.
+
+Secondary modes (one GPU, not the headline metric):
+  python bench.py --mode enc    BASELINE.json config 5: encoder block kernels, 1920x1088 4:4:4
+  python bench.py --mode e2e    packets in host memory -> th_decode_* -> YUV in host memory
 """
 import argparse
 import json
@@ -26,13 +30,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SIZES = {"4k": (3840, 2160), "1080p": (1920, 1088), "720p": (1280, 720), "qcif": (176, 144)}
+SIZES = {"4k": (3840, 2160), "1080p": (1920, 1088), "720p": (1280, 720), "cif": (352, 288), "qcif": (176, 144)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec peak
 KF_INTERVAL = 64
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="decode", choices=["decode", "enc", "e2e"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
@@ -43,11 +48,126 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of stream 0 the CPU oracle decodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
-    return ap.parse_args()
+    return ap.parse_known_args()
+
+
+def main_enc():
+    import torch
+    import theora_amd
+    import oracle
+
+    torch.cuda.set_device(0)
+    W, H, planes = 1920, 1088, 3
+    rng = np.random.default_rng(7)
+    # frame f-1 and frame f (f = f-1 shifted by (3,1) + noise), three planes stacked vertically
+    prev = rng.integers(0, 256, (H * planes + 16, W + 16)).astype(np.uint8)
+    cur = np.roll(prev, (1, 3), (0, 1))
+    cur = np.clip(cur.astype(np.int32) + rng.integers(-6, 7, cur.shape), 0, 255).astype(np.uint8)
+    stride = prev.shape[1]
+    by, bx = np.mgrid[0:H * planes // 8, 0:W // 8]
+    base = ((by * 8 + 8) * stride + bx * 8 + 8).reshape(-1).astype(np.int32)      # 97 920 blocks, 8-px margin
+    sites = [(0, 0), (-1, -1), (0, -1), (1, -1), (-1, 0), (1, 0), (-1, 1), (0, 1), (1, 1)]
+    src_offs = np.tile(base, len(sites))
+    ref_offs = np.concatenate([base + dy * stride + dx for dx, dy in sites]).astype(np.int32)
+    ref2_offs = (ref_offs + 1).astype(np.int32)
+    nblk = base.size
+    d_prev, d_cur = torch.from_numpy(prev).cuda(), torch.from_numpy(cur).cuda()
+    d_so, d_ro, d_r2 = (torch.from_numpy(a).cuda() for a in (src_offs, ref_offs, ref2_offs))
+    resid = rng.integers(-255, 256, (nblk, 64)).astype(np.int16)
+    d_res = torch.from_numpy(resid).cuda()
+
+    def timed(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    results = []
+    # --- fDCT ---------------------------------------------------------------------------------
+    t = timed(lambda: theora_amd.fdct8x8_batch(d_res))
+    got = theora_amd.fdct8x8_batch(d_res).cpu().numpy().reshape(-1, 64)
+    ncpu = 20000
+    t0 = time.perf_counter()
+    want = oracle.fdct8x8_batch(resid[:ncpu])
+    tc = time.perf_counter() - t0
+    assert np.array_equal(got[:ncpu], want)
+    results.append(dict(kernel="oc_enc_fdct8x8", units=nblk, unit="blocks", seconds=t, bytes_per_unit=256, cpu_rate=ncpu / tc))
+    # --- SAD / SATD / SATD2 ---------------------------------------------------------------------
+    for op, bpu in (("sad", 132), ("satd", 136), ("satd2", 136 + 64), ("intra_satd", 72)):
+        call = lambda: theora_amd.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)   # noqa: E731
+        t = timed(call)
+        v, dc = call()
+        ncpu = 30000
+        t0 = time.perf_counter()
+        wv, wdc = oracle.enc_metric_batch(op, cur, prev, stride, src_offs[:ncpu], ref_offs[:ncpu], ref2_offs[:ncpu], 0)
+        tc = time.perf_counter() - t0
+        assert np.array_equal(v.cpu().numpy()[:ncpu].view(np.uint32), wv)
+        results.append(dict(kernel="oc_enc_frag_" + op, units=src_offs.size, unit="(block,candidate)", seconds=t,
+                            bytes_per_unit=bpu, cpu_rate=ncpu / tc))
+    for r in results:
+        gbs = r["units"] * r["bytes_per_unit"] / r["seconds"] / 1e9
+        print(json.dumps({
+            "metric": r["kernel"] + " throughput", "value": round(r["units"] / r["seconds"] / 1e6, 1), "unit": "M%s/s" % r["unit"],
+            "config": {"workload": "1920x1088 4:4:4, %d %s per call, 9-site square pattern" % (r["units"], r["unit"])},
+            "ms_per_call": round(1e3 * r["seconds"], 4), "dtype": "u8/i16", "data": "synthetic", "bit_exact_vs_oracle": True,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "alg_bytes_per_unit": r["bytes_per_unit"]},
+            "cpu_baseline": {"value": round(r["cpu_rate"] / 1e6, 3), "unit": "M%s/s" % r["unit"], "cores": 1, "kind": "port"}}))
+
+
+
+def main_e2e(main_args, argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--loops", type=int, default=5)
+    ap.add_argument("--no-output", action="store_true", help="skip th_decode_ycbcr_out (no D2H)")
+    args = ap.parse_args(argv)
+    args.size = main_args.size if main_args.size != "4k" else "720p"   # the generator is Python: keep it small
+    import torch
+    from tests import streamgen
+    from theora_amd.decoder import Decoder
+    torch.cuda.set_device(0)
+    w, h = SIZES[args.size]
+    st = streamgen.Stream(w, h, 0, seed=99)
+    hdr = st.header_packets()
+    pkts = []
+    for f in range(args.frames):
+        pkt, truth = st.frame(0 if f % 8 == 0 else 1, density=0.7, p_dc_only=0.5, p_empty=0.2)
+        pkts.append(pkt)
+    nbytes = sum(len(p) for p in pkts)
+    dec = Decoder(hdr)
+    for p in pkts:                      # warm-up pass
+        dec.packetin(p)
+        dec.ycbcr_out()
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(args.loops):
+        for p in pkts:
+            dec.packetin(p)
+            if not args.no_output:
+                dec.ycbcr_out()
+            n += 1
+    if args.no_output:
+        dec.ycbcr_out()
+    el = time.perf_counter() - t0
+    print(json.dumps({"metric": "end-to-end decode frames/sec (%s 4:2:0, packets in host memory -> YUV in host memory)" % args.size,
+                      "value": round(n / el, 2), "unit": "frames/s", "frames": n, "host_threads": 1,
+                      "avg_packet_bytes": nbytes // len(pkts), "with_ycbcr_out": not args.no_output,
+                      "data": "synthetic packets (tests/streamgen.py)", "note": "host-bound: single-thread entropy decode + PCIe"}))
+
 
 
 def main():
-    args = parse_args()
+    args, rest = parse_args()
+    if args.mode == "enc":
+        return main_enc()
+    if args.mode == "e2e":
+        return main_e2e(args, rest)
     import torch
     import torch.distributed as dist
 
