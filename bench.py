@@ -97,6 +97,17 @@ def main_enc():
     tc = time.perf_counter() - t0
     assert np.array_equal(got[:ncpu], want)
     results.append(dict(kernel="oc_enc_fdct8x8", units=nblk, unit="blocks", seconds=t, bytes_per_unit=256, cpu_rate=ncpu / tc))
+    # --- quantiser (enquant.c:219) on the fDCT output ------------------------------------------
+    d_dct = theora_amd.fdct8x8_batch(d_res)
+    dq = np.clip(np.arange(64) * 3 + 16, 8, 4096).astype(np.uint16)
+    d_dq = torch.from_numpy(dq).cuda()
+    t = timed(lambda: theora_amd.enc_quantize_batch(d_dct, d_dq))
+    gq, gnz = theora_amd.enc_quantize_batch(d_dct, d_dq)
+    t0 = time.perf_counter()
+    wq, wnz = oracle.quantize_batch(got[:ncpu], dq)
+    tc = time.perf_counter() - t0
+    assert np.array_equal(gq.cpu().numpy().reshape(-1, 64)[:ncpu], wq) and np.array_equal(gnz.cpu().numpy()[:ncpu], wnz)
+    results.append(dict(kernel="oc_enc_quantize", units=nblk, unit="blocks", seconds=t, bytes_per_unit=260, cpu_rate=ncpu / tc))
     # --- SAD / SATD / SATD2 ---------------------------------------------------------------------
     for op, bpu in (("sad", 132), ("satd", 136), ("satd2", 136 + 64), ("intra_satd", 72)):
         call = lambda: theora_amd.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)   # noqa: E731

@@ -222,6 +222,12 @@ int thip_enc_frag_copy2_batch(uint8_t *dst_plane, const uint8_t *src_plane, int 
                               const int32_t *src2_offs, int64_t n);
 /* oc_enc_fdct8x8 (fdct.c:128): natural-order int16 in, ZIG-ZAG-ordered int16 out. */
 int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n);
+/* oc_enc_quantize (enquant.c:219) with the reciprocals of oc_enc_enquant_table_init
+   (enquant.c:193) derived on the device: n blocks of 64 zig-zag-ordered coefficients against
+   one 64-entry dequantisation table (device, zig-zag order); nonzero[i] = index of the last
+   non-zero quantised coefficient (the function's return value). */
+int thip_enc_quantize_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t *dequant,
+                            int64_t n);
 
 /* ------------------------------------------------------------------------------------
  * Measurement support for bench.py: HIP-event timing of the kernels of

@@ -76,6 +76,7 @@ def lib():
     L.orc_idct8x8.argtypes = [P, P, C.c_int]
     L.orc_idct8x8_full.argtypes = [P, P]
     L.orc_enc_fdct8x8_batch.argtypes = [P, P, C.c_ssize_t]
+    L.orc_enc_quantize_batch.argtypes = [P, P, P, P, C.c_ssize_t]
     L.orc_enc_metric_batch.argtypes = [C.c_int, P, P, P, P, C.c_int, P, P, P, C.c_uint, C.c_ssize_t]
     L.orc_mv_offsets.restype = C.c_int
     L.orc_mv_offsets.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -203,6 +204,16 @@ def fdct8x8_batch(x):
     y = np.empty_like(x)
     lib().orc_enc_fdct8x8_batch(_p(y), _p(x), x.shape[0])
     return y
+
+
+def quantize_batch(dct, dequant):
+    """oc_enc_quantize_c over [n,64] zig-zag-ordered coefficients with one 64-entry table."""
+    d = _c(dct, np.int16).reshape(-1, 64)
+    dq = _c(dequant, np.uint16)
+    q = np.empty_like(d)
+    nz = np.empty(d.shape[0], np.int32)
+    lib().orc_enc_quantize_batch(_p(q), _p(nz), _p(d), _p(dq), d.shape[0])
+    return q, nz
 
 
 METRIC_OPS = dict(sad=0, sad_thresh=1, sad2_thresh=2, intra_sad=3, satd=4, satd2=5, intra_satd=6, ssd=7)

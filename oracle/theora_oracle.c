@@ -839,6 +839,43 @@ void orc_enc_fdct8x8(int16_t y[64], const int16_t x[64]) {               /* fdct
   for (i = 0; i < 64; i++) y[i] = S16((w[ORC_FZIG_ZAG[i]] + 2) >> 2);   /* zig-zag ordered output */
 }
 
+/* reciprocal of one quantiser step, enquant.c:183-191 */
+void orc_enc_enquant_table_init(int16_t enquant[128], const uint16_t dequant[64]) {
+  int zzi;
+  for (zzi = 0; zzi < 64; zzi++) {
+    uint32_t d = (uint32_t)dequant[zzi] << 1, t;
+    int l = 0;
+    while ((d >> (l + 1)) != 0) l++;          /* OC_ILOGNZ_32(d)-1 */
+    t = 1 + ((uint32_t)1 << (16 + l)) / d;
+    enquant[2 * zzi] = (int16_t)(t - 0x10000);
+    enquant[2 * zzi + 1] = (int16_t)l;
+  }
+}
+
+/* enquant.c:219-248 */
+int orc_enc_quantize(int16_t qdct[64], const int16_t dct[64], const uint16_t dequant[64], const int16_t enquant[128]) {
+  int nonzero = 0, zzi;
+  for (zzi = 0; zzi < 64; zzi++) {
+    int val = dct[zzi], d = dequant[zzi], s;
+    val = val << 1;
+    if (abs(val) >= d) {
+      s = -(val < 0);
+      val += (d + s) ^ s;                      /* +-d: ties round away from zero */
+      val = (((((int32_t)enquant[2 * zzi] * (int32_t)val) >> 16) + val) >> enquant[2 * zzi + 1]) - s;
+      qdct[zzi] = S16(val);
+      nonzero = zzi;
+    } else qdct[zzi] = 0;
+  }
+  return nonzero;
+}
+
+void orc_enc_quantize_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t dequant[64], ptrdiff_t n) {
+  int16_t enq[128];
+  ptrdiff_t i;
+  orc_enc_enquant_table_init(enq, dequant);
+  for (i = 0; i < n; i++) nonzero[i] = orc_enc_quantize(qdct + i * 64, dct + i * 64, dequant, enq);
+}
+
 void orc_enc_fdct8x8_batch(int16_t *y, const int16_t *x, ptrdiff_t n) {
   ptrdiff_t i;
   for (i = 0; i < n; i++) orc_enc_fdct8x8(y + i * 64, x + i * 64);

@@ -144,6 +144,10 @@ unsigned orc_enc_frag_ssd(const uint8_t *src, const uint8_t *ref, int ystride); 
 unsigned orc_enc_frag_border_ssd(const uint8_t *src, const uint8_t *ref, int ystride, int64_t mask); /* :352 */
 void orc_enc_frag_copy2(uint8_t *dst, const uint8_t *src1, const uint8_t *src2, int ystride);   /* :368 */
 void orc_enc_fdct8x8(int16_t y[64], const int16_t x[64]);                                       /* fdct.c:128 */
+/* oc_iquant_init + oc_enc_quantize_c (enquant.c:183-248): enquant is 64 {m,l} int16 pairs */
+void orc_enc_enquant_table_init(int16_t enquant[128], const uint16_t dequant[64]);
+int orc_enc_quantize(int16_t qdct[64], const int16_t dct[64], const uint16_t dequant[64], const int16_t enquant[128]);
+void orc_enc_quantize_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t dequant[64], ptrdiff_t n);
 
 /* ---- batch drivers used by the tests and by bench.py's cpu_baseline leg ---- */
 void orc_idct8x8_batch(int16_t *y, const int16_t *x, const int32_t *last_zzi, ptrdiff_t n);

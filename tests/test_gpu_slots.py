@@ -229,3 +229,22 @@ def test_enc_sub_copy2_border_ssd(hip):
     rc = L.thip_enc_frag_copy2_batch(d_dst.data_ptr(), d_ref.data_ptr(), stride, dev(do).data_ptr(),
                                      dev(ro[:400]).data_ptr(), dev(r2[:400]).data_ptr(), 400)
     assert rc == 0 and np.array_equal(want, d_dst.cpu().numpy())
+
+
+def test_enc_quantize(hip):
+    """oc_enc_quantize_c + oc_iquant_init (enquant.c:183-248) for every legal step size."""
+    from theora_amd import _lib
+    import torch
+    rng = np.random.default_rng(10)
+    L = _lib.load()
+    n = 5000
+    for trial in range(6):
+        dq = rng.integers(8, 4097, 64).astype(np.uint16) if trial else np.full(64, 8, np.uint16)
+        if trial == 1:
+            dq[:] = 4096
+        dct = rng.integers(-32768 if trial > 3 else -9000, 32768 if trial > 3 else 9000, (n, 64)).astype(np.int16)
+        want_q, want_nz = oracle.quantize_batch(dct, dq)
+        q = torch.empty((n, 64), dtype=torch.int16, device="cuda")
+        nz = torch.empty(n, dtype=torch.int32, device="cuda")
+        assert L.thip_enc_quantize_batch(q.data_ptr(), nz.data_ptr(), dev(dct).data_ptr(), dev(dq).data_ptr(), n) == 0
+        assert np.array_equal(want_q, q.cpu().numpy()) and np.array_equal(want_nz, nz.cpu().numpy()), trial

@@ -239,6 +239,17 @@ def fdct8x8_batch(x_dev):
     return y
 
 
+def enc_quantize_batch(dct_dev, dequant_dev):
+    """oc_enc_quantize over [n,64] zig-zag-ordered int16 blocks; returns (qdct, nonzero)."""
+    import torch
+    n = dct_dev.numel() // 64
+    q = torch.empty_like(dct_dev)
+    nz = torch.empty(n, dtype=torch.int32, device=dct_dev.device)
+    _lib.check(_lib.load().thip_enc_quantize_batch(_ptr(q), _ptr(nz), _ptr(dct_dev), _ptr(dequant_dev), n),
+               "enc_quantize_batch")
+    return q, nz
+
+
 def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None, ref2_offs=None, thresh=0):
     import torch
     n = src_offs.numel()

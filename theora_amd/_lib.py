@@ -73,6 +73,7 @@ SYMBOLS = [
     ("thip_enc_frag_sub_batch", _I, [_P, _P, _P, _I, _P, _P, _I64]),
     ("thip_enc_frag_copy2_batch", _I, [_P, _P, _I, _P, _P, _P, _I64]),
     ("thip_enc_fdct8x8_batch", _I, [_P, _P, _I64]),
+    ("thip_enc_quantize_batch", _I, [_P, _P, _P, _P, _I64]),
     ("thip_profile_enable", _I, [_I]),
     ("thip_profile_read", _I, [C.POINTER(_I64), C.POINTER(C.c_double)]),
     ("thip_profile_reset", _I, []),

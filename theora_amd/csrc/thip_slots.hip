@@ -339,10 +339,57 @@ __global__ __launch_bounds__(256) void k_enc_fdct(int16_t *y, const int16_t *x, 
   store_block16(y + i * 64, o);
 }
 
+// oc_enc_quantize_c (enquant.c:219-248); the {m,l} reciprocal of each step is derived in
+// place exactly as oc_iquant_init does (enquant.c:183-191).
+__global__ __launch_bounds__(256) void k_enc_quantize(int16_t *qdct, int32_t *nonzero, const int16_t *dct,
+                                                     const uint16_t *dequant, int64_t n) {
+  __shared__ int s_d[64], s_m[64], s_l[64];
+  if (threadIdx.x < 64) {
+    const uint32_t d = (uint32_t)dequant[threadIdx.x] << 1;
+    const int l = 31 - __builtin_clz(d);                       // OC_ILOGNZ_32(d)-1
+    const uint32_t t = 1u + ((1u << (16 + l)) / d);
+    s_d[threadIdx.x] = (int)dequant[threadIdx.x];
+    s_m[threadIdx.x] = (int)(int16_t)(t - 0x10000u);
+    s_l[threadIdx.x] = l;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int v[64];
+  load_block16(v, dct + i * 64);
+  int nz = 0;
+#pragma unroll
+  for (int z = 0; z < 64; z++) {
+    int val = v[z] << 1;
+    const int d = s_d[z];
+    int q = 0;
+    if (abs(val) >= d) {
+      const int s = val >> 31;
+      val += (d + s) ^ s;
+      q = sx16((((s_m[z] * val) >> 16) + val >> s_l[z]) - s);
+      nz = z;
+    }
+    v[z] = q;
+  }
+  store_block16(qdct + i * 64, v);
+  nonzero[i] = nz;
+}
+
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
 extern "C" {
+
+int thip_enc_quantize_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t *dequant,
+                            int64_t n) {
+  if (!qdct || !nonzero || !dct || !dequant) return THIP_EFAULT;
+  if (n < 0) return THIP_EINVAL;
+  if (n == 0) return THIP_OK;
+  hipLaunchKernelGGL(k_enc_quantize, grid_for(n), dim3(256), 0, 0, qdct, nonzero, dct, dequant, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
 
 int thip_idct8x8_batch(int16_t *y, const int16_t *x, const int32_t *last_zzi, int64_t n) {
   if (!y || !x) return THIP_EFAULT;
