@@ -88,7 +88,7 @@ struct StreamK {
   int flimit2;            // 2*flimit
   int qpx, qpy;           // chroma axis decimated (quarter-pel chroma vectors)
   int tile_end[3];        // cumulative tile counts per plane (k_recon: one wave per tile)
-  int cell_end[3];        // cumulative filter-cell counts per plane (k_loopfilter)
+  int cell_end[3];        // cumulative filter-cell counts per plane, each plane padded to 64 (k_loopfilter)
   int lf_y0[3], lf_y1[3]; // fragment-row range whose filter operations are applied
   int debug;              // ablation switches for profiling (THIP_DEBUG env), 0 in production
   PlaneK pl[3];
@@ -181,29 +181,45 @@ __device__ __forceinline__ void unpack_row(int *P, uint32_t lo, uint32_t hi) {
   }
 }
 
-// A cell directly on a plane in memory (k_loopfilter, thip_loop_filter_plane).  The pixel
-// loads do not depend on the coded flags, so they are issued first and the flag loads
-// overlap them (one memory latency instead of two); cells without work simply skip the
-// stores.
+// A cell directly on a plane in memory (k_loopfilter, thip_loop_filter_plane).  Neither the
+// pixel loads nor the flag loads depend on anything loaded before, and none of them is
+// predicated: coordinates are clamped into the plane instead (border cells read a valid
+// neighbour whose value is never used), so a cell costs ONE memory round trip of eight
+// 8-byte loads + four flag bytes; cells without work skip the stores.
 struct CellPix {
   uint32_t lo[8], hi[8];
 };
+struct __attribute__((aligned(4))) Pix8 {
+  uint32_t x, y;
+};
 __device__ __forceinline__ void lf_cell_load(CellPix &C, const uint8_t *plane, int stride, int nh, int nv, int k,
                                              int m) {
-  const bool lo_ok = k >= 1, hi_ok = k <= nh - 1;
-  const uint8_t *base = plane + (ptrdiff_t)(8 * m - 4) * stride + (8 * k - 4);
-  const int H = nv * 8;
+  const int W = nh * 8, H = nv * 8;
+  const int xb = min(max(8 * k - 4, 0), W - 8);
 #pragma unroll
   for (int r = 0; r < 8; r++) {
-    const int y = 8 * m - 4 + r;
-    C.lo[r] = 0;
-    C.hi[r] = 0;
-    if (y >= 0 && y < H) {
-      const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)r * stride);
-      if (lo_ok) C.lo[r] = p[0];
-      if (hi_ok) C.hi[r] = p[1];
-    }
+    const int y = min(max(8 * m - 4 + r, 0), H - 1);
+    const Pix8 v = *reinterpret_cast<const Pix8 *>(plane + (ptrdiff_t)y * stride + xb);
+    C.lo[r] = k == nh ? v.y : v.x;   // right border: the half that exists is the upper dword of the clamped load
+    C.hi[r] = k == 0 ? v.x : v.y;    // left border: ... the lower dword
   }
+}
+// Keeps the pixel loads where they are written: without it the compiler sinks them below the
+// "no work in this cell" test, i.e. behind the flag loads' round trip.
+__device__ __forceinline__ void lf_cell_pin(const CellPix &C) {
+  asm volatile("" ::"v"(C.lo[0]), "v"(C.lo[1]), "v"(C.lo[2]), "v"(C.lo[3]), "v"(C.lo[4]), "v"(C.lo[5]), "v"(C.lo[6]),
+               "v"(C.lo[7]), "v"(C.hi[0]), "v"(C.hi[1]), "v"(C.hi[2]), "v"(C.hi[3]), "v"(C.hi[4]), "v"(C.hi[5]),
+               "v"(C.hi[6]), "v"(C.hi[7]));
+}
+// coded flags of the four fragments around corner (k,m), clamped the same way
+__device__ __forceinline__ void lf_cell_flags(const uint8_t *coded, int nh, int nv, int k, int m, bool &a, bool &b,
+                                              bool &c, bool &d) {
+  const int ka = max(k - 1, 0), kb = min(k, nh - 1), ma = max(m - 1, 0), mb = min(m, nv - 1);
+  const uint8_t fa = coded[ma * nh + ka], fb = coded[ma * nh + kb], fc = coded[mb * nh + ka], fd = coded[mb * nh + kb];
+  a = (k >= 1) & (m >= 1) & (fa != 0);
+  b = (k <= nh - 1) & (m >= 1) & (fb != 0);
+  c = (k >= 1) & (m <= nv - 1) & (fc != 0);
+  d = (k <= nh - 1) & (m <= nv - 1) & (fd != 0);
 }
 __device__ __forceinline__ void lf_cell_finish(const CellPix &C, uint8_t *plane, int stride, int nh, int nv, int k,
                                                int m, uint32_t t, int L2) {
@@ -219,9 +235,19 @@ __device__ __forceinline__ void lf_cell_finish(const CellPix &C, uint8_t *plane,
   for (int r = 0; r < 8; r++) {
     const int y = 8 * m - 4 + r;
     if (y >= 0 && y < H) {
-      uint32_t *p = reinterpret_cast<uint32_t *>(base + (ptrdiff_t)r * stride);
-      if (lo_ok) p[0] = pack4(P[r * 8 + 0], P[r * 8 + 1], P[r * 8 + 2], P[r * 8 + 3]);
-      if (hi_ok) p[1] = pack4(P[r * 8 + 4], P[r * 8 + 5], P[r * 8 + 6], P[r * 8 + 7]);
+      uint8_t *p = base + (ptrdiff_t)r * stride;
+      const uint32_t lo = pack4(P[r * 8 + 0], P[r * 8 + 1], P[r * 8 + 2], P[r * 8 + 3]);
+      const uint32_t hi = pack4(P[r * 8 + 4], P[r * 8 + 5], P[r * 8 + 6], P[r * 8 + 7]);
+      if (lo_ok & hi_ok) {
+        Pix8 o;
+        o.x = lo;
+        o.y = hi;
+        *reinterpret_cast<Pix8 *>(p) = o;
+      } else if (lo_ok) {
+        *reinterpret_cast<uint32_t *>(p) = lo;
+      } else {
+        *reinterpret_cast<uint32_t *>(p + 4) = hi;
+      }
     }
   }
 }
@@ -243,65 +269,81 @@ __device__ __forceinline__ void load_slot(const int4 *coeffs, uint32_t slot, uin
 }
 
 // Predictor of an inter block (fragment.c:59-80 with the offsets of state.c:846-957): one
-// reference block or the truncating average of two.
-__device__ __forceinline__ void fetch_predictor(const uint8_t *ref, int stride, int W, int H, int x0, int y0,
-                                                uint32_t flags, bool qpx, bool qpy, uint2 pred[8]) {
+// reference block or the truncating average of two.  Split in two so that the loads are in
+// flight while the inverse DCT runs: pred_issue() only computes addresses and issues the
+// row loads, pred_finish() turns the raw windows into the eight predictor rows.
+struct PredWin {
+  Row12 w[9];
+  int sx, sy, mx2, my2;   // first sample's position, second sample's offset (0 or +-1 per axis)
+  bool inside;            // the 9x9 footprint lies inside the frame: windows were loaded
+};
+
+__device__ __forceinline__ void pred_issue(PredWin &Q, const uint8_t *ref, int stride, int W, int H, int x0, int y0,
+                                           uint32_t flags, bool qpx, bool qpy) {
   const int dx = (int)(int8_t)(flags >> THIP_INFO_MVX_SHIFT);
   const int dy = (int)(int8_t)(flags >> THIP_INFO_MVY_SHIFT);
-  int mx, my, mx2, my2;
-  mv_axis(dx, qpx, mx, mx2);
-  mv_axis(dy, qpy, my, my2);
-  const int sx = x0 + mx, sy = y0 + my;
-  const bool two = (mx2 | my2) != 0;
-  const bool inside = sx + min(mx2, 0) >= 0 && sx + max(mx2, 0) + 8 <= W && sy + min(my2, 0) >= 0 &&
-                      sy + max(my2, 0) + 8 <= H;
-  if (inside) {
+  int mx, my;
+  mv_axis(dx, qpx, mx, Q.mx2);
+  mv_axis(dy, qpy, my, Q.my2);
+  Q.sx = x0 + mx;
+  Q.sy = y0 + my;
+  const int xs = Q.sx + min(Q.mx2, 0), ys = Q.sy + min(Q.my2, 0);
+  // (bitwise & on purpose: one compare chain, no nest of divergent branches)
+  Q.inside = (xs >= 0) & (Q.sx + max(Q.mx2, 0) + 8 <= W) & (ys >= 0) & (Q.sy + max(Q.my2, 0) + 8 <= H);
+  if (Q.inside) {
     // Both samples of a row lie in the 9 bytes starting at xs, i.e. inside one 12-byte
     // window aligned down to 4: one dword-aligned dwordx3 load per source row and byte
     // funnel shifts.  Vertical half-pel needs 9 source rows, not 16.
-    const int xs = sx + min(mx2, 0);
-    const int xw = xs & ~3;
-    const int offA = sx - xw, offB = sx + mx2 - xw;  // 0..4
-    const int ys = sy + min(my2, 0);
-    const int ra = sy - ys, rb = sy + my2 - ys;      // first source row of each sample: 0 or 1
-    const uint8_t *p1 = ref + (ptrdiff_t)ys * stride + xw;
-    Row12 w[9];
+    const uint8_t *p1 = ref + (ptrdiff_t)ys * stride + (xs & ~3);
 #pragma unroll
-    for (int r = 0; r < 8; r++) w[r] = load_row12(p1 + (ptrdiff_t)r * stride);
-    w[8] = w[7];
-    if (my2 != 0) w[8] = load_row12(p1 + (ptrdiff_t)8 * stride);
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const Row12 wa = ra ? w[r + 1] : w[r];
-      pred[r] = extract8(wa, offA);
-      if (two) {
-        const Row12 wb = rb ? w[r + 1] : w[r];
-        const uint2 b = extract8(wb, offB);
-        pred[r].x = avg4_trunc(pred[r].x, b.x);
-        pred[r].y = avg4_trunc(pred[r].y, b.y);
-      }
-    }
-  } else {
-    // the block reaches into the reference's UMV border: clamp every coordinate
-    // (== replicated padding, state.c:770-835)
+    for (int r = 0; r < 8; r++) Q.w[r] = load_row12(p1 + (ptrdiff_t)r * stride);
+    // the ninth row only exists for vertical half-pel; re-reading row 7 otherwise keeps the
+    // load unconditional and inside the frame
+    Q.w[8] = load_row12(p1 + (ptrdiff_t)(Q.my2 != 0 ? 8 : 7) * stride);
+  }
+}
+
+// The block reaches into the reference's UMV border: clamp every coordinate (== replicated
+// padding, state.c:770-835).  Rare (frame-edge blocks with outward vectors), so it runs
+// late, with its own exposed latency, instead of complicating the common path.
+__device__ __forceinline__ void pred_border(const uint8_t *ref, int stride, int W, int H, int sx, int sy, int mx2,
+                                         int my2, uint2 pred[8]) {
+  const bool two = (mx2 | my2) != 0;
 #pragma unroll 1
-    for (int r = 0; r < 8; r++) {
-      const int ya = min(max(sy + r, 0), H - 1);
-      const int yb = min(max(sy + my2 + r, 0), H - 1);
-      uint32_t w[2] = {0u, 0u};
+  for (int r = 0; r < 8; r++) {
+    const int ya = min(max(sy + r, 0), H - 1);
+    const int yb = min(max(sy + my2 + r, 0), H - 1);
+    uint32_t w[2] = {0u, 0u};
 #pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const int xa = min(max(sx + c, 0), W - 1);
-        int v = ref[(ptrdiff_t)ya * stride + xa];
-        if (two) {
-          const int xb = min(max(sx + mx2 + c, 0), W - 1);
-          v = (v + ref[(ptrdiff_t)yb * stride + xb]) >> 1;
-        }
-        w[c >> 2] |= (uint32_t)v << (8 * (c & 3));
+    for (int c = 0; c < 8; c++) {
+      const int xa = min(max(sx + c, 0), W - 1);
+      int v = ref[(ptrdiff_t)ya * stride + xa];
+      if (two) {
+        const int xb = min(max(sx + mx2 + c, 0), W - 1);
+        v = (v + ref[(ptrdiff_t)yb * stride + xb]) >> 1;
       }
+      w[c >> 2] |= (uint32_t)v << (8 * (c & 3));
+    }
 #pragma unroll
-      for (int rr = 0; rr < 8; rr++)
-        if (rr == r) pred[rr] = make_uint2(w[0], w[1]);
+    for (int rr = 0; rr < 8; rr++)
+      if (rr == r) pred[rr] = make_uint2(w[0], w[1]);
+  }
+}
+
+__device__ __forceinline__ void pred_finish(const PredWin &Q, uint2 pred[8]) {
+  const int xw = (Q.sx + min(Q.mx2, 0)) & ~3;
+  const int offA = Q.sx - xw, offB = Q.sx + Q.mx2 - xw;   // 0..4
+  const bool ra = Q.my2 < 0, rb = Q.my2 > 0;              // that sample starts one source row down
+  const bool two = (Q.mx2 | Q.my2) != 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const Row12 wa = ra ? Q.w[r + 1] : Q.w[r];
+    pred[r] = extract8(wa, offA);
+    if (two) {
+      const Row12 wb = rb ? Q.w[r + 1] : Q.w[r];
+      const uint2 b = extract8(wb, offB);
+      pred[r].x = avg4_trunc(pred[r].x, b.x);
+      pred[r].y = avg4_trunc(pred[r].y, b.y);
     }
   }
 }
@@ -309,121 +351,245 @@ __device__ __forceinline__ void fetch_predictor(const uint8_t *ref, int stride, 
 #ifndef THIP_RECON_WAVES
 #define THIP_RECON_WAVES 4
 #endif
-__global__ __launch_bounds__(256, THIP_RECON_WAVES) void k_recon(const BatchK B) {
-  const StreamK &S = B.s[blockIdx.y];
-  const int lane = (int)threadIdx.x & 63;
-  const int unit = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);   // this wave's tile, per plane
-  if (unit >= S.tile_end[2]) return;
-  const int pli = (unit >= S.tile_end[0] ? 1 : 0) + (unit >= S.tile_end[1] ? 1 : 0);
-  const PlaneK &G = S.pl[pli];
-  const int rel = unit - (pli == 0 ? 0 : (pli == 1 ? S.tile_end[0] : S.tile_end[1]));
-  const int sby = rel / G.tiles_x;
-  const int tx = rel - sby * G.tiles_x;
-  const int nh = G.nh, nv = G.nv, stride = G.stride;
-  const int h = lane & 15;
-  const int bx = tx * 16 + (lane >> 4) * 4 + hilb_col(h);
-  const int by = sby * 4 + hilb_row(h);
-  const bool valid = bx < nh && by < nv;
+// Waves per workgroup of k_recon.  Waves never cooperate, and a workgroup's wave slots and
+// LDS only become reusable together, so siblings of different length idle slots: 1 is best.
+#ifndef THIP_RECON_WG_WAVES
+#define THIP_RECON_WG_WAVES 1
+#endif
 
-  // ---- 1. command word; coefficient slot by ballot / prefix count over the coded mask -----
-  const uint2 info = S.info[(size_t)unit * THIP_TILE_FRAGS + lane];
-  const uint32_t flags = valid ? info.x : 0u;
-  const bool coded = (flags & THIP_INFO_CODED) != 0;
-  const bool dc_only = (flags & THIP_INFO_DC_ONLY) != 0;
-  const bool has_coeff = coded && !dc_only;
-  const uint64_t mask = __ballot(has_coeff);
-  uint32_t P[32];
-  if (mask != 0 && !(S.debug & 8)) {
-    const uint32_t slot = S.tile_slot0[unit] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    if (has_coeff) load_slot(S.coeffs, slot, P);
-  }
-  if (!has_coeff) {
-#pragma unroll
-    for (int i = 0; i < 32; i++) P[i] = 0u;
-  }
-  if (!valid) return;   // past the ragged edge of the plane (after the ballot)
-  S.coded_map[G.fro + by * nh + bx] = coded ? 1 : 0;
-  const int refi = (int)((flags >> THIP_INFO_REFI_SHIFT) & 3u);
-  const int last_zzi = (int)((flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
-  const int x0 = bx * 8, y0 = by * 8;
-  uint8_t *dst = S.self + G.off + (ptrdiff_t)y0 * stride + x0;
+// Optional wave-timeline instrumentation (tools/wave_trace.py builds a private copy of the
+// library with -DTHIP_TRACE; never defined in the product build).
+#ifdef THIP_TRACE
+__device__ unsigned long long *g_trace_buf;   // [blockIdx.y][tile][8]
+__device__ __forceinline__ unsigned long long trace_now() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define THIP_TR(rec, i) do { if (rec) (rec)[i] = trace_now(); } while (0)
+#else
+#define THIP_TR(rec, i) do { } while (0)
+#endif
 
-  // ---- 2. uncoded: copy from the previous frame (fragment.c:20-47) ------------------------------
-  if (!coded) {
-    const uint8_t *p = S.prev + G.off + (ptrdiff_t)y0 * stride + x0;
-    uint2 t[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) t[r] = *reinterpret_cast<const uint2 *>(p + (ptrdiff_t)r * stride);
-#pragma unroll
-    for (int r = 0; r < 8; r++) store_row8(dst + (ptrdiff_t)r * stride, t[r]);
-    return;
-  }
+// What a lane knows after the first round trip.
+struct ReconLane {
+  uint32_t flags, dcp;            // command word 0 (0 past the ragged edge), DC-only value
+  bool coded, dc_only, has_coeff;
+  int x0, y0;                     // pixel position of the block in its plane
+};
+struct ReconPlane {               // wave-uniform
+  uint8_t *self;
+  const uint8_t *prev, *gold;
+  uint8_t *coded_map;             // already offset to the plane's first fragment
+  int nh, nv, stride;
+  bool qpx, qpy;
+  int debug;
+  unsigned long long *tr;         // THIP_TRACE: this wave's record (lane 0 only), else null
+};
 
-  // ---- 3. predictor (fragment.c:49-80): 128, one reference block, or the average of two -----
-  uint2 pred[8];
-#pragma unroll
-  for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
-  if (refi != THIP_FRAME_SELF && !(S.debug & 2)) {
-    const uint8_t *ref = (refi == THIP_FRAME_PREV ? S.prev : S.gold) + G.off;
-    fetch_predictor(ref, stride, nh * 8, nv * 8, x0, y0, flags, pli != 0 && S.qpx, pli != 0 && S.qpy, pred);
-  }
+// Steps 3-5 of k_recon.  IDCT: the wave's coefficient loads into P are in flight.  Two
+// instantiations instead of one body with a merged P: a merge makes the register allocator
+// copy loaded registers right behind the loads, i.e. wait for them before the predictor
+// loads are even issued.
+template <bool IDCT>
+__device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane &L, const uint4 *lds_coef) {
+  uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
+
+  // ---- 3. predictor loads.  An uncoded fragment (fragment.c:20-47) is the zero-vector
+  //         predictor from the previous frame plus a zero residual: the same code path. ------------
+  const int refi = L.coded ? (int)((L.flags >> THIP_INFO_REFI_SHIFT) & 3u) : THIP_FRAME_PREV;
+  const bool inter = refi != THIP_FRAME_SELF && !(R.debug & 2);
+  const uint8_t *const ref = refi == THIP_FRAME_PREV ? R.prev : R.gold;
+  PredWin Q;
+  Q.inside = true;
+  if (inter) pred_issue(Q, ref, R.stride, R.nh * 8, R.nv * 8, L.x0, L.y0, L.coded ? L.flags : 0u, R.qpx, R.qpy);
+  R.coded_map[(L.y0 >> 3) * R.nh + (L.x0 >> 3)] = L.coded ? 1 : 0;
+  THIP_TR(R.tr, 2);   // every load of the second round trip is issued
 
   // ---- 4. residual: DC-only shortcut (state.c:967-975) or inverse DCT (idct.c:301) ------------
   uint32_t Y[32];
-  const uint32_t dcp = (info.y & 0xFFFFu) * 0x00010001u;   // {p, p}
-  const bool need_any = __any(has_coeff);
-  if (need_any && !(S.debug & 1)) {
+  if (IDCT) {
+    uint32_t P[32];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint4 w = lds_coef[q * 64];
+      P[q * 4 + 0] = w.x;
+      P[q * 4 + 1] = w.y;
+      P[q * 4 + 2] = w.z;
+      P[q * 4 + 3] = w.w;
+    }
+#ifdef THIP_TRACE
+    asm volatile("" : "+v"(P[31]));
+    THIP_TR(R.tr, 3);   // coefficients (and, with them, the predictor windows) have arrived
+#endif
+    const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
     pk_mask_by_last_zzi(P, last_zzi);
-    const bool all_zz10 = !__any(has_coeff && last_zzi > 10);
+    const bool all_zz10 = !__any(L.has_coeff && last_zzi > 10);
     pk_idct8x8(P, Y, all_zz10);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 32; i++) Y[i] = P[i];
   }
-  if (dc_only) {
+  if (!IDCT || !L.has_coeff) {   // DC-only: the pre-rounded value; uncoded: zero residual
+    const uint32_t fill = L.dc_only ? L.dcp : 0u;
 #pragma unroll
-    for (int i = 0; i < 32; i++) Y[i] = dcp;
+    for (int i = 0; i < 32; i++) Y[i] = fill;
   }
 
-  // ---- 5. reconstruct and store (8 aligned bytes per lane per row) --------------------------------
-  if (!(S.debug & 4)) {
+  // ---- 5. predictor rows (fragment.c:49-80: 128, one block, or the average of two),
+  //         reconstruct and store (8 aligned bytes per lane per row) ------------------------------
+  uint2 pred[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
+  if (inter) {
+    if (Q.inside) pred_finish(Q, pred);
+    else pred_border(ref, R.stride, R.nh * 8, R.nv * 8, Q.sx, Q.sy, Q.mx2, Q.my2, pred);
+  }
+  if (!(R.debug & 4)) {
 #pragma unroll
     for (int r = 0; r < 8; r++)
-      store_row8(dst + (ptrdiff_t)r * stride,
+      store_row8(dst + (ptrdiff_t)r * R.stride,
                  pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]),
                               pred[r]));
+  }
+  THIP_TR(R.tr, 4);   // stores issued
+}
+
+// A wave's life is exactly two memory round trips: (1) its 64 command words and the tile's
+// first slot number, (2) coefficients and predictor windows, all issued before anything
+// waits.  Everything read from the kernel arguments is wave-uniform and is forced into
+// scalar registers (readfirstlane on the tile number), so the per-plane table lookups are
+// scalar loads, not dependent vector loads.
+__global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_recon(const BatchK B) {
+  const StreamK &S = B.s[blockIdx.y];
+  const int lane = (int)threadIdx.x & 63;
+  const int unit = __builtin_amdgcn_readfirstlane((int)blockIdx.x * THIP_RECON_WG_WAVES + ((int)threadIdx.x >> 6));  // tile
+#ifdef THIP_TRACE
+  unsigned long long *tr = nullptr;
+  if (g_trace_buf && lane == 0) {
+    tr = g_trace_buf + ((size_t)blockIdx.y * (gridDim.x * THIP_RECON_WG_WAVES) + unit) * 8;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+    tr[5] = hwid;
+    tr[6] = xcc;
+  }
+  THIP_TR(tr, 0);
+#endif
+  // scalar batch 1: the stream's pointers and the plane boundaries (pinned by the empty asm:
+  // left alone, the compiler sinks each scalar load to its first use, which turns one wait
+  // into a chain of dependent ones)
+  const uint2 *info_p = S.info;
+  const int4 *coeffs_p = S.coeffs;
+  const uint32_t *slot0_p = S.tile_slot0;
+  uint8_t *self = S.self;
+  const uint8_t *prev = S.prev, *gold = S.gold;
+  uint8_t *coded_map = S.coded_map;
+  const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2];
+  const int debug = S.debug, sqpx = S.qpx, sqpy = S.qpy;
+  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
+               "s"(te0), "s"(te1), "s"(te2), "s"(debug), "s"(sqpx), "s"(sqpy));
+  if (unit >= te2) return;
+  const int pli = (unit >= te0 ? 1 : 0) + (unit >= te1 ? 1 : 0);
+  // scalar batch 2: the plane's geometry
+  const PlaneK G = S.pl[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.fro));
+
+  // ---- 1. command word + first slot of the tile (one round trip) -------------------------------
+  const uint32_t slot0 = slot0_p[unit];
+  const uint2 info = info_p[(size_t)unit * THIP_TILE_FRAGS + lane];
+  // both loads are consumed here as far as the compiler can tell, so the scalar load is issued
+  // next to the vector load instead of being sunk behind the wait for it
+  asm volatile("" ::"s"(slot0), "v"(info.x));
+#ifdef THIP_TRACE
+  THIP_TR(tr, 1);   // first round trip done
+#endif
+
+  const int rel = unit - (pli == 0 ? 0 : (pli == 1 ? te0 : te1));
+  const int sby = rel / G.tiles_x;
+  const int tx = rel - sby * G.tiles_x;
+  const int h = lane & 15;
+  const int bx = tx * 16 + (lane >> 4) * 4 + hilb_col(h);
+  const int by = sby * 4 + hilb_row(h);
+  const bool valid = bx < G.nh && by < G.nv;
+
+  ReconLane L;
+  L.flags = valid ? info.x : 0u;
+  L.dcp = (info.y & 0xFFFFu) * 0x00010001u;   // {p, p}
+  L.coded = (L.flags & THIP_INFO_CODED) != 0;
+  L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
+  L.has_coeff = L.coded && !L.dc_only;
+  L.x0 = bx * 8;
+  L.y0 = by * 8;
+  ReconPlane R;
+  R.self = self + G.off;
+  R.prev = prev + G.off;
+  R.gold = gold + G.off;
+  R.coded_map = coded_map + G.fro;
+  R.nh = G.nh;
+  R.nv = G.nv;
+  R.stride = G.stride;
+  R.qpx = pli != 0 && sqpx;
+  R.qpy = pli != 0 && sqpy;
+  R.debug = debug;
+#ifdef THIP_TRACE
+  R.tr = tr;
+#else
+  R.tr = nullptr;
+#endif
+
+  // ---- 2. coefficient loads (slot by prefix count over the mask), issued, not waited for.
+  //         The branch is wave-uniform and every lane loads (lanes without coefficients re-read
+  //         the tile's first slot -- same cache lines, no extra traffic -- and are overridden
+  //         in step 4). -----------------------------------------------------------------------------
+  const uint64_t mask = __ballot(L.has_coeff);
+  __shared__ uint4 s_coef[THIP_RECON_WG_WAVES * 8 * 64];   // [wave][piece][lane]: 8 KB per wave, wave-private
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  uint4 *const lds_wave = s_coef + wave * 512;
+  if (mask != 0 && !(debug & 9)) {
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
+    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
+    // global -> LDS directly (LDS address = wave-uniform base + lane*16): no VGPRs are tied up
+    // and nothing can make the compiler touch the data before the predictor loads are out
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
+                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
+    if (valid) recon_tail<true>(R, L, lds_wave + lane);   // (!valid: past the ragged edge of the plane)
+  } else {
+    if (valid) recon_tail<false>(R, L, lds_wave);
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // k_loopfilter (K3): one filter cell per lane over the whole frame
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool coded_at(const StreamK &S, const PlaneK &G, int bx, int by) {
-  return S.coded_map[G.fro + by * G.nh + bx] != 0;
-}
-
+// One wave never straddles two planes (the cumulative cell counts in StreamK::cell_end are
+// padded to whole waves), so the plane lookup is scalar, like k_recon's.
 __global__ __launch_bounds__(256) void k_loopfilter(const BatchK B) {
   const StreamK &S = B.s[blockIdx.y];
-  const int idx = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (idx >= S.cell_end[2] || S.flimit2 == 0) return;
-  const int pli = (idx >= S.cell_end[0] ? 1 : 0) + (idx >= S.cell_end[1] ? 1 : 0);
-  const PlaneK &G = S.pl[pli];
-  const int rel = idx - (pli == 0 ? 0 : (pli == 1 ? S.cell_end[0] : S.cell_end[1]));
+  const int lane = (int)threadIdx.x & 63;
+  const int wbase = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));
+  uint8_t *self = S.self;
+  const uint8_t *cmap = S.coded_map;
+  const int ce0 = S.cell_end[0], ce1 = S.cell_end[1], ce2 = S.cell_end[2], L2 = S.flimit2;
+  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2));
+  if (wbase >= ce2 || L2 == 0) return;
+  const int pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(fy0), "s"(fy1));
+  const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
   const int nh = G.nh, nv = G.nv;
+  if (rel >= (nh + 1) * (nv + 1)) return;
   uint32_t mu, ku;
   divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
   const int k = (int)ku, m = (int)mu;
   CellPix C;
-  lf_cell_load(C, S.self + G.off, G.stride, nh, nv, k, m);
-  const bool a = k >= 1 && m >= 1 && coded_at(S, G, k - 1, m - 1);
-  const bool b = k <= nh - 1 && m >= 1 && coded_at(S, G, k, m - 1);
-  const bool c = k >= 1 && m <= nv - 1 && coded_at(S, G, k - 1, m);
-  const bool d = k <= nh - 1 && m <= nv - 1 && coded_at(S, G, k, m);
-  const int fy0 = pli == 0 ? S.lf_y0[0] : (pli == 1 ? S.lf_y0[1] : S.lf_y0[2]);
-  const int fy1 = pli == 0 ? S.lf_y1[0] : (pli == 1 ? S.lf_y1[1] : S.lf_y1[2]);
+  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
+  bool a, b, c, d;
+  lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
   const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
-  lf_cell_finish(C, S.self + G.off, G.stride, nh, nv, k, m, t, S.flimit2);
+  lf_cell_pin(C);
+  lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
 }
 
 // plane-level entry for the slot parity test (thip_loop_filter_plane)
@@ -435,12 +601,10 @@ __global__ __launch_bounds__(256) void k_loopfilter_plane(uint8_t *plane, int st
   uint32_t mu, ku;
   divmod_u24((uint32_t)cell, (uint32_t)(nh + 1), rcp_cx, mu, ku);
   const int k = (int)ku, m = (int)mu;
-  const bool a = k >= 1 && m >= 1 && coded[(m - 1) * nh + k - 1];
-  const bool b = k <= nh - 1 && m >= 1 && coded[(m - 1) * nh + k];
-  const bool c = k >= 1 && m <= nv - 1 && coded[m * nh + k - 1];
-  const bool d = k <= nh - 1 && m <= nv - 1 && coded[m * nh + k];
   CellPix C;
   lf_cell_load(C, plane, stride, nh, nv, k, m);
+  bool a, b, c, d;
+  lf_cell_flags(coded, nh, nv, k, m, a, b, c, d);
   lf_cell_finish(C, plane, stride, nh, nv, k, m, lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1), L2);
 }
 
@@ -543,7 +707,7 @@ void fill_stream_geom(StreamK &K, const thip_state *st) {
     k.rcp_cx = 1.0f / (float)(g.nhfrags + 1);
     tiles += st->tiles.tiles_x[pli] * st->tiles.tiles_y[pli];
     K.tile_end[pli] = tiles;
-    cells += (g.nhfrags + 1) * (g.nvfrags + 1);
+    cells += ((g.nhfrags + 1) * (g.nvfrags + 1) + 63) & ~63;   // whole waves per plane (k_loopfilter)
     K.cell_end[pli] = cells;
   }
 }
@@ -730,6 +894,13 @@ int thip_synchronize(void) {
   return THIP_OK;
 }
 
+#ifdef THIP_TRACE
+int thip_debug_trace_buffer(void *dev_buf) {
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &dev_buf, sizeof(dev_buf)));
+  return THIP_OK;
+}
+#endif
+
 int thip_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_profile = on;
@@ -811,7 +982,8 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       K.lf_y0[pli] = st->lf_rows_custom ? st->lf_y0[pli] : 0;
       K.lf_y1[pli] = st->lf_rows_custom ? st->lf_y1[pli] : st->geom[pli].nvfrags;
     }
-    if ((K.tile_end[2] + 3) / 4 > max_wg) max_wg = (K.tile_end[2] + 3) / 4;
+    const int wgs = (K.tile_end[2] + THIP_RECON_WG_WAVES - 1) / THIP_RECON_WG_WAVES;
+    if (wgs > max_wg) max_wg = wgs;
     if (d.flimit) {
       any_lf = 1;
       const int swg = (K.cell_end[2] + 255) / 256;
@@ -822,7 +994,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   if (!nlive) return THIP_OK;
   {
     ScopedTimer t(s, THIP_KERNEL_RECON);
-    hipLaunchKernelGGL(k_recon, dim3(max_wg, nlive), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(k_recon, dim3(max_wg, nlive), dim3(64 * THIP_RECON_WG_WAVES), 0, s, B);
   }
   if (any_lf) {
     ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);

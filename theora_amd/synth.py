@@ -84,6 +84,13 @@ CLASSES = {
                    p_zz10=0.15, amp=24, edge_mv=0.0, extreme=0.0),
     "mixed": dict(p_coded=0.6, intra=0.15, golden=0.15, zeromv=0.15, halfpel=0.4, p_dc_only=0.3,
                   p_zz10=0.3, amp=300, edge_mv=0.3, extreme=0.02),
+    # diagnostic classes: each isolates one access pattern of k_recon (bench.py --content)
+    "skip": dict(p_coded=0.0, intra=0.0, golden=0.0, zeromv=1.0, halfpel=0.0, p_dc_only=1.0,
+                 p_zz10=0.0, amp=24, edge_mv=0.0, extreme=0.0),            # copy prev -> self only
+    "zeromv_dc": dict(p_coded=1.0, intra=0.0, golden=0.0, zeromv=1.0, halfpel=0.0, p_dc_only=1.0,
+                      p_zz10=0.0, amp=24, edge_mv=0.0, extreme=0.0),       # aligned predictor + DC, no slots
+    "intra_dense": dict(p_coded=1.0, intra=1.0, golden=0.0, zeromv=1.0, halfpel=0.0, p_dc_only=0.0,
+                        p_zz10=0.0, amp=40, edge_mv=0.0, extreme=0.0),     # coefficients + iDCT, no predictor
 }
 
 
