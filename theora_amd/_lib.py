@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libtheora_hip.so")
+# THIP_LIB: developer override to A/B a differently compiled copy of the same library (tools/)
+SO_PATH = os.environ.get("THIP_LIB") or os.path.join(_HERE, "libtheora_hip.so")
 
 OK, EFAULT, EINVAL, EIMPL, DUPFRAME = 0, -1, -10, -23, 1
 FRAME_GOLD, FRAME_PREV, FRAME_SELF = 0, 1, 2

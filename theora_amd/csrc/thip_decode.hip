@@ -1,22 +1,24 @@
 // thip_decode.hip -- frame-scope reconstruction path for gfx950 (MI355X).
 //
-// Two kernels per batch of frames (one 8x8 block per lane, wave64, 256-thread workgroups):
+// Two kernels per batch of frames (one 8x8 block per lane, wave64):
 //
-//   k_recon       K1+K2.  One wave per TILE (4 super blocks = 16x4 fragments = 128x32 pixels),
-//                 lanes in coded order (super block by super block, Hilbert inside).  A lane
-//                 reads its fragment's command word, finds its coefficient slot with a
-//                 ballot / prefix count over the tile's coded mask, and either reconstructs
-//                 (dequantised coefficients -> iDCT -> predictor -> pixels; state.c:959,
-//                 idct.c:301, fragment.c:49-80) or copies the fragment from PREV
-//                 (fragment.c:37).  DC-only fragments carry their value in the command word
-//                 and own no coefficient slot.
+//   k_recon       K1+K2.  One wave (= one workgroup) per TILE (4 super blocks = 16x4 fragments
+//                 = 128x32 pixels), lanes in coded order (super block by super block, Hilbert
+//                 inside).  Round trip 1: the 64 command words + the tile's first slot number.
+//                 Round trip 2: coefficients (slot found by ballot / prefix count over the
+//                 tile's mask, global -> LDS directly) and predictor windows, all issued
+//                 before anything waits.  Then dequantised coefficients -> iDCT -> predictor
+//                 -> pixels (state.c:959, idct.c:301, fragment.c:49-80); an uncoded fragment
+//                 (fragment.c:37) is the zero-vector predictor plus a zero residual; DC-only
+//                 fragments carry their value in the command word and own no slot.
 //   k_loopfilter  K3.  Whole-frame in-loop deblocking (state.c:1055-1105), one 8x8 "corner
-//                 cell" per lane; cells are independent, so the pass is fully parallel.
+//                 cell" per lane; cells are independent, so the pass is fully parallel and a
+//                 cell is one memory round trip.
 //
-// A fused variant (reconstruct into an LDS image of a strip, filter there, write once) was
-// built and measured: bit-exact but slower -- these kernels are latency/occupancy bound at
-// the frame sizes involved, so extra in-kernel phases cost more than the saved traffic
-// (DESIGN.md section 5).
+// What makes these kernels fast or slow on this chip is not arithmetic but (a) how many
+// DEPENDENT memory round trips a wave makes (kernel arguments indexed by a value the compiler
+// cannot prove uniform become vector loads; a register copy behind a load is a hidden wait),
+// and (b) straggler waves.  tools/wave_trace.py shows both; DESIGN.md section 5 has the story.
 //
 // K4 (UMV border fill, state.c:770-835) does not exist: device frames are unpadded and
 // motion-compensated reads clamp their coordinates, which is bit-identical.
@@ -273,10 +275,15 @@ __device__ __forceinline__ void load_slot(const int4 *coeffs, uint32_t slot, uin
 // flight while the inverse DCT runs: pred_issue() only computes addresses and issues the
 // row loads, pred_finish() turns the raw windows into the eight predictor rows.
 struct PredWin {
-  Row12 w[9];
+  Row12 w[9];             // rows clamp(ys+r, 0, H-1), 12 bytes from column xw (see pred_xw)
   int sx, sy, mx2, my2;   // first sample's position, second sample's offset (0 or +-1 per axis)
-  bool inside;            // the 9x9 footprint lies inside the frame: windows were loaded
+  bool border;            // the footprint leaves the frame: replicated-border addressing
 };
+
+// First column of the 12-byte window: the footprint's first column aligned down to 4, pulled
+// inside the row.  Every column a sample can need -- after clamping to [0,W-1], which is what
+// the reference's replicated UMV border amounts to (state.c:770-835) -- lies inside it.
+__device__ __forceinline__ int pred_xw(int xs, int W) { return max(min(xs, W - 12), 0) & ~3; }
 
 __device__ __forceinline__ void pred_issue(PredWin &Q, const uint8_t *ref, int stride, int W, int H, int x0, int y0,
                                            uint32_t flags, bool qpx, bool qpy) {
@@ -288,62 +295,68 @@ __device__ __forceinline__ void pred_issue(PredWin &Q, const uint8_t *ref, int s
   Q.sx = x0 + mx;
   Q.sy = y0 + my;
   const int xs = Q.sx + min(Q.mx2, 0), ys = Q.sy + min(Q.my2, 0);
-  // (bitwise & on purpose: one compare chain, no nest of divergent branches)
-  Q.inside = (xs >= 0) & (Q.sx + max(Q.mx2, 0) + 8 <= W) & (ys >= 0) & (Q.sy + max(Q.my2, 0) + 8 <= H);
-  if (Q.inside) {
-    // Both samples of a row lie in the 9 bytes starting at xs, i.e. inside one 12-byte
-    // window aligned down to 4: one dword-aligned dwordx3 load per source row and byte
-    // funnel shifts.  Vertical half-pel needs 9 source rows, not 16.
-    const uint8_t *p1 = ref + (ptrdiff_t)ys * stride + (xs & ~3);
+  // (bitwise | on purpose: one compare chain, no nest of divergent branches)
+  Q.border = (xs < 0) | (Q.sx + max(Q.mx2, 0) + 8 > W) | (ys < 0) | (Q.sy + max(Q.my2, 0) + 8 > H);
+  // Both samples of a row lie in the 9 bytes starting at xs, i.e. inside one 12-byte window
+  // aligned down to 4: one dword-aligned dwordx3 load per source row.  Vertical half-pel needs
+  // 9 source rows, not 16; without it the ninth load re-reads row 7.  Row and column clamps are
+  // no-ops for a footprint inside the frame, so there is one code path and no straggler waves.
+  const uint8_t *p1 = ref + pred_xw(xs, W);
 #pragma unroll
-    for (int r = 0; r < 8; r++) Q.w[r] = load_row12(p1 + (ptrdiff_t)r * stride);
-    // the ninth row only exists for vertical half-pel; re-reading row 7 otherwise keeps the
-    // load unconditional and inside the frame
-    Q.w[8] = load_row12(p1 + (ptrdiff_t)(Q.my2 != 0 ? 8 : 7) * stride);
+  for (int r = 0; r < 9; r++) {
+    const int y = min(max(ys + (r < 8 ? r : (Q.my2 != 0 ? 8 : 7)), 0), H - 1);
+    Q.w[r] = load_row12(p1 + (ptrdiff_t)y * stride);
   }
 }
 
-// The block reaches into the reference's UMV border: clamp every coordinate (== replicated
-// padding, state.c:770-835).  Rare (frame-edge blocks with outward vectors), so it runs
-// late, with its own exposed latency, instead of complicating the common path.
-__device__ __forceinline__ void pred_border(const uint8_t *ref, int stride, int W, int H, int sx, int sy, int mx2,
-                                         int my2, uint2 pred[8]) {
-  const bool two = (mx2 | my2) != 0;
-#pragma unroll 1
-  for (int r = 0; r < 8; r++) {
-    const int ya = min(max(sy + r, 0), H - 1);
-    const int yb = min(max(sy + my2 + r, 0), H - 1);
-    uint32_t w[2] = {0u, 0u};
+// byte selectors for v_perm_b32: the four window columns col0+i (clamped to the row), as
+// offsets from the window dword pair {4k..4k+7}
+__device__ __forceinline__ void pred_sel(int col0, int xw, int W, uint32_t &sel, bool &k) {
+  int c[4];
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const int xa = min(max(sx + c, 0), W - 1);
-      int v = ref[(ptrdiff_t)ya * stride + xa];
-      if (two) {
-        const int xb = min(max(sx + mx2 + c, 0), W - 1);
-        v = (v + ref[(ptrdiff_t)yb * stride + xb]) >> 1;
-      }
-      w[c >> 2] |= (uint32_t)v << (8 * (c & 3));
-    }
-#pragma unroll
-    for (int rr = 0; rr < 8; rr++)
-      if (rr == r) pred[rr] = make_uint2(w[0], w[1]);
-  }
+  for (int i = 0; i < 4; i++) c[i] = min(max(col0 + i, 0), W - 1) - xw;   // 0..11, non-decreasing
+  k = c[0] >= 4;
+  const int o = k ? 4 : 0;
+  sel = (uint32_t)(c[0] - o) | (uint32_t)(c[1] - o) << 8 | (uint32_t)(c[2] - o) << 16 | (uint32_t)(c[3] - o) << 24;
+}
+__device__ __forceinline__ uint32_t pred_pick(const Row12 &w, uint32_t sel, bool k) {
+  return __builtin_amdgcn_perm(k ? w.c : w.b, k ? w.b : w.a, sel);
 }
 
-__device__ __forceinline__ void pred_finish(const PredWin &Q, uint2 pred[8]) {
-  const int xw = (Q.sx + min(Q.mx2, 0)) & ~3;
-  const int offA = Q.sx - xw, offB = Q.sx + Q.mx2 - xw;   // 0..4
-  const bool ra = Q.my2 < 0, rb = Q.my2 > 0;              // that sample starts one source row down
+__device__ __forceinline__ void pred_finish(const PredWin &Q, int W, uint2 pred[8]) {
+  const int xw = pred_xw(Q.sx + min(Q.mx2, 0), W);
+  const bool ra = Q.my2 < 0, rb = Q.my2 > 0;   // that sample starts one source row down
   const bool two = (Q.mx2 | Q.my2) != 0;
+  if (!__any(Q.border)) {
+    const int offA = Q.sx - xw, offB = Q.sx + Q.mx2 - xw;   // 0..4
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const Row12 wa = ra ? Q.w[r + 1] : Q.w[r];
-    pred[r] = extract8(wa, offA);
-    if (two) {
-      const Row12 wb = rb ? Q.w[r + 1] : Q.w[r];
-      const uint2 b = extract8(wb, offB);
-      pred[r].x = avg4_trunc(pred[r].x, b.x);
-      pred[r].y = avg4_trunc(pred[r].y, b.y);
+    for (int r = 0; r < 8; r++) {
+      const Row12 wa = ra ? Q.w[r + 1] : Q.w[r];
+      pred[r] = extract8(wa, offA);
+      if (two) {
+        const Row12 wb = rb ? Q.w[r + 1] : Q.w[r];
+        const uint2 b = extract8(wb, offB);
+        pred[r].x = avg4_trunc(pred[r].x, b.x);
+        pred[r].y = avg4_trunc(pred[r].y, b.y);
+      }
+    }
+  } else {
+    // some lane of the wave needs replicated columns: general byte gather for the whole wave
+    uint32_t sa0, sa1, sb0, sb1;
+    bool ka0, ka1, kb0, kb1;
+    pred_sel(Q.sx, xw, W, sa0, ka0);
+    pred_sel(Q.sx + 4, xw, W, sa1, ka1);
+    pred_sel(Q.sx + Q.mx2, xw, W, sb0, kb0);
+    pred_sel(Q.sx + Q.mx2 + 4, xw, W, sb1, kb1);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const Row12 wa = ra ? Q.w[r + 1] : Q.w[r];
+      pred[r] = make_uint2(pred_pick(wa, sa0, ka0), pred_pick(wa, sa1, ka1));
+      if (two) {
+        const Row12 wb = rb ? Q.w[r + 1] : Q.w[r];
+        pred[r].x = avg4_trunc(pred[r].x, pred_pick(wb, sb0, kb0));
+        pred[r].y = avg4_trunc(pred[r].y, pred_pick(wb, sb1, kb1));
+      }
     }
   }
 }
@@ -401,7 +414,7 @@ __device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane 
   const bool inter = refi != THIP_FRAME_SELF && !(R.debug & 2);
   const uint8_t *const ref = refi == THIP_FRAME_PREV ? R.prev : R.gold;
   PredWin Q;
-  Q.inside = true;
+  Q.border = false;
   if (inter) pred_issue(Q, ref, R.stride, R.nh * 8, R.nv * 8, L.x0, L.y0, L.coded ? L.flags : 0u, R.qpx, R.qpy);
   R.coded_map[(L.y0 >> 3) * R.nh + (L.x0 >> 3)] = L.coded ? 1 : 0;
   THIP_TR(R.tr, 2);   // every load of the second round trip is issued
@@ -438,10 +451,7 @@ __device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane 
   uint2 pred[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
-  if (inter) {
-    if (Q.inside) pred_finish(Q, pred);
-    else pred_border(ref, R.stride, R.nh * 8, R.nv * 8, Q.sx, Q.sy, Q.mx2, Q.my2, pred);
-  }
+  if (inter) pred_finish(Q, R.nh * 8, pred);
   if (!(R.debug & 4)) {
 #pragma unroll
     for (int r = 0; r < 8; r++)
@@ -460,7 +470,12 @@ __device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane 
 __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_recon(const BatchK B) {
   const StreamK &S = B.s[blockIdx.y];
   const int lane = (int)threadIdx.x & 63;
-  const int unit = __builtin_amdgcn_readfirstlane((int)blockIdx.x * THIP_RECON_WG_WAVES + ((int)threadIdx.x >> 6));  // tile
+  // Workgroups are handed to the 8 XCDs round-robin (id mod 8) and each XCD has its own L2:
+  // give XCD x the x-th contiguous band of tiles, so that the predictor windows of
+  // neighbouring tiles -- which overlap by up to 16 pixels -- meet in one L2 instead of being
+  // fetched from HBM by two.  gridDim.x is a multiple of 8.
+  const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  const int unit = __builtin_amdgcn_readfirstlane(wg * THIP_RECON_WG_WAVES + ((int)threadIdx.x >> 6));  // tile
 #ifdef THIP_TRACE
   unsigned long long *tr = nullptr;
   if (g_trace_buf && lane == 0) {
@@ -539,7 +554,10 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   //         the tile's first slot -- same cache lines, no extra traffic -- and are overridden
   //         in step 4). -----------------------------------------------------------------------------
   const uint64_t mask = __ballot(L.has_coeff);
-  __shared__ uint4 s_coef[THIP_RECON_WG_WAVES * 8 * 64];   // [wave][piece][lane]: 8 KB per wave, wave-private
+#ifndef THIP_RECON_LDS_PAD
+#define THIP_RECON_LDS_PAD 0
+#endif
+  __shared__ uint4 s_coef[THIP_RECON_WG_WAVES * 8 * 64 + THIP_RECON_LDS_PAD / 16];   // [wave][piece][lane]: 8 KB per wave, wave-private
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   uint4 *const lds_wave = s_coef + wave * 512;
   if (mask != 0 && !(debug & 9)) {
@@ -982,7 +1000,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       K.lf_y0[pli] = st->lf_rows_custom ? st->lf_y0[pli] : 0;
       K.lf_y1[pli] = st->lf_rows_custom ? st->lf_y1[pli] : st->geom[pli].nvfrags;
     }
-    const int wgs = (K.tile_end[2] + THIP_RECON_WG_WAVES - 1) / THIP_RECON_WG_WAVES;
+    const int wgs = ((K.tile_end[2] + THIP_RECON_WG_WAVES - 1) / THIP_RECON_WG_WAVES + 7) & ~7;   // 8 XCD bands
     if (wgs > max_wg) max_wg = wgs;
     if (d.flimit) {
       any_lf = 1;
