@@ -296,7 +296,7 @@ __device__ __forceinline__ void pred_issue(PredWin &Q, const uint8_t *ref, int s
   Q.sy = y0 + my;
   const int xs = Q.sx + min(Q.mx2, 0), ys = Q.sy + min(Q.my2, 0);
   // (bitwise | on purpose: one compare chain, no nest of divergent branches)
-  Q.border = (xs < 0) | (Q.sx + max(Q.mx2, 0) + 8 > W) | (ys < 0) | (Q.sy + max(Q.my2, 0) + 8 > H);
+  Q.border = ((int)(xs < 0) | (int)(Q.sx + max(Q.mx2, 0) + 8 > W) | (int)(ys < 0) | (int)(Q.sy + max(Q.my2, 0) + 8 > H)) != 0;
   // Both samples of a row lie in the 9 bytes starting at xs, i.e. inside one 12-byte window
   // aligned down to 4: one dword-aligned dwordx3 load per source row.  Vertical half-pel needs
   // 9 source rows, not 16; without it the ninth load re-reads row 7.  Row and column clamps are
@@ -646,6 +646,8 @@ struct thip_state {
   uint32_t *h_info, *d_info;
   int16_t *h_coeffs, *d_coeffs;
   uint32_t *h_slot0, *d_slot0;
+  hipStream_t last_stream;   // stream of the most recent launch for this state (ycbcr_out copies on it)
+  uint8_t *h_out;       // pinned image of one frame for thip_state_ycbcr_out (allocated on first use)
   int32_t *enq_last_lane;   // per tile: last lane that received a slot (arrival-order check)
   int enq_ncoded, enq_nuncoded, enq_nslots, enq_frame_type, enq_flimit, enq_active, enq_last_tile;
   int enq_lf_y0[3], enq_lf_y1[3], enq_lf_any;
@@ -819,6 +821,7 @@ void thip_state_free(thip_state *st) {
   if (st->h_info) (void)hipHostFree(st->h_info);
   if (st->h_coeffs) (void)hipHostFree(st->h_coeffs);
   if (st->h_slot0) (void)hipHostFree(st->h_slot0);
+  if (st->h_out) (void)hipHostFree(st->h_out);
   if (st->d_info) (void)hipFree(st->d_info);
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
   if (st->d_slot0) (void)hipFree(st->d_slot0);
@@ -891,18 +894,21 @@ int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *hos
 int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t dst_stride[3]) {
   if (!st || !dst || !dst_stride) return THIP_EFAULT;
   if (st->last_decoded < 0) return THIP_EINVAL;
-  HIP_TRY(hipDeviceSynchronize());
+  for (int pli = 0; pli < 3; pli++)
+    if (!dst[pli] || dst_stride[pli] < st->geom[pli].width) return THIP_EINVAL;
+  // one DMA of the whole frame (planes are contiguous, pitch == width) into pinned memory, on
+  // the stream that produced it, then the top-down flip on the host
+  if (!st->h_out) HIP_TRY(hipHostMalloc((void **)&st->h_out, st->frame_bytes, hipHostMallocDefault));
+  hipStream_t s = st->last_stream;   // null (legacy stream) if the frame came from write_plane only
+  HIP_TRY(hipMemcpyAsync(st->h_out, st->frames[st->last_decoded], st->frame_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   for (int pli = 0; pli < 3; pli++) {
     const thip_plane_geom &g = st->geom[pli];
-    if (!dst[pli] || dst_stride[pli] < g.width) return THIP_EINVAL;
     // the device keeps row 0 at the bottom of the picture; hand the frame back top-down
     // (decode.c:2988-2992 flips pointers instead)
-    std::vector<uint8_t> tmp((size_t)g.width * g.height);
-    HIP_TRY(hipMemcpy2D(tmp.data(), g.width, st->frames[st->last_decoded] + g.plane_off, g.stride, g.width,
-                        g.height, hipMemcpyDeviceToHost));
+    const uint8_t *src = st->h_out + g.plane_off;
     uint8_t *last = dst[pli] + (size_t)(g.height - 1) * dst_stride[pli];
-    for (int y = 0; y < g.height; y++)
-      memcpy(last - (size_t)y * dst_stride[pli], tmp.data() + (size_t)y * g.width, g.width);
+    for (int y = 0; y < g.height; y++) memcpy(last - (size_t)y * dst_stride[pli], src + (size_t)y * g.stride, g.width);
   }
   return THIP_OK;
 }
@@ -1026,6 +1032,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     if (descs[live_state[j]].frame_type == THIP_INTRA_FRAME) st->ref_idx[THIP_FRAME_GOLD] = self;
     st->ref_idx[THIP_FRAME_PREV] = self;
     st->last_decoded = self;
+    st->last_stream = s;
   }
   return THIP_OK;
 }

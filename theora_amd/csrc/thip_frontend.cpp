@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <vector>
 
@@ -26,20 +27,46 @@ namespace {
 // bit reader: MSB first, reads past the end return zeros (spec 5.2, "Decoding")
 // ---------------------------------------------------------------------------------------
 struct BitReader {
-  const uint8_t *p;
-  size_t nbits, pos;
-  BitReader(const uint8_t *data, size_t bytes) : p(data), nbits(bytes * 8), pos(0) {}
-  inline uint32_t bit() {
-    uint32_t b = 0;
-    if (pos < nbits) b = (p[pos >> 3] >> (7 - (pos & 7))) & 1u;
-    pos++;
-    return b;
+  const uint8_t *data;
+  size_t nbytes, bytepos;   // next byte to pull into the window
+  uint64_t win;             // upcoming bits, MSB-aligned
+  int have;                 // valid bits in win
+  size_t nbits, pos;        // packet size and bits consumed so far (pos may run past nbits)
+  BitReader(const uint8_t *d, size_t bytes) : data(d), nbytes(bytes), bytepos(0), win(0), have(0), nbits(bytes * 8), pos(0) {}
+  inline void refill() {   // afterwards have >= 57; bytes past the end are zeros
+    if (bytepos + 8 <= nbytes) {
+      uint64_t v;
+      memcpy(&v, data + bytepos, 8);
+      v = __builtin_bswap64(v);
+      win |= v >> have;
+      const int take = (64 - have) >> 3;
+      bytepos += (size_t)take;
+      have += take * 8;
+    } else {
+      while (have <= 56) {
+        const uint64_t b = bytepos < nbytes ? data[bytepos] : 0;
+        bytepos++;
+        win |= b << (56 - have);
+        have += 8;
+      }
+    }
   }
-  inline uint32_t read(int n) {
-    uint32_t v = 0;
-    while (n-- > 0) v = (v << 1) | bit();
+  inline uint32_t peek(int n) {   // 1 <= n <= 32, does not consume
+    if (have < n) refill();
+    return (uint32_t)(win >> (64 - n));
+  }
+  inline void skip(int n) {       // n <= have
+    win <<= n;
+    have -= n;
+    pos += (size_t)n;
+  }
+  inline uint32_t read(int n) {   // 0 <= n <= 32
+    if (n <= 0) return 0;
+    const uint32_t v = peek(n);
+    skip(n);
     return v;
   }
+  inline uint32_t bit() { return read(1); }
   bool overrun() const { return pos > nbits; }
 };
 
@@ -72,11 +99,14 @@ const uint8_t kModeRefi[8] = {THIP_FRAME_PREV, THIP_FRAME_SELF, THIP_FRAME_PREV,
 enum { MODE_INTER_NOMV = 0, MODE_INTRA = 1, MODE_INTER_MV = 2, MODE_INTER_MV_LAST = 3, MODE_INTER_MV_LAST2 = 4,
        MODE_GOLDEN_NOMV = 5, MODE_GOLDEN_MV = 6, MODE_INTER_MV_FOUR = 7 };
 
+constexpr int kHuffLutBits = 9;
 struct HuffTree {
   // node i: child[i][b] >= 0 is another node, < 0 is the leaf -(token+1)
   int16_t child[32][2];
   int nnodes;
   int root_leaf;   // a single-leaf tree: token+1, else 0
+  // next kHuffLutBits bits -> (code length << 8 | token), or 0x8000 | node to continue from
+  uint16_t lut[1 << kHuffLutBits];
 };
 
 struct QuantParams {
@@ -109,8 +139,31 @@ struct MacroBlock {
   int nchroma;         // chroma blocks per plane in this macro block
 };
 
+// THIP_FE_PROF=1: wall time per section of th_decode_packetin, printed by th_decode_free
+enum { FE_FLAGS, FE_MODES, FE_QI, FE_TOKENS, FE_DC, FE_EXPAND, FE_FLUSH, FE_OUT, FE_NSEC };
+static const char *const kFeNames[FE_NSEC] = {"header+coded flags", "modes+MVs", "block qi", "DCT tokens", "DC unpredict",
+                                              "expand+dequant+stage", "flush (H2D, launch, sync)", "ycbcr_out (D2H)"};
+static inline double fe_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+struct FeProf {
+  bool on;
+  double acc[FE_NSEC], t;
+  long frames;
+  void start() { if (on) t = fe_now(); }
+  void lap(int s) {
+    if (!on) return;
+    const double n = fe_now();
+    acc[s] += n - t;
+    t = n;
+  }
+};
+
 struct th_dec_ctx {
   th_info info;
+  FeProf prof;
   th_setup_info setup;
   thip_state *hip;
   int nh[3], nv[3], fro[3], nfrags_pl[3];
@@ -227,6 +280,28 @@ int parse_huff_tree(BitReader &br, HuffTree &t, int depth, int *nleaves) {   // 
   return me;
 }
 
+void build_huff_lut(HuffTree &t) {
+  for (int v = 0; v < (1 << kHuffLutBits); v++) {
+    uint16_t e = 0;
+    if (t.root_leaf) e = (uint16_t)(t.root_leaf - 1);   // zero-length code
+    else {
+      int node = 0, len = 0;
+      e = 0x8000;
+      while (len < kHuffLutBits) {
+        const int c = t.child[node][(v >> (kHuffLutBits - 1 - len)) & 1];
+        len++;
+        if (c < 0) {
+          e = (uint16_t)((len << 8) | (-c - 1));
+          break;
+        }
+        node = c;
+        e = (uint16_t)(0x8000 | node);
+      }
+    }
+    t.lut[v] = e;
+  }
+}
+
 int parse_setup(BitReader &br, th_setup_info *s) {   // spec 6.4
   QuantParams &q = s->qp;
   int nbits = (int)br.read(3);   // 6.4.1 loop filter limits
@@ -281,6 +356,7 @@ int parse_setup(BitReader &br, th_setup_info *s) {   // spec 6.4
     if (r == kHuffErr) return TH_EBADHEADER;
     if (t.nnodes == 0) t.root_leaf = -r;   // degenerate one-leaf tree: zero-length code
     else if (r != 0) return TH_EBADHEADER;
+    build_huff_lut(t);
   }
   return br.overrun() ? TH_EBADHEADER : 0;
 }
@@ -388,9 +464,7 @@ inline int round_div(int v, int shift) {   // round(v / 2^shift), ties away from
 // ---------------------------------------------------------------------------------------
 // DCT tokens (spec 7.7)
 // ---------------------------------------------------------------------------------------
-inline int read_token(BitReader &br, const HuffTree &t) {
-  if (t.root_leaf) return t.root_leaf - 1;
-  int node = 0;
+inline int read_token_bitwise(BitReader &br, const HuffTree &t, int node) {
   for (;;) {
     const int c = t.child[node][br.bit()];
     if (c < 0) return -c - 1;
@@ -398,60 +472,66 @@ inline int read_token(BitReader &br, const HuffTree &t) {
     if (br.overrun()) return 0;
   }
 }
+inline int read_token(BitReader &br, const HuffTree &t) {
+  if (t.root_leaf) return t.root_leaf - 1;
+  if (br.pos + kHuffLutBits > br.nbits) return read_token_bitwise(br, t, 0);   // tail of the packet
+  const uint16_t e = t.lut[br.peek(kHuffLutBits)];
+  if (!(e & 0x8000)) {
+    br.skip(e >> 8);
+    return e & 0xFF;
+  }
+  br.skip(kHuffLutBits);
+  return read_token_bitwise(br, t, e & 0x7FFF);
+}
 
-// Tables 7.33 / 7.38: expands token + extra bits.  For EOB tokens returns the run length in
-// tok.eob (0 extra on token 6 -> "all remaining", signalled as 0xFFFFFFFF).
+// Tables 7.33 / 7.38: number of extra bits that follow each token ...
+const uint8_t kTokExtraBits[32] = {0, 0, 0, 2, 3, 4, 12, 3, 6, 0, 0, 0, 0, 1, 1, 1, 1, 2, 3, 4, 5, 6, 10, 1, 1, 1, 1, 1, 3, 4, 2, 3};
+// ... and what token + extra bits x (sign first where there is one) expand to.  For EOB tokens
+// the run length goes to tok.eob (0 extra on token 6 -> "all remaining", signalled as 0xFFFFFFFF).
 inline void decode_token(BitReader &br, int token, Tok &k) {
+  const int eb = kTokExtraBits[token];
+  const uint32_t x = br.read(eb);
+  const int sign = eb ? (int)(x >> (eb - 1)) : 0;            // meaningful for tokens >= 13
+  const uint32_t rest = eb ? x & ((1u << (eb - 1)) - 1u) : 0;  // bits after the sign
   k.value = 0;
   k.skip = 0;
   k.adv = 1;
   k.eob = 0;
-  int sign;
   switch (token) {
     case 0: k.eob = 1; k.adv = 0; break;
     case 1: k.eob = 2; k.adv = 0; break;
     case 2: k.eob = 3; k.adv = 0; break;
-    case 3: k.eob = 4 + br.read(2); k.adv = 0; break;
-    case 4: k.eob = 8 + br.read(3); k.adv = 0; break;
-    case 5: k.eob = 16 + br.read(4); k.adv = 0; break;
-    case 6: k.eob = br.read(12); if (!k.eob) k.eob = 0xFFFFFFFFu; k.adv = 0; break;
-    case 7: k.adv = (uint8_t)(br.read(3) + 1); k.skip = k.adv; break;    // pure zero runs: value 0
-    case 8: k.adv = (uint8_t)(br.read(6) + 1); k.skip = k.adv; break;
+    case 3: k.eob = 4 + x; k.adv = 0; break;
+    case 4: k.eob = 8 + x; k.adv = 0; break;
+    case 5: k.eob = 16 + x; k.adv = 0; break;
+    case 6: k.eob = x ? x : 0xFFFFFFFFu; k.adv = 0; break;
+    case 7: case 8: k.adv = (uint8_t)(x + 1); k.skip = k.adv; break;    // pure zero runs: value 0
     case 9: k.value = 1; break;
     case 10: k.value = -1; break;
     case 11: k.value = 2; break;
     case 12: k.value = -2; break;
-    case 13: case 14: case 15: case 16:
-      k.value = (int16_t)(token - 10);
-      if (br.bit()) k.value = (int16_t)-k.value;
-      break;
-    case 17: sign = (int)br.bit(); k.value = (int16_t)(7 + br.read(1)); if (sign) k.value = (int16_t)-k.value; break;
-    case 18: sign = (int)br.bit(); k.value = (int16_t)(9 + br.read(2)); if (sign) k.value = (int16_t)-k.value; break;
-    case 19: sign = (int)br.bit(); k.value = (int16_t)(13 + br.read(3)); if (sign) k.value = (int16_t)-k.value; break;
-    case 20: sign = (int)br.bit(); k.value = (int16_t)(21 + br.read(4)); if (sign) k.value = (int16_t)-k.value; break;
-    case 21: sign = (int)br.bit(); k.value = (int16_t)(37 + br.read(5)); if (sign) k.value = (int16_t)-k.value; break;
-    case 22: sign = (int)br.bit(); k.value = (int16_t)(69 + br.read(9)); if (sign) k.value = (int16_t)-k.value; break;
+    case 13: case 14: case 15: case 16: k.value = (int16_t)(token - 10); break;
+    case 17: k.value = (int16_t)(7 + rest); break;
+    case 18: k.value = (int16_t)(9 + rest); break;
+    case 19: k.value = (int16_t)(13 + rest); break;
+    case 20: k.value = (int16_t)(21 + rest); break;
+    case 21: k.value = (int16_t)(37 + rest); break;
+    case 22: k.value = (int16_t)(69 + rest); break;
     case 23: case 24: case 25: case 26: case 27:
       k.skip = (uint8_t)(token - 22);
-      k.value = br.bit() ? -1 : 1;
-      k.adv = (uint8_t)(k.skip + 1);
+      k.value = 1;
       break;
-    case 28: sign = (int)br.bit(); k.skip = (uint8_t)(6 + br.read(2)); k.value = sign ? -1 : 1; k.adv = (uint8_t)(k.skip + 1); break;
-    case 29: sign = (int)br.bit(); k.skip = (uint8_t)(10 + br.read(3)); k.value = sign ? -1 : 1; k.adv = (uint8_t)(k.skip + 1); break;
-    case 30:
-      sign = (int)br.bit();
-      k.value = (int16_t)(2 + br.read(1));
-      if (sign) k.value = (int16_t)-k.value;
-      k.skip = 1;
-      k.adv = 2;
+    case 28: k.skip = (uint8_t)(6 + rest); k.value = 1; break;
+    case 29: k.skip = (uint8_t)(10 + rest); k.value = 1; break;
+    case 30: k.value = (int16_t)(2 + rest); k.skip = 1; break;
+    default:   // 31: sign, one value bit, one run bit
+      k.value = (int16_t)(2 + (rest >> 1));
+      k.skip = (uint8_t)(2 + (rest & 1));
       break;
-    default:   // 31
-      sign = (int)br.bit();
-      k.value = (int16_t)(2 + br.read(1));
-      if (sign) k.value = (int16_t)-k.value;
-      k.skip = (uint8_t)(2 + br.read(1));
-      k.adv = (uint8_t)(k.skip + 1);
-      break;
+  }
+  if (token >= 13) {
+    if (sign) k.value = (int16_t)-k.value;
+    k.adv = (uint8_t)(k.skip + 1);
   }
 }
 
@@ -624,12 +704,22 @@ th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup) {
                                                    (info->version_minor == 2 && info->version_subminor >= 1))))
                         ? 1 : 0;
   d->have_frame = false;
+  memset(&d->prof, 0, sizeof(d->prof));
+  d->prof.on = getenv("THIP_FE_PROF") != nullptr;
   for (int p = 0; p < 3; p++) d->mirror[p].assign((size_t)d->nh[p] * 8 * d->nv[p] * 8, 0);
   return d;
 }
 
 void th_decode_free(th_dec_ctx *d) {
   if (!d) return;
+  if (d->prof.on && d->prof.frames) {
+    double tot = 0;
+    for (int s = 0; s < FE_NSEC; s++) tot += d->prof.acc[s];
+    fprintf(stderr, "[thip front end] %ld frames, %.3f ms/frame\n", d->prof.frames, 1e3 * tot / (double)d->prof.frames);
+    for (int s = 0; s < FE_NSEC; s++)
+      fprintf(stderr, "  %-28s %8.3f ms/frame %5.1f %%\n", kFeNames[s], 1e3 * d->prof.acc[s] / (double)d->prof.frames,
+              100.0 * d->prof.acc[s] / tot);
+  }
   thip_state_free(d->hip);
   delete d;
 }
@@ -674,6 +764,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   const int N = d->nfrags;
   int ncoded_total = 0;
   BitReader br(op->packet, op->bytes > 0 ? (size_t)op->bytes : 0);
+  d->prof.start();
   if (op->bytes == 0) {
     // an empty packet is a dropped frame: an inter frame with no coded blocks (decode.c:2746)
     d->frame_type = THIP_INTER_FRAME;
@@ -722,6 +813,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     if (granpos) *granpos = d->granpos;
     return TH_DUPFRAME;
   }
+  d->prof.lap(FE_FLAGS);
   if (d->frame_type == THIP_INTRA_FRAME) {
     d->keyframe_num = d->curframe_num;
     d->granpos = ((d->keyframe_num + d->granpos_bias) << d->info.keyframe_granule_shift);
@@ -822,6 +914,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         }
     }
   }
+  d->prof.lap(FE_MODES);
   // ---- 7.6 block-level qi ---------------------------------------------------------------------------
   memset(d->qii.data(), 0, (size_t)N);
   for (int q = 0; q + 1 < d->nqis; q++) {
@@ -838,6 +931,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
       if (d->coded[f] && d->qii[f] == q) d->qii[f] = (uint8_t)(d->qii[f] + bits[bi++]);
     }
   }
+  d->prof.lap(FE_QI);
   // ---- 7.7 DCT tokens, unpacked by counts per (plane, index) list -------------------------------------
   {
     size_t left[3][64];
@@ -899,6 +993,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
       }
     }
   }
+  d->prof.lap(FE_TOKENS);
   // ---- 7.8 undo DC prediction (the DC token values are the first coefficient of each block) -----------
   // first pull the DC values out of the zzi == 0 lists, in coded order
   {
@@ -958,6 +1053,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         }
     }
   }
+  d->prof.lap(FE_DC);
   // ---- 7.9 reconstruction through the backend's vtable slots -------------------------------------------
   int rc = thip_frame_begin(d->hip, d->frame_type);
   if (rc < 0) return TH_EFAULT;
@@ -1012,8 +1108,11 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         return TH_EFAULT;
     }
   }
+  d->prof.lap(FE_EXPAND);
   rc = thip_frame_flush(d->hip);
   if (rc < 0) return TH_EFAULT;
+  d->prof.lap(FE_FLUSH);
+  d->prof.frames++;
   d->have_frame = true;
   d->curframe_num++;
   if (granpos) *granpos = d->granpos;
@@ -1032,7 +1131,9 @@ int th_decode_ycbcr_out(th_dec_ctx *d, th_ycbcr_buffer ycbcr) {
     ycbcr[p].stride = strides[p];
     ycbcr[p].data = dst[p];
   }
+  d->prof.start();
   if (d->have_frame && thip_state_ycbcr_out(d->hip, dst, strides) < 0) return TH_EFAULT;
+  d->prof.lap(FE_OUT);
   return 0;
 }
 

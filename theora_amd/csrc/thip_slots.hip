@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_enc_quantize(int16_t *qdct, int32_t *no
     if (abs(val) >= d) {
       const int s = val >> 31;
       val += (d + s) ^ s;
-      q = sx16((((s_m[z] * val) >> 16) + val >> s_l[z]) - s);
+      q = sx16(((((s_m[z] * val) >> 16) + val) >> s_l[z]) - s);
       nz = z;
     }
     v[z] = q;
