@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <mutex>
 #include <vector>
@@ -1245,7 +1246,8 @@ int thip_frame_flush(thip_state *st) {
   }
   hipStream_t s = g_lanes[st->lane];
   const size_t ngroups = ((size_t)st->enq_nslots + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
-  if (st->enq_ncoded) {
+  static const int zerocopy = getenv("THIP_ZEROCOPY") ? atoi(getenv("THIP_ZEROCOPY")) : 1;
+  if (st->enq_ncoded && !zerocopy) {
     HIP_TRY(hipMemcpyAsync(st->d_info, st->h_info, (size_t)st->tiles.ntiles * THIP_TILE_FRAGS * 8,
                            hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(st->d_slot0, st->h_slot0, (size_t)st->tiles.ntiles * 4, hipMemcpyHostToDevice, s));
@@ -1254,9 +1256,11 @@ int thip_frame_flush(thip_state *st) {
   }
   thip_frame_desc d;
   memset(&d, 0, sizeof(d));
-  d.frag_info = st->d_info;
-  d.coeffs = st->d_coeffs;
-  d.tile_slot0 = st->d_slot0;
+  // zero-copy: the kernels read the pinned staging buffers across PCIe themselves (every
+  // byte exactly once, coalesced); hipMemcpyAsync of ~1 MB costs more host time than that
+  d.frag_info = zerocopy ? st->h_info : st->d_info;
+  d.coeffs = zerocopy ? st->h_coeffs : st->d_coeffs;
+  d.tile_slot0 = zerocopy ? st->h_slot0 : st->d_slot0;
   d.nslots = st->enq_nslots;
   d.ncoded = st->enq_ncoded;
   d.frame_type = st->enq_frame_type;
