@@ -92,3 +92,45 @@ def test_corrupted_packet_changes_the_picture(hip):
     b.packetin(bytes(bad))
     dirty = b.ycbcr_out()
     assert any(not np.array_equal(x, y) for x, y in zip(clean, dirty))
+
+
+def test_contexts_on_concurrent_host_threads(hip):
+    """Decoder contexts are independent (no mutable globals on the path, SURVEY 8b
+    "Threading"): four streams decoded by four host threads at once give the pictures the same
+    packets give one after the other."""
+    import threading
+    from theora_amd.decoder import Decoder
+    geoms = [(176, 144, 0), (64, 48, 3), (336, 32, 0), (80, 48, 2)]
+    streams = []
+    for i, (w, h, fmt) in enumerate(geoms):
+        st = streamgen.Stream(w, h, fmt, seed=40 + i)
+        hdr = st.header_packets()
+        pkts = [st.frame(0 if f % 4 == 0 else 1, density=0.6)[0] for f in range(8)]
+        streams.append((hdr, pkts))
+
+    def decode(hdr, pkts, out, reps):
+        for _ in range(reps):
+            dec = Decoder(hdr)
+            frames = []
+            for p in pkts:
+                dec.packetin(p)
+                frames.append([pl.copy() for pl in dec.ycbcr_out()])
+            dec.close()
+            out.append(frames)
+
+    serial = []
+    for hdr, pkts in streams:
+        o = []
+        decode(hdr, pkts, o, 1)
+        serial.append(o[0])
+    outs = [[] for _ in streams]
+    ths = [threading.Thread(target=decode, args=(hdr, pkts, outs[i], 3)) for i, (hdr, pkts) in enumerate(streams)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(len(streams)):
+        assert len(outs[i]) == 3
+        for rep in outs[i]:
+            for fa, fb in zip(rep, serial[i]):
+                assert all(np.array_equal(a, b) for a, b in zip(fa, fb)), i

@@ -647,6 +647,7 @@ struct thip_state {
   uint32_t *h_info, *d_info;
   int16_t *h_coeffs, *d_coeffs;
   uint32_t *h_slot0, *d_slot0;
+  hipEvent_t ev_staging;     // recorded behind the kernels that read the staging buffers (enqueue path)
   hipStream_t last_stream;   // stream of the most recent launch for this state (ycbcr_out copies on it)
   uint8_t *h_out;       // pinned image of one frame for thip_state_ycbcr_out (allocated on first use)
   int32_t *enq_last_lane;   // per tile: last lane that received a slot (arrival-order check)
@@ -823,6 +824,7 @@ void thip_state_free(thip_state *st) {
   if (st->h_coeffs) (void)hipHostFree(st->h_coeffs);
   if (st->h_slot0) (void)hipHostFree(st->h_slot0);
   if (st->h_out) (void)hipHostFree(st->h_out);
+  if (st->ev_staging) (void)hipEventDestroy(st->ev_staging);
   if (st->d_info) (void)hipFree(st->d_info);
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
   if (st->d_slot0) (void)hipFree(st->d_slot0);
@@ -1123,9 +1125,9 @@ int thip_frame_begin(thip_state *st, int frame_type) {
   if (frame_type != THIP_INTRA_FRAME && frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
   int rc = ensure_staging(st);
   if (rc) return rc;
-  // the previous frame's upload must have drained before the staging buffers are reused
-  rc = thip_synchronize();
-  if (rc) return rc;
+  // the previous frame's kernels must have read the staging buffers before they are reused;
+  // only this stream's own work is waited for, so contexts on other host threads keep going
+  if (st->ev_staging) HIP_TRY(hipEventSynchronize(st->ev_staging));
   memset(st->h_info, 0, (size_t)st->tiles.ntiles * THIP_TILE_FRAGS * 8);   // everything uncoded
   memset(st->h_slot0, 0, (size_t)st->tiles.ntiles * 4);
   for (int t = 0; t < st->tiles.ntiles; t++) st->enq_last_lane[t] = -1;
@@ -1275,6 +1277,8 @@ int thip_frame_flush(thip_state *st) {
   rc = thip_decode_frames(&sp, &d, 1, nullptr, &res);
   st->lf_rows_custom = 0;
   if (rc < 0) return rc;
+  if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(st->ev_staging, s));
   return res;
 }
 
