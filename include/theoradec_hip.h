@@ -94,6 +94,27 @@ int64_t th_granule_frame(void *encdec, int64_t granpos);
 #define TH_DECCTL_GET_PPLEVEL_MAX (1)
 #define TH_DECCTL_SET_PPLEVEL (3)
 #define TH_DECCTL_SET_GRANPOS (5)
+/* Extension (not in theoradec.h): a context allocated while THIP_FE_TRACE_BACKEND=1 is set owns no
+   device state; th_decode_packetin parses the packet completely and RECORDS the accel-vtable slot
+   calls of the frame (state_frag_recon per coded fragment in coded order, frag_copy_list, the loop
+   filter limit) instead of making them.  This request fills a thip_slot_trace describing the most
+   recent frame (pointers stay valid until the next packet).  It exists so that the host logic can be
+   tested without a GPU; on a normal context it returns TH_EINVAL. */
+#define TH_DECCTL_THIP_GET_SLOT_TRACE (0x7101)
+typedef struct thip_slot_trace {
+  int64_t ncoded;           /* state_frag_recon calls, in call (= coded) order */
+  const int32_t *fragi;     /* _fragi */
+  const uint8_t *pli;       /* _pli */
+  const uint8_t *last_zzi;  /* _last_zzi */
+  const uint8_t *refi;      /* frags[_fragi].refi */
+  const uint16_t *dc_quant; /* _dc_quant */
+  const int16_t *mv;        /* frag_mvs[_fragi], OC_MV packing */
+  const int16_t *coeffs;    /* _dct_coeffs[0..63] of each call: natural order, AC dequantised, raw DC */
+  int64_t nuncoded;         /* fragments handed to frag_copy_list */
+  const int64_t *uncoded;
+  int32_t flimit;           /* loop_filter_limits[qis[0]] */
+  int32_t frame_type;
+} thip_slot_trace;
 
 #ifdef __cplusplus
 }

@@ -186,6 +186,15 @@ struct th_dec_ctx {
   int granpos_bias;
   bool have_frame;
   std::vector<uint8_t> mirror[3];
+  // slot-trace mode (THIP_FE_TRACE_BACKEND=1 at th_decode_alloc): no device state exists; the
+  // vtable-slot calls of a frame are recorded instead of made (TH_DECCTL_THIP_GET_SLOT_TRACE)
+  bool trace;
+  std::vector<int32_t> tr_fragi;
+  std::vector<uint8_t> tr_pli, tr_last_zzi, tr_refi;
+  std::vector<uint16_t> tr_dcq;
+  std::vector<int16_t> tr_mv, tr_coeffs;
+  std::vector<int64_t> tr_uncoded;
+  int tr_flimit;
 };
 
 namespace {
@@ -678,7 +687,10 @@ th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup) {
   d->info = *info;
   d->setup = *setup;
   d->hip = nullptr;
-  if (thip_state_create(&d->hip, (int)info->frame_width, (int)info->frame_height, (int)info->pixel_fmt) < 0) {
+  d->trace = getenv("THIP_FE_TRACE_BACKEND") != nullptr && atoi(getenv("THIP_FE_TRACE_BACKEND")) != 0;
+  d->tr_flimit = 0;
+  if (!d->trace &&
+      thip_state_create(&d->hip, (int)info->frame_width, (int)info->frame_height, (int)info->pixel_fmt) < 0) {
     delete d;
     return nullptr;
   }
@@ -720,7 +732,7 @@ void th_decode_free(th_dec_ctx *d) {
       fprintf(stderr, "  %-28s %8.3f ms/frame %5.1f %%\n", kFeNames[s], 1e3 * d->prof.acc[s] / (double)d->prof.frames,
               100.0 * d->prof.acc[s] / tot);
   }
-  thip_state_free(d->hip);
+  if (d->hip) thip_state_free(d->hip);
   delete d;
 }
 
@@ -743,6 +755,25 @@ int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
       d->granpos = g;
       d->keyframe_num = (g >> d->info.keyframe_granule_shift) - d->granpos_bias;
       d->curframe_num = d->keyframe_num + (g & (((int64_t)1 << d->info.keyframe_granule_shift) - 1));
+      return 0;
+    }
+    case TH_DECCTL_THIP_GET_SLOT_TRACE: {
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(thip_slot_trace)) return TH_EINVAL;
+      if (!d->trace) return TH_EINVAL;
+      thip_slot_trace *t = (thip_slot_trace *)buf;
+      t->ncoded = (int64_t)d->tr_fragi.size();
+      t->fragi = d->tr_fragi.data();
+      t->pli = d->tr_pli.data();
+      t->last_zzi = d->tr_last_zzi.data();
+      t->refi = d->tr_refi.data();
+      t->dc_quant = d->tr_dcq.data();
+      t->mv = d->tr_mv.data();
+      t->coeffs = d->tr_coeffs.data();
+      t->nuncoded = (int64_t)d->tr_uncoded.size();
+      t->uncoded = d->tr_uncoded.data();
+      t->flimit = d->tr_flimit;
+      t->frame_type = d->frame_type;
       return 0;
     }
     default: return TH_EIMPL;
@@ -1055,9 +1086,16 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   }
   d->prof.lap(FE_DC);
   // ---- 7.9 reconstruction through the backend's vtable slots -------------------------------------------
-  int rc = thip_frame_begin(d->hip, d->frame_type);
-  if (rc < 0) return TH_EFAULT;
+  int rc = 0;
+  if (d->trace) {
+    d->tr_fragi.clear(); d->tr_pli.clear(); d->tr_last_zzi.clear(); d->tr_refi.clear();
+    d->tr_dcq.clear(); d->tr_mv.clear(); d->tr_coeffs.clear(); d->tr_uncoded.clear();
+  } else {
+    rc = thip_frame_begin(d->hip, d->frame_type);
+    if (rc < 0) return TH_EFAULT;
+  }
   const int flimit = d->setup.qp.lflims[d->qis[0]];
+  d->tr_flimit = flimit;
   {
     alignas(16) int16_t block[128];
     memset(block, 0, sizeof(block));
@@ -1099,8 +1137,23 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         }
         block[0] = d->dc[f];   // raw un-predicted DC; the slot dequantises it (state.c:967-979)
         const int16_t mv = (int16_t)(((int)d->mvx[f] & 0xFF) | ((int)d->mvy[f] * 256));
+        if (d->trace) {
+          d->tr_fragi.push_back(f);
+          d->tr_pli.push_back((uint8_t)p);
+          d->tr_last_zzi.push_back((uint8_t)last_zzi);
+          d->tr_refi.push_back(d->refi[f]);
+          d->tr_dcq.push_back(dcq);
+          d->tr_mv.push_back(mv);
+          d->tr_coeffs.insert(d->tr_coeffs.end(), block, block + 64);
+          memset(block, 0, 64 * sizeof(block[0]));   // what the slot does (idct.c:245,276,295)
+          continue;
+        }
         rc = thip_state_frag_recon(d->hip, f, p, block, last_zzi, dcq, d->refi[f], mv);
         if (rc < 0) return TH_EFAULT;
+      }
+      if (d->trace) {
+        for (ptrdiff_t u : uncoded) d->tr_uncoded.push_back((int64_t)u);
+        continue;
       }
       if (!uncoded.empty() && thip_frag_copy_list(d->hip, uncoded.data(), (ptrdiff_t)uncoded.size()) < 0)
         return TH_EFAULT;
@@ -1109,8 +1162,10 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     }
   }
   d->prof.lap(FE_EXPAND);
-  rc = thip_frame_flush(d->hip);
-  if (rc < 0) return TH_EFAULT;
+  if (!d->trace) {
+    rc = thip_frame_flush(d->hip);
+    if (rc < 0) return TH_EFAULT;
+  }
   d->prof.lap(FE_FLUSH);
   d->prof.frames++;
   d->have_frame = true;
@@ -1132,7 +1187,7 @@ int th_decode_ycbcr_out(th_dec_ctx *d, th_ycbcr_buffer ycbcr) {
     ycbcr[p].data = dst[p];
   }
   d->prof.start();
-  if (d->have_frame && thip_state_ycbcr_out(d->hip, dst, strides) < 0) return TH_EFAULT;
+  if (d->have_frame && !d->trace && thip_state_ycbcr_out(d->hip, dst, strides) < 0) return TH_EFAULT;
   d->prof.lap(FE_OUT);
   return 0;
 }

@@ -8,6 +8,16 @@ from . import _lib
 from ._lib import OggPacket, ThComment, ThImgPlane, ThInfo, TheoraHipError
 
 TH_DUPFRAME = 1
+TH_DECCTL_THIP_GET_SLOT_TRACE = 0x7101
+
+
+class SlotTrace(C.Structure):
+    """thip_slot_trace (include/theoradec_hip.h)."""
+    _fields_ = [("ncoded", C.c_int64), ("fragi", C.POINTER(C.c_int32)), ("pli", C.POINTER(C.c_uint8)),
+                ("last_zzi", C.POINTER(C.c_uint8)), ("refi", C.POINTER(C.c_uint8)),
+                ("dc_quant", C.POINTER(C.c_uint16)), ("mv", C.POINTER(C.c_int16)),
+                ("coeffs", C.POINTER(C.c_int16)), ("nuncoded", C.c_int64), ("uncoded", C.POINTER(C.c_int64)),
+                ("flimit", C.c_int32), ("frame_type", C.c_int32)]
 
 
 def _packet(data, bos=0, packetno=0):
@@ -58,6 +68,25 @@ class Decoder:
             a = np.ctypeslib.as_array(p.data, (p.height, p.stride))[:, :p.width]
             out.append(a.copy())
         return out
+
+    def slot_trace(self):
+        """The accel-vtable slot calls of the last frame as numpy arrays; only on a context
+        allocated with THIP_FE_TRACE_BACKEND=1 in the environment (no device needed)."""
+        t = SlotTrace()
+        rc = self._L.th_decode_ctl(self._dec, TH_DECCTL_THIP_GET_SLOT_TRACE, C.byref(t), C.sizeof(t))
+        if rc < 0:
+            raise TheoraHipError("TH_DECCTL_THIP_GET_SLOT_TRACE returned %d" % rc)
+        n, u = int(t.ncoded), int(t.nuncoded)
+
+        def arr(ptr, count, shape=None):
+            if count == 0:
+                return np.zeros(shape or (0,), np.ctypeslib.as_array(ptr, (1,)).dtype if ptr else np.int64)
+            a = np.ctypeslib.as_array(ptr, (count,)).copy()
+            return a.reshape(shape) if shape else a
+
+        return dict(fragi=arr(t.fragi, n), pli=arr(t.pli, n), last_zzi=arr(t.last_zzi, n), refi=arr(t.refi, n),
+                    dc_quant=arr(t.dc_quant, n), mv=arr(t.mv, n), coeffs=arr(t.coeffs, n * 64, (n, 64)),
+                    uncoded=arr(t.uncoded, u), flimit=int(t.flimit), frame_type=int(t.frame_type))
 
     def close(self):
         if getattr(self, "_dec", None):
