@@ -12,6 +12,7 @@
 //
 // Exports the th_decode_* API declared in include/theoradec_hip.h.
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -151,7 +152,7 @@ static inline double fe_now() {
 struct FeProf {
   bool on;
   double acc[FE_NSEC], t;
-  long frames;
+  long frames, tokens;
   void start() { if (on) t = fe_now(); }
   void lap(int s) {
     if (!on) return;
@@ -483,65 +484,72 @@ inline int read_token_bitwise(BitReader &br, const HuffTree &t, int node) {
 }
 inline int read_token(BitReader &br, const HuffTree &t) {
   if (t.root_leaf) return t.root_leaf - 1;
-  if (br.pos + kHuffLutBits > br.nbits) return read_token_bitwise(br, t, 0);   // tail of the packet
-  const uint16_t e = t.lut[br.peek(kHuffLutBits)];
+  if (br.pos + 32 > br.nbits) return read_token_bitwise(br, t, 0);   // tail of the packet
+  const uint32_t w = br.peek(32);   // a code is at most 32 bits long
+  const uint16_t e = t.lut[w >> (32 - kHuffLutBits)];
   if (!(e & 0x8000)) {
     br.skip(e >> 8);
     return e & 0xFF;
   }
-  br.skip(kHuffLutBits);
-  return read_token_bitwise(br, t, e & 0x7FFF);
+  // longer than the table covers: finish the walk on the peeked word, one skip at the end
+  int node = e & 0x7FFF, len = kHuffLutBits;
+  for (;;) {
+    const int c = t.child[node][(w >> (31 - len)) & 1u];
+    len++;
+    if (c < 0) {
+      br.skip(len);
+      return -c - 1;
+    }
+    node = c;
+  }
 }
 
-// Tables 7.33 / 7.38: number of extra bits that follow each token ...
-const uint8_t kTokExtraBits[32] = {0, 0, 0, 2, 3, 4, 12, 3, 6, 0, 0, 0, 0, 1, 1, 1, 1, 2, 3, 4, 5, 6, 10, 1, 1, 1, 1, 1, 3, 4, 2, 3};
-// ... and what token + extra bits x (sign first where there is one) expand to.  For EOB tokens
-// the run length goes to tok.eob (0 extra on token 6 -> "all remaining", signalled as 0xFFFFFFFF).
+// Tables 7.33 / 7.38 as data: what token + extra bits expand to.  Extra bits x are read in one
+// go; where the token carries a sign it is the first of them.
+//   EOB tokens (0-6):   run = vbase + x            (token 6 with x == 0: "all remaining")
+//   zero runs (7, 8):   skip = adv = 1 + x, no value
+//   values (9-31):      |value| = vbase + ((rest >> vshift) & vmask), skip = sbase + (rest & smask),
+//                       adv = skip + 1, rest = the bits after the sign
+struct TokDef {
+  uint8_t ebits;     // extra bits in total
+  uint8_t kind;      // 0 EOB run, 1 zero run, 2 value
+  uint8_t sign;      // 0 positive, 1 negative, 2 read from the stream
+  uint8_t vshift, sbase, smask;
+  uint16_t vmask;
+  int16_t vbase;
+};
+#define TD(eb, kind, sign, vshift, vmask, sbase, smask, vbase) {eb, kind, sign, vshift, sbase, smask, vmask, vbase}
+const TokDef kTokDef[32] = {
+    TD(0, 0, 0, 0, 0, 0, 0, 1),      TD(0, 0, 0, 0, 0, 0, 0, 2),      TD(0, 0, 0, 0, 0, 0, 0, 3),
+    TD(2, 0, 0, 0, 0x3, 0, 0, 4),    TD(3, 0, 0, 0, 0x7, 0, 0, 8),    TD(4, 0, 0, 0, 0xF, 0, 0, 16),
+    TD(12, 0, 0, 0, 0xFFF, 0, 0, 0), TD(3, 1, 0, 0, 0, 1, 0x07, 0),   TD(6, 1, 0, 0, 0, 1, 0x3F, 0),
+    TD(0, 2, 0, 0, 0, 0, 0, 1),      TD(0, 2, 1, 0, 0, 0, 0, 1),      TD(0, 2, 0, 0, 0, 0, 0, 2),
+    TD(0, 2, 1, 0, 0, 0, 0, 2),      TD(1, 2, 2, 0, 0, 0, 0, 3),      TD(1, 2, 2, 0, 0, 0, 0, 4),
+    TD(1, 2, 2, 0, 0, 0, 0, 5),      TD(1, 2, 2, 0, 0, 0, 0, 6),      TD(2, 2, 2, 0, 0x01, 0, 0, 7),
+    TD(3, 2, 2, 0, 0x03, 0, 0, 9),   TD(4, 2, 2, 0, 0x07, 0, 0, 13),  TD(5, 2, 2, 0, 0x0F, 0, 0, 21),
+    TD(6, 2, 2, 0, 0x1F, 0, 0, 37),  TD(10, 2, 2, 0, 0x1FF, 0, 0, 69), TD(1, 2, 2, 0, 0, 1, 0, 1),
+    TD(1, 2, 2, 0, 0, 2, 0, 1),      TD(1, 2, 2, 0, 0, 3, 0, 1),      TD(1, 2, 2, 0, 0, 4, 0, 1),
+    TD(1, 2, 2, 0, 0, 5, 0, 1),      TD(3, 2, 2, 0, 0, 6, 0x03, 1),   TD(4, 2, 2, 0, 0, 10, 0x07, 1),
+    TD(2, 2, 2, 0, 0x01, 1, 0, 2),   TD(3, 2, 2, 1, 0x01, 2, 0x01, 2)};
+#undef TD
+
+// Straight-line on purpose: which of the 32 tokens comes next is close to random, so a switch
+// costs a mispredicted branch per token.
 inline void decode_token(BitReader &br, int token, Tok &k) {
-  const int eb = kTokExtraBits[token];
-  const uint32_t x = br.read(eb);
-  const int sign = eb ? (int)(x >> (eb - 1)) : 0;            // meaningful for tokens >= 13
-  const uint32_t rest = eb ? x & ((1u << (eb - 1)) - 1u) : 0;  // bits after the sign
-  k.value = 0;
-  k.skip = 0;
-  k.adv = 1;
-  k.eob = 0;
-  switch (token) {
-    case 0: k.eob = 1; k.adv = 0; break;
-    case 1: k.eob = 2; k.adv = 0; break;
-    case 2: k.eob = 3; k.adv = 0; break;
-    case 3: k.eob = 4 + x; k.adv = 0; break;
-    case 4: k.eob = 8 + x; k.adv = 0; break;
-    case 5: k.eob = 16 + x; k.adv = 0; break;
-    case 6: k.eob = x ? x : 0xFFFFFFFFu; k.adv = 0; break;
-    case 7: case 8: k.adv = (uint8_t)(x + 1); k.skip = k.adv; break;    // pure zero runs: value 0
-    case 9: k.value = 1; break;
-    case 10: k.value = -1; break;
-    case 11: k.value = 2; break;
-    case 12: k.value = -2; break;
-    case 13: case 14: case 15: case 16: k.value = (int16_t)(token - 10); break;
-    case 17: k.value = (int16_t)(7 + rest); break;
-    case 18: k.value = (int16_t)(9 + rest); break;
-    case 19: k.value = (int16_t)(13 + rest); break;
-    case 20: k.value = (int16_t)(21 + rest); break;
-    case 21: k.value = (int16_t)(37 + rest); break;
-    case 22: k.value = (int16_t)(69 + rest); break;
-    case 23: case 24: case 25: case 26: case 27:
-      k.skip = (uint8_t)(token - 22);
-      k.value = 1;
-      break;
-    case 28: k.skip = (uint8_t)(6 + rest); k.value = 1; break;
-    case 29: k.skip = (uint8_t)(10 + rest); k.value = 1; break;
-    case 30: k.value = (int16_t)(2 + rest); k.skip = 1; break;
-    default:   // 31: sign, one value bit, one run bit
-      k.value = (int16_t)(2 + (rest >> 1));
-      k.skip = (uint8_t)(2 + (rest & 1));
-      break;
-  }
-  if (token >= 13) {
-    if (sign) k.value = (int16_t)-k.value;
-    k.adv = (uint8_t)(k.skip + 1);
-  }
+  const TokDef &t = kTokDef[token];
+  const uint32_t x = br.read(t.ebits);
+  const uint32_t rd = t.sign == 2;
+  const uint32_t sbit = rd ? t.ebits - 1u : 0u;                // position of the sign among the extra bits
+  const uint32_t neg = rd ? (x >> sbit) & 1u : t.sign;
+  const uint32_t rest = x & ((1u << (rd ? sbit : t.ebits)) - 1u);
+  const int mag = t.vbase + (int)((rest >> t.vshift) & t.vmask);
+  const int isval = t.kind == 2, iseob = t.kind == 0;
+  const int skip = t.sbase + (int)(rest & t.smask);
+  k.value = (int16_t)(isval ? (neg ? -mag : mag) : 0);
+  k.skip = (uint8_t)skip;
+  k.adv = (uint8_t)(iseob ? 0 : skip + isval);
+  k.eob = iseob ? (uint32_t)mag : 0u;
+  if (iseob && mag == 0) k.eob = 0xFFFFFFFFu;                  // token 6 with a zero run field: all remaining
 }
 
 // ---------------------------------------------------------------------------------------
@@ -727,7 +735,7 @@ void th_decode_free(th_dec_ctx *d) {
   if (d->prof.on && d->prof.frames) {
     double tot = 0;
     for (int s = 0; s < FE_NSEC; s++) tot += d->prof.acc[s];
-    fprintf(stderr, "[thip front end] %ld frames, %.3f ms/frame\n", d->prof.frames, 1e3 * tot / (double)d->prof.frames);
+    fprintf(stderr, "[thip front end] %ld frames, %.3f ms/frame, %ld tokens/frame\n", d->prof.frames, 1e3 * tot / (double)d->prof.frames, d->prof.tokens / d->prof.frames);
     for (int s = 0; s < FE_NSEC; s++)
       fprintf(stderr, "  %-28s %8.3f ms/frame %5.1f %%\n", kFeNames[s], 1e3 * d->prof.acc[s] / (double)d->prof.frames,
               100.0 * d->prof.acc[s] / tot);
@@ -993,8 +1001,13 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
           n -= take;
         }
         const HuffTree &tree = d->setup.huff[16 * hg + (p == 0 ? htil : htic)];
+        // every token closes at least one open block of this list: at most n tokens (+1 for the
+        // closing entry of a truncated packet)
+        std::vector<Tok> &list = d->toks[p][z];
+        list.resize(n + 1);
+        Tok *out = list.data();
         while (n > 0) {
-          Tok k;
+          Tok &k = *out++;
           decode_token(br, read_token(br, tree), k);
           if (k.eob) {
             if (k.eob == 0xFFFFFFFFu) {   // every block still open anywhere ends (7.7.1)
@@ -1007,20 +1020,19 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
             const uint32_t take = k.eob < n ? k.eob : (uint32_t)n;
             eobs = k.eob - take;
             n -= take;
-            d->toks[p][z].push_back(k);
           } else {
             const int nz = z + k.adv;
             if (nz < 64) left[p][nz]++;
             n--;
-            d->toks[p][z].push_back(k);
           }
           if (br.overrun() && n > 0) {   // truncated packet: close everything that is open
-            Tok e;
+            Tok &e = *out++;
             e.value = 0; e.skip = 0; e.adv = 0; e.eob = (uint32_t)n;
-            d->toks[p][z].push_back(e);
             n = 0;
           }
         }
+        list.resize((size_t)(out - list.data()));
+        d->prof.tokens += (long)list.size();
       }
     }
   }
