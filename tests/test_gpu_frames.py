@@ -129,3 +129,18 @@ def test_parity_check_has_teeth(hip):
     desc, ka = synth.upload_frame(synth.pack_frame(geom, wrong))
     hip.decode_frames([gst], [desc])
     assert util.planes_equal(ost, gst), "comparison failed to notice a different filter limit"
+
+
+def test_fused_recon_loopfilter_variant(hip):
+    """THIP_FUSE=1 selects k_recon_lf + k_lf_seam (strip reconstructed and filtered in LDS, written
+    once).  It is off by default because it measured slower, but it must stay bit-exact: run the
+    sequence tests of this file in a child process with the switch on."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, THIP_FUSE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q",
+                        "-k", "sequence or enqueue or batched or grey or dup"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

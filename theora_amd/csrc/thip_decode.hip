@@ -78,6 +78,8 @@ struct PlaneK {
   int tile_off;      // index of the plane's first tile
   int fro;           // raster index of the plane's first fragment
   float rcp_cx;      // 1/(nh+1)
+  int nseg, seglen;  // a tile row is cut into nseg segments of seglen tiles (k_recon_lf)
+  int seam_rows;     // cell rows filtered by k_lf_seam: m = 0,4,8,... and m = nv
 };
 
 struct StreamK {
@@ -94,6 +96,9 @@ struct StreamK {
   int cell_end[3];        // cumulative filter-cell counts per plane, each plane padded to 64 (k_loopfilter)
   int lf_y0[3], lf_y1[3]; // fragment-row range whose filter operations are applied
   int debug;              // ablation switches for profiling (THIP_DEBUG env), 0 in production
+  // fused reconstruction + loop filter (k_recon_lf / k_lf_seam)
+  int seg_end[3];         // cumulative workgroup counts per plane: one workgroup per (tile row, segment)
+  int seam_end[3];        // cumulative seam-cell counts per plane, each plane padded to 64
   PlaneK pl[3];
 };
 
@@ -405,8 +410,11 @@ struct ReconPlane {               // wave-uniform
 // instantiations instead of one body with a merged P: a merge makes the register allocator
 // copy loaded registers right behind the loads, i.e. wait for them before the predictor
 // loads are even issued.
-template <bool IDCT>
-__device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane &L, const uint4 *lds_coef) {
+// LDSOUT: the rows go to the tile image in LDS (128-byte pitch, lds_img = this lane's block) for
+// the fused loop filter instead of to the frame.
+template <bool IDCT, bool LDSOUT = false>
+__device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane &L, const uint4 *lds_coef,
+                                           uint8_t *lds_img = nullptr) {
   uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
 
   // ---- 3. predictor loads.  An uncoded fragment (fragment.c:20-47) is the zero-vector
@@ -453,7 +461,12 @@ __device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane 
 #pragma unroll
   for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
   if (inter) pred_finish(Q, R.nh * 8, pred);
-  if (!(R.debug & 4)) {
+  if (LDSOUT) {
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      *reinterpret_cast<uint2 *>(lds_img + r * 128) =
+          pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]), pred[r]);
+  } else if (!(R.debug & 4)) {
 #pragma unroll
     for (int r = 0; r < 8; r++)
       store_row8(dst + (ptrdiff_t)r * R.stride,
@@ -576,6 +589,199 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   } else {
     if (valid) recon_tail<false>(R, L, lds_wave);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_recon_lf (K1+K2+most of K3): reconstruction fused with the loop filter
+// ---------------------------------------------------------------------------------------
+// One workgroup per SEGMENT of a tile row (up to 16 horizontally adjacent tiles, one wave each,
+// exactly k_recon's two round trips per wave).  The reconstructed tiles go to LDS (each wave's
+// 128x32 image re-uses its coefficient staging area), the workgroup meets at a barrier, and
+// every filter cell that lies completely inside the segment's 32-pixel-high strip -- cell rows
+// m = 1..3 of the tile row, all columns except the segment's outer edges -- is filtered there
+// (cells are independent), then the strip is written to the frame ONCE.
+// What is left for k_lf_seam are the cell rows on tile-row boundaries (m = 0 mod 4, and m = nv)
+// and the columns on segment boundaries: about a quarter of the cells, read and written in full
+// rows.  The separate k_loopfilter pass re-read and re-wrote every pixel.
+constexpr int kSegMax = 8;             // waves per workgroup (8 x 8 KB of LDS: two workgroups per CU)
+constexpr int kChunkBytes = 8192;      // LDS per wave: coefficient staging, then image (4096) + flags (64)
+
+__device__ __forceinline__ uint32_t lds_px(const uint8_t *base, int x, int y) {   // 4 pixels at (x, y) of the strip
+  return *reinterpret_cast<const uint32_t *>(base + (x >> 7) * kChunkBytes + y * 128 + (x & 127));
+}
+__device__ __forceinline__ void lds_px_store(uint8_t *base, int x, int y, uint32_t v) {
+  *reinterpret_cast<uint32_t *>(base + (x >> 7) * kChunkBytes + y * 128 + (x & 127)) = v;
+}
+
+__global__ __launch_bounds__(64 * kSegMax, 1) void k_recon_lf(const BatchK B) {
+  extern __shared__ uint4 s_dyn[];
+  const StreamK &S = B.s[blockIdx.y];
+  const int lane = (int)threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, see k_recon
+  const uint2 *info_p = S.info;
+  const int4 *coeffs_p = S.coeffs;
+  const uint32_t *slot0_p = S.tile_slot0;
+  uint8_t *self = S.self;
+  const uint8_t *prev = S.prev, *gold = S.gold;
+  uint8_t *coded_map = S.coded_map;
+  const int se0 = S.seg_end[0], se1 = S.seg_end[1], se2 = S.seg_end[2];
+  const int te0 = S.tile_end[0], te1 = S.tile_end[1];
+  const int debug = S.debug, sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
+  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
+               "s"(se0), "s"(se1), "s"(se2), "s"(te0), "s"(te1), "s"(debug), "s"(sqpx), "s"(sqpy), "s"(L2));
+  if (wg >= se2) return;
+  const int pli = (wg >= se0 ? 1 : 0) + (wg >= se1 ? 1 : 0);
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.fro), "s"(G.nseg),
+               "s"(G.seglen), "s"(fy0), "s"(fy1));
+  const int rel = wg - (pli == 0 ? 0 : (pli == 1 ? se0 : se1));
+  const int sby = rel / G.nseg;                 // tile row
+  const int seg = rel - sby * G.nseg;
+  const int tx0 = seg * G.seglen;               // first tile of the segment
+  const int ntx = min(G.seglen, G.tiles_x - tx0);
+  if (wave >= ntx) return;                      // (whole waves only: the barriers below count live waves)
+  const int tx = tx0 + wave;
+  const int unit = (pli == 0 ? 0 : (pli == 1 ? te0 : te1)) + sby * G.tiles_x + tx;   // tile number, as in k_recon
+
+  const uint32_t slot0 = slot0_p[unit];
+  const uint2 info = info_p[(size_t)unit * THIP_TILE_FRAGS + lane];
+  asm volatile("" ::"s"(slot0), "v"(info.x));
+
+  const int h = lane & 15;
+  const int lx = (lane >> 4) * 4 + hilb_col(h), ly = hilb_row(h);   // fragment inside the tile
+  const int bx = tx * 16 + lx, by = sby * 4 + ly;
+  const bool valid = bx < G.nh && by < G.nv;
+
+  ReconLane L;
+  L.flags = valid ? info.x : 0u;
+  L.dcp = (info.y & 0xFFFFu) * 0x00010001u;
+  L.coded = (L.flags & THIP_INFO_CODED) != 0;
+  L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
+  L.has_coeff = L.coded && !L.dc_only;
+  L.x0 = bx * 8;
+  L.y0 = by * 8;
+  ReconPlane R;
+  R.self = self + G.off;
+  R.prev = prev + G.off;
+  R.gold = gold + G.off;
+  R.coded_map = coded_map + G.fro;
+  R.nh = G.nh;
+  R.nv = G.nv;
+  R.stride = G.stride;
+  R.qpx = pli != 0 && sqpx;
+  R.qpy = pli != 0 && sqpy;
+  R.debug = debug;
+  R.tr = nullptr;
+
+  uint8_t *const strip = reinterpret_cast<uint8_t *>(s_dyn);          // chunk w = tile w of the segment
+  uint8_t *const chunk = strip + wave * kChunkBytes;
+  uint8_t *const img = chunk + (ly * 8) * 128 + lx * 8;               // this lane's block in the tile image
+  const uint64_t mask = __ballot(L.has_coeff);
+  if (mask != 0 && !(debug & 9)) {
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
+    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
+    uint4 *lds_wave = reinterpret_cast<uint4 *>(chunk);
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
+                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
+    if (valid) recon_tail<true, true>(R, L, lds_wave + lane, img);
+  } else {
+    if (valid) recon_tail<false, true>(R, L, nullptr, img);
+  }
+  chunk[4096 + ly * 16 + lx] = (valid && L.coded) ? 1 : 0;           // coded flags of the tile, for the cells
+  __syncthreads();
+
+  // ---- loop filter on the cells inside the strip ---------------------------------------------------
+  // columns: every corner from the segment's first to its last, except a segment edge that is
+  // not a plane edge; rows: m = 1..3 of this tile row, below the plane's last corner row
+  if (L2 != 0) {
+    const int k0 = tx0 * 16, k1 = min(k0 + ntx * 16, G.nh);
+    const int ka = k0 + (k0 > 0 ? 1 : 0), kb = k1 - (k1 < G.nh ? 1 : 0);
+    const int ncols = kb - ka + 1;
+    const int t = (int)threadIdx.x;
+    const int mr = 1 + (t >= ncols ? 1 : 0) + (t >= 2 * ncols ? 1 : 0);
+    const int k = ka + t - (mr - 1) * ncols, m = sby * 4 + mr;
+    if (t < 3 * ncols && m < G.nv) {
+      const int kx = (k - k0) * 8, my = mr * 8;                        // corner in strip pixels
+      // flags of a=(k-1,m-1) b=(k,m-1) c=(k-1,m) d=(k,m); fragments outside the plane read as uncoded
+      auto flag = [&](int fk, int fm) -> bool {
+        const int rk = fk - k0;
+        return fk >= 0 && fk < G.nh && strip[(rk >> 4) * kChunkBytes + 4096 + (fm - sby * 4) * 16 + (rk & 15)] != 0;
+      };
+      const bool a = flag(k - 1, m - 1), b = flag(k, m - 1), c = flag(k - 1, m), d = flag(k, m);
+      const uint32_t ops = lf_cell_ops(k, m, G.nh, G.nv, a, b, c, d, fy0, fy1);
+      if (ops) {
+        const bool lo_ok = k >= 1, hi_ok = k <= G.nh - 1;
+        int P[64];
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          unpack_row(P + r * 8, lo_ok ? lds_px(strip, kx - 4, my - 4 + r) : 0u, hi_ok ? lds_px(strip, kx, my - 4 + r) : 0u);
+        lf_cell_apply(P, ops, L2);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          if (lo_ok) lds_px_store(strip, kx - 4, my - 4 + r, pack4(P[r * 8 + 0], P[r * 8 + 1], P[r * 8 + 2], P[r * 8 + 3]));
+          if (hi_ok) lds_px_store(strip, kx, my - 4 + r, pack4(P[r * 8 + 4], P[r * 8 + 5], P[r * 8 + 6], P[r * 8 + 7]));
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- the strip goes to the frame, once --------------------------------------------------------------
+  if (valid && !(debug & 4)) {
+    uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) store_row8(dst + (ptrdiff_t)r * R.stride, *reinterpret_cast<const uint2 *>(img + r * 128));
+  }
+}
+
+// The cells k_recon_lf leaves: per plane first the seam ROWS (m = 0, 4, 8, ... and m = nv, every
+// column), then the seam COLUMNS (k on a segment boundary, the remaining rows).
+__global__ __launch_bounds__(256) void k_lf_seam(const BatchK B) {
+  const StreamK &S = B.s[blockIdx.y];
+  const int lane = (int)threadIdx.x & 63;
+  const int wbase = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));
+  uint8_t *self = S.self;
+  const uint8_t *cmap = S.coded_map;
+  const int ce0 = S.seam_end[0], ce1 = S.seam_end[1], ce2 = S.seam_end[2], L2 = S.flimit2;
+  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2));
+  if (wbase >= ce2 || L2 == 0) return;
+  const int pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(G.nseg),
+               "s"(G.seglen), "s"(G.seam_rows), "s"(fy0), "s"(fy1));
+  const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
+  const int nh = G.nh, nv = G.nv;
+  const int nrowcells = G.seam_rows * (nh + 1);
+  int k, m;
+  if (rel < nrowcells) {
+    uint32_t mu, ku;
+    divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
+    k = (int)ku;
+    m = min((int)mu * 4, nv);            // the last seam row is m = nv whether or not nv is a multiple of 4
+  } else {
+    // seam columns: (nseg-1) columns x (nv + 1 - seam_rows) rows; row index -> m skips the seam rows
+    const int r2 = rel - nrowcells;
+    const int ncol = G.nseg - 1, nrow = nv + 1 - G.seam_rows;
+    if (ncol <= 0 || r2 >= ncol * nrow) return;
+    const int ci = r2 / nrow, ri = r2 - ci * nrow;   // (small numbers: plain division)
+    k = (ci + 1) * G.seglen * 16;
+    m = ri + ri / 3 + 1;                 // rows 1,2,3, 5,6,7, 9,...: skip every multiple of 4
+    if (k > nh - 1 || m >= nv) return;   // (a column beyond the plane cannot happen; m < nv by construction)
+  }
+  CellPix C;
+  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
+  bool a, b, c, d;
+  lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
+  const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
+  lf_cell_pin(C);
+  lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -715,7 +921,7 @@ struct ScopedTimer {
 
 // Fills the per-plane kernel geometry and the cumulative tile / cell counts.
 void fill_stream_geom(StreamK &K, const thip_state *st) {
-  int tiles = 0, cells = 0;
+  int tiles = 0, cells = 0, segs = 0, seams = 0;
   for (int pli = 0; pli < 3; pli++) {
     const thip_plane_geom &g = st->geom[pli];
     PlaneK &k = K.pl[pli];
@@ -731,6 +937,14 @@ void fill_stream_geom(StreamK &K, const thip_state *st) {
     K.tile_end[pli] = tiles;
     cells += ((g.nhfrags + 1) * (g.nvfrags + 1) + 63) & ~63;   // whole waves per plane (k_loopfilter)
     K.cell_end[pli] = cells;
+    // fused path: segments of at most kSegMax tiles, as equal as possible
+    k.nseg = (k.tiles_x + kSegMax - 1) / kSegMax;
+    k.seglen = (k.tiles_x + k.nseg - 1) / k.nseg;
+    segs += st->tiles.tiles_y[pli] * k.nseg;
+    K.seg_end[pli] = segs;
+    k.seam_rows = g.nvfrags / 4 + 1 + (g.nvfrags % 4 ? 1 : 0);
+    seams += (k.seam_rows * (g.nhfrags + 1) + (k.nseg - 1) * (g.nvfrags + 1 - k.seam_rows) + 63) & ~63;
+    K.seam_end[pli] = seams;
   }
 }
 }  // namespace
@@ -967,6 +1181,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   BatchK B;
   memset(&B, 0, sizeof(B));
   int max_wg = 0, max_seam_wg = 0, any_lf = 0, nlive = 0;
+  int max_fwg = 0, max_seglen = 1, max_fseam_wg = 0;   // fused path
   int live_state[THIP_MAX_BATCH];
   for (int i = 0; i < n; i++) {
     thip_state *st = states[i];
@@ -1015,17 +1230,46 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       any_lf = 1;
       const int swg = (K.cell_end[2] + 255) / 256;
       if (swg > max_seam_wg) max_seam_wg = swg;
+      const int fswg = (K.seam_end[2] + 255) / 256;
+      if (fswg > max_fseam_wg) max_fseam_wg = fswg;
     }
+    const int fwg = (K.seg_end[2] + 7) & ~7;   // 8 XCD bands
+    if (fwg > max_fwg) max_fwg = fwg;
+    for (int pli = 0; pli < 3; pli++)
+      if (K.pl[pli].seglen > max_seglen) max_seglen = K.pl[pli].seglen;
     live_state[nlive++] = i;
   }
   if (!nlive) return THIP_OK;
-  {
-    ScopedTimer t(s, THIP_KERNEL_RECON);
-    hipLaunchKernelGGL(k_recon, dim3(max_wg, nlive), dim3(64 * THIP_RECON_WG_WAVES), 0, s, B);
-  }
-  if (any_lf) {
-    ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
-    hipLaunchKernelGGL(k_loopfilter, dim3(max_seam_wg, nlive), dim3(256), 0, s, B);
+  // THIP_FUSE=1: reconstruct and filter a strip in LDS and write the frame once (k_recon_lf +
+  // k_lf_seam) instead of k_recon + k_loopfilter over the whole frame.  Bit-exact, 70 MB less
+  // traffic per 4K step, but measured SLOWER (58+17 us vs 44+23 us per 4-frame launch: the
+  // workgroup-wide barriers and the filter's arithmetic cost more than the bytes saved), so it
+  // is off by default; DESIGN.md section 5.
+  static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 0;
+  if (fuse && any_lf) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_recon_lf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kSegMax * kChunkBytes));
+      attr_set = true;
+    }
+    {
+      ScopedTimer t(s, THIP_KERNEL_RECON);
+      hipLaunchKernelGGL(k_recon_lf, dim3(max_fwg, nlive), dim3(64 * max_seglen), (size_t)max_seglen * kChunkBytes, s, B);
+    }
+    {
+      ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
+      hipLaunchKernelGGL(k_lf_seam, dim3(max_fseam_wg, nlive), dim3(256), 0, s, B);
+    }
+  } else {
+    {
+      ScopedTimer t(s, THIP_KERNEL_RECON);
+      hipLaunchKernelGGL(k_recon, dim3(max_wg, nlive), dim3(64 * THIP_RECON_WG_WAVES), 0, s, B);
+    }
+    if (any_lf) {
+      ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
+      hipLaunchKernelGGL(k_loopfilter, dim3(max_seam_wg, nlive), dim3(256), 0, s, B);
+    }
   }
   HIP_TRY(hipGetLastError());
   // decode.c:2947-2962
