@@ -1,0 +1,43 @@
+"""Mutated packets through the th_decode_* front end under AddressSanitizer + UBSan (native
+driver tests/native/fe_fuzz.cpp, gcc, no GPU): a decoder library parses untrusted input, so bit
+flips, truncations, garbage runs and shifted payloads in header and data packets must end in a
+TH_E* code or a decoded frame -- never in a crash, an out-of-bounds access or undefined
+behaviour."""
+import os
+import struct
+import subprocess
+
+import pytest
+
+from tests import streamgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fuzz_bin(tmp_path_factory):
+    out = tmp_path_factory.mktemp("fuzz") / "fe_fuzz"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "fe_fuzz.cpp"),
+           os.path.join(ROOT, "theora_amd", "csrc", "thip_frontend.cpp"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("g++ with sanitizers not usable here: " + r.stderr[-300:])
+    return str(out)
+
+
+@pytest.mark.parametrize("w,h,fmt,seed", [(64, 48, 0, 1), (48, 32, 3, 2), (80, 48, 2, 3)])
+def test_mutated_packets_never_crash(fuzz_bin, tmp_path, w, h, fmt, seed):
+    st = streamgen.Stream(w, h, fmt, seed=seed)
+    hdr = st.header_packets()
+    pkts = [st.frame(0 if f % 3 == 0 else 1, density=0.7)[0] for f in range(6)]
+    path = tmp_path / "pkts.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", len(hdr), len(pkts)))
+        for p in list(hdr) + list(pkts):
+            f.write(struct.pack("<I", len(p)))
+            f.write(bytes(p))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([fuzz_bin, str(path), "300", str(seed)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:] + r.stderr[-3000:])
+    assert "fe_fuzz: 300 iterations" in r.stdout

@@ -863,7 +863,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   } else {
     // ---- 7.4 macro block coding modes -----------------------------------------------------------
     const int mscheme = (int)br.read(3);
-    uint8_t alphabet[8];
+    uint8_t alphabet[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // a malformed scheme-0 list may leave entries unset
     if (mscheme == 0) {
       for (int mode = 0; mode < 8; mode++) alphabet[br.read(3)] = (uint8_t)mode;
     } else if (mscheme != 7) {
