@@ -21,7 +21,9 @@ def test_sequence_small(hip, w, h, fmt, content):
 
 
 def test_sequence_720p(hip):
-    rep = util.run_sequence(hip, 1280, 720, PF_420, nframes=6, content="mixed", seed=3, kf_interval=64)
+    """BASELINE.json config 2: one 720p stream, more than a key-frame interval of 64, every plane of
+    every frame compared."""
+    rep = util.run_sequence(hip, 1280, 720, PF_420, nframes=66, content="mixed", seed=3, kf_interval=64)
     assert not rep, rep[:3]
 
 

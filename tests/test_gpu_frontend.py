@@ -134,3 +134,44 @@ def test_contexts_on_concurrent_host_threads(hip):
         for rep in outs[i]:
             for fa, fb in zip(rep, serial[i]):
                 assert all(np.array_equal(a, b) for a, b in zip(fa, fb)), i
+
+
+def test_mutated_packets_through_the_device_path(hip):
+    """The same kind of damage tests/test_frontend_fuzz.py applies on the host, through the real
+    backend: whatever th_decode_packetin accepts must reconstruct without a device fault (vectors
+    pointing anywhere are clamped reads; slots and tiles are assigned by the library itself) and
+    the context must stay usable -- a clean key frame afterwards decodes bit-exactly."""
+    from theora_amd.decoder import Decoder
+    from theora_amd._lib import TheoraHipError
+    rng = np.random.default_rng(7)
+    st = streamgen.Stream(176, 144, 0, seed=77)
+    dec = Decoder(st.header_packets())
+    ost = oracle.State(176, 144, 0)
+    clean = [st.frame(0 if f % 3 == 0 else 1, density=0.7) for f in range(6)]
+    accepted = 0
+    for it in range(60):
+        pkt = bytearray(clean[it % 6][0])
+        kind = it % 3
+        if kind == 0:
+            for _ in range(3):
+                pkt[int(rng.integers(1, len(pkt)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            del pkt[int(rng.integers(2, len(pkt))):]
+        else:
+            a = int(rng.integers(1, len(pkt)))
+            pkt[a:a + 40] = bytes(rng.integers(0, 256, min(40, len(pkt) - a), dtype=np.uint8))
+        try:
+            rc, _ = dec.packetin(bytes(pkt))
+            accepted += rc == 0
+            dec.ycbcr_out()
+        except TheoraHipError:
+            pass
+    assert accepted > 10
+    pkt, truth = st.frame(0, density=0.9)          # a clean key frame resynchronises everything
+    assert dec.packetin(pkt)[0] == 0
+    args = st.oracle_inputs(truth, ost)
+    assert ost.decode_frame(**args) == 0
+    got = dec.ycbcr_out()
+    for pli in range(3):
+        assert np.array_equal(got[pli], ost.get_plane(oracle.FRAME_PREV, pli)[::-1])
+    dec.close()
