@@ -1,0 +1,166 @@
+/* dump_video_hip -- what the reference's examples/dump_video.c does (Ogg file -> decoded frames as
+ * YUV4MPEG2 or raw planes), written against this repository's library only: thip_ogg.h for the
+ * container (the reference uses libogg), theoradec_hip.h for th_decode_*.
+ *
+ *   cc -Iinclude examples/dump_video_hip.c -Ltheora_amd -ltheora_hip -o dump_video_hip
+ *   dump_video_hip [-o out.y4m] [-c|--crop] [-r|--raw] [-f|--fps-only] in.ogv
+ *
+ * Same observable behaviour as the reference tool for one Theora stream: the first logical stream
+ * whose first packet is a Theora identification header is decoded, other streams are skipped;
+ * the YUV4MPEG2 header line has the reference's form; a frame is written for every data packet,
+ * duplicate frames included; without --crop the full coded frame is written.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "thip_ogg.h"
+#include "theoradec_hip.h"
+
+static void write_frame(FILE *out, const th_info *ti, th_ycbcr_buffer yb, int crop, int raw) {
+  int x0 = 0, y0 = 0, xend = (int)ti->frame_width, yend = (int)ti->frame_height;
+  int pli, hdec = 0, vdec = 0;
+  if (crop) {
+    x0 = (int)ti->pic_x;
+    y0 = (int)ti->pic_y;
+    xend = x0 + (int)ti->pic_width;
+    yend = y0 + (int)ti->pic_height;
+  }
+  if (!raw) fputs("FRAME\n", out);
+  for (pli = 0; pli < 3; pli++) {
+    int y;
+    for (y = y0 >> vdec; y < ((yend + vdec) >> vdec); y++)
+      fwrite(yb[pli].data + (size_t)yb[pli].stride * (size_t)y + (x0 >> hdec), 1,
+             (size_t)(((xend + hdec) >> hdec) - (x0 >> hdec)), out);
+    hdec = !(ti->pixel_fmt & 1);
+    vdec = !(ti->pixel_fmt & 2);
+  }
+}
+
+int main(int argc, char **argv) {
+  const char *in = NULL, *outname = NULL;
+  int crop = 0, raw = 0, fps_only = 0, i;
+  for (i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "-o") && i + 1 < argc) outname = argv[++i];
+    else if (!strcmp(argv[i], "-c") || !strcmp(argv[i], "--crop")) crop = 1;
+    else if (!strcmp(argv[i], "-r") || !strcmp(argv[i], "--raw")) raw = 1;
+    else if (!strcmp(argv[i], "-f") || !strcmp(argv[i], "--fps-only")) fps_only = 1;
+    else if (argv[i][0] != '-') in = argv[i];
+    else {
+      fprintf(stderr, "usage: %s [-o out.y4m] [--crop] [--raw] [--fps-only] in.ogv\n", argv[0]);
+      return 1;
+    }
+  }
+  if (!in) {
+    fprintf(stderr, "usage: %s [-o out.y4m] [--crop] [--raw] [--fps-only] in.ogv\n", argv[0]);
+    return 1;
+  }
+  thip_ogg_reader *og = thip_ogg_open_file(in);
+  if (!og) {
+    fprintf(stderr, "cannot read %s\n", in);
+    return 1;
+  }
+  FILE *out = NULL;
+  if (!fps_only) {
+    out = outname ? fopen(outname, "wb") : stdout;
+    if (!out) {
+      fprintf(stderr, "cannot write %s\n", outname);
+      return 1;
+    }
+  }
+  th_info ti;
+  th_comment tc;
+  th_setup_info *ts = NULL;
+  th_dec_ctx *td = NULL;
+  th_info_init(&ti);
+  th_comment_init(&tc);
+  int have_stream = 0, headers_done = 0;
+  uint32_t theora_serial = 0;
+  long frames = 0;
+  ogg_packet op;
+  uint32_t serial;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  while (thip_ogg_next_packet(og, &op, &serial) == 1) {
+    if (!have_stream) {
+      /* the first Theora identification header picks the stream (dump_video.c:383-407) */
+      if (!op.b_o_s) continue;
+      th_info probe_i;
+      th_comment probe_c;
+      th_setup_info *probe_s = NULL;
+      th_info_init(&probe_i);
+      th_comment_init(&probe_c);
+      if (th_decode_headerin(&probe_i, &probe_c, &probe_s, &op) > 0) {
+        ti = probe_i;
+        tc = probe_c;
+        ts = probe_s;
+        theora_serial = serial;
+        have_stream = 1;
+      } else {
+        th_comment_clear(&probe_c);
+        th_info_clear(&probe_i);
+      }
+      continue;
+    }
+    if (serial != theora_serial) continue;
+    if (!headers_done) {
+      const int rc = th_decode_headerin(&ti, &tc, &ts, &op);
+      if (rc > 0) continue;   /* another header packet consumed */
+      if (rc < 0) {
+        fprintf(stderr, "error parsing Theora stream headers (%d)\n", rc);
+        return 1;
+      }
+      /* rc == 0: first data packet */
+      td = th_decode_alloc(&ti, ts);
+      th_setup_free(ts);
+      ts = NULL;
+      if (!td) {
+        fprintf(stderr, "th_decode_alloc failed\n");
+        return 1;
+      }
+      headers_done = 1;
+      if (out && !raw) {
+        static const char *const chroma[4] = {"420jpeg", NULL, "422jpeg", "444"};
+        int w = (int)ti.frame_width, h = (int)ti.frame_height;
+        if (crop) {
+          const int hdec = !(ti.pixel_fmt & 1), vdec = !(ti.pixel_fmt & 2);
+          if ((hdec && ((ti.pic_x & 1) || (ti.pic_width & 1))) || (vdec && ((ti.pic_y & 1) || (ti.pic_height & 1)))) {
+            fprintf(stderr, "cropped images with odd offsets/sizes and chroma subsampling cannot be output to YUV4MPEG2\n");
+            return 1;
+          }
+          w = (int)ti.pic_width;
+          h = (int)ti.pic_height;
+        }
+        fprintf(out, "YUV4MPEG2 C%s W%d H%d F%d:%d I%c A%d:%d\n", chroma[ti.pixel_fmt], w, h, (int)ti.fps_numerator,
+                (int)ti.fps_denominator, 'p', (int)ti.aspect_numerator, (int)ti.aspect_denominator);
+      }
+    }
+    {
+      int64_t gp = -1;
+      const int rc = th_decode_packetin(td, &op, &gp);
+      if (rc < 0) continue;   /* undecodable packet: no frame, like the reference */
+      frames++;
+      if (out) {
+        th_ycbcr_buffer yb;
+        if (th_decode_ycbcr_out(td, yb) < 0) return 1;
+        write_frame(out, &ti, yb, crop, raw);
+      }
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  {
+    int64_t bad = 0, gaps = 0;
+    const double el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    thip_ogg_stats(og, &bad, &gaps);
+    fprintf(stderr, "%ld frames in %.3f s (%.1f fps); %lld damaged pages, %lld gaps\n", frames, el, el > 0 ? frames / el : 0.0,
+            (long long)bad, (long long)gaps);
+  }
+  if (td) th_decode_free(td);
+  if (ts) th_setup_free(ts);
+  th_comment_clear(&tc);
+  th_info_clear(&ti);
+  thip_ogg_close(og);
+  if (out && out != stdout) fclose(out);
+  return have_stream ? 0 : 1;
+}

@@ -175,3 +175,54 @@ def test_mutated_packets_through_the_device_path(hip):
     for pli in range(3):
         assert np.array_equal(got[pli], ost.get_plane(oracle.FRAME_PREV, pli)[::-1])
     dec.close()
+
+
+def test_dump_video_example_on_an_ogg_file(hip, tmp_path):
+    """examples/dump_video_hip.c (the reference's dump_video, against this library only): an Ogg
+    file with a Theora stream multiplexed with another logical stream -> YUV4MPEG2, one FRAME per
+    data packet including duplicates, pictures bit-identical to the oracle's."""
+    import os
+    import subprocess
+    from tests import oggmux
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "dump_video_hip"
+    cc = subprocess.run(["gcc", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "dump_video_hip.c"),
+                         "-L" + os.path.join(root, "theora_amd"), "-ltheora_hip",
+                         "-Wl,-rpath," + os.path.join(root, "theora_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    w, h, fmt = 176, 144, 0
+    st = streamgen.Stream(w, h, fmt, seed=123)
+    ost = oracle.State(w, h, fmt)
+    video = oggmux.LogicalStream(0x5EED, max_segs=40)
+    other = oggmux.LogicalStream(0xA0D10, max_segs=9)
+    hdr = st.header_packets()
+    for k, p in enumerate(hdr):
+        video.add_packet(p, granulepos=0, flush=(k == 0 or k == len(hdr) - 1))
+    other.add_packet(b"\x01vorbis-not-really" + bytes(30), flush=True)
+    want = []
+    for f in range(9):
+        pkt, truth = st.frame(0 if f % 4 == 0 else 1, density=0.6)
+        video.add_packet(pkt, granulepos=f + 1)
+        other.add_packet(bytes([f]) * (50 + 37 * f))
+        if not truth["dup"]:
+            assert ost.decode_frame(**st.oracle_inputs(truth, ost)) == 0
+        want.append([ost.get_plane(oracle.FRAME_PREV, pli)[::-1].copy() for pli in range(3)])
+    ogv = tmp_path / "clip.ogv"
+    ogv.write_bytes(oggmux.interleave(video.finish(), other.finish()))
+    out = tmp_path / "clip.y4m"
+    r = subprocess.run([str(exe), "-o", str(out), str(ogv)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    data = out.read_bytes()
+    head, _, rest = data.partition(b"\n")
+    assert head == b"YUV4MPEG2 C420jpeg W176 H144 F30:1 Ip A1:1"        # the form of dump_video.c:507-510
+    fsz = 6 + w * h * 3 // 2
+    assert len(rest) == fsz * len(want)
+    for f, planes in enumerate(want):
+        rec = rest[f * fsz:(f + 1) * fsz]
+        assert rec[:6] == b"FRAME\n"
+        y = np.frombuffer(rec, np.uint8, w * h, 6).reshape(h, w)
+        cb = np.frombuffer(rec, np.uint8, w * h // 4, 6 + w * h).reshape(h // 2, w // 2)
+        cr = np.frombuffer(rec, np.uint8, w * h // 4, 6 + w * h * 5 // 4).reshape(h // 2, w // 2)
+        assert np.array_equal(y, planes[0]) and np.array_equal(cb, planes[1]) and np.array_equal(cr, planes[2]), f
+    assert "9 frames" in r.stderr

@@ -1,0 +1,124 @@
+"""The library's Ogg demultiplexer (include/thip_ogg.h, RFC 3533) against pages built by
+tests/oggmux.py: lacing, packets spanning pages, zero-length and 255-multiple packets,
+interleaved logical streams, flags and granule positions, and damage (bad checksum, lost page,
+garbage between pages, truncated file).  No GPU involved."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import oggmux
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def demux(data):
+    from theora_amd.decoder import ogg_packets
+    return ogg_packets(data)
+
+
+def test_header_and_binding_agree():
+    from theora_amd import _lib
+    text = open(os.path.join(ROOT, "include", "thip_ogg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(thip_ogg_[a-z0-9_]+)\s*\(", text)))
+    assert declared == sorted(n for n, _, _ in _lib.OGG_SYMBOLS)
+    L = _lib.load()
+    for name in declared:
+        assert hasattr(L, name)
+
+
+def test_crc_known_answer():
+    # an Ogg page from RFC 3533's own description cannot be quoted, but the CRC is the plain
+    # MSB-first CRC-32 with generator 0x04c11db7, zero initial value and no final xor; its
+    # value over "123456789" is the published check value of that parameter set (CRC-32/MPEG-2
+    # differs only in the initial value), computed here bit by bit as a cross-check of the table
+    def bitwise(data):
+        r = 0
+        for b in data:
+            r ^= b << 24
+            for _ in range(8):
+                r = ((r << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if r & 0x80000000 else (r << 1) & 0xFFFFFFFF
+        return r
+    for s in (b"", b"a", b"123456789", bytes(range(256)) * 3):
+        assert oggmux.crc32_ogg(s) == bitwise(s)
+
+
+@pytest.mark.parametrize("max_segs", [255, 7, 2, 1])
+def test_packets_round_trip(max_segs):
+    rng = np.random.default_rng(max_segs)
+    sizes = [0, 1, 254, 255, 256, 509, 510, 511, 3000, 70000, 17, 0, 255 * 4]
+    pkts = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in sizes]
+    ls = oggmux.LogicalStream(0x1234ABCD, max_segs=max_segs)
+    for i, p in enumerate(pkts):
+        ls.add_packet(p, granulepos=100 + i, flush=(i == 2))
+    data = b"".join(ls.finish())
+    got, (bad, gaps) = demux(data)
+    assert (bad, gaps) == (0, 0)
+    assert [g[1] for g in got] == pkts
+    assert all(g[0] == 0x1234ABCD for g in got)
+    assert [g[5] for g in got] == list(range(len(pkts)))
+    assert got[0][2] == 1 and got[-1][3] == 1                      # b_o_s on the first page's packets, e_o_s at the end
+    # the granule position travels with the last packet that ends on each page
+    gps = [g[4] for g in got]
+    assert gps[-1] == 100 + len(pkts) - 1
+    assert all(g == -1 or g == 100 + i for i, g in enumerate(gps))
+
+
+def test_interleaved_streams_keep_their_packets_apart():
+    rng = np.random.default_rng(5)
+    a = [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in rng.integers(1, 2000, 12)]
+    b = [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in rng.integers(1, 900, 20)]
+    la, lb = oggmux.LogicalStream(1, max_segs=3), oggmux.LogicalStream(2, max_segs=5)
+    for p in a:
+        la.add_packet(p)
+    for p in b:
+        lb.add_packet(p)
+    got, stats = demux(oggmux.interleave(la.finish(), lb.finish()))
+    assert stats == (0, 0)
+    assert [g[1] for g in got if g[0] == 1] == a
+    assert [g[1] for g in got if g[0] == 2] == b
+
+
+def test_damage_is_contained():
+    rng = np.random.default_rng(9)
+    pkts = [bytes(rng.integers(0, 256, 600, dtype=np.uint8)) for _ in range(10)]
+    ls = oggmux.LogicalStream(7, max_segs=3)       # 600 bytes = 3 segments: one packet per page
+    for p in pkts:
+        ls.add_packet(p)
+    pages = ls.finish()
+    assert len(pages) == 10
+    # (a) a flipped payload bit fails the checksum: that page's packet is gone, the rest survive
+    bad = bytearray(pages[4])
+    bad[40] ^= 0x10
+    got, (nbad, gaps) = demux(b"".join(pages[:4] + [bytes(bad)] + pages[5:]))
+    assert [g[1] for g in got] == pkts[:4] + pkts[5:] and nbad == 1 and gaps == 1
+    # (b) a page missing altogether is seen as a sequence gap
+    got, (nbad, gaps) = demux(b"".join(pages[:6] + pages[7:]))
+    assert [g[1] for g in got] == pkts[:6] + pkts[7:] and (nbad, gaps) == (0, 1)
+    # (c) garbage between pages (even garbage containing the capture pattern) is skipped
+    junk = b"\x00\xffOggS" + bytes(rng.integers(0, 256, 50, dtype=np.uint8))
+    got, (nbad, gaps) = demux(pages[0] + junk + b"".join(pages[1:]))
+    assert [g[1] for g in got] == pkts and gaps == 0 and nbad >= 1
+    # (d) a file cut in the middle of a page yields the complete pages before it
+    data = b"".join(pages)
+    got, _ = demux(data[: len(data) - len(pages[-1]) // 2])
+    assert [g[1] for g in got] == pkts[:9]
+    # (e) nothing at all / not Ogg at all
+    assert demux(b"")[0] == [] and demux(b"RIFF" + bytes(100))[0] == []
+
+
+def test_packet_spanning_a_lost_page_is_dropped_whole():
+    rng = np.random.default_rng(11)
+    big = bytes(rng.integers(0, 256, 255 * 7 + 10, dtype=np.uint8))       # spans 4 pages at 2 segments per page
+    small = [bytes(rng.integers(0, 256, 100, dtype=np.uint8)) for _ in range(3)]
+    ls = oggmux.LogicalStream(3, max_segs=2)
+    ls.add_packet(small[0], flush=True)
+    ls.add_packet(big, flush=True)
+    ls.add_packet(small[1], flush=True)
+    ls.add_packet(small[2])
+    pages = ls.finish()
+    assert len(pages) == 7
+    got, (nbad, gaps) = demux(b"".join(pages[:2] + pages[3:]))           # lose the second page of the big packet
+    assert [g[1] for g in got] == [small[0], small[1], small[2]] and gaps == 1

@@ -121,6 +121,15 @@ DEC_SYMBOLS = [
     ("th_granule_frame", _I64, [_P, _I64]),
 ]
 
+# include/thip_ogg.h
+OGG_SYMBOLS = [
+    ("thip_ogg_open_memory", _P, [_P, C.c_size_t]),
+    ("thip_ogg_open_file", _P, [C.c_char_p]),
+    ("thip_ogg_next_packet", _I, [_P, C.POINTER(OggPacket), C.POINTER(C.c_uint32)]),
+    ("thip_ogg_stats", None, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    ("thip_ogg_close", None, [_P]),
+]
+
 _lib = None
 
 
@@ -139,7 +148,7 @@ def load():
             "%s not found: build it with `python -m theora_amd.build` (hipcc, gfx950). "
             "theora_amd has no CPU fallback." % SO_PATH)
     L = C.CDLL(SO_PATH)
-    for name, restype, argtypes in SYMBOLS + DEC_SYMBOLS:
+    for name, restype, argtypes in SYMBOLS + DEC_SYMBOLS + OGG_SYMBOLS:
         fn = getattr(L, name)   # AttributeError if the library does not export it
         fn.restype = restype
         fn.argtypes = argtypes

@@ -99,3 +99,23 @@ class Decoder:
             self.close()
         except Exception:
             pass
+
+
+def ogg_packets(data):
+    """Packets of a physical Ogg bitstream held in `data` (bytes), in page order, through the
+    library's demultiplexer (include/thip_ogg.h): a list of (serialno, payload, b_o_s, e_o_s,
+    granulepos, packetno) and the (bad_pages, gaps) counters."""
+    L = _lib.load()
+    buf = (C.c_ubyte * max(len(data), 1)).from_buffer_copy(bytes(data) if len(data) else b"\0")
+    r = L.thip_ogg_open_memory(C.cast(buf, C.c_void_p), len(data))
+    if not r:
+        raise TheoraHipError("thip_ogg_open_memory failed")
+    out = []
+    op, serial = OggPacket(), C.c_uint32()
+    while L.thip_ogg_next_packet(r, C.byref(op), C.byref(serial)) == 1:
+        payload = C.string_at(op.packet, op.bytes) if op.bytes else b""
+        out.append((serial.value, payload, int(op.b_o_s), int(op.e_o_s), int(op.granulepos), int(op.packetno)))
+    bad, gaps = C.c_int64(), C.c_int64()
+    L.thip_ogg_stats(r, C.byref(bad), C.byref(gaps))
+    L.thip_ogg_close(r)
+    return out, (bad.value, gaps.value)
