@@ -122,3 +122,27 @@ def test_packet_spanning_a_lost_page_is_dropped_whole():
     assert len(pages) == 7
     got, (nbad, gaps) = demux(b"".join(pages[:2] + pages[3:]))           # lose the second page of the big packet
     assert [g[1] for g in got] == [small[0], small[1], small[2]] and gaps == 1
+
+
+def test_real_world_ogg_file_if_the_image_has_one():
+    """Pages written by the real libogg: a Vorbis sound that ships inside MathJax in this image
+    (not copied into the repository, so the test skips where the file is absent, e.g. on the GPU
+    box).  Every page checksum must verify, the first packet is the Vorbis identification header,
+    the last packet carries e_o_s and the final granule position."""
+    import glob
+    cands = glob.glob("/usr/local/lib/python3*/dist-packages/**/invalid_keypress.ogg", recursive=True)
+    if not cands:
+        pytest.skip("no libogg-made file in this image")
+    data = open(cands[0], "rb").read()
+    got, (bad, gaps) = demux(data)
+    assert (bad, gaps) == (0, 0) and len(got) > 3
+    assert got[0][1].startswith(b"\x01vorbis") and got[0][2] == 1
+    assert got[1][1].startswith(b"\x03vorbis") and got[2][1].startswith(b"\x05vorbis")
+    assert got[-1][3] == 1 and got[-1][4] > 0
+    assert len({g[0] for g in got}) == 1
+    # re-muxing the same packets with the test muxer and demuxing again gives the same packets
+    ls = oggmux.LogicalStream(got[0][0])
+    for g in got:
+        ls.add_packet(g[1], granulepos=g[4])
+    again, _ = demux(b"".join(ls.finish()))
+    assert [a[1] for a in again] == [g[1] for g in got]
