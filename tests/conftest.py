@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """A fresh checkout has no libtheora_hip.so (build artefacts are not in the history): build it
+    once per session, exactly as __graft_entry__.build() does.  Nothing is rebuilt if it exists."""
+    from theora_amd import build
+    if not os.path.exists(build.OUT):
+        build.build()
+    yield
+
+
 @pytest.fixture(scope="session")
 def hip():
     """The product library; on the GPU box it must load and a device must be visible."""

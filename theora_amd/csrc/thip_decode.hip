@@ -877,7 +877,9 @@ struct EvPair { hipEvent_t a, b; int kernel; };
 std::vector<EvPair> g_events;
 std::vector<hipEvent_t> g_pool;
 
-int ensure_lanes() {
+std::mutex g_lanes_mu;
+int ensure_lanes() {   // callable with or without g_mu held, from any host thread
+  std::lock_guard<std::mutex> lk(g_lanes_mu);
   if (g_nlanes) return 0;
   int n = getenv("THIP_LANES") ? atoi(getenv("THIP_LANES")) : 2;
   if (n < 1) n = 1;
