@@ -476,6 +476,122 @@ __device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane 
   THIP_TR(R.tr, 4);   // stores issued
 }
 
+// ---- k_recon in three parts, so that the residual can be computed by ALL lanes of the wave ------
+// (recon_tail above is the same thing in one piece; the fused variant still uses it.)
+__device__ __forceinline__ void recon_issue(const ReconPlane &R, const ReconLane &L, PredWin &Q, bool &inter,
+                                            const uint8_t *&ref) {
+  const int refi = L.coded ? (int)((L.flags >> THIP_INFO_REFI_SHIFT) & 3u) : THIP_FRAME_PREV;
+  inter = refi != THIP_FRAME_SELF && !(R.debug & 2);
+  ref = refi == THIP_FRAME_PREV ? R.prev : R.gold;
+  Q.border = false;
+  if (inter) pred_issue(Q, ref, R.stride, R.nh * 8, R.nv * 8, L.x0, L.y0, L.coded ? L.flags : 0u, R.qpx, R.qpy);
+  R.coded_map[(L.y0 >> 3) * R.nh + (L.x0 >> 3)] = L.coded ? 1 : 0;
+}
+
+__device__ __forceinline__ void recon_finish(const ReconPlane &R, const ReconLane &L, const PredWin &Q, bool inter,
+                                             const uint32_t Y[32]) {
+  uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
+  uint2 pred[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
+  if (inter) pred_finish(Q, R.nh * 8, pred);
+  if (!(R.debug & 4)) {
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      store_row8(dst + (ptrdiff_t)r * R.stride,
+                 pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]),
+                              pred[r]));
+  }
+}
+
+// Residual of the lanes that own coefficients, one block per lane (the whole wave executes the
+// 16 one-dimensional transforms whether 1 lane or 64 need them).
+__device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const ReconLane &L, uint32_t Y[32]) {
+  uint32_t P[32];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const uint4 w = lds_coef[q * 64];
+    P[q * 4 + 0] = w.x;
+    P[q * 4 + 1] = w.y;
+    P[q * 4 + 2] = w.z;
+    P[q * 4 + 3] = w.w;
+  }
+  const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
+  pk_mask_by_last_zzi(P, last_zzi);
+  const bool all_zz10 = !__any(L.has_coeff && last_zzi > 10);
+  pk_idct8x8(P, Y, all_zz10);
+}
+
+// The same residuals when at most 64/LPB lanes of the wave own coefficients (the usual case
+// outside synthetic worst cases: SURVEY section 6 has 80 % of the coded blocks DC-only): LPB lanes
+// (4 or 2) share a block -- lane LPB*g+j takes row pairs j*NP..j*NP+NP-1 (NP = 4/LPB) of the
+// g-th owner for the row pass and the same column pairs for the column pass, the transpose
+// between goes through the wave's LDS area (free once the coefficients are in registers) -- so
+// the wave executes 2*NP packed 1-D transforms instead of 8.  Bit-exact with residual_per_lane:
+// the same operations on the same values.  Must be called by all 64 lanes.
+// lds = the wave's 8 KB area as dwords; meta = 64/LPB dwords of LDS.
+template <int LPB>
+__device__ __forceinline__ void residual_shared(uint32_t *lds, uint32_t *meta, int lane, const ReconLane &L,
+                                                uint32_t prefix, uint32_t Y[32]) {
+  constexpr int NP = 4 / LPB;                        // row pairs (and column pairs) per lane
+  const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
+  if (L.has_coeff) meta[prefix] = (uint32_t)lane | (uint32_t)last_zzi << 8;   // rank -> owner lane
+  const int g = lane / LPB, j = lane % LPB;
+  const uint32_t m = meta[g];                       // (garbage for g >= number of owners: results unused)
+  const int src = (int)(m & 63u), lz = (int)((m >> 8) & 0x7Fu);
+  const bool c3 = lz <= 3, c10 = lz <= 10;
+  const uint4 *c4 = reinterpret_cast<const uint4 *>(lds);
+  pk16 Rr[NP][8];
+#pragma unroll
+  for (int n = 0; n < NP; n++) {
+    const int rp = j * NP + n;                       // row pair: rows 2rp, 2rp+1
+    const uint4 w0 = c4[(2 * rp) * 64 + src], w1 = c4[(2 * rp + 1) * 64 + src];
+    uint32_t P8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};   // {x[2rp][c], x[2rp+1][c]}, c = 0..7
+    // what the variant selected by last_zzi does not read is zero (pk_mask_by_last_zzi)
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const uint32_t m10 = ((2 * rp + c <= 3) ? 0x0000FFFFu : 0u) | ((2 * rp + 1 + c <= 3) ? 0xFFFF0000u : 0u);
+      const uint32_t m3 = ((rp == 0 && c <= 1) ? 0x0000FFFFu : 0u) | ((rp == 0 && c == 0) ? 0xFFFF0000u : 0u);
+      Rr[n][c] = as_pk(P8[c] & (c3 ? m3 : (c10 ? m10 : 0xFFFFFFFFu)));
+    }
+    pk_idct8(Rr[n][0], Rr[n][1], Rr[n][2], Rr[n][3], Rr[n][4], Rr[n][5], Rr[n][6], Rr[n][7]);
+  }
+  // exchange inside the group: every lane publishes its row pairs, collects its column pairs
+  uint32_t *xch = lds;                       // NP*8 dwords per lane
+  uint32_t *res = lds + 64 * NP * 8;         // 32 dwords per owner
+#pragma unroll
+  for (int n = 0; n < NP; n++) {
+    uint4 *x4 = reinterpret_cast<uint4 *>(xch + (lane * NP + n) * 8);
+    x4[0] = make_uint4(as_u32(Rr[n][0]), as_u32(Rr[n][1]), as_u32(Rr[n][2]), as_u32(Rr[n][3]));
+    x4[1] = make_uint4(as_u32(Rr[n][4]), as_u32(Rr[n][5]), as_u32(Rr[n][6]), as_u32(Rr[n][7]));
+  }
+#pragma unroll
+  for (int n = 0; n < NP; n++) {
+    const int cp = j * NP + n;                       // column pair: columns 2cp, 2cp+1
+    pk16 Q[8];
+#pragma unroll
+    for (int rp = 0; rp < 4; rp++) {                 // row pair rp lives at slot (g*LPB*NP + rp) = g*4 + rp
+      const uint2 ab = *reinterpret_cast<const uint2 *>(xch + (g * 4 + rp) * 8 + 2 * cp);
+      Q[2 * rp] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x05040100u));
+      Q[2 * rp + 1] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x07060302u));
+    }
+    pk_idct8(Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], Q[6], Q[7]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) res[g * 32 + r * 4 + cp] = as_u32(pk_descale(Q[r]));   // Y[r*4+k] layout of the owner
+  }
+  if (L.has_coeff) {
+    const uint4 *y4 = reinterpret_cast<const uint4 *>(res + prefix * 32);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint4 w = y4[q];
+      Y[q * 4 + 0] = w.x;
+      Y[q * 4 + 1] = w.y;
+      Y[q * 4 + 2] = w.z;
+      Y[q * 4 + 3] = w.w;
+    }
+  }
+}
+
 // A wave's life is exactly two memory round trips: (1) its 64 command words and the tile's
 // first slot number, (2) coefficients and predictor windows, all issued before anything
 // waits.  Everything read from the kernel arguments is wave-uniform and is forced into
@@ -574,6 +690,11 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   __shared__ uint4 s_coef[THIP_RECON_WG_WAVES * 8 * 64 + THIP_RECON_LDS_PAD / 16];   // [wave][piece][lane]: 8 KB per wave, wave-private
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   uint4 *const lds_wave = s_coef + wave * 512;
+  __shared__ uint32_t s_meta[THIP_RECON_WG_WAVES * 32];
+  PredWin Q;
+  bool inter = false;
+  const uint8_t *ref = nullptr;
+  uint32_t Y[32];
   if (mask != 0 && !(debug & 9)) {
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -585,10 +706,28 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
     for (int q = 0; q < 8; q++)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
                                        (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
-    if (valid) recon_tail<true>(R, L, lds_wave + lane);   // (!valid: past the ragged edge of the plane)
+    if (valid) recon_issue(R, L, Q, inter, ref);   // (!valid: past the ragged edge of the plane)
+    THIP_TR(R.tr, 2);
+    // ---- residual: few owners -> four lanes per block, else one lane per block ---------------
+    const int nown = __popcll(mask);
+    if (nown <= 16 && !(debug & 32))
+      residual_shared<4>(reinterpret_cast<uint32_t *>(lds_wave), s_meta + wave * 32, lane, L, prefix, Y);
+    else if (nown <= 32 && !(debug & 32))
+      residual_shared<2>(reinterpret_cast<uint32_t *>(lds_wave), s_meta + wave * 32, lane, L, prefix, Y);
+    else
+      residual_per_lane(lds_wave + lane, L, Y);
+    THIP_TR(R.tr, 3);
   } else {
-    if (valid) recon_tail<false>(R, L, lds_wave);
+    if (valid) recon_issue(R, L, Q, inter, ref);
   }
+  if (!valid) return;
+  if (!L.has_coeff || mask == 0 || (debug & 9)) {   // DC-only: the pre-rounded value; uncoded: zero residual
+    const uint32_t fill = L.dc_only ? L.dcp : 0u;
+#pragma unroll
+    for (int i = 0; i < 32; i++) Y[i] = fill;
+  }
+  recon_finish(R, L, Q, inter, Y);
+  THIP_TR(R.tr, 4);
 }
 
 // ---------------------------------------------------------------------------------------
