@@ -20,6 +20,18 @@ def test_sequence_small(hip, w, h, fmt, content):
     assert not rep, rep[:3]
 
 
+@pytest.mark.parametrize("p_dc_only", [0.97, 0.75, 0.5, 0.0])
+def test_lane_shared_transform_boundaries(hip, p_dc_only):
+    """k_recon picks 4, 2 or 1 lanes per block from the number of coefficient-owning lanes in a tile
+    (<=16, <=32, more).  Fully coded frames whose DC-only share puts that number around 2, 16, 32 and
+    at 64, with blocks whose last_zzi claims fewer coefficients than are present (the masking each
+    path must apply), decode bit-exactly."""
+    content = dict(p_coded=1.0, intra=0.2, golden=0.1, zeromv=0.2, halfpel=0.4, p_dc_only=p_dc_only, p_zz10=0.4 * (1 - p_dc_only),
+                   amp=200, edge_mv=0.2, extreme=0.1)
+    rep = util.run_sequence(hip, 256, 96, PF_420, nframes=8, content=content, seed=int(p_dc_only * 100), kf_interval=4)
+    assert not rep, rep[:3]
+
+
 def test_sequence_720p(hip):
     """BASELINE.json config 2: one 720p stream, more than a key-frame interval of 64, every plane of
     every frame compared."""
