@@ -200,6 +200,58 @@ struct CellPix {
 struct __attribute__((aligned(4))) Pix8 {
   uint32_t x, y;
 };
+
+// ---- the filter on the packed image: two pixels per register -------------------------------------
+// f = P2 - P5 + 3*(P4 - P3), R = (f+4)>>3, lflim(R), P3 += ., P4 -= . (state.c:1002-1031) in
+// 16-bit lanes: |f| <= 1020, every intermediate fits; the final clamp is v_sat_pk_u8_i16.
+__device__ __forceinline__ pk16 pk_lf_delta(pk16 p2, pk16 p3, pk16 p4, pk16 p5, int L2) {
+  const pk16 d = p4 - p3;
+  const pk16 f = p2 - p5 + d + d + d;
+  const pk16 R = (f + (short)4) >> 3;
+  const pk16 a = __builtin_elementwise_max(R, -R);
+  const pk16 l2 = {(short)L2, (short)L2};
+  const pk16 z = {0, 0};
+  const pk16 m = __builtin_elementwise_min(a, __builtin_elementwise_max(l2 - a, z));
+  const pk16 s = R >> 15;                      // 0 or -1 per half
+  return as_pk(as_u32(m) ^ as_u32(s)) - s;     // R < 0 ? -m : m
+}
+// horizontal edge y = 4 of the cell, columns 0..3 (half 0: the lo dwords) or 4..7 (half 1)
+__device__ __forceinline__ void lf_horz_pk(CellPix &C, int half, int L2) {
+  uint32_t *w = half ? C.hi : C.lo;
+  const pk16 d01 = pk_lf_delta(pk_bytes01(w[2]), pk_bytes01(w[3]), pk_bytes01(w[4]), pk_bytes01(w[5]), L2);
+  const pk16 d23 = pk_lf_delta(pk_bytes23(w[2]), pk_bytes23(w[3]), pk_bytes23(w[4]), pk_bytes23(w[5]), L2);
+  const uint32_t n3 = sat_pk_u8(pk_bytes01(w[3]) + d01) | sat_pk_u8(pk_bytes23(w[3]) + d23) << 16;
+  const uint32_t n4 = sat_pk_u8(pk_bytes01(w[4]) - d01) | sat_pk_u8(pk_bytes23(w[4]) - d23) << 16;
+  w[3] = n3;
+  w[4] = n4;
+}
+// vertical edge x = 4 of the cell, rows r0..r0+3: columns 2,3 are bytes 2,3 of lo, columns 4,5
+// bytes 0,1 of hi; two rows per register
+__device__ __forceinline__ void lf_vert_pk(CellPix &C, int r0, int L2) {
+#pragma unroll
+  for (int r = r0; r < r0 + 4; r += 2) {
+    const pk16 p2 = as_pk(__builtin_amdgcn_perm(C.lo[r + 1], C.lo[r], 0x0c060c02u));
+    const pk16 p3 = as_pk(__builtin_amdgcn_perm(C.lo[r + 1], C.lo[r], 0x0c070c03u));
+    const pk16 p4 = as_pk(__builtin_amdgcn_perm(C.hi[r + 1], C.hi[r], 0x0c040c00u));
+    const pk16 p5 = as_pk(__builtin_amdgcn_perm(C.hi[r + 1], C.hi[r], 0x0c050c01u));
+    const pk16 d = pk_lf_delta(p2, p3, p4, p5, L2);
+    const uint32_t n3 = sat_pk_u8(p3 + d), n4 = sat_pk_u8(p4 - d);   // byte 0: row r, byte 1: row r+1
+    C.lo[r] = __builtin_amdgcn_perm(n3, C.lo[r], 0x04020100u);       // byte 3 <- n3.byte0
+    C.lo[r + 1] = __builtin_amdgcn_perm(n3, C.lo[r + 1], 0x05020100u);
+    C.hi[r] = __builtin_amdgcn_perm(n4, C.hi[r], 0x03020104u);       // byte 0 <- n4.byte0
+    C.hi[r + 1] = __builtin_amdgcn_perm(n4, C.hi[r + 1], 0x03020105u);
+  }
+}
+__device__ __forceinline__ void lf_cell_apply_pk(CellPix &C, uint32_t t, int L2) {
+  if (__any(t & 1u)) { if (t & 1u) lf_vert_pk(C, 0, L2); }
+  if (__any(t & 2u)) { if (t & 2u) lf_horz_pk(C, 0, L2); }
+  if (__any(t & 4u)) { if (t & 4u) lf_vert_pk(C, 0, L2); }
+  if (__any(t & 8u)) { if (t & 8u) lf_horz_pk(C, 1, L2); }
+  if (__any(t & 16u)) { if (t & 16u) lf_horz_pk(C, 0, L2); }
+  if (__any(t & 32u)) { if (t & 32u) lf_vert_pk(C, 4, L2); }
+  if (__any(t & 64u)) { if (t & 64u) lf_vert_pk(C, 4, L2); }
+  if (__any(t & 128u)) { if (t & 128u) lf_horz_pk(C, 1, L2); }
+}
 __device__ __forceinline__ void lf_cell_load(CellPix &C, const uint8_t *plane, int stride, int nh, int nv, int k,
                                              int m) {
   const int W = nh * 8, H = nv * 8;
@@ -229,32 +281,28 @@ __device__ __forceinline__ void lf_cell_flags(const uint8_t *coded, int nh, int 
   c = (k >= 1) & (m <= nv - 1) & (fc != 0);
   d = (k <= nh - 1) & (m <= nv - 1) & (fd != 0);
 }
-__device__ __forceinline__ void lf_cell_finish(const CellPix &C, uint8_t *plane, int stride, int nh, int nv, int k,
+__device__ __forceinline__ void lf_cell_finish(const CellPix &Cin, uint8_t *plane, int stride, int nh, int nv, int k,
                                                int m, uint32_t t, int L2) {
   if (!t) return;
   const bool lo_ok = k >= 1, hi_ok = k <= nh - 1;
   uint8_t *base = plane + (ptrdiff_t)(8 * m - 4) * stride + (8 * k - 4);
   const int H = nv * 8;
-  int P[64];
-#pragma unroll
-  for (int r = 0; r < 8; r++) unpack_row(P + r * 8, C.lo[r], C.hi[r]);
-  lf_cell_apply(P, t, L2);
+  CellPix C = Cin;
+  lf_cell_apply_pk(C, t, L2);
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     const int y = 8 * m - 4 + r;
     if (y >= 0 && y < H) {
       uint8_t *p = base + (ptrdiff_t)r * stride;
-      const uint32_t lo = pack4(P[r * 8 + 0], P[r * 8 + 1], P[r * 8 + 2], P[r * 8 + 3]);
-      const uint32_t hi = pack4(P[r * 8 + 4], P[r * 8 + 5], P[r * 8 + 6], P[r * 8 + 7]);
       if (lo_ok & hi_ok) {
         Pix8 o;
-        o.x = lo;
-        o.y = hi;
+        o.x = C.lo[r];
+        o.y = C.hi[r];
         *reinterpret_cast<Pix8 *>(p) = o;
       } else if (lo_ok) {
-        *reinterpret_cast<uint32_t *>(p) = lo;
+        *reinterpret_cast<uint32_t *>(p) = C.lo[r];
       } else {
-        *reinterpret_cast<uint32_t *>(p + 4) = hi;
+        *reinterpret_cast<uint32_t *>(p + 4) = C.hi[r];
       }
     }
   }
