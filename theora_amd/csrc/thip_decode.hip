@@ -480,6 +480,7 @@ __device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane 
   uint32_t Y[32];
   if (IDCT) {
     uint32_t P[32];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the caller's LDS-DMA loads have landed (see k_recon)
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const uint4 w = lds_coef[q * 64];
@@ -578,23 +579,40 @@ __device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const R
 // the wave executes 2*NP packed 1-D transforms instead of 8.  Bit-exact with residual_per_lane:
 // the same operations on the same values.  Must be called by all 64 lanes.
 // lds = the wave's 8 KB area as dwords; meta = 64/LPB dwords of LDS.
+// The g-th owner's coefficients sit in slot slot0+g (slots are numbered in lane order inside a
+// tile), so the sharing lanes fetch their own row pairs straight from the slot -- 32*NP bytes per
+// lane instead of the whole wave staging 8 KB of which a fraction is used.
 template <int LPB>
-__device__ __forceinline__ void residual_shared(uint32_t *lds, uint32_t *meta, int lane, const ReconLane &L,
-                                                uint32_t prefix, uint32_t Y[32]) {
+__device__ __forceinline__ void residual_shared_load(const int4 *coeffs, uint32_t slot0, int nown, int lane,
+                                                     int4 W[4 / LPB][2]) {
+  constexpr int NP = 4 / LPB;
+  const int g = min(lane / LPB, nown - 1), j = lane % LPB;   // surplus groups re-read the last owner's slot
+  const uint32_t slot = slot0 + (uint32_t)g;
+  const int4 *tp = coeffs + ((size_t)(slot >> 6) * 512 + (slot & 63));
+#pragma unroll
+  for (int n = 0; n < NP; n++) {
+    const int rp = j * NP + n;
+    W[n][0] = tp[(2 * rp) * 64];
+    W[n][1] = tp[(2 * rp + 1) * 64];
+  }
+}
+
+template <int LPB>
+__device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32_t *lds, uint32_t *meta, int lane,
+                                                const ReconLane &L, uint32_t prefix, uint32_t Y[32]) {
   constexpr int NP = 4 / LPB;                        // row pairs (and column pairs) per lane
   const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
-  if (L.has_coeff) meta[prefix] = (uint32_t)lane | (uint32_t)last_zzi << 8;   // rank -> owner lane
+  if (L.has_coeff) meta[prefix] = (uint32_t)last_zzi;   // rank -> last_zzi of that owner
   const int g = lane / LPB, j = lane % LPB;
-  const uint32_t m = meta[g];                       // (garbage for g >= number of owners: results unused)
-  const int src = (int)(m & 63u), lz = (int)((m >> 8) & 0x7Fu);
+  const int lz = (int)(meta[g] & 0x7Fu);            // (garbage for g >= number of owners: results unused)
   const bool c3 = lz <= 3, c10 = lz <= 10;
-  const uint4 *c4 = reinterpret_cast<const uint4 *>(lds);
   pk16 Rr[NP][8];
 #pragma unroll
   for (int n = 0; n < NP; n++) {
     const int rp = j * NP + n;                       // row pair: rows 2rp, 2rp+1
-    const uint4 w0 = c4[(2 * rp) * 64 + src], w1 = c4[(2 * rp + 1) * 64 + src];
-    uint32_t P8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};   // {x[2rp][c], x[2rp+1][c]}, c = 0..7
+    const int4 w0 = W[n][0], w1 = W[n][1];
+    const uint32_t P8[8] = {(uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w,
+                            (uint32_t)w1.x, (uint32_t)w1.y, (uint32_t)w1.z, (uint32_t)w1.w};   // {x[2rp][c], x[2rp+1][c]}, c = 0..7
     // what the variant selected by last_zzi does not read is zero (pk_mask_by_last_zzi)
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -743,33 +761,50 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   bool inter = false;
   const uint8_t *ref = nullptr;
   uint32_t Y[32];
-  if (mask != 0 && !(debug & 9)) {
-    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
-    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
-    // global -> LDS directly (LDS address = wave-uniform base + lane*16): no VGPRs are tied up
-    // and nothing can make the compiler touch the data before the predictor loads are out
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
-                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
+  const int nown = __popcll(mask);
+  const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  uint32_t *const lds_dw = reinterpret_cast<uint32_t *>(lds_wave);
+  if (nown == 0 || (debug & 9)) {
     if (valid) recon_issue(R, L, Q, inter, ref);   // (!valid: past the ragged edge of the plane)
+  } else if (nown <= 16 && !(debug & 32)) {
+    // ---- few owners: four lanes per block, pieces straight from the slots ------------------------
+    int4 W[1][2];
+    residual_shared_load<4>(coeffs_p, slot0, nown, lane, W);
+    if (valid) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
-    // ---- residual: few owners -> four lanes per block, else one lane per block ---------------
-    const int nown = __popcll(mask);
-    if (nown <= 16 && !(debug & 32))
-      residual_shared<4>(reinterpret_cast<uint32_t *>(lds_wave), s_meta + wave * 32, lane, L, prefix, Y);
-    else if (nown <= 32 && !(debug & 32))
-      residual_shared<2>(reinterpret_cast<uint32_t *>(lds_wave), s_meta + wave * 32, lane, L, prefix, Y);
-    else
-      residual_per_lane(lds_wave + lane, L, Y);
+    residual_shared<4>(W, lds_dw, s_meta + wave * 32, lane, L, prefix, Y);
+    THIP_TR(R.tr, 3);
+  } else if (nown <= 32 && !(debug & 32)) {
+    int4 W[2][2];
+    residual_shared_load<2>(coeffs_p, slot0, nown, lane, W);
+    if (valid) recon_issue(R, L, Q, inter, ref);
+    THIP_TR(R.tr, 2);
+    residual_shared<2>(W, lds_dw, s_meta + wave * 32, lane, L, prefix, Y);
     THIP_TR(R.tr, 3);
   } else {
+    // ---- many owners: one lane per block.  Coefficients go global -> LDS directly (LDS address
+    //      = wave-uniform base + lane*16): no VGPRs are tied up and nothing can make the compiler
+    //      touch the data before the predictor loads are out.  Every lane loads (lanes without
+    //      coefficients re-read the tile's first slot: same cache lines). ---------------------------
+    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
+    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
+    if (!(debug & 64)) {   // (ablation: transforms on whatever the LDS holds)
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
+                                         (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
+    }
     if (valid) recon_issue(R, L, Q, inter, ref);
+    THIP_TR(R.tr, 2);
+    // The LDS-DMA loads above are counted by vmcnt; the compiler's own wait before the LDS reads
+    // below is not something to rely on (it vanished when the loads moved into a conditional
+    // block and the reads returned stale LDS), so it is stated.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    residual_per_lane(lds_wave + lane, L, Y);
+    THIP_TR(R.tr, 3);
   }
   if (!valid) return;
-  if (!L.has_coeff || mask == 0 || (debug & 9)) {   // DC-only: the pre-rounded value; uncoded: zero residual
+  if (!L.has_coeff || (debug & 9)) {   // DC-only: the pre-rounded value; uncoded: zero residual
     const uint32_t fill = L.dc_only ? L.dcp : 0u;
 #pragma unroll
     for (int i = 0; i < 32; i++) Y[i] = fill;
