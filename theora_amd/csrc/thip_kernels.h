@@ -1,0 +1,1017 @@
+// thip_kernels.h -- device side of the frame-scope path: the geometry constants shared with the
+// host, the per-stream kernel-argument tables, and the kernels k_recon, k_recon_lf, k_lf_seam,
+// k_loopfilter, k_loopfilter_plane.  Included by thip_decode.hip only (which holds the host
+// side and the C ABI); see the header comment there for the overall picture.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/theora_hip.h"
+#include "thip_device.h"
+
+using namespace thip;
+
+// ---------------------------------------------------------------------------------------
+// geometry shared by host and device
+// ---------------------------------------------------------------------------------------
+// (row, col) of the h-th block on the 4x4 Hilbert curve of a super block, the order of
+// coded_fragis inside a super block (state.c:134-139), two bits per entry.
+constexpr uint32_t kHilbRow = 0u | 0u << 2 | 1u << 4 | 1u << 6 | 2u << 8 | 3u << 10 | 3u << 12 | 2u << 14 |
+                              2u << 16 | 3u << 18 | 3u << 20 | 2u << 22 | 1u << 24 | 1u << 26 | 0u << 28 | 0u << 30;
+constexpr uint32_t kHilbCol = 0u | 1u << 2 | 1u << 4 | 0u << 6 | 0u << 8 | 0u << 10 | 1u << 12 | 1u << 14 |
+                              2u << 16 | 2u << 18 | 3u << 20 | 3u << 22 | 3u << 24 | 2u << 26 | 2u << 28 | 3u << 30;
+// inverse: Hilbert index of (row, col), four bits per entry, entry = row*4+col
+constexpr uint64_t kHilbInv = 0ull | 1ull << 4 | 14ull << 8 | 15ull << 12 |      // row 0
+                              3ull << 16 | 2ull << 20 | 13ull << 24 | 12ull << 28 |   // row 1
+                              4ull << 32 | 7ull << 36 | 8ull << 40 | 11ull << 44 |    // row 2
+                              5ull << 48 | 6ull << 52 | 9ull << 56 | 10ull << 60;     // row 3
+
+__host__ __device__ inline int hilb_row(int h) { return (int)((kHilbRow >> (2 * h)) & 3u); }
+__host__ __device__ inline int hilb_col(int h) { return (int)((kHilbCol >> (2 * h)) & 3u); }
+__host__ __device__ inline int hilb_inv(int r, int c) { return (int)((kHilbInv >> (4 * (r * 4 + c))) & 15ull); }
+
+struct PlaneK {
+  int nh, nv;        // fragments across / down
+  int stride;        // device pitch
+  int off;           // byte offset of the plane in a frame
+  int tiles_x;       // tiles across
+  int tile_off;      // index of the plane's first tile
+  int fro;           // raster index of the plane's first fragment
+  float rcp_cx;      // 1/(nh+1)
+  int nseg, seglen;  // a tile row is cut into nseg segments of seglen tiles (k_recon_lf)
+  int seam_rows;     // cell rows filtered by k_lf_seam: m = 0,4,8,... and m = nv
+};
+
+struct StreamK {
+  const uint2 *info;
+  const int4 *coeffs;
+  const uint32_t *tile_slot0;
+  uint8_t *self;
+  const uint8_t *prev;
+  const uint8_t *gold;
+  uint8_t *coded_map;     // 1 byte per fragment, raster order: written by k_recon, read by k_loopfilter
+  int flimit2;            // 2*flimit
+  int qpx, qpy;           // chroma axis decimated (quarter-pel chroma vectors)
+  int tile_end[3];        // cumulative tile counts per plane (k_recon: one wave per tile)
+  int cell_end[3];        // cumulative filter-cell counts per plane, each plane padded to 64 (k_loopfilter)
+  int lf_y0[3], lf_y1[3]; // fragment-row range whose filter operations are applied
+  int debug;              // ablation switches for profiling (THIP_DEBUG env), 0 in production
+  // fused reconstruction + loop filter (k_recon_lf / k_lf_seam)
+  int seg_end[3];         // cumulative workgroup counts per plane: one workgroup per (tile row, segment)
+  int seam_end[3];        // cumulative seam-cell counts per plane, each plane padded to 64
+  PlaneK pl[3];
+};
+
+struct BatchK {
+  StreamK s[THIP_MAX_BATCH];
+};
+
+// ---------------------------------------------------------------------------------------
+// in-loop filter on a register image of one 8x8 "cell"
+// ---------------------------------------------------------------------------------------
+// The reference filters, for every coded fragment in raster order, its left edge, its
+// edge towards the previous fragment row, then its right / next-row edge when that
+// neighbour is uncoded (state.c:1083-1104).  Order only matters where a vertical-edge
+// filter and a horizontal-edge filter touch the same pixels: the 4x4 patch centred on a
+// fragment corner.  The 8x8 "cell" centred on corner (k,m) -- pixels
+// [8k-4,8k+4)x[8m-4,8m+4) -- contains, completely, four half-edge operations:
+//   Vlo  vertical edge x=8k, fragment row m-1, its rows 4..7   (cell rows 0..3)
+//   Vhi  vertical edge x=8k, fragment row m,   its rows 0..3   (cell rows 4..7)
+//   Hl   horizontal edge y=8m, fragment column k-1, columns 4..7 (cell cols 0..3)
+//   Hr   horizontal edge y=8m, fragment column k,   columns 0..3 (cell cols 4..7)
+// and nothing else reads or writes those pixels, so cells are independent and tile the
+// plane.  Inside a cell the operations run in the reference's order, which depends on which
+// of the four fragments around the corner are coded (a=(k-1,m-1) b=(k,m-1) c=(k-1,m)
+// d=(k,m)): raster time of an op = (row, column, slot) of the fragment that triggers it,
+// slots left=0, previous-row=1, right=2, next-row=3.  Sorted, the eight candidates are
+//   T1 Vlo by a (!b)   T2 Hl by a (!c)   T3 Vlo by b   T4 Hr by b (!d)
+//   T5 Hl by c         T6 Vhi by c (!d)  T7 Vhi by d   T8 Hr by d
+__device__ __forceinline__ void lf_vert(int P[64], int r0, int L2) {
+#pragma unroll
+  for (int r = r0; r < r0 + 4; r++) {
+    int f = P[r * 8 + 2] - P[r * 8 + 5] + 3 * (P[r * 8 + 4] - P[r * 8 + 3]);  // state.c:1007
+    f = lflim((f + 4) >> 3, L2);
+    P[r * 8 + 3] = clamp255(P[r * 8 + 3] + f);
+    P[r * 8 + 4] = clamp255(P[r * 8 + 4] - f);
+  }
+}
+__device__ __forceinline__ void lf_horz(int P[64], int c0, int L2) {
+#pragma unroll
+  for (int c = c0; c < c0 + 4; c++) {
+    int f = P[2 * 8 + c] - P[5 * 8 + c] + 3 * (P[4 * 8 + c] - P[3 * 8 + c]);  // state.c:1023
+    f = lflim((f + 4) >> 3, L2);
+    P[3 * 8 + c] = clamp255(P[3 * 8 + c] + f);
+    P[4 * 8 + c] = clamp255(P[4 * 8 + c] - f);
+  }
+}
+
+// Which of T1..T8 apply to cell (k,m) of a plane with nh x nv fragments, given the coded
+// flags around the corner and the fragment-row range [fy0,fy1) being filtered.  Bit i-1 of
+// the result = Ti.
+__device__ __forceinline__ uint32_t lf_cell_ops(int k, int m, int nh, int nv, bool a, bool b, bool c, bool d,
+                                                int fy0, int fy1) {
+  const bool kin = k >= 1 && k <= nh - 1;   // a vertical edge exists at x=8k
+  const bool min_ = m >= 1 && m <= nv - 1;  // a horizontal edge exists at y=8m
+  a = a && k >= 1 && m >= 1;
+  b = b && k <= nh - 1 && m >= 1;
+  c = c && k >= 1 && m <= nv - 1;
+  d = d && k <= nh - 1 && m <= nv - 1;
+  const bool rlo = (m - 1) >= fy0 && (m - 1) < fy1;  // ops triggered from fragment row m-1
+  const bool rhi = m >= fy0 && m < fy1;              // ops triggered from fragment row m
+  uint32_t t = 0;
+  t |= (kin && a && !b && rlo) ? 1u : 0u;
+  t |= (min_ && k >= 1 && a && !c && rlo) ? 2u : 0u;
+  t |= (kin && b && rlo) ? 4u : 0u;
+  t |= (min_ && k <= nh - 1 && b && !d && rlo) ? 8u : 0u;
+  t |= (min_ && k >= 1 && c && rhi) ? 16u : 0u;
+  t |= (kin && c && !d && rhi) ? 32u : 0u;
+  t |= (kin && d && rhi) ? 64u : 0u;
+  t |= (min_ && k <= nh - 1 && d && rhi) ? 128u : 0u;
+  return t;
+}
+
+__device__ __forceinline__ void lf_cell_apply(int P[64], uint32_t t, int L2) {
+  if (__any(t & 1u)) { if (t & 1u) lf_vert(P, 0, L2); }
+  if (__any(t & 2u)) { if (t & 2u) lf_horz(P, 0, L2); }
+  if (__any(t & 4u)) { if (t & 4u) lf_vert(P, 0, L2); }
+  if (__any(t & 8u)) { if (t & 8u) lf_horz(P, 4, L2); }
+  if (__any(t & 16u)) { if (t & 16u) lf_horz(P, 0, L2); }
+  if (__any(t & 32u)) { if (t & 32u) lf_vert(P, 4, L2); }
+  if (__any(t & 64u)) { if (t & 64u) lf_vert(P, 4, L2); }
+  if (__any(t & 128u)) { if (t & 128u) lf_horz(P, 4, L2); }
+}
+
+__device__ __forceinline__ void unpack_row(int *P, uint32_t lo, uint32_t hi) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    P[q] = byte_of(lo, q);
+    P[4 + q] = byte_of(hi, q);
+  }
+}
+
+// A cell directly on a plane in memory (k_loopfilter, thip_loop_filter_plane).  Neither the
+// pixel loads nor the flag loads depend on anything loaded before, and none of them is
+// predicated: coordinates are clamped into the plane instead (border cells read a valid
+// neighbour whose value is never used), so a cell costs ONE memory round trip of eight
+// 8-byte loads + four flag bytes; cells without work skip the stores.
+struct CellPix {
+  uint32_t lo[8], hi[8];
+};
+struct __attribute__((aligned(4))) Pix8 {
+  uint32_t x, y;
+};
+
+// ---- the filter on the packed image: two pixels per register -------------------------------------
+// f = P2 - P5 + 3*(P4 - P3), R = (f+4)>>3, lflim(R), P3 += ., P4 -= . (state.c:1002-1031) in
+// 16-bit lanes: |f| <= 1020, every intermediate fits; the final clamp is v_sat_pk_u8_i16.
+__device__ __forceinline__ pk16 pk_lf_delta(pk16 p2, pk16 p3, pk16 p4, pk16 p5, int L2) {
+  const pk16 d = p4 - p3;
+  const pk16 f = p2 - p5 + d + d + d;
+  const pk16 R = (f + (short)4) >> 3;
+  const pk16 a = __builtin_elementwise_max(R, -R);
+  const pk16 l2 = {(short)L2, (short)L2};
+  const pk16 z = {0, 0};
+  const pk16 m = __builtin_elementwise_min(a, __builtin_elementwise_max(l2 - a, z));
+  const pk16 s = R >> 15;                      // 0 or -1 per half
+  return as_pk(as_u32(m) ^ as_u32(s)) - s;     // R < 0 ? -m : m
+}
+// horizontal edge y = 4 of the cell, columns 0..3 (half 0: the lo dwords) or 4..7 (half 1)
+__device__ __forceinline__ void lf_horz_pk(CellPix &C, int half, int L2) {
+  uint32_t *w = half ? C.hi : C.lo;
+  const pk16 d01 = pk_lf_delta(pk_bytes01(w[2]), pk_bytes01(w[3]), pk_bytes01(w[4]), pk_bytes01(w[5]), L2);
+  const pk16 d23 = pk_lf_delta(pk_bytes23(w[2]), pk_bytes23(w[3]), pk_bytes23(w[4]), pk_bytes23(w[5]), L2);
+  const uint32_t n3 = sat_pk_u8(pk_bytes01(w[3]) + d01) | sat_pk_u8(pk_bytes23(w[3]) + d23) << 16;
+  const uint32_t n4 = sat_pk_u8(pk_bytes01(w[4]) - d01) | sat_pk_u8(pk_bytes23(w[4]) - d23) << 16;
+  w[3] = n3;
+  w[4] = n4;
+}
+// vertical edge x = 4 of the cell, rows r0..r0+3: columns 2,3 are bytes 2,3 of lo, columns 4,5
+// bytes 0,1 of hi; two rows per register
+__device__ __forceinline__ void lf_vert_pk(CellPix &C, int r0, int L2) {
+#pragma unroll
+  for (int r = r0; r < r0 + 4; r += 2) {
+    const pk16 p2 = as_pk(__builtin_amdgcn_perm(C.lo[r + 1], C.lo[r], 0x0c060c02u));
+    const pk16 p3 = as_pk(__builtin_amdgcn_perm(C.lo[r + 1], C.lo[r], 0x0c070c03u));
+    const pk16 p4 = as_pk(__builtin_amdgcn_perm(C.hi[r + 1], C.hi[r], 0x0c040c00u));
+    const pk16 p5 = as_pk(__builtin_amdgcn_perm(C.hi[r + 1], C.hi[r], 0x0c050c01u));
+    const pk16 d = pk_lf_delta(p2, p3, p4, p5, L2);
+    const uint32_t n3 = sat_pk_u8(p3 + d), n4 = sat_pk_u8(p4 - d);   // byte 0: row r, byte 1: row r+1
+    C.lo[r] = __builtin_amdgcn_perm(n3, C.lo[r], 0x04020100u);       // byte 3 <- n3.byte0
+    C.lo[r + 1] = __builtin_amdgcn_perm(n3, C.lo[r + 1], 0x05020100u);
+    C.hi[r] = __builtin_amdgcn_perm(n4, C.hi[r], 0x03020104u);       // byte 0 <- n4.byte0
+    C.hi[r + 1] = __builtin_amdgcn_perm(n4, C.hi[r + 1], 0x03020105u);
+  }
+}
+__device__ __forceinline__ void lf_cell_apply_pk(CellPix &C, uint32_t t, int L2) {
+  if (__any(t & 1u)) { if (t & 1u) lf_vert_pk(C, 0, L2); }
+  if (__any(t & 2u)) { if (t & 2u) lf_horz_pk(C, 0, L2); }
+  if (__any(t & 4u)) { if (t & 4u) lf_vert_pk(C, 0, L2); }
+  if (__any(t & 8u)) { if (t & 8u) lf_horz_pk(C, 1, L2); }
+  if (__any(t & 16u)) { if (t & 16u) lf_horz_pk(C, 0, L2); }
+  if (__any(t & 32u)) { if (t & 32u) lf_vert_pk(C, 4, L2); }
+  if (__any(t & 64u)) { if (t & 64u) lf_vert_pk(C, 4, L2); }
+  if (__any(t & 128u)) { if (t & 128u) lf_horz_pk(C, 1, L2); }
+}
+__device__ __forceinline__ void lf_cell_load(CellPix &C, const uint8_t *plane, int stride, int nh, int nv, int k,
+                                             int m) {
+  const int W = nh * 8, H = nv * 8;
+  const int xb = min(max(8 * k - 4, 0), W - 8);
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int y = min(max(8 * m - 4 + r, 0), H - 1);
+    const Pix8 v = *reinterpret_cast<const Pix8 *>(plane + (ptrdiff_t)y * stride + xb);
+    C.lo[r] = k == nh ? v.y : v.x;   // right border: the half that exists is the upper dword of the clamped load
+    C.hi[r] = k == 0 ? v.x : v.y;    // left border: ... the lower dword
+  }
+}
+// Keeps the pixel loads where they are written: without it the compiler sinks them below the
+// "no work in this cell" test, i.e. behind the flag loads' round trip.
+__device__ __forceinline__ void lf_cell_pin(const CellPix &C) {
+  asm volatile("" ::"v"(C.lo[0]), "v"(C.lo[1]), "v"(C.lo[2]), "v"(C.lo[3]), "v"(C.lo[4]), "v"(C.lo[5]), "v"(C.lo[6]),
+               "v"(C.lo[7]), "v"(C.hi[0]), "v"(C.hi[1]), "v"(C.hi[2]), "v"(C.hi[3]), "v"(C.hi[4]), "v"(C.hi[5]),
+               "v"(C.hi[6]), "v"(C.hi[7]));
+}
+// coded flags of the four fragments around corner (k,m), clamped the same way
+__device__ __forceinline__ void lf_cell_flags(const uint8_t *coded, int nh, int nv, int k, int m, bool &a, bool &b,
+                                              bool &c, bool &d) {
+  const int ka = max(k - 1, 0), kb = min(k, nh - 1), ma = max(m - 1, 0), mb = min(m, nv - 1);
+  const uint8_t fa = coded[ma * nh + ka], fb = coded[ma * nh + kb], fc = coded[mb * nh + ka], fd = coded[mb * nh + kb];
+  a = (k >= 1) & (m >= 1) & (fa != 0);
+  b = (k <= nh - 1) & (m >= 1) & (fb != 0);
+  c = (k >= 1) & (m <= nv - 1) & (fc != 0);
+  d = (k <= nh - 1) & (m <= nv - 1) & (fd != 0);
+}
+__device__ __forceinline__ void lf_cell_finish(const CellPix &Cin, uint8_t *plane, int stride, int nh, int nv, int k,
+                                               int m, uint32_t t, int L2) {
+  if (!t) return;
+  const bool lo_ok = k >= 1, hi_ok = k <= nh - 1;
+  uint8_t *base = plane + (ptrdiff_t)(8 * m - 4) * stride + (8 * k - 4);
+  const int H = nv * 8;
+  CellPix C = Cin;
+  lf_cell_apply_pk(C, t, L2);
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int y = 8 * m - 4 + r;
+    if (y >= 0 && y < H) {
+      uint8_t *p = base + (ptrdiff_t)r * stride;
+      if (lo_ok & hi_ok) {
+        Pix8 o;
+        o.x = C.lo[r];
+        o.y = C.hi[r];
+        *reinterpret_cast<Pix8 *>(p) = o;
+      } else if (lo_ok) {
+        *reinterpret_cast<uint32_t *>(p) = C.lo[r];
+      } else {
+        *reinterpret_cast<uint32_t *>(p + 4) = C.hi[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_recon (K1 + K2): one wave per tile, one fragment per lane, in coded order
+// ---------------------------------------------------------------------------------------
+// residual of this lane's block as eight rows of packed int16 pairs
+__device__ __forceinline__ void load_slot(const int4 *coeffs, uint32_t slot, uint32_t P[32]) {
+  const int4 *tp = coeffs + ((size_t)(slot >> 6) * 512 + (slot & 63));
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int4 w = tp[q * 64];
+    P[q * 4 + 0] = (uint32_t)w.x;
+    P[q * 4 + 1] = (uint32_t)w.y;
+    P[q * 4 + 2] = (uint32_t)w.z;
+    P[q * 4 + 3] = (uint32_t)w.w;
+  }
+}
+
+// Predictor of an inter block (fragment.c:59-80 with the offsets of state.c:846-957): one
+// reference block or the truncating average of two.  Split in two so that the loads are in
+// flight while the inverse DCT runs: pred_issue() only computes addresses and issues the
+// row loads, pred_finish() turns the raw windows into the eight predictor rows.
+struct PredWin {
+  Row12 w[9];             // rows clamp(ys+r, 0, H-1), 12 bytes from column xw (see pred_xw)
+  int sx, sy, mx2, my2;   // first sample's position, second sample's offset (0 or +-1 per axis)
+  bool border;            // the footprint leaves the frame: replicated-border addressing
+};
+
+// First column of the 12-byte window: the footprint's first column aligned down to 4, pulled
+// inside the row.  Every column a sample can need -- after clamping to [0,W-1], which is what
+// the reference's replicated UMV border amounts to (state.c:770-835) -- lies inside it.
+__device__ __forceinline__ int pred_xw(int xs, int W) { return max(min(xs, W - 12), 0) & ~3; }
+
+__device__ __forceinline__ void pred_issue(PredWin &Q, const uint8_t *ref, int stride, int W, int H, int x0, int y0,
+                                           uint32_t flags, bool qpx, bool qpy) {
+  const int dx = (int)(int8_t)(flags >> THIP_INFO_MVX_SHIFT);
+  const int dy = (int)(int8_t)(flags >> THIP_INFO_MVY_SHIFT);
+  int mx, my;
+  mv_axis(dx, qpx, mx, Q.mx2);
+  mv_axis(dy, qpy, my, Q.my2);
+  Q.sx = x0 + mx;
+  Q.sy = y0 + my;
+  const int xs = Q.sx + min(Q.mx2, 0), ys = Q.sy + min(Q.my2, 0);
+  // (bitwise | on purpose: one compare chain, no nest of divergent branches)
+  Q.border = ((int)(xs < 0) | (int)(Q.sx + max(Q.mx2, 0) + 8 > W) | (int)(ys < 0) | (int)(Q.sy + max(Q.my2, 0) + 8 > H)) != 0;
+  // Both samples of a row lie in the 9 bytes starting at xs, i.e. inside one 12-byte window
+  // aligned down to 4: one dword-aligned dwordx3 load per source row.  Vertical half-pel needs
+  // 9 source rows, not 16; without it the ninth load re-reads row 7.  Row and column clamps are
+  // no-ops for a footprint inside the frame, so there is one code path and no straggler waves.
+  const uint8_t *p1 = ref + pred_xw(xs, W);
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const int y = min(max(ys + (r < 8 ? r : (Q.my2 != 0 ? 8 : 7)), 0), H - 1);
+    Q.w[r] = load_row12(p1 + (ptrdiff_t)y * stride);
+  }
+}
+
+// byte selectors for v_perm_b32: the four window columns col0+i (clamped to the row), as
+// offsets from the window dword pair {4k..4k+7}
+__device__ __forceinline__ void pred_sel(int col0, int xw, int W, uint32_t &sel, bool &k) {
+  int c[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) c[i] = min(max(col0 + i, 0), W - 1) - xw;   // 0..11, non-decreasing
+  k = c[0] >= 4;
+  const int o = k ? 4 : 0;
+  sel = (uint32_t)(c[0] - o) | (uint32_t)(c[1] - o) << 8 | (uint32_t)(c[2] - o) << 16 | (uint32_t)(c[3] - o) << 24;
+}
+__device__ __forceinline__ uint32_t pred_pick(const Row12 &w, uint32_t sel, bool k) {
+  return __builtin_amdgcn_perm(k ? w.c : w.b, k ? w.b : w.a, sel);
+}
+
+__device__ __forceinline__ void pred_finish(const PredWin &Q, int W, uint2 pred[8]) {
+  const int xw = pred_xw(Q.sx + min(Q.mx2, 0), W);
+  const bool ra = Q.my2 < 0, rb = Q.my2 > 0;   // that sample starts one source row down
+  const bool two = (Q.mx2 | Q.my2) != 0;
+  if (!__any(Q.border)) {
+    const int offA = Q.sx - xw, offB = Q.sx + Q.mx2 - xw;   // 0..4
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const Row12 wa = ra ? Q.w[r + 1] : Q.w[r];
+      pred[r] = extract8(wa, offA);
+      if (two) {
+        const Row12 wb = rb ? Q.w[r + 1] : Q.w[r];
+        const uint2 b = extract8(wb, offB);
+        pred[r].x = avg4_trunc(pred[r].x, b.x);
+        pred[r].y = avg4_trunc(pred[r].y, b.y);
+      }
+    }
+  } else {
+    // some lane of the wave needs replicated columns: general byte gather for the whole wave
+    uint32_t sa0, sa1, sb0, sb1;
+    bool ka0, ka1, kb0, kb1;
+    pred_sel(Q.sx, xw, W, sa0, ka0);
+    pred_sel(Q.sx + 4, xw, W, sa1, ka1);
+    pred_sel(Q.sx + Q.mx2, xw, W, sb0, kb0);
+    pred_sel(Q.sx + Q.mx2 + 4, xw, W, sb1, kb1);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const Row12 wa = ra ? Q.w[r + 1] : Q.w[r];
+      pred[r] = make_uint2(pred_pick(wa, sa0, ka0), pred_pick(wa, sa1, ka1));
+      if (two) {
+        const Row12 wb = rb ? Q.w[r + 1] : Q.w[r];
+        pred[r].x = avg4_trunc(pred[r].x, pred_pick(wb, sb0, kb0));
+        pred[r].y = avg4_trunc(pred[r].y, pred_pick(wb, sb1, kb1));
+      }
+    }
+  }
+}
+
+#ifndef THIP_RECON_WAVES
+#define THIP_RECON_WAVES 4
+#endif
+// Waves per workgroup of k_recon.  Waves never cooperate, and a workgroup's wave slots and
+// LDS only become reusable together, so siblings of different length idle slots: 1 is best.
+#ifndef THIP_RECON_WG_WAVES
+#define THIP_RECON_WG_WAVES 1
+#endif
+
+// Optional wave-timeline instrumentation (tools/wave_trace.py builds a private copy of the
+// library with -DTHIP_TRACE; never defined in the product build).
+#ifdef THIP_TRACE
+__device__ unsigned long long *g_trace_buf;   // [blockIdx.y][tile][8]
+__device__ __forceinline__ unsigned long long trace_now() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define THIP_TR(rec, i) do { if (rec) (rec)[i] = trace_now(); } while (0)
+#else
+#define THIP_TR(rec, i) do { } while (0)
+#endif
+
+// What a lane knows after the first round trip.
+struct ReconLane {
+  uint32_t flags, dcp;            // command word 0 (0 past the ragged edge), DC-only value
+  bool coded, dc_only, has_coeff;
+  int x0, y0;                     // pixel position of the block in its plane
+};
+struct ReconPlane {               // wave-uniform
+  uint8_t *self;
+  const uint8_t *prev, *gold;
+  uint8_t *coded_map;             // already offset to the plane's first fragment
+  int nh, nv, stride;
+  bool qpx, qpy;
+  int debug;
+  unsigned long long *tr;         // THIP_TRACE: this wave's record (lane 0 only), else null
+};
+
+// Steps 3-5 of k_recon.  IDCT: the wave's coefficient loads into P are in flight.  Two
+// instantiations instead of one body with a merged P: a merge makes the register allocator
+// copy loaded registers right behind the loads, i.e. wait for them before the predictor
+// loads are even issued.
+// LDSOUT: the rows go to the tile image in LDS (128-byte pitch, lds_img = this lane's block) for
+// the fused loop filter instead of to the frame.
+template <bool IDCT, bool LDSOUT = false>
+__device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane &L, const uint4 *lds_coef,
+                                           uint8_t *lds_img = nullptr) {
+  uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
+
+  // ---- 3. predictor loads.  An uncoded fragment (fragment.c:20-47) is the zero-vector
+  //         predictor from the previous frame plus a zero residual: the same code path. ------------
+  const int refi = L.coded ? (int)((L.flags >> THIP_INFO_REFI_SHIFT) & 3u) : THIP_FRAME_PREV;
+  const bool inter = refi != THIP_FRAME_SELF && !(R.debug & 2);
+  const uint8_t *const ref = refi == THIP_FRAME_PREV ? R.prev : R.gold;
+  PredWin Q;
+  Q.border = false;
+  if (inter) pred_issue(Q, ref, R.stride, R.nh * 8, R.nv * 8, L.x0, L.y0, L.coded ? L.flags : 0u, R.qpx, R.qpy);
+  R.coded_map[(L.y0 >> 3) * R.nh + (L.x0 >> 3)] = L.coded ? 1 : 0;
+  THIP_TR(R.tr, 2);   // every load of the second round trip is issued
+
+  // ---- 4. residual: DC-only shortcut (state.c:967-975) or inverse DCT (idct.c:301) ------------
+  uint32_t Y[32];
+  if (IDCT) {
+    uint32_t P[32];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the caller's LDS-DMA loads have landed (see k_recon)
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint4 w = lds_coef[q * 64];
+      P[q * 4 + 0] = w.x;
+      P[q * 4 + 1] = w.y;
+      P[q * 4 + 2] = w.z;
+      P[q * 4 + 3] = w.w;
+    }
+#ifdef THIP_TRACE
+    asm volatile("" : "+v"(P[31]));
+    THIP_TR(R.tr, 3);   // coefficients (and, with them, the predictor windows) have arrived
+#endif
+    const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
+    pk_mask_by_last_zzi(P, last_zzi);
+    const bool all_zz10 = !__any(L.has_coeff && last_zzi > 10);
+    pk_idct8x8(P, Y, all_zz10);
+  }
+  if (!IDCT || !L.has_coeff) {   // DC-only: the pre-rounded value; uncoded: zero residual
+    const uint32_t fill = L.dc_only ? L.dcp : 0u;
+#pragma unroll
+    for (int i = 0; i < 32; i++) Y[i] = fill;
+  }
+
+  // ---- 5. predictor rows (fragment.c:49-80: 128, one block, or the average of two),
+  //         reconstruct and store (8 aligned bytes per lane per row) ------------------------------
+  uint2 pred[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
+  if (inter) pred_finish(Q, R.nh * 8, pred);
+  if (LDSOUT) {
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      *reinterpret_cast<uint2 *>(lds_img + r * 128) =
+          pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]), pred[r]);
+  } else if (!(R.debug & 4)) {
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      store_row8(dst + (ptrdiff_t)r * R.stride,
+                 pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]),
+                              pred[r]));
+  }
+  THIP_TR(R.tr, 4);   // stores issued
+}
+
+// ---- k_recon in three parts, so that the residual can be computed by ALL lanes of the wave ------
+// (recon_tail above is the same thing in one piece; the fused variant still uses it.)
+__device__ __forceinline__ void recon_issue(const ReconPlane &R, const ReconLane &L, PredWin &Q, bool &inter,
+                                            const uint8_t *&ref) {
+  const int refi = L.coded ? (int)((L.flags >> THIP_INFO_REFI_SHIFT) & 3u) : THIP_FRAME_PREV;
+  inter = refi != THIP_FRAME_SELF && !(R.debug & 2);
+  ref = refi == THIP_FRAME_PREV ? R.prev : R.gold;
+  Q.border = false;
+  if (inter) pred_issue(Q, ref, R.stride, R.nh * 8, R.nv * 8, L.x0, L.y0, L.coded ? L.flags : 0u, R.qpx, R.qpy);
+  R.coded_map[(L.y0 >> 3) * R.nh + (L.x0 >> 3)] = L.coded ? 1 : 0;
+}
+
+__device__ __forceinline__ void recon_finish(const ReconPlane &R, const ReconLane &L, const PredWin &Q, bool inter,
+                                             const uint32_t Y[32]) {
+  uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
+  uint2 pred[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
+  if (inter) pred_finish(Q, R.nh * 8, pred);
+  if (!(R.debug & 4)) {
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      store_row8(dst + (ptrdiff_t)r * R.stride,
+                 pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]),
+                              pred[r]));
+  }
+}
+
+// Residual of the lanes that own coefficients, one block per lane (the whole wave executes the
+// 16 one-dimensional transforms whether 1 lane or 64 need them).
+__device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const ReconLane &L, uint32_t Y[32]) {
+  uint32_t P[32];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const uint4 w = lds_coef[q * 64];
+    P[q * 4 + 0] = w.x;
+    P[q * 4 + 1] = w.y;
+    P[q * 4 + 2] = w.z;
+    P[q * 4 + 3] = w.w;
+  }
+  const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
+  pk_mask_by_last_zzi(P, last_zzi);
+  const bool all_zz10 = !__any(L.has_coeff && last_zzi > 10);
+  pk_idct8x8(P, Y, all_zz10);
+}
+
+// The same residuals when at most 64/LPB lanes of the wave own coefficients (the usual case
+// outside synthetic worst cases: SURVEY section 6 has 80 % of the coded blocks DC-only): LPB lanes
+// (4 or 2) share a block -- lane LPB*g+j takes row pairs j*NP..j*NP+NP-1 (NP = 4/LPB) of the
+// g-th owner for the row pass and the same column pairs for the column pass, the transpose
+// between goes through the wave's LDS area (free once the coefficients are in registers) -- so
+// the wave executes 2*NP packed 1-D transforms instead of 8.  Bit-exact with residual_per_lane:
+// the same operations on the same values.  Must be called by all 64 lanes.
+// lds = the wave's 8 KB area as dwords; meta = 64/LPB dwords of LDS.
+// The g-th owner's coefficients sit in slot slot0+g (slots are numbered in lane order inside a
+// tile), so the sharing lanes fetch their own row pairs straight from the slot -- 32*NP bytes per
+// lane instead of the whole wave staging 8 KB of which a fraction is used.
+template <int LPB>
+__device__ __forceinline__ void residual_shared_load(const int4 *coeffs, uint32_t slot0, int nown, int lane,
+                                                     int4 W[4 / LPB][2]) {
+  constexpr int NP = 4 / LPB;
+  const int g = min(lane / LPB, nown - 1), j = lane % LPB;   // surplus groups re-read the last owner's slot
+  const uint32_t slot = slot0 + (uint32_t)g;
+  const int4 *tp = coeffs + ((size_t)(slot >> 6) * 512 + (slot & 63));
+#pragma unroll
+  for (int n = 0; n < NP; n++) {
+    const int rp = j * NP + n;
+    W[n][0] = tp[(2 * rp) * 64];
+    W[n][1] = tp[(2 * rp + 1) * 64];
+  }
+}
+
+template <int LPB>
+__device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32_t *lds, uint32_t *meta, int lane,
+                                                const ReconLane &L, uint32_t prefix, uint32_t Y[32]) {
+  constexpr int NP = 4 / LPB;                        // row pairs (and column pairs) per lane
+  const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
+  if (L.has_coeff) meta[prefix] = (uint32_t)last_zzi;   // rank -> last_zzi of that owner
+  const int g = lane / LPB, j = lane % LPB;
+  const int lz = (int)(meta[g] & 0x7Fu);            // (garbage for g >= number of owners: results unused)
+  const bool c3 = lz <= 3, c10 = lz <= 10;
+  pk16 Rr[NP][8];
+#pragma unroll
+  for (int n = 0; n < NP; n++) {
+    const int rp = j * NP + n;                       // row pair: rows 2rp, 2rp+1
+    const int4 w0 = W[n][0], w1 = W[n][1];
+    const uint32_t P8[8] = {(uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w,
+                            (uint32_t)w1.x, (uint32_t)w1.y, (uint32_t)w1.z, (uint32_t)w1.w};   // {x[2rp][c], x[2rp+1][c]}, c = 0..7
+    // what the variant selected by last_zzi does not read is zero (pk_mask_by_last_zzi)
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const uint32_t m10 = ((2 * rp + c <= 3) ? 0x0000FFFFu : 0u) | ((2 * rp + 1 + c <= 3) ? 0xFFFF0000u : 0u);
+      const uint32_t m3 = ((rp == 0 && c <= 1) ? 0x0000FFFFu : 0u) | ((rp == 0 && c == 0) ? 0xFFFF0000u : 0u);
+      Rr[n][c] = as_pk(P8[c] & (c3 ? m3 : (c10 ? m10 : 0xFFFFFFFFu)));
+    }
+    pk_idct8(Rr[n][0], Rr[n][1], Rr[n][2], Rr[n][3], Rr[n][4], Rr[n][5], Rr[n][6], Rr[n][7]);
+  }
+  // exchange inside the group: every lane publishes its row pairs, collects its column pairs
+  uint32_t *xch = lds;                       // NP*8 dwords per lane
+  uint32_t *res = lds + 64 * NP * 8;         // 32 dwords per owner
+#pragma unroll
+  for (int n = 0; n < NP; n++) {
+    uint4 *x4 = reinterpret_cast<uint4 *>(xch + (lane * NP + n) * 8);
+    x4[0] = make_uint4(as_u32(Rr[n][0]), as_u32(Rr[n][1]), as_u32(Rr[n][2]), as_u32(Rr[n][3]));
+    x4[1] = make_uint4(as_u32(Rr[n][4]), as_u32(Rr[n][5]), as_u32(Rr[n][6]), as_u32(Rr[n][7]));
+  }
+#pragma unroll
+  for (int n = 0; n < NP; n++) {
+    const int cp = j * NP + n;                       // column pair: columns 2cp, 2cp+1
+    pk16 Q[8];
+#pragma unroll
+    for (int rp = 0; rp < 4; rp++) {                 // row pair rp lives at slot (g*LPB*NP + rp) = g*4 + rp
+      const uint2 ab = *reinterpret_cast<const uint2 *>(xch + (g * 4 + rp) * 8 + 2 * cp);
+      Q[2 * rp] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x05040100u));
+      Q[2 * rp + 1] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x07060302u));
+    }
+    pk_idct8(Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], Q[6], Q[7]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) res[g * 32 + r * 4 + cp] = as_u32(pk_descale(Q[r]));   // Y[r*4+k] layout of the owner
+  }
+  if (L.has_coeff) {
+    const uint4 *y4 = reinterpret_cast<const uint4 *>(res + prefix * 32);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint4 w = y4[q];
+      Y[q * 4 + 0] = w.x;
+      Y[q * 4 + 1] = w.y;
+      Y[q * 4 + 2] = w.z;
+      Y[q * 4 + 3] = w.w;
+    }
+  }
+}
+
+// A wave's life is exactly two memory round trips: (1) its 64 command words and the tile's
+// first slot number, (2) coefficients and predictor windows, all issued before anything
+// waits.  Everything read from the kernel arguments is wave-uniform and is forced into
+// scalar registers (readfirstlane on the tile number), so the per-plane table lookups are
+// scalar loads, not dependent vector loads.
+__global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_recon(const BatchK B) {
+  const StreamK &S = B.s[blockIdx.y];
+  const int lane = (int)threadIdx.x & 63;
+  // Workgroups are handed to the 8 XCDs round-robin (id mod 8) and each XCD has its own L2:
+  // give XCD x the x-th contiguous band of tiles, so that the predictor windows of
+  // neighbouring tiles -- which overlap by up to 16 pixels -- meet in one L2 instead of being
+  // fetched from HBM by two.  gridDim.x is a multiple of 8.
+  const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  const int unit = __builtin_amdgcn_readfirstlane(wg * THIP_RECON_WG_WAVES + ((int)threadIdx.x >> 6));  // tile
+#ifdef THIP_TRACE
+  unsigned long long *tr = nullptr;
+  if (g_trace_buf && lane == 0) {
+    tr = g_trace_buf + ((size_t)blockIdx.y * (gridDim.x * THIP_RECON_WG_WAVES) + unit) * 8;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+    tr[5] = hwid;
+    tr[6] = xcc;
+  }
+  THIP_TR(tr, 0);
+#endif
+  // scalar batch 1: the stream's pointers and the plane boundaries (pinned by the empty asm:
+  // left alone, the compiler sinks each scalar load to its first use, which turns one wait
+  // into a chain of dependent ones)
+  const uint2 *info_p = S.info;
+  const int4 *coeffs_p = S.coeffs;
+  const uint32_t *slot0_p = S.tile_slot0;
+  uint8_t *self = S.self;
+  const uint8_t *prev = S.prev, *gold = S.gold;
+  uint8_t *coded_map = S.coded_map;
+  const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2];
+  const int debug = S.debug, sqpx = S.qpx, sqpy = S.qpy;
+  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
+               "s"(te0), "s"(te1), "s"(te2), "s"(debug), "s"(sqpx), "s"(sqpy));
+  if (unit >= te2) return;
+  const int pli = (unit >= te0 ? 1 : 0) + (unit >= te1 ? 1 : 0);
+  // scalar batch 2: the plane's geometry
+  const PlaneK G = S.pl[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.fro));
+
+  // ---- 1. command word + first slot of the tile (one round trip) -------------------------------
+  const uint32_t slot0 = slot0_p[unit];
+  const uint2 info = info_p[(size_t)unit * THIP_TILE_FRAGS + lane];
+  // both loads are consumed here as far as the compiler can tell, so the scalar load is issued
+  // next to the vector load instead of being sunk behind the wait for it
+  asm volatile("" ::"s"(slot0), "v"(info.x));
+#ifdef THIP_TRACE
+  THIP_TR(tr, 1);   // first round trip done
+#endif
+
+  const int rel = unit - (pli == 0 ? 0 : (pli == 1 ? te0 : te1));
+  const int sby = rel / G.tiles_x;
+  const int tx = rel - sby * G.tiles_x;
+  const int h = lane & 15;
+  const int bx = tx * 16 + (lane >> 4) * 4 + hilb_col(h);
+  const int by = sby * 4 + hilb_row(h);
+  const bool valid = bx < G.nh && by < G.nv;
+
+  ReconLane L;
+  L.flags = valid ? info.x : 0u;
+  L.dcp = (info.y & 0xFFFFu) * 0x00010001u;   // {p, p}
+  L.coded = (L.flags & THIP_INFO_CODED) != 0;
+  L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
+  L.has_coeff = L.coded && !L.dc_only;
+  L.x0 = bx * 8;
+  L.y0 = by * 8;
+  ReconPlane R;
+  R.self = self + G.off;
+  R.prev = prev + G.off;
+  R.gold = gold + G.off;
+  R.coded_map = coded_map + G.fro;
+  R.nh = G.nh;
+  R.nv = G.nv;
+  R.stride = G.stride;
+  R.qpx = pli != 0 && sqpx;
+  R.qpy = pli != 0 && sqpy;
+  R.debug = debug;
+#ifdef THIP_TRACE
+  R.tr = tr;
+#else
+  R.tr = nullptr;
+#endif
+
+  // ---- 2. coefficient loads (slot by prefix count over the mask), issued, not waited for.
+  //         The branch is wave-uniform and every lane loads (lanes without coefficients re-read
+  //         the tile's first slot -- same cache lines, no extra traffic -- and are overridden
+  //         in step 4). -----------------------------------------------------------------------------
+  const uint64_t mask = __ballot(L.has_coeff);
+#ifndef THIP_RECON_LDS_PAD
+#define THIP_RECON_LDS_PAD 0
+#endif
+  __shared__ uint4 s_coef[THIP_RECON_WG_WAVES * 8 * 64 + THIP_RECON_LDS_PAD / 16];   // [wave][piece][lane]: 8 KB per wave, wave-private
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  uint4 *const lds_wave = s_coef + wave * 512;
+  __shared__ uint32_t s_meta[THIP_RECON_WG_WAVES * 32];
+  PredWin Q;
+  bool inter = false;
+  const uint8_t *ref = nullptr;
+  uint32_t Y[32];
+  const int nown = __popcll(mask);
+  const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  uint32_t *const lds_dw = reinterpret_cast<uint32_t *>(lds_wave);
+  if (nown == 0 || (debug & 9)) {
+    if (valid) recon_issue(R, L, Q, inter, ref);   // (!valid: past the ragged edge of the plane)
+  } else if (nown <= 16 && !(debug & 32)) {
+    // ---- few owners: four lanes per block, pieces straight from the slots ------------------------
+    int4 W[1][2];
+    residual_shared_load<4>(coeffs_p, slot0, nown, lane, W);
+    if (valid) recon_issue(R, L, Q, inter, ref);
+    THIP_TR(R.tr, 2);
+    residual_shared<4>(W, lds_dw, s_meta + wave * 32, lane, L, prefix, Y);
+    THIP_TR(R.tr, 3);
+  } else if (nown <= 32 && !(debug & 32)) {
+    int4 W[2][2];
+    residual_shared_load<2>(coeffs_p, slot0, nown, lane, W);
+    if (valid) recon_issue(R, L, Q, inter, ref);
+    THIP_TR(R.tr, 2);
+    residual_shared<2>(W, lds_dw, s_meta + wave * 32, lane, L, prefix, Y);
+    THIP_TR(R.tr, 3);
+  } else {
+    // ---- many owners: one lane per block.  Coefficients go global -> LDS directly (LDS address
+    //      = wave-uniform base + lane*16): no VGPRs are tied up and nothing can make the compiler
+    //      touch the data before the predictor loads are out.  Every lane loads (lanes without
+    //      coefficients re-read the tile's first slot: same cache lines). ---------------------------
+    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
+    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
+    if (!(debug & 64)) {   // (ablation: transforms on whatever the LDS holds)
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
+                                         (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
+    }
+    if (valid) recon_issue(R, L, Q, inter, ref);
+    THIP_TR(R.tr, 2);
+    // The LDS-DMA loads above are counted by vmcnt; the compiler's own wait before the LDS reads
+    // below is not something to rely on (it vanished when the loads moved into a conditional
+    // block and the reads returned stale LDS), so it is stated.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    residual_per_lane(lds_wave + lane, L, Y);
+    THIP_TR(R.tr, 3);
+  }
+  if (!valid) return;
+  if (!L.has_coeff || (debug & 9)) {   // DC-only: the pre-rounded value; uncoded: zero residual
+    const uint32_t fill = L.dc_only ? L.dcp : 0u;
+#pragma unroll
+    for (int i = 0; i < 32; i++) Y[i] = fill;
+  }
+  recon_finish(R, L, Q, inter, Y);
+  THIP_TR(R.tr, 4);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_recon_lf (K1+K2+most of K3): reconstruction fused with the loop filter
+// ---------------------------------------------------------------------------------------
+// One workgroup per SEGMENT of a tile row (up to 16 horizontally adjacent tiles, one wave each,
+// exactly k_recon's two round trips per wave).  The reconstructed tiles go to LDS (each wave's
+// 128x32 image re-uses its coefficient staging area), the workgroup meets at a barrier, and
+// every filter cell that lies completely inside the segment's 32-pixel-high strip -- cell rows
+// m = 1..3 of the tile row, all columns except the segment's outer edges -- is filtered there
+// (cells are independent), then the strip is written to the frame ONCE.
+// What is left for k_lf_seam are the cell rows on tile-row boundaries (m = 0 mod 4, and m = nv)
+// and the columns on segment boundaries: about a quarter of the cells, read and written in full
+// rows.  The separate k_loopfilter pass re-read and re-wrote every pixel.
+constexpr int kSegMax = 8;             // waves per workgroup (8 x 8 KB of LDS: two workgroups per CU)
+constexpr int kChunkBytes = 8192;      // LDS per wave: coefficient staging, then image (4096) + flags (64)
+
+__device__ __forceinline__ uint32_t lds_px(const uint8_t *base, int x, int y) {   // 4 pixels at (x, y) of the strip
+  return *reinterpret_cast<const uint32_t *>(base + (x >> 7) * kChunkBytes + y * 128 + (x & 127));
+}
+__device__ __forceinline__ void lds_px_store(uint8_t *base, int x, int y, uint32_t v) {
+  *reinterpret_cast<uint32_t *>(base + (x >> 7) * kChunkBytes + y * 128 + (x & 127)) = v;
+}
+
+__global__ __launch_bounds__(64 * kSegMax, 1) void k_recon_lf(const BatchK B) {
+  extern __shared__ uint4 s_dyn[];
+  const StreamK &S = B.s[blockIdx.y];
+  const int lane = (int)threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, see k_recon
+  const uint2 *info_p = S.info;
+  const int4 *coeffs_p = S.coeffs;
+  const uint32_t *slot0_p = S.tile_slot0;
+  uint8_t *self = S.self;
+  const uint8_t *prev = S.prev, *gold = S.gold;
+  uint8_t *coded_map = S.coded_map;
+  const int se0 = S.seg_end[0], se1 = S.seg_end[1], se2 = S.seg_end[2];
+  const int te0 = S.tile_end[0], te1 = S.tile_end[1];
+  const int debug = S.debug, sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
+  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
+               "s"(se0), "s"(se1), "s"(se2), "s"(te0), "s"(te1), "s"(debug), "s"(sqpx), "s"(sqpy), "s"(L2));
+  if (wg >= se2) return;
+  const int pli = (wg >= se0 ? 1 : 0) + (wg >= se1 ? 1 : 0);
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.fro), "s"(G.nseg),
+               "s"(G.seglen), "s"(fy0), "s"(fy1));
+  const int rel = wg - (pli == 0 ? 0 : (pli == 1 ? se0 : se1));
+  const int sby = rel / G.nseg;                 // tile row
+  const int seg = rel - sby * G.nseg;
+  const int tx0 = seg * G.seglen;               // first tile of the segment
+  const int ntx = min(G.seglen, G.tiles_x - tx0);
+  if (wave >= ntx) return;                      // (whole waves only: the barriers below count live waves)
+  const int tx = tx0 + wave;
+  const int unit = (pli == 0 ? 0 : (pli == 1 ? te0 : te1)) + sby * G.tiles_x + tx;   // tile number, as in k_recon
+
+  const uint32_t slot0 = slot0_p[unit];
+  const uint2 info = info_p[(size_t)unit * THIP_TILE_FRAGS + lane];
+  asm volatile("" ::"s"(slot0), "v"(info.x));
+
+  const int h = lane & 15;
+  const int lx = (lane >> 4) * 4 + hilb_col(h), ly = hilb_row(h);   // fragment inside the tile
+  const int bx = tx * 16 + lx, by = sby * 4 + ly;
+  const bool valid = bx < G.nh && by < G.nv;
+
+  ReconLane L;
+  L.flags = valid ? info.x : 0u;
+  L.dcp = (info.y & 0xFFFFu) * 0x00010001u;
+  L.coded = (L.flags & THIP_INFO_CODED) != 0;
+  L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
+  L.has_coeff = L.coded && !L.dc_only;
+  L.x0 = bx * 8;
+  L.y0 = by * 8;
+  ReconPlane R;
+  R.self = self + G.off;
+  R.prev = prev + G.off;
+  R.gold = gold + G.off;
+  R.coded_map = coded_map + G.fro;
+  R.nh = G.nh;
+  R.nv = G.nv;
+  R.stride = G.stride;
+  R.qpx = pli != 0 && sqpx;
+  R.qpy = pli != 0 && sqpy;
+  R.debug = debug;
+  R.tr = nullptr;
+
+  uint8_t *const strip = reinterpret_cast<uint8_t *>(s_dyn);          // chunk w = tile w of the segment
+  uint8_t *const chunk = strip + wave * kChunkBytes;
+  uint8_t *const img = chunk + (ly * 8) * 128 + lx * 8;               // this lane's block in the tile image
+  const uint64_t mask = __ballot(L.has_coeff);
+  if (mask != 0 && !(debug & 9)) {
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
+    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
+    uint4 *lds_wave = reinterpret_cast<uint4 *>(chunk);
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
+                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
+    if (valid) recon_tail<true, true>(R, L, lds_wave + lane, img);
+  } else {
+    if (valid) recon_tail<false, true>(R, L, nullptr, img);
+  }
+  chunk[4096 + ly * 16 + lx] = (valid && L.coded) ? 1 : 0;           // coded flags of the tile, for the cells
+  __syncthreads();
+
+  // ---- loop filter on the cells inside the strip ---------------------------------------------------
+  // columns: every corner from the segment's first to its last, except a segment edge that is
+  // not a plane edge; rows: m = 1..3 of this tile row, below the plane's last corner row
+  if (L2 != 0) {
+    const int k0 = tx0 * 16, k1 = min(k0 + ntx * 16, G.nh);
+    const int ka = k0 + (k0 > 0 ? 1 : 0), kb = k1 - (k1 < G.nh ? 1 : 0);
+    const int ncols = kb - ka + 1;
+    const int t = (int)threadIdx.x;
+    const int mr = 1 + (t >= ncols ? 1 : 0) + (t >= 2 * ncols ? 1 : 0);
+    const int k = ka + t - (mr - 1) * ncols, m = sby * 4 + mr;
+    if (t < 3 * ncols && m < G.nv) {
+      const int kx = (k - k0) * 8, my = mr * 8;                        // corner in strip pixels
+      // flags of a=(k-1,m-1) b=(k,m-1) c=(k-1,m) d=(k,m); fragments outside the plane read as uncoded
+      auto flag = [&](int fk, int fm) -> bool {
+        const int rk = fk - k0;
+        return fk >= 0 && fk < G.nh && strip[(rk >> 4) * kChunkBytes + 4096 + (fm - sby * 4) * 16 + (rk & 15)] != 0;
+      };
+      const bool a = flag(k - 1, m - 1), b = flag(k, m - 1), c = flag(k - 1, m), d = flag(k, m);
+      const uint32_t ops = lf_cell_ops(k, m, G.nh, G.nv, a, b, c, d, fy0, fy1);
+      if (ops) {
+        const bool lo_ok = k >= 1, hi_ok = k <= G.nh - 1;
+        int P[64];
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          unpack_row(P + r * 8, lo_ok ? lds_px(strip, kx - 4, my - 4 + r) : 0u, hi_ok ? lds_px(strip, kx, my - 4 + r) : 0u);
+        lf_cell_apply(P, ops, L2);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          if (lo_ok) lds_px_store(strip, kx - 4, my - 4 + r, pack4(P[r * 8 + 0], P[r * 8 + 1], P[r * 8 + 2], P[r * 8 + 3]));
+          if (hi_ok) lds_px_store(strip, kx, my - 4 + r, pack4(P[r * 8 + 4], P[r * 8 + 5], P[r * 8 + 6], P[r * 8 + 7]));
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- the strip goes to the frame, once --------------------------------------------------------------
+  if (valid && !(debug & 4)) {
+    uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) store_row8(dst + (ptrdiff_t)r * R.stride, *reinterpret_cast<const uint2 *>(img + r * 128));
+  }
+}
+
+// The cells k_recon_lf leaves: per plane first the seam ROWS (m = 0, 4, 8, ... and m = nv, every
+// column), then the seam COLUMNS (k on a segment boundary, the remaining rows).
+__global__ __launch_bounds__(256) void k_lf_seam(const BatchK B) {
+  const StreamK &S = B.s[blockIdx.y];
+  const int lane = (int)threadIdx.x & 63;
+  const int wbase = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));
+  uint8_t *self = S.self;
+  const uint8_t *cmap = S.coded_map;
+  const int ce0 = S.seam_end[0], ce1 = S.seam_end[1], ce2 = S.seam_end[2], L2 = S.flimit2;
+  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2));
+  if (wbase >= ce2 || L2 == 0) return;
+  const int pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(G.nseg),
+               "s"(G.seglen), "s"(G.seam_rows), "s"(fy0), "s"(fy1));
+  const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
+  const int nh = G.nh, nv = G.nv;
+  const int nrowcells = G.seam_rows * (nh + 1);
+  int k, m;
+  if (rel < nrowcells) {
+    uint32_t mu, ku;
+    divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
+    k = (int)ku;
+    m = min((int)mu * 4, nv);            // the last seam row is m = nv whether or not nv is a multiple of 4
+  } else {
+    // seam columns: (nseg-1) columns x (nv + 1 - seam_rows) rows; row index -> m skips the seam rows
+    const int r2 = rel - nrowcells;
+    const int ncol = G.nseg - 1, nrow = nv + 1 - G.seam_rows;
+    if (ncol <= 0 || r2 >= ncol * nrow) return;
+    const int ci = r2 / nrow, ri = r2 - ci * nrow;   // (small numbers: plain division)
+    k = (ci + 1) * G.seglen * 16;
+    m = ri + ri / 3 + 1;                 // rows 1,2,3, 5,6,7, 9,...: skip every multiple of 4
+    if (k > nh - 1 || m >= nv) return;   // (a column beyond the plane cannot happen; m < nv by construction)
+  }
+  CellPix C;
+  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
+  bool a, b, c, d;
+  lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
+  const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
+  lf_cell_pin(C);
+  lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_loopfilter (K3): one filter cell per lane over the whole frame
+// ---------------------------------------------------------------------------------------
+// One wave never straddles two planes (the cumulative cell counts in StreamK::cell_end are
+// padded to whole waves), so the plane lookup is scalar, like k_recon's.
+__global__ __launch_bounds__(256) void k_loopfilter(const BatchK B) {
+  const StreamK &S = B.s[blockIdx.y];
+  const int lane = (int)threadIdx.x & 63;
+  const int wbase = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));
+  uint8_t *self = S.self;
+  const uint8_t *cmap = S.coded_map;
+  const int ce0 = S.cell_end[0], ce1 = S.cell_end[1], ce2 = S.cell_end[2], L2 = S.flimit2;
+  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2));
+  if (wbase >= ce2 || L2 == 0) return;
+  const int pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(fy0), "s"(fy1));
+  const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
+  const int nh = G.nh, nv = G.nv;
+  if (rel >= (nh + 1) * (nv + 1)) return;
+  uint32_t mu, ku;
+  divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
+  const int k = (int)ku, m = (int)mu;
+  CellPix C;
+  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
+  bool a, b, c, d;
+  lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
+  const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
+  lf_cell_pin(C);
+  lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
+}
+
+// plane-level entry for the slot parity test (thip_loop_filter_plane)
+__global__ __launch_bounds__(256) void k_loopfilter_plane(uint8_t *plane, int stride, int nh, int nv,
+                                                         const uint8_t *coded, int L2, int fy0, int fy1,
+                                                         float rcp_cx) {
+  const int cell = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (cell >= (nh + 1) * (nv + 1)) return;
+  uint32_t mu, ku;
+  divmod_u24((uint32_t)cell, (uint32_t)(nh + 1), rcp_cx, mu, ku);
+  const int k = (int)ku, m = (int)mu;
+  CellPix C;
+  lf_cell_load(C, plane, stride, nh, nv, k, m);
+  bool a, b, c, d;
+  lf_cell_flags(coded, nh, nv, k, m, a, b, c, d);
+  lf_cell_finish(C, plane, stride, nh, nv, k, m, lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1), L2);
+}
+
