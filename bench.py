@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--content", default="dense", choices=["dense", "smooth", "mixed", "skip", "zeromv_dc", "intra_dense"])
     ap.add_argument("--streams-per-gpu", type=int, default=4)
     ap.add_argument("--pool", type=int, default=6, help="distinct inter-frame command streams per stream")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of stream 0 the CPU oracle decodes")
+    ap.add_argument("--cpu-frames", type=int, default=288, help="frames of stream 0 the CPU oracle decodes (~10 s at 4K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_known_args()
