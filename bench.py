@@ -190,6 +190,26 @@ def main_e2e(main_args, argv):
                       "note": "host-bound: one entropy-decode thread per stream + PCIe; th_decode_* contexts are independent"}))
     for dec in decs:
         dec.close()
+    # the same packets in an Ogg file through the C program (examples/dump_video_hip.c): no Python between the calls
+    exe = os.path.join(ROOT, "examples", "dump_video_hip")
+    if os.path.exists(exe):
+        import subprocess
+        import tempfile
+        from tests import oggmux
+        ls = oggmux.LogicalStream(0x7E0)
+        for k, hp in enumerate(hdr):
+            ls.add_packet(hp, granulepos=0, flush=(k == 0 or k == len(hdr) - 1))
+        for rep in range(4 * args.loops):
+            for k, pk in enumerate(pkts):
+                ls.add_packet(pk, granulepos=rep * len(pkts) + k + 1)
+        with tempfile.TemporaryDirectory() as td:
+            ogv = os.path.join(td, "clip.ogv")
+            with open(ogv, "wb") as f:
+                f.write(b"".join(ls.finish()))
+            for label, extra in (("decode only", ["--fps-only"]), ("with YUV4MPEG2 output", ["-o", "/dev/null"])):
+                r = subprocess.run([exe] + extra + [ogv], capture_output=True, text=True, timeout=600)
+                print(json.dumps({"metric": "dump_video_hip on an Ogg file (%s 4:2:0, %s)" % (args.size, label),
+                                  "stderr": r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "", "rc": r.returncode}))
 
 
 

@@ -120,6 +120,7 @@ int main(int argc, char **argv) {
         return 1;
       }
       headers_done = 1;
+      clock_gettime(CLOCK_MONOTONIC, &t0); /* the rate below is of the decode loop, not of device start-up */
       if (out && !raw) {
         static const char *const chroma[4] = {"420jpeg", NULL, "422jpeg", "444"};
         int w = (int)ti.frame_width, h = (int)ti.frame_height;
