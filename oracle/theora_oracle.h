@@ -13,8 +13,9 @@
  * restatement therefore follows the reference source line by line (citations
  * below are file:line into /root/reference) and is cross-checked against an
  * independent restatement of the normative specification text
- * (oracle/spec_model.py, doc/spec/spec.tex), but it has not been run against
- * the reference binary.
+ * (oracle/spec_model.py, doc/spec/spec.tex) and against a third-party decoder
+ * (FFmpeg's, inside the Chromium of the kaleido package: tests/test_thirdparty_decoder.py),
+ * but it has not been run against the reference binary.
  */
 #ifndef THEORA_ORACLE_H
 #define THEORA_ORACLE_H

@@ -464,7 +464,7 @@ class Stream:
             modes = []
             for (luma, chroma) in self.mbs:
                 if coded[luma].any():
-                    mode = int(rng.integers(0, 8))
+                    mode = int(rng.choice(self.mode_choices)) if getattr(self, "mode_choices", None) else int(rng.integers(0, 8))
                     if scheme != 7:
                         mi = alphabet.index(mode)
                         bw.code("1" * mi + ("0" if mi < 7 else ""))
@@ -479,6 +479,8 @@ class Stream:
             last1, last2 = (0, 0), (0, 0)
 
             def rnd_mv():
+                if getattr(self, "mv_choices", None):      # diagnostic knob: draw each component from a list
+                    return (int(rng.choice(self.mv_choices)), int(rng.choice(self.mv_choices)))
                 return (int(rng.integers(-31, 32)), int(rng.integers(-31, 32))) if rng.random() < 0.5 else \
                     (int(rng.integers(-4, 5)), int(rng.integers(-4, 5)))
             for (luma, chroma), mode in zip(self.mbs, modes):
@@ -553,8 +555,8 @@ class Stream:
         last_zzi = np.zeros(n, np.int64)
         for i in range(n):
             u = rng.random()
-            if u < p_empty:
-                nzpos = []
+            if u < p_empty or (getattr(self, "chroma_empty", False) and plane_of[i] > 0):
+                nzpos = []           # (chroma_empty: diagnostic knob, grey pictures)
             elif u < p_empty + p_dc_only:
                 nzpos = [0]
             else:
@@ -565,6 +567,8 @@ class Stream:
                 r = rng.random()
                 mag = 1 if r < 0.45 else int(rng.integers(2, 7)) if r < 0.8 else int(rng.integers(7, 69)) if r < 0.97 \
                     else int(rng.integers(69, 581))
+                if getattr(self, "max_mag", None):
+                    mag = min(mag, int(self.max_mag))   # diagnostic knob: keep the transform inside its valid range
                 v = mag if rng.random() < 0.5 else -mag
                 nz.append((z, v))
                 qcoef[i, z] = v

@@ -226,3 +226,42 @@ def test_dump_video_example_on_an_ogg_file(hip, tmp_path):
         cr = np.frombuffer(rec, np.uint8, w * h // 4, 6 + w * h * 5 // 4).reshape(h // 2, w // 2)
         assert np.array_equal(y, planes[0]) and np.array_equal(cb, planes[1]) and np.array_equal(cr, planes[2]), f
     assert "9 frames" in r.stderr
+
+
+def test_hip_decoder_agrees_with_ffmpeg_in_chromium(hip):
+    """The whole product chain -- Ogg demultiplexer, th_decode_* front end, HIP reconstruction,
+    th_decode_ycbcr_out -- against FFmpeg's Theora decoder in the Chromium that the kaleido package
+    bundles (tests/test_thirdparty_decoder.py explains the method and its limits).  Skips where
+    that browser is not available."""
+    import base64
+    import json
+    from tests import test_thirdparty_decoder as T
+    from theora_amd.decoder import Decoder, ogg_packets
+    try:
+        from kaleido.scopes.plotly import PlotlyScope
+        scope = PlotlyScope(plotlyjs=T.JS)
+        probe = json.loads(scope.transform({"data": [{"ogv": "", "nframes": 0, "fps": 30}], "layout": {}}, format="json"))
+        assert "frames" in probe
+    except Exception as e:   # noqa: BLE001
+        pytest.skip("no usable kaleido/Chromium here: %r" % (e,))
+    w, h, n = 64, 48, 10
+    ogv, want, modes = T.make_clip(w, h, 31, n, 5, 6, False, [48, 40])
+    pkts, stats = ogg_packets(ogv)
+    assert stats == (0, 0)
+    dec = Decoder([p[1] for p in pkts[:3]])
+    mine = []
+    for p in pkts[3:]:
+        dec.packetin(p[1])
+        mine.append([pl.astype(np.float64) for pl in dec.ycbcr_out()])
+    dec.close()
+    assert len(mine) == n
+    for a, b in zip(mine, want):                           # HIP == oracle, bit for bit
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    out = T.play(scope, ogv, n)
+    exact = 0
+    for f in range(n):
+        scores = T.compare({"frames": [out["frames"][f]] * n}, mine, w, h)
+        g = min(range(n), key=lambda i: scores[i][0])
+        assert abs(g - f) <= 1 and scores[g][0] < 0.6 and scores[g][1] < 1.5, (f, g, scores[g])
+        exact += g == f
+    assert exact >= n - 2
