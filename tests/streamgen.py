@@ -557,8 +557,8 @@ class Stream:
             u = rng.random()
             if u < p_empty or (getattr(self, "chroma_empty", False) and plane_of[i] > 0):
                 nzpos = []           # (chroma_empty: diagnostic knob, grey pictures)
-            elif u < p_empty + p_dc_only:
-                nzpos = [0]
+            elif u < p_empty + p_dc_only or (getattr(self, "chroma_dc_only", False) and plane_of[i] > 0):
+                nzpos = [0]          # (chroma_dc_only: diagnostic knob, piecewise-constant chroma)
             else:
                 cnt = int(rng.integers(1, 12)) if rng.random() < 0.8 else int(rng.integers(12, 65))
                 nzpos = sorted(rng.choice(64, cnt, replace=False).tolist())

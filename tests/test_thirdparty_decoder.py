@@ -51,9 +51,10 @@ def play(scope, ogv, nframes):
     return out
 
 
-def make_clip(w, h, seed, nframes, lflim, max_mag, grey, force_qis=None):
+def make_clip(w, h, seed, nframes, lflim, max_mag, grey, force_qis=None, fmt=3, chroma_dc_only=False):
     from theora_amd.decoder import Decoder
-    st = streamgen.Stream(w, h, 3, seed=seed)           # 4:4:4
+    st = streamgen.Stream(w, h, fmt, seed=seed)         # 4:4:4 unless told otherwise
+    st.chroma_dc_only = chroma_dc_only
     st.setup.lflims = [lflim] * 64
     st.max_mag = max_mag
     st.chroma_empty = grey
@@ -67,7 +68,7 @@ def make_clip(w, h, seed, nframes, lflim, max_mag, grey, force_qis=None):
             del os.environ["THIP_FE_TRACE_BACKEND"]
         else:
             os.environ["THIP_FE_TRACE_BACKEND"] = old
-    ost = oracle.State(w, h, 3)
+    ost = oracle.State(w, h, fmt)
     ls = oggmux.LogicalStream(0x7E0 + seed)
     for k, p in enumerate(hdr):
         ls.add_packet(p, granulepos=0, flush=(k == 0 or k == len(hdr) - 1))
@@ -84,16 +85,32 @@ def make_clip(w, h, seed, nframes, lflim, max_mag, grey, force_qis=None):
     return b"".join(ls.pages), want, modes
 
 
+def _flat3x3(c):
+    p = np.pad(c, 1, mode="edge")
+    m = np.ones(c.shape, bool)
+    for dy in range(3):
+        for dx in range(3):
+            m &= p[dy:dy + c.shape[0], dx:dx + c.shape[1]] == c
+    return m
+
+
 def compare(out, want, w, h):
-    """Per frame: (mean, worst 8x8-block mean) absolute RGB error over in-gamut pixels, and their share."""
+    """Per frame: (mean, worst 8x8-block mean) absolute RGB error over comparable pixels, and their
+    share.  Comparable = in gamut and, for subsampled chroma, with a flat 3x3 chroma neighbourhood
+    (there the browser's chroma resampling filter, whatever it is, returns the sample itself)."""
     res = []
     for f, planes in enumerate(want):
         rgb = np.frombuffer(base64.b64decode(out["frames"][f]), np.uint8).reshape(h, w, 3).astype(np.float64)
         Y, Cb, Cr = planes
+        sub = np.ones(Y.shape, bool)
+        if Cb.shape != Y.shape:
+            ry, rx = Y.shape[0] // Cb.shape[0], Y.shape[1] // Cb.shape[1]
+            sub = np.repeat(np.repeat(_flat3x3(Cb) & _flat3x3(Cr), ry, 0), rx, 1)
+            Cb, Cr = np.repeat(np.repeat(Cb, ry, 0), rx, 1), np.repeat(np.repeat(Cr, ry, 0), rx, 1)
         raw = np.stack([1.164383 * (Y - 16) + 1.596027 * (Cr - 128),
                         1.164383 * (Y - 16) - 0.391762 * (Cb - 128) - 0.812968 * (Cr - 128),
                         1.164383 * (Y - 16) + 2.017232 * (Cb - 128)], -1)          # BT.601, limited range
-        ok = ((raw > 6) & (raw < 249)).all(-1)
+        ok = ((raw > 6) & (raw < 249)).all(-1) & sub
         err = np.abs(np.clip(np.round(raw), 0, 255) - rgb).max(-1)
         err[~ok] = np.nan
         blocks = [np.nanmean(err[y:y + 8, x:x + 8]) for y in range(0, h, 8) for x in range(0, w, 8)
@@ -130,6 +147,26 @@ def test_ffmpeg_in_chromium_agrees_with_the_oracle(browser, seed, lflim, max_mag
         assert share > 0.15, (f, share)                           # enough in-gamut pixels to mean something
         assert mean < (0.15 if grey else 0.6), (f, g, mean)     # RGB rounding only
         assert worst_block < 1.5, (f, g, worst_block)           # no 8x8 block is off by more than conversion noise
+        exact += g == f
+    assert exact >= n - 2
+
+
+@pytest.mark.parametrize("fmt", [0, 2])
+def test_subsampled_formats(browser, fmt):
+    """4:2:0 and 4:2:2: chroma vectors are derived from the luma ones (averaged over the macro block
+    for 4MV, quarter-pel units).  With DC-only chroma blocks the chroma planes are piecewise constant,
+    so wherever a 3x3 chroma neighbourhood is flat the browser's resampling is exact and the pixel can
+    be compared; a wrong chroma vector moves the flat regions."""
+    w, h, n = 64, 48, 8
+    ogv, want, modes = make_clip(w, h, 3, n, 0, 5, False, [50], fmt=fmt, chroma_dc_only=True)
+    out = play(browser, ogv, n)
+    assert len(out["frames"]) == n and len(modes) >= 6
+    exact = 0
+    for f in range(n):
+        scores = compare({"frames": [out["frames"][f]] * n}, want, w, h)
+        g = min(range(n), key=lambda i: scores[i][0])
+        assert abs(g - f) <= 1 and scores[g][2] > 0.25, (f, g, scores[g])
+        assert scores[g][0] < 0.5 and scores[g][1] < 1.5, (f, g, scores[g])
         exact += g == f
     assert exact >= n - 2
 
