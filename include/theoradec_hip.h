@@ -11,8 +11,8 @@
  * lib/decode.c:2858-2962 drives oc_state_frag_recon / oc_frag_copy_list /
  * oc_state_loop_filter_frag_rows.
  *
- * Not provided (out of scope): post-processing levels > 0, telemetry,
- * the legacy theora_* API, th_granule_* helpers beyond th_granule_frame, the encoder.
+ * Not provided (out of scope): post-processing levels > 0, the telemetry
+ * requests, the legacy theora_* API, th_granule_* helpers beyond th_granule_frame, the encoder.
  */
 #ifndef THEORADEC_HIP_H
 #define THEORADEC_HIP_H
@@ -94,6 +94,17 @@ int64_t th_granule_frame(void *encdec, int64_t granpos);
 #define TH_DECCTL_GET_PPLEVEL_MAX (1)
 #define TH_DECCTL_SET_PPLEVEL (3)
 #define TH_DECCTL_SET_GRANPOS (5)
+/* theoradec.h:79-92,141-151.  The reference calls back after every few fragment rows while the
+   frame is still being decoded; a frame is one batch of GPU work here, so the callback is made
+   ONCE per decoded frame, after it is complete and copied to the host, with the whole range of
+   fragment rows [0, frame_height/8) -- what the reference's telemetry build does
+   (decode.c:2974-2977).  The buffer is the one th_decode_ycbcr_out returns. */
+#define TH_DECCTL_SET_STRIPE_CB (7)
+typedef void (*th_stripe_decoded_func)(void *ctx, th_ycbcr_buffer buf, int yfrag0, int yfrag_end);
+typedef struct {
+  void *ctx;
+  th_stripe_decoded_func stripe_decoded;
+} th_stripe_callback;
 /* Extension (not in theoradec.h): a context allocated while THIP_FE_TRACE_BACKEND=1 is set owns no
    device state; th_decode_packetin parses the packet completely and RECORDS the accel-vtable slot
    calls of the frame (state_frag_recon per coded fragment in coded order, frag_copy_list, the loop

@@ -265,3 +265,40 @@ def test_hip_decoder_agrees_with_ffmpeg_in_chromium(hip):
         assert abs(g - f) <= 1 and scores[g][0] < 0.6 and scores[g][1] < 1.5, (f, g, scores[g])
         exact += g == f
     assert exact >= n - 2
+
+
+def test_stripe_callback(hip):
+    """TH_DECCTL_SET_STRIPE_CB (theoradec.h:79-92): called once per decoded frame with the whole
+    row range and the buffer th_decode_ycbcr_out would return; not called for duplicate frames; a
+    NULL function switches it off."""
+    import ctypes as C
+    from theora_amd import _lib
+    from theora_amd.decoder import Decoder
+    st = streamgen.Stream(64, 48, 0, seed=9)
+    dec = Decoder(st.header_packets())
+    L = _lib.load()
+    calls = []
+    FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(_lib.ThImgPlane), C.c_int, C.c_int)
+
+    def on_stripe(ctx, buf, y0, y1):
+        luma = np.ctypeslib.as_array(buf[0].data, (buf[0].height, buf[0].stride))[:, :buf[0].width].copy()
+        calls.append((ctx, y0, y1, luma))
+    cb = FN(on_stripe)
+
+    class StripeCb(C.Structure):
+        _fields_ = [("ctx", C.c_void_p), ("fn", FN)]
+    s = StripeCb(0x1234, cb)
+    assert L.th_decode_ctl(dec._dec, 7, C.byref(s), C.sizeof(s)) == 0
+    assert L.th_decode_ctl(dec._dec, 7, C.byref(s), 3) == -10          # TH_EINVAL
+    pkt, _ = st.frame(0)
+    assert dec.packetin(pkt)[0] == 0
+    assert len(calls) == 1 and calls[0][:3] == (0x1234, 0, 6)
+    assert np.array_equal(calls[0][3], dec.ycbcr_out()[0])
+    assert dec.packetin(b"")[0] == 1                                   # duplicate frame: no callback
+    assert len(calls) == 1
+    off = StripeCb(0, FN())
+    assert L.th_decode_ctl(dec._dec, 7, C.byref(off), C.sizeof(off)) == 0
+    pkt, _ = st.frame(1, density=0.9)
+    dec.packetin(pkt)
+    assert len(calls) == 1
+    dec.close()

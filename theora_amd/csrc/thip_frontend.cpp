@@ -187,6 +187,7 @@ struct th_dec_ctx {
   int granpos_bias;
   bool have_frame;
   std::vector<uint8_t> mirror[3];
+  th_stripe_callback stripe_cb;
   // slot-trace mode (THIP_FE_TRACE_BACKEND=1 at th_decode_alloc): no device state exists; the
   // vtable-slot calls of a frame are recorded instead of made (TH_DECCTL_THIP_GET_SLOT_TRACE)
   bool trace;
@@ -724,6 +725,8 @@ th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup) {
                                                    (info->version_minor == 2 && info->version_subminor >= 1))))
                         ? 1 : 0;
   d->have_frame = false;
+  d->stripe_cb.ctx = nullptr;
+  d->stripe_cb.stripe_decoded = nullptr;
   memset(&d->prof, 0, sizeof(d->prof));
   d->prof.on = getenv("THIP_FE_PROF") != nullptr;
   for (int p = 0; p < 3; p++) d->mirror[p].assign((size_t)d->nh[p] * 8 * d->nv[p] * 8, 0);
@@ -765,6 +768,11 @@ int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
       d->curframe_num = d->keyframe_num + (g & (((int64_t)1 << d->info.keyframe_granule_shift) - 1));
       return 0;
     }
+    case TH_DECCTL_SET_STRIPE_CB:
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(th_stripe_callback)) return TH_EINVAL;
+      d->stripe_cb = *(const th_stripe_callback *)buf;
+      return 0;
     case TH_DECCTL_THIP_GET_SLOT_TRACE: {
       if (!d || !buf) return TH_EFAULT;
       if (buf_sz != sizeof(thip_slot_trace)) return TH_EINVAL;
@@ -1183,6 +1191,11 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   d->have_frame = true;
   d->curframe_num++;
   if (granpos) *granpos = d->granpos;
+  if (d->stripe_cb.stripe_decoded && !d->trace) {   // decode.c:2929-2941, once for the whole frame
+    th_ycbcr_buffer yb;
+    if (th_decode_ycbcr_out(d, yb) < 0) return TH_EFAULT;
+    d->stripe_cb.stripe_decoded(d->stripe_cb.ctx, yb, 0, d->nv[0]);
+  }
   return 0;
 }
 
