@@ -76,15 +76,23 @@ def main_enc():
     resid = rng.integers(-255, 256, (nblk, 64)).astype(np.int16)
     d_res = torch.from_numpy(resid).cuda()
 
-    def timed(fn, reps=20):
+    from theora_amd import _lib
+    L = _lib.load()
+
+    def timed(fn, reps=50):
+        """Average time of one call when the calls are enqueued back to back on one stream
+        (thip_set_batch_stream(..., synchronous=0)): kernel time, not launch-and-wait time."""
         fn()
         torch.cuda.synchronize()
+        s = torch.cuda.current_stream()
+        L.thip_set_batch_stream(s.cuda_stream, 0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(s)
         for _ in range(reps):
             fn()
-        e1.record()
+        e1.record(s)
         torch.cuda.synchronize()
+        L.thip_set_batch_stream(None, 1)
         return e0.elapsed_time(e1) * 1e-3 / reps
 
     results = []

@@ -220,6 +220,13 @@ int thip_enc_frag_sub_batch(int16_t *diff, const uint8_t *src_plane, const uint8
 int thip_enc_frag_copy2_batch(uint8_t *dst_plane, const uint8_t *src_plane, int ystride,
                               const int32_t *dst_offs, const int32_t *src1_offs,
                               const int32_t *src2_offs, int64_t n);
+/* The batched single-slot and encoder entry points of this header (thip_idct8x8_batch ...
+   thip_enc_quantize_batch) run on the null stream and return when the work is done, like the C
+   slots they stand for.  An encoder that chains them (sub -> fdct -> quantize ...) sets a stream
+   of its own and synchronous = 0: the calls then only enqueue, in order, on that stream (a
+   hipStream_t; NULL = the null stream) and the caller synchronises when it needs the results.
+   Process-wide setting. */
+int thip_set_batch_stream(void *stream, int synchronous);
 /* oc_enc_fdct8x8 (fdct.c:128): natural-order int16 in, ZIG-ZAG-ordered int16 out. */
 int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n);
 /* oc_enc_quantize (enquant.c:219) with the reciprocals of oc_enc_enquant_table_init

@@ -73,6 +73,7 @@ SYMBOLS = [
     ("thip_enc_frag_border_ssd_batch", _I, [_P, _P, _P, _I, _P, _P, _P, _I64]),
     ("thip_enc_frag_sub_batch", _I, [_P, _P, _P, _I, _P, _P, _I64]),
     ("thip_enc_frag_copy2_batch", _I, [_P, _P, _I, _P, _P, _P, _I64]),
+    ("thip_set_batch_stream", _I, [_P, _I]),
     ("thip_enc_fdct8x8_batch", _I, [_P, _P, _I64]),
     ("thip_enc_quantize_batch", _I, [_P, _P, _P, _P, _I64]),
     ("thip_profile_enable", _I, [_I]),

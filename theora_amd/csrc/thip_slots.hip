@@ -375,19 +375,29 @@ __global__ __launch_bounds__(256) void k_enc_quantize(int16_t *qdct, int32_t *no
   nonzero[i] = nz;
 }
 
+// Stream and completion policy of the batched entry points below (thip_set_batch_stream).
+static hipStream_t g_batch_stream = nullptr;
+static int g_batch_sync = 1;
+
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
 extern "C" {
+
+int thip_set_batch_stream(void *stream, int synchronous) {
+  g_batch_stream = (hipStream_t)stream;
+  g_batch_sync = synchronous ? 1 : 0;
+  return THIP_OK;
+}
 
 int thip_enc_quantize_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t *dequant,
                             int64_t n) {
   if (!qdct || !nonzero || !dct || !dequant) return THIP_EFAULT;
   if (n < 0) return THIP_EINVAL;
   if (n == 0) return THIP_OK;
-  hipLaunchKernelGGL(k_enc_quantize, grid_for(n), dim3(256), 0, 0, qdct, nonzero, dct, dequant, n);
+  hipLaunchKernelGGL(k_enc_quantize, grid_for(n), dim3(256), 0, g_batch_stream, qdct, nonzero, dct, dequant, n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
 }
 
@@ -395,9 +405,9 @@ int thip_idct8x8_batch(int16_t *y, const int16_t *x, const int32_t *last_zzi, in
   if (!y || !x) return THIP_EFAULT;
   if (n < 0) return THIP_EINVAL;
   if (n == 0) return THIP_OK;
-  hipLaunchKernelGGL(k_idct_batch, grid_for(n), dim3(256), 0, 0, y, x, last_zzi, n);
+  hipLaunchKernelGGL(k_idct_batch, grid_for(n), dim3(256), 0, g_batch_stream, y, x, last_zzi, n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
 }
 
@@ -409,16 +419,16 @@ int thip_frag_recon_batch(uint8_t *dst_frame, const uint8_t *src_frame, int ystr
   if ((nsrc >= 1 && (!src_frame || !src1_offs)) || (nsrc == 2 && !src2_offs)) return THIP_EFAULT;
   if (n == 0) return THIP_OK;
   if (nsrc == 0)
-    hipLaunchKernelGGL(k_frag_recon_batch<0>, grid_for(n), dim3(256), 0, 0, dst_frame, src_frame, ystride,
+    hipLaunchKernelGGL(k_frag_recon_batch<0>, grid_for(n), dim3(256), 0, g_batch_stream, dst_frame, src_frame, ystride,
                        dst_offs, src1_offs, src2_offs, residue, n);
   else if (nsrc == 1)
-    hipLaunchKernelGGL(k_frag_recon_batch<1>, grid_for(n), dim3(256), 0, 0, dst_frame, src_frame, ystride,
+    hipLaunchKernelGGL(k_frag_recon_batch<1>, grid_for(n), dim3(256), 0, g_batch_stream, dst_frame, src_frame, ystride,
                        dst_offs, src1_offs, src2_offs, residue, n);
   else
-    hipLaunchKernelGGL(k_frag_recon_batch<2>, grid_for(n), dim3(256), 0, 0, dst_frame, src_frame, ystride,
+    hipLaunchKernelGGL(k_frag_recon_batch<2>, grid_for(n), dim3(256), 0, g_batch_stream, dst_frame, src_frame, ystride,
                        dst_offs, src1_offs, src2_offs, residue, n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
 }
 
@@ -427,10 +437,10 @@ int thip_frag_copy_list_batch(uint8_t *dst_frame, const uint8_t *src_frame, int 
   if (!dst_frame || !src_frame || !fragis || !frag_buf_offs) return THIP_EFAULT;
   if (nfragis < 0) return THIP_EINVAL;
   if (nfragis == 0) return THIP_OK;
-  hipLaunchKernelGGL(k_frag_copy_list, grid_for(nfragis), dim3(256), 0, 0, dst_frame, src_frame, ystride,
+  hipLaunchKernelGGL(k_frag_copy_list, grid_for(nfragis), dim3(256), 0, g_batch_stream, dst_frame, src_frame, ystride,
                      fragis, nfragis, frag_buf_offs);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
 }
 
@@ -446,7 +456,7 @@ int thip_enc_frag_metric_batch(int op, uint32_t *out, int32_t *dc_out, const uin
   if (n == 0) return THIP_OK;
 #define LAUNCH_METRIC(OPC)                                                                              \
   case OPC:                                                                                             \
-    hipLaunchKernelGGL(k_enc_metric<OPC>, grid_for(n), dim3(256), 0, 0, out, dc_out, src_plane, ref_plane, \
+    hipLaunchKernelGGL(k_enc_metric<OPC>, grid_for(n), dim3(256), 0, g_batch_stream, out, dc_out, src_plane, ref_plane, \
                        ystride, src_offs, ref_offs, ref2_offs, thresh, n);                              \
     break;
   switch (op) {
@@ -461,7 +471,7 @@ int thip_enc_frag_metric_batch(int op, uint32_t *out, int32_t *dc_out, const uin
   }
 #undef LAUNCH_METRIC
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
 }
 
@@ -471,10 +481,10 @@ int thip_enc_frag_border_ssd_batch(uint32_t *out, const uint8_t *src_plane, cons
   if (!out || !src_plane || !ref_plane || !src_offs || !ref_offs || !masks) return THIP_EFAULT;
   if (n < 0) return THIP_EINVAL;
   if (n == 0) return THIP_OK;
-  hipLaunchKernelGGL(k_enc_border_ssd, grid_for(n), dim3(256), 0, 0, out, src_plane, ref_plane, ystride,
+  hipLaunchKernelGGL(k_enc_border_ssd, grid_for(n), dim3(256), 0, g_batch_stream, out, src_plane, ref_plane, ystride,
                      src_offs, ref_offs, masks, n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
 }
 
@@ -483,10 +493,10 @@ int thip_enc_frag_sub_batch(int16_t *diff, const uint8_t *src_plane, const uint8
   if (!diff || !src_plane || !src_offs || (ref_offs && !ref_plane)) return THIP_EFAULT;
   if (n < 0) return THIP_EINVAL;
   if (n == 0) return THIP_OK;
-  hipLaunchKernelGGL(k_enc_sub, grid_for(n), dim3(256), 0, 0, diff, src_plane, ref_plane, ystride, src_offs,
+  hipLaunchKernelGGL(k_enc_sub, grid_for(n), dim3(256), 0, g_batch_stream, diff, src_plane, ref_plane, ystride, src_offs,
                      ref_offs, n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
 }
 
@@ -496,10 +506,10 @@ int thip_enc_frag_copy2_batch(uint8_t *dst_plane, const uint8_t *src_plane, int 
   if (!dst_plane || !src_plane || !dst_offs || !src1_offs || !src2_offs) return THIP_EFAULT;
   if (n < 0) return THIP_EINVAL;
   if (n == 0) return THIP_OK;
-  hipLaunchKernelGGL(k_enc_copy2, grid_for(n), dim3(256), 0, 0, dst_plane, src_plane, ystride, dst_offs,
+  hipLaunchKernelGGL(k_enc_copy2, grid_for(n), dim3(256), 0, g_batch_stream, dst_plane, src_plane, ystride, dst_offs,
                      src1_offs, src2_offs, n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
 }
 
@@ -507,9 +517,9 @@ int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n) {
   if (!y || !x) return THIP_EFAULT;
   if (n < 0) return THIP_EINVAL;
   if (n == 0) return THIP_OK;
-  hipLaunchKernelGGL(k_enc_fdct, grid_for(n), dim3(256), 0, 0, y, x, n);
+  hipLaunchKernelGGL(k_enc_fdct, grid_for(n), dim3(256), 0, g_batch_stream, y, x, n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
 }
 
