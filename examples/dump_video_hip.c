@@ -18,23 +18,22 @@
 #include "thip_ogg.h"
 #include "theoradec_hip.h"
 
+/* One frame: every plane's rectangle, row by row.  The rectangle is the coded frame, or the picture
+   region with --crop; chroma rectangles follow from the luma one by the format's decimation, rounding
+   the far edge up (dump_video.c:206-241 writes the same bytes). */
 static void write_frame(FILE *out, const th_info *ti, th_ycbcr_buffer yb, int crop, int raw) {
-  int x0 = 0, y0 = 0, xend = (int)ti->frame_width, yend = (int)ti->frame_height;
-  int pli, hdec = 0, vdec = 0;
-  if (crop) {
-    x0 = (int)ti->pic_x;
-    y0 = (int)ti->pic_y;
-    xend = x0 + (int)ti->pic_width;
-    yend = y0 + (int)ti->pic_height;
-  }
+  const int left = crop ? (int)ti->pic_x : 0, top = crop ? (int)ti->pic_y : 0;
+  const int right = crop ? left + (int)ti->pic_width : (int)ti->frame_width;
+  const int bottom = crop ? top + (int)ti->pic_height : (int)ti->frame_height;
+  int pli;
   if (!raw) fputs("FRAME\n", out);
   for (pli = 0; pli < 3; pli++) {
-    int y;
-    for (y = y0 >> vdec; y < ((yend + vdec) >> vdec); y++)
-      fwrite(yb[pli].data + (size_t)yb[pli].stride * (size_t)y + (x0 >> hdec), 1,
-             (size_t)(((xend + hdec) >> hdec) - (x0 >> hdec)), out);
-    hdec = !(ti->pixel_fmt & 1);
-    vdec = !(ti->pixel_fmt & 2);
+    const int sx = pli && !(ti->pixel_fmt & 1), sy = pli && !(ti->pixel_fmt & 2); /* log2 decimation of this plane */
+    const int col0 = left >> sx, ncols = ((right + sx) >> sx) - col0;
+    const int row1 = (bottom + sy) >> sy;
+    int row;
+    for (row = top >> sy; row < row1; row++)
+      fwrite(yb[pli].data + (size_t)row * (size_t)yb[pli].stride + (size_t)col0, 1, (size_t)ncols, out);
   }
 }
 
