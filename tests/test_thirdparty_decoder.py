@@ -138,6 +138,7 @@ def test_ffmpeg_in_chromium_agrees_with_the_oracle(browser, seed, lflim, max_mag
     # pictures (to within RGB rounding) at index f or f+-1, and nearly all of them at index f --
     # which, inter frames depending on all their predecessors, covers the whole sequence.
     exact = 0
+    seen = {}
     for f in range(n):
         one = {"frames": [out["frames"][f]] * n}
         scores = compare(one, want, w, h)
@@ -148,7 +149,23 @@ def test_ffmpeg_in_chromium_agrees_with_the_oracle(browser, seed, lflim, max_mag
         assert mean < (0.15 if grey else 0.6), (f, g, mean)     # RGB rounding only
         assert worst_block < 1.5, (f, g, worst_block)           # no 8x8 block is off by more than conversion noise
         exact += g == f
+        if grey and g == f:
+            # grey pictures make the comparison EXACT: R = G = B is a function of Y alone and, its slope
+            # being above 1, an injective one.  So over all in-gamut pixels the browser's R must be a
+            # single-valued, injective function of the oracle's Y -- any +-1 disagreement in a decoded luma
+            # sample would give one Y two different R.  (No formula for the conversion is assumed.)
+            rgb = np.frombuffer(base64.b64decode(out["frames"][f]), np.uint8).reshape(h, w, 3)
+            Y = want[f][0].astype(np.int64)
+            sel = (Y >= 24) & (Y <= 228)
+            assert (rgb[..., 0][sel] == rgb[..., 1][sel]).all() and (rgb[..., 1][sel] == rgb[..., 2][sel]).all()
+            for y, r in zip(Y[sel].ravel(), rgb[..., 0][sel].ravel()):
+                seen.setdefault(int(y), set()).add(int(r))
     assert exact >= n - 2
+    if grey:
+        assert len(seen) > 100                                        # most luma levels occurred
+        assert all(len(v) == 1 for v in seen.values()), {k: v for k, v in seen.items() if len(v) > 1}
+        rs = [next(iter(v)) for _, v in sorted(seen.items())]
+        assert all(b > a for a, b in zip(rs, rs[1:]))                 # strictly increasing: injective
 
 
 @pytest.mark.parametrize("fmt", [0, 2])
