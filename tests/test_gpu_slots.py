@@ -248,3 +248,39 @@ def test_enc_quantize(hip):
         nz = torch.empty(n, dtype=torch.int32, device="cuda")
         assert L.thip_enc_quantize_batch(q.data_ptr(), nz.data_ptr(), dev(dct).data_ptr(), dev(dq).data_ptr(), n) == 0
         assert np.array_equal(want_q, q.cpu().numpy()) and np.array_equal(want_nz, nz.cpu().numpy()), trial
+
+
+def test_enc_chain_on_a_caller_stream(hip):
+    """thip_set_batch_stream(stream, 0): residual -> forward DCT -> quantiser enqueued back to back
+    on a caller-owned stream, no host wait in between, one synchronisation at the end -- the result
+    is what the three C slots give one after the other (encfrag.c:21, fdct.c:128, enquant.c:219)."""
+    from theora_amd import _lib
+    import torch
+    rng = np.random.default_rng(12)
+    stride, src, ref, so, ro, _ = _enc_planes(rng)
+    n = so.size
+    L, O = _lib.load(), oracle.lib()
+    dq = rng.integers(8, 600, 64).astype(np.uint16)
+    want_res = np.empty((n, 64), np.int16)
+    for i in range(n):
+        O.orc_enc_frag_sub(want_res[i].ctypes.data, src.ctypes.data + int(so[i]), ref.ctypes.data + int(ro[i]), stride)
+    want_dct = oracle.fdct8x8_batch(want_res)
+    want_q, want_nz = oracle.quantize_batch(want_dct, dq)
+    s = torch.cuda.Stream()
+    d_src, d_ref, d_so, d_ro, d_dq = dev(src), dev(ref), dev(so), dev(ro), dev(dq)
+    res = torch.empty((n, 64), dtype=torch.int16, device="cuda")
+    dct = torch.empty_like(res)
+    q = torch.empty_like(res)
+    nz = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert L.thip_set_batch_stream(s.cuda_stream, 0) == 0
+    try:
+        assert L.thip_enc_frag_sub_batch(res.data_ptr(), d_src.data_ptr(), d_ref.data_ptr(), stride, d_so.data_ptr(),
+                                         d_ro.data_ptr(), n) == 0
+        assert L.thip_enc_fdct8x8_batch(dct.data_ptr(), res.data_ptr(), n) == 0
+        assert L.thip_enc_quantize_batch(q.data_ptr(), nz.data_ptr(), dct.data_ptr(), d_dq.data_ptr(), n) == 0
+        s.synchronize()
+    finally:
+        L.thip_set_batch_stream(None, 1)
+    assert np.array_equal(q.cpu().numpy(), want_q) and np.array_equal(nz.cpu().numpy(), want_nz)
+    assert np.array_equal(dct.cpu().numpy(), want_dct)
