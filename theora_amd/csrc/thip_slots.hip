@@ -57,15 +57,63 @@ __device__ __forceinline__ void store_block16(int16_t *p, const int v[64]) {
   }
 }
 
+// Wave-cooperative forms of the two functions above for arrays of consecutive blocks (block i of
+// the array belongs to thread i).  A thread that fetches its own 128-byte block makes every load
+// instruction of the wave touch 64 different cache lines; instead the wave moves its 64 blocks
+// (8 KB contiguous) with eight fully coalesced 1-KB instructions and redistributes through LDS.
+// Piece p of block b is parked at int4 index b*8 + ((p + b) & 7): the rotation keeps both the
+// linear side and the per-block side free of bank conflicts.  All 64 lanes must call; `i < n`
+// says whether this lane's block exists (the others move nothing).  lds: 512 int4 per wave.
+__device__ __forceinline__ void load_block16_wave(int v[64], const int16_t *array, int64_t i, int64_t n, int4 *lds) {
+  const int lane = (int)threadIdx.x & 63;
+  const int64_t b0 = i - lane;                                     // first block of the wave
+  const int4 *g = reinterpret_cast<const int4 *>(array) + b0 * 8;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int idx = q * 64 + lane, b = idx >> 3, pc = idx & 7;
+    if (b0 + b < n) lds[b * 8 + ((pc + b) & 7)] = g[idx];
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int4 w = lds[lane * 8 + ((r + lane) & 7)];
+    const int w4[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      v[r * 8 + 2 * k] = sx16(w4[k]);
+      v[r * 8 + 2 * k + 1] = w4[k] >> 16;
+    }
+  }
+}
+__device__ __forceinline__ void store_block16_wave(int16_t *array, int64_t i, int64_t n, const int v[64], int4 *lds) {
+  const int lane = (int)threadIdx.x & 63;
+  const int64_t b0 = i - lane;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    int4 w;
+    w.x = (v[r * 8 + 0] & 0xFFFF) | (v[r * 8 + 1] << 16);
+    w.y = (v[r * 8 + 2] & 0xFFFF) | (v[r * 8 + 3] << 16);
+    w.z = (v[r * 8 + 4] & 0xFFFF) | (v[r * 8 + 5] << 16);
+    w.w = (v[r * 8 + 6] & 0xFFFF) | (v[r * 8 + 7] << 16);
+    lds[lane * 8 + ((r + lane) & 7)] = w;
+  }
+  int4 *g = reinterpret_cast<int4 *>(array) + b0 * 8;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int idx = q * 64 + lane, b = idx >> 3, pc = idx & 7;
+    if (b0 + b < n) g[idx] = lds[b * 8 + ((pc + b) & 7)];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_idct_batch(int16_t *y, const int16_t *x, const int32_t *last_zzi,
                                                    int64_t n) {
+  __shared__ int4 s_x[4 * 512];
+  int4 *lds = s_x + (threadIdx.x >> 6) * 512;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   int v[64];
-  load_block16(v, x + i * 64);
-  idct_mask_by_last_zzi(v, last_zzi ? last_zzi[i] : 64);
+  load_block16_wave(v, x, i, n, lds);
+  idct_mask_by_last_zzi(v, (last_zzi && i < n) ? last_zzi[i] : 64);
   idct8x8(v);
-  store_block16(y + i * 64, v);
+  store_block16_wave(y, i, n, v, lds);
 }
 
 template <int NSRC>
@@ -312,10 +360,11 @@ __device__ constexpr int kFZigZag[64] = {
     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 __global__ __launch_bounds__(256) void k_enc_fdct(int16_t *y, const int16_t *x, int64_t n) {
+  __shared__ int4 s_x[4 * 512];
+  int4 *lds = s_x + (threadIdx.x >> 6) * 512;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   int w[64];
-  load_block16(w, x + i * 64);
+  load_block16_wave(w, x, i, n, lds);
 #pragma unroll
   for (int k = 0; k < 64; k++) w[k] = sx16(w[k] << 2);        // fdct.c:136
   w[0] = sx16(w[0] + (w[0] != 0) + 1);                        // fdct.c:139-141
@@ -336,7 +385,7 @@ __global__ __launch_bounds__(256) void k_enc_fdct(int16_t *y, const int16_t *x, 
   int o[64];
 #pragma unroll
   for (int k = 0; k < 64; k++) o[k] = sx16((w[kFZigZag[k]] + 2) >> 2);   // fdct.c:149
-  store_block16(y + i * 64, o);
+  store_block16_wave(y, i, n, o, lds);
 }
 
 // oc_enc_quantize_c (enquant.c:219-248); the {m,l} reciprocal of each step is derived in
@@ -353,10 +402,11 @@ __global__ __launch_bounds__(256) void k_enc_quantize(int16_t *qdct, int32_t *no
     s_l[threadIdx.x] = l;
   }
   __syncthreads();
+  __shared__ int4 s_x[4 * 512];
+  int4 *lds = s_x + (threadIdx.x >> 6) * 512;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   int v[64];
-  load_block16(v, dct + i * 64);
+  load_block16_wave(v, dct, i, n, lds);
   int nz = 0;
 #pragma unroll
   for (int z = 0; z < 64; z++) {
@@ -371,8 +421,8 @@ __global__ __launch_bounds__(256) void k_enc_quantize(int16_t *qdct, int32_t *no
     }
     v[z] = q;
   }
-  store_block16(qdct + i * 64, v);
-  nonzero[i] = nz;
+  store_block16_wave(qdct, i, n, v, lds);
+  if (i < n) nonzero[i] = nz;
 }
 
 // Stream and completion policy of the batched entry points below (thip_set_batch_stream).
