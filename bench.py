@@ -218,6 +218,19 @@ def main_e2e(main_args, argv):
                 r = subprocess.run([exe] + extra + [ogv], capture_output=True, text=True, timeout=600)
                 print(json.dumps({"metric": "dump_video_hip on an Ogg file (%s 4:2:0, %s)" % (args.size, label),
                                   "stderr": r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "", "rc": r.returncode}))
+            # many streams, one native host thread each (examples/decode_bench.c)
+            nb = os.path.join(ROOT, "examples", "decode_bench")
+            if os.path.exists(nb):
+                for nt in (1, 8, 32, 64):
+                    r = subprocess.run([nb, ogv, str(nt), "2"], capture_output=True, text=True, timeout=900)
+                    line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "{}"
+                    try:
+                        d = json.loads(line)
+                    except ValueError:
+                        d = {"raw": line}
+                    d["metric"] = "decode_bench: concurrent %s streams, native threads, packets -> host YUV" % args.size
+                    d["rc"] = r.returncode
+                    print(json.dumps(d))
 
 
 
