@@ -111,7 +111,9 @@ int ensure_lanes() {   // callable with or without g_mu held, from any host thre
   return 0;
 }
 
+std::mutex g_prof_mu;   // guards g_events / g_pool (touched from launch paths only while profiling)
 hipEvent_t take_event() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_pool.empty()) {
     hipEvent_t e = g_pool.back();
     g_pool.pop_back();
@@ -138,6 +140,7 @@ struct ScopedTimer {
   ~ScopedTimer() {
     if (on) {
       (void)hipEventRecord(p.b, s);
+      std::lock_guard<std::mutex> lk(g_prof_mu);
       g_events.push_back(p);
     }
   }
@@ -373,7 +376,7 @@ int thip_profile_enable(int on) {
 }
 
 int thip_profile_reset(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   HIP_TRY(hipDeviceSynchronize());
   for (auto &p : g_events) {
     g_pool.push_back(p.a);
@@ -384,7 +387,7 @@ int thip_profile_reset(void) {
 }
 
 int thip_profile_read(int64_t launches[THIP_NKERNELS], double ms[THIP_NKERNELS]) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   HIP_TRY(hipDeviceSynchronize());
   for (int k = 0; k < THIP_NKERNELS; k++) {
     launches[k] = 0;
@@ -471,7 +474,9 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   // is off by default; DESIGN.md section 5.
   static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 0;
   if (fuse && any_lf) {
+    static std::mutex attr_mu;
     static bool attr_set = false;
+    std::lock_guard<std::mutex> alk(attr_mu);
     if (!attr_set) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_recon_lf), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   kSegMax * kChunkBytes));
@@ -512,7 +517,9 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
                        void *stream, int32_t *results) {
   if (!states || !descs) return THIP_EFAULT;
   if (nstreams < 0) return THIP_EINVAL;
-  std::lock_guard<std::mutex> lk(g_mu);
+  // No library-wide lock around the launches: a state belongs to the calling thread, the HIP
+  // runtime is thread safe, and contexts on different host threads must not queue behind each
+  // other here.  Only the lane assignment is shared.
   if (stream) {   // caller-owned stream: everything in submission order on it
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < nstreams; i += THIP_MAX_BATCH) {
@@ -526,7 +533,10 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
   if (rc) return rc;
   for (int i = 0; i < nstreams; i++) {
     if (!states[i]) return THIP_EFAULT;
-    if (states[i]->lane < 0) states[i]->lane = g_next_lane++ % g_nlanes;
+    if (states[i]->lane < 0) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      states[i]->lane = g_next_lane++ % g_nlanes;
+    }
   }
   // group by lane (order inside a lane preserved), launch chunk by chunk
   for (int lane = 0; lane < g_nlanes; lane++) {
