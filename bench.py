@@ -35,6 +35,44 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec peak
 KF_INTERVAL = 64
 
 
+def _usable_cores():
+    """CPU cores this process may really use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _cpu_worker(job):
+    """One process of the all-cores CPU baseline: the oracle decoding `nframes` frames of stream 0
+    (regenerated here from its seed: nothing but numbers crosses the process boundary)."""
+    size, content, pool, nframes = job
+    import oracle
+    import theora_amd
+    from theora_amd import shard, synth
+    w, h = SIZES[size]
+    geom = synth.Geometry(w, h)
+    rng = np.random.default_rng(shard.stream_seed(12345, 0))
+    frames = [synth.gen_frame(geom, rng, theora_amd.INTRA_FRAME, content, flimit=2)]
+    for _ in range(pool):
+        frames.append(synth.gen_frame(geom, rng, theora_amd.INTER_FRAME, content, flimit=2))
+    ost = oracle.State(w, h)
+    t = 0.0
+    for i in range(nframes):
+        fr = frames[0 if i % KF_INTERVAL == 0 else 1 + (i % pool)]
+        ost.refi[:] = fr["refi"]
+        ost.mvs[:] = ((fr["mvx"] & 0xFF) | (fr["mvy"] << 8)).astype(np.int16)
+        t0 = time.perf_counter()
+        ost.decode_frame(fr["frame_type"], fr["coded_fragis"], fr["ncoded"], fr["coeffs"], fr["last_zzi"],
+                         fr["dc_quant"], fr["uncoded_fragis"], fr["flimit"])
+        t += time.perf_counter() - t0
+    return t
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="decode", choices=["decode", "enc", "e2e"])
@@ -47,6 +85,7 @@ def parse_args():
     ap.add_argument("--pool", type=int, default=6, help="distinct inter-frame command streams per stream")
     ap.add_argument("--cpu-frames", type=int, default=288, help="frames of stream 0 the CPU oracle decodes (~10 s at 4K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-process-per-core leg of the CPU baseline")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_known_args()
 
@@ -332,6 +371,16 @@ def main():
         ost.close()
         if not ok:
             raise SystemExit("bench: GPU output differs from the oracle -- refusing to report a number")
+        # the same decoder on every core the box gives us, one process per core (the reference is
+        # single-threaded per stream; many streams are many processes)
+        ncores = min(_usable_cores(), 64)
+        if ncores > 1 and not args.no_cpu_all_cores:
+            import multiprocessing as mp
+            per = max(16, nf // 4)
+            with mp.get_context("spawn").Pool(ncores) as pool_:
+                times = pool_.map(_cpu_worker, [(args.size, args.content, args.pool, per)] * ncores)
+            cpu_baseline["all_cores"] = {"value": round(ncores * per / max(times), 2), "unit": "frames/s", "cores": ncores,
+                                         "sample": "%d processes x %d frames, decode time of the slowest" % (ncores, per)}
 
     # ---- timed region ---------------------------------------------------------------------
     # Pass A: exactly K steps, no instrumentation -> `value`.
