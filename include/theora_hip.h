@@ -150,7 +150,8 @@ int thip_synchronize(void);
 /* ------------------------------------------------------------------------------------
  * Host-enqueue form of the same path: the vtable slots as the reference calls them, one
  * fragment at a time from decode.c:1584 / :1601 / :2882.  They only stage into pinned
- * memory; thip_frame_flush uploads and launches.
+ * memory; thip_frame_flush launches the kernels, which read the pinned staging in place
+ * across PCIe (THIP_ZEROCOPY=0 in the environment copies it to device memory first).
  * ---------------------------------------------------------------------------------- */
 /* Where th_decode_packetin picks the SELF buffer (decode.c:2790-2794). */
 int thip_frame_begin(thip_state *st, int frame_type);
