@@ -526,7 +526,8 @@ __device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const R
     P[q * 4 + 3] = w.w;
   }
   const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
-  pk_mask_by_last_zzi(P, last_zzi);
+  // the masks are all ones for last_zzi > 10: ~100 instructions skipped when no owner needs them
+  if (__any(L.has_coeff && last_zzi <= 10)) pk_mask_by_last_zzi(P, last_zzi);
   const bool all_zz10 = !__any(L.has_coeff && last_zzi > 10);
   pk_idct8x8(P, Y, all_zz10);
 }
