@@ -302,3 +302,29 @@ def test_stripe_callback(hip):
     dec.packetin(pkt)
     assert len(calls) == 1
     dec.close()
+
+
+def test_contexts_release_their_device_memory(hip):
+    """th_decode_alloc ... th_decode_free in a loop: device memory in use afterwards is what it was
+    before (three frames, the coded map, staging and the pinned output image all go back)."""
+    import torch
+    from theora_amd.decoder import Decoder
+    st = streamgen.Stream(176, 144, 0, seed=2)
+    hdr = st.header_packets()
+    pkts = [st.frame(0)[0], st.frame(1, density=0.8)[0]]
+
+    def cycle():
+        dec = Decoder(hdr)
+        for p in pkts:
+            dec.packetin(p)
+            dec.ycbcr_out()
+        dec.close()
+    for _ in range(3):
+        cycle()                       # first uses create streams, load code objects, warm allocator pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(60):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)
