@@ -89,6 +89,17 @@ int th_decode_packetin(th_dec_ctx *dec, const ogg_packet *op, int64_t *granpos);
 int th_decode_ycbcr_out(th_dec_ctx *dec, th_ycbcr_buffer ycbcr);
 void th_decode_free(th_dec_ctx *dec);
 int64_t th_granule_frame(void *encdec, int64_t granpos);
+double th_granule_time(void *encdec, int64_t granpos);                      /* state.c:1259 */
+
+/* codec.h "Basic shared functions" and comment helpers (internal.c:189-210, info.c) */
+const char *th_version_string(void);
+uint32_t th_version_number(void);                                          /* bitstream 3.2.1 -> 0x030201 */
+int th_packet_isheader(ogg_packet *op);
+int th_packet_iskeyframe(ogg_packet *op);                                  /* 1 key, 0 delta (or empty), -1 header */
+void th_comment_add(th_comment *tc, const char *comment);
+void th_comment_add_tag(th_comment *tc, const char *tag, const char *value);
+char *th_comment_query(th_comment *tc, const char *tag, int count);        /* value of the count-th TAG=, or NULL */
+int th_comment_query_count(th_comment *tc, const char *tag);
 
 /* th_decode_ctl requests that are honoured (theoradec.h:40-105) */
 #define TH_DECCTL_GET_PPLEVEL_MAX (1)

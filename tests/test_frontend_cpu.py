@@ -80,3 +80,35 @@ def test_trace_request_needs_a_trace_context(trace_env):
     t = dec.slot_trace()
     assert t["fragi"].size + t["uncoded"].size == truth["coded"].size
     dec.close()
+
+
+def test_small_codec_h_helpers(trace_env):
+    """th_version_*, th_packet_isheader / _iskeyframe, th_granule_time, th_comment_* (codec.h;
+    internal.c:189-210, state.c:1259, info.c) -- the bits of the API players call around the decoder."""
+    import ctypes as C
+    from theora_amd import _lib
+    from theora_amd.decoder import Decoder, _packet
+    L = _lib.load()
+    assert L.th_version_number() == 0x030201 and b"theora" in L.th_version_string()
+    st = streamgen.Stream(32, 32, 0, seed=4)
+    hdr = st.header_packets()
+    dec = Decoder(hdr)
+    key, _ = st.frame(0)
+    delta, _ = st.frame(1, density=0.9)
+    for data, want_hdr, want_key in ((hdr[0], 1, -1), (hdr[2], 1, -1), (key, 0, 1), (delta, 0, 0), (b"", 0, 0)):
+        op, keep = _packet(data)
+        assert L.th_packet_isheader(C.byref(op)) == want_hdr
+        assert L.th_packet_iskeyframe(C.byref(op)) == want_key
+    rc, gp0 = dec.packetin(key)
+    rc, gp1 = dec.packetin(delta)
+    assert L.th_granule_frame(dec._dec, gp0) == 0 and L.th_granule_frame(dec._dec, gp1) == 1
+    assert abs(L.th_granule_time(dec._dec, gp1) - 2 / 30.0) < 1e-12 and L.th_granule_time(dec._dec, -1) == -1
+    tc = dec.comment
+    assert L.th_comment_query_count(C.byref(tc), b"title") == 1                      # case-insensitive tag
+    assert C.string_at(L.th_comment_query(C.byref(tc), b"TITLE", 0)) == b"gen"
+    assert L.th_comment_query(C.byref(tc), b"TITLE", 1) is None and L.th_comment_query(C.byref(tc), b"ARTIST", 0) is None
+    L.th_comment_add_tag(C.byref(tc), b"Artist", b"nobody")
+    L.th_comment_add(C.byref(tc), b"ARTIST=somebody")
+    assert L.th_comment_query_count(C.byref(tc), b"artist") == 2
+    assert C.string_at(L.th_comment_query(C.byref(tc), b"artist", 1)) == b"somebody"
+    dec.close()

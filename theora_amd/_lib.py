@@ -120,6 +120,15 @@ DEC_SYMBOLS = [
     ("th_decode_ycbcr_out", _I, [_P, C.POINTER(ThImgPlane)]),
     ("th_decode_free", None, [_P]),
     ("th_granule_frame", _I64, [_P, _I64]),
+    ("th_granule_time", C.c_double, [_P, _I64]),
+    ("th_version_string", C.c_char_p, []),
+    ("th_version_number", C.c_uint32, []),
+    ("th_packet_isheader", _I, [C.POINTER(OggPacket)]),
+    ("th_packet_iskeyframe", _I, [C.POINTER(OggPacket)]),
+    ("th_comment_add", None, [C.POINTER(ThComment), C.c_char_p]),
+    ("th_comment_add_tag", None, [C.POINTER(ThComment), C.c_char_p, C.c_char_p]),
+    ("th_comment_query", C.c_void_p, [C.POINTER(ThComment), C.c_char_p, _I]),
+    ("th_comment_query_count", _I, [C.POINTER(ThComment), C.c_char_p]),
 ]
 
 # include/thip_ogg.h

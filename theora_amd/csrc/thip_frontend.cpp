@@ -639,6 +639,72 @@ void th_comment_clear(th_comment *tc) {
   memset(tc, 0, sizeof(*tc));
 }
 
+// codec.h:545-589: tags are compared without regard to case, up to the '='
+static int tag_matches(const char *comment, const char *tag, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    char a = comment[i], b = tag[i];
+    if (a >= 'a' && a <= 'z') a = (char)(a - 32);
+    if (b >= 'a' && b <= 'z') b = (char)(b - 32);
+    if (a != b || !a) return 0;
+  }
+  return comment[n] == '=';
+}
+void th_comment_add(th_comment *tc, const char *comment) {
+  if (!tc || !comment) return;
+  char **uc = (char **)realloc(tc->user_comments, sizeof(char *) * (size_t)(tc->comments + 2));
+  if (!uc) return;
+  tc->user_comments = uc;
+  int *cl = (int *)realloc(tc->comment_lengths, sizeof(int) * (size_t)(tc->comments + 2));
+  if (!cl) return;
+  tc->comment_lengths = cl;
+  const size_t len = strlen(comment);
+  char *c = (char *)malloc(len + 1);
+  if (!c) return;
+  memcpy(c, comment, len + 1);
+  tc->user_comments[tc->comments] = c;
+  tc->comment_lengths[tc->comments] = (int)len;
+  tc->comments++;
+  tc->user_comments[tc->comments] = nullptr;
+}
+void th_comment_add_tag(th_comment *tc, const char *tag, const char *val) {
+  if (!tc || !tag || !val) return;
+  const size_t tl = strlen(tag), vl = strlen(val);
+  char *c = (char *)malloc(tl + vl + 2);
+  if (!c) return;
+  memcpy(c, tag, tl);
+  c[tl] = '=';
+  memcpy(c + tl + 1, val, vl + 1);
+  th_comment_add(tc, c);
+  free(c);
+}
+char *th_comment_query(th_comment *tc, const char *tag, int count) {
+  if (!tc || !tag) return nullptr;
+  const size_t n = strlen(tag);
+  int found = 0;
+  for (int i = 0; i < tc->comments; i++)
+    if ((size_t)tc->comment_lengths[i] > n && tag_matches(tc->user_comments[i], tag, n)) {
+      if (found == count) return tc->user_comments[i] + n + 1;
+      found++;
+    }
+  return nullptr;
+}
+int th_comment_query_count(th_comment *tc, const char *tag) {
+  if (!tc || !tag) return 0;
+  const size_t n = strlen(tag);
+  int found = 0;
+  for (int i = 0; i < tc->comments; i++)
+    if ((size_t)tc->comment_lengths[i] > n && tag_matches(tc->user_comments[i], tag, n)) found++;
+  return found;
+}
+
+// codec.h "Basic shared functions" (internal.c:189-210, state.c:1259-1267)
+const char *th_version_string(void) { return "theora-hip 0.2 (MI355X backend; bitstream 3.2.1)"; }
+uint32_t th_version_number(void) { return (3u << 16) + (2u << 8) + 1u; }
+int th_packet_isheader(ogg_packet *op) { return op && op->bytes > 0 ? op->packet[0] >> 7 : 0; }
+int th_packet_iskeyframe(ogg_packet *op) {
+  return !op || op->bytes <= 0 ? 0 : (op->packet[0] & 0x80) ? -1 : !(op->packet[0] & 0x40);
+}
+
 int th_decode_headerin(th_info *info, th_comment *tc, th_setup_info **setup, ogg_packet *op) {
   if (!op) return TH_EBADHEADER;
   if (!info) return TH_EFAULT;
@@ -803,6 +869,12 @@ int64_t th_granule_frame(void *encdec, int64_t granpos) {
   const int64_t iframe = granpos >> shift;
   const int64_t pframe = granpos - (iframe << shift);
   return iframe + pframe - d->granpos_bias;
+}
+
+double th_granule_time(void *encdec, int64_t granpos) {
+  th_dec_ctx *d = (th_dec_ctx *)encdec;
+  if (!d || granpos < 0 || !d->info.fps_numerator) return -1;
+  return (double)(th_granule_frame(encdec, granpos) + 1) * ((double)d->info.fps_denominator / (double)d->info.fps_numerator);
 }
 
 // One data packet: spec 7.1 - 7.11, ending in the vtable slots of the HIP backend.
