@@ -99,3 +99,14 @@ def test_tile_positions_match_numpy_geometry():
         assert st.ntiles == g.ntiles and st.tile_off == g.tile_off
         for f in list(range(0, g.nfrags, max(1, g.nfrags // 97))) + [g.nfrags - 1]:
             assert st.frag_pos(f) == g.frag_pos[f]
+
+
+def test_integration_shim_compiles(tmp_path):
+    """The glue INTEGRATION.md asks a libtheora maintainer to write (tests/native/integration_shim.c,
+    against a stand-in for the oc_theora_state fields it touches) compiles, warning-free, against
+    include/theora_hip.h as it is: the documented drop-in cannot drift away from the ABI."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native", "integration_shim.c")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-c", src, "-o", str(tmp_path / "shim.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
