@@ -103,15 +103,19 @@ int64_t thip_state_frag_pos(const thip_state *st, int64_t fragi);
  *                      dc_only     bit  3     last_zzi<2 (state.c:967-975)
  *                      last_zzi    bits 8-14  0..64 (idct.c:301-330 picks its variant on it)
  *                      mv x, mv y  bits 16-23, 24-31 signed (oc_mv, state.h:232-240)
- *               word1  dc_only blocks: p=(dc*dc_quant+15)>>5 as int16 in bits 0-15
- *                      (state.c:972); otherwise unused
+ *               word1  dc_quant    bits 16-31 the _dc_quant argument of oc_state_frag_recon
+ *                      dc          bits 0-15  dc_only blocks: the raw (un-predicted, not yet
+ *                                             dequantised) DC coefficient; the kernel forms
+ *                                             p=(dc*dc_quant+15)>>5 (state.c:972)
  *  coeffs     one 128-byte slot per coded fragment that is NOT dc_only, slots numbered in
  *             tile/lane order (== the order the reference reconstructs them in).  Slot s
  *             lives in group-of-64 s/64, lane s%64: the block is eight 16-byte pieces, piece
  *             q = 2*j+h (j = row pair 0..3, h = column half 0..1) at
  *             (s/64)*8192 + q*1024 + (s%64)*16, holding for columns c = 4h..4h+3 the int16
- *             pairs { x[2j][c], x[2j+1][c] } (x = dequantised coefficients, natural order,
- *             x[0][0] = (int16)(dc*dc_quant), state.c:978).  This is the backend's
+ *             pairs { x[2j][c], x[2j+1][c] } (x = the _dct_coeffs argument of
+ *             oc_state_frag_recon: natural order, AC dequantised by the caller as in
+ *             decode.c:1573, x[0][0] the RAW DC -- the kernel multiplies it by dc_quant,
+ *             state.c:978).  This is the backend's
  *             counterpart of the per-backend dct_fzig_zag table (state.h:374-376,
  *             x86state.c:44-64).  Allocate whole groups of 64 slots.
  *  tile_slot0 per tile: slot number of its first non-dc_only coded fragment; the kernel

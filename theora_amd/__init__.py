@@ -36,10 +36,12 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------
 # host-side packing of a frame's fragment command stream (layout of include/theora_hip.h)
 # ---------------------------------------------------------------------------------------
-def info_words(npos, pos, refi, last_zzi, mvx, mvy, dc_p):
+def info_words(npos, pos, refi, last_zzi, mvx, mvy, dc, dc_quant):
     """[npos,2] uint32 frag_info array (include/theora_hip.h): coded fragments at tile
-    positions `pos`; every other position stays 0 (uncoded / outside the plane).  dc_p is the
-    pre-rounded DC value of the DC-only fragments (ignored for the others)."""
+    positions `pos`; every other position stays 0 (uncoded / outside the plane).  dc is the raw
+    DC coefficient (used for the DC-only fragments, whose value has no coefficient slot),
+    dc_quant the per-fragment DC quantiser: the dequantisation itself (state.c:967-979) is the
+    kernel's."""
     out = np.zeros((npos, 2), np.uint32)
     lz = np.asarray(last_zzi, np.uint32)
     w0 = np.uint32(_lib.INFO_CODED) | ((np.asarray(refi, np.uint32) & 3) << 1) | (lz << 8)
@@ -47,20 +49,10 @@ def info_words(npos, pos, refi, last_zzi, mvx, mvy, dc_p):
     w0 |= (np.asarray(mvx, np.int32).astype(np.uint32) & 0xFF) << 16
     w0 |= (np.asarray(mvy, np.int32).astype(np.uint32) & 0xFF) << 24
     out[pos, 0] = w0
-    out[pos, 1] = np.where(lz < 2, np.asarray(dc_p, np.int32).astype(np.uint32) & 0xFFFF, 0)
+    w1 = (np.asarray(dc_quant, np.int64).astype(np.uint32) & 0xFFFF) << 16
+    w1 |= np.where(lz < 2, np.asarray(dc, np.int32).astype(np.uint32) & 0xFFFF, 0).astype(np.uint32)
+    out[pos, 1] = w1
     return out
-
-
-def dequant_dc(coeffs, last_zzi, dc_quant):
-    """What oc_state_frag_recon does to coefficient 0 before the transform
-    (state.c:967-979): p=(dc*dc_quant+15)>>5 for DC-only blocks, (int16)(dc*dc_quant)
-    otherwise.  coeffs [n,64] int16 with the raw DC in [:,0]; returns a new array."""
-    co = np.array(coeffs, np.int16, copy=True).reshape(-1, 64)
-    dc = co[:, 0].astype(np.int32) * np.asarray(dc_quant, np.int32)
-    lz = np.asarray(last_zzi)
-    co[:, 0] = np.where(lz < 2, (dc + 15) >> 5, dc).astype(np.int16)  # wraps like the C cast
-    co[lz < 2, 1:] = 0
-    return co
 
 
 def pack_tiles(coeffs):

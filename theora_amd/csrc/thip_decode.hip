@@ -634,11 +634,12 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
                    ((uint32_t)last_zzi << THIP_INFO_LAST_ZZI_SHIFT) |
                    ((uint32_t)(uint8_t)(mv & 0xFF) << THIP_INFO_MVX_SHIFT) |
                    ((uint32_t)(uint8_t)((mv >> 8) & 0xFF) << THIP_INFO_MVY_SHIFT);
-  uint32_t word1 = 0;
+  // The DC coefficient travels raw; k_recon applies state.c:967-979 (the rounded DC-only form or the
+  // 16-bit product) with the dc_quant carried in the upper half of command word 1.
+  uint32_t word1 = (uint32_t)dc_quant << 16;
   if (last_zzi < 2) {
-    // state.c:967-975: the only rounded dequantisation of the path; no coefficient slot
-    flags |= THIP_INFO_DC_ONLY;
-    word1 = (uint32_t)(uint16_t)(int16_t)((dct_coeffs[0] * (int32_t)dc_quant + 15) >> 5);
+    flags |= THIP_INFO_DC_ONLY;   // no coefficient slot
+    word1 |= (uint32_t)(uint16_t)dct_coeffs[0];
   } else {
     // Slots are handed out in arrival order, which for the reference's caller is coded
     // order == tile/lane order (decode.c:1530-1586); the kernel re-derives a lane's slot
@@ -651,7 +652,6 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
     st->enq_last_lane[tile] = lane;
     st->enq_last_tile = tile;
     const int slot = st->enq_nslots++;
-    dct_coeffs[0] = (int16_t)(dct_coeffs[0] * (int)dc_quant);   // state.c:978
     // piece q = 2*j+h of the block: columns c = 4h..4h+3 as pairs { x[2j][c], x[2j+1][c] }
     int16_t *blk = st->h_coeffs + (size_t)(slot >> 6) * (THIP_SLOT_GROUP_BYTES / 2) + (size_t)(slot & 63) * 8;
     for (int j = 0; j < 4; j++)

@@ -399,8 +399,14 @@ __device__ __forceinline__ unsigned long long trace_now() {
 #endif
 
 // What a lane knows after the first round trip.
+// state.c:978: x[0][0] = (int16)(dc * dc_quant) -- the low half of the block's first dword; the low
+// 16 bits of a product depend on the low 16 bits of the factors only.
+__device__ __forceinline__ uint32_t dequant_dc_lo(uint32_t w, uint32_t dcq) {
+  return (w & 0xFFFF0000u) | (((w & 0xFFFFu) * dcq) & 0xFFFFu);
+}
+
 struct ReconLane {
-  uint32_t flags, dcp;            // command word 0 (0 past the ragged edge), DC-only value
+  uint32_t flags, dcp, dcq;       // command word 0 (0 past the ragged edge), DC-only value {p,p}, dc_quant
   bool coded, dc_only, has_coeff;
   int x0, y0;                     // pixel position of the block in its plane
 };
@@ -453,12 +459,13 @@ __device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane 
     asm volatile("" : "+v"(P[31]));
     THIP_TR(R.tr, 3);   // coefficients (and, with them, the predictor windows) have arrived
 #endif
+    P[0] = dequant_dc_lo(P[0], L.dcq);
     const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
     pk_mask_by_last_zzi(P, last_zzi);
     const bool all_zz10 = !__any(L.has_coeff && last_zzi > 10);
     pk_idct8x8(P, Y, all_zz10);
   }
-  if (!IDCT || !L.has_coeff) {   // DC-only: the pre-rounded value; uncoded: zero residual
+  if (!IDCT || !L.has_coeff) {   // DC-only: the rounded value (state.c:972); uncoded: zero residual
     const uint32_t fill = L.dc_only ? L.dcp : 0u;
 #pragma unroll
     for (int i = 0; i < 32; i++) Y[i] = fill;
@@ -525,6 +532,7 @@ __device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const R
     P[q * 4 + 2] = w.z;
     P[q * 4 + 3] = w.w;
   }
+  P[0] = dequant_dc_lo(P[0], L.dcq);   // x[0][0] arrives raw
   const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
   // the masks are all ones for last_zzi > 10: ~100 instructions skipped when no owner needs them
   if (__any(L.has_coeff && last_zzi <= 10)) pk_mask_by_last_zzi(P, last_zzi);
@@ -563,16 +571,18 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32
                                                 const ReconLane &L, uint32_t prefix, uint32_t Y[32]) {
   constexpr int NP = 4 / LPB;                        // row pairs (and column pairs) per lane
   const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
-  if (L.has_coeff) meta[prefix] = (uint32_t)last_zzi;   // rank -> last_zzi of that owner
+  if (L.has_coeff) meta[prefix] = (uint32_t)last_zzi | (L.dcq << 16);   // rank -> last_zzi, dc_quant of that owner
   const int g = lane / LPB, j = lane % LPB;
-  const int lz = (int)(meta[g] & 0x7Fu);            // (garbage for g >= number of owners: results unused)
+  const uint32_t mg = meta[g];                      // (garbage for g >= number of owners: results unused)
+  const int lz = (int)(mg & 0x7Fu);
+  const uint32_t dcq_g = j == 0 ? mg >> 16 : 1u;    // the lane holding row pair 0 dequantises x[0][0]
   const bool c3 = lz <= 3, c10 = lz <= 10;
   pk16 Rr[NP][8];
 #pragma unroll
   for (int n = 0; n < NP; n++) {
     const int rp = j * NP + n;                       // row pair: rows 2rp, 2rp+1
     const int4 w0 = W[n][0], w1 = W[n][1];
-    const uint32_t P8[8] = {(uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w,
+    const uint32_t P8[8] = {n == 0 ? dequant_dc_lo((uint32_t)w0.x, dcq_g) : (uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w,
                             (uint32_t)w1.x, (uint32_t)w1.y, (uint32_t)w1.z, (uint32_t)w1.w};   // {x[2rp][c], x[2rp+1][c]}, c = 0..7
     // what the variant selected by last_zzi does not read is zero (pk_mask_by_last_zzi)
 #pragma unroll
@@ -683,7 +693,9 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
 
   ReconLane L;
   L.flags = valid ? info.x : 0u;
-  L.dcp = (info.y & 0xFFFFu) * 0x00010001u;   // {p, p}
+  // DC dequantisation (state.c:967-979): command word 1 = dc_quant << 16 | raw DC of a DC-only block
+  L.dcq = info.y >> 16;
+  L.dcp = ((uint32_t)(((int)(int16_t)(info.y & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;   // {p, p}
   L.coded = (L.flags & THIP_INFO_CODED) != 0;
   L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
   L.has_coeff = L.coded && !L.dc_only;
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
     THIP_TR(R.tr, 3);
   }
   if (!valid) return;
-  if (!L.has_coeff || (debug & 9)) {   // DC-only: the pre-rounded value; uncoded: zero residual
+  if (!L.has_coeff || (debug & 9)) {   // DC-only: the rounded value (state.c:972); uncoded: zero residual
     const uint32_t fill = L.dc_only ? L.dcp : 0u;
 #pragma unroll
     for (int i = 0; i < 32; i++) Y[i] = fill;
@@ -839,7 +851,8 @@ __global__ __launch_bounds__(64 * kSegMax, 1) void k_recon_lf(const BatchK B) {
 
   ReconLane L;
   L.flags = valid ? info.x : 0u;
-  L.dcp = (info.y & 0xFFFFu) * 0x00010001u;
+  L.dcq = info.y >> 16;
+  L.dcp = ((uint32_t)(((int)(int16_t)(info.y & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;
   L.coded = (L.flags & THIP_INFO_CODED) != 0;
   L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
   L.has_coeff = L.coded && !L.dc_only;

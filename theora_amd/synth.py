@@ -191,14 +191,15 @@ def gen_frame(geom, rng, frame_type, content="mixed", flimit=None, global_mv=Non
 
 def pack_frame(geom, frame):
     """numpy command stream -> the device layout of include/theora_hip.h (host arrays)."""
-    from . import dequant_dc, info_words, pack_tiles
+    from . import info_words, pack_tiles
     cf = frame["coded_fragis"]
     pos = geom.frag_pos[cf]
     assert (np.diff(pos) > 0).all(), "coded order must equal tile/lane order"
     lz = frame["last_zzi"]
-    co = dequant_dc(frame["coeffs"], lz, frame["dc_quant"])
+    co = np.asarray(frame["coeffs"], np.int16).reshape(-1, 64)   # AC dequantised, DC raw (the slot's _dct_coeffs)
     has = lz >= 2
-    info = info_words(geom.ntiles * 64, pos, frame["refi"][cf], lz, frame["mvx"][cf], frame["mvy"][cf], co[:, 0])
+    info = info_words(geom.ntiles * 64, pos, frame["refi"][cf], lz, frame["mvx"][cf], frame["mvy"][cf], co[:, 0],
+                      frame["dc_quant"])
     # first slot of every tile: number of coefficient-carrying fragments in earlier tiles
     per_tile = np.bincount(pos[has] >> 6, minlength=geom.ntiles)
     slot0 = np.concatenate([[0], np.cumsum(per_tile)[:-1]]).astype(np.uint32)
