@@ -329,11 +329,28 @@ def tokenize_block(rng, nz):
 # stream
 # ---------------------------------------------------------------------------------------
 class Stream:
-    def __init__(self, width, height, fmt, seed, kfgshift=6):
+    def __init__(self, width, height, fmt, seed, kfgshift=6, trees="random", probe_kwargs=None):
+        """trees="random": the 80 Huffman trees come from random token weights, so that frequent
+        tokens get long codes too (what the parity tests want).  trees="matched": the trees of each
+        index group are built from the token statistics of probe frames of the same kind of content
+        (frame() arguments in probe_kwargs), as an encoder's are -- what a throughput measurement
+        wants, since code length is what a Huffman decoder's speed depends on."""
         self.rng = np.random.default_rng(seed)
         self.w, self.h, self.fmt = width, height, fmt
         self.geom = synth.Geometry(width, height, fmt)
         self.setup = Setup(self.rng)
+        self.tok_hist = np.zeros((5, 32), np.int64)
+        if trees == "matched":
+            probe = Stream(width, height, fmt, seed + 7919, kfgshift)
+            for ft in (0, 1, 1):
+                probe.frame(ft, **(probe_kwargs or {}))
+            self.setup.codes = []
+            for hg in range(5):
+                for _ in range(16):
+                    w = (probe.tok_hist[hg] + 0.5) * (1 + 0.2 * self.rng.random(32))
+                    self.setup.codes.append(huffman_codes(w))
+        elif trees != "random":
+            raise ValueError(trees)
         self.kfgshift = kfgshift
         g = self.geom
         # super blocks (all planes) as ranges of coded order, macro blocks in coded order
@@ -623,6 +640,7 @@ class Stream:
             for p in range(3):
                 codes = self.setup.codes[16 * hg + (htis[0] if p == 0 else htis[1])]
                 for (tok, extra, nb) in lists.get((z, p), []):
+                    self.tok_hist[hg, tok] += 1
                     bw.code(codes[tok])
                     bw.write(extra, nb)
         truth.update(coded_fragis=cf, qii=qii, refi=refi, mvx=mvx, mvy=mvy, frag_mode=frag_mode, qcoef=qcoef,

@@ -107,7 +107,7 @@ struct HuffTree {
   int nnodes;
   int root_leaf;   // a single-leaf tree: token+1, else 0
   // next kHuffLutBits bits -> (code length << 8 | token), or 0x8000 | node to continue from
-  uint16_t lut[1 << kHuffLutBits];
+  uint32_t lut[1 << kHuffLutBits];
 };
 
 struct QuantParams {
@@ -180,7 +180,8 @@ struct th_dec_ctx {
   std::vector<int8_t> mvx, mvy;
   std::vector<int16_t> dc;
   std::vector<uint8_t> sbp, sbf, mbmodes;
-  std::vector<Tok> toks[3][64];
+  std::vector<Tok> toks[3][64];   // storage; the lists of the current frame are the first ntoks entries
+  size_t ntoks[3][64];
   uint32_t eob_carry[3][64];
   int qis[3], nqis, frame_type;
   int64_t keyframe_num, curframe_num, granpos;
@@ -291,22 +292,30 @@ int parse_huff_tree(BitReader &br, HuffTree &t, int depth, int *nleaves) {   // 
   return me;
 }
 
+// extra bits that follow each DCT token (Tables 7.33 / 7.38; kTokDef below has the rest)
+const uint8_t kTokExtraBits[32] = {0, 0, 0, 2, 3, 4, 12, 3, 6, 0, 0, 0, 0, 1, 1, 1,
+                                   1, 2, 3, 4, 5, 6, 10, 1, 1, 1, 1, 1, 3, 4, 2, 3};
+constexpr uint32_t kLutMore = 0x80000000u;
+// lut entry: token | code length << 8 | (code length + extra bits) << 16, so that how far the bit
+// window moves is known one load after the window (the token loop's dependency chain), or
+// kLutMore | node when the code is longer than the table covers.
 void build_huff_lut(HuffTree &t) {
   for (int v = 0; v < (1 << kHuffLutBits); v++) {
-    uint16_t e = 0;
-    if (t.root_leaf) e = (uint16_t)(t.root_leaf - 1);   // zero-length code
+    uint32_t e = 0;
+    if (t.root_leaf) e = (uint32_t)(t.root_leaf - 1) | ((uint32_t)kTokExtraBits[t.root_leaf - 1] << 16);   // zero-length code
     else {
       int node = 0, len = 0;
-      e = 0x8000;
+      e = kLutMore;
       while (len < kHuffLutBits) {
         const int c = t.child[node][(v >> (kHuffLutBits - 1 - len)) & 1];
         len++;
         if (c < 0) {
-          e = (uint16_t)((len << 8) | (-c - 1));
+          const int token = -c - 1;
+          e = (uint32_t)token | ((uint32_t)len << 8) | ((uint32_t)(len + kTokExtraBits[token]) << 16);
           break;
         }
         node = c;
-        e = (uint16_t)(0x8000 | node);
+        e = kLutMore | (uint32_t)node;
       }
     }
     t.lut[v] = e;
@@ -487,13 +496,13 @@ inline int read_token(BitReader &br, const HuffTree &t) {
   if (t.root_leaf) return t.root_leaf - 1;
   if (br.pos + 32 > br.nbits) return read_token_bitwise(br, t, 0);   // tail of the packet
   const uint32_t w = br.peek(32);   // a code is at most 32 bits long
-  const uint16_t e = t.lut[w >> (32 - kHuffLutBits)];
-  if (!(e & 0x8000)) {
-    br.skip(e >> 8);
+  const uint32_t e = t.lut[w >> (32 - kHuffLutBits)];
+  if (!(e & kLutMore)) {
+    br.skip((e >> 8) & 0xFF);
     return e & 0xFF;
   }
   // longer than the table covers: finish the walk on the peeked word, one skip at the end
-  int node = e & 0x7FFF, len = kHuffLutBits;
+  int node = (int)(e & 0x7FFFu), len = kHuffLutBits;
   for (;;) {
     const int c = t.child[node][(w >> (31 - len)) & 1u];
     len++;
@@ -534,23 +543,160 @@ const TokDef kTokDef[32] = {
     TD(2, 2, 2, 0, 0x01, 1, 0, 2),   TD(3, 2, 2, 1, 0x01, 2, 0x01, 2)};
 #undef TD
 
-// Straight-line on purpose: which of the 32 tokens comes next is close to random, so a switch
-// costs a mispredicted branch per token.
-inline void decode_token(BitReader &br, int token, Tok &k) {
-  const TokDef &t = kTokDef[token];
-  const uint32_t x = br.read(t.ebits);
-  const uint32_t rd = t.sign == 2;
-  const uint32_t sbit = rd ? t.ebits - 1u : 0u;                // position of the sign among the extra bits
-  const uint32_t neg = rd ? (x >> sbit) & 1u : t.sign;
-  const uint32_t rest = x & ((1u << (rd ? sbit : t.ebits)) - 1u);
-  const int mag = t.vbase + (int)((rest >> t.vshift) & t.vmask);
-  const int isval = t.kind == 2, iseob = t.kind == 0;
-  const int skip = t.sbase + (int)(rest & t.smask);
-  k.value = (int16_t)(isval ? (neg ? -mag : mag) : 0);
+// kTokDef with every selection turned into a mask.  Straight-line on purpose: which of the 32
+// tokens comes next is close to random, so a switch costs a mispredicted branch per token, and the
+// token loop of a frame is the one place where a nanosecond per token is a percent of the frame.
+// expand_token(kTokFast.t[token], x, k) fills k once the token's extra bits x are known.
+struct TokFast {
+  uint8_t ebits, sign_shift, sign_and, sign_const;
+  uint8_t vshift, sbase, smask, isval;
+  uint16_t vmask, rest_mask;
+  int32_t vbase;
+  int32_t val_mask;    // -1 for value tokens
+  uint32_t eob_mask;   // ~0 for EOB tokens
+  uint8_t adv_mask;    // 0 for EOB tokens
+};
+struct TokFastTable {
+  TokFast t[32];
+  TokFastTable() {
+    for (int i = 0; i < 32; i++) {
+      const TokDef &d = kTokDef[i];
+      TokFast &f = t[i];
+      const bool rd = d.sign == 2;
+      if (kTokExtraBits[i] != d.ebits) abort();   // the two tables state the same thing
+      f.ebits = d.ebits;
+      f.sign_shift = (uint8_t)(rd ? d.ebits - 1 : 0);
+      f.sign_and = rd ? 1 : 0;
+      f.sign_const = (uint8_t)(rd ? 0 : d.sign);
+      f.vshift = d.vshift;
+      f.sbase = d.sbase;
+      f.smask = d.smask;
+      f.isval = d.kind == 2;
+      f.vmask = d.vmask;
+      f.rest_mask = (uint16_t)((1u << (rd ? d.ebits - 1 : d.ebits)) - 1u);
+      f.vbase = d.vbase;
+      f.val_mask = d.kind == 2 ? -1 : 0;
+      f.eob_mask = d.kind == 0 ? 0xFFFFFFFFu : 0u;
+      f.adv_mask = d.kind == 0 ? 0 : 0xFF;
+    }
+  }
+};
+const TokFastTable kTokFast;
+
+inline void expand_token(const TokFast &t, uint32_t x, Tok &k) {
+  const int32_t neg = (int32_t)(((x >> t.sign_shift) & t.sign_and) | t.sign_const);
+  const uint32_t rest = x & t.rest_mask;
+  const int32_t mag = t.vbase + (int32_t)((rest >> t.vshift) & t.vmask);
+  const int32_t skip = t.sbase + (int32_t)(rest & t.smask);
+  k.value = (int16_t)(((mag ^ -neg) + neg) & t.val_mask);
   k.skip = (uint8_t)skip;
-  k.adv = (uint8_t)(iseob ? 0 : skip + isval);
-  k.eob = iseob ? (uint32_t)mag : 0u;
-  if (iseob && mag == 0) k.eob = 0xFFFFFFFFu;                  // token 6 with a zero run field: all remaining
+  k.adv = (uint8_t)((skip + t.isval) & t.adv_mask);
+  k.eob = t.eob_mask & (mag ? (uint32_t)mag : 0xFFFFFFFFu);   // token 6 with a zero run field: all remaining
+}
+
+// ... and tabulated: every (token, extra bits) pair there is -- 5405 of them, of which the few dozen
+// that real streams use stay in L1 -- so the token loop copies eight bytes instead of computing them.
+struct TokTable {
+  uint16_t base[32];
+  Tok tab[5405];
+  TokTable() {
+    int n = 0;
+    for (int i = 0; i < 32; i++) {
+      base[i] = (uint16_t)n;
+      for (uint32_t x = 0; x < (1u << kTokExtraBits[i]); x++) expand_token(kTokFast.t[i], x, tab[n++]);
+    }
+    if (n != 5405) abort();
+  }
+};
+const TokTable kTokTab;
+
+// One (plane, index) token list (7.7.2): n blocks are open at index z of plane p; every token closes
+// or advances at least one of them.  Writes the tokens to out (room for n + 1), counts the blocks
+// that move on to index z + adv in left[p][z + adv], leaves in *eobs what is left of an EOB run that
+// reaches past this list, and returns the end of the written tokens.  A function of its own (not
+// inlined) so that the bit window and the counters get registers instead of stack slots.
+__attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &tree, size_t n, Tok *out,
+                                                 size_t (*left)[128], int p, int z, uint32_t *eobs) {
+  // the reader's state as plain locals: br itself is only touched on the slow paths, so nothing
+  // here has its address taken
+  uint64_t win = br.win;
+  int have = br.have;
+  size_t pos = br.pos, bytepos = br.bytepos;
+  const size_t nbits = br.nbits, nbytes = br.nbytes;
+  const uint8_t *const data = br.data;
+  size_t *const left_next = &left[p][z];
+  const bool lut_ok = !tree.root_leaf;
+  const uint32_t *const lut = tree.lut;
+  uint32_t run_left = *eobs;   // what the last token's EOB run has left for later lists
+  while (n > 0) {
+    Tok &k = *out++;
+    bool fast = false;
+    // Fast path: the next 64 bits are all inside the packet (the longest code and the most extra
+    // bits together are 44) and eight bytes can be loaded at the read position.  Nothing on it depends on the data except through arithmetic: which token
+    // comes next and whether the window needs topping up are both close to random, and a
+    // mispredicted branch costs more than all the arithmetic of a token.
+    if (lut_ok && pos + 64 <= nbits && bytepos + 8 <= nbytes) {
+      // top the window up to 56..63 bits: bits that are loaded but not yet counted in `have` are the
+      // stream's own and are OR-ed in again, unchanged, next time
+      uint64_t v;
+      memcpy(&v, data + bytepos, 8);
+      win |= __builtin_bswap64(v) >> have;
+      bytepos += (size_t)((63 - have) >> 3);
+      have |= 56;
+      const uint64_t w = win;
+      uint32_t e = lut[w >> (64 - kHuffLutBits)];
+      if (e & kLutMore) {
+        // a code longer than the table covers (at most 32 bits): finish the walk on the window
+        int node = (int)(e & 0x7FFFu), len = kHuffLutBits;
+        for (;;) {
+          const int c = tree.child[node][(w >> (63 - len)) & 1u];
+          len++;
+          if (c < 0) {
+            const int token = -c - 1;
+            e = (uint32_t)token | ((uint32_t)len << 8) | ((uint32_t)(len + kTokExtraBits[token]) << 16);
+            break;
+          }
+          node = c;
+        }
+      }
+      const int len = (int)((e >> 8) & 0xFF), total = (int)(e >> 16);   // total <= 32 + 12 <= have
+      win <<= total;   // the only thing the next token waits for
+      have -= total;
+      pos += (size_t)total;
+      const uint32_t x = (uint32_t)(((w << len) >> 1) >> (63 - (total - len)));   // the extra bits (none: 0)
+      k = kTokTab.tab[kTokTab.base[e & 0xFF] + x];
+      fast = true;
+    }
+    if (!fast) {   // single-leaf tree or the last bytes of the packet
+      br.win = win; br.have = have; br.pos = pos; br.bytepos = bytepos;
+      const TokFast &t = kTokFast.t[read_token(br, tree)];
+      expand_token(t, br.read(t.ebits), k);
+      win = br.win; have = br.have; pos = br.pos; bytepos = br.bytepos;
+    }
+    if (k.eob == 0xFFFFFFFFu) {   // every block still open anywhere ends (7.7.1)
+      size_t all = n;
+      for (int pp = p + 1; pp < 3; pp++) all += left[pp][z];
+      for (int zz = z + 1; zz < 64; zz++)
+        for (int pp = 0; pp < 3; pp++) all += left[pp][zz];
+      k.eob = (uint32_t)all;
+    }
+    // an EOB token ends up to k.eob of the open blocks, any other token advances one of them
+    // (for an EOB token adv is 0 and the count lands in this list's own, no longer needed, entry)
+    const size_t want = k.eob ? k.eob : 1u;
+    const size_t take = want < n ? want : n;
+    run_left = (uint32_t)(want - take);
+    left_next[k.adv]++;   // z + adv <= 127
+    n -= take;
+    if (!fast && pos > nbits && n > 0) {   // truncated packet: close everything that is open
+      Tok &e = *out++;
+      e.value = 0; e.skip = 0; e.adv = 0; e.eob = (uint32_t)n;
+      n = 0;
+      run_left = 0;
+    }
+  }
+  *eobs = run_left;
+  br.win = win; br.have = have; br.pos = pos; br.bytepos = bytepos;
+  return out;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1053,15 +1199,15 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   d->prof.lap(FE_QI);
   // ---- 7.7 DCT tokens, unpacked by counts per (plane, index) list -------------------------------------
   {
-    size_t left[3][64];
+    size_t left[3][128];   // [64..127]: where advances past the last index land
     memset(left, 0, sizeof(left));
     int cstart[4] = {0, d->nfrags_pl[0], d->nfrags_pl[0] + d->nfrags_pl[1], N};
     for (int p = 0; p < 3; p++) {
       size_t n = 0;
       for (int k = cstart[p]; k < cstart[p + 1]; k++) n += d->coded[d->coded_order[k]];
       left[p][0] = n;
-      for (int z = 0; z < 64; z++) d->toks[p][z].clear();
     }
+    memset(d->ntoks, 0, sizeof(d->ntoks));
     memset(d->eob_carry, 0, sizeof(d->eob_carry));
     uint32_t eobs = 0;
     int htil = 0, htic = 0;
@@ -1082,37 +1228,12 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         }
         const HuffTree &tree = d->setup.huff[16 * hg + (p == 0 ? htil : htic)];
         // every token closes at least one open block of this list: at most n tokens (+1 for the
-        // closing entry of a truncated packet)
+        // closing entry of a truncated packet).  The lists only ever grow; ntoks is their length.
         std::vector<Tok> &list = d->toks[p][z];
-        list.resize(n + 1);
-        Tok *out = list.data();
-        while (n > 0) {
-          Tok &k = *out++;
-          decode_token(br, read_token(br, tree), k);
-          if (k.eob) {
-            if (k.eob == 0xFFFFFFFFu) {   // every block still open anywhere ends (7.7.1)
-              size_t all = n;
-              for (int pp = p + 1; pp < 3; pp++) all += left[pp][z];
-              for (int zz = z + 1; zz < 64; zz++)
-                for (int pp = 0; pp < 3; pp++) all += left[pp][zz];
-              k.eob = (uint32_t)all;
-            }
-            const uint32_t take = k.eob < n ? k.eob : (uint32_t)n;
-            eobs = k.eob - take;
-            n -= take;
-          } else {
-            const int nz = z + k.adv;
-            if (nz < 64) left[p][nz]++;
-            n--;
-          }
-          if (br.overrun() && n > 0) {   // truncated packet: close everything that is open
-            Tok &e = *out++;
-            e.value = 0; e.skip = 0; e.adv = 0; e.eob = (uint32_t)n;
-            n = 0;
-          }
-        }
-        list.resize((size_t)(out - list.data()));
-        d->prof.tokens += (long)list.size();
+        if (list.size() < n + 1) list.resize(n + 1);
+        Tok *const out = decode_token_list(br, tree, n, list.data(), left, p, z, &eobs);
+        d->ntoks[p][z] = (size_t)(out - list.data());
+        d->prof.tokens += (long)d->ntoks[p][z];
       }
     }
   }
@@ -1130,6 +1251,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         int16_t v = 0;
         if (run) run--;
         else {
+          if (ti >= d->ntoks[p][0]) break;   // (cannot happen: the list covers every coded block)
           const Tok &t = d->toks[p][0][ti];
           if (t.eob) run = t.eob - 1;
           else if (t.skip == 0) v = t.value;
@@ -1217,7 +1339,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
             run[z]--;
             break;
           }
-          if (ti[z] >= d->toks[p][z].size()) break;   // malformed stream
+          if (ti[z] >= d->ntoks[p][z]) break;   // malformed stream
           const Tok &t = d->toks[p][z][ti[z]++];
           if (t.eob) {
             run[z] = t.eob - 1;
