@@ -185,6 +185,7 @@ def main_e2e(main_args, argv):
     ap.add_argument("--loops", type=int, default=5)
     ap.add_argument("--no-output", action="store_true", help="skip th_decode_ycbcr_out (no D2H)")
     ap.add_argument("--threads", type=int, default=1, help="host threads, one independent stream each")
+    ap.add_argument("--trees", choices=["matched", "random"], default="matched")
     args = ap.parse_args(argv)
     args.size = main_args.size if main_args.size != "4k" else "720p"   # the generator is Python: keep it small
     import torch
@@ -192,11 +193,14 @@ def main_e2e(main_args, argv):
     from theora_amd.decoder import Decoder
     torch.cuda.set_device(0)
     w, h = SIZES[args.size]
-    st = streamgen.Stream(w, h, 0, seed=99)
+    # Huffman trees built from the content's own token statistics, as an encoder's are (--trees random:
+    # trees unrelated to the content, a fifth of the tokens with codes of 10+ bits)
+    content = dict(density=0.7, p_dc_only=0.5, p_empty=0.2)
+    st = streamgen.Stream(w, h, 0, seed=99, trees=args.trees, probe_kwargs=content)
     hdr = st.header_packets()
     pkts = []
     for f in range(args.frames):
-        pkt, truth = st.frame(0 if f % 8 == 0 else 1, density=0.7, p_dc_only=0.5, p_empty=0.2)
+        pkt, truth = st.frame(0 if f % 8 == 0 else 1, **content)
         pkts.append(pkt)
     nbytes = sum(len(p) for p in pkts)
     import threading
@@ -233,7 +237,7 @@ def main_e2e(main_args, argv):
     print(json.dumps({"metric": "end-to-end decode frames/sec (%s 4:2:0, packets in host memory -> YUV in host memory)" % args.size,
                       "value": round(n / el, 2), "unit": "frames/s", "frames": n, "host_threads": T, "streams": T,
                       "avg_packet_bytes": nbytes // len(pkts), "with_ycbcr_out": not args.no_output,
-                      "data": "synthetic packets (tests/streamgen.py)",
+                      "data": "synthetic packets (tests/streamgen.py), %s Huffman trees" % args.trees,
                       "note": "host-bound: one entropy-decode thread per stream + PCIe; th_decode_* contexts are independent"}))
     for dec in decs:
         dec.close()

@@ -652,16 +652,19 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
     st->enq_last_lane[tile] = lane;
     st->enq_last_tile = tile;
     const int slot = st->enq_nslots++;
-    // piece q = 2*j+h of the block: columns c = 4h..4h+3 as pairs { x[2j][c], x[2j+1][c] }
+    // piece q = 2*j+h of the block: columns c = 4h..4h+3 as pairs { x[2j][c], x[2j+1][c] }, i.e. the
+    // low (h = 0) and high (h = 1) halves of rows 2j and 2j+1 interleaved: two shuffles per row pair
+    typedef int16_t v8s __attribute__((vector_size(16)));
     int16_t *blk = st->h_coeffs + (size_t)(slot >> 6) * (THIP_SLOT_GROUP_BYTES / 2) + (size_t)(slot & 63) * 8;
-    for (int j = 0; j < 4; j++)
-      for (int hh = 0; hh < 2; hh++) {
-        int16_t *g = blk + (size_t)(2 * j + hh) * 512;
-        for (int cc = 0; cc < 4; cc++) {
-          g[2 * cc] = dct_coeffs[(2 * j) * 8 + 4 * hh + cc];
-          g[2 * cc + 1] = dct_coeffs[(2 * j + 1) * 8 + 4 * hh + cc];
-        }
-      }
+    for (int j = 0; j < 4; j++) {
+      v8s a, b;
+      memcpy(&a, dct_coeffs + (2 * j) * 8, 16);
+      memcpy(&b, dct_coeffs + (2 * j + 1) * 8, 16);
+      const v8s lo = __builtin_shufflevector(a, b, 0, 8, 1, 9, 2, 10, 3, 11);
+      const v8s hi = __builtin_shufflevector(a, b, 4, 12, 5, 13, 6, 14, 7, 15);
+      memcpy(blk + (size_t)(2 * j) * 512, &lo, 16);
+      memcpy(blk + (size_t)(2 * j + 1) * 512, &hi, 16);
+    }
   }
   memset(dct_coeffs, 0, 64 * sizeof(int16_t));   // idct.c:245,276,295
   st->h_info[2 * (size_t)pos] = flags;

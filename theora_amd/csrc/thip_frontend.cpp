@@ -85,6 +85,16 @@ const uint8_t kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+// the same for positions 0..127: everything past 63 goes to entry 64 (a dump slot)
+struct ZigZagDump {
+  uint8_t t[128];
+  ZigZagDump() {
+    for (int i = 0; i < 128; i++) t[i] = i < 64 ? kZigZag[i] : 64;
+  }
+  uint8_t operator[](int i) const { return t[i]; }
+};
+const ZigZagDump kZigZagDump;
+
 // (row, col) of the k-th block of a super block in coded (Hilbert) order (spec Figure 2.4)
 const uint8_t kHilbert[16][2] = {{0, 0}, {0, 1}, {1, 1}, {1, 0}, {2, 0}, {3, 0}, {3, 1}, {2, 1},
                                  {2, 2}, {3, 2}, {3, 3}, {2, 3}, {1, 3}, {1, 2}, {0, 2}, {0, 3}};
@@ -179,6 +189,8 @@ struct th_dec_ctx {
   std::vector<uint8_t> coded, refi, qii, mbmode_of_frag;
   std::vector<int8_t> mvx, mvy;
   std::vector<int16_t> dc;
+  std::vector<uint8_t> dc_key;   // scratch of the DC un-prediction (one plane, bordered)
+  std::vector<int16_t> dc_val;
   std::vector<uint8_t> sbp, sbf, mbmodes;
   std::vector<Tok> toks[3][64];   // storage; the lists of the current frame are the first ntoks entries
   size_t ntoks[3][64];
@@ -1228,11 +1240,15 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         }
         const HuffTree &tree = d->setup.huff[16 * hg + (p == 0 ? htil : htic)];
         // every token closes at least one open block of this list: at most n tokens (+1 for the
-        // closing entry of a truncated packet).  The lists only ever grow; ntoks is their length.
+        // closing entry of a truncated packet, +1 for the sentinel).  The lists only ever grow; ntoks
+        // is their length.
         std::vector<Tok> &list = d->toks[p][z];
-        if (list.size() < n + 1) list.resize(n + 1);
+        if (list.size() < n + 2) list.resize(n + 2);
         Tok *const out = decode_token_list(br, tree, n, list.data(), left, p, z, &eobs);
         d->ntoks[p][z] = (size_t)(out - list.data());
+        // behind the list: an EOB run without end, so that the expansion needs no end-of-list test
+        // (a malformed stream that asks for more tokens than the list has finds its blocks ended)
+        out->value = 0; out->skip = 0; out->adv = 0; out->eob = 0xFFFFFFFFu;
         d->prof.tokens += (long)d->ntoks[p][z];
       }
     }
@@ -1261,41 +1277,55 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         d->dc[f] = v;
       }
     }
+    // Which neighbours predict a block is a question of "coded, and from the same reference frame"
+    // (7.8.1, Table 7.47): one byte per block (reference index, 0xFF = not coded) in an array with a
+    // border of 0xFF all round answers it with four compares and no position tests.
     for (int p = 0; p < 3; p++) {
-      const int nh = d->nh[p], nv = d->nv[p];
+      const int nh = d->nh[p], nv = d->nv[p], W = nh + 2;
+      std::vector<uint8_t> &key = d->dc_key;
+      std::vector<int16_t> &val = d->dc_val;
+      key.assign((size_t)W * (nv + 1) + 1, 0xFF);
+      val.assign((size_t)W * (nv + 1) + 1, 0);
+      for (int y = 0; y < nv; y++) {
+        const int f0 = d->fro[p] + y * nh;
+        uint8_t *kr = &key[(size_t)(y + 1) * W + 1];
+        for (int x = 0; x < nh; x++) kr[x] = d->coded[f0 + x] ? d->refi[f0 + x] : 0xFF;
+      }
+      // weights and divisors of Table 7.47, indexed by which neighbours are available (bit 0 left,
+      // 1 up-left, 2 up, 3 up-right); the divisors are powers of two, the division truncates
+      static const int8_t Wt[16][4] = {{0, 0, 0, 0},  {1, 0, 0, 0},   {0, 1, 0, 0},  {1, 0, 0, 0},
+                                       {0, 0, 1, 0},  {1, 0, 1, 0},   {0, 0, 1, 0},  {29, -26, 29, 0},
+                                       {0, 0, 0, 1},  {75, 0, 0, 53}, {0, 1, 0, 1},  {75, 0, 0, 53},
+                                       {0, 0, 1, 0},  {75, 0, 0, 53}, {0, 3, 10, 3}, {29, -26, 29, 0}};
+      static const uint8_t Dsh[16] = {0, 0, 0, 0, 0, 1, 0, 5, 0, 7, 1, 7, 0, 7, 4, 5};
       int last[3] = {0, 0, 0};
-      for (int y = 0; y < nv; y++)
+      for (int y = 0; y < nv; y++) {
+        const int f0 = d->fro[p] + y * nh;
+        const uint8_t *kr = &key[(size_t)(y + 1) * W + 1];
+        int16_t *vr = &val[(size_t)(y + 1) * W + 1];
         for (int x = 0; x < nh; x++) {
-          const int f = d->fro[p] + y * nh + x;
-          if (!d->coded[f]) continue;
-          const int r = d->refi[f];
-          // neighbours that are coded and predicted from the same frame (7.8.1, Table 7.47)
-          int mask = 0, l = 0, ul = 0, u = 0, ur = 0;
-          if (x > 0 && d->coded[f - 1] && d->refi[f - 1] == r) { mask |= 1; l = d->dc[f - 1]; }
-          if (y > 0) {
-            if (x > 0 && d->coded[f - nh - 1] && d->refi[f - nh - 1] == r) { mask |= 2; ul = d->dc[f - nh - 1]; }
-            if (d->coded[f - nh] && d->refi[f - nh] == r) { mask |= 4; u = d->dc[f - nh]; }
-            if (x + 1 < nh && d->coded[f - nh + 1] && d->refi[f - nh + 1] == r) { mask |= 8; ur = d->dc[f - nh + 1]; }
-          }
-          // weights and divisors of Table 7.47, indexed by which neighbours are available
-          static const int8_t W[16][4] = {{0, 0, 0, 0},  {1, 0, 0, 0},   {0, 1, 0, 0},  {1, 0, 0, 0},
-                                          {0, 0, 1, 0},  {1, 0, 1, 0},   {0, 0, 1, 0},  {29, -26, 29, 0},
-                                          {0, 0, 0, 1},  {75, 0, 0, 53}, {0, 1, 0, 1},  {75, 0, 0, 53},
-                                          {0, 0, 1, 0},  {75, 0, 0, 53}, {0, 3, 10, 3}, {29, -26, 29, 0}};
-          static const int16_t D[16] = {1, 1, 1, 1, 1, 2, 1, 32, 1, 128, 2, 128, 1, 128, 16, 32};
+          const int r = kr[x];
+          if (r == 0xFF) continue;
+          const int mask = (kr[x - 1] == r) | (kr[x - W - 1] == r) << 1 | (kr[x - W] == r) << 2 | (kr[x - W + 1] == r) << 3;
           int pred;
           if (mask == 0) pred = last[r];
           else {
-            pred = (W[mask][0] * l + W[mask][1] * ul + W[mask][2] * u + W[mask][3] * ur) / D[mask];
+            const int l = vr[x - 1], ul = vr[x - W - 1], u = vr[x - W], ur = vr[x - W + 1];
+            const int num = Wt[mask][0] * l + Wt[mask][1] * ul + Wt[mask][2] * u + Wt[mask][3] * ur;
+            const int sh = Dsh[mask];
+            pred = (num + ((num >> 31) & ((1 << sh) - 1))) >> sh;   // num / 2^sh, towards zero
             if ((mask & 7) == 7) {   // L, UL and U all present: clamp outliers (7.8.1 step 5)
               if (abs(pred - u) > 128) pred = u;
               else if (abs(pred - l) > 128) pred = l;
               else if (abs(pred - ul) > 128) pred = ul;
             }
           }
-          d->dc[f] = (int16_t)(d->dc[f] + pred);   // 16-bit wrap
-          last[r] = d->dc[f];
+          const int16_t v = (int16_t)(d->dc[f0 + x] + pred);   // 16-bit wrap
+          d->dc[f0 + x] = v;
+          vr[x] = v;
+          last[r] = v;
         }
+      }
     }
   }
   d->prof.lap(FE_DC);
@@ -1316,10 +1346,10 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     std::vector<ptrdiff_t> uncoded;
     int cstart[4] = {0, d->nfrags_pl[0], d->nfrags_pl[0] + d->nfrags_pl[1], N};
     for (int p = 0; p < 3; p++) {
-      size_t ti[64];
+      const Tok *tp[64];   // next token of every index list (each list ends in an endless EOB run)
       uint32_t run[64];
       for (int z = 0; z < 64; z++) {
-        ti[z] = 0;
+        tp[z] = d->toks[p][z].data();
         run[z] = d->eob_carry[p][z];
       }
       uncoded.clear();
@@ -1339,14 +1369,17 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
             run[z]--;
             break;
           }
-          if (ti[z] >= d->ntoks[p][z]) break;   // malformed stream
-          const Tok &t = d->toks[p][z][ti[z]++];
+          const Tok &t = *tp[z]++;
           if (t.eob) {
             run[z] = t.eob - 1;
             break;
           }
-          const int at = z + t.skip;
-          if (t.value != 0 && at < 64) block[kZigZag[at]] = (int16_t)(t.value * (int)acq[at]);   // spec 7.9.2
+          // spec 7.9.2.  Unconditional: a pure zero run stores a zero where nothing has been stored
+          // yet (positions only grow), and positions past 63 (a malformed run) land in the second
+          // half of block[], which nobody reads (the reference keeps such a dump slot too,
+          // decint.h:96).
+          const int at = z + t.skip;   // <= 63 + 63
+          block[kZigZagDump[at]] = (int16_t)(t.value * (int)acq[at & 63]);
           z += t.adv;
         }
         block[0] = d->dc[f];   // raw un-predicted DC; the slot dequantises it (state.c:967-979)
