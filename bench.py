@@ -264,7 +264,7 @@ def main_e2e(main_args, argv):
             # many streams, one native host thread each (examples/decode_bench.c)
             nb = os.path.join(ROOT, "examples", "decode_bench")
             if os.path.exists(nb):
-                for nt in (1, 8, 32, 64):
+                for nt in (1, 2, 4, 8, 16, 32, 64):
                     r = subprocess.run([nb, ogv, str(nt), "2"], capture_output=True, text=True, timeout=900)
                     line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "{}"
                     try:

@@ -74,6 +74,16 @@ int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *hos
 /* th_decode_ycbcr_out (decode.c:2988): copies the most recently decoded frame to host
    planes in DISPLAY order (top row first), dst_stride[pli] bytes per row. */
 int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t dst_stride[3]);
+/* The same without the copy: pointers to the library's own pinned image of the most recently
+   decoded frame (display order, strides[pli] == plane width).  Like the reference's buffers
+   (theoradec.h:283-299) they belong to the decoder and must not be written; they stay intact until
+   the SECOND following frame has been decoded (two images alternate). */
+int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strides[3]);
+/* on != 0: every decoded frame of this state is sent to its pinned host image by the launch that
+   decodes it (a kernel behind the loop filter writes it across PCIe), so that
+   thip_state_ycbcr_map / _out only wait.  Off by default: a caller that keeps frames on the
+   device (bench.py, transcoding) pays nothing. */
+int thip_state_set_eager_output(thip_state *st, int on);
 
 /* ------------------------------------------------------------------------------------
  * Work tiles.  The device walks a frame in the reference's CODED ORDER (state.c:123-190):

@@ -23,6 +23,8 @@ int thip_frag_copy_list(thip_state *, const ptrdiff_t *, ptrdiff_t) { return -1;
 int thip_state_loop_filter_frag_rows(thip_state *, int, int, int, int, int) { return -1; }
 int thip_frame_flush(thip_state *) { return -1; }
 int thip_state_ycbcr_out(thip_state *, uint8_t *const *, const int32_t *) { return -1; }
+int thip_state_ycbcr_map(thip_state *, const uint8_t **, int32_t *) { return -1; }
+int thip_state_set_eager_output(thip_state *, int) { return -1; }
 }
 
 static uint32_t g_rng;

@@ -138,6 +138,44 @@ def test_ycbcr_out_is_top_down(hip):
         assert np.array_equal(outs[pli], ost.get_plane(oracle.FRAME_PREV, pli)[::-1])
 
 
+@pytest.mark.parametrize("eager", [False, True])
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, PF_420), (80, 112, PF_422), (48, 32, PF_444)])
+def test_ycbcr_map_pinned_images(hip, w, h, fmt, eager):
+    """thip_state_ycbcr_map: the library's pinned image equals the copy of thip_state_ycbcr_out, with
+    and without eager output; two images alternate, so the view handed out for frame n is still frame
+    n after frame n+1 has been decoded, and a DUP frame leaves the current view alone."""
+    geom = synth.Geometry(w, h, fmt)
+    rng = np.random.default_rng(w + h)
+    ost = oracle.State(w, h, fmt)
+    gst = hip.State(w, h, fmt)
+    gst.set_eager_output(eager)
+    prev_view, prev_want = None, None
+    for i in range(5):
+        fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if i == 0 else hip.INTER_FRAME, "mixed")
+        util.oracle_apply(ost, fr)
+        desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+        hip.decode_frames([gst], [desc])
+        want = [ost.get_plane(oracle.FRAME_PREV, pli)[::-1].copy() for pli in range(3)]
+        view = gst.ycbcr_map()
+        copy = gst.ycbcr_out()
+        for pli in range(3):
+            assert np.array_equal(view[pli], want[pli])
+            assert np.array_equal(copy[pli], want[pli])
+            if prev_view is not None:
+                assert np.array_equal(prev_view[pli], prev_want[pli])   # the older image is untouched
+        prev_view, prev_want = view, want
+    # nothing coded: DUP frame, the picture and its image stay (decode.c:2764-2772)
+    empty = dict(fr)
+    empty.update(frame_type=hip.INTER_FRAME, coded_fragis=np.zeros(0, np.int64), ncoded=[0, 0, 0],
+                 uncoded_fragis=geom.coded_order[::-1].copy(), coeffs=np.zeros((0, 64), np.int16),
+                 last_zzi=np.zeros(0, np.uint8), dc_quant=np.zeros(0, np.uint16))
+    desc2, ka2 = synth.upload_frame(synth.pack_frame(geom, empty))
+    assert hip.decode_frames([gst], [desc2]) == [hip.DUPFRAME]
+    view2 = gst.ycbcr_map()
+    for pli in range(3):
+        assert np.array_equal(view2[pli], prev_want[pli])
+
+
 def test_parity_check_has_teeth(hip):
     """Negative control: a frame decoded with a different loop-filter limit on the GPU side
     must be reported as a mismatch by the same comparison the other tests rely on."""

@@ -139,6 +139,21 @@ class State:
         _lib.check(self._L.thip_state_ycbcr_out(self._h, ptrs, strides), "ycbcr_out")
         return outs
 
+    def ycbcr_map(self):
+        """The same frame without the copy: numpy views of the library's pinned image (valid
+        until the second following frame has been decoded; do not write)."""
+        ptrs = (C.c_void_p * 3)()
+        strides = (C.c_int32 * 3)()
+        _lib.check(self._L.thip_state_ycbcr_map(self._h, ptrs, strides), "ycbcr_map")
+        outs = []
+        for pli, g in enumerate(self.planes):
+            buf = (C.c_ubyte * (strides[pli] * g["height"])).from_address(ptrs[pli])
+            outs.append(np.frombuffer(buf, np.uint8).reshape(g["height"], strides[pli])[:, :g["width"]])
+        return outs
+
+    def set_eager_output(self, on):
+        _lib.check(self._L.thip_state_set_eager_output(self._h, int(bool(on))), "set_eager_output")
+
     # ---- host-enqueue form: the vtable slots, one fragment at a time --------------------
     def frame_begin(self, frame_type):
         _lib.check(self._L.thip_frame_begin(self._h, frame_type), "frame_begin")

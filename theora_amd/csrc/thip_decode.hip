@@ -36,6 +36,7 @@
 #include <time.h>
 
 #include <mutex>
+#include <sched.h>
 #include <vector>
 
 #include "../../include/theora_hip.h"
@@ -77,7 +78,13 @@ struct thip_state {
   uint32_t *h_slot0, *d_slot0;
   hipEvent_t ev_staging;     // recorded behind the kernels that read the staging buffers (enqueue path)
   hipStream_t last_stream;   // stream of the most recent launch for this state (ycbcr_out copies on it)
-  uint8_t *h_out;       // pinned image of one frame for thip_state_ycbcr_out (allocated on first use)
+  // Output to the host: k_frame_out writes the finished frame, top row first and tightly packed,
+  // straight into one of two pinned images (the kernel's stores cross PCIe; no DMA call, no flip
+  // on the host).  frame_serial counts finished frames, out_serial is the frame h_out[out_cur] holds.
+  uint8_t *h_out[2];
+  int out_cur, eager_out;
+  int64_t frame_serial, out_serial;
+  hipEvent_t ev_out;         // recorded behind k_frame_out
   int32_t *enq_last_lane;   // per tile: last lane that received a slot (arrival-order check)
   int enq_ncoded, enq_nuncoded, enq_nslots, enq_frame_type, enq_flimit, enq_active, enq_last_tile;
   int enq_lf_y0[3], enq_lf_y1[3], enq_lf_any;
@@ -251,6 +258,8 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
   st->ref_idx[0] = st->ref_idx[1] = st->ref_idx[2] = -1;   // state.c:658-663
   st->last_decoded = -1;
   st->lane = -1;
+  st->out_cur = -1;
+  st->out_serial = -1;
   *out = st;
   return THIP_OK;
 }
@@ -264,7 +273,9 @@ void thip_state_free(thip_state *st) {
   if (st->h_info) (void)hipHostFree(st->h_info);
   if (st->h_coeffs) (void)hipHostFree(st->h_coeffs);
   if (st->h_slot0) (void)hipHostFree(st->h_slot0);
-  if (st->h_out) (void)hipHostFree(st->h_out);
+  for (int b = 0; b < 2; b++)
+    if (st->h_out[b]) (void)hipHostFree(st->h_out[b]);
+  if (st->ev_out) (void)hipEventDestroy(st->ev_out);
   if (st->ev_staging) (void)hipEventDestroy(st->ev_staging);
   if (st->d_info) (void)hipFree(st->d_info);
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
@@ -307,6 +318,7 @@ int thip_state_set_ref_idx(thip_state *st, int gold, int prev, int self) {
   st->ref_idx[THIP_FRAME_PREV] = prev;
   st->ref_idx[THIP_FRAME_SELF] = self;
   if (self >= 0) st->last_decoded = self;
+  st->frame_serial++;
   return THIP_OK;
 }
 
@@ -332,6 +344,92 @@ int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *hos
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy2D(st->frames[bufi] + g.plane_off, g.stride, host_in, g.width, g.width, g.height,
                       hipMemcpyHostToDevice));
+  st->frame_serial++;
+  return THIP_OK;
+}
+
+// The finished frame -> pinned host memory in display order.  One thread moves 8 bytes (plane
+// widths are multiples of 8); a wave writes 512 contiguous bytes.
+struct OutK {
+  const uint8_t *src;
+  uint8_t *dst;
+  int width[3], height[3], stride[3], src_off[3], dst_off[3], unit_end[3];
+};
+__global__ __launch_bounds__(256) void k_frame_out(const OutK K) {
+  const int u = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (u >= K.unit_end[2]) return;
+  const int p = (u >= K.unit_end[0]) + (u >= K.unit_end[1]);
+  const int v = u - (p ? K.unit_end[p - 1] : 0);
+  const int wu = K.width[p] >> 3;
+  const int y = v / wu, x = v - y * wu;
+  // the device keeps row 0 at the bottom of the picture (decode.c:2988-2992 flips pointers instead)
+  const uint2 val = *reinterpret_cast<const uint2 *>(K.src + K.src_off[p] + (size_t)(K.height[p] - 1 - y) * K.stride[p] + x * 8);
+  *reinterpret_cast<uint2 *>(K.dst + K.dst_off[p] + (size_t)y * K.width[p] + x * 8) = val;
+}
+
+// Wait for an event of this state only.  hipEventSynchronize spins; with more decoder threads than
+// cores (every thread waiting for its own 60 us of GPU work) the spinning threads take the cores
+// from the parsing ones, so: poll, and give the core away between polls once the wait is no longer short.
+static int wait_event(hipEvent_t ev) {
+  for (int spins = 0;; spins++) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return THIP_OK;
+    if (e != hipErrorNotReady) {
+      fprintf(stderr, "theora_hip: hipEventQuery: %s\n", hipGetErrorString(e));
+      return THIP_EFAULT;
+    }
+    if (spins >= 64) sched_yield();
+  }
+}
+
+// Enqueue the copy of the most recently finished frame on stream s (the one that produced it).
+static int launch_frame_out(thip_state *st, hipStream_t s) {
+  const int nb = st->out_cur < 0 ? 0 : st->out_cur ^ 1;   // the other image: the previous one stays intact
+  if (!st->h_out[nb]) HIP_TRY(hipHostMalloc((void **)&st->h_out[nb], st->frame_bytes, hipHostMallocDefault));
+  if (!st->ev_out) HIP_TRY(hipEventCreateWithFlags(&st->ev_out, hipEventDisableTiming));
+  OutK K;
+  K.src = st->frames[st->last_decoded];
+  K.dst = st->h_out[nb];
+  int units = 0, off = 0;
+  for (int p = 0; p < 3; p++) {
+    const thip_plane_geom &g = st->geom[p];
+    K.width[p] = g.width;
+    K.height[p] = g.height;
+    K.stride[p] = g.stride;
+    K.src_off[p] = g.plane_off;
+    K.dst_off[p] = off;
+    off += g.width * g.height;
+    units += (g.width >> 3) * g.height;
+    K.unit_end[p] = units;
+  }
+  hipLaunchKernelGGL(k_frame_out, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, K);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(st->ev_out, s));
+  st->out_cur = nb;
+  st->out_serial = st->frame_serial;
+  return THIP_OK;
+}
+
+int thip_state_set_eager_output(thip_state *st, int on) {
+  if (!st) return THIP_EFAULT;
+  st->eager_out = on ? 1 : 0;
+  return THIP_OK;
+}
+
+int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strides[3]) {
+  if (!st || !planes || !strides) return THIP_EFAULT;
+  if (st->last_decoded < 0) return THIP_EINVAL;
+  if (st->out_serial != st->frame_serial) {   // not copied yet (no eager output, or the frame came from write_plane)
+    const int rc = launch_frame_out(st, st->last_stream);
+    if (rc < 0) return rc;
+  }
+  if (wait_event(st->ev_out) < 0) return THIP_EFAULT;
+  int off = 0;
+  for (int p = 0; p < 3; p++) {
+    planes[p] = st->h_out[st->out_cur] + off;
+    strides[p] = st->geom[p].width;
+    off += st->geom[p].width * st->geom[p].height;
+  }
   return THIP_OK;
 }
 
@@ -340,19 +438,13 @@ int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t ds
   if (st->last_decoded < 0) return THIP_EINVAL;
   for (int pli = 0; pli < 3; pli++)
     if (!dst[pli] || dst_stride[pli] < st->geom[pli].width) return THIP_EINVAL;
-  // one DMA of the whole frame (planes are contiguous, pitch == width) into pinned memory, on
-  // the stream that produced it, then the top-down flip on the host
-  if (!st->h_out) HIP_TRY(hipHostMalloc((void **)&st->h_out, st->frame_bytes, hipHostMallocDefault));
-  hipStream_t s = st->last_stream;   // null (legacy stream) if the frame came from write_plane only
-  HIP_TRY(hipMemcpyAsync(st->h_out, st->frames[st->last_decoded], st->frame_bytes, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  const uint8_t *src[3];
+  int32_t stride[3];
+  const int rc = thip_state_ycbcr_map(st, src, stride);
+  if (rc < 0) return rc;
   for (int pli = 0; pli < 3; pli++) {
     const thip_plane_geom &g = st->geom[pli];
-    // the device keeps row 0 at the bottom of the picture; hand the frame back top-down
-    // (decode.c:2988-2992 flips pointers instead)
-    const uint8_t *src = st->h_out + g.plane_off;
-    uint8_t *last = dst[pli] + (size_t)(g.height - 1) * dst_stride[pli];
-    for (int y = 0; y < g.height; y++) memcpy(last - (size_t)y * dst_stride[pli], src + (size_t)y * g.stride, g.width);
+    for (int y = 0; y < g.height; y++) memcpy(dst[pli] + (size_t)y * dst_stride[pli], src[pli] + (size_t)y * stride[pli], g.width);
   }
   return THIP_OK;
 }
@@ -425,6 +517,8 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       HIP_TRY(hipMemsetAsync(st->frames[0], 0x80, st->frame_bytes, s));
       st->ref_idx[0] = st->ref_idx[1] = st->ref_idx[2] = 0;
       st->last_decoded = 0;
+      st->last_stream = s;
+      st->frame_serial++;
     }
     if (d.ncoded == 0) {  // decode.c:2764-2772
       if (results) results[i] = THIP_DUPFRAME;
@@ -509,6 +603,11 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     st->ref_idx[THIP_FRAME_PREV] = self;
     st->last_decoded = self;
     st->last_stream = s;
+    st->frame_serial++;
+    if (st->eager_out) {
+      const int rc = launch_frame_out(st, s);
+      if (rc < 0) return rc;
+    }
   }
   return THIP_OK;
 }
@@ -605,7 +704,7 @@ int thip_frame_begin(thip_state *st, int frame_type) {
   if (rc) return rc;
   // the previous frame's kernels must have read the staging buffers before they are reused;
   // only this stream's own work is waited for, so contexts on other host threads keep going
-  if (st->ev_staging) HIP_TRY(hipEventSynchronize(st->ev_staging));
+  if (st->ev_staging && wait_event(st->ev_staging) < 0) return THIP_EFAULT;
   memset(st->h_info, 0, (size_t)st->tiles.ntiles * THIP_TILE_FRAGS * 8);   // everything uncoded
   memset(st->h_slot0, 0, (size_t)st->tiles.ntiles * 4);
   for (int t = 0; t < st->tiles.ntiles; t++) st->enq_last_lane[t] = -1;

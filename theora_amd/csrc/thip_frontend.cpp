@@ -927,6 +927,7 @@ th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup) {
     delete d;
     return nullptr;
   }
+  if (d->hip) thip_state_set_eager_output(d->hip, 1);   // every frame is wanted on the host (th_decode_ycbcr_out)
   build_geometry(d);
   d->dequant.resize((size_t)64 * 3 * 2 * 64);
   for (int qi = 0; qi < 64; qi++)
@@ -1428,19 +1429,20 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
 
 int th_decode_ycbcr_out(th_dec_ctx *d, th_ycbcr_buffer ycbcr) {
   if (!d || !ycbcr) return TH_EFAULT;
-  uint8_t *dst[3];
-  int32_t strides[3];
+  // Before the first frame (and in slot-trace mode) the picture is the context's own blank image;
+  // afterwards it is the backend's pinned image of the last decoded frame, which the decoding
+  // launch itself has been filling (thip_state_set_eager_output): nothing is copied here.
+  const uint8_t *src[3] = {d->mirror[0].data(), d->mirror[1].data(), d->mirror[2].data()};
+  int32_t strides[3] = {d->nh[0] * 8, d->nh[1] * 8, d->nh[2] * 8};
+  d->prof.start();
+  if (d->have_frame && !d->trace && thip_state_ycbcr_map(d->hip, src, strides) < 0) return TH_EFAULT;
+  d->prof.lap(FE_OUT);
   for (int p = 0; p < 3; p++) {
-    dst[p] = d->mirror[p].data();
-    strides[p] = d->nh[p] * 8;
     ycbcr[p].width = d->nh[p] * 8;
     ycbcr[p].height = d->nv[p] * 8;
     ycbcr[p].stride = strides[p];
-    ycbcr[p].data = dst[p];
+    ycbcr[p].data = const_cast<uint8_t *>(src[p]);
   }
-  d->prof.start();
-  if (d->have_frame && !d->trace && thip_state_ycbcr_out(d->hip, dst, strides) < 0) return TH_EFAULT;
-  d->prof.lap(FE_OUT);
   return 0;
 }
 
