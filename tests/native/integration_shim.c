@@ -68,3 +68,9 @@ int oc_hip_frame(oc_theora_state *_state, unsigned char *planes[3], const int32_
   if (thip_frame_flush(_state->hip) < 0) return -1;
   return thip_state_ycbcr_out(_state->hip, planes, strides);
 }
+
+/* th_decode_alloc / th_decode_ycbcr_out glue of INTEGRATION.md section 3: pointers instead of a copy */
+int oc_hip_map(oc_theora_state *_state, const unsigned char *planes[3], int32_t strides[3]) {
+  if (thip_state_set_eager_output(_state->hip, 1) < 0) return -1;
+  return thip_state_ycbcr_map(_state->hip, planes, strides);
+}
