@@ -186,6 +186,9 @@ def main_e2e(main_args, argv):
     ap.add_argument("--no-output", action="store_true", help="skip th_decode_ycbcr_out (no D2H)")
     ap.add_argument("--threads", type=int, default=1, help="host threads, one independent stream each")
     ap.add_argument("--trees", choices=["matched", "random"], default="matched")
+    ap.add_argument("--packets", choices=["dense", "typical"], default="dense",
+                    help="dense: 70 %% of the super blocks coded, 30 %% of the coded blocks with AC coefficients "
+                         "(~80 KB per 720p frame); typical: 35 %% / 15 %% (closer to SURVEY section 6's statistics, ~30 KB)")
     args = ap.parse_args(argv)
     args.size = main_args.size if main_args.size != "4k" else "720p"   # the generator is Python: keep it small
     import torch
@@ -195,7 +198,8 @@ def main_e2e(main_args, argv):
     w, h = SIZES[args.size]
     # Huffman trees built from the content's own token statistics, as an encoder's are (--trees random:
     # trees unrelated to the content, a fifth of the tokens with codes of 10+ bits)
-    content = dict(density=0.7, p_dc_only=0.5, p_empty=0.2)
+    content = dict(density=0.7, p_dc_only=0.5, p_empty=0.2) if args.packets == "dense" else \
+        dict(density=0.35, p_dc_only=0.45, p_empty=0.4)
     st = streamgen.Stream(w, h, 0, seed=99, trees=args.trees, probe_kwargs=content)
     hdr = st.header_packets()
     pkts = []
@@ -237,7 +241,7 @@ def main_e2e(main_args, argv):
     print(json.dumps({"metric": "end-to-end decode frames/sec (%s 4:2:0, packets in host memory -> YUV in host memory)" % args.size,
                       "value": round(n / el, 2), "unit": "frames/s", "frames": n, "host_threads": T, "streams": T,
                       "avg_packet_bytes": nbytes // len(pkts), "with_ycbcr_out": not args.no_output,
-                      "data": "synthetic packets (tests/streamgen.py), %s Huffman trees" % args.trees,
+                      "data": "synthetic packets (tests/streamgen.py), %s content, %s Huffman trees" % (args.packets, args.trees),
                       "note": "host-bound: one entropy-decode thread per stream + PCIe; th_decode_* contexts are independent"}))
     for dec in decs:
         dec.close()

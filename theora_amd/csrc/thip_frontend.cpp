@@ -189,9 +189,13 @@ struct th_dec_ctx {
   std::vector<uint8_t> coded, refi, qii, mbmode_of_frag;
   std::vector<int8_t> mvx, mvy;
   std::vector<int16_t> dc;
+  std::vector<int> clist;        // coded blocks (raster fragment index) in coded order; plane p is [cl_start[p], cl_start[p+1])
+  size_t cl_start[4];
+  std::vector<ptrdiff_t> ulist;  // the uncoded ones likewise (what frag_copy_list gets)
+  size_t ul_start[4];
   std::vector<uint8_t> dc_key;   // scratch of the DC un-prediction (one plane, bordered)
   std::vector<int16_t> dc_val;
-  std::vector<uint8_t> sbp, sbf, mbmodes;
+  std::vector<uint8_t> sbp, sbf, mbmodes, qi_bits;
   std::vector<Tok> toks[3][64];   // storage; the lists of the current frame are the first ntoks entries
   size_t ntoks[3][64];
   uint32_t eob_carry[3][64];
@@ -425,15 +429,12 @@ void read_long_run_bits(BitReader &br, size_t nbits, std::vector<uint8_t> &out) 
   if (!nbits) return;
   uint32_t bit = br.bit();
   for (;;) {
-    int rstart, rbits;
-    if (!br.bit()) { rstart = 1; rbits = 0; }
-    else if (!br.bit()) { rstart = 2; rbits = 1; }
-    else if (!br.bit()) { rstart = 4; rbits = 1; }
-    else if (!br.bit()) { rstart = 6; rbits = 2; }
-    else if (!br.bit()) { rstart = 10; rbits = 3; }
-    else if (!br.bit()) { rstart = 18; rbits = 4; }
-    else { rstart = 34; rbits = 12; }
-    size_t rlen = (size_t)rstart + br.read(rbits);
+    // Table 7.7: the run-length class is the number of leading ones (0..6) of the next six bits
+    static const uint8_t kStart[7] = {1, 2, 4, 6, 10, 18, 34}, kBits[7] = {0, 1, 1, 2, 3, 4, 12};
+    int ones = __builtin_clz(~(br.peek(6) << 26));
+    if (ones > 6) ones = 6;
+    br.skip(ones < 6 ? ones + 1 : 6);
+    size_t rlen = (size_t)kStart[ones] + br.read(kBits[ones]);
     const bool full = rlen == 4129;
     if (rlen > nbits - len) rlen = nbits - len;   // invalid stream: clip
     memset(&out[len], (int)bit, rlen);
@@ -449,14 +450,12 @@ void read_short_run_bits(BitReader &br, size_t nbits, std::vector<uint8_t> &out)
   if (!nbits) return;
   uint32_t bit = br.bit();
   for (;;) {
-    int rstart, rbits;
-    if (!br.bit()) { rstart = 1; rbits = 1; }
-    else if (!br.bit()) { rstart = 3; rbits = 1; }
-    else if (!br.bit()) { rstart = 5; rbits = 1; }
-    else if (!br.bit()) { rstart = 7; rbits = 2; }
-    else if (!br.bit()) { rstart = 11; rbits = 2; }
-    else { rstart = 15; rbits = 4; }
-    size_t rlen = (size_t)rstart + br.read(rbits);
+    // Table 7.11: leading ones (0..5) of the next five bits
+    static const uint8_t kStart[6] = {1, 3, 5, 7, 11, 15}, kBits[6] = {1, 1, 1, 2, 2, 4};
+    int ones = __builtin_clz(~(br.peek(5) << 27));
+    if (ones > 5) ones = 5;
+    br.skip(ones < 5 ? ones + 1 : 5);
+    size_t rlen = (size_t)kStart[ones] + br.read(kBits[ones]);
     if (rlen > nbits - len) rlen = nbits - len;
     memset(&out[len], (int)bit, rlen);
     len += rlen;
@@ -1091,6 +1090,26 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     if (granpos) *granpos = d->granpos;
     return TH_DUPFRAME;
   }
+  // the coded blocks in coded order, per plane: what every later stage walks
+  {
+    d->clist.resize((size_t)ncoded_total + 1);   // + 1: the slot a block is written to and not kept
+    d->ulist.resize((size_t)(N - ncoded_total) + 1);
+    int cstart[4] = {0, d->nfrags_pl[0], d->nfrags_pl[0] + d->nfrags_pl[1], N};
+    size_t n = 0, u = 0;
+    for (int p = 0; p < 3; p++) {
+      d->cl_start[p] = n;
+      d->ul_start[p] = u;
+      for (int k = cstart[p]; k < cstart[p + 1]; k++) {
+        const int f = d->coded_order[k];
+        d->clist[n] = f;   // both unconditionally; the right one keeps it (no branch on a random flag)
+        d->ulist[u] = f;
+        n += d->coded[f];
+        u += !d->coded[f];
+      }
+    }
+    d->cl_start[3] = n;
+    d->ul_start[3] = u;
+  }
   d->prof.lap(FE_FLAGS);
   if (d->frame_type == THIP_INTRA_FRAME) {
     d->keyframe_num = d->curframe_num;
@@ -1195,18 +1214,22 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   d->prof.lap(FE_MODES);
   // ---- 7.6 block-level qi ---------------------------------------------------------------------------
   memset(d->qii.data(), 0, (size_t)N);
-  for (int q = 0; q + 1 < d->nqis; q++) {
-    size_t nb = 0;
-    for (int k = 0; k < N; k++) {
-      const int f = d->coded_order[k];
-      nb += d->coded[f] && d->qii[f] == q;
-    }
-    std::vector<uint8_t> bits;
-    read_long_run_bits(br, nb, bits);
-    size_t bi = 0;
-    for (int k = 0; k < N; k++) {
-      const int f = d->coded_order[k];
-      if (d->coded[f] && d->qii[f] == q) d->qii[f] = (uint8_t)(d->qii[f] + bits[bi++]);
+  {
+    const size_t nc = d->cl_start[3];
+    const int *cl = d->clist.data();
+    std::vector<uint8_t> &bits = d->qi_bits;
+    for (int q = 0; q + 1 < d->nqis; q++) {
+      size_t nb = 0;
+      for (size_t i = 0; i < nc; i++) nb += d->qii[cl[i]] == q;
+      read_long_run_bits(br, nb, bits);
+      bits.push_back(0);   // the entry a block that takes no bit looks at
+      size_t bi = 0;
+      for (size_t i = 0; i < nc; i++) {
+        const int f = cl[i];
+        const unsigned m = d->qii[f] == q;
+        d->qii[f] = (uint8_t)(d->qii[f] + (m & bits[bi]));
+        bi += m;
+      }
     }
   }
   d->prof.lap(FE_QI);
@@ -1214,12 +1237,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   {
     size_t left[3][128];   // [64..127]: where advances past the last index land
     memset(left, 0, sizeof(left));
-    int cstart[4] = {0, d->nfrags_pl[0], d->nfrags_pl[0] + d->nfrags_pl[1], N};
-    for (int p = 0; p < 3; p++) {
-      size_t n = 0;
-      for (int k = cstart[p]; k < cstart[p + 1]; k++) n += d->coded[d->coded_order[k]];
-      left[p][0] = n;
-    }
+    for (int p = 0; p < 3; p++) left[p][0] = d->cl_start[p + 1] - d->cl_start[p];
     memset(d->ntoks, 0, sizeof(d->ntoks));
     memset(d->eob_carry, 0, sizeof(d->eob_carry));
     uint32_t eobs = 0;
@@ -1256,27 +1274,21 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   }
   d->prof.lap(FE_TOKENS);
   // ---- 7.8 undo DC prediction (the DC token values are the first coefficient of each block) -----------
-  // first pull the DC values out of the zzi == 0 lists, in coded order
+  // first pull the DC values out of the zzi == 0 lists: token by token over the coded blocks in order
   {
-    int cstart[4] = {0, d->nfrags_pl[0], d->nfrags_pl[0] + d->nfrags_pl[1], N};
     for (int p = 0; p < 3; p++) {
-      size_t ti = 0;
-      uint32_t run = d->eob_carry[p][0];
-      for (int k = cstart[p]; k < cstart[p + 1]; k++) {
-        const int f = d->coded_order[k];
-        if (!d->coded[f]) continue;
-        int16_t v = 0;
-        if (run) run--;
-        else {
-          if (ti >= d->ntoks[p][0]) break;   // (cannot happen: the list covers every coded block)
-          const Tok &t = d->toks[p][0][ti];
-          if (t.eob) run = t.eob - 1;
-          else if (t.skip == 0) v = t.value;
-          // the token is consumed again by the expansion below; do not advance past it here
-          ti++;
-        }
-        d->dc[f] = v;
+      const int *cl = d->clist.data() + d->cl_start[p];
+      const size_t nb = d->cl_start[p + 1] - d->cl_start[p];
+      size_t i = d->eob_carry[p][0] < nb ? d->eob_carry[p][0] : nb;   // blocks ended by a run from before
+      for (size_t j = 0; j < i; j++) d->dc[cl[j]] = 0;
+      const Tok *t = d->toks[p][0].data();
+      for (const Tok *const tend = t + d->ntoks[p][0]; t < tend && i < nb; t++) {
+        if (t->eob) {   // this block and the next eob - 1 have no coefficients at all
+          size_t e = nb - i < t->eob ? nb - i : t->eob;
+          while (e--) d->dc[cl[i++]] = 0;
+        } else d->dc[cl[i++]] = (int16_t)(t->skip == 0 ? t->value : 0);
       }
+      while (i < nb) d->dc[cl[i++]] = 0;   // (cannot happen: the list covers every coded block)
     }
     // Which neighbours predict a block is a question of "coded, and from the same reference frame"
     // (7.8.1, Table 7.47): one byte per block (reference index, 0xFF = not coded) in an array with a
@@ -1344,8 +1356,6 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   {
     alignas(16) int16_t block[128];
     memset(block, 0, sizeof(block));
-    std::vector<ptrdiff_t> uncoded;
-    int cstart[4] = {0, d->nfrags_pl[0], d->nfrags_pl[0] + d->nfrags_pl[1], N};
     for (int p = 0; p < 3; p++) {
       const Tok *tp[64];   // next token of every index list (each list ends in an endless EOB run)
       uint32_t run[64];
@@ -1353,13 +1363,8 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         tp[z] = d->toks[p][z].data();
         run[z] = d->eob_carry[p][z];
       }
-      uncoded.clear();
-      for (int k = cstart[p]; k < cstart[p + 1]; k++) {
-        const int f = d->coded_order[k];
-        if (!d->coded[f]) {
-          uncoded.push_back(f);
-          continue;
-        }
+      for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
+        const int f = d->clist[ci];
         const int qti = d->mbmode_of_frag[f] != MODE_INTRA;
         const uint16_t *acq = &d->dequant[(((size_t)d->qis[d->qii[f]] * 3 + p) * 2 + qti) * 64];
         const uint16_t dcq = d->dequant[(((size_t)d->qis[0] * 3 + p) * 2 + qti) * 64];
@@ -1399,12 +1404,13 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         rc = thip_state_frag_recon(d->hip, f, p, block, last_zzi, dcq, d->refi[f], mv);
         if (rc < 0) return TH_EFAULT;
       }
+      const ptrdiff_t *const uncoded = d->ulist.data() + d->ul_start[p];
+      const size_t nuncoded = d->ul_start[p + 1] - d->ul_start[p];
       if (d->trace) {
-        for (ptrdiff_t u : uncoded) d->tr_uncoded.push_back((int64_t)u);
+        for (size_t u = 0; u < nuncoded; u++) d->tr_uncoded.push_back((int64_t)uncoded[u]);
         continue;
       }
-      if (!uncoded.empty() && thip_frag_copy_list(d->hip, uncoded.data(), (ptrdiff_t)uncoded.size()) < 0)
-        return TH_EFAULT;
+      if (nuncoded && thip_frag_copy_list(d->hip, uncoded, (ptrdiff_t)nuncoded) < 0) return TH_EFAULT;
       if (flimit && thip_state_loop_filter_frag_rows(d->hip, flimit, THIP_FRAME_SELF, p, 0, d->nv[p]) < 0)
         return TH_EFAULT;
     }
