@@ -1321,17 +1321,21 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
           if (r == 0xFF) continue;
           const int mask = (kr[x - 1] == r) | (kr[x - W - 1] == r) << 1 | (kr[x - W] == r) << 2 | (kr[x - W + 1] == r) << 3;
           int pred;
-          if (mask == 0) pred = last[r];
+          if ((mask & 7) == 7) {
+            // L, UL and U all present (every interior block of a key frame): (29 L - 26 UL + 29 U) / 32
+            // whether or not UR is, then the outlier clamp (7.8.1 step 5)
+            const int l = vr[x - 1], ul = vr[x - W - 1], u = vr[x - W];
+            const int num = 29 * (l + u) - 26 * ul;
+            pred = (num + ((num >> 31) & 31)) >> 5;   // num / 32, towards zero
+            if (abs(pred - u) > 128) pred = u;
+            else if (abs(pred - l) > 128) pred = l;
+            else if (abs(pred - ul) > 128) pred = ul;
+          } else if (mask == 0) pred = last[r];
           else {
             const int l = vr[x - 1], ul = vr[x - W - 1], u = vr[x - W], ur = vr[x - W + 1];
             const int num = Wt[mask][0] * l + Wt[mask][1] * ul + Wt[mask][2] * u + Wt[mask][3] * ur;
             const int sh = Dsh[mask];
             pred = (num + ((num >> 31) & ((1 << sh) - 1))) >> sh;   // num / 2^sh, towards zero
-            if ((mask & 7) == 7) {   // L, UL and U all present: clamp outliers (7.8.1 step 5)
-              if (abs(pred - u) > 128) pred = u;
-              else if (abs(pred - l) > 128) pred = l;
-              else if (abs(pred - ul) > 128) pred = ul;
-            }
           }
           const int16_t v = (int16_t)(d->dc[f0 + x] + pred);   // 16-bit wrap
           d->dc[f0 + x] = v;
