@@ -24,10 +24,11 @@ def trace_env():
         os.environ["THIP_FE_TRACE_BACKEND"] = old
 
 
+@pytest.mark.parametrize("trees", ["random", "matched"])
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0)])
-def test_slot_calls_match_ground_truth(trace_env, w, h, fmt):
+def test_slot_calls_match_ground_truth(trace_env, w, h, fmt, trees):
     from theora_amd.decoder import Decoder
-    st = streamgen.Stream(w, h, fmt, seed=w * 5 + h + fmt)
+    st = streamgen.Stream(w, h, fmt, seed=w * 5 + h + fmt, trees=trees)
     dec = Decoder(st.header_packets())
     ost = oracle.State(w, h, fmt)          # ground truth -> oracle
     ost2 = oracle.State(w, h, fmt)         # recorded slot calls -> oracle

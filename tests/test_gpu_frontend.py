@@ -12,9 +12,9 @@ from tests import streamgen, util
 pytestmark = pytest.mark.gpu
 
 
-def run_stream(hip, w, h, fmt, seed, nframes, kf=5):
+def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random"):
     from theora_amd.decoder import Decoder
-    st = streamgen.Stream(w, h, fmt, seed)
+    st = streamgen.Stream(w, h, fmt, seed, trees=trees)
     dec = Decoder(st.header_packets())
     assert dec.info.frame_width == w and dec.info.frame_height == h and dec.info.pixel_fmt == fmt
     assert dec.comment.vendor == b"theora-hip streamgen"
@@ -42,6 +42,12 @@ def run_stream(hip, w, h, fmt, seed, nframes, kf=5):
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (336, 32, 0)])
 def test_packets_decode_bit_exact(hip, w, h, fmt):
     assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9) >= 6
+
+
+def test_packets_decode_bit_exact_720p(hip):
+    """BASELINE.json's 720p size through the whole API (key frame + inter frames of three densities),
+    with Huffman trees matched to the content: the short-code fast path of the token loop at scale."""
+    assert run_stream(hip, 1280, 720, 0, seed=720, nframes=4, kf=3, trees="matched") >= 3
 
 
 def test_empty_packet_is_dup_frame(hip):
