@@ -547,6 +547,9 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     K.coded_map = st->coded_map;
     K.flimit2 = 2 * d.flimit;
     K.debug = g_debug;
+    // flags-first loop filter when at least a tenth of the frame is uncoded (THIP_LF_SPARSE=0/1 forces)
+    static const int lf_sparse_env = getenv("THIP_LF_SPARSE") ? atoi(getenv("THIP_LF_SPARSE")) : -1;
+    K.lf_sparse = lf_sparse_env >= 0 ? lf_sparse_env : (int64_t)d.ncoded * 10 < (int64_t)st->nfrags * 9;
     K.qpx = st->hdec;
     K.qpy = st->vdec;
     fill_stream_geom(K, st);

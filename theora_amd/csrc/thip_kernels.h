@@ -56,6 +56,7 @@ struct StreamK {
   int cell_end[3];        // cumulative filter-cell counts per plane, each plane padded to 64 (k_loopfilter)
   int lf_y0[3], lf_y1[3]; // fragment-row range whose filter operations are applied
   int debug;              // ablation switches for profiling (THIP_DEBUG env), 0 in production
+  int lf_sparse;          // k_loopfilter reads the coded flags first and skips waves without a coded block
   // fused reconstruction + loop filter (k_recon_lf / k_lf_seam)
   int seg_end[3];         // cumulative workgroup counts per plane: one workgroup per (tile row, segment)
   int seam_end[3];        // cumulative seam-cell counts per plane, each plane padded to 64
@@ -1005,8 +1006,21 @@ __global__ __launch_bounds__(256) void k_loopfilter(const BatchK B) {
   divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
   const int k = (int)ku, m = (int)mu;
   CellPix C;
-  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
   bool a, b, c, d;
+  if (S.lf_sparse) {
+    // A frame with uncoded regions (wave-uniform choice, made on the host from the coded count):
+    // the coded flags come first, and a wave none of whose 64 cells has an edge to filter -- a
+    // static background -- ends here without touching a pixel.  The price is a second, dependent
+    // round trip for the waves that stay, which is why fully coded frames take the other branch.
+    lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
+    const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
+    if (!__any(t != 0)) return;
+    lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
+    lf_cell_pin(C);
+    lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
+    return;
+  }
+  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
   lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
   const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
   lf_cell_pin(C);

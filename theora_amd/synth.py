@@ -84,6 +84,9 @@ CLASSES = {
                    p_zz10=0.15, amp=24, edge_mv=0.0, extreme=0.0),
     "mixed": dict(p_coded=0.6, intra=0.15, golden=0.15, zeromv=0.15, halfpel=0.4, p_dc_only=0.3,
                   p_zz10=0.3, amp=300, edge_mv=0.3, extreme=0.02),
+    # a quarter of the picture changes (smooth statistics inside), the rest is a static background
+    "static_bg": dict(p_coded=0.9, intra=0.039, golden=0.003, zeromv=0.086, halfpel=0.025, p_dc_only=0.80,
+                      p_zz10=0.15, amp=24, edge_mv=0.0, extreme=0.0, window=0.25),
     # diagnostic classes: each isolates one access pattern of k_recon (bench.py --content)
     "skip": dict(p_coded=0.0, intra=0.0, golden=0.0, zeromv=1.0, halfpel=0.0, p_dc_only=1.0,
                  p_zz10=0.0, amp=24, edge_mv=0.0, extreme=0.0),            # copy prev -> self only
@@ -131,6 +134,12 @@ def gen_frame(geom, rng, frame_type, content="mixed", flimit=None, global_mv=Non
         mb_mvy[mb_refi == FRAME_SELF] = 0
         # spatially coherent coded probability
         mb_coded_p = np.clip(P["p_coded"] + 0.5 * (rng.random(nmb) - 0.5) * (P["p_coded"] < 1.0), 0.0, 1.0)
+        if P.get("window"):
+            # only a centred window of the picture (this fraction of its area) changes: static background
+            f = float(P["window"]) ** 0.5
+            my, mx = np.divmod(np.arange(nmb), geom.nhmb)
+            inside = (np.abs(mx - geom.nhmb / 2) <= f * geom.nhmb / 2) & (np.abs(my - geom.nvmb / 2) <= f * geom.nvmb / 2)
+            mb_coded_p = np.where(inside, mb_coded_p, 0.0)
     # --- per fragment -------------------------------------------------------------------
     refi = mb_refi[geom.mb_of]
     mvx = mb_mvx[geom.mb_of].astype(np.int32)
