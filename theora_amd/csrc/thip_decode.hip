@@ -171,7 +171,9 @@ void fill_stream_geom(StreamK &K, const thip_state *st) {
     cells += ((g.nhfrags + 1) * (g.nvfrags + 1) + 63) & ~63;   // whole waves per plane (k_loopfilter)
     K.cell_end[pli] = cells;
     // fused path: segments of at most kSegMax tiles, as equal as possible
-    k.nseg = (k.tiles_x + kSegMax - 1) / kSegMax;
+    static const int segmax_env = getenv("THIP_SEGMAX") ? atoi(getenv("THIP_SEGMAX")) : kSegMax;
+    const int segmax = segmax_env < 1 ? 1 : (segmax_env > kSegMax ? kSegMax : segmax_env);
+    k.nseg = (k.tiles_x + segmax - 1) / segmax;
     k.seglen = (k.tiles_x + k.nseg - 1) / k.nseg;
     segs += st->tiles.tiles_y[pli] * k.nseg;
     K.seg_end[pli] = segs;
