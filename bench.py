@@ -80,7 +80,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--size", default="4k", choices=sorted(SIZES))
-    ap.add_argument("--content", default="dense", choices=["dense", "smooth", "mixed", "static_bg", "skip", "zeromv_dc", "intra_dense"])
+    ap.add_argument("--content", default="dense", choices=["dense", "smooth", "mixed", "static_bg", "static_1pct", "skip", "zeromv_dc", "intra_dense"])
     ap.add_argument("--streams-per-gpu", type=int, default=4)
     ap.add_argument("--pool", type=int, default=6, help="distinct inter-frame command streams per stream")
     ap.add_argument("--cpu-frames", type=int, default=288, help="frames of stream 0 the CPU oracle decodes (~10 s at 4K)")

@@ -88,6 +88,8 @@ CLASSES = {
     "static_bg": dict(p_coded=0.9, intra=0.039, golden=0.003, zeromv=0.086, halfpel=0.025, p_dc_only=0.80,
                       p_zz10=0.15, amp=24, edge_mv=0.0, extreme=0.0, window=0.25),
     # diagnostic classes: each isolates one access pattern of k_recon (bench.py --content)
+    "static_1pct": dict(p_coded=0.9, intra=0.039, golden=0.003, zeromv=0.086, halfpel=0.025, p_dc_only=0.80,
+                        p_zz10=0.15, amp=24, edge_mv=0.0, extreme=0.0, window=0.01),   # almost nothing changes
     "skip": dict(p_coded=0.0, intra=0.0, golden=0.0, zeromv=1.0, halfpel=0.0, p_dc_only=1.0,
                  p_zz10=0.0, amp=24, edge_mv=0.0, extreme=0.0),            # copy prev -> self only
     "zeromv_dc": dict(p_coded=1.0, intra=0.0, golden=0.0, zeromv=1.0, halfpel=0.0, p_dc_only=1.0,
