@@ -32,6 +32,43 @@ def test_lane_shared_transform_boundaries(hip, p_dc_only):
     assert not rep, rep[:3]
 
 
+@pytest.mark.parametrize("w,h,fmt", [(256, 160, PF_420), (176, 144, PF_444), (336, 96, PF_422), (64, 48, PF_420)])
+@pytest.mark.parametrize("window", [0.25, 0.6, 0.02])
+def test_static_background_blocks_stay_in_place(hip, w, h, fmt, window):
+    """Blocks that are uncoded in two consecutive frames and whose edge neighbours were uncoded in the first
+    of them are not copied: the ring buffer they would be copied into holds them already (k_recon,
+    launch_chunk).  A centred window of the picture changes, the rest is static, over key frames (which
+    break the two-buffer rotation), golden references and edge vectors; every plane of every frame is
+    compared, with the elision on (default) -- the same sequences with it off are the other tests."""
+    content = dict(synth.CLASSES["mixed"], p_coded=0.85, window=window)
+    rep = util.run_sequence(hip, w, h, fmt, nframes=14, content=content, seed=int(window * 100) + w, kf_interval=6)
+    assert not rep, rep[:3]
+
+
+def test_static_background_through_the_slots_and_across_dup_frames(hip):
+    """The same through the one-fragment-at-a-time slots, and with frames in which nothing is coded in
+    between (decode.c:2764-2772: the state does not move, so the next frame still finds the frame before
+    the previous one in its buffer)."""
+    content = dict(synth.CLASSES["mixed"], p_coded=0.85, window=0.3)
+    rep = util.run_sequence(hip, 176, 144, PF_420, nframes=9, content=content, seed=77, kf_interval=5, enqueue=True)
+    assert not rep, rep[:3]
+    w, h = 256, 96
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(5)
+    ost = oracle.State(w, h, PF_420)
+    gst = hip.State(w, h, PF_420)
+    for f in range(12):
+        fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, content)
+        if f in (4, 5, 9):   # nothing coded
+            fr = dict(fr)
+            fr.update(coded_fragis=np.zeros(0, np.int64), ncoded=[0, 0, 0], uncoded_fragis=geom.coded_order[::-1].copy(),
+                      coeffs=np.zeros((0, 64), np.int16), last_zzi=np.zeros(0, np.uint8), dc_quant=np.zeros(0, np.uint16))
+        rc_o = util.oracle_apply(ost, fr)
+        desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+        assert hip.decode_frames([gst], [desc])[0] == rc_o
+        assert not util.planes_equal(ost, gst), f
+
+
 def test_sequence_720p(hip):
     """BASELINE.json config 2: one 720p stream, more than a key-frame interval of 64, every plane of
     every frame compared."""
@@ -203,6 +240,22 @@ def test_fused_recon_loopfilter_variant(hip):
     env = dict(os.environ, THIP_FUSE="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q",
-                        "-k", "sequence or enqueue or batched or grey or dup"], cwd=root, env=env,
+                        "-k", "(sequence or enqueue or batched or grey or dup) and not elision and not fused"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_static_block_elision_forced_on_every_frame(hip):
+    """THIP_SKIP_STATIC=2 lifts the "most of the frame is uncoded" condition, so that every inter frame of
+    the sequence tests of this file (scattered uncoded blocks, all content classes, the slots, batches, DUP
+    frames, the grey start) takes the path that leaves untouched blocks where they are."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, THIP_SKIP_STATIC="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q",
+                        "-k", "(sequence_small or static_background or enqueue or batched or grey or dup or lane_shared) "
+                              "and not elision and not fused"], cwd=root,
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

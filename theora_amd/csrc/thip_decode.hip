@@ -65,7 +65,10 @@ struct thip_state {
   int64_t nfrags;
   size_t frame_bytes;
   uint8_t *frames[3];   // device
-  uint8_t *coded_map;   // device, nfrags bytes
+  uint8_t *coded_map;   // device, 2 x nfrags bytes: the coded flags of the current and of the previous frame
+  // Which decoded frame (counted by frame_serial) each buffer holds, -1 if unknown, and which frame's
+  // flags sit in each half of coded_map: what makes leaving static blocks in place safe (launch_chunk).
+  int64_t buf_serial[3], map_serial[2];
   int ref_idx[3];       // THIP_FRAME_* -> buffer index
   int last_decoded;     // buffer index of the most recently completed frame, -1 if none
   int lane;             // library-owned HIP stream this state is bound to, -1 until first use
@@ -249,8 +252,8 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
   hipError_t err = hipSuccess;
   // +256: aligned 12-byte predictor windows may read 3 bytes past a row end
   for (int b = 0; b < 3 && err == hipSuccess; b++) err = hipMalloc((void **)&st->frames[b], st->frame_bytes + 256);
-  if (err == hipSuccess) err = hipMalloc((void **)&st->coded_map, (size_t)st->nfrags);
-  if (err == hipSuccess) err = hipMemset(st->coded_map, 0, (size_t)st->nfrags);
+  if (err == hipSuccess) err = hipMalloc((void **)&st->coded_map, 2 * (size_t)st->nfrags);
+  if (err == hipSuccess) err = hipMemset(st->coded_map, 0, 2 * (size_t)st->nfrags);
   if (err != hipSuccess) {
     fprintf(stderr, "theora_hip: thip_state_create: device allocation failed: %s\n", hipGetErrorString(err));
     thip_state_free(st);
@@ -261,6 +264,8 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
   st->lane = -1;
   st->out_cur = -1;
   st->out_serial = -1;
+  st->buf_serial[0] = st->buf_serial[1] = st->buf_serial[2] = -1;
+  st->map_serial[0] = st->map_serial[1] = -1;
   *out = st;
   return THIP_OK;
 }
@@ -320,6 +325,7 @@ int thip_state_set_ref_idx(thip_state *st, int gold, int prev, int self) {
   st->ref_idx[THIP_FRAME_SELF] = self;
   if (self >= 0) st->last_decoded = self;
   st->frame_serial++;
+  st->buf_serial[0] = st->buf_serial[1] = st->buf_serial[2] = -1;   // the caller re-labelled the buffers
   return THIP_OK;
 }
 
@@ -346,6 +352,7 @@ int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *hos
   HIP_TRY(hipMemcpy2D(st->frames[bufi] + g.plane_off, g.stride, host_in, g.width, g.width, g.height,
                       hipMemcpyHostToDevice));
   st->frame_serial++;
+  st->buf_serial[bufi] = -1;
   return THIP_OK;
 }
 
@@ -530,6 +537,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       st->last_decoded = 0;
       st->last_stream = s;
       st->frame_serial++;
+      st->buf_serial[0] = st->buf_serial[1] = st->buf_serial[2] = -1;
     }
     if (d.ncoded == 0) {  // decode.c:2764-2772
       if (results) results[i] = THIP_DUPFRAME;
@@ -546,7 +554,24 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     K.self = st->frames[bufi];
     K.prev = st->ref_idx[THIP_FRAME_PREV] >= 0 ? st->frames[st->ref_idx[THIP_FRAME_PREV]] : st->frames[bufi];
     K.gold = st->ref_idx[THIP_FRAME_GOLD] >= 0 ? st->frames[st->ref_idx[THIP_FRAME_GOLD]] : st->frames[bufi];
-    K.coded_map = st->coded_map;
+    // The flags of this frame go to the half of coded_map that does not hold the previous frame's.
+    // A block that is uncoded now can stay where it is if the destination already holds it: the
+    // buffer was last written two frames ago (the usual rotation between two key frames), the
+    // previous frame is the PREV reference, and the previous frame's flags are at hand to tell that
+    // it did not touch the block (k_recon).  THIP_SKIP_STATIC=0 switches the elision off, 2 applies it to
+    // every frame with an uncoded block (tests).
+    static const int skip_static = getenv("THIP_SKIP_STATIC") ? atoi(getenv("THIP_SKIP_STATIC")) : 1;
+    const int64_t serial = st->frame_serial + 1;   // of the frame being decoded
+    const int pm = st->map_serial[0] == serial - 1 ? 0 : (st->map_serial[1] == serial - 1 ? 1 : -1);
+    const int cm = pm == 0 ? 1 : 0;
+    K.coded_map = st->coded_map + (size_t)cm * st->nfrags;
+    K.coded_prev = st->coded_map + (size_t)(pm < 0 ? cm : pm) * st->nfrags;
+    // (only when most of the frame is uncoded: the test costs every tile five byte loads per block, and
+    //  with scattered uncoded blocks -- the smooth class, 34 % -- hardly a 64-byte line is saved)
+    K.skip_ok = skip_static && pm >= 0 && ((int64_t)d.ncoded * 2 < st->nfrags || (skip_static == 2 && d.ncoded < st->nfrags)) && serial >= 2 && st->buf_serial[bufi] == serial - 2 &&
+                st->ref_idx[THIP_FRAME_PREV] >= 0 && st->buf_serial[st->ref_idx[THIP_FRAME_PREV]] == serial - 1;
+    st->map_serial[cm] = serial;
+    st->buf_serial[bufi] = serial;
     K.flimit2 = 2 * d.flimit;
     K.debug = g_debug;
     // flags-first loop filter when at least a tenth of the frame is uncoded (THIP_LF_SPARSE=0/1 forces)

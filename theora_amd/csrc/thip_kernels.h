@@ -50,6 +50,9 @@ struct StreamK {
   const uint8_t *prev;
   const uint8_t *gold;
   uint8_t *coded_map;     // 1 byte per fragment, raster order: written by k_recon, read by k_loopfilter
+  const uint8_t *coded_prev;   // the same map of the previous frame of this stream (two maps alternate)
+  int skip_ok;            // the buffer this frame goes to holds the frame before the previous one: an uncoded
+                          // block that was not touched in the previous frame either is already in place
   int flimit2;            // 2*flimit
   int qpx, qpy;           // chroma axis decimated (quarter-pel chroma vectors)
   int tile_end[3];        // cumulative tile counts per plane (k_recon: one wave per tile)
@@ -664,25 +667,16 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   uint8_t *self = S.self;
   const uint8_t *prev = S.prev, *gold = S.gold;
   uint8_t *coded_map = S.coded_map;
+  const uint8_t *coded_prev = S.coded_prev;
   const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2];
-  const int debug = S.debug, sqpx = S.qpx, sqpy = S.qpy;
+  const int debug = S.debug, sqpx = S.qpx, sqpy = S.qpy, skip_ok = S.skip_ok;
   asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
-               "s"(te0), "s"(te1), "s"(te2), "s"(debug), "s"(sqpx), "s"(sqpy));
+               "s"(coded_prev), "s"(te0), "s"(te1), "s"(te2), "s"(debug), "s"(sqpx), "s"(sqpy), "s"(skip_ok));
   if (unit >= te2) return;
   const int pli = (unit >= te0 ? 1 : 0) + (unit >= te1 ? 1 : 0);
   // scalar batch 2: the plane's geometry
   const PlaneK G = S.pl[pli];
   asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.fro));
-
-  // ---- 1. command word + first slot of the tile (one round trip) -------------------------------
-  const uint32_t slot0 = slot0_p[unit];
-  const uint2 info = info_p[(size_t)unit * THIP_TILE_FRAGS + lane];
-  // both loads are consumed here as far as the compiler can tell, so the scalar load is issued
-  // next to the vector load instead of being sunk behind the wait for it
-  asm volatile("" ::"s"(slot0), "v"(info.x));
-#ifdef THIP_TRACE
-  THIP_TR(tr, 1);   // first round trip done
-#endif
 
   const int rel = unit - (pli == 0 ? 0 : (pli == 1 ? te0 : te1));
   const int sby = rel / G.tiles_x;
@@ -691,6 +685,28 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   const int bx = tx * 16 + (lane >> 4) * 4 + hilb_col(h);
   const int by = sby * 4 + hilb_row(h);
   const bool valid = bx < G.nh && by < G.nv;
+
+  // ---- 1. command word + first slot of the tile (one round trip) -------------------------------
+  const uint32_t slot0 = slot0_p[unit];
+  const uint2 info = info_p[(size_t)unit * THIP_TILE_FRAGS + lane];
+  // ... and, when the frame may leave blocks where they are (skip_ok, wave-uniform), what the
+  // previous frame did to this block and to the four blocks it shares an edge with: if none of
+  // them was coded, neither the reconstruction nor the loop filter of the previous frame changed
+  // a pixel of it (an edge is filtered only if a block on one of its sides is coded).
+  uint32_t touched = 1;
+  if (skip_ok) {
+    const int cx = min(bx, G.nh - 1), cy = min(by, G.nv - 1);
+    const uint8_t *op = coded_prev + G.fro + cy * G.nh + cx;
+    const int dl = cx > 0 ? 1 : 0, dr = cx < G.nh - 1 ? 1 : 0, du = cy > 0 ? G.nh : 0, dd = cy < G.nv - 1 ? G.nh : 0;
+    // (a neighbour outside the plane reads the block's own flag again)
+    touched = (uint32_t)op[0] | op[-dl] | op[dr] | op[-du] | op[dd];
+  }
+  // all loads are consumed here as far as the compiler can tell, so the scalar load is issued
+  // next to the vector loads instead of being sunk behind the wait for them
+  asm volatile("" ::"s"(slot0), "v"(info.x), "v"(touched));
+#ifdef THIP_TRACE
+  THIP_TR(tr, 1);   // first round trip done
+#endif
 
   ReconLane L;
   L.flags = valid ? info.x : 0u;
@@ -702,6 +718,9 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   L.has_coeff = L.coded && !L.dc_only;
   L.x0 = bx * 8;
   L.y0 = by * 8;
+  // Uncoded now, untouched by the previous frame, and the destination buffer holds the frame before
+  // that: the copy PREV -> SELF of fragment.c:37 would write what is there already.
+  const bool work = valid && (L.coded || touched != 0);
   ReconPlane R;
   R.self = self + G.off;
   R.prev = prev + G.off;
@@ -718,6 +737,9 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
 #else
   R.tr = nullptr;
 #endif
+
+  if (valid && !work) R.coded_map[by * G.nh + bx] = 0;   // (recon_issue writes the flag of the others)
+  if (!__any(work)) return;                               // a tile of static background
 
   // ---- 2. coefficient loads (slot by prefix count over the mask), issued, not waited for.
   //         The branch is wave-uniform and every lane loads (lanes without coefficients re-read
@@ -739,19 +761,19 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
   uint32_t *const lds_dw = reinterpret_cast<uint32_t *>(lds_wave);
   if (nown == 0 || (debug & 9)) {
-    if (valid) recon_issue(R, L, Q, inter, ref);   // (!valid: past the ragged edge of the plane)
+    if (work) recon_issue(R, L, Q, inter, ref);   // (!valid: past the ragged edge of the plane)
   } else if (nown <= 16 && !(debug & 32)) {
     // ---- few owners: four lanes per block, pieces straight from the slots ------------------------
     int4 W[1][2];
     residual_shared_load<4>(coeffs_p, slot0, nown, lane, W);
-    if (valid) recon_issue(R, L, Q, inter, ref);
+    if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
     residual_shared<4>(W, lds_dw, s_meta + wave * 32, lane, L, prefix, Y);
     THIP_TR(R.tr, 3);
   } else if (nown <= 32 && !(debug & 32)) {
     int4 W[2][2];
     residual_shared_load<2>(coeffs_p, slot0, nown, lane, W);
-    if (valid) recon_issue(R, L, Q, inter, ref);
+    if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
     residual_shared<2>(W, lds_dw, s_meta + wave * 32, lane, L, prefix, Y);
     THIP_TR(R.tr, 3);
@@ -768,7 +790,7 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
                                          (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
     }
-    if (valid) recon_issue(R, L, Q, inter, ref);
+    if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
     // The LDS-DMA loads above are counted by vmcnt; the compiler's own wait before the LDS reads
     // below is not something to rely on (it vanished when the loads moved into a conditional
@@ -777,7 +799,7 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
     residual_per_lane(lds_wave + lane, L, Y);
     THIP_TR(R.tr, 3);
   }
-  if (!valid) return;
+  if (!work) return;
   if (!L.has_coeff || (debug & 9)) {   // DC-only: the rounded value (state.c:972); uncoded: zero residual
     const uint32_t fill = L.dc_only ? L.dcp : 0u;
 #pragma unroll
