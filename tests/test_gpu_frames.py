@@ -69,6 +69,28 @@ def test_static_background_through_the_slots_and_across_dup_frames(hip):
         assert not util.planes_equal(ost, gst), f
 
 
+def test_static_blocks_are_copied_again_after_the_caller_wrote_a_buffer(hip):
+    """thip_state_write_plane into the buffer the next frame will be decoded into: the library must stop
+    assuming that buffer still holds the frame before the previous one."""
+    w, h = 256, 96
+    content = dict(synth.CLASSES["mixed"], p_coded=0.85, window=0.1)
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(8)
+    ost = oracle.State(w, h, PF_420)
+    gst = hip.State(w, h, PF_420)
+    for f in range(8):
+        fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, content)
+        util.oracle_apply(ost, fr)
+        desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+        hip.decode_frames([gst], [desc])
+        assert not util.planes_equal(ost, gst), f
+        if f == 5:   # scribble over the buffer that is neither GOLD nor PREV
+            nxt = [b for b in range(3) if b not in (gst.ref_idx(hip.FRAME_GOLD), gst.ref_idx(hip.FRAME_PREV))][0]
+            for pli in range(3):
+                g = gst.planes[pli]
+                gst.write_plane(nxt, pli, rng.integers(0, 256, (g["height"], g["width"])).astype(np.uint8))
+
+
 def test_sequence_720p(hip):
     """BASELINE.json config 2: one 720p stream, more than a key-frame interval of 64, every plane of
     every frame compared."""
