@@ -100,10 +100,12 @@ def test_sequence_720p(hip):
 
 @pytest.mark.parametrize("w,h,fmt,content,n", [(3840, 2160, PF_420, "smooth", 20), (3840, 2160, PF_420, "mixed", 20),
                                                  (3840, 2160, PF_420, "dense", 10), (1920, 1088, PF_444, "mixed", 20),
-                                                 (1920, 1088, PF_422, "smooth", 20)])
+                                                 (1920, 1088, PF_422, "smooth", 20), (3840, 2160, PF_420, "static_bg", 20),
+                                                 (1920, 1088, PF_420, "static_1pct", 20)])
 def test_full_size_sequences(hip, w, h, fmt, content, n):
     """BASELINE.json's sizes against the oracle directly (it decodes a 4K frame in ~40 ms): every
-    plane of every frame, key-frame interval 16, all three content classes and pixel formats."""
+    plane of every frame, key-frame interval 16, all three content classes and pixel formats, and the two
+    static-background classes (blocks left in place, whole tiles and filter waves skipped)."""
     rep = util.run_sequence(hip, w, h, fmt, nframes=n, content=content, seed=w + n, kf_interval=16)
     assert not rep, rep[:3]
 
