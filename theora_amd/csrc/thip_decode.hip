@@ -588,7 +588,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     if (wgs > max_wg) max_wg = wgs;
     if (d.flimit) {
       any_lf = 1;
-      const int swg = (K.cell_end[2] + 255) / 256;
+      const int swg = (K.cell_end[2] + THIP_LF_WG - 1) / THIP_LF_WG;
       if (swg > max_seam_wg) max_seam_wg = swg;
       const int fswg = (K.seam_end[2] + 255) / 256;
       if (fswg > max_fseam_wg) max_fseam_wg = fswg;
@@ -630,7 +630,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     }
     if (any_lf) {
       ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
-      hipLaunchKernelGGL(k_loopfilter, dim3(max_seam_wg, nlive), dim3(256), 0, s, B);
+      hipLaunchKernelGGL(k_loopfilter, dim3(max_seam_wg, nlive), dim3(THIP_LF_WG), 0, s, B);
     }
   }
   HIP_TRY(hipGetLastError());

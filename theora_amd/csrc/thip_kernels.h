@@ -1008,10 +1008,13 @@ __global__ __launch_bounds__(256) void k_lf_seam(const BatchK B) {
 // ---------------------------------------------------------------------------------------
 // One wave never straddles two planes (the cumulative cell counts in StreamK::cell_end are
 // padded to whole waves), so the plane lookup is scalar, like k_recon's.
-__global__ __launch_bounds__(256) void k_loopfilter(const BatchK B) {
+#ifndef THIP_LF_WG
+#define THIP_LF_WG 256   // threads per workgroup of k_loopfilter
+#endif
+__global__ __launch_bounds__(THIP_LF_WG) void k_loopfilter(const BatchK B) {
   const StreamK &S = B.s[blockIdx.y];
   const int lane = (int)threadIdx.x & 63;
-  const int wbase = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));
+  const int wbase = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)THIP_LF_WG + (threadIdx.x & ~63u)));
   uint8_t *self = S.self;
   const uint8_t *cmap = S.coded_map;
   const int ce0 = S.cell_end[0], ce1 = S.cell_end[1], ce2 = S.cell_end[2], L2 = S.flimit2;
