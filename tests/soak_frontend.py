@@ -1,0 +1,20 @@
+"""Extra front-end assurance (a script, not collected by pytest): random generator streams through th_decode_*
+against the oracle fed with the generator's ground truth, for a given time.
+  python tests/soak_frontend.py <seed> <seconds>     (end of round 1: 3 196 streams, all bit-exact)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import theora_amd
+from tests import test_gpu_frontend as T
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+limit = float(sys.argv[2]) if len(sys.argv) > 2 else 120
+t0, cases = time.time(), 0
+while time.time() - t0 < limit:
+    w = int(rng.choice([16, 32, 64, 176, 336])); h = int(rng.choice([16, 48, 80, 144]))
+    fmt = int(rng.choice([0, 2, 3]))
+    trees = str(rng.choice(["random", "matched"]))
+    seed = int(rng.integers(1 << 30))
+    T.run_stream(theora_amd, w, h, fmt, seed=seed, nframes=int(rng.integers(4, 10)), kf=int(rng.integers(2, 6)), trees=trees)
+    cases += 1
+print("front-end soak: %d streams bit-exact, %.0f s" % (cases, time.time() - t0))
