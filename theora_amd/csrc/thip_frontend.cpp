@@ -643,10 +643,12 @@ __attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &
     Tok &k = *out++;
     bool fast = false;
     // Fast path: the next 64 bits are all inside the packet (the longest code and the most extra
-    // bits together are 44) and eight bytes can be loaded at the read position.  Nothing on it depends on the data except through arithmetic: which token
-    // comes next and whether the window needs topping up are both close to random, and a
-    // mispredicted branch costs more than all the arithmetic of a token.
-    if (lut_ok && pos + 64 <= nbits && bytepos + 8 <= nbytes) {
+    // bits together are 44) and eight bytes can be loaded at the read position.  Nothing on it
+    // depends on the data except through arithmetic: which token comes next and whether the window
+    // needs topping up are both close to random, and a mispredicted branch costs more than all the
+    // arithmetic of a token.  (have < 64: a window that is full to the last bit -- possible only
+    // right after a refill nobody consumed from -- cannot be shifted by `have`.)
+    if (lut_ok && have < 64 && pos + 64 <= nbits && bytepos + 8 <= nbytes) {
       // top the window up to 56..63 bits: bits that are loaded but not yet counted in `have` are the
       // stream's own and are OR-ed in again, unchanged, next time
       uint64_t v;
