@@ -66,7 +66,11 @@ int thip_state_get_geom(const thip_state *st, thip_plane_geom geom[3], int64_t *
 int thip_state_ref_idx(const thip_state *st, int which);
 /* Force the ring (tests / seeking; mirrors the bookkeeping of decode.c:2947-2962). */
 int thip_state_set_ref_idx(thip_state *st, int gold, int prev, int self);
-/* device pointer of buffer bufi (0..2); planes at +geom[pli].plane_off */
+/* device pointer of buffer bufi (0..2); planes at +geom[pli].plane_off.  For reading (encoders,
+   on-device consumers of decoded frames).  The library keeps track of which decoded frame every
+   buffer holds so that it can leave unchanged blocks where they are; a caller that WRITES a buffer
+   through this pointer must say so with thip_state_set_ref_idx (which forgets that bookkeeping), as
+   thip_state_write_plane does by itself. */
 uint8_t *thip_state_frame_ptr(const thip_state *st, int bufi);
 /* Synchronous copies of one plane of buffer bufi, tightly packed, bitstream row order. */
 int thip_state_read_plane(thip_state *st, int bufi, int pli, uint8_t *host_out);
