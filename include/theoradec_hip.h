@@ -26,8 +26,8 @@ extern "C" {
 /* codec.h:77-93 */
 #define TH_EFAULT (-1)
 #define TH_EINVAL (-10)
-#define TH_ENOTFORMAT (-20)
-#define TH_EBADHEADER (-21)
+#define TH_EBADHEADER (-20)
+#define TH_ENOTFORMAT (-21)
 #define TH_EVERSION (-22)
 #define TH_EIMPL (-23)
 #define TH_EBADPACKET (-24)

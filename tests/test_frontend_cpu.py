@@ -113,3 +113,63 @@ def test_small_codec_h_helpers(trace_env):
     assert L.th_comment_query_count(C.byref(tc), b"artist") == 2
     assert C.string_at(L.th_comment_query(C.byref(tc), b"artist", 1)) == b"somebody"
     dec.close()
+
+
+def test_headerin_return_codes_follow_decinfo(trace_env):
+    """th_decode_headerin's codes and the order of its checks (decinfo.c:182-258, codec.h:77-93):
+    TH_EBADHEADER = -20, TH_ENOTFORMAT = -21; the codec string is checked before anything that
+    depends on the packet type; a data packet is 'not Theora' only while no info header has been seen."""
+    import ctypes as C
+    from theora_amd import _lib
+    from theora_amd.decoder import _packet
+    L = _lib.load()
+    EBADHEADER, ENOTFORMAT, EFAULT = -20, -21, -1
+    st = streamgen.Stream(64, 48, 0, seed=6)
+    hp = st.header_packets()
+    data, _ = st.frame(0)
+
+    def fresh():
+        info, tc, setup = _lib.ThInfo(), _lib.ThComment(), C.c_void_p()
+        L.th_info_init(C.byref(info))
+        L.th_comment_init(C.byref(tc))
+        return info, tc, setup
+
+    def hin(ctx, pkt, bos=0, tc_null=False, setup_null=False):
+        info, tc, setup = ctx
+        op, keep = _packet(pkt, bos=bos)
+        return L.th_decode_headerin(C.byref(info), None if tc_null else C.byref(tc),
+                                    None if setup_null else C.byref(setup), C.byref(op))
+
+    ctx = fresh()
+    assert hin(ctx, data) == ENOTFORMAT                      # data packet, nothing seen (decinfo.c:196)
+    assert hin(ctx, hp[1]) == EBADHEADER                     # comment before info (:226)
+    assert hin(ctx, hp[2]) == EBADHEADER                     # setup before info (:238)
+    bad = bytearray(hp[0]); bad[3] ^= 0xFF
+    assert hin(ctx, bytes(bad), bos=1) == ENOTFORMAT         # not "theora" (:213)
+    bad = bytearray(hp[1]); bad[2] ^= 0xFF
+    assert hin(ctx, bytes(bad)) == ENOTFORMAT                # the codec string comes before the type's state checks
+    assert hin(ctx, hp[0], bos=0) == EBADHEADER              # info header must be b_o_s (:218)
+    assert hin(ctx, bytes([0x83]) + b"theora") == EBADHEADER  # unknown header type (:251)
+    assert hin(ctx, hp[0], bos=1) == 3
+    assert hin(ctx, hp[0], bos=1) == EBADHEADER              # a second info header
+    assert hin(ctx, data) == EBADHEADER                      # data packet, info seen, comment missing (:202)
+    assert hin(ctx, data, tc_null=True) == EFAULT            # (:199)
+    assert hin(ctx, hp[1]) == 2
+    assert hin(ctx, data) == EBADHEADER                      # setup missing (:207)
+    assert hin(ctx, data, setup_null=True) == EFAULT         # (:205)
+    assert hin(ctx, hp[2]) == 1
+    assert hin(ctx, data) == 0                               # all three seen: header decode ends
+    L.th_setup_free(ctx[2])
+    L.th_comment_clear(C.byref(ctx[1]))
+
+
+def test_dropped_frame_before_any_frame_shows_grey(trace_env):
+    """decode.c:2757-2772: a dropped frame with no reference yet initialises the mid-grey dummy frame,
+    and that is what th_decode_ycbcr_out shows."""
+    from theora_amd.decoder import Decoder
+    st = streamgen.Stream(32, 32, 0, seed=3)
+    dec = Decoder(st.header_packets())
+    assert dec.packetin(b"")[0] == 1
+    for pl in dec.ycbcr_out():
+        assert pl.size and np.all(pl == 0x80)
+    dec.close()

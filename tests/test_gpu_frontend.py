@@ -73,11 +73,11 @@ def test_header_errors(hip):
     L.th_info_init(C.byref(info))
     L.th_comment_init(C.byref(tc))
     op, k1 = _packet(hp[1], bos=0)
-    assert L.th_decode_headerin(C.byref(info), C.byref(tc), C.byref(setup), C.byref(op)) == -21   # comment before info
+    assert L.th_decode_headerin(C.byref(info), C.byref(tc), C.byref(setup), C.byref(op)) == -20   # TH_EBADHEADER: comment before info (decinfo.c:226)
     bad = bytearray(hp[0])
     bad[3] ^= 0xFF
     op, k2 = _packet(bytes(bad), bos=1)
-    assert L.th_decode_headerin(C.byref(info), C.byref(tc), C.byref(setup), C.byref(op)) == -20   # not "theora"
+    assert L.th_decode_headerin(C.byref(info), C.byref(tc), C.byref(setup), C.byref(op)) == -21   # TH_ENOTFORMAT: not "theora" (decinfo.c:213)
     with pytest.raises(Exception):
         Decoder([hp[0], hp[2]])
 

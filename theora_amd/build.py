@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtheora_hip.so")
 SOURCES = ["thip_decode.hip", "thip_slots.hip", "thip_frontend.cpp", "thip_ogg.cpp"]
 HEADERS = ["thip_device.h", "thip_kernels.h", os.path.join("..", "..", "include", "theora_hip.h"),
-           os.path.join("..", "..", "include", "theoradec_hip.h")]
+           os.path.join("..", "..", "include", "theoradec_hip.h"), os.path.join("..", "..", "include", "thip_ogg.h")]
 
 
 def _stale():

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <new>
 #include <vector>
 
 #include "../../include/theora_hip.h"
@@ -221,13 +222,11 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // headers (spec 6.1 - 6.4)
 // ---------------------------------------------------------------------------------------
-int read_common_header(BitReader &br, int expect) {
-  const int type = (int)br.read(8);
+int read_common_header(BitReader &br) {   // packet type octet + codec string (decinfo.c:188, :211-213)
+  (void)br.read(8);
   static const char magic[] = "theora";
   for (int i = 0; i < 6; i++)
     if ((char)br.read(8) != magic[i]) return TH_ENOTFORMAT;
-  if (!(type & 0x80)) return TH_ENOTFORMAT;
-  if (type != expect) return TH_EBADHEADER;
   return 0;
 }
 
@@ -271,7 +270,8 @@ uint32_t read_le32(BitReader &br) {   // spec 6.3.1: lengths are little-endian
 int parse_comment(BitReader &br, th_comment *tc) {   // spec 6.3
   uint32_t len = read_le32(br);
   if (len > br.nbits / 8) return TH_EBADHEADER;
-  tc->vendor = (char *)malloc(len + 1);
+  tc->vendor = (char *)malloc((size_t)len + 1);
+  if (!tc->vendor) return TH_EFAULT;
   for (uint32_t i = 0; i < len; i++) tc->vendor[i] = (char)br.read(8);
   tc->vendor[len] = 0;
   const uint32_t n = read_le32(br);
@@ -279,10 +279,15 @@ int parse_comment(BitReader &br, th_comment *tc) {   // spec 6.3
   tc->comments = (int)n;
   tc->user_comments = (char **)calloc(n ? n : 1, sizeof(char *));
   tc->comment_lengths = (int *)calloc(n ? n : 1, sizeof(int));
+  if (!tc->user_comments || !tc->comment_lengths) {
+    tc->comments = 0;
+    return TH_EFAULT;
+  }
   for (uint32_t k = 0; k < n; k++) {
     len = read_le32(br);
     if (len > br.nbits / 8) return TH_EBADHEADER;
-    tc->user_comments[k] = (char *)malloc(len + 1);
+    tc->user_comments[k] = (char *)malloc((size_t)len + 1);
+    if (!tc->user_comments[k]) return TH_EFAULT;
     tc->comment_lengths[k] = (int)len;
     for (uint32_t i = 0; i < len; i++) tc->user_comments[k][i] = (char)br.read(8);
     tc->user_comments[k][len] = 0;
@@ -347,7 +352,7 @@ int parse_setup(BitReader &br, th_setup_info *s) {   // spec 6.4
   nbits = (int)br.read(4) + 1;
   for (int qi = 0; qi < 64; qi++) q.dcscale[qi] = (uint16_t)br.read(nbits);
   q.nbms = (int)br.read(9) + 1;
-  if (q.nbms > 384) return TH_EBADHEADER;
+  if (q.nbms > 384 || br.overrun()) return TH_EBADHEADER;
   q.bms.resize((size_t)q.nbms * 64);
   for (int i = 0; i < q.nbms * 64; i++) q.bms[i] = (uint8_t)br.read(8);
   for (int qti = 0; qti < 2; qti++)
@@ -700,12 +705,9 @@ __attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &
     run_left = (uint32_t)(want - take);
     left_next[k.adv]++;   // z + adv <= 127
     n -= take;
-    if (!fast && pos > nbits && n > 0) {   // truncated packet: close everything that is open
-      Tok &e = *out++;
-      e.value = 0; e.skip = 0; e.adv = 0; e.eob = (uint32_t)n;
-      n = 0;
-      run_left = 0;
-    }
+    // (A truncated packet is not special: past the end the reader supplies zero bits, as
+    //  oc_pack_read does, and tokens go on being decoded from them -- every token closes or
+    //  advances at least one block, so the list still ends -- which is what libtheora outputs.)
   }
   *eobs = run_left;
   br.win = win; br.have = have; br.pos = pos; br.bytepos = bytepos;
@@ -868,17 +870,23 @@ int th_decode_headerin(th_info *info, th_comment *tc, th_setup_info **setup, ogg
   if (!op) return TH_EBADHEADER;
   if (!info) return TH_EFAULT;
   if (op->bytes <= 0 || !op->packet) return TH_EBADHEADER;
-  // a data packet after all three headers ends header decode (theoradec.h:218-233)
+  // a data packet after all three headers ends header decode (theoradec.h:218-233); the order of
+  // the checks and their codes are decinfo.c:191-210
   if (!(op->packet[0] & 0x80)) {
-    if (info->frame_width && tc && tc->vendor && setup && *setup) return 0;
-    return TH_ENOTFORMAT;
+    if (info->frame_width <= 0) return TH_ENOTFORMAT;
+    if (!tc) return TH_EFAULT;
+    if (!tc->vendor) return TH_EBADHEADER;
+    if (!setup) return TH_EFAULT;
+    if (!*setup) return TH_EBADHEADER;
+    return 0;
   }
   BitReader br(op->packet, (size_t)op->bytes);
   const int type = op->packet[0];
   int rc;
+  // the codec string comes before anything that depends on the packet type (decinfo.c:211-213)
+  if ((rc = read_common_header(br)) < 0) return rc;
   if (type == 0x80) {
-    if (!op->b_o_s || info->frame_width) return TH_EBADHEADER;
-    if ((rc = read_common_header(br, 0x80)) < 0) return rc;
+    if (!op->b_o_s || info->frame_width > 0) return TH_EBADHEADER;
     if ((rc = parse_info(br, info)) < 0) {
       th_info_clear(info);
       return rc;
@@ -888,7 +896,6 @@ int th_decode_headerin(th_info *info, th_comment *tc, th_setup_info **setup, ogg
   if (type == 0x81) {
     if (!tc) return TH_EFAULT;
     if (!info->frame_width || tc->vendor) return TH_EBADHEADER;
-    if ((rc = read_common_header(br, 0x81)) < 0) return rc;
     if ((rc = parse_comment(br, tc)) < 0) {
       th_comment_clear(tc);
       return rc;
@@ -898,8 +905,8 @@ int th_decode_headerin(th_info *info, th_comment *tc, th_setup_info **setup, ogg
   if (type == 0x82) {
     if (!tc || !setup) return TH_EFAULT;
     if (!info->frame_width || !tc->vendor || *setup) return TH_EBADHEADER;
-    if ((rc = read_common_header(br, 0x82)) < 0) return rc;
-    th_setup_info *s = new th_setup_info();
+    th_setup_info *s = new (std::nothrow) th_setup_info();
+    if (!s) return TH_EFAULT;
     if ((rc = parse_setup(br, s)) < 0) {
       delete s;
       return rc;
@@ -907,7 +914,7 @@ int th_decode_headerin(th_info *info, th_comment *tc, th_setup_info **setup, ogg
     *setup = s;
     return 1;
   }
-  return TH_EBADHEADER;
+  return TH_EBADHEADER;   // an unknown header type (decinfo.c:251-254)
 }
 
 void th_setup_free(th_setup_info *setup) { delete setup; }
@@ -1042,6 +1049,8 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   if (!d || !op) return TH_EFAULT;
   const int N = d->nfrags;
   int ncoded_total = 0;
+  // (a negative length reads as all-zero bits here and in the reference alike -- oc_pack_readinit with
+  //  a stop pointer before the start -- i.e. as an intra frame header; only bytes == 0 is a drop)
   BitReader br(op->packet, op->bytes > 0 ? (size_t)op->bytes : 0);
   d->prof.start();
   if (op->bytes == 0) {
@@ -1088,6 +1097,11 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   d->granpos = ((d->keyframe_num + d->granpos_bias) << d->info.keyframe_granule_shift) +
                (d->curframe_num - d->keyframe_num);
   if (ncoded_total == 0) {   // decode.c:2764-2772
+    // Nothing decoded yet: the reference has just made its mid-grey dummy frame (decode.c:2757-2762,
+    // oc_dec_init_dummy_frame) and th_decode_ycbcr_out shows that; the backend substitutes the same
+    // grey when the first inter frame with coded blocks arrives (thip_decode_frames).
+    if (!d->have_frame)
+      for (int p = 0; p < 3; p++) memset(d->mirror[p].data(), 0x80, d->mirror[p].size());
     d->curframe_num++;
     if (granpos) *granpos = d->granpos;
     return TH_DUPFRAME;
