@@ -269,6 +269,26 @@ def test_fused_recon_loopfilter_variant(hip):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("waves,iters", [(8, 4), (16, 2), (1, 4), (3, 1), (5, 64)])
+def test_row_walking_fused_variant(hip, waves, iters):
+    """THIP_FUSE=2 selects k_recon_row + k_lf_rowseam: the waves of a workgroup deal out the tiles of a
+    tile row, hand the tile edges to each other through LDS, filter every cell that does not lie on a
+    tile-row boundary and write the frame once; the second kernel filters the boundary rows.  The
+    sequence tests of this file in a child process with the switch on, for several workgroup shapes:
+    one wave walking a whole row alone, several rows per workgroup, one tile per wave."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, THIP_FUSE="2", THIP_ROW_WAVES=str(waves), THIP_ROW_ITERS=str(iters))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sel = "(sequence or enqueue or batched or grey or dup or lane_shared or static_background) and not elision and not fused"
+    if (waves, iters) != (8, 4):
+        sel = "(sequence_small or sequence_1080p or enqueue or batched or lane_shared) and not elision and not fused"
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q", "-k", sel],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_static_block_elision_forced_on_every_frame(hip):
     """THIP_SKIP_STATIC=2 lifts the "most of the frame is uncoded" condition, so that every inter frame of
     the sequence tests of this file (scattered uncoded blocks, all content classes, the slots, batches, DUP

@@ -156,8 +156,24 @@ struct ScopedTimer {
 };
 
 // Fills the per-plane kernel geometry and the cumulative tile / cell counts.
+// Row-walking fused path: waves per workgroup and tiles per wave (k_recon_row).
+int row_waves() {
+  static const int w = [] {
+    int v = getenv("THIP_ROW_WAVES") ? atoi(getenv("THIP_ROW_WAVES")) : 8;
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+  }();
+  return w;
+}
+int row_iters() {
+  static const int n = [] {
+    int v = getenv("THIP_ROW_ITERS") ? atoi(getenv("THIP_ROW_ITERS")) : 4;
+    return v < 1 ? 1 : v;
+  }();
+  return n;
+}
+
 void fill_stream_geom(StreamK &K, const thip_state *st) {
-  int tiles = 0, cells = 0, segs = 0, seams = 0;
+  int tiles = 0, cells = 0, segs = 0, seams = 0, rgs = 0, rsc = 0;
   for (int pli = 0; pli < 3; pli++) {
     const thip_plane_geom &g = st->geom[pli];
     PlaneK &k = K.pl[pli];
@@ -183,6 +199,18 @@ void fill_stream_geom(StreamK &K, const thip_state *st) {
     k.seam_rows = g.nvfrags / 4 + 1 + (g.nvfrags % 4 ? 1 : 0);
     seams += (k.seam_rows * (g.nhfrags + 1) + (k.nseg - 1) * (g.nvfrags + 1 - k.seam_rows) + 63) & ~63;
     K.seam_end[pli] = seams;
+    // row-walking path: wpr waves deal out the tiles of a row, about row_iters() tiles each; a
+    // workgroup of row_waves() waves holds as many rows as fit
+    k.tiles_y = st->tiles.tiles_y[pli];
+    k.wpr = (k.tiles_x + row_iters() - 1) / row_iters();
+    if (k.wpr > row_waves()) k.wpr = row_waves();
+    if (k.wpr < 1) k.wpr = 1;
+    k.rpw = row_waves() / k.wpr;
+    rgs += (k.tiles_y + k.rpw - 1) / k.rpw;
+    K.rg_end[pli] = rgs;
+    k.rs_rows = g.nvfrags / 4 + 1;
+    rsc += (k.rs_rows * (g.nhfrags + 1) + 63) & ~63;
+    K.rs_end[pli] = rsc;
   }
 }
 }  // namespace
@@ -519,6 +547,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   memset(&B, 0, sizeof(B));
   int max_wg = 0, max_seam_wg = 0, any_lf = 0, nlive = 0;
   int max_fwg = 0, max_seglen = 1, max_fseam_wg = 0;   // fused path
+  int max_rwg = 0, max_rswg = 0, any_skip = 0;          // row-walking fused path
   int live_state[THIP_MAX_BATCH];
   for (int i = 0; i < n; i++) {
     thip_state *st = states[i];
@@ -595,6 +624,13 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     }
     const int fwg = (K.seg_end[2] + 7) & ~7;   // 8 XCD bands
     if (fwg > max_fwg) max_fwg = fwg;
+    const int rwg = (K.rg_end[2] + 7) & ~7;
+    if (rwg > max_rwg) max_rwg = rwg;
+    if (d.flimit) {
+      const int rswg = ((K.rs_end[2] + 255) / 256 + 7) & ~7;
+      if (rswg > max_rswg) max_rswg = rswg;
+    }
+    if (K.skip_ok) any_skip = 1;
     for (int pli = 0; pli < 3; pli++)
       if (K.pl[pli].seglen > max_seglen) max_seglen = K.pl[pli].seglen;
     live_state[nlive++] = i;
@@ -605,8 +641,31 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   // traffic per 4K step, but measured SLOWER (58+17 us vs 44+23 us per 4-frame launch: the
   // workgroup-wide barriers and the filter's arithmetic cost more than the bytes saved), so it
   // is off by default; DESIGN.md section 5.
+  // THIP_FUSE=2: the row-walking fused kernel (k_recon_row + k_lf_rowseam): no vertical seams, a quarter
+  // of the lines re-read.  Frames that leave static blocks in place (skip_ok) keep the two-pass path,
+  // whose first kernel knows how to skip whole tiles.
   static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 0;
-  if (fuse && any_lf) {
+  if (fuse == 2 && any_lf && !any_skip) {
+    static std::mutex attr_mu2;
+    static bool attr_set2 = false;
+    const size_t lds = (size_t)row_waves() * kRowWaveLds;
+    {
+      std::lock_guard<std::mutex> alk(attr_mu2);
+      if (!attr_set2) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_recon_row), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    16 * kRowWaveLds));
+        attr_set2 = true;
+      }
+    }
+    {
+      ScopedTimer t(s, THIP_KERNEL_RECON);
+      hipLaunchKernelGGL(k_recon_row, dim3(max_rwg, nlive), dim3(64 * row_waves()), lds, s, B);
+    }
+    {
+      ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
+      hipLaunchKernelGGL(k_lf_rowseam, dim3(max_rswg, nlive), dim3(256), 0, s, B);
+    }
+  } else if (fuse == 1 && any_lf) {
     static std::mutex attr_mu;
     static bool attr_set = false;
     std::lock_guard<std::mutex> alk(attr_mu);

@@ -40,6 +40,9 @@ struct PlaneK {
   float rcp_cx;      // 1/(nh+1)
   int nseg, seglen;  // a tile row is cut into nseg segments of seglen tiles (k_recon_lf)
   int seam_rows;     // cell rows filtered by k_lf_seam: m = 0,4,8,... and m = nv
+  // k_recon_row: wpr waves share a tile row (wave j takes tiles j, j+wpr, ...), a workgroup holds rpw rows
+  int tiles_y, wpr, rpw;
+  int rs_rows;       // cell rows left to k_lf_rowseam: m = 0, 4, ..., 4*(nv/4)
 };
 
 struct StreamK {
@@ -63,6 +66,9 @@ struct StreamK {
   // fused reconstruction + loop filter (k_recon_lf / k_lf_seam)
   int seg_end[3];         // cumulative workgroup counts per plane: one workgroup per (tile row, segment)
   int seam_end[3];        // cumulative seam-cell counts per plane, each plane padded to 64
+  // row-walking fused path (k_recon_row / k_lf_rowseam)
+  int rg_end[3];          // cumulative workgroup counts per plane: one workgroup per group of rpw tile rows
+  int rs_end[3];          // cumulative row-seam cell counts per plane, each plane padded to 64
   PlaneK pl[3];
 };
 
@@ -508,19 +514,27 @@ __device__ __forceinline__ void recon_issue(const ReconPlane &R, const ReconLane
   R.coded_map[(L.y0 >> 3) * R.nh + (L.x0 >> 3)] = L.coded ? 1 : 0;
 }
 
-__device__ __forceinline__ void recon_finish(const ReconPlane &R, const ReconLane &L, const PredWin &Q, bool inter,
-                                             const uint32_t Y[32]) {
-  uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
+// The eight reconstructed rows of this lane's block: predictor (fragment.c:49-80: 128, one block, or the
+// average of two) + residual, clamped.
+__device__ __forceinline__ void recon_rows(const ReconPlane &R, const PredWin &Q, bool inter, const uint32_t Y[32],
+                                           uint2 rows[8]) {
   uint2 pred[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
   if (inter) pred_finish(Q, R.nh * 8, pred);
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    rows[r] = pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]), pred[r]);
+}
+
+__device__ __forceinline__ void recon_finish(const ReconPlane &R, const ReconLane &L, const PredWin &Q, bool inter,
+                                             const uint32_t Y[32]) {
+  uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
+  uint2 rows[8];
+  recon_rows(R, Q, inter, Y, rows);
   if (!(R.debug & 4)) {
 #pragma unroll
-    for (int r = 0; r < 8; r++)
-      store_row8(dst + (ptrdiff_t)r * R.stride,
-                 pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]),
-                              pred[r]));
+    for (int r = 0; r < 8; r++) store_row8(dst + (ptrdiff_t)r * R.stride, rows[r]);
   }
 }
 
@@ -994,6 +1008,322 @@ __global__ __launch_bounds__(256) void k_lf_seam(const BatchK B) {
     m = ri + ri / 3 + 1;                 // rows 1,2,3, 5,6,7, 9,...: skip every multiple of 4
     if (k > nh - 1 || m >= nv) return;   // (a column beyond the plane cannot happen; m < nv by construction)
   }
+  CellPix C;
+  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
+  bool a, b, c, d;
+  lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
+  const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
+  lf_cell_pin(C);
+  lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_recon_row (K1+K2+three quarters of K3): waves walk along a tile row
+// ---------------------------------------------------------------------------------------
+// The second pass over the frame (k_loopfilter) costs a read and a write of every pixel.  What a
+// second pass can fix CHEAPLY is a horizontal seam -- eight whole rows, contiguous memory -- and
+// what it cannot is a vertical one: an 8-byte column piece per row touches every cache line of the
+// frame.  So this kernel leaves no vertical seam at all.  The tiles of one tile row are dealt
+// round-robin to the wpr waves of one workgroup (wave j: tiles j, j+wpr, ...), so the tile to the
+// left of any tile belongs to a neighbour wave of the same workgroup (or to this wave's previous
+// iteration), and its last four pixel columns -- unfiltered, 32 rows x 4 bytes -- come over through
+// LDS with a pair of counters, no workgroup barrier.  A wave
+//   1. reconstructs its tile exactly as k_recon does (the two memory round trips; the command words
+//      of its NEXT tile are requested first, so from the second tile on there is one round trip),
+//   2. writes the 128x32 image into its LDS area (the coefficient staging area, free by then),
+//      publishes the right edge, waits for the left neighbour's,
+//   3. becomes 16 x 4 filter cells (cells are independent): lane (kx, m) takes
+//      the cell centred on corner (16t + kx, 4*sby + m) for m = 1..3 and filters it; the lanes with
+//      m = 0 carry the tile's pixel rows 28..31 and 0..3 unfiltered.  The cells are shifted by half a
+//      block against the tile, so what the wave stores is the frame region [128t-4, 128t+124) x
+//      [32*sby, 32*sby+32): 128 contiguous bytes per row, every byte of the frame exactly once.
+// k_lf_rowseam then filters the cell rows on tile-row boundaries (m = 0 mod 4): a quarter of the
+// lines instead of all of them.  The order of operations inside every cell is the reference's
+// (state.c:1055-1105), as in k_loopfilter; both kernels honour the row range of the slot.
+constexpr int kRowPitch = 144;                  // LDS image row: 8-byte left margin (4 used), 128 pixels, 8 spare
+constexpr int kRowImgX0 = 8;                    // byte offset of pixel column 0 in an image row
+constexpr int kRowFlagOff = 32 * kRowPitch;     // coded flags: 4 rows of kRowFlagPitch bytes
+constexpr int kRowFlagPitch = 20;               // [0] left neighbour's column 15, [1..16] the tile, [17] column k = nh
+constexpr int kRowMetaOff = 8192;               // 32 dwords for residual_shared
+constexpr int kRowEdgeOff = 8320;               // published right edge: 2 buffers x 32 dwords (column bytes 124..127 per row)
+constexpr int kRowEFlagOff = 8576;              // 2 dwords: coded flags of block column 15, one byte per block row
+constexpr int kRowPubOff = 8584;                // tiles this wave has published
+constexpr int kRowConsOff = 8588;               // tiles of this wave its right neighbour has consumed
+constexpr int kRowWaveLds = 8704;               // per wave, multiple of 16
+
+__device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Waits until *ctr >= need.  Waves of one workgroup are co-resident, so the producer always makes
+// progress; the spin is bounded all the same (a wrong picture is a failed test, a hang is a dead GPU).
+__device__ __forceinline__ void lds_wait_ge(const uint32_t *ctr, uint32_t need) {
+  for (int spins = 0; spins < (1 << 22); spins++) {
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One filter cell of the row kernel: corner column kx (0..16) of the tile, cell row m (0..3); reads the
+// LDS image, filters (m >= 1), stores to the frame.  The cell's upper half is image rows
+// (8m-4 .. 8m-1) mod 32 and its lower half rows 8m .. 8m+3: for m = 0 the former wraps to rows 28..31,
+// which is how the m = 0 lanes come to carry the tile's first and last four rows.
+__device__ __forceinline__ void row_cell(const uint8_t *mine, uint8_t *plane, int stride, int nh, int nv, int t, int sby,
+                                         int kx, int m, bool active, int L2, int fy0, int fy1) {
+  const int k = 16 * t + kx, mm = 4 * sby + m;
+  const bool lo_ok = active && k >= 1 && k <= nh, hi_ok = active && k <= nh - 1;
+  const int row_up = (8 * m - 4) & 31, row_dn = 8 * m;   // first image row of each half
+  CellPix C;
+  const uint8_t *img_up = mine + kRowImgX0 + 8 * kx - 4 + row_up * kRowPitch;
+  const uint8_t *img_dn = mine + kRowImgX0 + 8 * kx - 4 + row_dn * kRowPitch;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t *qu = reinterpret_cast<const uint32_t *>(img_up + r * kRowPitch);
+    const uint32_t *qd = reinterpret_cast<const uint32_t *>(img_dn + r * kRowPitch);
+    C.lo[r] = qu[0];
+    C.hi[r] = qu[1];
+    C.lo[4 + r] = qd[0];
+    C.hi[4 + r] = qd[1];
+  }
+  const uint8_t *fl = mine + kRowFlagOff + kx;    // fl[row * pitch + 0] = column kx-1, [+1] = column kx
+  const int ma = max(m - 1, 0);
+  const bool a = fl[ma * kRowFlagPitch] != 0, b = fl[ma * kRowFlagPitch + 1] != 0;
+  const bool c = fl[m * kRowFlagPitch] != 0, d = fl[m * kRowFlagPitch + 1] != 0;
+  uint32_t ops = lf_cell_ops(k, mm, nh, nv, a, b, c, d, fy0, fy1);
+  if (m == 0 || L2 == 0 || !(lo_ok || hi_ok)) ops = 0;
+  lf_cell_apply_pk(C, ops, L2);
+  const int H = nv * 8;
+  uint8_t *p_up = plane + (ptrdiff_t)(32 * sby + row_up) * stride + (8 * k - 4);
+  uint8_t *p_dn = plane + (ptrdiff_t)(32 * sby + row_dn) * stride + (8 * k - 4);
+  // (plane heights are multiples of 8 and the halves are 4 rows: a half is inside the plane or outside)
+  const bool up_ok = 32 * sby + row_up < H, dn_ok = 32 * sby + row_dn < H;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    uint8_t *p = (r < 4 ? p_up : p_dn) + (ptrdiff_t)(r & 3) * stride;
+    if (r < 4 ? up_ok : dn_ok) {
+      if (lo_ok & hi_ok) {
+        Pix8 o;
+        o.x = C.lo[r];
+        o.y = C.hi[r];
+        *reinterpret_cast<Pix8 *>(p) = o;
+      } else if (lo_ok) {
+        *reinterpret_cast<uint32_t *>(p) = C.lo[r];
+      } else if (hi_ok) {
+        *reinterpret_cast<uint32_t *>(p + 4) = C.hi[r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_recon_row(const BatchK B) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_row[];
+  const StreamK &S = B.s[blockIdx.y];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, see k_recon
+  const uint2 *info_p = S.info;
+  const int4 *coeffs_p = S.coeffs;
+  const uint32_t *slot0_p = S.tile_slot0;
+  uint8_t *self = S.self;
+  const uint8_t *prev = S.prev, *gold = S.gold;
+  uint8_t *coded_map = S.coded_map;
+  const int rg0 = S.rg_end[0], rg1 = S.rg_end[1], rg2 = S.rg_end[2];
+  const int te0 = S.tile_end[0], te1 = S.tile_end[1];
+  const int sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
+  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
+               "s"(rg0), "s"(rg1), "s"(rg2), "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2));
+  uint8_t *const mine = s_row + wave * kRowWaveLds;
+  // the hand-off counters start at zero before any wave of the workgroup looks at a neighbour's
+  if (((int)threadIdx.x & 63) == 0) {
+    *reinterpret_cast<uint32_t *>(mine + kRowPubOff) = 0;
+    *reinterpret_cast<uint32_t *>(mine + kRowConsOff) = 0;
+  }
+  __syncthreads();
+  if (wg >= rg2) return;
+  const int pli = (wg >= rg0 ? 1 : 0) + (wg >= rg1 ? 1 : 0);
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.fro), "s"(G.tiles_y),
+               "s"(G.wpr), "s"(G.rpw), "s"(fy0), "s"(fy1));
+  const int rel = wg - (pli == 0 ? 0 : (pli == 1 ? rg0 : rg1));
+  const int grp = wave / G.wpr, j = wave - grp * G.wpr;       // (scalar)
+  const int sby = rel * G.rpw + grp;                          // tile row of this wave
+  if (grp >= G.rpw || sby >= G.tiles_y) return;               // (no barrier below: spare waves just leave)
+  const int unit0 = (pli == 0 ? 0 : (pli == 1 ? te0 : te1)) + sby * G.tiles_x;   // first tile of the row, as in k_recon
+  const uint8_t *const left = s_row + (grp * G.wpr + (j == 0 ? G.wpr - 1 : j - 1)) * kRowWaveLds;   // the wave that holds tile t-1
+
+  ReconPlane R;
+  R.self = self + G.off;
+  R.prev = prev + G.off;
+  R.gold = gold + G.off;
+  R.coded_map = coded_map + G.fro;
+  R.nh = G.nh;
+  R.nv = G.nv;
+  R.stride = G.stride;
+  R.qpx = pli != 0 && sqpx;
+  R.qpy = pli != 0 && sqpy;
+  R.debug = 0;
+  R.tr = nullptr;
+  uint4 *const lds_wave = reinterpret_cast<uint4 *>(mine);
+  uint32_t *const lds_dw = reinterpret_cast<uint32_t *>(mine);
+  uint32_t *const meta = reinterpret_cast<uint32_t *>(mine + kRowMetaOff);
+  const bool col17 = (G.nh & 15) == 0;   // the plane's right edge, cell column k = nh, is a 17th column of the last tile
+
+  int t = j;
+  uint32_t slot0 = 0;
+  uint2 info = make_uint2(0u, 0u);
+  if (t < G.tiles_x) {
+    slot0 = slot0_p[unit0 + t];
+    info = info_p[(size_t)(unit0 + t) * THIP_TILE_FRAGS + ((int)threadIdx.x & 63)];
+  }
+  for (int it = 0; t < G.tiles_x; it++, t += G.wpr) {
+    // The lane number is made opaque once per tile: left alone, the compiler hoists everything that
+    // depends on the lane only (addresses, masks, predicates of all three transform paths and of the
+    // cells) out of the tile loop and ends up with 250 live registers.
+    int lane = (int)threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int h = lane & 15;
+    const int lx = (lane >> 4) * 4 + hilb_col(h), ly = hilb_row(h);   // fragment inside the tile
+    const int by = sby * 4 + ly;
+    uint8_t *const img = mine + (ly * 8) * kRowPitch + kRowImgX0 + lx * 8;   // this lane's block in the tile image
+    // ---- the next tile's command words: requested now, used after this tile is done --------------
+    const int tn = min(t + G.wpr, G.tiles_x - 1);
+    const uint32_t slot0_n = slot0_p[unit0 + tn];
+    const uint2 info_n = info_p[(size_t)(unit0 + tn) * THIP_TILE_FRAGS + lane];
+
+    const int bx = t * 16 + lx;
+    const bool valid = bx < G.nh && by < G.nv;
+    ReconLane L;
+    L.flags = valid ? info.x : 0u;
+    L.dcq = info.y >> 16;
+    L.dcp = ((uint32_t)(((int)(int16_t)(info.y & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;
+    L.coded = (L.flags & THIP_INFO_CODED) != 0;
+    L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
+    L.has_coeff = L.coded && !L.dc_only;
+    L.x0 = bx * 8;
+    L.y0 = by * 8;
+
+    // ---- coefficients + predictor: k_recon's second round trip ------------------------------------
+    const uint64_t mask = __ballot(L.has_coeff);
+    const int nown = __popcll(mask);
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    // Every register of the predictor windows and of the residual is DEFINED here, for every lane: a
+    // value that only some lanes (or some paths) assign is carried around the tile loop by the
+    // compiler as if the previous tile's mattered -- sixty registers of nothing.
+    PredWin Q;
+#pragma unroll
+    for (int r = 0; r < 9; r++) Q.w[r].a = Q.w[r].b = Q.w[r].c = 0u;
+    Q.sx = Q.sy = Q.mx2 = Q.my2 = 0;
+    Q.border = false;
+    bool inter = false;
+    const uint8_t *ref = nullptr;
+    const uint32_t fill = L.dc_only ? L.dcp : 0u;   // DC-only: the rounded value (state.c:972); uncoded: zero residual
+    uint32_t Y[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) Y[i] = fill;
+    if (nown == 0) {
+      if (valid) recon_issue(R, L, Q, inter, ref);
+    } else if (nown <= 16) {
+      int4 W[1][2];
+      residual_shared_load<4>(coeffs_p, slot0, nown, lane, W);
+      if (valid) recon_issue(R, L, Q, inter, ref);
+      residual_shared<4>(W, lds_dw, meta, lane, L, prefix, Y);
+    } else if (nown <= 32) {
+      int4 W[2][2];
+      residual_shared_load<2>(coeffs_p, slot0, nown, lane, W);
+      if (valid) recon_issue(R, L, Q, inter, ref);
+      residual_shared<2>(W, lds_dw, meta, lane, L, prefix, Y);
+    } else {
+      const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
+      const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
+                                         (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
+      if (valid) recon_issue(R, L, Q, inter, ref);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)
+      residual_per_lane(lds_wave + lane, L, Y);
+      if (!L.has_coeff) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) Y[i] = fill;
+      }
+    }
+    uint2 rows[8];
+    recon_rows(R, Q, inter, Y, rows);
+
+    // ---- the tile image, its coded flags, the right edge for the neighbour -------------------------
+    lds_settle();                                   // every lane is done with the staging area
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(img + r * kRowPitch) = rows[r];
+    }
+    mine[kRowFlagOff + ly * kRowFlagPitch + 1 + lx] = (valid && L.coded) ? 1 : 0;
+    uint32_t *const pubc = reinterpret_cast<uint32_t *>(mine + kRowPubOff);
+    if (it >= 2) lds_wait_ge(reinterpret_cast<const uint32_t *>(mine + kRowConsOff), (uint32_t)(it - 1));   // buffer it&1 is free again
+    lds_settle();
+    if (lane < 32)
+      reinterpret_cast<uint32_t *>(mine + kRowEdgeOff)[(it & 1) * 32 + lane] =
+          *reinterpret_cast<const uint32_t *>(mine + lane * kRowPitch + kRowImgX0 + 124);
+    else if (lane == 32)
+      reinterpret_cast<uint32_t *>(mine + kRowEFlagOff)[it & 1] =
+          (uint32_t)mine[kRowFlagOff + 16] | (uint32_t)mine[kRowFlagOff + kRowFlagPitch + 16] << 8 |
+          (uint32_t)mine[kRowFlagOff + 2 * kRowFlagPitch + 16] << 16 | (uint32_t)mine[kRowFlagOff + 3 * kRowFlagPitch + 16] << 24;
+    lds_settle();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(pubc, (uint32_t)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+    // ---- the left neighbour's edge into the image margin ---------------------------------------------
+    if (t > 0) {
+      const int il = j == 0 ? it - 1 : it;          // the iteration in which the left wave did tile t-1
+      lds_wait_ge(reinterpret_cast<const uint32_t *>(left + kRowPubOff), (uint32_t)(il + 1));
+      if (lane < 32)
+        *reinterpret_cast<uint32_t *>(mine + lane * kRowPitch + kRowImgX0 - 4) =
+            reinterpret_cast<const uint32_t *>(left + kRowEdgeOff)[(il & 1) * 32 + lane];
+      else if (lane < 36)
+        mine[kRowFlagOff + (lane - 32) * kRowFlagPitch] =
+            (uint8_t)(reinterpret_cast<const uint32_t *>(left + kRowEFlagOff)[il & 1] >> (8 * (lane - 32)));
+      lds_settle();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0)
+        __hip_atomic_store(const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(left + kRowConsOff)), (uint32_t)(il + 1),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      if (lane >= 32 && lane < 36) mine[kRowFlagOff + (lane - 32) * kRowFlagPitch] = 0;
+      lds_settle();
+    }
+
+    // ---- 16 x 4 filter cells; the plane's right edge column is a 17th in the last tile ----------------
+    row_cell(mine, R.self, R.stride, G.nh, G.nv, t, sby, lane & 15, lane >> 4, true, L2, fy0, fy1);
+    if (col17 && t == G.tiles_x - 1)
+      row_cell(mine, R.self, R.stride, G.nh, G.nv, t, sby, 16, lane & 3, lane < 4, L2, fy0, fy1);
+    lds_settle();                                   // the image is read; the next tile may overwrite it
+    slot0 = slot0_n;
+    info = info_n;
+  }
+}
+
+// The cell rows k_recon_row leaves: m = 0, 4, 8, ..., 4*(nv/4), every column.  (m = nv is among them
+// when nv is a multiple of 4; otherwise it lies inside the last tile row and k_recon_row has done it.)
+__global__ __launch_bounds__(256) void k_lf_rowseam(const BatchK B) {
+  const StreamK &S = B.s[blockIdx.y];
+  const int lane = (int)threadIdx.x & 63;
+  // XCD bands over the workgroups, like the kernel whose rows these are
+  const int wgb = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  const int wbase = __builtin_amdgcn_readfirstlane(wgb * 256 + (int)(threadIdx.x & ~63u));
+  uint8_t *self = S.self;
+  const uint8_t *cmap = S.coded_map;
+  const int ce0 = S.rs_end[0], ce1 = S.rs_end[1], ce2 = S.rs_end[2], L2 = S.flimit2;
+  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2));
+  if (wbase >= ce2 || L2 == 0) return;
+  const int pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(G.rs_rows), "s"(fy0),
+               "s"(fy1));
+  const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
+  const int nh = G.nh, nv = G.nv;
+  if (rel >= G.rs_rows * (nh + 1)) return;
+  uint32_t mu, ku;
+  divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
+  const int k = (int)ku, m = (int)mu * 4;
   CellPix C;
   lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
   bool a, b, c, d;
