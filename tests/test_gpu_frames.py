@@ -254,35 +254,23 @@ def test_parity_check_has_teeth(hip):
     assert util.planes_equal(ost, gst), "comparison failed to notice a different filter limit"
 
 
-def test_fused_recon_loopfilter_variant(hip):
-    """THIP_FUSE=1 selects k_recon_lf + k_lf_seam (strip reconstructed and filtered in LDS, written
-    once).  It is off by default because it measured slower, but it must stay bit-exact: run the
-    sequence tests of this file in a child process with the switch on."""
+@pytest.mark.parametrize("waves,groups", [(8, 0), (16, 64), (1, 8), (3, 40), (5, 2048)])
+def test_fused_walk_variant(hip, waves, groups):
+    """THIP_FUSE=1 selects k_recon_walk + k_lf_seams: the waves of a work group deal out a range of tiles,
+    hand the tile edges to each other through LDS, filter every cell that does not lie on a tile-row
+    boundary and write the frame once; the second kernel filters the boundary rows and the cells on the
+    cuts between two groups' ranges.  The sequence tests of this file in a child process with the switch
+    on, for several shapes: the default, a single wave walking alone, few large ranges, more groups
+    than tiles (cuts everywhere)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, THIP_FUSE="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q",
-                        "-k", "(sequence or enqueue or batched or grey or dup) and not elision and not fused"], cwd=root, env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-@pytest.mark.parametrize("waves,iters", [(8, 4), (16, 2), (1, 4), (3, 1), (5, 64)])
-def test_row_walking_fused_variant(hip, waves, iters):
-    """THIP_FUSE=2 selects k_recon_row + k_lf_rowseam: the waves of a workgroup deal out the tiles of a
-    tile row, hand the tile edges to each other through LDS, filter every cell that does not lie on a
-    tile-row boundary and write the frame once; the second kernel filters the boundary rows.  The
-    sequence tests of this file in a child process with the switch on, for several workgroup shapes:
-    one wave walking a whole row alone, several rows per workgroup, one tile per wave."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, THIP_FUSE="2", THIP_ROW_WAVES=str(waves), THIP_ROW_ITERS=str(iters))
+    env = dict(os.environ, THIP_FUSE="1", THIP_WALK_WAVES=str(waves))
+    if groups:
+        env["THIP_WALK_WGS"] = str(groups)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sel = "(sequence or enqueue or batched or grey or dup or lane_shared or static_background) and not elision and not fused"
-    if (waves, iters) != (8, 4):
+    if groups:
         sel = "(sequence_small or sequence_1080p or enqueue or batched or lane_shared) and not elision and not fused"
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q", "-k", sel],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1500)

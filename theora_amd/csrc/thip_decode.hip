@@ -155,25 +155,31 @@ struct ScopedTimer {
   }
 };
 
-// Fills the per-plane kernel geometry and the cumulative tile / cell counts.
-// Row-walking fused path: waves per workgroup and tiles per wave (k_recon_row).
-int row_waves() {
+// Fused path (k_recon_walk): waves per work group, and how many groups one launch spreads over the chip.
+int walk_waves() {
   static const int w = [] {
-    int v = getenv("THIP_ROW_WAVES") ? atoi(getenv("THIP_ROW_WAVES")) : 8;
+    int v = getenv("THIP_WALK_WAVES") ? atoi(getenv("THIP_WALK_WAVES")) : 8;
     return v < 1 ? 1 : (v > 16 ? 16 : v);
   }();
   return w;
 }
-int row_iters() {
+int walk_groups_per_launch() {   // default: what is resident at once -- CUs x (groups that fit a CU's LDS)
   static const int n = [] {
-    int v = getenv("THIP_ROW_ITERS") ? atoi(getenv("THIP_ROW_ITERS")) : 4;
-    return v < 1 ? 1 : v;
+    if (getenv("THIP_WALK_WGS")) return atoi(getenv("THIP_WALK_WGS")) < 8 ? 8 : atoi(getenv("THIP_WALK_WGS"));
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int per_cu = (160 * 1024) / (walk_waves() * kWalkWaveLds);
+    constexpr int kWavesPerCu = THIP_WALK_MAXTHREADS >= 1024 ? 16 : 12;   // four (three) waves per SIMD: the register cap the launch bound implies
+    if (per_cu * walk_waves() > kWavesPerCu) per_cu = kWavesPerCu / walk_waves();
+    if (per_cu < 1) per_cu = 1;
+    return cus * per_cu;
   }();
   return n;
 }
 
+// Fills the per-plane kernel geometry and the cumulative tile / cell counts.
 void fill_stream_geom(StreamK &K, const thip_state *st) {
-  int tiles = 0, cells = 0, segs = 0, seams = 0, rgs = 0, rsc = 0;
+  int tiles = 0, cells = 0, rsc = 0;
   for (int pli = 0; pli < 3; pli++) {
     const thip_plane_geom &g = st->geom[pli];
     PlaneK &k = K.pl[pli];
@@ -189,26 +195,8 @@ void fill_stream_geom(StreamK &K, const thip_state *st) {
     K.tile_end[pli] = tiles;
     cells += ((g.nhfrags + 1) * (g.nvfrags + 1) + 63) & ~63;   // whole waves per plane (k_loopfilter)
     K.cell_end[pli] = cells;
-    // fused path: segments of at most kSegMax tiles, as equal as possible
-    static const int segmax_env = getenv("THIP_SEGMAX") ? atoi(getenv("THIP_SEGMAX")) : kSegMax;
-    const int segmax = segmax_env < 1 ? 1 : (segmax_env > kSegMax ? kSegMax : segmax_env);
-    k.nseg = (k.tiles_x + segmax - 1) / segmax;
-    k.seglen = (k.tiles_x + k.nseg - 1) / k.nseg;
-    segs += st->tiles.tiles_y[pli] * k.nseg;
-    K.seg_end[pli] = segs;
-    k.seam_rows = g.nvfrags / 4 + 1 + (g.nvfrags % 4 ? 1 : 0);
-    seams += (k.seam_rows * (g.nhfrags + 1) + (k.nseg - 1) * (g.nvfrags + 1 - k.seam_rows) + 63) & ~63;
-    K.seam_end[pli] = seams;
-    // row-walking path: wpr waves deal out the tiles of a row, about row_iters() tiles each; a
-    // workgroup of row_waves() waves holds as many rows as fit
     k.tiles_y = st->tiles.tiles_y[pli];
-    k.wpr = (k.tiles_x + row_iters() - 1) / row_iters();
-    if (k.wpr > row_waves()) k.wpr = row_waves();
-    if (k.wpr < 1) k.wpr = 1;
-    k.rpw = row_waves() / k.wpr;
-    rgs += (k.tiles_y + k.rpw - 1) / k.rpw;
-    K.rg_end[pli] = rgs;
-    k.rs_rows = g.nvfrags / 4 + 1;
+    k.rs_rows = g.nvfrags / 4 + 1;                              // cell rows m = 0, 4, ... (k_lf_seams)
     rsc += (k.rs_rows * (g.nhfrags + 1) + 63) & ~63;
     K.rs_end[pli] = rsc;
   }
@@ -546,8 +534,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   BatchK B;
   memset(&B, 0, sizeof(B));
   int max_wg = 0, max_seam_wg = 0, any_lf = 0, nlive = 0;
-  int max_fwg = 0, max_seglen = 1, max_fseam_wg = 0;   // fused path
-  int max_rwg = 0, max_rswg = 0, any_skip = 0;          // row-walking fused path
+  int max_swg = 0, any_skip = 0;   // fused path
   int live_state[THIP_MAX_BATCH];
   for (int i = 0; i < n; i++) {
     thip_state *st = states[i];
@@ -619,20 +606,8 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       any_lf = 1;
       const int swg = (K.cell_end[2] + THIP_LF_WG - 1) / THIP_LF_WG;
       if (swg > max_seam_wg) max_seam_wg = swg;
-      const int fswg = (K.seam_end[2] + 255) / 256;
-      if (fswg > max_fseam_wg) max_fseam_wg = fswg;
-    }
-    const int fwg = (K.seg_end[2] + 7) & ~7;   // 8 XCD bands
-    if (fwg > max_fwg) max_fwg = fwg;
-    const int rwg = (K.rg_end[2] + 7) & ~7;
-    if (rwg > max_rwg) max_rwg = rwg;
-    if (d.flimit) {
-      const int rswg = ((K.rs_end[2] + 255) / 256 + 7) & ~7;
-      if (rswg > max_rswg) max_rswg = rswg;
     }
     if (K.skip_ok) any_skip = 1;
-    for (int pli = 0; pli < 3; pli++)
-      if (K.pl[pli].seglen > max_seglen) max_seglen = K.pl[pli].seglen;
     live_state[nlive++] = i;
   }
   if (!nlive) return THIP_OK;
@@ -641,46 +616,39 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   // traffic per 4K step, but measured SLOWER (58+17 us vs 44+23 us per 4-frame launch: the
   // workgroup-wide barriers and the filter's arithmetic cost more than the bytes saved), so it
   // is off by default; DESIGN.md section 5.
-  // THIP_FUSE=2: the row-walking fused kernel (k_recon_row + k_lf_rowseam): no vertical seams, a quarter
-  // of the lines re-read.  Frames that leave static blocks in place (skip_ok) keep the two-pass path,
-  // whose first kernel knows how to skip whole tiles.
+  // THIP_FUSE=1: the fused path (k_recon_walk + k_lf_seams): no vertical seams, a quarter of the lines
+  // re-read.  Frames that leave static blocks in place (skip_ok) keep the two-pass path, whose first
+  // kernel knows how to skip whole tiles.
   static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 0;
-  if (fuse == 2 && any_lf && !any_skip) {
-    static std::mutex attr_mu2;
-    static bool attr_set2 = false;
-    const size_t lds = (size_t)row_waves() * kRowWaveLds;
+  if (fuse && any_lf && !any_skip) {
+    // one launch = one round of resident work groups: the streams share them equally
+    int ng = (walk_groups_per_launch() / nlive) & ~7;
+    if (ng < 8) ng = 8;
+    for (int j = 0; j < nlive; j++) {
+      StreamK &K = B.s[j];
+      int n = ng;
+      while (n > 8 && K.tile_end[2] < n * walk_waves()) n -= 8;   // small pictures: at least a tile per wave
+      K.walk_wgs = n;
+      const int swg = ((K.rs_end[2] + 64 * n + 255) / 256 + 7) & ~7;
+      if (swg > max_swg) max_swg = swg;
+    }
+    static std::mutex attr_mu;
+    static bool attr_set = false;
     {
-      std::lock_guard<std::mutex> alk(attr_mu2);
-      if (!attr_set2) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_recon_row), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    16 * kRowWaveLds));
-        attr_set2 = true;
+      std::lock_guard<std::mutex> alk(attr_mu);
+      if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_recon_walk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    16 * kWalkWaveLds));
+        attr_set = true;
       }
     }
     {
       ScopedTimer t(s, THIP_KERNEL_RECON);
-      hipLaunchKernelGGL(k_recon_row, dim3(max_rwg, nlive), dim3(64 * row_waves()), lds, s, B);
+      hipLaunchKernelGGL(k_recon_walk, dim3(ng, nlive), dim3(64 * walk_waves()), (size_t)walk_waves() * kWalkWaveLds, s, B);
     }
     {
       ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
-      hipLaunchKernelGGL(k_lf_rowseam, dim3(max_rswg, nlive), dim3(256), 0, s, B);
-    }
-  } else if (fuse == 1 && any_lf) {
-    static std::mutex attr_mu;
-    static bool attr_set = false;
-    std::lock_guard<std::mutex> alk(attr_mu);
-    if (!attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_recon_lf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kSegMax * kChunkBytes));
-      attr_set = true;
-    }
-    {
-      ScopedTimer t(s, THIP_KERNEL_RECON);
-      hipLaunchKernelGGL(k_recon_lf, dim3(max_fwg, nlive), dim3(64 * max_seglen), (size_t)max_seglen * kChunkBytes, s, B);
-    }
-    {
-      ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
-      hipLaunchKernelGGL(k_lf_seam, dim3(max_fseam_wg, nlive), dim3(256), 0, s, B);
+      hipLaunchKernelGGL(k_lf_seams, dim3(max_swg, nlive), dim3(256), 0, s, B);
     }
   } else {
     {

@@ -1,5 +1,5 @@
 // thip_kernels.h -- device side of the frame-scope path: the geometry constants shared with the
-// host, the per-stream kernel-argument tables, and the kernels k_recon, k_recon_lf, k_lf_seam,
+// host, the per-stream kernel-argument tables, and the kernels k_recon, k_recon_walk, k_lf_seams,
 // k_loopfilter, k_loopfilter_plane.  Included by thip_decode.hip only (which holds the host
 // side and the C ABI); see the header comment there for the overall picture.
 #pragma once
@@ -38,11 +38,8 @@ struct PlaneK {
   int tile_off;      // index of the plane's first tile
   int fro;           // raster index of the plane's first fragment
   float rcp_cx;      // 1/(nh+1)
-  int nseg, seglen;  // a tile row is cut into nseg segments of seglen tiles (k_recon_lf)
-  int seam_rows;     // cell rows filtered by k_lf_seam: m = 0,4,8,... and m = nv
-  // k_recon_row: wpr waves share a tile row (wave j takes tiles j, j+wpr, ...), a workgroup holds rpw rows
-  int tiles_y, wpr, rpw;
-  int rs_rows;       // cell rows left to k_lf_rowseam: m = 0, 4, ..., 4*(nv/4)
+  int tiles_y;       // tile rows
+  int rs_rows;       // cell rows left to k_lf_seams: m = 0, 4, ..., 4*(nv/4)
 };
 
 struct StreamK {
@@ -63,11 +60,8 @@ struct StreamK {
   int lf_y0[3], lf_y1[3]; // fragment-row range whose filter operations are applied
   int debug;              // ablation switches for profiling (THIP_DEBUG env), 0 in production
   int lf_sparse;          // k_loopfilter reads the coded flags first and skips waves without a coded block
-  // fused reconstruction + loop filter (k_recon_lf / k_lf_seam)
-  int seg_end[3];         // cumulative workgroup counts per plane: one workgroup per (tile row, segment)
-  int seam_end[3];        // cumulative seam-cell counts per plane, each plane padded to 64
-  // row-walking fused path (k_recon_row / k_lf_rowseam)
-  int rg_end[3];          // cumulative workgroup counts per plane: one workgroup per group of rpw tile rows
+  // fused reconstruction + loop filter (k_recon_walk / k_lf_seams)
+  int walk_wgs;           // work groups of k_recon_walk for this stream: group g walks tiles [g*n/walk_wgs, (g+1)*n/walk_wgs)
   int rs_end[3];          // cumulative row-seam cell counts per plane, each plane padded to 64
   PlaneK pl[3];
 };
@@ -96,25 +90,6 @@ struct BatchK {
 // slots left=0, previous-row=1, right=2, next-row=3.  Sorted, the eight candidates are
 //   T1 Vlo by a (!b)   T2 Hl by a (!c)   T3 Vlo by b   T4 Hr by b (!d)
 //   T5 Hl by c         T6 Vhi by c (!d)  T7 Vhi by d   T8 Hr by d
-__device__ __forceinline__ void lf_vert(int P[64], int r0, int L2) {
-#pragma unroll
-  for (int r = r0; r < r0 + 4; r++) {
-    int f = P[r * 8 + 2] - P[r * 8 + 5] + 3 * (P[r * 8 + 4] - P[r * 8 + 3]);  // state.c:1007
-    f = lflim((f + 4) >> 3, L2);
-    P[r * 8 + 3] = clamp255(P[r * 8 + 3] + f);
-    P[r * 8 + 4] = clamp255(P[r * 8 + 4] - f);
-  }
-}
-__device__ __forceinline__ void lf_horz(int P[64], int c0, int L2) {
-#pragma unroll
-  for (int c = c0; c < c0 + 4; c++) {
-    int f = P[2 * 8 + c] - P[5 * 8 + c] + 3 * (P[4 * 8 + c] - P[3 * 8 + c]);  // state.c:1023
-    f = lflim((f + 4) >> 3, L2);
-    P[3 * 8 + c] = clamp255(P[3 * 8 + c] + f);
-    P[4 * 8 + c] = clamp255(P[4 * 8 + c] - f);
-  }
-}
-
 // Which of T1..T8 apply to cell (k,m) of a plane with nh x nv fragments, given the coded
 // flags around the corner and the fragment-row range [fy0,fy1) being filtered.  Bit i-1 of
 // the result = Ti.
@@ -138,25 +113,6 @@ __device__ __forceinline__ uint32_t lf_cell_ops(int k, int m, int nh, int nv, bo
   t |= (kin && d && rhi) ? 64u : 0u;
   t |= (min_ && k <= nh - 1 && d && rhi) ? 128u : 0u;
   return t;
-}
-
-__device__ __forceinline__ void lf_cell_apply(int P[64], uint32_t t, int L2) {
-  if (__any(t & 1u)) { if (t & 1u) lf_vert(P, 0, L2); }
-  if (__any(t & 2u)) { if (t & 2u) lf_horz(P, 0, L2); }
-  if (__any(t & 4u)) { if (t & 4u) lf_vert(P, 0, L2); }
-  if (__any(t & 8u)) { if (t & 8u) lf_horz(P, 4, L2); }
-  if (__any(t & 16u)) { if (t & 16u) lf_horz(P, 0, L2); }
-  if (__any(t & 32u)) { if (t & 32u) lf_vert(P, 4, L2); }
-  if (__any(t & 64u)) { if (t & 64u) lf_vert(P, 4, L2); }
-  if (__any(t & 128u)) { if (t & 128u) lf_horz(P, 4, L2); }
-}
-
-__device__ __forceinline__ void unpack_row(int *P, uint32_t lo, uint32_t hi) {
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    P[q] = byte_of(lo, q);
-    P[4 + q] = byte_of(hi, q);
-  }
 }
 
 // A cell directly on a plane in memory (k_loopfilter, thip_loop_filter_plane).  Neither the
@@ -430,80 +386,7 @@ struct ReconPlane {               // wave-uniform
   unsigned long long *tr;         // THIP_TRACE: this wave's record (lane 0 only), else null
 };
 
-// Steps 3-5 of k_recon.  IDCT: the wave's coefficient loads into P are in flight.  Two
-// instantiations instead of one body with a merged P: a merge makes the register allocator
-// copy loaded registers right behind the loads, i.e. wait for them before the predictor
-// loads are even issued.
-// LDSOUT: the rows go to the tile image in LDS (128-byte pitch, lds_img = this lane's block) for
-// the fused loop filter instead of to the frame.
-template <bool IDCT, bool LDSOUT = false>
-__device__ __forceinline__ void recon_tail(const ReconPlane &R, const ReconLane &L, const uint4 *lds_coef,
-                                           uint8_t *lds_img = nullptr) {
-  uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
-
-  // ---- 3. predictor loads.  An uncoded fragment (fragment.c:20-47) is the zero-vector
-  //         predictor from the previous frame plus a zero residual: the same code path. ------------
-  const int refi = L.coded ? (int)((L.flags >> THIP_INFO_REFI_SHIFT) & 3u) : THIP_FRAME_PREV;
-  const bool inter = refi != THIP_FRAME_SELF && !(R.debug & 2);
-  const uint8_t *const ref = refi == THIP_FRAME_PREV ? R.prev : R.gold;
-  PredWin Q;
-  Q.border = false;
-  if (inter) pred_issue(Q, ref, R.stride, R.nh * 8, R.nv * 8, L.x0, L.y0, L.coded ? L.flags : 0u, R.qpx, R.qpy);
-  R.coded_map[(L.y0 >> 3) * R.nh + (L.x0 >> 3)] = L.coded ? 1 : 0;
-  THIP_TR(R.tr, 2);   // every load of the second round trip is issued
-
-  // ---- 4. residual: DC-only shortcut (state.c:967-975) or inverse DCT (idct.c:301) ------------
-  uint32_t Y[32];
-  if (IDCT) {
-    uint32_t P[32];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the caller's LDS-DMA loads have landed (see k_recon)
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const uint4 w = lds_coef[q * 64];
-      P[q * 4 + 0] = w.x;
-      P[q * 4 + 1] = w.y;
-      P[q * 4 + 2] = w.z;
-      P[q * 4 + 3] = w.w;
-    }
-#ifdef THIP_TRACE
-    asm volatile("" : "+v"(P[31]));
-    THIP_TR(R.tr, 3);   // coefficients (and, with them, the predictor windows) have arrived
-#endif
-    P[0] = dequant_dc_lo(P[0], L.dcq);
-    const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
-    pk_mask_by_last_zzi(P, last_zzi);
-    const bool all_zz10 = !__any(L.has_coeff && last_zzi > 10);
-    pk_idct8x8(P, Y, all_zz10);
-  }
-  if (!IDCT || !L.has_coeff) {   // DC-only: the rounded value (state.c:972); uncoded: zero residual
-    const uint32_t fill = L.dc_only ? L.dcp : 0u;
-#pragma unroll
-    for (int i = 0; i < 32; i++) Y[i] = fill;
-  }
-
-  // ---- 5. predictor rows (fragment.c:49-80: 128, one block, or the average of two),
-  //         reconstruct and store (8 aligned bytes per lane per row) ------------------------------
-  uint2 pred[8];
-#pragma unroll
-  for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
-  if (inter) pred_finish(Q, R.nh * 8, pred);
-  if (LDSOUT) {
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-      *reinterpret_cast<uint2 *>(lds_img + r * 128) =
-          pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]), pred[r]);
-  } else if (!(R.debug & 4)) {
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-      store_row8(dst + (ptrdiff_t)r * R.stride,
-                 pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]),
-                              pred[r]));
-  }
-  THIP_TR(R.tr, 4);   // stores issued
-}
-
 // ---- k_recon in three parts, so that the residual can be computed by ALL lanes of the wave ------
-// (recon_tail above is the same thing in one piece; the fused variant still uses it.)
 __device__ __forceinline__ void recon_issue(const ReconPlane &R, const ReconLane &L, PredWin &Q, bool &inter,
                                             const uint8_t *&ref) {
   const int refi = L.coded ? (int)((L.flags >> THIP_INFO_REFI_SHIFT) & 3u) : THIP_FRAME_PREV;
@@ -584,7 +467,9 @@ __device__ __forceinline__ void residual_shared_load(const int4 *coeffs, uint32_
   }
 }
 
-template <int LPB>
+// COMPACT: the results go where the exchange was (4 KB of LDS instead of 8 for LPB = 2): every lane
+// collects all its column pairs first, the wave's LDS traffic settles, then results are written.
+template <int LPB, bool COMPACT = false>
 __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32_t *lds, uint32_t *meta, int lane,
                                                 const ReconLane &L, uint32_t prefix, uint32_t Y[32]) {
   constexpr int NP = 4 / LPB;                        // row pairs (and column pairs) per lane
@@ -612,27 +497,32 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32
     pk_idct8(Rr[n][0], Rr[n][1], Rr[n][2], Rr[n][3], Rr[n][4], Rr[n][5], Rr[n][6], Rr[n][7]);
   }
   // exchange inside the group: every lane publishes its row pairs, collects its column pairs
-  uint32_t *xch = lds;                       // NP*8 dwords per lane
-  uint32_t *res = lds + 64 * NP * 8;         // 32 dwords per owner
+  uint32_t *xch = lds;                                       // NP*8 dwords per lane
+  uint32_t *res = COMPACT ? lds : lds + 64 * NP * 8;         // 32 dwords per owner
 #pragma unroll
   for (int n = 0; n < NP; n++) {
     uint4 *x4 = reinterpret_cast<uint4 *>(xch + (lane * NP + n) * 8);
     x4[0] = make_uint4(as_u32(Rr[n][0]), as_u32(Rr[n][1]), as_u32(Rr[n][2]), as_u32(Rr[n][3]));
     x4[1] = make_uint4(as_u32(Rr[n][4]), as_u32(Rr[n][5]), as_u32(Rr[n][6]), as_u32(Rr[n][7]));
   }
+  pk16 Qc[NP][8];
 #pragma unroll
   for (int n = 0; n < NP; n++) {
     const int cp = j * NP + n;                       // column pair: columns 2cp, 2cp+1
-    pk16 Q[8];
 #pragma unroll
     for (int rp = 0; rp < 4; rp++) {                 // row pair rp lives at slot (g*LPB*NP + rp) = g*4 + rp
       const uint2 ab = *reinterpret_cast<const uint2 *>(xch + (g * 4 + rp) * 8 + 2 * cp);
-      Q[2 * rp] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x05040100u));
-      Q[2 * rp + 1] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x07060302u));
+      Qc[n][2 * rp] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x05040100u));
+      Qc[n][2 * rp + 1] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x07060302u));
     }
-    pk_idct8(Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], Q[6], Q[7]);
+  }
+  if (COMPACT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all of the exchange is read before results overwrite it
 #pragma unroll
-    for (int r = 0; r < 8; r++) res[g * 32 + r * 4 + cp] = as_u32(pk_descale(Q[r]));   // Y[r*4+k] layout of the owner
+  for (int n = 0; n < NP; n++) {
+    const int cp = j * NP + n;
+    pk_idct8(Qc[n][0], Qc[n][1], Qc[n][2], Qc[n][3], Qc[n][4], Qc[n][5], Qc[n][6], Qc[n][7]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) res[g * 32 + r * 4 + cp] = as_u32(pk_descale(Qc[n][r]));   // Y[r*4+k] layout of the owner
   }
   if (L.has_coeff) {
     const uint4 *y4 = reinterpret_cast<const uint4 *>(res + prefix * 32);
@@ -824,210 +714,17 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
 }
 
 // ---------------------------------------------------------------------------------------
-// k_recon_lf (K1+K2+most of K3): reconstruction fused with the loop filter
-// ---------------------------------------------------------------------------------------
-// One workgroup per SEGMENT of a tile row (up to 16 horizontally adjacent tiles, one wave each,
-// exactly k_recon's two round trips per wave).  The reconstructed tiles go to LDS (each wave's
-// 128x32 image re-uses its coefficient staging area), the workgroup meets at a barrier, and
-// every filter cell that lies completely inside the segment's 32-pixel-high strip -- cell rows
-// m = 1..3 of the tile row, all columns except the segment's outer edges -- is filtered there
-// (cells are independent), then the strip is written to the frame ONCE.
-// What is left for k_lf_seam are the cell rows on tile-row boundaries (m = 0 mod 4, and m = nv)
-// and the columns on segment boundaries: about a quarter of the cells, read and written in full
-// rows.  The separate k_loopfilter pass re-read and re-wrote every pixel.
-constexpr int kSegMax = 8;             // waves per workgroup (8 x 8 KB of LDS: two workgroups per CU)
-constexpr int kChunkBytes = 8192;      // LDS per wave: coefficient staging, then image (4096) + flags (64)
-
-__device__ __forceinline__ uint32_t lds_px(const uint8_t *base, int x, int y) {   // 4 pixels at (x, y) of the strip
-  return *reinterpret_cast<const uint32_t *>(base + (x >> 7) * kChunkBytes + y * 128 + (x & 127));
-}
-__device__ __forceinline__ void lds_px_store(uint8_t *base, int x, int y, uint32_t v) {
-  *reinterpret_cast<uint32_t *>(base + (x >> 7) * kChunkBytes + y * 128 + (x & 127)) = v;
-}
-
-__global__ __launch_bounds__(64 * kSegMax, 1) void k_recon_lf(const BatchK B) {
-  extern __shared__ uint4 s_dyn[];
-  const StreamK &S = B.s[blockIdx.y];
-  const int lane = (int)threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, see k_recon
-  const uint2 *info_p = S.info;
-  const int4 *coeffs_p = S.coeffs;
-  const uint32_t *slot0_p = S.tile_slot0;
-  uint8_t *self = S.self;
-  const uint8_t *prev = S.prev, *gold = S.gold;
-  uint8_t *coded_map = S.coded_map;
-  const int se0 = S.seg_end[0], se1 = S.seg_end[1], se2 = S.seg_end[2];
-  const int te0 = S.tile_end[0], te1 = S.tile_end[1];
-  const int debug = S.debug, sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
-  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
-               "s"(se0), "s"(se1), "s"(se2), "s"(te0), "s"(te1), "s"(debug), "s"(sqpx), "s"(sqpy), "s"(L2));
-  if (wg >= se2) return;
-  const int pli = (wg >= se0 ? 1 : 0) + (wg >= se1 ? 1 : 0);
-  const PlaneK G = S.pl[pli];
-  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
-  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.fro), "s"(G.nseg),
-               "s"(G.seglen), "s"(fy0), "s"(fy1));
-  const int rel = wg - (pli == 0 ? 0 : (pli == 1 ? se0 : se1));
-  const int sby = rel / G.nseg;                 // tile row
-  const int seg = rel - sby * G.nseg;
-  const int tx0 = seg * G.seglen;               // first tile of the segment
-  const int ntx = min(G.seglen, G.tiles_x - tx0);
-  if (wave >= ntx) return;                      // (whole waves only: the barriers below count live waves)
-  const int tx = tx0 + wave;
-  const int unit = (pli == 0 ? 0 : (pli == 1 ? te0 : te1)) + sby * G.tiles_x + tx;   // tile number, as in k_recon
-
-  const uint32_t slot0 = slot0_p[unit];
-  const uint2 info = info_p[(size_t)unit * THIP_TILE_FRAGS + lane];
-  asm volatile("" ::"s"(slot0), "v"(info.x));
-
-  const int h = lane & 15;
-  const int lx = (lane >> 4) * 4 + hilb_col(h), ly = hilb_row(h);   // fragment inside the tile
-  const int bx = tx * 16 + lx, by = sby * 4 + ly;
-  const bool valid = bx < G.nh && by < G.nv;
-
-  ReconLane L;
-  L.flags = valid ? info.x : 0u;
-  L.dcq = info.y >> 16;
-  L.dcp = ((uint32_t)(((int)(int16_t)(info.y & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;
-  L.coded = (L.flags & THIP_INFO_CODED) != 0;
-  L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
-  L.has_coeff = L.coded && !L.dc_only;
-  L.x0 = bx * 8;
-  L.y0 = by * 8;
-  ReconPlane R;
-  R.self = self + G.off;
-  R.prev = prev + G.off;
-  R.gold = gold + G.off;
-  R.coded_map = coded_map + G.fro;
-  R.nh = G.nh;
-  R.nv = G.nv;
-  R.stride = G.stride;
-  R.qpx = pli != 0 && sqpx;
-  R.qpy = pli != 0 && sqpy;
-  R.debug = debug;
-  R.tr = nullptr;
-
-  uint8_t *const strip = reinterpret_cast<uint8_t *>(s_dyn);          // chunk w = tile w of the segment
-  uint8_t *const chunk = strip + wave * kChunkBytes;
-  uint8_t *const img = chunk + (ly * 8) * 128 + lx * 8;               // this lane's block in the tile image
-  const uint64_t mask = __ballot(L.has_coeff);
-  if (mask != 0 && !(debug & 9)) {
-    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
-    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
-    uint4 *lds_wave = reinterpret_cast<uint4 *>(chunk);
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
-                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
-    if (valid) recon_tail<true, true>(R, L, lds_wave + lane, img);
-  } else {
-    if (valid) recon_tail<false, true>(R, L, nullptr, img);
-  }
-  chunk[4096 + ly * 16 + lx] = (valid && L.coded) ? 1 : 0;           // coded flags of the tile, for the cells
-  __syncthreads();
-
-  // ---- loop filter on the cells inside the strip ---------------------------------------------------
-  // columns: every corner from the segment's first to its last, except a segment edge that is
-  // not a plane edge; rows: m = 1..3 of this tile row, below the plane's last corner row
-  if (L2 != 0) {
-    const int k0 = tx0 * 16, k1 = min(k0 + ntx * 16, G.nh);
-    const int ka = k0 + (k0 > 0 ? 1 : 0), kb = k1 - (k1 < G.nh ? 1 : 0);
-    const int ncols = kb - ka + 1;
-    const int t = (int)threadIdx.x;
-    const int mr = 1 + (t >= ncols ? 1 : 0) + (t >= 2 * ncols ? 1 : 0);
-    const int k = ka + t - (mr - 1) * ncols, m = sby * 4 + mr;
-    if (t < 3 * ncols && m < G.nv) {
-      const int kx = (k - k0) * 8, my = mr * 8;                        // corner in strip pixels
-      // flags of a=(k-1,m-1) b=(k,m-1) c=(k-1,m) d=(k,m); fragments outside the plane read as uncoded
-      auto flag = [&](int fk, int fm) -> bool {
-        const int rk = fk - k0;
-        return fk >= 0 && fk < G.nh && strip[(rk >> 4) * kChunkBytes + 4096 + (fm - sby * 4) * 16 + (rk & 15)] != 0;
-      };
-      const bool a = flag(k - 1, m - 1), b = flag(k, m - 1), c = flag(k - 1, m), d = flag(k, m);
-      const uint32_t ops = lf_cell_ops(k, m, G.nh, G.nv, a, b, c, d, fy0, fy1);
-      if (ops) {
-        const bool lo_ok = k >= 1, hi_ok = k <= G.nh - 1;
-        int P[64];
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-          unpack_row(P + r * 8, lo_ok ? lds_px(strip, kx - 4, my - 4 + r) : 0u, hi_ok ? lds_px(strip, kx, my - 4 + r) : 0u);
-        lf_cell_apply(P, ops, L2);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-          if (lo_ok) lds_px_store(strip, kx - 4, my - 4 + r, pack4(P[r * 8 + 0], P[r * 8 + 1], P[r * 8 + 2], P[r * 8 + 3]));
-          if (hi_ok) lds_px_store(strip, kx, my - 4 + r, pack4(P[r * 8 + 4], P[r * 8 + 5], P[r * 8 + 6], P[r * 8 + 7]));
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- the strip goes to the frame, once --------------------------------------------------------------
-  if (valid && !(debug & 4)) {
-    uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
-#pragma unroll
-    for (int r = 0; r < 8; r++) store_row8(dst + (ptrdiff_t)r * R.stride, *reinterpret_cast<const uint2 *>(img + r * 128));
-  }
-}
-
-// The cells k_recon_lf leaves: per plane first the seam ROWS (m = 0, 4, 8, ... and m = nv, every
-// column), then the seam COLUMNS (k on a segment boundary, the remaining rows).
-__global__ __launch_bounds__(256) void k_lf_seam(const BatchK B) {
-  const StreamK &S = B.s[blockIdx.y];
-  const int lane = (int)threadIdx.x & 63;
-  const int wbase = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 256u + (threadIdx.x & ~63u)));
-  uint8_t *self = S.self;
-  const uint8_t *cmap = S.coded_map;
-  const int ce0 = S.seam_end[0], ce1 = S.seam_end[1], ce2 = S.seam_end[2], L2 = S.flimit2;
-  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2));
-  if (wbase >= ce2 || L2 == 0) return;
-  const int pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
-  const PlaneK G = S.pl[pli];
-  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
-  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(G.nseg),
-               "s"(G.seglen), "s"(G.seam_rows), "s"(fy0), "s"(fy1));
-  const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
-  const int nh = G.nh, nv = G.nv;
-  const int nrowcells = G.seam_rows * (nh + 1);
-  int k, m;
-  if (rel < nrowcells) {
-    uint32_t mu, ku;
-    divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
-    k = (int)ku;
-    m = min((int)mu * 4, nv);            // the last seam row is m = nv whether or not nv is a multiple of 4
-  } else {
-    // seam columns: (nseg-1) columns x (nv + 1 - seam_rows) rows; row index -> m skips the seam rows
-    const int r2 = rel - nrowcells;
-    const int ncol = G.nseg - 1, nrow = nv + 1 - G.seam_rows;
-    if (ncol <= 0 || r2 >= ncol * nrow) return;
-    const int ci = r2 / nrow, ri = r2 - ci * nrow;   // (small numbers: plain division)
-    k = (ci + 1) * G.seglen * 16;
-    m = ri + ri / 3 + 1;                 // rows 1,2,3, 5,6,7, 9,...: skip every multiple of 4
-    if (k > nh - 1 || m >= nv) return;   // (a column beyond the plane cannot happen; m < nv by construction)
-  }
-  CellPix C;
-  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
-  bool a, b, c, d;
-  lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
-  const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
-  lf_cell_pin(C);
-  lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
-}
-
-// ---------------------------------------------------------------------------------------
-// k_recon_row (K1+K2+three quarters of K3): waves walk along a tile row
+// k_recon_walk (K1+K2+three quarters of K3): work groups walk through the tiles
 // ---------------------------------------------------------------------------------------
 // The second pass over the frame (k_loopfilter) costs a read and a write of every pixel.  What a
 // second pass can fix CHEAPLY is a horizontal seam -- eight whole rows, contiguous memory -- and
 // what it cannot is a vertical one: an 8-byte column piece per row touches every cache line of the
-// frame.  So this kernel leaves no vertical seam at all.  The tiles of one tile row are dealt
-// round-robin to the wpr waves of one workgroup (wave j: tiles j, j+wpr, ...), so the tile to the
-// left of any tile belongs to a neighbour wave of the same workgroup (or to this wave's previous
-// iteration), and its last four pixel columns -- unfiltered, 32 rows x 4 bytes -- come over through
-// LDS with a pair of counters, no workgroup barrier.  A wave
+// frame.  So this kernel leaves (almost) no vertical seam.  A stream's tiles, in tile order (plane by
+// plane, tile row by tile row, left to right), are cut into walk_wgs equal ranges, one per work group,
+// and dealt round-robin to the group's waves: wave j takes tiles u0+j, u0+j+W, ...  The tile to the
+// left of a tile is the previous one in that order, so it belongs to the neighbour wave (or to this
+// wave's previous round), and its last four pixel columns -- unfiltered, 32 rows x 4 bytes -- come
+// over through LDS with a pair of counters; there is no work-group barrier.  A wave
 //   1. reconstructs its tile exactly as k_recon does (the two memory round trips; the command words
 //      of its NEXT tile are requested first, so from the second tile on there is one round trip),
 //   2. writes the 128x32 image into its LDS area (the coefficient staging area, free by then),
@@ -1037,23 +734,28 @@ __global__ __launch_bounds__(256) void k_lf_seam(const BatchK B) {
 //      m = 0 carry the tile's pixel rows 28..31 and 0..3 unfiltered.  The cells are shifted by half a
 //      block against the tile, so what the wave stores is the frame region [128t-4, 128t+124) x
 //      [32*sby, 32*sby+32): 128 contiguous bytes per row, every byte of the frame exactly once.
-// k_lf_rowseam then filters the cell rows on tile-row boundaries (m = 0 mod 4): a quarter of the
-// lines instead of all of them.  The order of operations inside every cell is the reference's
-// (state.c:1055-1105), as in k_loopfilter; both kernels honour the row range of the slot.
-constexpr int kRowPitch = 144;                  // LDS image row: 8-byte left margin (4 used), 128 pixels, 8 spare
-constexpr int kRowImgX0 = 8;                    // byte offset of pixel column 0 in an image row
-constexpr int kRowFlagOff = 32 * kRowPitch;     // coded flags: 4 rows of kRowFlagPitch bytes
-constexpr int kRowFlagPitch = 20;               // [0] left neighbour's column 15, [1..16] the tile, [17] column k = nh
-constexpr int kRowMetaOff = 8192;               // 32 dwords for residual_shared
-constexpr int kRowEdgeOff = 8320;               // published right edge: 2 buffers x 32 dwords (column bytes 124..127 per row)
-constexpr int kRowEFlagOff = 8576;              // 2 dwords: coded flags of block column 15, one byte per block row
-constexpr int kRowPubOff = 8584;                // tiles this wave has published
-constexpr int kRowConsOff = 8588;               // tiles of this wave its right neighbour has consumed
-constexpr int kRowWaveLds = 8704;               // per wave, multiple of 16
+// k_lf_seams then filters the cell rows on tile-row boundaries (m = 0 mod 4) -- a quarter of the
+// lines instead of all of them -- and the three cells on each CUT, the place where one group's range
+// ends in the middle of a tile row (walk_wgs - 1 places per stream; both sides store their halves of
+// those cells unfiltered).  Equal ranges are what makes this a balanced single round of resident
+// groups: one group per tile row (30 tiles of luma, 15 of chroma, 408 groups for 256 CUs) measured 65 us
+// against 43 for k_recon, half of the CUs carrying twice the load of the others.
+// The order of operations inside every cell is the reference's (state.c:1055-1105), as in
+// k_loopfilter; both kernels honour the row range of the slot.
+constexpr int kWalkPitch = 144;                  // LDS image row: 8-byte left margin (4 used), 128 pixels, 8 spare
+constexpr int kWalkImgX0 = 8;                    // byte offset of pixel column 0 in an image row
+constexpr int kWalkFlagOff = 32 * kWalkPitch;    // coded flags: 4 rows of kWalkFlagPitch bytes
+constexpr int kWalkFlagPitch = 20;               // [0] left neighbour's column 15, [1..16] the tile, [17] column 16 (never coded)
+constexpr int kWalkMetaOff = 8192;               // 32 dwords for residual_shared
+constexpr int kWalkEdgeOff = 8320;               // published right edge: 2 buffers x 32 dwords (column bytes 124..127 per row)
+constexpr int kWalkEFlagOff = 8576;              // 2 dwords: coded flags of block column 15, one byte per block row
+constexpr int kWalkPubOff = 8584;                // tiles this wave has published
+constexpr int kWalkConsOff = 8588;               // tiles of this wave its right neighbour has consumed
+constexpr int kWalkWaveLds = 8704;               // per wave, multiple of 16
 
 __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// Waits until *ctr >= need.  Waves of one workgroup are co-resident, so the producer always makes
+// Waits until *ctr >= need.  Waves of one work group are co-resident, so the producer always makes
 // progress; the spin is bounded all the same (a wrong picture is a failed test, a hang is a dead GPU).
 __device__ __forceinline__ void lds_wait_ge(const uint32_t *ctr, uint32_t need) {
   for (int spins = 0; spins < (1 << 22); spins++) {
@@ -1063,33 +765,34 @@ __device__ __forceinline__ void lds_wait_ge(const uint32_t *ctr, uint32_t need) 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// One filter cell of the row kernel: corner column kx (0..16) of the tile, cell row m (0..3); reads the
-// LDS image, filters (m >= 1), stores to the frame.  The cell's upper half is image rows
-// (8m-4 .. 8m-1) mod 32 and its lower half rows 8m .. 8m+3: for m = 0 the former wraps to rows 28..31,
-// which is how the m = 0 lanes come to carry the tile's first and last four rows.
-__device__ __forceinline__ void row_cell(const uint8_t *mine, uint8_t *plane, int stride, int nh, int nv, int t, int sby,
-                                         int kx, int m, bool active, int L2, int fy0, int fy1) {
+// One filter cell of the walk: corner column kx (0..16) of the tile, cell row m (0..3); reads the LDS
+// image, filters (m >= 1, unless the cell lies on a cut), stores to the frame.  The cell's upper half
+// is image rows (8m-4 .. 8m-1) mod 32 and its lower half rows 8m .. 8m+3: for m = 0 the former wraps to
+// rows 28..31, which is how the m = 0 lanes come to carry the tile's first and last four rows.
+__device__ __forceinline__ void walk_cell(const uint8_t *mine, uint8_t *plane, int stride, int nh, int nv, int t, int sby,
+                                          int kx, int m, bool active, int L2, int fy0, int fy1, bool unfiltered,
+                                          bool lo_mine, bool hi_mine) {
   const int k = 16 * t + kx, mm = 4 * sby + m;
-  const bool lo_ok = active && k >= 1 && k <= nh, hi_ok = active && k <= nh - 1;
+  const bool lo_ok = active && lo_mine && k >= 1 && k <= nh, hi_ok = active && hi_mine && k <= nh - 1;
   const int row_up = (8 * m - 4) & 31, row_dn = 8 * m;   // first image row of each half
   CellPix C;
-  const uint8_t *img_up = mine + kRowImgX0 + 8 * kx - 4 + row_up * kRowPitch;
-  const uint8_t *img_dn = mine + kRowImgX0 + 8 * kx - 4 + row_dn * kRowPitch;
+  const uint8_t *img_up = mine + kWalkImgX0 + 8 * kx - 4 + row_up * kWalkPitch;
+  const uint8_t *img_dn = mine + kWalkImgX0 + 8 * kx - 4 + row_dn * kWalkPitch;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const uint32_t *qu = reinterpret_cast<const uint32_t *>(img_up + r * kRowPitch);
-    const uint32_t *qd = reinterpret_cast<const uint32_t *>(img_dn + r * kRowPitch);
+    const uint32_t *qu = reinterpret_cast<const uint32_t *>(img_up + r * kWalkPitch);
+    const uint32_t *qd = reinterpret_cast<const uint32_t *>(img_dn + r * kWalkPitch);
     C.lo[r] = qu[0];
     C.hi[r] = qu[1];
     C.lo[4 + r] = qd[0];
     C.hi[4 + r] = qd[1];
   }
-  const uint8_t *fl = mine + kRowFlagOff + kx;    // fl[row * pitch + 0] = column kx-1, [+1] = column kx
+  const uint8_t *fl = mine + kWalkFlagOff + kx;    // fl[row * pitch + 0] = column kx-1, [+1] = column kx
   const int ma = max(m - 1, 0);
-  const bool a = fl[ma * kRowFlagPitch] != 0, b = fl[ma * kRowFlagPitch + 1] != 0;
-  const bool c = fl[m * kRowFlagPitch] != 0, d = fl[m * kRowFlagPitch + 1] != 0;
+  const bool a = fl[ma * kWalkFlagPitch] != 0, b = fl[ma * kWalkFlagPitch + 1] != 0;
+  const bool c = fl[m * kWalkFlagPitch] != 0, d = fl[m * kWalkFlagPitch + 1] != 0;
   uint32_t ops = lf_cell_ops(k, mm, nh, nv, a, b, c, d, fy0, fy1);
-  if (m == 0 || L2 == 0 || !(lo_ok || hi_ok)) ops = 0;
+  if (m == 0 || L2 == 0 || unfiltered || !(lo_ok || hi_ok)) ops = 0;
   lf_cell_apply_pk(C, ops, L2);
   const int H = nv * 8;
   uint8_t *p_up = plane + (ptrdiff_t)(32 * sby + row_up) * stride + (8 * k - 4);
@@ -1114,83 +817,104 @@ __device__ __forceinline__ void row_cell(const uint8_t *mine, uint8_t *plane, in
   }
 }
 
-__global__ __launch_bounds__(1024) void k_recon_row(const BatchK B) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_row[];
+// first tile of group g's range when n tiles are cut into ng equal ranges
+__host__ __device__ inline int walk_cut(int g, int n, int ng) { return (int)(((long long)g * n) / ng); }
+
+#ifndef THIP_WALK_MAXTHREADS
+#define THIP_WALK_MAXTHREADS 1024   // launch bound = register cap: 1024 -> 128 VGPRs (4 waves per SIMD)
+#endif
+__global__ __launch_bounds__(THIP_WALK_MAXTHREADS) void k_recon_walk(const BatchK B) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_walk[];
   const StreamK &S = B.s[blockIdx.y];
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, see k_recon
+  const int W = (int)blockDim.x >> 6;
+  const int g = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, see k_recon
   const uint2 *info_p = S.info;
   const int4 *coeffs_p = S.coeffs;
   const uint32_t *slot0_p = S.tile_slot0;
   uint8_t *self = S.self;
   const uint8_t *prev = S.prev, *gold = S.gold;
   uint8_t *coded_map = S.coded_map;
-  const int rg0 = S.rg_end[0], rg1 = S.rg_end[1], rg2 = S.rg_end[2];
-  const int te0 = S.tile_end[0], te1 = S.tile_end[1];
+  const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2], ng = S.walk_wgs;
   const int sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
   asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
-               "s"(rg0), "s"(rg1), "s"(rg2), "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2));
-  uint8_t *const mine = s_row + wave * kRowWaveLds;
-  // the hand-off counters start at zero before any wave of the workgroup looks at a neighbour's
+               "s"(te0), "s"(te1), "s"(te2), "s"(ng), "s"(sqpx), "s"(sqpy), "s"(L2));
+  uint8_t *const mine = s_walk + wave * kWalkWaveLds;
+  // the hand-off counters start at zero before any wave of the group looks at a neighbour's
   if (((int)threadIdx.x & 63) == 0) {
-    *reinterpret_cast<uint32_t *>(mine + kRowPubOff) = 0;
-    *reinterpret_cast<uint32_t *>(mine + kRowConsOff) = 0;
+    *reinterpret_cast<uint32_t *>(mine + kWalkPubOff) = 0;
+    *reinterpret_cast<uint32_t *>(mine + kWalkConsOff) = 0;
   }
   __syncthreads();
-  if (wg >= rg2) return;
-  const int pli = (wg >= rg0 ? 1 : 0) + (wg >= rg1 ? 1 : 0);
-  const PlaneK G = S.pl[pli];
-  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
-  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.fro), "s"(G.tiles_y),
-               "s"(G.wpr), "s"(G.rpw), "s"(fy0), "s"(fy1));
-  const int rel = wg - (pli == 0 ? 0 : (pli == 1 ? rg0 : rg1));
-  const int grp = wave / G.wpr, j = wave - grp * G.wpr;       // (scalar)
-  const int sby = rel * G.rpw + grp;                          // tile row of this wave
-  if (grp >= G.rpw || sby >= G.tiles_y) return;               // (no barrier below: spare waves just leave)
-  const int unit0 = (pli == 0 ? 0 : (pli == 1 ? te0 : te1)) + sby * G.tiles_x;   // first tile of the row, as in k_recon
-  const uint8_t *const left = s_row + (grp * G.wpr + (j == 0 ? G.wpr - 1 : j - 1)) * kRowWaveLds;   // the wave that holds tile t-1
+  if (g >= ng) return;
+  const int u0 = walk_cut(g, te2, ng), u1 = walk_cut(g + 1, te2, ng);   // this group's tiles
+  int u = u0 + wave;
+  if (u >= u1) return;                                                   // (no barrier below: spare waves just leave)
+  const uint8_t *const left = s_walk + (wave == 0 ? W - 1 : wave - 1) * kWalkWaveLds;   // the wave that holds tile u-1
 
   ReconPlane R;
-  R.self = self + G.off;
-  R.prev = prev + G.off;
-  R.gold = gold + G.off;
-  R.coded_map = coded_map + G.fro;
-  R.nh = G.nh;
-  R.nv = G.nv;
-  R.stride = G.stride;
-  R.qpx = pli != 0 && sqpx;
-  R.qpy = pli != 0 && sqpy;
   R.debug = 0;
   R.tr = nullptr;
   uint4 *const lds_wave = reinterpret_cast<uint4 *>(mine);
   uint32_t *const lds_dw = reinterpret_cast<uint32_t *>(mine);
-  uint32_t *const meta = reinterpret_cast<uint32_t *>(mine + kRowMetaOff);
-  const bool col17 = (G.nh & 15) == 0;   // the plane's right edge, cell column k = nh, is a 17th column of the last tile
+  uint32_t *const meta = reinterpret_cast<uint32_t *>(mine + kWalkMetaOff);
 
-  int t = j;
-  uint32_t slot0 = 0;
-  uint2 info = make_uint2(0u, 0u);
-  if (t < G.tiles_x) {
-    slot0 = slot0_p[unit0 + t];
-    info = info_p[(size_t)(unit0 + t) * THIP_TILE_FRAGS + ((int)threadIdx.x & 63)];
-  }
-  for (int it = 0; t < G.tiles_x; it++, t += G.wpr) {
+  uint32_t slot0 = slot0_p[u];
+  uint2 info = info_p[(size_t)u * THIP_TILE_FRAGS + ((int)threadIdx.x & 63)];
+  int cur_pli = -1, tiles_x = 1, tile_base = 0, fy0 = 0, fy1 = 0;
+  for (int it = 0; u < u1; it++, u += W) {
     // The lane number is made opaque once per tile: left alone, the compiler hoists everything that
     // depends on the lane only (addresses, masks, predicates of all three transform paths and of the
     // cells) out of the tile loop and ends up with 250 live registers.
     int lane = (int)threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
+    // ---- the next tile's command words: requested now, used after this tile is done --------------
+    const int un = min(u + W, u1 - 1);
+    const uint32_t slot0_n = slot0_p[un];
+    const uint2 info_n = info_p[(size_t)un * THIP_TILE_FRAGS + lane];
+
+    // ---- where this tile is (scalar); the plane's geometry is re-read when the walk enters a plane ----
+    const int pli = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
+    if (pli != cur_pli) {
+      const PlaneK &G = S.pl[pli];
+      R.self = self + G.off;
+      R.prev = prev + G.off;
+      R.gold = gold + G.off;
+      R.coded_map = coded_map + G.fro;
+      R.nh = G.nh;
+      R.nv = G.nv;
+      R.stride = G.stride;
+      R.qpx = pli != 0 && sqpx;
+      R.qpy = pli != 0 && sqpy;
+      tiles_x = G.tiles_x;
+      tile_base = pli == 0 ? 0 : (pli == 1 ? te0 : te1);
+      fy0 = S.lf_y0[pli];
+      fy1 = S.lf_y1[pli];
+      cur_pli = pli;
+    }
+#ifdef THIP_TRACE
+    // tools/walk_trace.py: lane 0 stamps the phases of every tile (record = stream's tile number)
+    unsigned long long *tr = nullptr;
+    if (g_trace_buf && lane == 0) {
+      tr = g_trace_buf + ((size_t)blockIdx.y * te2 + u) * 8;
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      tr[7] = (unsigned long long)hwid | (unsigned long long)it << 32 | (unsigned long long)wave << 40 | (unsigned long long)g << 48;
+    }
+    THIP_TR(tr, 0);   // tile begins
+#endif
+    const int rel = u - tile_base;
+    const int sby = rel / tiles_x, t = rel - sby * tiles_x;
+    const bool has_left = u > u0;                      // a wave of this group holds tile u-1: its edge gets consumed
+    const bool cut_left = !has_left && t > 0;          // the left neighbour belongs to another group
+    const bool row_end = t == tiles_x - 1;
+    const bool cut_right = u == u1 - 1 && !row_end;    // the right neighbour belongs to another group
+
     const int h = lane & 15;
     const int lx = (lane >> 4) * 4 + hilb_col(h), ly = hilb_row(h);   // fragment inside the tile
-    const int by = sby * 4 + ly;
-    uint8_t *const img = mine + (ly * 8) * kRowPitch + kRowImgX0 + lx * 8;   // this lane's block in the tile image
-    // ---- the next tile's command words: requested now, used after this tile is done --------------
-    const int tn = min(t + G.wpr, G.tiles_x - 1);
-    const uint32_t slot0_n = slot0_p[unit0 + tn];
-    const uint2 info_n = info_p[(size_t)(unit0 + tn) * THIP_TILE_FRAGS + lane];
-
-    const int bx = t * 16 + lx;
-    const bool valid = bx < G.nh && by < G.nv;
+    const int bx = t * 16 + lx, by = sby * 4 + ly;
+    uint8_t *const img = mine + (ly * 8) * kWalkPitch + kWalkImgX0 + lx * 8;   // this lane's block in the tile image
+    const bool valid = bx < R.nh && by < R.nv;
     ReconLane L;
     L.flags = valid ? info.x : 0u;
     L.dcq = info.y >> 16;
@@ -1222,15 +946,15 @@ __global__ __launch_bounds__(1024) void k_recon_row(const BatchK B) {
     if (nown == 0) {
       if (valid) recon_issue(R, L, Q, inter, ref);
     } else if (nown <= 16) {
-      int4 W[1][2];
-      residual_shared_load<4>(coeffs_p, slot0, nown, lane, W);
+      int4 Wc[1][2];
+      residual_shared_load<4>(coeffs_p, slot0, nown, lane, Wc);
       if (valid) recon_issue(R, L, Q, inter, ref);
-      residual_shared<4>(W, lds_dw, meta, lane, L, prefix, Y);
+      residual_shared<4>(Wc, lds_dw, meta, lane, L, prefix, Y);
     } else if (nown <= 32) {
-      int4 W[2][2];
-      residual_shared_load<2>(coeffs_p, slot0, nown, lane, W);
+      int4 Wc[2][2];
+      residual_shared_load<2>(coeffs_p, slot0, nown, lane, Wc);
       if (valid) recon_issue(R, L, Q, inter, ref);
-      residual_shared<2>(W, lds_dw, meta, lane, L, prefix, Y);
+      residual_shared<2>(Wc, lds_dw, meta, lane, L, prefix, Y);
     } else {
       const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
       const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
@@ -1246,84 +970,133 @@ __global__ __launch_bounds__(1024) void k_recon_row(const BatchK B) {
         for (int i = 0; i < 32; i++) Y[i] = fill;
       }
     }
+#ifdef THIP_TRACE
+    asm volatile("" : "+v"(Y[0]), "+v"(Y[31]));
+    THIP_TR(tr, 1);   // residual done (coefficients had arrived)
+#endif
     uint2 rows[8];
     recon_rows(R, Q, inter, Y, rows);
+#ifdef THIP_TRACE
+    asm volatile("" : "+v"(rows[0].x), "+v"(rows[7].y));
+    THIP_TR(tr, 2);   // pixels done (predictor windows had arrived)
+#endif
 
     // ---- the tile image, its coded flags, the right edge for the neighbour -------------------------
     lds_settle();                                   // every lane is done with the staging area
     if (valid) {
 #pragma unroll
-      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(img + r * kRowPitch) = rows[r];
+      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(img + r * kWalkPitch) = rows[r];
     }
-    mine[kRowFlagOff + ly * kRowFlagPitch + 1 + lx] = (valid && L.coded) ? 1 : 0;
-    uint32_t *const pubc = reinterpret_cast<uint32_t *>(mine + kRowPubOff);
-    if (it >= 2) lds_wait_ge(reinterpret_cast<const uint32_t *>(mine + kRowConsOff), (uint32_t)(it - 1));   // buffer it&1 is free again
+    mine[kWalkFlagOff + ly * kWalkFlagPitch + 1 + lx] = (valid && L.coded) ? 1 : 0;
+    if (lane < 4) mine[kWalkFlagOff + lane * kWalkFlagPitch + 17] = 0;   // "column 16": the next tile's, never ours to filter
+    if (it >= 2) lds_wait_ge(reinterpret_cast<const uint32_t *>(mine + kWalkConsOff), (uint32_t)(it - 1));   // buffer it&1 is free again
     lds_settle();
     if (lane < 32)
-      reinterpret_cast<uint32_t *>(mine + kRowEdgeOff)[(it & 1) * 32 + lane] =
-          *reinterpret_cast<const uint32_t *>(mine + lane * kRowPitch + kRowImgX0 + 124);
+      reinterpret_cast<uint32_t *>(mine + kWalkEdgeOff)[(it & 1) * 32 + lane] =
+          *reinterpret_cast<const uint32_t *>(mine + lane * kWalkPitch + kWalkImgX0 + 124);
     else if (lane == 32)
-      reinterpret_cast<uint32_t *>(mine + kRowEFlagOff)[it & 1] =
-          (uint32_t)mine[kRowFlagOff + 16] | (uint32_t)mine[kRowFlagOff + kRowFlagPitch + 16] << 8 |
-          (uint32_t)mine[kRowFlagOff + 2 * kRowFlagPitch + 16] << 16 | (uint32_t)mine[kRowFlagOff + 3 * kRowFlagPitch + 16] << 24;
+      reinterpret_cast<uint32_t *>(mine + kWalkEFlagOff)[it & 1] =
+          (uint32_t)mine[kWalkFlagOff + 16] | (uint32_t)mine[kWalkFlagOff + kWalkFlagPitch + 16] << 8 |
+          (uint32_t)mine[kWalkFlagOff + 2 * kWalkFlagPitch + 16] << 16 | (uint32_t)mine[kWalkFlagOff + 3 * kWalkFlagPitch + 16] << 24;
     lds_settle();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(pubc, (uint32_t)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0)
+      __hip_atomic_store(reinterpret_cast<uint32_t *>(mine + kWalkPubOff), (uint32_t)(it + 1), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
 
-    // ---- the left neighbour's edge into the image margin ---------------------------------------------
-    if (t > 0) {
-      const int il = j == 0 ? it - 1 : it;          // the iteration in which the left wave did tile t-1
-      lds_wait_ge(reinterpret_cast<const uint32_t *>(left + kRowPubOff), (uint32_t)(il + 1));
+#ifdef THIP_TRACE
+    THIP_TR(tr, 3);   // image in LDS, edge published
+#endif
+    // ---- tile u-1's edge into the image margin.  It is consumed (and acknowledged) even when tile u
+    //      starts a row and has no use for it: the producer waits for the acknowledgement before it
+    //      re-uses the buffer. -----------------------------------------------------------------------
+    if (has_left) {
+      const int il = wave == 0 ? it - 1 : it;       // the round in which the left wave did tile u-1
+      lds_wait_ge(reinterpret_cast<const uint32_t *>(left + kWalkPubOff), (uint32_t)(il + 1));
       if (lane < 32)
-        *reinterpret_cast<uint32_t *>(mine + lane * kRowPitch + kRowImgX0 - 4) =
-            reinterpret_cast<const uint32_t *>(left + kRowEdgeOff)[(il & 1) * 32 + lane];
+        *reinterpret_cast<uint32_t *>(mine + lane * kWalkPitch + kWalkImgX0 - 4) =
+            reinterpret_cast<const uint32_t *>(left + kWalkEdgeOff)[(il & 1) * 32 + lane];
       else if (lane < 36)
-        mine[kRowFlagOff + (lane - 32) * kRowFlagPitch] =
-            (uint8_t)(reinterpret_cast<const uint32_t *>(left + kRowEFlagOff)[il & 1] >> (8 * (lane - 32)));
+        mine[kWalkFlagOff + (lane - 32) * kWalkFlagPitch] =
+            t > 0 ? (uint8_t)(reinterpret_cast<const uint32_t *>(left + kWalkEFlagOff)[il & 1] >> (8 * (lane - 32))) : (uint8_t)0;
       lds_settle();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0)
-        __hip_atomic_store(const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(left + kRowConsOff)), (uint32_t)(il + 1),
+        __hip_atomic_store(const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(left + kWalkConsOff)), (uint32_t)(il + 1),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-      if (lane >= 32 && lane < 36) mine[kRowFlagOff + (lane - 32) * kRowFlagPitch] = 0;
+      if (lane >= 32 && lane < 36) mine[kWalkFlagOff + (lane - 32) * kWalkFlagPitch] = 0;
       lds_settle();
     }
 
-    // ---- 16 x 4 filter cells; the plane's right edge column is a 17th in the last tile ----------------
-    row_cell(mine, R.self, R.stride, G.nh, G.nv, t, sby, lane & 15, lane >> 4, true, L2, fy0, fy1);
-    if (col17 && t == G.tiles_x - 1)
-      row_cell(mine, R.self, R.stride, G.nh, G.nv, t, sby, 16, lane & 3, lane < 4, L2, fy0, fy1);
+#ifdef THIP_TRACE
+    THIP_TR(tr, 4);   // left edge consumed
+#endif
+    // ---- 16 x 4 filter cells.  Column kx = 0 on a cut is stored unfiltered, right half only (k_lf_seams
+    //      filters it); a 17th column -- left half only -- exists where the tile ends the row of a plane
+    //      whose width is a whole number of tiles (cell column k = nh: the horizontal edges reach the
+    //      plane's border) and on the other side of a cut. ----------------------------------------------
+    {
+      const int kx = lane & 15;
+      const bool on_cut = cut_left && kx == 0;
+      walk_cell(mine, R.self, R.stride, R.nh, R.nv, t, sby, kx, lane >> 4, true, L2, fy0, fy1, on_cut, !on_cut, true);
+    }
+    if (cut_right || (row_end && (R.nh & 15) == 0))
+      walk_cell(mine, R.self, R.stride, R.nh, R.nv, t, sby, 16, lane & 3, lane < 4, L2, fy0, fy1, cut_right, true, false);
     lds_settle();                                   // the image is read; the next tile may overwrite it
+#ifdef THIP_TRACE
+    THIP_TR(tr, 5);   // cells filtered, stores issued
+#endif
     slot0 = slot0_n;
     info = info_n;
   }
 }
 
-// The cell rows k_recon_row leaves: m = 0, 4, 8, ..., 4*(nv/4), every column.  (m = nv is among them
-// when nv is a multiple of 4; otherwise it lies inside the last tile row and k_recon_row has done it.)
-__global__ __launch_bounds__(256) void k_lf_rowseam(const BatchK B) {
+// What k_recon_walk leaves: the cell rows m = 0, 4, 8, ..., 4*(nv/4), every column (m = nv is among them
+// when nv is a multiple of 4; otherwise it lies inside the last tile row and the walk has done it), and,
+// one wave each, the three cells m = 1..3 on every cut between two groups' ranges.
+__global__ __launch_bounds__(256) void k_lf_seams(const BatchK B) {
   const StreamK &S = B.s[blockIdx.y];
   const int lane = (int)threadIdx.x & 63;
-  // XCD bands over the workgroups, like the kernel whose rows these are
+  // XCD bands over the work groups, like the kernel whose rows these are
   const int wgb = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
   const int wbase = __builtin_amdgcn_readfirstlane(wgb * 256 + (int)(threadIdx.x & ~63u));
   uint8_t *self = S.self;
   const uint8_t *cmap = S.coded_map;
   const int ce0 = S.rs_end[0], ce1 = S.rs_end[1], ce2 = S.rs_end[2], L2 = S.flimit2;
-  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2));
-  if (wbase >= ce2 || L2 == 0) return;
-  const int pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
+  const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2], ng = S.walk_wgs;
+  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2), "s"(te0), "s"(te1), "s"(te2), "s"(ng));
+  if (L2 == 0) return;
+  int pli, k, m;
+  if (wbase < ce2) {
+    pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
+  } else {
+    const int cut = (wbase - ce2) / 64 + 1;         // cut between group cut-1 and group cut
+    if (cut >= ng) return;
+    const int u = walk_cut(cut, te2, ng);
+    pli = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
+  }
   const PlaneK G = S.pl[pli];
   const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
-  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(G.rs_rows), "s"(fy0),
-               "s"(fy1));
-  const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(G.rs_rows), "s"(G.tiles_x),
+               "s"(fy0), "s"(fy1));
   const int nh = G.nh, nv = G.nv;
-  if (rel >= G.rs_rows * (nh + 1)) return;
-  uint32_t mu, ku;
-  divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
-  const int k = (int)ku, m = (int)mu * 4;
+  if (wbase < ce2) {
+    const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
+    if (rel >= G.rs_rows * (nh + 1)) return;
+    uint32_t mu, ku;
+    divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
+    k = (int)ku;
+    m = (int)mu * 4;
+  } else {
+    const int cut = (wbase - ce2) / 64 + 1;
+    const int rel = walk_cut(cut, te2, ng) - (pli == 0 ? 0 : (pli == 1 ? te0 : te1));
+    const int sby = rel / G.tiles_x, t = rel - sby * G.tiles_x;
+    if (t == 0 || lane >= 3) return;                // the range starts with a tile row: no vertical seam
+    k = 16 * t;
+    m = 4 * sby + 1 + lane;
+    if (m > nv) return;
+  }
   CellPix C;
   lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
   bool a, b, c, d;

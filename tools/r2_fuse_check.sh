@@ -6,12 +6,12 @@ out=gpurun_out/r2row
 mkdir -p $out
 export TMPDIR=/tmp
 sel='sequence_small or lane_shared or enqueue or batched'
-[ "$mode" = full ] && sel='(sequence or enqueue or batched or grey or dup or lane_shared or static_background) and not elision and not fused and not row_walking'
-THIP_FUSE=2 timeout 900 python -m pytest tests/test_gpu_frames.py -m gpu -x -q -k "$sel" > $out/pytest_fuse2.log 2>&1
+[ "$mode" = full ] && sel='(sequence or enqueue or batched or grey or dup or lane_shared or static_background) and not elision and not fused and not fused_walk'
+THIP_FUSE=1 timeout 900 python -m pytest tests/test_gpu_frames.py -m gpu -x -q -k "$sel" > $out/pytest_fuse2.log 2>&1
 echo "pytest fuse2 rc=$?" | tee $out/summary.txt
 tail -5 $out/pytest_fuse2.log | tee -a $out/summary.txt
 for content in dense smooth; do
-  for fuse in 0 2; do
+  for fuse in ${FUSES:-0 1}; do
     THIP_FUSE=$fuse timeout 600 python bench.py --steps 256 --warmup 16 --content $content --no-cpu-baseline > $out/bench_${content}_fuse$fuse.json 2> $out/bench_${content}_fuse$fuse.err
     echo "bench $content fuse=$fuse rc=$?" | tee -a $out/summary.txt
     python - <<PY | tee -a $out/summary.txt
