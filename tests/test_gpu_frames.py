@@ -291,3 +291,28 @@ def test_static_block_elision_forced_on_every_frame(hip):
                               "and not elision and not fused"], cwd=root,
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("content", ["dense", "smooth"])
+def test_four_concurrent_4k_streams_one_call(hip, content):
+    """BASELINE.json config 4's per-GPU share exactly as bench.py times it: four 4K 4:2:0 streams with
+    different content decoded in lock step, ONE thip_decode_frames call per step (the library spreads
+    them over its two lanes), nine frames with a key frame inside the run; every plane of every stream
+    after every step against the oracle."""
+    w, h, S, nframes = 3840, 2160, 4, 9
+    geom = synth.Geometry(w, h, PF_420)
+    rngs = [np.random.default_rng(4000 + 17 * i) for i in range(S)]
+    osts = [oracle.State(w, h, PF_420) for _ in range(S)]
+    gsts = [hip.State(w, h, PF_420) for _ in range(S)]
+    for f in range(nframes):
+        descs, keep = [], []
+        for i in range(S):
+            ftype = hip.INTRA_FRAME if f in (0, 6) else hip.INTER_FRAME
+            fr = synth.gen_frame(geom, rngs[i], ftype, content, flimit=2 if i != 3 else 5)
+            assert util.oracle_apply(osts[i], fr) == 0
+            d, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+            descs.append(d)
+            keep.append(ka)
+        assert hip.decode_frames(gsts, descs) == [0] * S
+        for i in range(S):
+            assert not util.planes_equal(osts[i], gsts[i]), (f, i)

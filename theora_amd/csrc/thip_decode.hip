@@ -604,7 +604,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     if (wgs > max_wg) max_wg = wgs;
     if (d.flimit) {
       any_lf = 1;
-      const int swg = (K.cell_end[2] + THIP_LF_WG - 1) / THIP_LF_WG;
+      const int swg = ((K.cell_end[2] + THIP_LF_WG - 1) / THIP_LF_WG + 7) & ~7;   // 8 XCD bands
       if (swg > max_seam_wg) max_seam_wg = swg;
     }
     if (K.skip_ok) any_skip = 1;
@@ -703,7 +703,11 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
       states[i]->lane = g_next_lane++ % g_nlanes;
     }
   }
-  // group by lane (order inside a lane preserved), launch chunk by chunk
+  // group by lane (order inside a lane preserved), launch chunk by chunk (THIP_CHUNK: streams per launch)
+  static const int chunk_max = [] {
+    const int v = getenv("THIP_CHUNK") ? atoi(getenv("THIP_CHUNK")) : THIP_MAX_BATCH;
+    return v < 1 ? 1 : (v > THIP_MAX_BATCH ? THIP_MAX_BATCH : v);
+  }();
   for (int lane = 0; lane < g_nlanes; lane++) {
     thip_state *ls[THIP_MAX_BATCH];
     thip_frame_desc ld[THIP_MAX_BATCH];
@@ -717,7 +721,7 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
         li[n] = i;
         n++;
       }
-      if (n == THIP_MAX_BATCH || (i == nstreams && n > 0)) {
+      if (n == chunk_max || (i == nstreams && n > 0)) {
         rc = launch_chunk(ls, ld, n, g_lanes[lane], lr);
         if (rc < 0) return rc;
         if (results)

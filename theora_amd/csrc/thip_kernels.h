@@ -1117,7 +1117,11 @@ __global__ __launch_bounds__(256) void k_lf_seams(const BatchK B) {
 __global__ __launch_bounds__(THIP_LF_WG) void k_loopfilter(const BatchK B) {
   const StreamK &S = B.s[blockIdx.y];
   const int lane = (int)threadIdx.x & 63;
-  const int wbase = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)THIP_LF_WG + (threadIdx.x & ~63u)));
+  // XCD bands over the work groups, like k_recon's (gridDim.x is a multiple of 8): the cells of a band are
+  // the pixels the same XCD's k_recon waves have just written, so what is still in that L2 is not
+  // fetched again
+  const int wgb = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  const int wbase = __builtin_amdgcn_readfirstlane(wgb * THIP_LF_WG + (int)(threadIdx.x & ~63u));
   uint8_t *self = S.self;
   const uint8_t *cmap = S.coded_map;
   const int ce0 = S.cell_end[0], ce1 = S.cell_end[1], ce2 = S.cell_end[2], L2 = S.flimit2;

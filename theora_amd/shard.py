@@ -46,3 +46,12 @@ def reduce_max(values, device):
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t.tolist()]
+
+
+def reduce_min(value, device):
+    """Minimum of an integer over ranks (e.g. "every rank's parity check passed")."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
