@@ -306,8 +306,12 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is created at any world size, one included:
+    # barriers, the MAX of the block times and the checksum gather then really go through RCCL
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -368,6 +372,7 @@ def main():
         run(nparity)
         sync()
         t_cpu, n_cpu, ok, bad = 0.0, 0, True, []
+        parity_crcs = []     # of every stream's frame nparity-1: the same at every world size and on every run
         for s_local, gid in enumerate(shard.stream_ids(rank, world, S)):
             ost = oracle.State(w, h)
             # stream 0 of rank 0 goes on to `cpu_frames` frames for the CPU baseline; the comparison is at frame nparity-1
@@ -383,12 +388,15 @@ def main():
                     t_cpu += time.perf_counter() - t0
                     n_cpu += 1
                 if i == nparity - 1:
+                    c = 0
                     for pli in range(3):
                         a = ost.get_plane(oracle.FRAME_PREV, pli)
                         b = states[s_local].read_plane(states[s_local].ref_idx(theora_amd.FRAME_PREV), pli)
+                        c = zlib.crc32(b.tobytes(), c)
                         if not np.array_equal(a, b):
                             ok = False
                             bad.append((gid, pli, int((a != b).sum())))
+                    parity_crcs.append(c)
             ost.close()
         ok_all = shard.reduce_min(1 if ok else 0, torch.device("cuda", local_rank))
         if not ok_all:
@@ -437,7 +445,7 @@ def main():
         elapsed_blocks.append(dt)
         total_t += dt
         step0 += args.steps
-        if world > 1:   # every rank must run the same number of blocks
+        if dist.is_initialized():   # every rank must run the same number of blocks
             total_t = shard.reduce_max([total_t], torch.device("cuda", local_rank))[0]
     # Pass B: steps with every kernel bracketed by HIP events on the stream it runs on -> per-kernel
     # durations for the roofline.  Kept out of pass A because four event records per step cost ~15 % of
@@ -470,6 +478,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     blocks = shard.reduce_max(elapsed_blocks, dev)          # per block: the slowest rank
     _, crcs = shard.reduce_results(0.0, crcs, dev)
+    if nparity:
+        _, parity_crcs = shard.reduce_results(0.0, parity_crcs, dev)
     kms = shard.reduce_max(kms, dev)
     elapsed = float(np.median(blocks))
 
@@ -545,7 +555,9 @@ def main():
             "config": {"workload": "%s (%dx%d coded) 4:2:0, %d concurrent streams per GPU, keyframe interval %d, "
                                    "content class '%s' (seeded fragment command streams resident in HBM), "
                                    "loop filter on (flimit 2)" % (args.size, w, h, S, KF_INTERVAL, args.content),
-                       "streams_per_gpu": S, "frame_pool": args.pool, "parallelism": "stream-sharded x%d" % world},
+                       "streams_per_gpu": S, "frame_pool": args.pool, "parallelism": "stream-sharded x%d" % world,
+                       "process_group": ("nccl (RCCL %s), world %d" % (".".join(map(str, torch.cuda.nccl.version())), world))
+                       if dist.is_initialized() else None},
             "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "statistic": "median block",
                        "ms_per_step_min": round(1e3 * min(blocks) / args.steps, 5),
                        "ms_per_step_max": round(1e3 * max(blocks) / args.steps, 5),
@@ -572,11 +584,12 @@ def main():
         if cpu_baseline:
             out["cpu_baseline"] = cpu_baseline
         if parity:
+            parity["stream_crc32_at_frame_%d" % (nparity - 1)] = ["%08x" % c for c in parity_crcs]
             out["parity"] = parity
         out["stream_crc32"] = ["%08x" % c for c in crcs]
         out["setup_s"] = round(t_gen, 1)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -5,6 +5,9 @@
  *   cc -O2 -pthread -Iinclude examples/decode_bench.c -Ltheora_amd -ltheora_hip -o decode_bench
  *   decode_bench in.ogv <threads> <loops> [--no-output]
  *
+ * The contexts take the node's GPUs in turn (context i on device i mod thip_device_count()): a single
+ * stream stays on one GPU, the batch is spread over all of them.
+ *
  * Every thread decodes the same packets (read once from the Ogg file) `loops` times; the clock
  * runs from a common start line, after every context exists, to the last thread's finish.
  */
@@ -16,6 +19,7 @@
 
 #include "thip_ogg.h"
 #include "theoradec_hip.h"
+#include "theora_hip.h"
 
 typedef struct {
   unsigned char *data;
@@ -97,8 +101,9 @@ int main(int argc, char **argv) {
   worker *w = (worker *)calloc((size_t)nthreads, sizeof(worker));
   pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
   int i;
+  const int ndev = thip_device_count();
   for (i = 0; i < nthreads; i++) {
-    w[i].dec = th_decode_alloc(&ti, ts);
+    w[i].dec = th_decode_alloc_on(&ti, ts, ndev > 0 ? i % ndev : -1);
     if (!w[i].dec) {
       fprintf(stderr, "th_decode_alloc failed for stream %d\n", i);
       return 1;
@@ -125,8 +130,9 @@ int main(int argc, char **argv) {
   clock_gettime(CLOCK_MONOTONIC, &t1);
   const double el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
   printf("{\"streams\": %d, \"host_threads\": %d, \"frames\": %ld, \"seconds\": %.4f, \"frames_per_s\": %.1f, "
-         "\"size\": \"%ux%u\", \"with_ycbcr_out\": %s, \"ok\": %s}\n",
+         "\"size\": \"%ux%u\", \"gpus\": %d, \"with_ycbcr_out\": %s, \"ok\": %s}\n",
          nthreads, nthreads, frames, el, el > 0 ? (double)frames / el : 0.0, (unsigned)ti.frame_width, (unsigned)ti.frame_height,
+         ndev < nthreads ? ndev : nthreads,
          g_output ? "true" : "false", bad ? "false" : "true");
   for (i = 0; i < nthreads; i++) th_decode_free(w[i].dec);
   th_comment_clear(&tc);

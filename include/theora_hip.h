@@ -59,6 +59,15 @@ typedef struct thip_plane_geom {
    side.  frame_width/height are the coded size (multiples of 16), pixel_fmt is
    th_pixel_fmt (codec.h: 0=4:2:0, 2=4:2:2, 3=4:4:4). */
 int thip_state_create(thip_state **out, int frame_width, int frame_height, int pixel_fmt);
+/* The same on HIP device `device` (0 .. hipGetDeviceCount()-1; -1 = the calling thread's current
+   device, which is what thip_state_create uses).  A state lives on its device for life: its frames,
+   staging buffers and library-owned streams are created there and every entry point that takes the
+   state switches to that device for the duration of the call and back, so the states of one process
+   may be spread over all GPUs of a node (a single stream stays on one GPU; streams are sharded whole).
+   thip_decode_frames accepts states of different devices in one call when `stream` is NULL.  */
+int thip_state_create_on(thip_state **out, int device, int frame_width, int frame_height, int pixel_fmt);
+int thip_state_device(const thip_state *st);
+int thip_device_count(void); /* hipGetDeviceCount, 0 when there is none */
 void thip_state_free(thip_state *st);
 int thip_state_get_geom(const thip_state *st, thip_plane_geom geom[3], int64_t *nfrags,
                         int64_t *frame_bytes);

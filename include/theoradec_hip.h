@@ -83,6 +83,11 @@ void th_comment_clear(th_comment *tc);
 /* theoradec.h:234-322 */
 int th_decode_headerin(th_info *info, th_comment *tc, th_setup_info **setup, ogg_packet *op);
 th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup);
+/* Extension (not in theoradec.h): the same with the GPU chosen -- device 0 .. thip_device_count()-1 (theora_hip.h), or -1 for
+   what th_decode_alloc does: the THIP_DEVICE environment variable if set (a device number, or "rr": the
+   contexts of the process take the visible devices in turn), else the calling thread's current device.
+   A context stays on its GPU (a single stream is not split); contexts of one process may use all GPUs. */
+th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, int device);
 void th_setup_free(th_setup_info *setup);
 int th_decode_ctl(th_dec_ctx *dec, int req, void *buf, size_t buf_sz);
 int th_decode_packetin(th_dec_ctx *dec, const ogg_packet *op, int64_t *granpos);

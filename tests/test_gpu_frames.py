@@ -316,3 +316,62 @@ def test_four_concurrent_4k_streams_one_call(hip, content):
         assert hip.decode_frames(gsts, descs) == [0] * S
         for i in range(S):
             assert not util.planes_equal(osts[i], gsts[i]), (f, i)
+
+
+def test_state_on_a_chosen_device(hip):
+    """thip_state_create_on: device -1 = the current device, an explicit device number is honoured and
+    reported by thip_state_device, a device the node does not have is TH_EINVAL; frames decode there."""
+    import ctypes as C
+    from theora_amd import _lib
+    L = _lib.load()
+    n = L.thip_device_count()
+    assert n >= 1
+    h = C.c_void_p()
+    assert L.thip_state_create_on(C.byref(h), n, 64, 48, PF_420) == _lib.EINVAL
+    assert L.thip_state_create_on(C.byref(h), -1, 64, 48, PF_420) == 0
+    assert L.thip_state_device(h) >= 0
+    L.thip_state_free(h)
+    for dev in sorted({0, n - 1}):
+        w, hgt = 176, 144
+        geom = synth.Geometry(w, hgt, PF_420)
+        rng = np.random.default_rng(31 + dev)
+        ost = oracle.State(w, hgt, PF_420)
+        gst = hip.State(w, hgt, PF_420, device=dev)
+        assert gst.device == dev
+        for f in range(4):
+            fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "mixed")
+            util.oracle_apply(ost, fr)
+            if f == 3:      # the slots stage in pinned host memory of the state's device
+                assert util.enqueue_frame(hip, gst, geom, fr) == 0
+            else:
+                import torch
+                with torch.cuda.device(dev):
+                    desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+                hip.decode_frames([gst], [desc])
+            assert not util.planes_equal(ost, gst), (dev, f)
+
+
+def test_streams_spread_over_two_devices_in_one_call(hip):
+    """A batch whose states live on different GPUs of the node in ONE thip_decode_frames call (skipped on a
+    single-GPU box): stream i on device i mod 2, every plane against the oracle."""
+    import torch
+    from theora_amd import _lib
+    if _lib.load().thip_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    w, h, S = 256, 160, 4
+    geom = synth.Geometry(w, h, PF_420)
+    rngs = [np.random.default_rng(900 + i) for i in range(S)]
+    osts = [oracle.State(w, h, PF_420) for _ in range(S)]
+    gsts = [hip.State(w, h, PF_420, device=i % 2) for i in range(S)]
+    for f in range(6):
+        descs, keep = [], []
+        for i in range(S):
+            fr = synth.gen_frame(geom, rngs[i], hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "mixed")
+            util.oracle_apply(osts[i], fr)
+            with torch.cuda.device(i % 2):
+                d, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+            descs.append(d)
+            keep.append(ka)
+        hip.decode_frames(gsts, descs)
+        for i in range(S):
+            assert not util.planes_equal(osts[i], gsts[i]), (f, i)

@@ -77,11 +77,16 @@ def unpack_tiles(tiles, n):
 class State:
     """Device side of one stream (thip_state): three resident frames + the reference ring."""
 
-    def __init__(self, frame_width, frame_height, pixel_fmt=PF_420):
+    def __init__(self, frame_width, frame_height, pixel_fmt=PF_420, device=None):
         self._L = _lib.load()
         h = C.c_void_p()
-        _lib.check(self._L.thip_state_create(C.byref(h), frame_width, frame_height, pixel_fmt),
-                   "thip_state_create")
+        if device is None:      # the calling thread's current HIP device
+            _lib.check(self._L.thip_state_create(C.byref(h), frame_width, frame_height, pixel_fmt),
+                       "thip_state_create")
+        else:
+            _lib.check(self._L.thip_state_create_on(C.byref(h), int(device), frame_width, frame_height, pixel_fmt),
+                       "thip_state_create_on")
+        self.device = self._L.thip_state_device(h)
         self._h = h
         geom = (PlaneGeom * 3)()
         nfrags, fbytes = C.c_int64(), C.c_int64()

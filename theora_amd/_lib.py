@@ -47,6 +47,9 @@ class TheoraHipError(RuntimeError):
 _P, _I, _I64, _U32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
 SYMBOLS = [
     ("thip_state_create", _I, [C.POINTER(_P), _I, _I, _I]),
+    ("thip_state_create_on", _I, [C.POINTER(_P), _I, _I, _I, _I]),
+    ("thip_state_device", _I, [_P]),
+    ("thip_device_count", _I, []),
     ("thip_state_free", None, [_P]),
     ("thip_state_get_geom", _I, [_P, C.POINTER(PlaneGeom), C.POINTER(_I64), C.POINTER(_I64)]),
     ("thip_state_get_tiles", _I, [_P, C.POINTER(TileGeom)]),
@@ -116,6 +119,7 @@ DEC_SYMBOLS = [
     ("th_comment_clear", None, [C.POINTER(ThComment)]),
     ("th_decode_headerin", _I, [C.POINTER(ThInfo), C.POINTER(ThComment), C.POINTER(_P), C.POINTER(OggPacket)]),
     ("th_decode_alloc", _P, [C.POINTER(ThInfo), _P]),
+    ("th_decode_alloc_on", _P, [C.POINTER(ThInfo), _P, _I]),
     ("th_setup_free", None, [_P]),
     ("th_decode_ctl", _I, [_P, _I, _P, C.c_size_t]),
     ("th_decode_packetin", _I, [_P, C.POINTER(OggPacket), C.POINTER(_I64)]),

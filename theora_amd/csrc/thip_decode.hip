@@ -59,6 +59,7 @@ using namespace thip;
 // host side
 // ---------------------------------------------------------------------------------------
 struct thip_state {
+  int device;             // HIP device the frames, the staging buffers and the launches of this state live on
   int frame_width, frame_height, pixel_fmt, hdec, vdec;
   thip_plane_geom geom[3];
   thip_tile_geom tiles;
@@ -99,9 +100,25 @@ std::mutex g_mu;
 // the frames of a stream stay ordered; different lanes let one group's loop filter overlap
 // another group's reconstruction (dependent kernels of one group cannot overlap).
 constexpr int kMaxLanes = 4;
-hipStream_t g_lanes[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
-int g_nlanes = 0;
-int g_next_lane = 0;
+constexpr int kMaxDevices = 16;
+hipStream_t g_lanes[kMaxDevices][kMaxLanes];   // per device, created on first use of that device
+int g_lanes_ready[kMaxDevices];
+int g_nlanes = 0;                              // lanes per device (THIP_LANES, default 2)
+int g_next_lane[kMaxDevices];
+
+// Makes `device` current for the calling host thread for the lifetime of the object (HIP's current
+// device is per thread) and puts the previous one back: a state may live on any GPU of the node
+// whatever the caller's current device is.
+struct DeviceGuard {
+  int prev = -1, want;
+  explicit DeviceGuard(int device) : want(device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != want) (void)hipSetDevice(want);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+  }
+};
 int g_profile = 0;
 const int g_debug = getenv("THIP_DEBUG") ? atoi(getenv("THIP_DEBUG")) : 0;
 struct EvPair { hipEvent_t a, b; int kernel; };
@@ -109,14 +126,16 @@ std::vector<EvPair> g_events;
 std::vector<hipEvent_t> g_pool;
 
 std::mutex g_lanes_mu;
-int ensure_lanes() {   // callable with or without g_mu held, from any host thread
+int ensure_lanes(int device) {   // the device must be current; callable from any host thread
   std::lock_guard<std::mutex> lk(g_lanes_mu);
-  if (g_nlanes) return 0;
+  if (device < 0 || device >= kMaxDevices) return THIP_EINVAL;
+  if (g_lanes_ready[device]) return 0;
   int n = getenv("THIP_LANES") ? atoi(getenv("THIP_LANES")) : 2;
   if (n < 1) n = 1;
   if (n > kMaxLanes) n = kMaxLanes;
-  for (int i = 0; i < n; i++) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[i], hipStreamNonBlocking));
+  for (int i = 0; i < n; i++) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[device][i], hipStreamNonBlocking));
   g_nlanes = n;
+  g_lanes_ready[device] = 1;
   return 0;
 }
 
@@ -208,6 +227,15 @@ extern "C" {
 const char *thip_version_string(void) { return "theora_hip 0.2 (gfx950; libtheora 1.2.0 fragment path)"; }
 
 int thip_state_create(thip_state **out, int frame_width, int frame_height, int pixel_fmt) {
+  return thip_state_create_on(out, -1, frame_width, frame_height, pixel_fmt);
+}
+
+int thip_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int thip_state_create_on(thip_state **out, int device, int frame_width, int frame_height, int pixel_fmt) {
   if (!out) return THIP_EFAULT;
   *out = nullptr;
   // state.c:712-727: coded size must be a positive multiple of 16, format not reserved
@@ -265,6 +293,21 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
             (st->tiles.tile_off[pli] + (by >> 2) * st->tiles.tiles_x[pli] + (bx >> 4)) * THIP_TILE_FRAGS +
             ((bx >> 2) & 3) * 16 + hilb_inv(by & 3, bx & 3);
   }
+  // (everything above is host arithmetic: argument errors are reported with or without a GPU)
+  if (device < 0) {   // the calling thread's current device
+    if (hipGetDevice(&device) != hipSuccess) device = -1;
+  } else if (device >= thip_device_count()) {
+    free(st->frag_pos);
+    free(st);
+    return THIP_EINVAL;
+  }
+  if (device < 0 || device >= kMaxDevices) {
+    free(st->frag_pos);
+    free(st);
+    return device < 0 ? THIP_EFAULT : THIP_EIMPL;
+  }
+  st->device = device;
+  DeviceGuard dg(device);
   hipError_t err = hipSuccess;
   // +256: aligned 12-byte predictor windows may read 3 bytes past a row end
   for (int b = 0; b < 3 && err == hipSuccess; b++) err = hipMalloc((void **)&st->frames[b], st->frame_bytes + 256);
@@ -286,8 +329,11 @@ int thip_state_create(thip_state **out, int frame_width, int frame_height, int p
   return THIP_OK;
 }
 
+int thip_state_device(const thip_state *st) { return st ? st->device : THIP_EFAULT; }
+
 void thip_state_free(thip_state *st) {
   if (!st) return;
+  DeviceGuard dg(st->device);
   (void)hipDeviceSynchronize();
   for (int b = 0; b < 3; b++)
     if (st->frames[b]) (void)hipFree(st->frames[b]);
@@ -354,6 +400,7 @@ int thip_state_read_plane(thip_state *st, int bufi, int pli, uint8_t *host_out) 
   if (!st || !host_out) return THIP_EFAULT;
   if (bufi < 0 || bufi > 2 || pli < 0 || pli > 2) return THIP_EINVAL;
   const thip_plane_geom &g = st->geom[pli];
+  DeviceGuard dg(st->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy2D(host_out, g.width, st->frames[bufi] + g.plane_off, g.stride, g.width, g.height,
                       hipMemcpyDeviceToHost));
@@ -364,6 +411,7 @@ int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *hos
   if (!st || !host_in) return THIP_EFAULT;
   if (bufi < 0 || bufi > 2 || pli < 0 || pli > 2) return THIP_EINVAL;
   const thip_plane_geom &g = st->geom[pli];
+  DeviceGuard dg(st->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy2D(st->frames[bufi] + g.plane_off, g.stride, host_in, g.width, g.width, g.height,
                       hipMemcpyHostToDevice));
@@ -453,6 +501,7 @@ int thip_state_set_eager_output(thip_state *st, int on) {
 int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strides[3]) {
   if (!st || !planes || !strides) return THIP_EFAULT;
   if (st->last_decoded < 0) return THIP_EINVAL;
+  DeviceGuard dg(st->device);
   if (st->out_serial != st->frame_serial) {   // not copied yet (no eager output, or the frame came from write_plane)
     const int rc = launch_frame_out(st, st->last_stream);
     if (rc < 0) return rc;
@@ -484,7 +533,11 @@ int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t ds
 }
 
 int thip_synchronize(void) {
-  for (int i = 0; i < g_nlanes; i++) HIP_TRY(hipStreamSynchronize(g_lanes[i]));
+  for (int d = 0; d < kMaxDevices; d++) {
+    if (!g_lanes_ready[d]) continue;
+    DeviceGuard dg(d);
+    for (int i = 0; i < g_nlanes; i++) HIP_TRY(hipStreamSynchronize(g_lanes[d][i]));
+  }
   return THIP_OK;
 }
 
@@ -678,55 +731,84 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   return THIP_OK;
 }
 
+// What launch_chunk would refuse, checked for the whole call before anything is launched or any
+// state is advanced: a bad descriptor in stream 11 must not leave streams 0..7 one frame ahead.
+static int validate_frames(thip_state *const *states, const thip_frame_desc *descs, int n) {
+  for (int i = 0; i < n; i++) {
+    const thip_state *st = states[i];
+    const thip_frame_desc &d = descs[i];
+    if (!st) return THIP_EFAULT;
+    if (d.ncoded < 0 || d.nslots < 0 || d.nslots > d.ncoded || d.ncoded > st->nfrags) return THIP_EINVAL;
+    if (d.ncoded && (!d.frag_info || !d.tile_slot0 || (d.nslots && !d.coeffs))) return THIP_EFAULT;
+    if (d.flimit < 0 || d.flimit > 127) return THIP_EINVAL;
+    if (d.frame_type != THIP_INTRA_FRAME && d.frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
+    if (d.frame_type == THIP_INTRA_FRAME && d.ncoded != st->nfrags) return THIP_EINVAL;
+    for (int j = 0; j < i; j++)
+      if (states[j] == st) return THIP_EINVAL;   // one frame per stream per call
+  }
+  return THIP_OK;
+}
+
 int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, int nstreams,
                        void *stream, int32_t *results) {
   if (!states || !descs) return THIP_EFAULT;
   if (nstreams < 0) return THIP_EINVAL;
+  int rc = validate_frames(states, descs, nstreams);
+  if (rc < 0) return rc;
   // No library-wide lock around the launches: a state belongs to the calling thread, the HIP
   // runtime is thread safe, and contexts on different host threads must not queue behind each
   // other here.  Only the lane assignment is shared.
-  if (stream) {   // caller-owned stream: everything in submission order on it
+  if (stream) {   // caller-owned stream: everything in submission order on it, all states on its device
     hipStream_t s = (hipStream_t)stream;
+    for (int i = 1; i < nstreams; i++)
+      if (states[i]->device != states[0]->device) return THIP_EINVAL;
+    if (!nstreams) return THIP_OK;
+    DeviceGuard dg(states[0]->device);
     for (int i = 0; i < nstreams; i += THIP_MAX_BATCH) {
       const int n = nstreams - i < THIP_MAX_BATCH ? nstreams - i : THIP_MAX_BATCH;
-      int rc = launch_chunk(states + i, descs + i, n, s, results ? results + i : nullptr);
+      rc = launch_chunk(states + i, descs + i, n, s, results ? results + i : nullptr);
       if (rc < 0) return rc;
     }
     return THIP_OK;
   }
-  int rc = ensure_lanes();
-  if (rc) return rc;
-  for (int i = 0; i < nstreams; i++) {
-    if (!states[i]) return THIP_EFAULT;
-    if (states[i]->lane < 0) {
-      std::lock_guard<std::mutex> lk(g_mu);
-      states[i]->lane = g_next_lane++ % g_nlanes;
-    }
-  }
-  // group by lane (order inside a lane preserved), launch chunk by chunk (THIP_CHUNK: streams per launch)
+  // group by device, then by lane (order inside a lane preserved), launch chunk by chunk
+  // (THIP_CHUNK: streams per launch)
   static const int chunk_max = [] {
     const int v = getenv("THIP_CHUNK") ? atoi(getenv("THIP_CHUNK")) : THIP_MAX_BATCH;
     return v < 1 ? 1 : (v > THIP_MAX_BATCH ? THIP_MAX_BATCH : v);
   }();
-  for (int lane = 0; lane < g_nlanes; lane++) {
-    thip_state *ls[THIP_MAX_BATCH];
-    thip_frame_desc ld[THIP_MAX_BATCH];
-    int32_t lr[THIP_MAX_BATCH];
-    int li[THIP_MAX_BATCH];
-    int n = 0;
-    for (int i = 0; i <= nstreams; i++) {
-      if (i < nstreams && states[i]->lane == lane) {
-        ls[n] = states[i];
-        ld[n] = descs[i];
-        li[n] = i;
-        n++;
+  uint32_t devmask = 0;
+  for (int i = 0; i < nstreams; i++) devmask |= 1u << states[i]->device;
+  for (int dev = 0; dev < kMaxDevices; dev++) {
+    if (!(devmask >> dev & 1u)) continue;
+    DeviceGuard dg(dev);
+    rc = ensure_lanes(dev);
+    if (rc) return rc;
+    for (int i = 0; i < nstreams; i++)
+      if (states[i]->device == dev && states[i]->lane < 0) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        states[i]->lane = g_next_lane[dev]++ % g_nlanes;
       }
-      if (n == chunk_max || (i == nstreams && n > 0)) {
-        rc = launch_chunk(ls, ld, n, g_lanes[lane], lr);
-        if (rc < 0) return rc;
-        if (results)
-          for (int k = 0; k < n; k++) results[li[k]] = lr[k];
-        n = 0;
+    for (int lane = 0; lane < g_nlanes; lane++) {
+      thip_state *ls[THIP_MAX_BATCH];
+      thip_frame_desc ld[THIP_MAX_BATCH];
+      int32_t lr[THIP_MAX_BATCH];
+      int li[THIP_MAX_BATCH];
+      int n = 0;
+      for (int i = 0; i <= nstreams; i++) {
+        if (i < nstreams && states[i]->device == dev && states[i]->lane == lane) {
+          ls[n] = states[i];
+          ld[n] = descs[i];
+          li[n] = i;
+          n++;
+        }
+        if (n == chunk_max || (i == nstreams && n > 0)) {
+          rc = launch_chunk(ls, ld, n, g_lanes[dev][lane], lr);
+          if (rc < 0) return rc;
+          if (results)
+            for (int k = 0; k < n; k++) results[li[k]] = lr[k];
+          n = 0;
+        }
       }
     }
   }
@@ -770,6 +852,7 @@ static int ensure_staging(thip_state *st) {
 int thip_frame_begin(thip_state *st, int frame_type) {
   if (!st) return THIP_EFAULT;
   if (frame_type != THIP_INTRA_FRAME && frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
+  DeviceGuard dg(st->device);
   int rc = ensure_staging(st);
   if (rc) return rc;
   // the previous frame's kernels must have read the staging buffers before they are reused;
@@ -890,13 +973,14 @@ int thip_frame_flush(thip_state *st) {
   st->enq_active = 0;
   // every fragment must have been reconstructed or copied exactly once
   if (st->enq_ncoded && (int64_t)st->enq_ncoded + st->enq_nuncoded != st->nfrags) return THIP_EINVAL;
-  int rc = ensure_lanes();
+  DeviceGuard dg(st->device);
+  int rc = ensure_lanes(st->device);
   if (rc) return rc;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (st->lane < 0) st->lane = g_next_lane++ % g_nlanes;
+    if (st->lane < 0) st->lane = g_next_lane[st->device]++ % g_nlanes;
   }
-  hipStream_t s = g_lanes[st->lane];
+  hipStream_t s = g_lanes[st->device][st->lane];
   const size_t ngroups = ((size_t)st->enq_nslots + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
   static const int zerocopy = getenv("THIP_ZEROCOPY") ? atoi(getenv("THIP_ZEROCOPY")) : 1;
   if (st->enq_ncoded && !zerocopy) {

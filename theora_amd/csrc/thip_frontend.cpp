@@ -17,6 +17,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -919,8 +920,20 @@ int th_decode_headerin(th_info *info, th_comment *tc, th_setup_info **setup, ogg
 
 void th_setup_free(th_setup_info *setup) { delete setup; }
 
-th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup) {
+th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup) { return th_decode_alloc_on(info, setup, -1); }
+
+th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, int device) {
   if (!info || !setup) return nullptr;
+  if (device < 0) {
+    const char *e = getenv("THIP_DEVICE");
+    if (e && !strcmp(e, "rr")) {
+      static std::atomic<unsigned> next{0};
+      const int n = thip_device_count();
+      device = n > 0 ? (int)(next.fetch_add(1) % (unsigned)n) : -1;
+    } else if (e && *e) {
+      device = atoi(e);
+    }
+  }
   if ((info->frame_width & 15) || (info->frame_height & 15) || !info->frame_width || !info->frame_height ||
       info->pixel_fmt == TH_PF_RSVD || (int)info->pixel_fmt < 0 || (int)info->pixel_fmt > 3)
     return nullptr;
@@ -931,7 +944,7 @@ th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup) {
   d->trace = getenv("THIP_FE_TRACE_BACKEND") != nullptr && atoi(getenv("THIP_FE_TRACE_BACKEND")) != 0;
   d->tr_flimit = 0;
   if (!d->trace &&
-      thip_state_create(&d->hip, (int)info->frame_width, (int)info->frame_height, (int)info->pixel_fmt) < 0) {
+      thip_state_create_on(&d->hip, device, (int)info->frame_width, (int)info->frame_height, (int)info->pixel_fmt) < 0) {
     delete d;
     return nullptr;
   }

@@ -29,7 +29,7 @@ def _packet(data, bos=0, packetno=0):
 class Decoder:
     """th_decode_headerin x3 -> th_decode_alloc -> {th_decode_packetin, th_decode_ycbcr_out}*."""
 
-    def __init__(self, header_packets):
+    def __init__(self, header_packets, device=None):
         L = self._L = _lib.load()
         self.info = ThInfo()
         self.comment = ThComment()
@@ -41,7 +41,8 @@ class Decoder:
             rc = L.th_decode_headerin(C.byref(self.info), C.byref(self.comment), C.byref(setup), C.byref(op))
             if rc <= 0:
                 raise TheoraHipError("th_decode_headerin(packet %d) returned %d" % (k, rc))
-        self._dec = L.th_decode_alloc(C.byref(self.info), setup)
+        self._dec = (L.th_decode_alloc(C.byref(self.info), setup) if device is None
+                     else L.th_decode_alloc_on(C.byref(self.info), setup, int(device)))
         L.th_setup_free(setup)
         if not self._dec:
             raise TheoraHipError("th_decode_alloc failed")

@@ -23,13 +23,15 @@ def stream_seed(base_seed, stream_id):
 
 
 def barrier(world):
-    if world > 1:
+    """Barrier over the ranks; a process group of one rank (torchrun --nproc-per-node 1) still goes
+    through the backend, so that the collective path is exercised on a single-GPU box too."""
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
 
 
 def reduce_results(elapsed, per_stream_values, device):
     """(max elapsed over ranks, values of all streams in global stream order)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(elapsed), [int(v) for v in per_stream_values]
     world = dist.get_world_size()
     t = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
@@ -41,7 +43,7 @@ def reduce_results(elapsed, per_stream_values, device):
 
 
 def reduce_max(values, device):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return [float(v) for v in values]
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -50,7 +52,7 @@ def reduce_max(values, device):
 
 def reduce_min(value, device):
     """Minimum of an integer over ranks (e.g. "every rank's parity check passed")."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
