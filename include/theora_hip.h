@@ -264,6 +264,45 @@ int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n);
 int thip_enc_quantize_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t *dequant,
                             int64_t n);
 
+/* oc_enc_enquant_table_init / _fixup (encint.h:316-318, enquant.c:194-217): HOST functions, as in the
+   reference -- the tables are built when the quantisation parameters change.  `enquant` is 64 entries
+   of {int16 m, int16 l} (oc_iquant), THIP_ENQUANT_TABLE_SIZE bytes; thip_enc_opt_data reports what
+   oc_enc_opt_data carries (encint.h:331-338). */
+#define THIP_ENQUANT_TABLE_SIZE 256
+void thip_enc_enquant_table_init(void *enquant, const uint16_t dequant[64]);
+void thip_enc_enquant_table_fixup(void *enquant[3][3][2], int nqis);
+void thip_enc_opt_data(size_t *enquant_table_size, int *enquant_table_alignment);
+/* oc_enc_quantize with the table the slot receives (encint.h:319-320): dequant and enquant are DEVICE
+   copies of one 64-entry table each, built once and reused by every launch. */
+int thip_enc_quantize_tab_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t *dequant,
+                                const void *enquant, int64_t n);
+
+/* ------------------------------------------------------------------------------------
+ * The single-block slots of oc_enc_opt_vtable (encint.h:292-326) with the reference's signatures:
+ * HOST pointers, one 8x8 block per call, each bound to a one-element batch of the kernels above.
+ * oc_enc_accel_init_hip fills the vtable with these; they exist so that every
+ * slot can be compared with its C original at the encoder's own call sites -- throughput comes from the
+ * batch entry points.  (enquant_table_init / _fixup: above.)
+ * ---------------------------------------------------------------------------------- */
+void thip_enc1_frag_sub(int16_t diff[64], const unsigned char *src, const unsigned char *ref, int ystride);
+void thip_enc1_frag_sub_128(int16_t diff[64], const unsigned char *src, int ystride);
+unsigned thip_enc1_frag_sad(const unsigned char *src, const unsigned char *ref, int ystride);
+unsigned thip_enc1_frag_sad_thresh(const unsigned char *src, const unsigned char *ref, int ystride, unsigned thresh);
+unsigned thip_enc1_frag_sad2_thresh(const unsigned char *src, const unsigned char *ref1, const unsigned char *ref2,
+                                    int ystride, unsigned thresh);
+unsigned thip_enc1_frag_intra_sad(const unsigned char *src, int ystride);
+unsigned thip_enc1_frag_satd(int *dc, const unsigned char *src, const unsigned char *ref, int ystride);
+unsigned thip_enc1_frag_satd2(int *dc, const unsigned char *src, const unsigned char *ref1, const unsigned char *ref2,
+                              int ystride);
+unsigned thip_enc1_frag_intra_satd(int *dc, const unsigned char *src, int ystride);
+unsigned thip_enc1_frag_ssd(const unsigned char *src, const unsigned char *ref, int ystride);
+unsigned thip_enc1_frag_border_ssd(const unsigned char *src, const unsigned char *ref, int ystride, int64_t mask);
+void thip_enc1_frag_copy2(unsigned char *dst, const unsigned char *src1, const unsigned char *src2, int ystride);
+int thip_enc1_quantize(int16_t qdct[64], const int16_t dct[64], const uint16_t dequant[64], const void *enquant);
+void thip_enc1_frag_recon_intra(unsigned char *dst, int ystride, const int16_t residue[64]);
+void thip_enc1_frag_recon_inter(unsigned char *dst, const unsigned char *src, int ystride, const int16_t residue[64]);
+void thip_enc1_fdct8x8(int16_t y[64], const int16_t x[64]);
+
 /* ------------------------------------------------------------------------------------
  * Measurement support for bench.py: HIP-event timing of the kernels of
  * thip_decode_frames on the stream they run on.

@@ -88,6 +88,17 @@ def lib():
     L.orc_enc_frag_copy2.argtypes = [P, P, P, C.c_int]
     L.orc_enc_frag_border_ssd.restype = C.c_uint
     L.orc_enc_frag_border_ssd.argtypes = [P, P, C.c_int, C.c_int64]
+    # the single-block encoder slots (tests/test_gpu_slots.py compares thip_enc1_* with them one call at a time)
+    U = C.c_uint
+    for name, res, args in (("orc_enc_frag_sad", U, [P, P, C.c_int]), ("orc_enc_frag_sad_thresh", U, [P, P, C.c_int, U]),
+                            ("orc_enc_frag_sad2_thresh", U, [P, P, P, C.c_int, U]), ("orc_enc_frag_intra_sad", U, [P, C.c_int]),
+                            ("orc_enc_frag_satd", U, [P, P, P, C.c_int]), ("orc_enc_frag_satd2", U, [P, P, P, P, C.c_int]),
+                            ("orc_enc_frag_intra_satd", U, [P, P, C.c_int]), ("orc_enc_frag_ssd", U, [P, P, C.c_int]),
+                            ("orc_enc_fdct8x8", None, [P, P]), ("orc_enc_enquant_table_init", None, [P, P]),
+                            ("orc_enc_quantize", C.c_int, [P, P, P, P])):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
     _lib = L
     return L
 

@@ -74,3 +74,59 @@ int oc_hip_map(oc_theora_state *_state, const unsigned char *planes[3], int32_t 
   if (thip_state_set_eager_output(_state->hip, 1) < 0) return -1;
   return thip_state_ycbcr_map(_state->hip, planes, strides);
 }
+
+/* ---- lib/hip/hipenc.c: oc_enc_accel_init_hip (cf. lib/x86/x86enc.c:21-62) ----
+   stand-in for the encoder context: the vtable and data of encint.h:292-338 */
+typedef int64_t ogg_int64_t;
+typedef struct {
+  void (*frag_sub)(ogg_int16_t _diff[64], const unsigned char *_src, const unsigned char *_ref, int _ystride);
+  void (*frag_sub_128)(ogg_int16_t _diff[64], const unsigned char *_src, int _ystride);
+  unsigned (*frag_sad)(const unsigned char *_src, const unsigned char *_ref, int _ystride);
+  unsigned (*frag_sad_thresh)(const unsigned char *_src, const unsigned char *_ref, int _ystride, unsigned _thresh);
+  unsigned (*frag_sad2_thresh)(const unsigned char *_src, const unsigned char *_ref1, const unsigned char *_ref2, int _ystride,
+                               unsigned _thresh);
+  unsigned (*frag_intra_sad)(const unsigned char *_src, int _ystride);
+  unsigned (*frag_satd)(int *_dc, const unsigned char *_src, const unsigned char *_ref, int _ystride);
+  unsigned (*frag_satd2)(int *_dc, const unsigned char *_src, const unsigned char *_ref1, const unsigned char *_ref2, int _ystride);
+  unsigned (*frag_intra_satd)(int *_dc, const unsigned char *_src, int _ystride);
+  unsigned (*frag_ssd)(const unsigned char *_src, const unsigned char *_ref, int _ystride);
+  unsigned (*frag_border_ssd)(const unsigned char *_src, const unsigned char *_ref, int _ystride, ogg_int64_t _mask);
+  void (*frag_copy2)(unsigned char *_dst, const unsigned char *_src1, const unsigned char *_src2, int _ystride);
+  void (*enquant_table_init)(void *_enquant, const ogg_uint16_t _dequant[64]);
+  void (*enquant_table_fixup)(void *_enquant[3][3][2], int _nqis);
+  int (*quantize)(ogg_int16_t _qdct[64], const ogg_int16_t _dct[64], const ogg_uint16_t _dequant[64], const void *_enquant);
+  void (*frag_recon_intra)(unsigned char *_dst, int _ystride, const ogg_int16_t _residue[64]);
+  void (*frag_recon_inter)(unsigned char *_dst, const unsigned char *_src, int _ystride, const ogg_int16_t _residue[64]);
+  void (*fdct8x8)(ogg_int16_t _y[64], const ogg_int16_t _x[64]);
+} oc_enc_opt_vtable;
+typedef struct {
+  size_t enquant_table_size;
+  int enquant_table_alignment;
+} oc_enc_opt_data;
+typedef struct {
+  oc_enc_opt_vtable opt_vtable;
+  oc_enc_opt_data opt_data;
+} oc_enc_ctx;
+
+void oc_enc_accel_init_hip(oc_enc_ctx *_enc) {
+  /* every slot keeps the reference's signature: the function pointers are assigned without a cast */
+  _enc->opt_vtable.frag_sub = thip_enc1_frag_sub;
+  _enc->opt_vtable.frag_sub_128 = thip_enc1_frag_sub_128;
+  _enc->opt_vtable.frag_sad = thip_enc1_frag_sad;
+  _enc->opt_vtable.frag_sad_thresh = thip_enc1_frag_sad_thresh;
+  _enc->opt_vtable.frag_sad2_thresh = thip_enc1_frag_sad2_thresh;
+  _enc->opt_vtable.frag_intra_sad = thip_enc1_frag_intra_sad;
+  _enc->opt_vtable.frag_satd = thip_enc1_frag_satd;
+  _enc->opt_vtable.frag_satd2 = thip_enc1_frag_satd2;
+  _enc->opt_vtable.frag_intra_satd = thip_enc1_frag_intra_satd;
+  _enc->opt_vtable.frag_ssd = thip_enc1_frag_ssd;
+  _enc->opt_vtable.frag_border_ssd = thip_enc1_frag_border_ssd;
+  _enc->opt_vtable.frag_copy2 = thip_enc1_frag_copy2;
+  _enc->opt_vtable.enquant_table_init = thip_enc_enquant_table_init;
+  _enc->opt_vtable.enquant_table_fixup = thip_enc_enquant_table_fixup;
+  _enc->opt_vtable.quantize = thip_enc1_quantize;
+  _enc->opt_vtable.frag_recon_intra = thip_enc1_frag_recon_intra;
+  _enc->opt_vtable.frag_recon_inter = thip_enc1_frag_recon_inter;
+  _enc->opt_vtable.fdct8x8 = thip_enc1_fdct8x8;
+  thip_enc_opt_data(&_enc->opt_data.enquant_table_size, &_enc->opt_data.enquant_table_alignment);
+}

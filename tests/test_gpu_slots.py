@@ -284,3 +284,143 @@ def test_enc_chain_on_a_caller_stream(hip):
         L.thip_set_batch_stream(None, 1)
     assert np.array_equal(q.cpu().numpy(), want_q) and np.array_equal(nz.cpu().numpy(), want_nz)
     assert np.array_equal(dct.cpu().numpy(), want_dct)
+
+
+def test_enc_enquant_table_slots_and_table_fed_quantiser(hip):
+    """oc_enc_enquant_table_init / _fixup (enquant.c:194-217) as host slots, and oc_enc_quantize fed with the
+    table they build (encint.h:316-320): equal to the oracle and to the batch that derives the table itself."""
+    import ctypes as C
+    import torch
+    from theora_amd import _lib
+    L, O = _lib.load(), oracle.lib()
+    rng = np.random.default_rng(21)
+    size, align = C.c_size_t(), C.c_int()
+    L.thip_enc_opt_data(C.byref(size), C.byref(align))
+    assert size.value == 256 and align.value == 16
+    for trial in range(5):
+        dq = (np.full(64, [8, 4096][trial], np.uint16) if trial < 2 else rng.integers(8, 4097, 64).astype(np.uint16))
+        tab = np.zeros(128, np.int16)
+        want_tab = np.zeros(128, np.int16)
+        L.thip_enc_enquant_table_init(tab.ctypes.data, dq.ctypes.data)
+        O.orc_enc_enquant_table_init(want_tab.ctypes.data, dq.ctypes.data)
+        assert np.array_equal(tab, want_tab), trial
+        n = 4000
+        dct = rng.integers(-32768, 32768, (n, 64)).astype(np.int16)
+        want_q, want_nz = oracle.quantize_batch(dct, dq)
+        q = torch.empty((n, 64), dtype=torch.int16, device="cuda")
+        nz = torch.empty(n, dtype=torch.int32, device="cuda")
+        assert L.thip_enc_quantize_tab_batch(q.data_ptr(), nz.data_ptr(), dev(dct).data_ptr(), dev(dq).data_ptr(),
+                                             dev(tab).data_ptr(), n) == 0
+        assert np.array_equal(want_q, q.cpu().numpy()) and np.array_equal(want_nz, nz.cpu().numpy()), trial
+    # fixup: the tables of qii > 0 become copies of qii = 0's first entry pair (enquant.c:210-217 copies one oc_iquant)
+    tabs = [[[np.full(128, 100 * p + 10 * q + t, np.int16) for t in range(2)] for q in range(3)] for p in range(3)]
+    arr = (C.c_void_p * 18)(*[tabs[p][q][t].ctypes.data for p in range(3) for q in range(3) for t in range(2)])
+    L.thip_enc_enquant_table_fixup(arr, 3)
+    for p in range(3):
+        for q in range(3):
+            for t in range(2):
+                want = np.full(128, 100 * p + 10 * q + t, np.int16)
+                if q > 0:
+                    want[:2] = 100 * p + t
+                assert np.array_equal(tabs[p][q][t], want)
+
+
+def test_enc_single_block_slots(hip):
+    """The oc_enc_opt_vtable slots with the reference's own signatures (host pointers, one block per call:
+    thip_enc1_*, what oc_enc_accel_init_hip binds) against their C originals as restated by the oracle."""
+    import ctypes as C
+    from theora_amd import _lib
+    L, O = _lib.load(), oracle.lib()
+    rng = np.random.default_rng(22)
+    stride = 40
+    for trial in range(12):
+        src = rng.integers(0, 256, (16, stride)).astype(np.uint8)
+        ref = np.clip(src.astype(np.int32) + rng.integers(-30, 31, src.shape), 0, 255).astype(np.uint8)
+        ref2 = rng.integers(0, 256, (16, stride)).astype(np.uint8)
+        if trial == 0:
+            src[:] = 255
+            ref[:] = 0
+        ps, pr, pr2 = src.ctypes.data + 3 * stride + 5, ref.ctypes.data + 2 * stride + 7, ref2.ctypes.data + 4 * stride + 1
+        a, b = np.zeros(64, np.int16), np.zeros(64, np.int16)
+        L.thip_enc1_frag_sub(a.ctypes.data, ps, pr, stride)
+        O.orc_enc_frag_sub(b.ctypes.data, ps, pr, stride)
+        assert np.array_equal(a, b)
+        L.thip_enc1_frag_sub_128(a.ctypes.data, ps, stride)
+        O.orc_enc_frag_sub_128(b.ctypes.data, ps, stride)
+        assert np.array_equal(a, b)
+        assert L.thip_enc1_frag_sad(ps, pr, stride) == O.orc_enc_frag_sad(ps, pr, stride)
+        for th in (0, 500, 1 << 30):
+            assert L.thip_enc1_frag_sad_thresh(ps, pr, stride, th) == O.orc_enc_frag_sad_thresh(ps, pr, stride, th)
+            assert L.thip_enc1_frag_sad2_thresh(ps, pr, pr2, stride, th) == O.orc_enc_frag_sad2_thresh(ps, pr, pr2, stride, th)
+        assert L.thip_enc1_frag_intra_sad(ps, stride) == O.orc_enc_frag_intra_sad(ps, stride)
+        d1, d2 = C.c_int(), C.c_int()
+        assert L.thip_enc1_frag_satd(C.byref(d1), ps, pr, stride) == O.orc_enc_frag_satd(C.byref(d2), ps, pr, stride)
+        assert d1.value == d2.value
+        assert L.thip_enc1_frag_satd2(C.byref(d1), ps, pr, pr2, stride) == O.orc_enc_frag_satd2(C.byref(d2), ps, pr, pr2, stride)
+        assert d1.value == d2.value
+        assert L.thip_enc1_frag_intra_satd(C.byref(d1), ps, stride) == O.orc_enc_frag_intra_satd(C.byref(d2), ps, stride)
+        assert d1.value == d2.value
+        assert L.thip_enc1_frag_ssd(ps, pr, stride) == O.orc_enc_frag_ssd(ps, pr, stride)
+        mask = int(rng.integers(-2 ** 63, 2 ** 63, dtype=np.int64))
+        assert L.thip_enc1_frag_border_ssd(ps, pr, stride, mask) == O.orc_enc_frag_border_ssd(ps, pr, stride, mask)
+        o1, o2 = np.zeros((8, stride), np.uint8), np.zeros((8, stride), np.uint8)
+        L.thip_enc1_frag_copy2(o1.ctypes.data + 2, pr, pr2, stride)
+        O.orc_enc_frag_copy2(o2.ctypes.data + 2, pr, pr2, stride)
+        assert np.array_equal(o1, o2)
+        x = rng.integers(-255, 256, 64).astype(np.int16)
+        L.thip_enc1_fdct8x8(a.ctypes.data, x.ctypes.data)
+        O.orc_enc_fdct8x8(b.ctypes.data, x.ctypes.data)
+        assert np.array_equal(a, b)
+        dq = rng.integers(8, 2000, 64).astype(np.uint16)
+        tab = np.zeros(128, np.int16)
+        L.thip_enc_enquant_table_init(tab.ctypes.data, dq.ctypes.data)
+        qa, qb = np.zeros(64, np.int16), np.zeros(64, np.int16)
+        assert L.thip_enc1_quantize(qa.ctypes.data, a.ctypes.data, dq.ctypes.data, tab.ctypes.data) == \
+            O.orc_enc_quantize(qb.ctypes.data, b.ctypes.data, dq.ctypes.data, tab.ctypes.data)
+        assert np.array_equal(qa, qb)
+        res = rng.integers(-300, 301, 64).astype(np.int16)
+        L.thip_enc1_frag_recon_intra(o1.ctypes.data + 1, stride, res.ctypes.data)
+        O.orc_frag_recon_intra(o2.ctypes.data + 1, stride, res.ctypes.data)
+        assert np.array_equal(o1, o2)
+        L.thip_enc1_frag_recon_inter(o1.ctypes.data + 9, pr, stride, res.ctypes.data)
+        O.orc_frag_recon_inter(o2.ctypes.data + 9, pr, stride, res.ctypes.data)
+        assert np.array_equal(o1, o2)
+
+
+def test_enc_kernels_at_config5_size(hip):
+    """BASELINE.json config 5 at its stated size: 1920x1088 4:4:4 (97 920 blocks per frame), the forward DCT
+    and the quantiser over every block, SAD / SATD / SATD2 / intra-SATD over the 9-site square pattern of
+    mcenc.c:50-53 (881 280 (block, candidate) pairs), all on the GPU; the oracle checks a 30 000-element
+    prefix AND a strided sample across the whole batch of each."""
+    import torch
+    W, H, planes = 1920, 1088, 3
+    rng = np.random.default_rng(7)
+    prev = rng.integers(0, 256, (H * planes + 16, W + 16)).astype(np.uint8)
+    cur = np.roll(prev, (1, 3), (0, 1))
+    cur = np.clip(cur.astype(np.int32) + rng.integers(-6, 7, cur.shape), 0, 255).astype(np.uint8)
+    stride = prev.shape[1]
+    by, bx = np.mgrid[0:H * planes // 8, 0:W // 8]
+    base = ((by * 8 + 8) * stride + bx * 8 + 8).reshape(-1).astype(np.int32)
+    sites = [(0, 0), (-1, -1), (0, -1), (1, -1), (-1, 0), (1, 0), (-1, 1), (0, 1), (1, 1)]
+    src_offs = np.tile(base, len(sites))
+    ref_offs = np.concatenate([base + dy * stride + dx for dx, dy in sites]).astype(np.int32)
+    ref2_offs = (ref_offs + 1).astype(np.int32)
+    nblk = base.size
+    assert nblk == 3 * 32640 and src_offs.size == 9 * nblk
+    resid = rng.integers(-255, 256, (nblk, 64)).astype(np.int16)
+    sample = np.unique(np.concatenate([np.arange(30000), np.arange(0, nblk, 37), [nblk - 1]]))
+    got = hip.fdct8x8_batch(dev(resid)).cpu().numpy().reshape(-1, 64)
+    assert np.array_equal(got[sample], oracle.fdct8x8_batch(resid[sample]))
+    dq = np.clip(np.arange(64) * 3 + 16, 8, 4096).astype(np.uint16)
+    gq, gnz = hip.enc_quantize_batch(dev(got), dev(dq))
+    wq, wnz = oracle.quantize_batch(got[sample], dq)
+    assert np.array_equal(gq.cpu().numpy().reshape(-1, 64)[sample], wq) and np.array_equal(gnz.cpu().numpy()[sample], wnz)
+    d_prev, d_cur = dev(prev), dev(cur)
+    d_so, d_ro, d_r2 = dev(src_offs), dev(ref_offs), dev(ref2_offs)
+    msample = np.unique(np.concatenate([np.arange(30000), np.arange(0, src_offs.size, 97), [src_offs.size - 1]]))
+    for op in ("sad", "satd", "satd2", "intra_satd"):
+        v, dc = hip.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)
+        wv, wdc = oracle.enc_metric_batch(op, cur, prev, stride, src_offs[msample], ref_offs[msample], ref2_offs[msample], 0)
+        assert np.array_equal(v.cpu().numpy().view(np.uint32)[msample], wv), op
+        if "satd" in op:
+            assert np.array_equal(dc.cpu().numpy()[msample], wdc), op

@@ -80,6 +80,26 @@ SYMBOLS = [
     ("thip_enc_frag_copy2_batch", _I, [_P, _P, _I, _P, _P, _P, _I64]),
     ("thip_set_batch_stream", _I, [_P, _I]),
     ("thip_enc_fdct8x8_batch", _I, [_P, _P, _I64]),
+    ("thip_enc_enquant_table_init", None, [_P, _P]),
+    ("thip_enc_enquant_table_fixup", None, [_P, _I]),
+    ("thip_enc_opt_data", None, [C.POINTER(C.c_size_t), C.POINTER(_I)]),
+    ("thip_enc_quantize_tab_batch", _I, [_P, _P, _P, _P, _P, _I64]),
+    ("thip_enc1_frag_sub", None, [_P, _P, _P, _I]),
+    ("thip_enc1_frag_sub_128", None, [_P, _P, _I]),
+    ("thip_enc1_frag_sad", _U32, [_P, _P, _I]),
+    ("thip_enc1_frag_sad_thresh", _U32, [_P, _P, _I, _U32]),
+    ("thip_enc1_frag_sad2_thresh", _U32, [_P, _P, _P, _I, _U32]),
+    ("thip_enc1_frag_intra_sad", _U32, [_P, _I]),
+    ("thip_enc1_frag_satd", _U32, [C.POINTER(_I), _P, _P, _I]),
+    ("thip_enc1_frag_satd2", _U32, [C.POINTER(_I), _P, _P, _P, _I]),
+    ("thip_enc1_frag_intra_satd", _U32, [C.POINTER(_I), _P, _I]),
+    ("thip_enc1_frag_ssd", _U32, [_P, _P, _I]),
+    ("thip_enc1_frag_border_ssd", _U32, [_P, _P, _I, _I64]),
+    ("thip_enc1_frag_copy2", None, [_P, _P, _P, _I]),
+    ("thip_enc1_quantize", _I, [_P, _P, _P, _P]),
+    ("thip_enc1_frag_recon_intra", None, [_P, _I, _P]),
+    ("thip_enc1_frag_recon_inter", None, [_P, _P, _I, _P]),
+    ("thip_enc1_fdct8x8", None, [_P, _P]),
     ("thip_enc_quantize_batch", _I, [_P, _P, _P, _P, _I64]),
     ("thip_profile_enable", _I, [_I]),
     ("thip_profile_read", _I, [C.POINTER(_I64), C.POINTER(C.c_double)]),

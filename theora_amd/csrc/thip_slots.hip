@@ -8,6 +8,7 @@
 // SATD family, SSD, sub, copy2 and the forward DCT -- one 8x8 block per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <stdio.h>
 
 #include "../../include/theora_hip.h"
@@ -425,6 +426,41 @@ __global__ __launch_bounds__(256) void k_enc_quantize(int16_t *qdct, int32_t *no
   if (i < n) nonzero[i] = nz;
 }
 
+// The same with the reciprocals handed in: `enquant` is the 64-entry {m, l} table
+// thip_enc_enquant_table_init built once (oc_enc_enquant_table_init, enquant.c:194), as the
+// reference's quantize slot receives it (encint.h:319-320), instead of being re-derived per launch.
+__global__ __launch_bounds__(256) void k_enc_quantize_tab(int16_t *qdct, int32_t *nonzero, const int16_t *dct,
+                                                         const uint16_t *dequant, const int16_t *enquant, int64_t n) {
+  __shared__ int s_d[64], s_m[64], s_l[64];
+  if (threadIdx.x < 64) {
+    s_d[threadIdx.x] = (int)dequant[threadIdx.x];
+    s_m[threadIdx.x] = (int)enquant[2 * threadIdx.x];
+    s_l[threadIdx.x] = (int)enquant[2 * threadIdx.x + 1];
+  }
+  __syncthreads();
+  __shared__ int4 s_x[4 * 512];
+  int4 *lds = s_x + (threadIdx.x >> 6) * 512;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int v[64];
+  load_block16_wave(v, dct, i, n, lds);
+  int nz = 0;
+#pragma unroll
+  for (int z = 0; z < 64; z++) {
+    int val = v[z] << 1;
+    const int d = s_d[z];
+    int q = 0;
+    if (abs(val) >= d) {
+      const int s = val >> 31;
+      val += (d + s) ^ s;
+      q = sx16(((((s_m[z] * val) >> 16) + val) >> s_l[z]) - s);
+      nz = z;
+    }
+    v[z] = q;
+  }
+  store_block16_wave(qdct, i, n, v, lds);
+  if (i < n) nonzero[i] = nz;
+}
+
 // Stream and completion policy of the batched entry points below (thip_set_batch_stream).
 static hipStream_t g_batch_stream = nullptr;
 static int g_batch_sync = 1;
@@ -446,6 +482,43 @@ int thip_enc_quantize_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct,
   if (n < 0) return THIP_EINVAL;
   if (n == 0) return THIP_OK;
   hipLaunchKernelGGL(k_enc_quantize, grid_for(n), dim3(256), 0, g_batch_stream, qdct, nonzero, dct, dequant, n);
+  HIP_TRY(hipGetLastError());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
+  return THIP_OK;
+}
+
+// ---- the enquant_table_* slots of oc_enc_opt_vtable (encint.h:316-318): host functions, like the
+//      reference's (the tables are built when the quantisation parameters change, not per block) -------
+void thip_enc_enquant_table_init(void *enquant, const uint16_t dequant[64]) {
+  int16_t *t = (int16_t *)enquant;   // oc_iquant {ogg_int16_t m, l} (enquant.h), 64 entries
+  for (int zzi = 0; zzi < 64; zzi++) {
+    // oc_iquant_init, enquant.c:183-191
+    const uint32_t d = (uint32_t)dequant[zzi] << 1;
+    const int l = 31 - __builtin_clz(d | 1u);
+    const uint32_t tt = 1u + ((1u << (16 + l)) / (d ? d : 1u));
+    t[2 * zzi] = (int16_t)(tt - 0x10000u);
+    t[2 * zzi + 1] = (int16_t)l;
+  }
+}
+
+void thip_enc_enquant_table_fixup(void *enquant[3][3][2], int nqis) {   // enquant.c:210-217
+  for (int pli = 0; pli < 3; pli++)
+    for (int qii = 1; qii < nqis; qii++)
+      for (int qti = 0; qti < 2; qti++) memcpy(enquant[pli][qii][qti], enquant[pli][0][qti], 4);
+}
+
+void thip_enc_opt_data(size_t *enquant_table_size, int *enquant_table_alignment) {   // encint.h:331-338
+  if (enquant_table_size) *enquant_table_size = THIP_ENQUANT_TABLE_SIZE;
+  if (enquant_table_alignment) *enquant_table_alignment = 16;
+}
+
+int thip_enc_quantize_tab_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t *dequant,
+                                const void *enquant, int64_t n) {
+  if (!qdct || !nonzero || !dct || !dequant || !enquant) return THIP_EFAULT;
+  if (n < 0) return THIP_EINVAL;
+  if (n == 0) return THIP_OK;
+  hipLaunchKernelGGL(k_enc_quantize_tab, grid_for(n), dim3(256), 0, g_batch_stream, qdct, nonzero, dct, dequant,
+                     (const int16_t *)enquant, n);
   HIP_TRY(hipGetLastError());
   if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
@@ -571,6 +644,166 @@ int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n) {
   HIP_TRY(hipGetLastError());
   if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// The single-block slots of oc_enc_opt_vtable (encint.h:292-326) with the reference's own
+// signatures -- HOST pointers, one 8x8 block, a value returned -- each bound to a one-element
+// batch of the kernels above.  This is what oc_enc_accel_init_hip fills the vtable with
+//  so that the encoder's existing call sites keep working and each slot
+// can be compared with its C original one call at a time; an encoder that wants throughput calls
+// the batch entry points.  A call stages its blocks through a small per-thread pinned/device
+// scratch and waits for the result: tens of microseconds, by design.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct Enc1 {
+  uint8_t *h = nullptr, *d = nullptr;   // 2 KB each: pinned host image and device copy of the layout below
+  ~Enc1() {
+    if (h) (void)hipHostFree(h);
+    if (d) (void)hipFree(d);
+  }
+};
+// layout (bytes): 0 src[64] | 64 ref1[64] | 128 ref2[64] | 192 dst[64] | 256 int16 in[64] | 384 int16 out[64] |
+//                 512 u32 out | 516 i32 dc | 520 i32 nonzero | 528 offs {0, 64, +3 for copy2} | 552 mask i64 | 576 dequant u16[64] | 704 enquant[256]
+constexpr int kE1Src = 0, kE1Ref1 = 64, kE1Ref2 = 128, kE1Dst = 192, kE1In = 256, kE1Out = 384, kE1Val = 512, kE1Dc = 516,
+              kE1Nz = 520, kE1Offs = 528, kE1Mask = 552, kE1Deq = 576, kE1Enq = 704, kE1Bytes = 1024;
+thread_local Enc1 t_e1;
+
+bool e1_ready() {
+  if (t_e1.h) return true;
+  if (hipHostMalloc((void **)&t_e1.h, kE1Bytes, hipHostMallocDefault) != hipSuccess) return false;
+  if (hipMalloc((void **)&t_e1.d, kE1Bytes) != hipSuccess) return false;
+  memset(t_e1.h, 0, kE1Bytes);
+  ((int32_t *)(t_e1.h + kE1Offs))[1] = 64;
+  return true;
+}
+void e1_block(int at, const unsigned char *p, int ystride) {
+  for (int r = 0; r < 8; r++) memcpy(t_e1.h + at + 8 * r, p + (ptrdiff_t)r * ystride, 8);
+}
+bool e1_up() { return hipMemcpy(t_e1.d, t_e1.h, kE1Bytes, hipMemcpyHostToDevice) == hipSuccess; }
+bool e1_down() {
+  if (hipStreamSynchronize(g_batch_stream) != hipSuccess) return false;
+  return hipMemcpy(t_e1.h, t_e1.d, kE1Bytes, hipMemcpyDeviceToHost) == hipSuccess;
+}
+unsigned e1_metric(int op, int *dc, const unsigned char *src, const unsigned char *ref1, const unsigned char *ref2, int ystride,
+                   unsigned thresh) {
+  if (!e1_ready()) return 0;
+  e1_block(kE1Src, src, ystride);
+  if (ref1) e1_block(kE1Ref1, ref1, ystride);
+  if (ref2) e1_block(kE1Ref2, ref2, ystride);
+  if (!e1_up()) return 0;
+  uint8_t *d = t_e1.d;
+  const int32_t *offs = (const int32_t *)(d + kE1Offs);
+  if (thip_enc_frag_metric_batch(op, (uint32_t *)(d + kE1Val), (int32_t *)(d + kE1Dc), d + kE1Src, d + kE1Ref1, 8, offs, offs,
+                                 offs + 1, thresh, 1) < 0 || !e1_down())
+    return 0;
+  if (dc) *dc = *(int32_t *)(t_e1.h + kE1Dc);
+  return *(uint32_t *)(t_e1.h + kE1Val);
+}
+}  // namespace
+
+void thip_enc1_frag_sub(int16_t diff[64], const unsigned char *src, const unsigned char *ref, int ystride) {
+  if (!e1_ready()) return;
+  e1_block(kE1Src, src, ystride);
+  e1_block(kE1Ref1, ref, ystride);
+  const int32_t *offs = (const int32_t *)(t_e1.d + kE1Offs);
+  if (!e1_up() || thip_enc_frag_sub_batch((int16_t *)(t_e1.d + kE1Out), t_e1.d + kE1Src, t_e1.d + kE1Ref1, 8, offs, offs, 1) < 0 ||
+      !e1_down())
+    return;
+  memcpy(diff, t_e1.h + kE1Out, 128);
+}
+void thip_enc1_frag_sub_128(int16_t diff[64], const unsigned char *src, int ystride) {
+  if (!e1_ready()) return;
+  e1_block(kE1Src, src, ystride);
+  const int32_t *offs = (const int32_t *)(t_e1.d + kE1Offs);
+  if (!e1_up() || thip_enc_frag_sub_batch((int16_t *)(t_e1.d + kE1Out), t_e1.d + kE1Src, nullptr, 8, offs, nullptr, 1) < 0 ||
+      !e1_down())
+    return;
+  memcpy(diff, t_e1.h + kE1Out, 128);
+}
+unsigned thip_enc1_frag_sad(const unsigned char *src, const unsigned char *ref, int ystride) {
+  return e1_metric(THIP_ENC_SAD, nullptr, src, ref, nullptr, ystride, 0);
+}
+unsigned thip_enc1_frag_sad_thresh(const unsigned char *src, const unsigned char *ref, int ystride, unsigned thresh) {
+  return e1_metric(THIP_ENC_SAD_THRESH, nullptr, src, ref, nullptr, ystride, thresh);
+}
+unsigned thip_enc1_frag_sad2_thresh(const unsigned char *src, const unsigned char *ref1, const unsigned char *ref2, int ystride,
+                                    unsigned thresh) {
+  return e1_metric(THIP_ENC_SAD2_THRESH, nullptr, src, ref1, ref2, ystride, thresh);
+}
+unsigned thip_enc1_frag_intra_sad(const unsigned char *src, int ystride) {
+  return e1_metric(THIP_ENC_INTRA_SAD, nullptr, src, nullptr, nullptr, ystride, 0);
+}
+unsigned thip_enc1_frag_satd(int *dc, const unsigned char *src, const unsigned char *ref, int ystride) {
+  return e1_metric(THIP_ENC_SATD, dc, src, ref, nullptr, ystride, 0);
+}
+unsigned thip_enc1_frag_satd2(int *dc, const unsigned char *src, const unsigned char *ref1, const unsigned char *ref2, int ystride) {
+  return e1_metric(THIP_ENC_SATD2, dc, src, ref1, ref2, ystride, 0);
+}
+unsigned thip_enc1_frag_intra_satd(int *dc, const unsigned char *src, int ystride) {
+  return e1_metric(THIP_ENC_INTRA_SATD, dc, src, nullptr, nullptr, ystride, 0);
+}
+unsigned thip_enc1_frag_ssd(const unsigned char *src, const unsigned char *ref, int ystride) {
+  return e1_metric(THIP_ENC_SSD, nullptr, src, ref, nullptr, ystride, 0);
+}
+unsigned thip_enc1_frag_border_ssd(const unsigned char *src, const unsigned char *ref, int ystride, int64_t mask) {
+  if (!e1_ready()) return 0;
+  e1_block(kE1Src, src, ystride);
+  e1_block(kE1Ref1, ref, ystride);
+  *(int64_t *)(t_e1.h + kE1Mask) = mask;
+  const int32_t *offs = (const int32_t *)(t_e1.d + kE1Offs);
+  if (!e1_up() || thip_enc_frag_border_ssd_batch((uint32_t *)(t_e1.d + kE1Val), t_e1.d + kE1Src, t_e1.d + kE1Ref1, 8, offs, offs,
+                                                 (const int64_t *)(t_e1.d + kE1Mask), 1) < 0 || !e1_down())
+    return 0;
+  return *(uint32_t *)(t_e1.h + kE1Val);
+}
+void thip_enc1_frag_copy2(unsigned char *dst, const unsigned char *src1, const unsigned char *src2, int ystride) {
+  if (!e1_ready()) return;
+  e1_block(kE1Ref1, src1, ystride);
+  e1_block(kE1Ref2, src2, ystride);
+  const int32_t *offs = (const int32_t *)(t_e1.d + kE1Offs);
+  // dst at kE1Dst = kE1Ref1 + 128: one plane pointer (ref1), offsets 128 / 0 / 64
+  static const int32_t h_offs3[3] = {kE1Dst - kE1Ref1, 0, kE1Ref2 - kE1Ref1};
+  memcpy(t_e1.h + kE1Offs + 8, h_offs3, sizeof(h_offs3));
+  if (!e1_up() || thip_enc_frag_copy2_batch(t_e1.d + kE1Ref1, t_e1.d + kE1Ref1, 8, offs + 2, offs + 3, offs + 4, 1) < 0 || !e1_down())
+    return;
+  for (int r = 0; r < 8; r++) memcpy(dst + (ptrdiff_t)r * ystride, t_e1.h + kE1Dst + 8 * r, 8);
+}
+int thip_enc1_quantize(int16_t qdct[64], const int16_t dct[64], const uint16_t dequant[64], const void *enquant) {
+  if (!e1_ready()) return 0;
+  memcpy(t_e1.h + kE1In, dct, 128);
+  memcpy(t_e1.h + kE1Deq, dequant, 128);
+  memcpy(t_e1.h + kE1Enq, enquant, THIP_ENQUANT_TABLE_SIZE);
+  if (!e1_up() || thip_enc_quantize_tab_batch((int16_t *)(t_e1.d + kE1Out), (int32_t *)(t_e1.d + kE1Nz), (const int16_t *)(t_e1.d + kE1In),
+                                              (const uint16_t *)(t_e1.d + kE1Deq), t_e1.d + kE1Enq, 1) < 0 || !e1_down())
+    return 0;
+  memcpy(qdct, t_e1.h + kE1Out, 128);
+  return *(int32_t *)(t_e1.h + kE1Nz);
+}
+void thip_enc1_frag_recon_intra(unsigned char *dst, int ystride, const int16_t residue[64]) {
+  if (!e1_ready()) return;
+  memcpy(t_e1.h + kE1In, residue, 128);
+  const int32_t *offs = (const int32_t *)(t_e1.d + kE1Offs);
+  if (!e1_up() || thip_frag_recon_batch(t_e1.d + kE1Dst, nullptr, 8, 0, offs, nullptr, nullptr, (const int16_t *)(t_e1.d + kE1In), 1) < 0 ||
+      !e1_down())
+    return;
+  for (int r = 0; r < 8; r++) memcpy(dst + (ptrdiff_t)r * ystride, t_e1.h + kE1Dst + 8 * r, 8);
+}
+void thip_enc1_frag_recon_inter(unsigned char *dst, const unsigned char *src, int ystride, const int16_t residue[64]) {
+  if (!e1_ready()) return;
+  e1_block(kE1Ref1, src, ystride);
+  memcpy(t_e1.h + kE1In, residue, 128);
+  const int32_t *offs = (const int32_t *)(t_e1.d + kE1Offs);
+  if (!e1_up() || thip_frag_recon_batch(t_e1.d + kE1Dst, t_e1.d + kE1Ref1, 8, 1, offs, offs, nullptr,
+                                        (const int16_t *)(t_e1.d + kE1In), 1) < 0 || !e1_down())
+    return;
+  for (int r = 0; r < 8; r++) memcpy(dst + (ptrdiff_t)r * ystride, t_e1.h + kE1Dst + 8 * r, 8);
+}
+void thip_enc1_fdct8x8(int16_t y[64], const int16_t x[64]) {
+  if (!e1_ready()) return;
+  memcpy(t_e1.h + kE1In, x, 128);
+  if (!e1_up() || thip_enc_fdct8x8_batch((int16_t *)(t_e1.d + kE1Out), (const int16_t *)(t_e1.d + kE1In), 1) < 0 || !e1_down()) return;
+  memcpy(y, t_e1.h + kE1Out, 128);
 }
 
 }  // extern "C"
