@@ -161,6 +161,13 @@ typedef struct thip_frame_desc {
   int32_t ncoded;             /* coded fragments in total; 0 => TH_DUPFRAME (decode.c:2764) */
   int32_t frame_type;         /* THIP_INTRA_FRAME / THIP_INTER_FRAME */
   int32_t flimit;             /* loop_filter_limits[qis[0]], 0 = filter off (decode.c:1369-1371) */
+  /* Optional (NULL = the DC values in frag_info / coeffs are final, as oc_state_frag_recon receives
+     them).  Non-NULL: device int16[nfrags], fragment-index (raster, plane by plane) order: the DC value of
+     every coded fragment AS DECODED FROM THE TOKENS, i.e. before oc_dec_dc_unpredict_mcu_plane
+     (decode.c:1392-1500).  The launch then undoes the DC prediction on the device (k_dc_unpredict, an
+     anti-diagonal wavefront per plane) and the reconstruction takes every block's DC from its result; the
+     DC fields of frag_info / coeffs are then ignored.  Planes of more than 1024 fragment rows: TH_EIMPL. */
+  const int16_t *dc_tokens;
 } thip_frame_desc;
 
 /* One frame of each of nstreams independent streams, all inputs resident in HBM:
@@ -197,6 +204,11 @@ int thip_state_loop_filter_frag_rows(thip_state *st, int flimit, int refi, int p
                                      int fragy_end);
 /* Upload, launch, rotate the ring.  Returns 0 or THIP_DUPFRAME. */
 int thip_frame_flush(thip_state *st);
+/* on != 0: the DC coefficient handed to thip_state_frag_recon (dct_coeffs[0]) is the value decoded from
+   the tokens, NOT yet un-predicted: the caller skips its oc_dec_dc_unpredict_mcu_plane calls
+   (decode.c:2869) and thip_frame_flush undoes the prediction on the device before reconstructing
+   (thip_frame_desc.dc_tokens).  Takes effect from the next thip_frame_begin. */
+int thip_state_set_device_dc(thip_state *st, int on);
 
 /* ------------------------------------------------------------------------------------
  * Batched forms of the individual slots (device pointers).  These exist so each vtable
@@ -212,6 +224,12 @@ int thip_frag_recon_batch(uint8_t *dst_frame, const uint8_t *src_frame, int ystr
 /* oc_frag_copy_list (fragment.c:37) with explicit frames and offsets. */
 int thip_frag_copy_list_batch(uint8_t *dst_frame, const uint8_t *src_frame, int ystride,
                               const int32_t *fragis, int64_t nfragis, const int32_t *frag_buf_offs);
+/* oc_dec_dc_unpredict_mcu_plane (the oc_dec_opt_vtable slot, decint.h:72-75; decode.c:1392-1500) over one
+   whole plane, in place on the device: dc = int16 per fragment (raster) holding the token DC values of the
+   coded fragments on entry and their un-predicted values on return; flags = 1 byte per fragment, bit 0
+   coded, bits 1-2 the fragment's reference frame index (state.h:170-176).  pred_last starts at 0
+   (decode.c:1367).  nvfrags <= 1024. */
+int thip_dc_unpredict_plane(int16_t *dc, const uint8_t *flags, int nhfrags, int nvfrags);
 /* oc_state_loop_filter_frag_rows (state.c:1055) on one plane: coded = 1 byte per fragment
    of that plane (raster), rows [fragy0,fragy_end). */
 int thip_loop_filter_plane(uint8_t *plane, int ystride, int nhfrags, int nvfrags,

@@ -128,6 +128,11 @@ typedef struct {
    recent frame (pointers stay valid until the next packet).  It exists so that the host logic can be
    tested without a GPU; on a normal context it returns TH_EINVAL. */
 #define TH_DECCTL_THIP_GET_SLOT_TRACE (0x7101)
+/* Extension: buf = int.  Non-zero: from the next packet on the DC prediction (spec 7.8, decode.c:1392-1500)
+   is undone by the backend on the GPU (thip_state_set_device_dc: an anti-diagonal wavefront per plane)
+   instead of by th_decode_packetin on the host; the pictures are the same.  TH_EIMPL for planes of more
+   than 1024 fragment rows.  The environment variable THIP_FE_DEVICE_DC=1 sets it for every new context. */
+#define TH_DECCTL_THIP_SET_DEVICE_DC (0x7102)
 typedef struct thip_slot_trace {
   int64_t ncoded;           /* state_frag_recon calls, in call (= coded) order */
   const int32_t *fragi;     /* _fragi */

@@ -375,3 +375,107 @@ def test_streams_spread_over_two_devices_in_one_call(hip):
         hip.decode_frames(gsts, descs)
         for i in range(S):
             assert not util.planes_equal(osts[i], gsts[i]), (f, i)
+
+
+def _predicted_tokens(geom, fr, fmt):
+    """The DC values a bitstream would carry for this frame: the frame's final DCs pushed back through the
+    predictor (an encoder's forward prediction, here by inverting the oracle's un-prediction fragment by
+    fragment in raster order)."""
+    ost = oracle.State(geom.frame_width, geom.frame_height, fmt)
+    n = geom.nfrags
+    cf = fr["coded_fragis"]
+    coded = np.zeros(n, bool)
+    coded[cf] = True
+    final = np.zeros(n, np.int16)
+    final[cf] = np.asarray(fr["coeffs"], np.int16).reshape(-1, 64)[:, 0]
+    ost.coded[:] = coded
+    ost.refi[:] = fr["refi"]
+    # un-predicting zeros gives minus nothing useful in general (the predictor is not linear), so build the
+    # tokens greedily: token = final - pred(final neighbours); the oracle's own pass then reproduces `final`
+    tokens = np.zeros(n, np.int16)
+    for pli in range(3):
+        nh, nv, fro = geom.nh[pli], geom.nv[pli], geom.froffset[pli]
+        pl = [0, 0, 0]
+        for y in range(nv):
+            for x in range(nh):
+                i = fro + y * nh + x
+                if not coded[i]:
+                    continue
+                r = int(fr["refi"][i])
+
+                def ok(xx, yy):
+                    j = fro + yy * nh + xx
+                    return 0 <= xx < nh and yy >= 0 and coded[j] and int(fr["refi"][j]) == r
+                m = (1 if ok(x - 1, y) else 0) | (2 if ok(x - 1, y - 1) else 0) | (4 if ok(x, y - 1) else 0) | (8 if ok(x + 1, y - 1) else 0)
+                d = lambda xx, yy: int(final[fro + yy * nh + xx])   # noqa: E731
+                tr = lambda a, b: int(a / b) if a * b >= 0 or a % b == 0 else -((-a) // b)   # noqa: E731  (C division)
+                if m == 0:
+                    p = pl[r]
+                elif m in (1, 3):
+                    p = d(x - 1, y)
+                elif m == 2:
+                    p = d(x - 1, y - 1)
+                elif m in (4, 6, 12):
+                    p = d(x, y - 1)
+                elif m == 5:
+                    p = tr(d(x - 1, y) + d(x, y - 1), 2)
+                elif m == 8:
+                    p = d(x + 1, y - 1)
+                elif m in (9, 11, 13):
+                    p = tr(75 * d(x - 1, y) + 53 * d(x + 1, y - 1), 128)
+                elif m == 10:
+                    p = tr(d(x - 1, y - 1) + d(x + 1, y - 1), 2)
+                elif m == 14:
+                    p = tr(3 * (d(x - 1, y - 1) + d(x + 1, y - 1)) + 10 * d(x, y - 1), 16)
+                else:
+                    p0, p1, p2 = d(x - 1, y), d(x - 1, y - 1), d(x, y - 1)
+                    p = tr(29 * (p0 + p2) - 26 * p1, 32)
+                    if abs(p - p2) > 128:
+                        p = p2
+                    elif abs(p - p0) > 128:
+                        p = p0
+                    elif abs(p - p1) > 128:
+                        p = p1
+                tokens[i] = np.int16((int(final[i]) - p + 32768) % 65536 - 32768)
+                pl[r] = int(final[i])
+    ost.dc[:] = tokens
+    ost.dc_unpredict()
+    assert np.array_equal(ost.dc[coded], final[coded]), "token construction does not invert the oracle's un-prediction"
+    ost.close()
+    return tokens
+
+
+@pytest.mark.parametrize("enqueue", [False, True])
+@pytest.mark.parametrize("w,h,fmt", [(176, 144, PF_420), (80, 112, PF_422), (64, 48, PF_444)])
+def test_dc_unprediction_on_the_device(hip, w, h, fmt, enqueue):
+    """thip_frame_desc.dc_tokens / thip_state_set_device_dc: the frame's DC values arrive as the bitstream
+    carries them (before oc_dec_dc_unpredict_mcu_plane, decode.c:1392-1500), with zeros where the command
+    stream would carry the final DC; the launch un-predicts on the device and the pictures equal the
+    oracle's, which was given the final values."""
+    import torch
+    geom = synth.Geometry(w, h, fmt)
+    rng = np.random.default_rng(w + h + fmt + int(enqueue))
+    ost = oracle.State(w, h, fmt)
+    gst = hip.State(w, h, fmt)
+    if enqueue:
+        from theora_amd import _lib
+        assert _lib.load().thip_state_set_device_dc(gst.handle, 1) == 0
+    keep = []
+    for f in range(6):
+        fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f % 4 == 0 else hip.INTER_FRAME, "mixed")
+        util.oracle_apply(ost, fr)
+        tokens = _predicted_tokens(geom, fr, fmt)
+        blind = dict(fr)
+        co = np.asarray(fr["coeffs"], np.int16).reshape(-1, 64).copy()
+        co[:, 0] = tokens[fr["coded_fragis"]] if enqueue else 0     # the slots receive the token DC; the descriptor path nothing
+        blind["coeffs"] = co
+        if enqueue:
+            assert util.enqueue_frame(hip, gst, geom, blind) == 0
+        else:
+            packed = synth.pack_frame(geom, blind)
+            desc, ka = synth.upload_frame(packed)
+            dct = torch.from_numpy(tokens).cuda()
+            desc.dc_tokens = dct.data_ptr()
+            keep.append((ka, dct))
+            assert hip.decode_frames([gst], [desc]) == [0]
+        assert not util.planes_equal(ost, gst), f

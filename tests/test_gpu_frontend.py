@@ -12,10 +12,14 @@ from tests import streamgen, util
 pytestmark = pytest.mark.gpu
 
 
-def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random"):
+def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=False):
+    import ctypes as C
     from theora_amd.decoder import Decoder
     st = streamgen.Stream(w, h, fmt, seed, trees=trees)
     dec = Decoder(st.header_packets())
+    if device_dc:   # TH_DECCTL_THIP_SET_DEVICE_DC: the DC prediction is undone on the GPU, not in th_decode_packetin
+        on = C.c_int(1)
+        assert dec._L.th_decode_ctl(dec._dec, 0x7102, C.byref(on), C.sizeof(on)) == 0
     assert dec.info.frame_width == w and dec.info.frame_height == h and dec.info.pixel_fmt == fmt
     assert dec.comment.vendor == b"theora-hip streamgen"
     ost = oracle.State(w, h, fmt)
@@ -42,6 +46,13 @@ def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random"):
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (336, 32, 0)])
 def test_packets_decode_bit_exact(hip, w, h, fmt):
     assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9) >= 6
+
+
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (1280, 720, 0)])
+def test_packets_decode_bit_exact_with_dc_unprediction_on_the_gpu(hip, w, h, fmt):
+    """The same streams with spec 7.8 / decode.c:1392-1500 left to the backend (k_dc_unpredict): the host
+    front end hands the slots the DC values as the tokens carry them."""
+    assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_dc=True) >= 3
 
 
 def test_packets_decode_bit_exact_720p(hip):

@@ -424,3 +424,54 @@ def test_enc_kernels_at_config5_size(hip):
         assert np.array_equal(v.cpu().numpy().view(np.uint32)[msample], wv), op
         if "satd" in op:
             assert np.array_equal(dc.cpu().numpy()[msample], wdc), op
+
+
+def _dc_case(rng, w, h, fmt, density, refmix, big):
+    """A frame's worth of coded flags, reference indices and token DC values in an oracle state."""
+    ost = oracle.State(w, h, fmt)
+    n = ost.nfrags
+    ost.coded[:] = rng.random(n) < density
+    if refmix == "one":
+        ost.refi[:] = 2
+    elif refmix == "runs":      # long horizontal runs of one reference: the predictor's common cases
+        ost.refi[:] = np.repeat(rng.integers(0, 3, n // 7 + 1), 7)[:n]
+    else:                       # every neighbour combination, many fragments with no usable neighbour
+        ost.refi[:] = rng.integers(0, 3, n)
+    lim = 32767 if big else 200
+    ost.dc[:] = rng.integers(-lim, lim + 1, n)
+    return ost
+
+
+@pytest.mark.parametrize("w,h,fmt", [(16, 16, 0), (16, 272, 3), (336, 16, 0), (176, 144, 0), (80, 112, 2), (1280, 720, 0),
+                                     (3840, 2160, 0)])
+def test_dc_unpredict_plane_slot(hip, w, h, fmt):
+    """oc_dec_dc_unpredict_mcu_plane (the oc_dec_opt_vtable slot, decode.c:1392-1500) as a device wavefront:
+    every plane of random frames -- sparse and dense coded masks, one / runs of / random reference frames (the
+    last makes most fragments fall back to pred_last, the dependency that breaks the wavefront), small values
+    and full-range ones (16-bit wrap, the 3-neighbour outlier clamp) -- against the oracle, in place."""
+    import torch
+    from theora_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(w * 3 + h + fmt)
+    cases = [(0.95, "one", False), (0.6, "runs", False), (0.5, "random", True), (0.08, "random", False), (1.0, "random", True)]
+    if w >= 1280:
+        cases = cases[1:3]
+    for density, refmix, big in cases:
+        ost = _dc_case(rng, w, h, fmt, density, refmix, big)
+        tokens = ost.dc.copy()
+        flags = (ost.coded.astype(np.uint8) | (ost.refi.astype(np.uint8) << 1)) * ost.coded.astype(np.uint8)
+        ost.dc_unpredict()
+        for pli in range(3):
+            g = ost.planes[pli]
+            lo, hi = g["froffset"], g["froffset"] + g["nfrags"]
+            d = torch.from_numpy(tokens[lo:hi].copy()).cuda()
+            f = torch.from_numpy(flags[lo:hi].copy()).cuda()
+            assert L.thip_dc_unpredict_plane(d.data_ptr(), f.data_ptr(), g["nhfrags"], g["nvfrags"]) == 0
+            got = d.cpu().numpy()
+            c = ost.coded[lo:hi].astype(bool)
+            assert np.array_equal(got[c], ost.dc[lo:hi][c]), (density, refmix, big, pli, int((got[c] != ost.dc[lo:hi][c]).sum()))
+        ost.close()
+    assert L.thip_dc_unpredict_plane(None, None, 4, 4) == _lib.EFAULT
+    d = torch.zeros(8, dtype=torch.int16, device="cuda")
+    f = torch.zeros(8, dtype=torch.uint8, device="cuda")
+    assert L.thip_dc_unpredict_plane(d.data_ptr(), f.data_ptr(), 1, 1025) == _lib.EIMPL

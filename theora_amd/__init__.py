@@ -214,8 +214,9 @@ def synchronize():
     _lib.check(_lib.load().thip_synchronize(), "thip_synchronize")
 
 
-def make_desc(info_dev, coeffs_dev, slot0_dev, nslots, ncoded, frame_type, flimit):
-    return FrameDesc(_ptr(info_dev), _ptr(coeffs_dev), _ptr(slot0_dev), nslots, ncoded, frame_type, flimit)
+def make_desc(info_dev, coeffs_dev, slot0_dev, nslots, ncoded, frame_type, flimit, dc_tokens_dev=None):
+    return FrameDesc(_ptr(info_dev), _ptr(coeffs_dev), _ptr(slot0_dev), nslots, ncoded, frame_type, flimit,
+                     _ptr(dc_tokens_dev))
 
 
 def profile_enable(on):

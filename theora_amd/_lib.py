@@ -31,7 +31,7 @@ class PlaneGeom(C.Structure):
 class FrameDesc(C.Structure):
     _fields_ = [("frag_info", C.c_void_p), ("coeffs", C.c_void_p), ("tile_slot0", C.c_void_p),
                 ("nslots", C.c_int32), ("ncoded", C.c_int32), ("frame_type", C.c_int32),
-                ("flimit", C.c_int32)]
+                ("flimit", C.c_int32), ("dc_tokens", C.c_void_p)]
 
 
 class TileGeom(C.Structure):
@@ -74,6 +74,8 @@ SYMBOLS = [
     ("thip_frag_recon_batch", _I, [_P, _P, _I, _I, _P, _P, _P, _P, _I64]),
     ("thip_frag_copy_list_batch", _I, [_P, _P, _I, _P, _I64, _P]),
     ("thip_loop_filter_plane", _I, [_P, _I, _I, _I, _P, _I, _I, _I]),
+    ("thip_dc_unpredict_plane", _I, [_P, _P, _I, _I]),
+    ("thip_state_set_device_dc", _I, [_P, _I]),
     ("thip_enc_frag_metric_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _U32, _I64]),
     ("thip_enc_frag_border_ssd_batch", _I, [_P, _P, _P, _I, _P, _P, _P, _I64]),
     ("thip_enc_frag_sub_batch", _I, [_P, _P, _P, _I, _P, _P, _I64]),

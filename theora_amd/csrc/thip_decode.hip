@@ -92,6 +92,13 @@ struct thip_state {
   int enq_ncoded, enq_nuncoded, enq_nslots, enq_frame_type, enq_flimit, enq_active, enq_last_tile;
   int enq_lf_y0[3], enq_lf_y1[3], enq_lf_any;
   int lf_y0[3], lf_y1[3], lf_rows_custom;
+  // DC un-prediction on the device (thip_frame_desc.dc_tokens / thip_state_set_device_dc)
+  int16_t *d_dc;        // device, nfrags: un-predicted DC values of the frame being decoded
+  int device_dc, enq_device_dc;
+  int16_t *h_dc, *d_dc_in;   // enqueue path: token DC values staged per fragment (pinned) and their device copy
+  uint8_t *h_flags, *d_flags;   // ... and the fragments' coded | refi << 1 in fragment-index order (the staged command
+                                // words stay in host memory: the wavefront kernel must not poll them across PCIe)
+  int flush_flags;              // set while thip_frame_flush runs: d_flags describes the frame being launched
 };
 
 namespace {
@@ -348,6 +355,11 @@ void thip_state_free(thip_state *st) {
   if (st->d_info) (void)hipFree(st->d_info);
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
   if (st->d_slot0) (void)hipFree(st->d_slot0);
+  if (st->d_dc) (void)hipFree(st->d_dc);
+  if (st->d_dc_in) (void)hipFree(st->d_dc_in);
+  if (st->h_dc) (void)hipHostFree(st->h_dc);
+  if (st->h_flags) (void)hipHostFree(st->h_flags);
+  if (st->d_flags) (void)hipFree(st->d_flags);
   free(st->enq_last_lane);
   free(st->frag_pos);
   free(st);
@@ -664,11 +676,37 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     live_state[nlive++] = i;
   }
   if (!nlive) return THIP_OK;
-  // THIP_FUSE=1: reconstruct and filter a strip in LDS and write the frame once (k_recon_lf +
-  // k_lf_seam) instead of k_recon + k_loopfilter over the whole frame.  Bit-exact, 70 MB less
-  // traffic per 4K step, but measured SLOWER (58+17 us vs 44+23 us per 4-frame launch: the
-  // workgroup-wide barriers and the filter's arithmetic cost more than the bytes saved), so it
-  // is off by default; DESIGN.md section 5.
+  // ---- DC un-prediction on the device for the streams that ask for it (decode.c:1392-1500) ----------
+  {
+    DcBatchK D;
+    memset(&D, 0, sizeof(D));
+    int ndc = 0, max_rows = 0;
+    for (int j = 0; j < nlive; j++) {
+      thip_state *st = states[live_state[j]];
+      const thip_frame_desc &d = descs[live_state[j]];
+      if (!d.dc_tokens) continue;
+      if (!st->d_dc) HIP_TRY(hipMalloc((void **)&st->d_dc, sizeof(int16_t) * (size_t)st->nfrags));
+      B.s[j].dc = st->d_dc;          // k_recon / k_recon_walk take every block's DC from here
+      for (int pli = 0; pli < 3; pli++) {
+        const thip_plane_geom &g = st->geom[pli];
+        DcPlaneK &p = D.p[ndc][pli];
+        p.in = d.dc_tokens + g.froffset;
+        p.out = st->d_dc + g.froffset;
+        p.flags = st->flush_flags ? st->d_flags + g.froffset : nullptr;
+        p.info = d.frag_info;
+        p.nh = g.nhfrags;
+        p.nv = g.nvfrags;
+        p.tiles_x = st->tiles.tiles_x[pli];
+        p.tile_base = st->tiles.tile_off[pli];
+        if (g.nvfrags > max_rows) max_rows = g.nvfrags;
+      }
+      ndc++;
+    }
+    if (ndc) {
+      hipLaunchKernelGGL(k_dc_unpredict, dim3(3, ndc), dim3((max_rows + 63) & ~63), 0, s, D);
+      HIP_TRY(hipGetLastError());
+    }
+  }
   // THIP_FUSE=1: the fused path (k_recon_walk + k_lf_seams): no vertical seams, a quarter of the lines
   // re-read.  Frames that leave static blocks in place (skip_ok) keep the two-pass path, whose first
   // kernel knows how to skip whole tiles.
@@ -743,6 +781,9 @@ static int validate_frames(thip_state *const *states, const thip_frame_desc *des
     if (d.flimit < 0 || d.flimit > 127) return THIP_EINVAL;
     if (d.frame_type != THIP_INTRA_FRAME && d.frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
     if (d.frame_type == THIP_INTRA_FRAME && d.ncoded != st->nfrags) return THIP_EINVAL;
+    if (d.dc_tokens)
+      for (int pli = 0; pli < 3; pli++)
+        if (st->geom[pli].nvfrags > kDcMaxRows) return THIP_EIMPL;
     for (int j = 0; j < i; j++)
       if (states[j] == st) return THIP_EINVAL;   // one frame per stream per call
   }
@@ -815,6 +856,33 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
   return THIP_OK;
 }
 
+int thip_dc_unpredict_plane(int16_t *dc, const uint8_t *flags, int nhfrags, int nvfrags) {
+  if (!dc || !flags) return THIP_EFAULT;
+  if (nhfrags <= 0 || nvfrags <= 0) return THIP_EINVAL;
+  if (nvfrags > kDcMaxRows) return THIP_EIMPL;
+  DcBatchK D;
+  memset(&D, 0, sizeof(D));
+  DcPlaneK &p = D.p[0][0];
+  p.in = dc;
+  p.out = dc;
+  p.flags = flags;
+  p.nh = nhfrags;
+  p.nv = nvfrags;
+  hipLaunchKernelGGL(k_dc_unpredict, dim3(1, 1), dim3((nvfrags + 63) & ~63), 0, 0, D);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return THIP_OK;
+}
+
+int thip_state_set_device_dc(thip_state *st, int on) {
+  if (!st) return THIP_EFAULT;
+  if (on)
+    for (int pli = 0; pli < 3; pli++)
+      if (st->geom[pli].nvfrags > kDcMaxRows) return THIP_EIMPL;
+  st->device_dc = on ? 1 : 0;
+  return THIP_OK;
+}
+
 int thip_loop_filter_plane(uint8_t *plane, int ystride, int nhfrags, int nvfrags, const uint8_t *coded,
                            int flimit, int fragy0, int fragy_end) {
   if (!plane || !coded) return THIP_EFAULT;
@@ -870,6 +938,14 @@ int thip_frame_begin(thip_state *st, int frame_type) {
     st->enq_lf_y0[p] = 0x7FFFFFFF;
     st->enq_lf_y1[p] = -1;
   }
+  st->enq_device_dc = st->device_dc;
+  if (st->enq_device_dc) {
+    if (!st->h_dc) HIP_TRY(hipHostMalloc((void **)&st->h_dc, sizeof(int16_t) * (size_t)st->nfrags, hipHostMallocDefault));
+    if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * (size_t)st->nfrags));
+    if (!st->h_flags) HIP_TRY(hipHostMalloc((void **)&st->h_flags, (size_t)st->nfrags, hipHostMallocDefault));
+    if (!st->d_flags) HIP_TRY(hipMalloc((void **)&st->d_flags, (size_t)st->nfrags));
+    memset(st->h_flags, 0, (size_t)st->nfrags);   // everything uncoded
+  }
   st->enq_active = 1;
   return THIP_OK;
 }
@@ -917,6 +993,10 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
       memcpy(blk + (size_t)(2 * j) * 512, &lo, 16);
       memcpy(blk + (size_t)(2 * j + 1) * 512, &hi, 16);
     }
+  }
+  if (st->enq_device_dc) {   // the token value: un-predicted on the device at flush
+    st->h_dc[fragi] = dct_coeffs[0];
+    st->h_flags[fragi] = (uint8_t)(1u | (uint32_t)refi << 1);
   }
   memset(dct_coeffs, 0, 64 * sizeof(int16_t));   // idct.c:245,276,295
   st->h_info[2 * (size_t)pos] = flags;
@@ -1001,6 +1081,13 @@ int thip_frame_flush(thip_state *st) {
   d.ncoded = st->enq_ncoded;
   d.frame_type = st->enq_frame_type;
   d.flimit = st->enq_lf_any ? st->enq_flimit : 0;
+  if (st->enq_device_dc && st->enq_ncoded) {
+    // (the wavefront kernel reads a value per thread per step: a device copy, not reads across PCIe)
+    HIP_TRY(hipMemcpyAsync(st->d_dc_in, st->h_dc, sizeof(int16_t) * (size_t)st->nfrags, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(st->d_flags, st->h_flags, (size_t)st->nfrags, hipMemcpyHostToDevice, s));
+    d.dc_tokens = st->d_dc_in;
+    st->flush_flags = 1;
+  }
   st->lf_rows_custom = st->enq_lf_any;
   for (int p = 0; p < 3; p++) {
     st->lf_y0[p] = st->enq_lf_y1[p] < 0 ? 0 : st->enq_lf_y0[p];
@@ -1010,6 +1097,7 @@ int thip_frame_flush(thip_state *st) {
   thip_state *sp = st;
   rc = thip_decode_frames(&sp, &d, 1, nullptr, &res);
   st->lf_rows_custom = 0;
+  st->flush_flags = 0;
   if (rc < 0) return rc;
   if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(st->ev_staging, s));

@@ -205,6 +205,7 @@ struct th_dec_ctx {
   int64_t keyframe_num, curframe_num, granpos;
   int granpos_bias;
   bool have_frame;
+  bool device_dc;   // DC un-prediction left to the backend (THIP_FE_DEVICE_DC=1, or TH_DECCTL_THIP_SET_DEVICE_DC)
   std::vector<uint8_t> mirror[3];
   th_stripe_callback stripe_cb;
   // slot-trace mode (THIP_FE_TRACE_BACKEND=1 at th_decode_alloc): no device state exists; the
@@ -949,6 +950,9 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
     return nullptr;
   }
   if (d->hip) thip_state_set_eager_output(d->hip, 1);   // every frame is wanted on the host (th_decode_ycbcr_out)
+  d->device_dc = false;
+  if (d->hip && getenv("THIP_FE_DEVICE_DC") && atoi(getenv("THIP_FE_DEVICE_DC")) != 0)
+    d->device_dc = thip_state_set_device_dc(d->hip, 1) == 0;   // (refused for planes of more than 1024 fragment rows)
   build_geometry(d);
   d->dequant.resize((size_t)64 * 3 * 2 * 64);
   for (int qi = 0; qi < 64; qi++)
@@ -1019,6 +1023,15 @@ int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
       if (buf_sz != sizeof(th_stripe_callback)) return TH_EINVAL;
       d->stripe_cb = *(const th_stripe_callback *)buf;
       return 0;
+    case TH_DECCTL_THIP_SET_DEVICE_DC: {
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(int)) return TH_EINVAL;
+      if (d->trace || !d->hip) return TH_EINVAL;
+      const int on = *(int *)buf != 0;
+      if (thip_state_set_device_dc(d->hip, on) < 0) return TH_EIMPL;
+      d->device_dc = on != 0;
+      return 0;
+    }
     case TH_DECCTL_THIP_GET_SLOT_TRACE: {
       if (!d || !buf) return TH_EFAULT;
       if (buf_sz != sizeof(thip_slot_trace)) return TH_EINVAL;
@@ -1322,7 +1335,9 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     // Which neighbours predict a block is a question of "coded, and from the same reference frame"
     // (7.8.1, Table 7.47): one byte per block (reference index, 0xFF = not coded) in an array with a
     // border of 0xFF all round answers it with four compares and no position tests.
-    for (int p = 0; p < 3; p++) {
+    // (With thip_state_set_device_dc the backend undoes the prediction itself -- k_dc_unpredict, a wavefront
+    //  per plane -- and the slots below are handed the token values.)
+    for (int p = 0; p < 3 && !d->device_dc; p++) {
       const int nh = d->nh[p], nv = d->nv[p], W = nh + 2;
       std::vector<uint8_t> &key = d->dc_key;
       std::vector<int16_t> &val = d->dc_val;

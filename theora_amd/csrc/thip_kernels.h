@@ -51,6 +51,8 @@ struct StreamK {
   const uint8_t *gold;
   uint8_t *coded_map;     // 1 byte per fragment, raster order: written by k_recon, read by k_loopfilter
   const uint8_t *coded_prev;   // the same map of the previous frame of this stream (two maps alternate)
+  const int16_t *dc;      // null, or the un-predicted DC of every fragment (fragment-index order, k_dc_unpredict's
+                          // output): used instead of the DC fields of the command words / coefficient slots
   int skip_ok;            // the buffer this frame goes to holds the frame before the previous one: an uncoded
                           // block that was not touched in the previous frame either is already in place
   int flimit2;            // 2*flimit
@@ -370,9 +372,14 @@ __device__ __forceinline__ unsigned long long trace_now() {
 __device__ __forceinline__ uint32_t dequant_dc_lo(uint32_t w, uint32_t dcq) {
   return (w & 0xFFFF0000u) | (((w & 0xFFFFu) * dcq) & 0xFFFFu);
 }
+// ... with the raw DC coming from the DC array instead of the slot when dcraw says so
+__device__ __forceinline__ uint32_t dequant_dc_lo(uint32_t w, uint32_t dcq, uint32_t dcraw) {
+  return dequant_dc_lo((dcraw & 0x10000u) ? ((w & 0xFFFF0000u) | (dcraw & 0xFFFFu)) : w, dcq);
+}
 
 struct ReconLane {
   uint32_t flags, dcp, dcq;       // command word 0 (0 past the ragged edge), DC-only value {p,p}, dc_quant
+  uint32_t dcraw;                 // bit 16 set: bits 0-15 are the block's raw DC (StreamK::dc), to be used instead of x[0][0] of its slot
   bool coded, dc_only, has_coeff;
   int x0, y0;                     // pixel position of the block in its plane
 };
@@ -433,7 +440,7 @@ __device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const R
     P[q * 4 + 2] = w.z;
     P[q * 4 + 3] = w.w;
   }
-  P[0] = dequant_dc_lo(P[0], L.dcq);   // x[0][0] arrives raw
+  P[0] = dequant_dc_lo(P[0], L.dcq, L.dcraw);   // x[0][0] arrives raw
   const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
   // the masks are all ones for last_zzi > 10: ~100 instructions skipped when no owner needs them
   if (__any(L.has_coeff && last_zzi <= 10)) pk_mask_by_last_zzi(P, last_zzi);
@@ -448,7 +455,7 @@ __device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const R
 // between goes through the wave's LDS area (free once the coefficients are in registers) -- so
 // the wave executes 2*NP packed 1-D transforms instead of 8.  Bit-exact with residual_per_lane:
 // the same operations on the same values.  Must be called by all 64 lanes.
-// lds = the wave's 8 KB area as dwords; meta = 64/LPB dwords of LDS.
+// lds = the wave's 8 KB area as dwords; meta = 64 dwords of LDS (two words per owner rank, up to 32 owners).
 // The g-th owner's coefficients sit in slot slot0+g (slots are numbered in lane order inside a
 // tile), so the sharing lanes fetch their own row pairs straight from the slot -- 32*NP bytes per
 // lane instead of the whole wave staging 8 KB of which a fraction is used.
@@ -474,9 +481,13 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32
                                                 const ReconLane &L, uint32_t prefix, uint32_t Y[32]) {
   constexpr int NP = 4 / LPB;                        // row pairs (and column pairs) per lane
   const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
-  if (L.has_coeff) meta[prefix] = (uint32_t)last_zzi | (L.dcq << 16);   // rank -> last_zzi, dc_quant of that owner
+  if (L.has_coeff) {
+    meta[prefix] = (uint32_t)last_zzi | (L.dcq << 16);   // rank -> last_zzi, dc_quant of that owner
+    meta[32 + prefix] = L.dcraw;                          // ... and its raw DC when that comes from the DC array
+  }
   const int g = lane / LPB, j = lane % LPB;
   const uint32_t mg = meta[g];                      // (garbage for g >= number of owners: results unused)
+  const uint32_t dcraw_g = meta[32 + g];
   const int lz = (int)(mg & 0x7Fu);
   const uint32_t dcq_g = j == 0 ? mg >> 16 : 1u;    // the lane holding row pair 0 dequantises x[0][0]
   const bool c3 = lz <= 3, c10 = lz <= 10;
@@ -485,7 +496,7 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32
   for (int n = 0; n < NP; n++) {
     const int rp = j * NP + n;                       // row pair: rows 2rp, 2rp+1
     const int4 w0 = W[n][0], w1 = W[n][1];
-    const uint32_t P8[8] = {n == 0 ? dequant_dc_lo((uint32_t)w0.x, dcq_g) : (uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w,
+    const uint32_t P8[8] = {n == 0 ? dequant_dc_lo((uint32_t)w0.x, dcq_g, j == 0 ? dcraw_g : 0u) : (uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w,
                             (uint32_t)w1.x, (uint32_t)w1.y, (uint32_t)w1.z, (uint32_t)w1.w};   // {x[2rp][c], x[2rp+1][c]}, c = 0..7
     // what the variant selected by last_zzi does not read is zero (pk_mask_by_last_zzi)
 #pragma unroll
@@ -572,10 +583,11 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   const uint8_t *prev = S.prev, *gold = S.gold;
   uint8_t *coded_map = S.coded_map;
   const uint8_t *coded_prev = S.coded_prev;
+  const int16_t *dc_p = S.dc;
   const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2];
   const int debug = S.debug, sqpx = S.qpx, sqpy = S.qpy, skip_ok = S.skip_ok;
   asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
-               "s"(coded_prev), "s"(te0), "s"(te1), "s"(te2), "s"(debug), "s"(sqpx), "s"(sqpy), "s"(skip_ok));
+               "s"(coded_prev), "s"(dc_p), "s"(te0), "s"(te1), "s"(te2), "s"(debug), "s"(sqpx), "s"(sqpy), "s"(skip_ok));
   if (unit >= te2) return;
   const int pli = (unit >= te0 ? 1 : 0) + (unit >= te1 ? 1 : 0);
   // scalar batch 2: the plane's geometry
@@ -605,9 +617,12 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
     // (a neighbour outside the plane reads the block's own flag again)
     touched = (uint32_t)op[0] | op[-dl] | op[dr] | op[-du] | op[dd];
   }
+  // the block's un-predicted DC when it does not travel in the command stream (k_dc_unpredict's output)
+  uint32_t dcv = 0;
+  if (dc_p) dcv = 0x10000u | (uint16_t)dc_p[G.fro + min(by, G.nv - 1) * G.nh + min(bx, G.nh - 1)];
   // all loads are consumed here as far as the compiler can tell, so the scalar load is issued
   // next to the vector loads instead of being sunk behind the wait for them
-  asm volatile("" ::"s"(slot0), "v"(info.x), "v"(touched));
+  asm volatile("" ::"s"(slot0), "v"(info.x), "v"(touched), "v"(dcv));
 #ifdef THIP_TRACE
   THIP_TR(tr, 1);   // first round trip done
 #endif
@@ -616,7 +631,8 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   L.flags = valid ? info.x : 0u;
   // DC dequantisation (state.c:967-979): command word 1 = dc_quant << 16 | raw DC of a DC-only block
   L.dcq = info.y >> 16;
-  L.dcp = ((uint32_t)(((int)(int16_t)(info.y & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;   // {p, p}
+  L.dcraw = dcv;
+  L.dcp = ((uint32_t)(((int)(int16_t)((dcv ? dcv : info.y) & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;   // {p, p}
   L.coded = (L.flags & THIP_INFO_CODED) != 0;
   L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
   L.has_coeff = L.coded && !L.dc_only;
@@ -656,7 +672,7 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   __shared__ uint4 s_coef[THIP_RECON_WG_WAVES * 8 * 64 + THIP_RECON_LDS_PAD / 16];   // [wave][piece][lane]: 8 KB per wave, wave-private
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   uint4 *const lds_wave = s_coef + wave * 512;
-  __shared__ uint32_t s_meta[THIP_RECON_WG_WAVES * 32];
+  __shared__ uint32_t s_meta[THIP_RECON_WG_WAVES * 64];
   PredWin Q;
   bool inter = false;
   const uint8_t *ref = nullptr;
@@ -672,14 +688,14 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
     residual_shared_load<4>(coeffs_p, slot0, nown, lane, W);
     if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
-    residual_shared<4>(W, lds_dw, s_meta + wave * 32, lane, L, prefix, Y);
+    residual_shared<4>(W, lds_dw, s_meta + wave * 64, lane, L, prefix, Y);
     THIP_TR(R.tr, 3);
   } else if (nown <= 32 && !(debug & 32)) {
     int4 W[2][2];
     residual_shared_load<2>(coeffs_p, slot0, nown, lane, W);
     if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
-    residual_shared<2>(W, lds_dw, s_meta + wave * 32, lane, L, prefix, Y);
+    residual_shared<2>(W, lds_dw, s_meta + wave * 64, lane, L, prefix, Y);
     THIP_TR(R.tr, 3);
   } else {
     // ---- many owners: one lane per block.  Coefficients go global -> LDS directly (LDS address
@@ -746,12 +762,12 @@ constexpr int kWalkPitch = 144;                  // LDS image row: 8-byte left m
 constexpr int kWalkImgX0 = 8;                    // byte offset of pixel column 0 in an image row
 constexpr int kWalkFlagOff = 32 * kWalkPitch;    // coded flags: 4 rows of kWalkFlagPitch bytes
 constexpr int kWalkFlagPitch = 20;               // [0] left neighbour's column 15, [1..16] the tile, [17] column 16 (never coded)
-constexpr int kWalkMetaOff = 8192;               // 32 dwords for residual_shared
-constexpr int kWalkEdgeOff = 8320;               // published right edge: 2 buffers x 32 dwords (column bytes 124..127 per row)
-constexpr int kWalkEFlagOff = 8576;              // 2 dwords: coded flags of block column 15, one byte per block row
-constexpr int kWalkPubOff = 8584;                // tiles this wave has published
-constexpr int kWalkConsOff = 8588;               // tiles of this wave its right neighbour has consumed
-constexpr int kWalkWaveLds = 8704;               // per wave, multiple of 16
+constexpr int kWalkMetaOff = 8192;               // 64 dwords for residual_shared
+constexpr int kWalkEdgeOff = 8448;               // published right edge: 2 buffers x 32 dwords (column bytes 124..127 per row)
+constexpr int kWalkEFlagOff = 8704;              // 2 dwords: coded flags of block column 15, one byte per block row
+constexpr int kWalkPubOff = 8712;                // tiles this wave has published
+constexpr int kWalkConsOff = 8716;               // tiles of this wave its right neighbour has consumed
+constexpr int kWalkWaveLds = 8832;               // per wave, multiple of 16
 
 __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -835,6 +851,7 @@ __global__ __launch_bounds__(THIP_WALK_MAXTHREADS) void k_recon_walk(const Batch
   uint8_t *self = S.self;
   const uint8_t *prev = S.prev, *gold = S.gold;
   uint8_t *coded_map = S.coded_map;
+  const int16_t *dc_p = S.dc;
   const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2], ng = S.walk_wgs;
   const int sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
   asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
@@ -915,10 +932,13 @@ __global__ __launch_bounds__(THIP_WALK_MAXTHREADS) void k_recon_walk(const Batch
     const int bx = t * 16 + lx, by = sby * 4 + ly;
     uint8_t *const img = mine + (ly * 8) * kWalkPitch + kWalkImgX0 + lx * 8;   // this lane's block in the tile image
     const bool valid = bx < R.nh && by < R.nv;
+    uint32_t dcv = 0;   // the block's un-predicted DC when it does not travel in the command stream
+    if (dc_p) dcv = 0x10000u | (uint16_t)dc_p[(int)(R.coded_map - coded_map) + min(by, R.nv - 1) * R.nh + min(bx, R.nh - 1)];
     ReconLane L;
     L.flags = valid ? info.x : 0u;
     L.dcq = info.y >> 16;
-    L.dcp = ((uint32_t)(((int)(int16_t)(info.y & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;
+    L.dcraw = dcv;
+    L.dcp = ((uint32_t)(((int)(int16_t)((dcv ? dcv : info.y) & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;
     L.coded = (L.flags & THIP_INFO_CODED) != 0;
     L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
     L.has_coeff = L.coded && !L.dc_only;
@@ -1104,6 +1124,143 @@ __global__ __launch_bounds__(256) void k_lf_seams(const BatchK B) {
   const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
   lf_cell_pin(C);
   lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_dc_unpredict: oc_dec_dc_unpredict_mcu_plane (decode.c:1392-1500) on the device
+// ---------------------------------------------------------------------------------------
+// The predictor of a fragment reads the FINAL DC of its left, up-left, up and up-right neighbours
+// (those that are coded and predicted from the same reference frame), so fragment (x, y) can be done
+// once (x-1, y) and (x+1, y-1) are: all fragments with equal x + 2y are independent -- an anti-diagonal
+// wavefront of slope 2.  One work group per plane, one thread per fragment ROW: a thread walks its row
+// left to right and may take fragment x when the row above has finished fragment x+1; the work group
+// steps in lock-step (one barrier per step, rows publish their progress in LDS), so a plane of
+// nh x nv fragments takes about nh + 2*nv steps instead of nh*nv.
+// What breaks the wavefront is pred_last (decode.c:1448: "default: pred=pred_last[refi]"): a fragment
+// none of whose four neighbours qualifies takes the DC of the LAST fragment with its reference frame in
+// raster order, which may sit at the far right end of the row above.  A thread therefore keeps its own
+// row's last value per reference frame, and when its row has none yet it needs pred_last as it stood at
+// the END of the row above (`carry`, handed down row by row): it waits until that row is complete.  Rows
+// below wait behind it through the same progress test, so the result is exact whatever the picture;
+// key frames never take that branch after row 0, inter frames rarely.
+struct DcPlaneK {
+  const int16_t *in;        // DC values as decoded from the tokens, raster order of the plane
+  int16_t *out;             // un-predicted DC values, raster (may equal `in`: a fragment is read before it is written)
+  const uint8_t *flags;     // raster flags (bit 0 coded, bits 1-2 refi) -- or null:
+  const uint32_t *info;     // ... the stream's tile-ordered command words (word 0 of each pair)
+  int nh, nv, tiles_x, tile_base;
+};
+struct DcBatchK {
+  DcPlaneK p[THIP_MAX_BATCH][3];
+};
+
+__device__ __forceinline__ uint32_t dc_flag(const DcPlaneK &P, int x, int y) {
+  if (P.flags) return P.flags[(size_t)y * P.nh + x] & 7u;
+  const int pos = (P.tile_base + (y >> 2) * P.tiles_x + (x >> 4)) * THIP_TILE_FRAGS + ((x >> 2) & 3) * 16 + hilb_inv(y & 3, x & 3);
+  const uint32_t w = P.info[2 * (size_t)pos];
+  return (w & THIP_INFO_CODED) ? (w & 7u) : 0u;   // coded | refi << 1; an uncoded fragment never matches (refi NONE, decode.c:658)
+}
+
+constexpr int kDcMaxRows = 1024;   // fragment rows per plane the kernel handles (one thread each): 8192 pixels
+
+__global__ __launch_bounds__(kDcMaxRows) void k_dc_unpredict(const DcBatchK B) {
+  const DcPlaneK &P = B.p[blockIdx.y][blockIdx.x];
+  const int nh = P.nh, nv = P.nv;
+  if (nh <= 0 || nv <= 0) return;
+  __shared__ int s_prog[2][kDcMaxRows];        // fragments finished per row, double-buffered by step parity
+  __shared__ short s_carry[kDcMaxRows][4];     // pred_last[refi] as it stands at the end of each row
+  const int y = (int)threadIdx.x;
+  const bool active = y < nv;
+  s_prog[0][y] = active ? 0 : nh;
+  s_prog[1][y] = active ? 0 : nh;
+  __syncthreads();
+  int x = 0;
+  uint32_t f_l = 0, f_ul = 0, f_u = 0, f_ur = 0;    // flags of the neighbours of fragment x (0 = does not count)
+  int d_l = 0, d_ul = 0, d_u = 0, d_ur = 0;         // their final DC values
+  int pl0 = 0, pl1 = 0, pl2 = 0;                    // this row's last DC per reference frame ...
+  uint32_t plv = 0;                                 // ... and which of them exist
+  const int16_t *up_dc = P.out + (size_t)(y > 0 ? y - 1 : 0) * nh;
+  const long long max_steps = (long long)nh * nv + 2 * nv + 8;   // even a fully serial picture ends
+  for (long long step = 0; step < max_steps; step++) {
+    const int cur = (int)(step & 1);
+    if (s_prog[cur][nv - 1] >= nh) break;           // the last row is the last to finish
+    int xn = x;
+    if (active && x < nh) {
+      const int above = y > 0 ? s_prog[cur][y - 1] : nh;
+      if (above >= min(x + 2, nh)) {
+        // the window over the row above slides with x; its new right end is final by the test above
+        if (y > 0) {
+          if (x == 0) {
+            f_u = dc_flag(P, 0, y - 1);
+            d_u = up_dc[0];
+          }
+          if (x + 1 < nh) {
+            f_ur = dc_flag(P, x + 1, y - 1);
+            d_ur = up_dc[x + 1];
+          } else {
+            f_ur = 0;
+          }
+        }
+        const uint32_t f = dc_flag(P, x, y);
+        bool done = true;
+        int dc = 0;
+        if (f & 1u) {
+          const int r = (int)(f >> 1);
+          const int mask = (f_l == f ? 1 : 0) | (f_ul == f ? 2 : 0) | (f_u == f ? 4 : 0) | (f_ur == f ? 8 : 0);
+          int pred = 0;
+          switch (mask) {                                       // decode.c:1450-1485
+            case 0:
+              if (plv >> r & 1u) pred = r == 0 ? pl0 : (r == 1 ? pl1 : pl2);
+              else if (y == 0) pred = 0;                        // decode.c:1367: pred_last starts at 0
+              else if (above >= nh) pred = s_carry[y - 1][r];
+              else done = false;                                // the row above must finish first
+              break;
+            case 1: case 3: pred = d_l; break;
+            case 2: pred = d_ul; break;
+            case 4: case 6: case 12: pred = d_u; break;
+            case 5: pred = (d_l + d_u) / 2; break;
+            case 8: pred = d_ur; break;
+            case 9: case 11: case 13: pred = (75 * d_l + 53 * d_ur) / 128; break;
+            case 10: pred = (d_ul + d_ur) / 2; break;
+            case 14: pred = (3 * (d_ul + d_ur) + 10 * d_u) / 16; break;
+            default:   // 7, 15
+              pred = (29 * (d_l + d_u) - 26 * d_ul) / 32;
+              if (abs(pred - d_u) > 128) pred = d_u;
+              else if (abs(pred - d_l) > 128) pred = d_l;
+              else if (abs(pred - d_ul) > 128) pred = d_ul;
+              break;
+          }
+          if (done) {
+            dc = (int)(short)(P.in[(size_t)y * nh + x] + pred);   // a signed 16-bit bit-field in the reference (state.h:321)
+            P.out[(size_t)y * nh + x] = (int16_t)dc;
+            if (r == 0) pl0 = dc;
+            else if (r == 1) pl1 = dc;
+            else pl2 = dc;
+            plv |= 1u << r;
+          }
+        }
+        if (done) {
+          f_l = f;
+          d_l = dc;
+          f_ul = f_u;
+          d_ul = d_u;
+          f_u = f_ur;
+          d_u = d_ur;
+          xn = x + 1;
+          if (xn == nh) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+              const int own = r == 0 ? pl0 : (r == 1 ? pl1 : pl2);
+              s_carry[y][r] = (short)((plv >> r & 1u) ? own : (y > 0 ? (int)s_carry[y - 1][r] : 0));
+            }
+          }
+        }
+      }
+    }
+    x = xn;
+    if (active) s_prog[cur ^ 1][y] = x;
+    __syncthreads();   // stores of this step are complete and the progress is published before anyone reads either
+  }
 }
 
 // ---------------------------------------------------------------------------------------
