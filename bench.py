@@ -85,6 +85,9 @@ def parse_args():
     ap.add_argument("--size", default="4k", choices=sorted(SIZES))
     ap.add_argument("--content", default="dense", choices=["dense", "smooth", "mixed", "static_bg", "static_1pct", "skip", "zeromv_dc", "intra_dense"])
     ap.add_argument("--streams-per-gpu", type=int, default=4)
+    ap.add_argument("--gop-parallel", type=int, default=1,
+                    help="key-frame intervals of ONE stream decoded side by side (they are independent: a key frame resets "
+                         "both references, decode.c:2947-2955): G decoder states per stream, state g takes intervals g, g+G, ...")
     ap.add_argument("--pool", type=int, default=6, help="distinct inter-frame command streams per stream")
     ap.add_argument("--cpu-frames", type=int, default=288, help="frames of stream 0 the CPU oracle decodes (~10 s at 4K)")
     ap.add_argument("--parity-frames", type=int, default=40, help="frames every timed stream is decoded and compared with the oracle before timing")
@@ -342,15 +345,36 @@ def main():
         descs.append(row)
         balg.append([synth.algorithmic_bytes(geom, f) for f in frames])
     t_gen = time.time() - t_gen
-    states = [theora_amd.State(w, h) for _ in range(S)]
-    plans = [theora_amd.BatchPlan(states, [descs[s][j] for s in range(S)]) for j in range(args.pool + 1)]
+    # A stream's frame sequence: interval n is a key frame followed by KF_INTERVAL-1 inter frames drawn from the pool
+    # (shifted by the interval number, so that consecutive intervals are different pictures).  With
+    # --gop-parallel G every stream has G states; state g decodes intervals g, g+G, g+2G, ...: at step i
+    # it is at frame i % KF_INTERVAL of interval g + G * (i // KF_INTERVAL).
+    G = max(1, args.gop_parallel)
+    states = [theora_amd.State(w, h) for _ in range(S * G)]     # state q = s * G + g
 
-    def frame_of_step(i):
-        return 0 if i % KF_INTERVAL == 0 else 1 + (i % args.pool)
+    def frame_in_interval(j, interval):
+        return 0 if j == 0 else 1 + ((j + 3 * interval) % args.pool)
+
+    def frame_of_state(g, i):
+        return frame_in_interval(i % KF_INTERVAL, g + G * (i // KF_INTERVAL))
+
+    def frame_of_step(i):       # G == 1: the sequence of a stream
+        return frame_of_state(0, i)
+
+    plan_cache = {}
+
+    def plan_for(i):
+        key = tuple(frame_of_state(g, i) for g in range(G))
+        if key not in plan_cache:
+            plan_cache[key] = theora_amd.BatchPlan(states, [descs[s][key[g]] for s in range(S) for g in range(G)])
+        return plan_cache[key]
 
     def run(nsteps, first=0, stream=None):
         for i in range(first, first + nsteps):
-            plans[frame_of_step(i)].submit(stream)
+            plan_for(i).submit(stream)
+
+    def alg_of_step(i, which):
+        return sum(balg[s][frame_of_state(g, i)][which] for s in range(S) for g in range(G))
 
     def sync():
         theora_amd.synchronize()
@@ -373,25 +397,25 @@ def main():
         sync()
         t_cpu, n_cpu, ok, bad = 0.0, 0, True, []
         parity_crcs = []     # of every stream's frame nparity-1: the same at every world size and on every run
-        for s_local, gid in enumerate(shard.stream_ids(rank, world, S)):
+        for q, (s_local, gid, g) in enumerate((sl, gi, gg) for sl, gi in enumerate(shard.stream_ids(rank, world, S)) for gg in range(G)):
             ost = oracle.State(w, h)
             # stream 0 of rank 0 goes on to `cpu_frames` frames for the CPU baseline; the comparison is at frame nparity-1
-            nf = max(nparity, args.cpu_frames) if (rank == 0 and s_local == 0 and not args.no_cpu_baseline) else nparity
+            nf = max(nparity, args.cpu_frames) if (rank == 0 and q == 0 and not args.no_cpu_baseline) else nparity
             for i in range(nf):
-                fr = host_frames[s_local][frame_of_step(i)]
+                fr = host_frames[s_local][frame_of_state(g, i)]
                 ost.refi[:] = fr["refi"]
                 ost.mvs[:] = ((fr["mvx"] & 0xFF) | (fr["mvy"] << 8)).astype(np.int16)
                 t0 = time.perf_counter()
                 ost.decode_frame(fr["frame_type"], fr["coded_fragis"], fr["ncoded"], fr["coeffs"], fr["last_zzi"],
                                  fr["dc_quant"], fr["uncoded_fragis"], fr["flimit"])
-                if rank == 0 and s_local == 0:
+                if rank == 0 and q == 0:
                     t_cpu += time.perf_counter() - t0
                     n_cpu += 1
                 if i == nparity - 1:
                     c = 0
                     for pli in range(3):
                         a = ost.get_plane(oracle.FRAME_PREV, pli)
-                        b = states[s_local].read_plane(states[s_local].ref_idx(theora_amd.FRAME_PREV), pli)
+                        b = states[q].read_plane(states[q].ref_idx(theora_amd.FRAME_PREV), pli)
                         c = zlib.crc32(b.tobytes(), c)
                         if not np.array_equal(a, b):
                             ok = False
@@ -402,9 +426,9 @@ def main():
         if not ok_all:
             raise SystemExit("bench: GPU output differs from the oracle %s -- refusing to report a number" % bad[:4])
         parity = {"frames": nparity, "bit_exact": True,
-                  "checked": "the timed batch itself: all %d streams of every rank, decoded %d frames deep by the timed "
+                  "checked": "the timed batch itself: all %d streams of every rank%s, decoded %d frames deep by the timed "
                              "states in the timed launch shape (one thip_decode_frames call per step), every plane of "
-                             "every stream against the oracle" % (S, nparity)}
+                             "every stream against the oracle" % (S, " (x %d key-frame intervals side by side)" % G if G > 1 else "", nparity)}
         if rank == 0 and not args.no_cpu_baseline:
             cpu_baseline = {"value": round(n_cpu / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                             "sample": "%d frames of one %s %s stream through oracle/theora_oracle.c "
@@ -429,6 +453,8 @@ def main():
     # number, so the block is repeated (at least `repeats` times and until ~0.3 s of GPU time has been
     # measured); `value` comes from the MEDIAN block, min and max are reported beside it.
     step0 = nparity
+    for i in range(step0, step0 + 3 * KF_INTERVAL * 2):   # every combination the timed steps can ask for exists before the clock starts
+        plan_for(i)
     run(args.warmup, first=step0)
     step0 += args.warmup
     sync()
@@ -486,7 +512,7 @@ def main():
     # ---- the same measurement on the content class SURVEY section 8d defines from the reference's own
     #      statistics (66 % coded, 80 % of the coded blocks DC-only): a second keyed entry on the line ------
     second = None
-    if args.second_content and args.second_content != args.content:
+    if args.second_content and args.second_content != args.content and G == 1:
         descs2, balg2, keep2 = [], [], []
         for gid in shard.stream_ids(rank, world, S):
             rng = np.random.default_rng(shard.stream_seed(12345, gid))
@@ -533,11 +559,11 @@ def main():
         first_timed = nparity + args.warmup
         med_i = int(np.argsort(blocks)[len(blocks) // 2])
         rng_steps = range(first_timed + med_i * args.steps, first_timed + (med_i + 1) * args.steps)
-        steps_b_alg = sum(balg[s][frame_of_step(i)][0] for i in rng_steps for s in range(S))
-        steps_b_read = sum(balg[s][frame_of_step(i)][1] for i in rng_steps for s in range(S))
+        steps_b_alg = sum(alg_of_step(i, 0) for i in rng_steps)
+        steps_b_read = sum(alg_of_step(i, 1) for i in rng_steps)
         first_prof = first_timed + len(blocks) * args.steps
-        prof_b_alg = sum(balg[s][frame_of_step(i)][0] for i in range(first_prof, first_prof + prof_steps) for s in range(S))
-        total_frames = args.steps * S * world
+        prof_b_alg = sum(alg_of_step(i, 0) for i in range(first_prof, first_prof + prof_steps))
+        total_frames = args.steps * S * G * world
         fps = total_frames / elapsed
         out = {
             "metric": "decode frames/sec (%s 4:2:0, bit-exact)" % args.size,
@@ -552,9 +578,11 @@ def main():
             "vs_baseline": None,
             "dtype": "i16",
             "data": "synthetic",
-            "config": {"workload": "%s (%dx%d coded) 4:2:0, %d concurrent streams per GPU, keyframe interval %d, "
+            "config": {"workload": "%s (%dx%d coded) 4:2:0, %d concurrent streams per GPU%s, keyframe interval %d, "
                                    "content class '%s' (seeded fragment command streams resident in HBM), "
-                                   "loop filter on (flimit 2)" % (args.size, w, h, S, KF_INTERVAL, args.content),
+                                   "loop filter on (flimit 2)" % (args.size, w, h, S, (", %d key-frame intervals of each stream decoded "
+                                                                  "side by side" % G) if G > 1 else "", KF_INTERVAL, args.content),
+                       "gop_parallel": G,
                        "streams_per_gpu": S, "frame_pool": args.pool, "parallelism": "stream-sharded x%d" % world,
                        "process_group": ("nccl (RCCL %s), world %d" % (".".join(map(str, torch.cuda.nccl.version())), world))
                        if dist.is_initialized() else None},
