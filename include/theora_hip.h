@@ -204,6 +204,18 @@ int thip_state_loop_filter_frag_rows(thip_state *st, int flimit, int refi, int p
                                      int fragy_end);
 /* Upload, launch, rotate the ring.  Returns 0 or THIP_DUPFRAME. */
 int thip_frame_flush(thip_state *st);
+/* Token form of the oc_state_frag_recon slot: what decode.c:1540-1581 does between the token lists and
+   the call -- zero fill, scatter through the zig-zag table, `(ogg_int16_t)(coeff*ac_quant[zzi])`
+   (decode.c:1573) -- moves to the device (k_expand_tokens).  The caller hands over the fragment's tokens
+   as they delimit it: toks[k] = zig-zag position (1..63) << 16 | quantised value (low 16 bits, two's
+   complement), ntoks <= 63, in any order, zero-valued ones left out; `dc` is the fragment's DC exactly as
+   dct_coeffs[0] would carry it; dqsel names one of the frame's AC dequantisation tables
+   (thip_frame_dequant_table: 64 entries in zig-zag order, the reference's dequant[pli][qii][qti],
+   decode.c:1537-1538; sel 0..17, valid until the flush).  4 bytes per non-zero coefficient cross PCIe
+   instead of 128 per block.  Fragments of one frame may arrive through either form. */
+int thip_frame_dequant_table(thip_state *st, int sel, const uint16_t dequant[64]);
+int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const uint32_t *toks, int ntoks,
+                                 int16_t dc, int last_zzi, uint16_t dc_quant, int dqsel, int refi, int16_t mv);
 /* on != 0: the DC coefficient handed to thip_state_frag_recon (dct_coeffs[0]) is the value decoded from
    the tokens, NOT yet un-predicted: the caller skips its oc_dec_dc_unpredict_mcu_plane calls
    (decode.c:2869) and thip_frame_flush undoes the prediction on the device before reconstructing

@@ -133,6 +133,11 @@ typedef struct {
    instead of by th_decode_packetin on the host; the pictures are the same.  TH_EIMPL for planes of more
    than 1024 fragment rows.  The environment variable THIP_FE_DEVICE_DC=1 sets it for every new context. */
 #define TH_DECCTL_THIP_SET_DEVICE_DC (0x7102)
+/* Extension: buf = int.  Non-zero: th_decode_packetin only delimits each fragment's DCT tokens; their
+   expansion into 64 coefficients and the AC dequantisation (decode.c:1540-1581) happen on the GPU
+   (thip_state_frag_recon_tokens / k_expand_tokens), and 4 bytes per non-zero coefficient cross PCIe
+   instead of 128 per block.  THIP_FE_DEVICE_TOKENS=1 sets it for every new context. */
+#define TH_DECCTL_THIP_SET_DEVICE_TOKENS (0x7103)
 typedef struct thip_slot_trace {
   int64_t ncoded;           /* state_frag_recon calls, in call (= coded) order */
   const int32_t *fragi;     /* _fragi */

@@ -12,7 +12,7 @@ from tests import streamgen, util
 pytestmark = pytest.mark.gpu
 
 
-def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=False):
+def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=False, device_tokens=False):
     import ctypes as C
     from theora_amd.decoder import Decoder
     st = streamgen.Stream(w, h, fmt, seed, trees=trees)
@@ -20,6 +20,9 @@ def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=Fa
     if device_dc:   # TH_DECCTL_THIP_SET_DEVICE_DC: the DC prediction is undone on the GPU, not in th_decode_packetin
         on = C.c_int(1)
         assert dec._L.th_decode_ctl(dec._dec, 0x7102, C.byref(on), C.sizeof(on)) == 0
+    if device_tokens:   # TH_DECCTL_THIP_SET_DEVICE_TOKENS: token expansion + AC dequantisation on the GPU
+        on = C.c_int(1)
+        assert dec._L.th_decode_ctl(dec._dec, 0x7103, C.byref(on), C.sizeof(on)) == 0
     assert dec.info.frame_width == w and dec.info.frame_height == h and dec.info.pixel_fmt == fmt
     assert dec.comment.vendor == b"theora-hip streamgen"
     ost = oracle.State(w, h, fmt)
@@ -53,6 +56,16 @@ def test_packets_decode_bit_exact_with_dc_unprediction_on_the_gpu(hip, w, h, fmt
     """The same streams with spec 7.8 / decode.c:1392-1500 left to the backend (k_dc_unpredict): the host
     front end hands the slots the DC values as the tokens carry them."""
     assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_dc=True) >= 3
+
+
+@pytest.mark.parametrize("device_dc", [False, True])
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (1280, 720, 0)])
+def test_packets_decode_bit_exact_with_token_expansion_on_the_gpu(hip, w, h, fmt, device_dc):
+    """The same streams with decode.c:1540-1581 (tokens -> 64 dequantised coefficients in natural order) left to
+    the backend (k_expand_tokens): the host only delimits each fragment's tokens; also together with the DC
+    un-prediction on the GPU."""
+    assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_dc=device_dc,
+                      device_tokens=True) >= 3
 
 
 def test_packets_decode_bit_exact_720p(hip):

@@ -76,6 +76,8 @@ SYMBOLS = [
     ("thip_loop_filter_plane", _I, [_P, _I, _I, _I, _P, _I, _I, _I]),
     ("thip_dc_unpredict_plane", _I, [_P, _P, _I, _I]),
     ("thip_state_set_device_dc", _I, [_P, _I]),
+    ("thip_frame_dequant_table", _I, [_P, _I, _P]),
+    ("thip_state_frag_recon_tokens", _I, [_P, C.c_ssize_t, _I, _P, _I, C.c_int16, _I, C.c_uint16, _I, _I, C.c_int16]),
     ("thip_enc_frag_metric_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _U32, _I64]),
     ("thip_enc_frag_border_ssd_batch", _I, [_P, _P, _P, _I, _P, _P, _P, _I64]),
     ("thip_enc_frag_sub_batch", _I, [_P, _P, _P, _I, _P, _P, _I64]),

@@ -99,6 +99,12 @@ struct thip_state {
   uint8_t *h_flags, *d_flags;   // ... and the fragments' coded | refi << 1 in fragment-index order (the staged command
                                 // words stay in host memory: the wavefront kernel must not poll them across PCIe)
   int flush_flags;              // set while thip_frame_flush runs: d_flags describes the frame being launched
+  // token form of the slot (thip_state_frag_recon_tokens): tokens, per-slot {first token, count | table << 8}, tables
+  uint32_t *h_tok, *d_tok;
+  uint32_t *h_slot_tok, *d_slot_tok;
+  uint16_t *h_dq, *d_dq;
+  size_t tok_cap;
+  int enq_ntok, enq_tok_slots, enq_dense_slots;
 };
 
 namespace {
@@ -359,6 +365,12 @@ void thip_state_free(thip_state *st) {
   if (st->d_dc_in) (void)hipFree(st->d_dc_in);
   if (st->h_dc) (void)hipHostFree(st->h_dc);
   if (st->h_flags) (void)hipHostFree(st->h_flags);
+  if (st->h_tok) (void)hipHostFree(st->h_tok);
+  if (st->h_slot_tok) (void)hipHostFree(st->h_slot_tok);
+  if (st->h_dq) (void)hipHostFree(st->h_dq);
+  if (st->d_tok) (void)hipFree(st->d_tok);
+  if (st->d_slot_tok) (void)hipFree(st->d_slot_tok);
+  if (st->d_dq) (void)hipFree(st->d_dq);
   if (st->d_flags) (void)hipFree(st->d_flags);
   free(st->enq_last_lane);
   free(st->frag_pos);
@@ -938,6 +950,7 @@ int thip_frame_begin(thip_state *st, int frame_type) {
     st->enq_lf_y0[p] = 0x7FFFFFFF;
     st->enq_lf_y1[p] = -1;
   }
+  st->enq_ntok = st->enq_tok_slots = st->enq_dense_slots = 0;
   st->enq_device_dc = st->device_dc;
   if (st->enq_device_dc) {
     if (!st->h_dc) HIP_TRY(hipHostMalloc((void **)&st->h_dc, sizeof(int16_t) * (size_t)st->nfrags, hipHostMallocDefault));
@@ -979,6 +992,8 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
     else if (st->enq_last_tile != tile) return THIP_EINVAL;   // a tile's slots must be contiguous
     st->enq_last_lane[tile] = lane;
     st->enq_last_tile = tile;
+    if (st->enq_tok_slots) return THIP_EINVAL;   // the frame's coefficient slots come from the token form (expanded on the device)
+    st->enq_dense_slots++;
     const int slot = st->enq_nslots++;
     // piece q = 2*j+h of the block: columns c = 4h..4h+3 as pairs { x[2j][c], x[2j+1][c] }, i.e. the
     // low (h = 0) and high (h = 1) halves of rows 2j and 2j+1 interleaved: two shuffles per row pair
@@ -999,6 +1014,79 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
     st->h_flags[fragi] = (uint8_t)(1u | (uint32_t)refi << 1);
   }
   memset(dct_coeffs, 0, 64 * sizeof(int16_t));   // idct.c:245,276,295
+  st->h_info[2 * (size_t)pos] = flags;
+  st->h_info[2 * (size_t)pos + 1] = word1;
+  st->enq_ncoded++;
+  return THIP_OK;
+}
+
+static int ensure_token_staging(thip_state *st) {
+  if (st->h_tok) return THIP_OK;
+  st->tok_cap = (size_t)st->nfrags * 63;   // every coefficient of every block non-zero
+  const size_t ngroups = ((size_t)st->nfrags + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
+  HIP_TRY(hipHostMalloc((void **)&st->h_tok, st->tok_cap * 4 + 64 * 4, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&st->h_slot_tok, ngroups * 64 * 8, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&st->h_dq, 18 * 64 * 2, hipHostMallocDefault));
+  HIP_TRY(hipMalloc((void **)&st->d_tok, st->tok_cap * 4 + 64 * 4));
+  HIP_TRY(hipMalloc((void **)&st->d_slot_tok, ngroups * 64 * 8));
+  HIP_TRY(hipMalloc((void **)&st->d_dq, 18 * 64 * 2));
+  memset(st->h_dq, 0, 18 * 64 * 2);
+  return THIP_OK;
+}
+
+int thip_frame_dequant_table(thip_state *st, int sel, const uint16_t dequant[64]) {
+  if (!st || !dequant) return THIP_EFAULT;
+  if (!st->enq_active || sel < 0 || sel >= 18) return THIP_EINVAL;
+  DeviceGuard dg(st->device);
+  const int rc = ensure_token_staging(st);
+  if (rc) return rc;
+  memcpy(st->h_dq + sel * 64, dequant, 128);
+  return THIP_OK;
+}
+
+int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const uint32_t *toks, int ntoks, int16_t dc,
+                                 int last_zzi, uint16_t dc_quant, int dqsel, int refi, int16_t mv) {
+  if (!st || (!toks && ntoks)) return THIP_EFAULT;
+  if (!st->enq_active || fragi < 0 || fragi >= st->nfrags || pli < 0 || pli > 2 || refi < 0 || refi > 2 ||
+      last_zzi < 0 || last_zzi > 64 || ntoks < 0 || ntoks > 63 || dqsel < 0 || dqsel >= 18 ||
+      (int64_t)st->enq_ncoded + st->enq_nuncoded >= st->nfrags)
+    return THIP_EINVAL;
+  if (st->enq_dense_slots) return THIP_EINVAL;   // (see thip_state_frag_recon: one form per frame for the coefficient slots)
+  const int32_t pos = st->frag_pos[fragi];
+  if (st->h_info[2 * (size_t)pos] & THIP_INFO_CODED) return THIP_EINVAL;   // fragment enqueued twice
+  uint32_t flags = THIP_INFO_CODED | ((uint32_t)refi << THIP_INFO_REFI_SHIFT) |
+                   ((uint32_t)last_zzi << THIP_INFO_LAST_ZZI_SHIFT) |
+                   ((uint32_t)(uint8_t)(mv & 0xFF) << THIP_INFO_MVX_SHIFT) |
+                   ((uint32_t)(uint8_t)((mv >> 8) & 0xFF) << THIP_INFO_MVY_SHIFT);
+  uint32_t word1 = (uint32_t)dc_quant << 16;
+  if (last_zzi < 2) {
+    flags |= THIP_INFO_DC_ONLY;
+    word1 |= (uint32_t)(uint16_t)dc;
+  } else {
+    if (!st->h_tok) {
+      DeviceGuard dg(st->device);
+      const int rc = ensure_token_staging(st);
+      if (rc) return rc;
+    }
+    const int tile = pos / THIP_TILE_FRAGS, lane = pos % THIP_TILE_FRAGS;
+    if (lane <= st->enq_last_lane[tile]) return THIP_EINVAL;
+    if (st->enq_last_lane[tile] < 0) st->h_slot0[tile] = (uint32_t)st->enq_nslots;
+    else if (st->enq_last_tile != tile) return THIP_EINVAL;   // a tile's slots must be contiguous
+    st->enq_last_lane[tile] = lane;
+    st->enq_last_tile = tile;
+    const int slot = st->enq_nslots++;
+    st->enq_tok_slots++;
+    uint32_t *t = st->h_tok + st->enq_ntok;
+    t[0] = (uint32_t)(uint16_t)dc;                       // position 0: the raw DC
+    for (int k = 0; k < ntoks; k++) t[1 + k] = toks[k];
+    st->h_slot_tok[2 * (size_t)slot] = (uint32_t)st->enq_ntok;
+    st->h_slot_tok[2 * (size_t)slot + 1] = (uint32_t)(ntoks + 1) | (uint32_t)dqsel << 8;
+    st->enq_ntok += ntoks + 1;
+  }
+  if (st->enq_device_dc) {
+    st->h_dc[fragi] = dc;
+    st->h_flags[fragi] = (uint8_t)(1u | (uint32_t)refi << 1);
+  }
   st->h_info[2 * (size_t)pos] = flags;
   st->h_info[2 * (size_t)pos + 1] = word1;
   st->enq_ncoded++;
@@ -1081,6 +1169,21 @@ int thip_frame_flush(thip_state *st) {
   d.ncoded = st->enq_ncoded;
   d.frame_type = st->enq_frame_type;
   d.flimit = st->enq_lf_any ? st->enq_flimit : 0;
+  if (st->enq_tok_slots) {
+    // tokens -> device, expanded there into the coefficient slots k_recon reads (decode.c:1540-1581)
+    HIP_TRY(hipMemcpyAsync(st->d_tok, st->h_tok, (size_t)st->enq_ntok * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(st->d_slot_tok, st->h_slot_tok, (size_t)st->enq_nslots * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(st->d_dq, st->h_dq, 18 * 64 * 2, hipMemcpyHostToDevice, s));
+    TokK T;
+    T.tok = st->d_tok;
+    T.slot_tok = reinterpret_cast<const uint2 *>(st->d_slot_tok);
+    T.dq = st->d_dq;
+    T.coeffs = reinterpret_cast<int4 *>(st->d_coeffs);
+    T.nslots = st->enq_nslots;
+    hipLaunchKernelGGL(k_expand_tokens, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, T);
+    HIP_TRY(hipGetLastError());
+    d.coeffs = st->d_coeffs;
+  }
   if (st->enq_device_dc && st->enq_ncoded) {
     // (the wavefront kernel reads a value per thread per step: a device copy, not reads across PCIe)
     HIP_TRY(hipMemcpyAsync(st->d_dc_in, st->h_dc, sizeof(int16_t) * (size_t)st->nfrags, hipMemcpyHostToDevice, s));

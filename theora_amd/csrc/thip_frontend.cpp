@@ -206,6 +206,7 @@ struct th_dec_ctx {
   int granpos_bias;
   bool have_frame;
   bool device_dc;   // DC un-prediction left to the backend (THIP_FE_DEVICE_DC=1, or TH_DECCTL_THIP_SET_DEVICE_DC)
+  bool device_tokens;   // token -> coefficient expansion and AC dequantisation left to the backend (THIP_FE_DEVICE_TOKENS=1, ctl)
   std::vector<uint8_t> mirror[3];
   th_stripe_callback stripe_cb;
   // slot-trace mode (THIP_FE_TRACE_BACKEND=1 at th_decode_alloc): no device state exists; the
@@ -953,6 +954,7 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   d->device_dc = false;
   if (d->hip && getenv("THIP_FE_DEVICE_DC") && atoi(getenv("THIP_FE_DEVICE_DC")) != 0)
     d->device_dc = thip_state_set_device_dc(d->hip, 1) == 0;   // (refused for planes of more than 1024 fragment rows)
+  d->device_tokens = d->hip && getenv("THIP_FE_DEVICE_TOKENS") && atoi(getenv("THIP_FE_DEVICE_TOKENS")) != 0;
   build_geometry(d);
   d->dequant.resize((size_t)64 * 3 * 2 * 64);
   for (int qi = 0; qi < 64; qi++)
@@ -1030,6 +1032,13 @@ int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
       const int on = *(int *)buf != 0;
       if (thip_state_set_device_dc(d->hip, on) < 0) return TH_EIMPL;
       d->device_dc = on != 0;
+      return 0;
+    }
+    case TH_DECCTL_THIP_SET_DEVICE_TOKENS: {
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(int)) return TH_EINVAL;
+      if (d->trace || !d->hip) return TH_EINVAL;
+      d->device_tokens = *(int *)buf != 0;
       return 0;
     }
     case TH_DECCTL_THIP_GET_SLOT_TRACE: {
@@ -1401,8 +1410,18 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   }
   const int flimit = d->setup.qp.lflims[d->qis[0]];
   d->tr_flimit = flimit;
+  const bool use_tokens = d->device_tokens && !d->trace;
+  if (use_tokens) {   // the frame's AC dequantisation tables (decode.c:1358-1366): number = (plane * 3 + qii) * 2 + qti
+    for (int p = 0; p < 3; p++)
+      for (int qii = 0; qii < d->nqis; qii++)
+        for (int qti = 0; qti < 2; qti++)
+          if (thip_frame_dequant_table(d->hip, (p * 3 + qii) * 2 + qti,
+                                       &d->dequant[(((size_t)d->qis[qii] * 3 + p) * 2 + qti) * 64]) < 0)
+            return TH_EFAULT;
+  }
   {
     alignas(16) int16_t block[128];
+    uint32_t toks[64];
     memset(block, 0, sizeof(block));
     for (int p = 0; p < 3; p++) {
       const Tok *tp[64];   // next token of every index list (each list ends in an endless EOB run)
@@ -1416,7 +1435,31 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         const int qti = d->mbmode_of_frag[f] != MODE_INTRA;
         const uint16_t *acq = &d->dequant[(((size_t)d->qis[d->qii[f]] * 3 + p) * 2 + qti) * 64];
         const uint16_t dcq = d->dequant[(((size_t)d->qis[0] * 3 + p) * 2 + qti) * 64];
-        int z = 0, last_zzi = 0;
+        int z = 0, last_zzi = 0, ntok = 0;
+        if (use_tokens) {
+          // The tokens only get delimited here: which of them belong to this block.  Zero fill, zig-zag
+          // scatter and `value * ac_quant` (decode.c:1573) happen on the device (k_expand_tokens).
+          while (z < 64) {
+            last_zzi = z;
+            if (run[z]) {
+              run[z]--;
+              break;
+            }
+            const Tok &t = *tp[z]++;
+            if (t.eob) {
+              run[z] = t.eob - 1;
+              break;
+            }
+            const int at = z + t.skip;
+            if (t.value != 0 && at >= 1 && at <= 63) toks[ntok++] = (uint32_t)at << 16 | (uint16_t)t.value;
+            z += t.adv;
+          }
+          const int16_t mvt = (int16_t)(((int)d->mvx[f] & 0xFF) | ((int)d->mvy[f] * 256));
+          rc = thip_state_frag_recon_tokens(d->hip, f, p, toks, ntok, d->dc[f], last_zzi, dcq, (p * 3 + d->qii[f]) * 2 + qti,
+                                            d->refi[f], mvt);
+          if (rc < 0) return TH_EFAULT;
+          continue;
+        }
         while (z < 64) {
           last_zzi = z;
           if (run[z]) {   // inside an EOB run at this index

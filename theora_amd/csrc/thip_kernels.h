@@ -1264,6 +1264,67 @@ __global__ __launch_bounds__(kDcMaxRows) void k_dc_unpredict(const DcBatchK B) {
 }
 
 // ---------------------------------------------------------------------------------------
+// k_expand_tokens: token -> coefficient expansion and AC dequantisation on the device
+// ---------------------------------------------------------------------------------------
+// What oc_dec_frags_recon_mcu_plane does per coded fragment before it calls oc_state_frag_recon
+// (decode.c:1540-1581): the block's DCT tokens become 64 coefficients -- zeros, and at the zig-zag
+// position of each token its value times the AC quantiser of that position, `(ogg_int16_t)(coeff *
+// ac_quant[zzi])` (decode.c:1573) -- in natural order (dct_fzig_zag, decode.c:1574).  Here the host has
+// only delimited the tokens (which tokens belong to which fragment is a serial walk through the per-index
+// lists with their shared end-of-block runs, decode.c:1544-1570, that stays with the entropy decoder);
+// what crosses PCIe is 4 bytes per non-zero coefficient instead of a 128-byte block, and the zero fill,
+// the scatter through the zig-zag table, the dequantisation and the tile layout happen here.
+// One wave per group of 64 coefficient slots: lane = slot; the group's 8 KB image is built in LDS in the
+// piece-major layout k_recon wants and written out with eight coalesced 1 KB stores per wave.
+struct TokK {
+  const uint32_t *tok;       // zig-zag position << 16 | quantised value (16 bits, two's complement); position 0: the raw DC
+  const uint2 *slot_tok;     // per slot: first token, count | dequant table number << 8
+  const uint16_t *dq;        // up to 18 tables of 64, zig-zag order (oc_dequant tables, pli x qii x qti)
+  int4 *coeffs;              // out: slot groups of 8192 bytes
+  int nslots;
+};
+// natural position of zig-zag index i (internal.c:27, OC_FZIG_ZAG), four per dword
+__device__ __forceinline__ int fzig_zag(int i) {
+  constexpr uint8_t T[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  return T[i];
+}
+__global__ __launch_bounds__(256) void k_expand_tokens(const TokK K) {
+  __shared__ int4 s_img[4 * 512];                 // [wave][piece q][lane]: 8 KB per wave
+  __shared__ uint16_t s_dq[18 * 64];
+  for (int i = (int)threadIdx.x; i < 18 * 64; i += 256) s_dq[i] = K.dq[i];
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int group = (int)blockIdx.x * 4 + wave;
+  int4 *img = s_img + wave * 512;
+#pragma unroll
+  for (int q = 0; q < 8; q++) img[q * 64 + lane] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  const int slot = group * 64 + lane;
+  if (slot < K.nslots) {
+    const uint2 st = K.slot_tok[slot];
+    const uint32_t *t = K.tok + st.x;
+    const int n = (int)(st.y & 0xFFu), sel = (int)(st.y >> 8) & 31;
+    const uint16_t *dq = s_dq + sel * 64;
+    int16_t *mine = reinterpret_cast<int16_t *>(img);
+    for (int k = 0; k < n; k++) {
+      const uint32_t w = t[k];
+      const int zz = (int)(w >> 16) & 63, v = (int)(int16_t)(w & 0xFFFFu);
+      const int c = zz == 0 ? v : (int)(int16_t)(v * (int)dq[zz]);     // decode.c:1573; the DC stays raw (state.c:967-979)
+      const int nat = fzig_zag(zz), r = nat >> 3, col = nat & 7;
+      // piece q = 2*(r>>1) + (col>>2) at q*1024 + lane*16; inside it the pairs {x[2j][c], x[2j+1][c]}
+      mine[((2 * (r >> 1) + (col >> 2)) * 1024 + lane * 16 + ((col & 3) * 2 + (r & 1)) * 2) >> 1] = (int16_t)c;
+    }
+  }
+  __syncthreads();
+  if ((size_t)group * 64 < (size_t)K.nslots) {
+    int4 *out = K.coeffs + (size_t)group * 512;
+#pragma unroll
+    for (int q = 0; q < 8; q++) out[q * 64 + lane] = img[q * 64 + lane];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_loopfilter (K3): one filter cell per lane over the whole frame
 // ---------------------------------------------------------------------------------------
 // One wave never straddles two planes (the cumulative cell counts in StreamK::cell_end are
