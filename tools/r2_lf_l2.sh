@@ -1,4 +1,5 @@
 #!/bin/bash
+# (FETCH_SIZE alone per pass: it takes 3 of the 4 TCC counter slots; with TCC_HIT/MISS beside it rocprofv3 never finishes.)
 # Does k_loopfilter find k_recon's pixels in the XCD's L2?  Kernel times and FETCH_SIZE / hit rate per launch shape.
 export TMPDIR=/tmp
 out=gpurun_out/lf_l2
@@ -10,7 +11,7 @@ for cfg in "2 8" "2 1" "1 8" "1 1" "4 1"; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('$tag', 'fps', d['value'], 'ms/step', d['ms_per_step'], 'recon_us', r['avg_launch_us'], 'lf_us', r['loopfilter_avg_launch_us'])"
-  THIP_LANES=$1 THIP_CHUNK=$2 timeout 300 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/$tag -- python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-profile > $out/$tag.log 2>&1
+  THIP_LANES=$1 THIP_CHUNK=$2 timeout 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$tag -- python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-profile > $out/$tag.log 2>&1
   python - $out/$tag <<'PY'
 import csv, glob, sys, collections
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
