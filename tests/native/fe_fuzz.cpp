@@ -25,6 +25,13 @@ int thip_frame_flush(thip_state *) { return -1; }
 int thip_state_ycbcr_out(thip_state *, uint8_t *const *, const int32_t *) { return -1; }
 int thip_state_ycbcr_map(thip_state *, const uint8_t **, int32_t *) { return -1; }
 int thip_state_set_eager_output(thip_state *, int) { return -1; }
+int thip_state_create_on(thip_state **, int, int, int, int) { return -1; }
+int thip_device_count(void) { return 0; }
+int thip_state_set_device_dc(thip_state *, int) { return -1; }
+int thip_frame_dequant_table(thip_state *, int, const uint16_t *) { return -1; }
+int thip_state_frag_recon_tokens(thip_state *, ptrdiff_t, int, const uint32_t *, int, int16_t, int, uint16_t, int, int, int16_t) {
+  return -1;
+}
 }
 
 static uint32_t g_rng;
