@@ -98,6 +98,19 @@ int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strid
    device (bench.py, transcoding) pays nothing. */
 int thip_state_set_eager_output(thip_state *st, int on);
 
+/* Out-of-loop post-processing of the most recently decoded frame (decode.c:1608-1957: oc_dec_deblock_frag_rows,
+   oc_dec_dering_frag_rows, driven by the MCU loop at decode.c:2893-2911): level as TH_DECCTL_SET_PPLEVEL
+   (theoradec.h:40-75; decode.c:32-48: 2 de-block Y, 3 de-ring Y, 4 strong de-ring Y, 5-7 the same for chroma;
+   0 and 1 change no pixel).  dc_qis[f]: the quantiser index in force when fragment f was last coded
+   (decode.c:1220-1243); frag_qi[f] = qis[frags[f].qii] (decode.c:1926); pp_dc_scale / pp_sharp_mod: the
+   decoder's tables (quant.c:88, decode.c:398-409).  All four are HOST arrays.  The decoded frame itself is not
+   touched (it stays the reference for the next frames); thip_state_ycbcr_map / _out hand out the post-processed
+   picture until the next frame is decoded. */
+int thip_state_postprocess(thip_state *st, int level, const uint8_t *dc_qis, const uint8_t *frag_qi,
+                           const int32_t pp_dc_scale[64], const int32_t pp_sharp_mod[64]);
+/* Synchronous copy of one plane of that picture, tightly packed, bitstream row order (tests). */
+int thip_state_read_pp_plane(thip_state *st, int pli, uint8_t *host_out);
+
 /* ------------------------------------------------------------------------------------
  * Work tiles.  The device walks a frame in the reference's CODED ORDER (state.c:123-190):
  * a tile is 4 consecutive super blocks of one super-block row of one plane -- 16x4

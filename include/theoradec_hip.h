@@ -11,8 +11,8 @@
  * lib/decode.c:2858-2962 drives oc_state_frag_recon / oc_frag_copy_list /
  * oc_state_loop_filter_frag_rows.
  *
- * Not provided (out of scope): post-processing levels > 0, the telemetry
- * requests, the legacy theora_* API, th_granule_* helpers beyond th_granule_frame, the encoder.
+ * Not provided (out of scope): the telemetry requests, the legacy theora_* API,
+ * th_granule_* helpers beyond th_granule_frame and th_granule_time, the encoder.
  */
 #ifndef THEORADEC_HIP_H
 #define THEORADEC_HIP_H
@@ -106,7 +106,11 @@ void th_comment_add_tag(th_comment *tc, const char *tag, const char *value);
 char *th_comment_query(th_comment *tc, const char *tag, int count);        /* value of the count-th TAG=, or NULL */
 int th_comment_query_count(th_comment *tc, const char *tag);
 
-/* th_decode_ctl requests that are honoured (theoradec.h:40-105) */
+/* th_decode_ctl requests that are honoured (theoradec.h:40-105).  TH_DECCTL_GET_PPLEVEL_MAX answers 7 and
+   TH_DECCTL_SET_PPLEVEL takes 0..7 as the reference does (decode.c:32-48, :1989-1997): the de-blocking and
+   de-ringing filters of decode.c:1608-1957 run on the GPU (thip_state_postprocess) and th_decode_ycbcr_out
+   hands out the post-processed picture; like the reference, a level set between two key frames takes
+   effect at the next key frame (decode.c:1221-1223). */
 #define TH_DECCTL_GET_PPLEVEL_MAX (1)
 #define TH_DECCTL_SET_PPLEVEL (3)
 #define TH_DECCTL_SET_GRANPOS (5)

@@ -88,6 +88,9 @@ def lib():
     L.orc_enc_frag_copy2.argtypes = [P, P, P, C.c_int]
     L.orc_enc_frag_border_ssd.restype = C.c_uint
     L.orc_enc_frag_border_ssd.argtypes = [P, P, C.c_int, C.c_int64]
+    L.orc_postprocess_frame.argtypes = [C.POINTER(_State), C.c_int, C.c_int, C.c_int, P, P, P, P, P, P]
+    L.orc_pp_deblock_frag_rows.argtypes = [P, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, C.c_int, C.c_int]
+    L.orc_pp_dering_frag_rows.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int]
     # the single-block encoder slots (tests/test_gpu_slots.py compares thip_enc1_* with them one call at a time)
     U = C.c_uint
     for name, res, args in (("orc_enc_frag_sad", U, [P, P, C.c_int]), ("orc_enc_frag_sad_thresh", U, [P, P, C.c_int, U]),
@@ -173,6 +176,21 @@ class State:
         for pli in range(3):
             pred_last = np.zeros(3, np.int32)
             self._L.orc_dc_unpredict_rows(self._st, pli, 0, self.planes[pli]["nvfrags"], _p(pred_last))
+
+    def postprocess(self, slot, level, loop_filter, dc_qis, frag_qi, pp_dc_scale, pp_sharp_mod):
+        """Out-of-loop post-processing (decode.c:1608-1957) of the frame in `slot`, driven MCU by MCU with the
+        reference's row delays (decode.c:2858-2945).  Returns ([Y, Cb, Cr] in bitstream row order, variances)."""
+        sizes = [g["width"] * g["height"] for g in self.planes]
+        out = np.zeros(sum(sizes), np.uint8)
+        var = np.zeros(self.nfrags, np.int32)
+        self._L.orc_postprocess_frame(self._st, slot, level, int(bool(loop_filter)), _p(_c(dc_qis, np.uint8)),
+                                      _p(_c(frag_qi, np.uint8)), _p(_c(pp_dc_scale, np.int32)), _p(_c(pp_sharp_mod, np.int32)),
+                                      _p(out), _p(var))
+        planes, off = [], 0
+        for g, n in zip(self.planes, sizes):
+            planes.append(out[off:off + n].reshape(g["height"], g["width"]).copy())
+            off += n
+        return planes, var
 
     def loop_filter_rows(self, flimit, slot, pli, fragy0, fragy_end):
         bv = np.zeros(256, np.int8)

@@ -639,6 +639,295 @@ int orc_decode_frame(orc_state *st, int frame_type, const ptrdiff_t *coded_fragi
 }
 
 /* ------------------------------------------------------------------------- */
+/* out-of-loop post-processing, decode.c:1608-1957                            */
+/* ------------------------------------------------------------------------- */
+
+#define ORC_MINI(a, b) ((a) < (b) ? (a) : (b))
+#define ORC_CLAMPI(a, b, c) ((b) < (a) ? (a) : ((b) > (c) ? (c) : (b)))
+
+/* decode.c:1610-1661 */
+static void pp_filter_hedge(uint8_t *dst, int dst_ystride, const uint8_t *src, int src_ystride, int qstep, int flimit,
+                            int *variance0, int *variance1) {
+  uint8_t *rdst = dst;
+  const uint8_t *rsrc = src;
+  int bx, by;
+  for (bx = 0; bx < 8; bx++) {
+    uint8_t *cdst = rdst;
+    const uint8_t *csrc = rsrc;
+    int r[10], sum0 = 0, sum1 = 0;
+    for (by = 0; by < 10; by++) {
+      r[by] = *csrc;
+      csrc += src_ystride;
+    }
+    for (by = 0; by < 4; by++) {
+      sum0 += abs(r[by + 1] - r[by]);
+      sum1 += abs(r[by + 5] - r[by + 6]);
+    }
+    *variance0 += ORC_MINI(255, sum0);
+    *variance1 += ORC_MINI(255, sum1);
+    if (sum0 < flimit && sum1 < flimit && r[5] - r[4] < qstep && r[4] - r[5] < qstep) {
+      *cdst = (uint8_t)((r[0] * 3 + r[1] * 2 + r[2] + r[3] + r[4] + 4) >> 3);
+      cdst += dst_ystride;
+      *cdst = (uint8_t)((r[0] * 2 + r[1] + r[2] * 2 + r[3] + r[4] + r[5] + 4) >> 3);
+      cdst += dst_ystride;
+      for (by = 0; by < 4; by++) {
+        *cdst = (uint8_t)((r[by] + r[by + 1] + r[by + 2] + r[by + 3] * 2 + r[by + 4] + r[by + 5] + r[by + 6] + 4) >> 3);
+        cdst += dst_ystride;
+      }
+      *cdst = (uint8_t)((r[4] + r[5] + r[6] + r[7] * 2 + r[8] + r[9] * 2 + 4) >> 3);
+      cdst += dst_ystride;
+      *cdst = (uint8_t)((r[5] + r[6] + r[7] + r[8] * 2 + r[9] * 3 + 4) >> 3);
+    } else {
+      for (by = 1; by <= 8; by++) {
+        *cdst = (uint8_t)r[by];
+        cdst += dst_ystride;
+      }
+    }
+    rdst++;
+    rsrc++;
+  }
+}
+
+/* decode.c:1663-1694 */
+static void pp_filter_vedge(uint8_t *dst, int dst_ystride, int qstep, int flimit, int *variances) {
+  uint8_t *cdst = dst;
+  int bx, by;
+  for (by = 0; by < 8; by++) {
+    const uint8_t *rsrc = cdst - 1;
+    uint8_t *rdst = cdst;
+    int r[10], sum0 = 0, sum1 = 0;
+    for (bx = 0; bx < 10; bx++) r[bx] = *rsrc++;
+    for (bx = 0; bx < 4; bx++) {
+      sum0 += abs(r[bx + 1] - r[bx]);
+      sum1 += abs(r[bx + 5] - r[bx + 6]);
+    }
+    variances[0] += ORC_MINI(255, sum0);
+    variances[1] += ORC_MINI(255, sum1);
+    if (sum0 < flimit && sum1 < flimit && r[5] - r[4] < qstep && r[4] - r[5] < qstep) {
+      *rdst++ = (uint8_t)((r[0] * 3 + r[1] * 2 + r[2] + r[3] + r[4] + 4) >> 3);
+      *rdst++ = (uint8_t)((r[0] * 2 + r[1] + r[2] * 2 + r[3] + r[4] + r[5] + 4) >> 3);
+      for (bx = 0; bx < 4; bx++)
+        *rdst++ = (uint8_t)((r[bx] + r[bx + 1] + r[bx + 2] + r[bx + 3] * 2 + r[bx + 4] + r[bx + 5] + r[bx + 6] + 4) >> 3);
+      *rdst++ = (uint8_t)((r[4] + r[5] + r[6] + r[7] * 2 + r[8] + r[9] * 2 + 4) >> 3);
+      *rdst = (uint8_t)((r[5] + r[6] + r[7] + r[8] * 2 + r[9] * 3 + 4) >> 3);
+    }
+    cdst += dst_ystride;
+  }
+}
+
+/* decode.c:1696-1786.  dst / src: pixel (0,0) of the plane in bitstream coordinates, any stride sign;
+   variances and dc_qis: the plane's own rows (already offset by froffset). */
+void orc_pp_deblock_frag_rows(uint8_t *dst_data, int dst_ystride, const uint8_t *src_data, int src_ystride, int width, int height,
+                              int nhfrags, int nvfrags, int *variances, const uint8_t *dc_qis, const int pp_dc_scale[64],
+                              int fragy0, int fragy_end) {
+  int *variance = variances + (ptrdiff_t)fragy0 * nhfrags;
+  const uint8_t *dc_qi = dc_qis + (ptrdiff_t)fragy0 * nhfrags;
+  int notstart = fragy0 > 0, notdone = fragy_end < nvfrags;
+  int flimit, qstep, y_end, y, x;
+  uint8_t *dst;
+  const uint8_t *src;
+  /* "We want to clear an extra row of variances, except at the end." */
+  if (fragy_end + notdone - fragy0 - notstart > 0)
+    memset(variance + (nhfrags & -notstart), 0, (size_t)(fragy_end + notdone - fragy0 - notstart) * ((size_t)nhfrags * sizeof(variance[0])));
+  y = (fragy0 << 3) + (notstart << 2);
+  dst = dst_data + y * (ptrdiff_t)dst_ystride;
+  src = src_data + y * (ptrdiff_t)src_ystride;
+  for (; y < 4; y++) {
+    memcpy(dst, src, (size_t)width);
+    dst += dst_ystride;
+    src += src_ystride;
+  }
+  y_end = (fragy_end - !notdone) << 3;
+  for (; y < y_end; y += 8) {
+    qstep = pp_dc_scale[*dc_qi];
+    flimit = (qstep * 3) >> 2;
+    pp_filter_hedge(dst, dst_ystride, src - src_ystride, src_ystride, qstep, flimit, variance, variance + nhfrags);
+    variance++;
+    dc_qi++;
+    for (x = 8; x < width; x += 8) {
+      qstep = pp_dc_scale[*dc_qi];
+      flimit = (qstep * 3) >> 2;
+      pp_filter_hedge(dst + x, dst_ystride, src + x - src_ystride, src_ystride, qstep, flimit, variance, variance + nhfrags);
+      pp_filter_vedge(dst + x - (dst_ystride * 4) - 4, dst_ystride, qstep, flimit, variance - 1);
+      variance++;
+      dc_qi++;
+    }
+    dst += dst_ystride * 8;
+    src += src_ystride * 8;
+  }
+  if (!notdone) {
+    for (; y < height; y++) {
+      memcpy(dst, src, (size_t)width);
+      dst += dst_ystride;
+      src += src_ystride;
+    }
+    dc_qi++;
+    for (x = 8; x < width; x += 8) {
+      qstep = pp_dc_scale[*dc_qi++];
+      flimit = (qstep * 3) >> 2;
+      pp_filter_vedge(dst + x - (dst_ystride * 8) - 4, dst_ystride, qstep, flimit, variance++);
+    }
+  }
+}
+
+/* decode.c:1788-1890 */
+static void pp_dering_block(uint8_t *idata, int ystride, int b, int dc_scale, int sharp_mod, int strong) {
+  static const unsigned char MOD_MAX[2] = {24, 32};
+  static const unsigned char MOD_SHIFT[2] = {1, 0};
+  const uint8_t *psrc, *src, *nsrc;
+  uint8_t *dst;
+  int vmod[72], hmod[72];
+  int mod_hi, by, bx;
+  mod_hi = ORC_MINI(3 * dc_scale, MOD_MAX[strong]);
+  dst = idata;
+  src = dst;
+  psrc = src - (ystride & -!(b & 4));
+  for (by = 0; by < 9; by++) {
+    for (bx = 0; bx < 8; bx++) {
+      int mod = 32 + dc_scale - (abs(src[bx] - psrc[bx]) << MOD_SHIFT[strong]);
+      vmod[(by << 3) + bx] = mod < -64 ? sharp_mod : ORC_CLAMPI(0, mod, mod_hi);
+    }
+    psrc = src;
+    src += ystride & -(!(b & 8) | (by < 7));
+  }
+  nsrc = dst;
+  psrc = dst - !(b & 1);
+  for (bx = 0; bx < 9; bx++) {
+    src = nsrc;
+    for (by = 0; by < 8; by++) {
+      int mod = 32 + dc_scale - (abs(*src - *psrc) << MOD_SHIFT[strong]);
+      hmod[(bx << 3) + by] = mod < -64 ? sharp_mod : ORC_CLAMPI(0, mod, mod_hi);
+      psrc += ystride;
+      src += ystride;
+    }
+    psrc = nsrc;
+    nsrc += !(b & 2) | (bx < 7);
+  }
+  src = dst;
+  psrc = src - (ystride & -!(b & 4));
+  nsrc = src + ystride;
+  for (by = 0; by < 8; by++) {
+    int a, bb, w;
+    a = 128; bb = 64;
+    w = hmod[by]; a -= w; bb += w * *(src - !(b & 1));
+    w = vmod[by << 3]; a -= w; bb += w * psrc[0];
+    w = vmod[(by + 1) << 3]; a -= w; bb += w * nsrc[0];
+    w = hmod[(1 << 3) + by]; a -= w; bb += w * src[1];
+    dst[0] = (uint8_t)ORC_CLAMPI(0, (a * src[0] + bb) >> 7, 255);
+    for (bx = 1; bx < 7; bx++) {
+      a = 128; bb = 64;
+      w = hmod[(bx << 3) + by]; a -= w; bb += w * src[bx - 1];
+      w = vmod[(by << 3) + bx]; a -= w; bb += w * psrc[bx];
+      w = vmod[((by + 1) << 3) + bx]; a -= w; bb += w * nsrc[bx];
+      w = hmod[((bx + 1) << 3) + by]; a -= w; bb += w * src[bx + 1];
+      dst[bx] = (uint8_t)ORC_CLAMPI(0, (a * src[bx] + bb) >> 7, 255);
+    }
+    a = 128; bb = 64;
+    w = hmod[(7 << 3) + by]; a -= w; bb += w * src[6];
+    w = vmod[(by << 3) + 7]; a -= w; bb += w * psrc[7];
+    w = vmod[((by + 1) << 3) + 7]; a -= w; bb += w * nsrc[7];
+    w = hmod[(8 << 3) + by]; a -= w; bb += w * src[7 + !(b & 2)];
+    dst[7] = (uint8_t)ORC_CLAMPI(0, (a * src[7] + bb) >> 7, 255);
+    dst += ystride;
+    psrc = src;
+    src = nsrc;
+    nsrc += ystride & -(!(b & 8) | (by < 6));
+  }
+}
+
+#define ORC_DERING_THRESH1 (384)
+#define ORC_DERING_THRESH2 (4 * ORC_DERING_THRESH1)
+#define ORC_DERING_THRESH3 (5 * ORC_DERING_THRESH1)
+#define ORC_DERING_THRESH4 (10 * ORC_DERING_THRESH1)
+
+/* decode.c:1897-1957.  frag_qi[f] = qis[frags[f].qii] (decode.c:1926), the plane's own rows. */
+void orc_pp_dering_frag_rows(uint8_t *img_data, int ystride, int width, int height, int nhfrags, const int *variances,
+                             const uint8_t *frag_qi, const int pp_dc_scale[64], const int pp_sharp_mod[64], int strong, int pli,
+                             int fragy0, int fragy_end) {
+  const int *variance = variances + (ptrdiff_t)fragy0 * nhfrags;
+  const uint8_t *fq = frag_qi + (ptrdiff_t)fragy0 * nhfrags;
+  int sthresh = pli ? ORC_DERING_THRESH4 : ORC_DERING_THRESH3;
+  int y = fragy0 << 3, y_end = fragy_end << 3, x;
+  uint8_t *idata = img_data + y * (ptrdiff_t)ystride;
+  for (; y < y_end; y += 8) {
+    for (x = 0; x < width; x += 8) {
+      int qi = *fq, var = *variance;
+      int b = (x <= 0) | (x + 8 >= width) << 1 | (y <= 0) << 2 | (y + 8 >= height) << 3;
+      if (strong && var > sthresh) {
+        pp_dering_block(idata + x, ystride, b, pp_dc_scale[qi], pp_sharp_mod[qi], 1);
+        if (pli || (!(b & 1) && *(variance - 1) > ORC_DERING_THRESH4) || (!(b & 2) && variance[1] > ORC_DERING_THRESH4) ||
+            (!(b & 4) && *(variance - nhfrags) > ORC_DERING_THRESH4) || (!(b & 8) && variance[nhfrags] > ORC_DERING_THRESH4)) {
+          pp_dering_block(idata + x, ystride, b, pp_dc_scale[qi], pp_sharp_mod[qi], 1);
+          pp_dering_block(idata + x, ystride, b, pp_dc_scale[qi], pp_sharp_mod[qi], 1);
+        }
+      } else if (var > ORC_DERING_THRESH2) {
+        pp_dering_block(idata + x, ystride, b, pp_dc_scale[qi], pp_sharp_mod[qi], 1);
+      } else if (var > ORC_DERING_THRESH1) {
+        pp_dering_block(idata + x, ystride, b, pp_dc_scale[qi], pp_sharp_mod[qi], 0);
+      }
+      fq++;
+      variance++;
+    }
+    idata += (ptrdiff_t)ystride * 8;
+  }
+}
+
+/* Post-processing of the frame in reference slot `slot` as th_decode_packetin's MCU loop drives it
+   (decode.c:2858-2945): per MCU and plane, de-blocking one fragment row behind the loop filter and
+   de-ringing one row behind that (sdelay / edelay), into `out` (three tightly packed planes, bitstream row
+   order).  level: decode.c:32-48 (2 de-block Y, 3 de-ring Y, 4 strong Y, 5-7 the same for chroma); planes
+   below their level are copies of the reference frame's (decode.c:1319-1323).  dc_qis, frag_qi: per fragment. */
+void orc_postprocess_frame(const orc_state *st, int slot, int level, int loop_filter, const uint8_t *dc_qis,
+                           const uint8_t *frag_qi, const int pp_dc_scale[64], const int pp_sharp_mod[64], uint8_t *out,
+                           int *variances) {
+  int bufi = st->ref_frame_idx[slot];
+  int mcu_nvfrags = 4 << st->vdec;
+  int pli, stripe, notstart = 0, notdone = 1;
+  uint8_t *pp[3];
+  size_t off = 0;
+  for (pli = 0; pli < 3; pli++) {
+    const orc_plane_geom *g = st->fplanes + pli;
+    int y;
+    pp[pli] = out + off;
+    off += (size_t)g->width * g->height;
+    /* planes that are not post-processed: the reference's own (decode.c:1319-1323, :1380-1382) */
+    if (level < 2 + 3 * (pli != 0))
+      for (y = 0; y < g->height; y++)
+        memcpy(pp[pli] + (size_t)y * g->width, st->ref_plane_data[bufi][pli] + (ptrdiff_t)y * g->stride, (size_t)g->width);
+  }
+  for (stripe = 0; notdone; stripe += mcu_nvfrags) {
+    notdone = stripe + mcu_nvfrags < st->fplanes[0].nvfrags;
+    for (pli = 0; pli < 3; pli++) {
+      const orc_plane_geom *g = st->fplanes + pli;
+      int frag_shift = pli != 0 && st->vdec;
+      int fragy0 = stripe >> frag_shift;
+      int fragy_end = fragy0 + (mcu_nvfrags >> frag_shift);
+      int sdelay = 0, edelay = 0, pp_offset = 3 * (pli != 0);
+      if (fragy_end > g->nvfrags) fragy_end = g->nvfrags;
+      if (loop_filter) {
+        sdelay += notstart;
+        edelay += notdone;
+      }
+      if (level >= 2 + pp_offset) {                          /* decode.c:2895-2911 */
+        sdelay += notstart;
+        edelay += notdone;
+        orc_pp_deblock_frag_rows(pp[pli], g->width, st->ref_plane_data[bufi][pli], g->stride, g->width, g->height,
+                                 g->nhfrags, g->nvfrags, variances + g->froffset, dc_qis + g->froffset, pp_dc_scale,
+                                 fragy0 - sdelay, fragy_end - edelay);
+        if (level >= 3 + pp_offset) {
+          sdelay += notstart;
+          edelay += notdone;
+          orc_pp_dering_frag_rows(pp[pli], g->width, g->width, g->height, g->nhfrags, variances + g->froffset,
+                                  frag_qi + g->froffset, pp_dc_scale, pp_sharp_mod, level >= (pli ? 7 : 4), pli,
+                                  fragy0 - sdelay, fragy_end - edelay);
+        }
+      }
+    }
+    notstart = 1;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* encoder block kernels, encfrag.c / fdct.c                                  */
 /* ------------------------------------------------------------------------- */
 

@@ -130,6 +130,16 @@ int orc_decode_frame(orc_state *st, int frame_type, const ptrdiff_t *coded_fragi
                      ptrdiff_t nuncoded, int flimit);
 
 /* ---- encoder block kernels (oc_enc_opt_vtable, encint.h:292-326) ---- */
+/* out-of-loop post-processing (decode.c:1608-1957), test infrastructure like the rest */
+void orc_pp_deblock_frag_rows(uint8_t *dst_data, int dst_ystride, const uint8_t *src_data, int src_ystride, int width, int height,
+                              int nhfrags, int nvfrags, int *variances, const uint8_t *dc_qis, const int pp_dc_scale[64],
+                              int fragy0, int fragy_end);
+void orc_pp_dering_frag_rows(uint8_t *img_data, int ystride, int width, int height, int nhfrags, const int *variances,
+                             const uint8_t *frag_qi, const int pp_dc_scale[64], const int pp_sharp_mod[64], int strong, int pli,
+                             int fragy0, int fragy_end);
+void orc_postprocess_frame(const orc_state *st, int slot, int level, int loop_filter, const uint8_t *dc_qis,
+                           const uint8_t *frag_qi, const int pp_dc_scale[64], const int pp_sharp_mod[64], uint8_t *out,
+                           int *variances);
 void orc_enc_frag_sub(int16_t diff[64], const uint8_t *src, const uint8_t *ref, int ystride);   /* encfrag.c:21 */
 void orc_enc_frag_sub_128(int16_t diff[64], const uint8_t *src, int ystride);                   /* encfrag.c:32 */
 unsigned orc_enc_frag_sad(const uint8_t *src, const uint8_t *ref, int ystride);                 /* encfrag.c:42 */

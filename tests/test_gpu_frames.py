@@ -479,3 +479,64 @@ def test_dc_unprediction_on_the_device(hip, w, h, fmt, enqueue):
             keep.append((ka, dct))
             assert hip.decode_frames([gst], [desc]) == [0]
         assert not util.planes_equal(ost, gst), f
+
+
+def _pp_case(rng, w, h, fmt, smooth):
+    ost = oracle.State(w, h, fmt)
+    ost.set_ref_idx(0, 0, 0)
+    planes = []
+    for pli in range(3):
+        g = ost.planes[pli]
+        if smooth:   # flat blocks with small steps: the de-blocking conditions fire, the variances stay low
+            base = rng.integers(60, 200, (g["nvfrags"], g["nhfrags"]))
+            img = np.kron(base, np.ones((8, 8), np.int64)) + rng.integers(-2, 3, (g["height"], g["width"]))
+        else:        # texture: high variances, de-ringing in all its strengths
+            base = rng.integers(40, 220, (g["nvfrags"], g["nhfrags"]))
+            img = np.kron(base, np.ones((8, 8), np.int64)) + rng.integers(-40, 41, (g["height"], g["width"])) * (rng.random((g["height"], g["width"])) < 0.5)
+        a = np.clip(img, 0, 255).astype(np.uint8)
+        ost.set_plane(oracle.FRAME_PREV, pli, a)
+        planes.append(a)
+    return ost, planes
+
+
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, PF_420), (48, 80, PF_444), (80, 64, PF_422), (16, 16, PF_420), (176, 144, PF_420),
+                                     (336, 272, PF_420), (1280, 720, PF_420)])
+def test_postprocessing(hip, w, h, fmt):
+    """TH_DECCTL_SET_PPLEVEL's filters on the device (thip_state_postprocess: k_pp_hedge, k_pp_vedge, k_pp_dering;
+    decode.c:1608-1957) against the oracle driven MCU by MCU as th_decode_packetin drives them: every level, flat
+    and textured pictures (all three de-ringing strengths, one and three passes), random per-fragment quantiser
+    indices, every plane of the post-processed picture; the decoded frame itself must stay untouched."""
+    import ctypes as C
+    from theora_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(w + 3 * h + fmt)
+    levels = range(0, 8) if w < 1000 else (7,)
+    for smooth in (True, False):
+        ost, planes = _pp_case(rng, w, h, fmt, smooth)
+        gst = hip.State(w, h, fmt)
+        for pli in range(3):
+            gst.write_plane(0, pli, planes[pli])
+        gst.set_ref_idx(0, 0, 0)
+        n = ost.nfrags
+        dc_qis = rng.integers(0, 64, n).astype(np.uint8)
+        frag_qi = rng.integers(0, 64, n).astype(np.uint8)
+        dcs = np.sort(rng.integers(1, 90, 64))[::-1].astype(np.int32).copy()
+        shm = (-rng.integers(0, 6, 64)).astype(np.int32)
+        for level in levels:
+            want, _ = ost.postprocess(oracle.FRAME_PREV, level, 1, dc_qis, frag_qi, dcs, shm)
+            assert L.thip_state_postprocess(gst.handle, level, dc_qis.ctypes.data, frag_qi.ctypes.data, dcs.ctypes.data,
+                                            shm.ctypes.data) == 0
+            if level >= 2:
+                for pli in range(3):
+                    g = gst.planes[pli]
+                    got = np.empty((g["height"], g["width"]), np.uint8)
+                    assert L.thip_state_read_pp_plane(gst.handle, pli, got.ctypes.data) == 0
+                    assert np.array_equal(got, want[pli]), (smooth, level, pli, int((got != want[pli]).sum()))
+            out = gst.ycbcr_out()            # what th_decode_ycbcr_out hands out: the post-processed picture, top row first
+            for pli in range(3):
+                assert np.array_equal(out[pli], want[pli][::-1]), (smooth, level, pli)
+                assert np.array_equal(gst.read_plane(0, pli), planes[pli])   # the reference frame is not touched
+        if not smooth and w >= 64:
+            want7, var = ost.postprocess(oracle.FRAME_PREV, 7, 1, dc_qis, frag_qi, dcs, shm)
+            assert (var > 5 * 384).any() and (var > 384).any()   # the strong and the three-pass branches were taken
+        ost.close()

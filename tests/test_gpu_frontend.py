@@ -358,3 +358,75 @@ def test_contexts_release_their_device_memory(hip):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+def _pp_tables(setup):
+    """pp_dc_scale and pp_sharp_mod from the setup header, following quant.c:88 (the inter / Cr pass is the last to
+    write it) and decode.c:398-409, independently of the library."""
+    from tests.streamgen import ZIGZAG
+    dcs, shm = np.zeros(64, np.int32), np.zeros(64, np.int32)
+    for qi in range(64):
+        sizes, bmis = setup.qr[(1, 2)]
+        qri, start = 0, 0
+        while qri < len(sizes) - 1 and qi > start + sizes[qri]:
+            start += sizes[qri]
+            qri += 1
+        size, end = sizes[qri], start + sizes[qri]
+        base0 = (2 * (end - qi) * int(setup.bms[bmis[qri]][0]) + 2 * (qi - start) * int(setup.bms[bmis[qri + 1]][0]) + size) // (2 * size)
+        dcs[qi] = setup.dcscale[qi] * base0 // 160
+        qsum = 0
+        for qti in range(2):
+            for pli in range(3):
+                zz = setup.qmat(qti, pli, qi)[ZIGZAG]     # dequant table in zig-zag order
+                qsum += int(zz[12] + zz[17] + zz[18] + zz[24]) << (1 if pli == 0 else 0)
+        shm[qi] = -(qsum >> 11)
+    return dcs, shm
+
+
+@pytest.mark.parametrize("w,h,fmt,level", [(176, 144, 0, 7), (64, 48, 0, 2), (48, 64, 3, 4), (80, 48, 2, 6), (176, 144, 0, 1),
+                                           (336, 32, 0, 7)])
+def test_postprocessing_through_th_decode_ctl(hip, w, h, fmt, level):
+    """TH_DECCTL_SET_PPLEVEL on real packets: the level is set before the first key frame; th_decode_ycbcr_out must
+    hand out the oracle's post-processed picture (oracle.State.postprocess on the oracle's own decode, the DC
+    quantiser indices tracked as decode.c:1220-1243 does, frag_qi = qis[qii] with stale qii for uncoded blocks)
+    while the references keep decoding bit-exactly underneath (inter frames follow)."""
+    import ctypes as C
+    from theora_amd.decoder import Decoder
+    st = streamgen.Stream(w, h, fmt, seed=w + h + level)
+    dec = Decoder(st.header_packets())
+    mx = C.c_int(-1)
+    assert dec._L.th_decode_ctl(dec._dec, 1, C.byref(mx), C.sizeof(mx)) == 0 and mx.value == 7     # TH_DECCTL_GET_PPLEVEL_MAX
+    bad = C.c_int(8)
+    assert dec._L.th_decode_ctl(dec._dec, 3, C.byref(bad), C.sizeof(bad)) == -10                   # TH_EINVAL
+    lv = C.c_int(level)
+    assert dec._L.th_decode_ctl(dec._dec, 3, C.byref(lv), C.sizeof(lv)) == 0                       # TH_DECCTL_SET_PPLEVEL
+    dcs, shm = _pp_tables(st.setup)
+    ost = oracle.State(w, h, fmt)
+    n = ost.nfrags
+    dc_qis, qii_persist, qis_persist = None, np.zeros(n, np.int64), [0, 0, 0]
+    for f in range(8):
+        pkt, truth = st.frame(0 if f % 5 == 0 else 1, density=[0.9, 0.5, 0.15][f % 3])
+        rc, _ = dec.packetin(pkt)
+        if truth["dup"]:
+            assert rc == 1
+        else:
+            assert rc == 0
+            assert ost.decode_frame(**st.oracle_inputs(truth, ost)) == 0
+            cf = truth["coded_fragis"]
+            for k, q in enumerate(truth["qis"]):
+                qis_persist[k] = int(q)
+            qii_persist[cf] = truth["qii"][cf]
+            if dc_qis is None:
+                if truth["frame_type"] == 0:
+                    dc_qis = np.full(n, truth["qis"][0], np.uint8)
+            else:
+                dc_qis[cf] = truth["qis"][0]
+            if level >= 2 and dc_qis is not None:
+                frag_qi = np.array(qis_persist, np.uint8)[qii_persist]
+                want, _ = ost.postprocess(oracle.FRAME_PREV, level, truth["flimit"] != 0, dc_qis, frag_qi, dcs, shm)
+            else:
+                want = [ost.get_plane(oracle.FRAME_PREV, p) for p in range(3)]
+        got = dec.ycbcr_out()
+        for pli in range(3):
+            assert np.array_equal(got[pli], want[pli][::-1]), (f, pli, int((got[pli] != want[pli][::-1]).sum()))
+    dec.close()

@@ -225,3 +225,61 @@ def test_golden_sequence_digest():
             c = zlib.crc32(st.get_plane(oracle.FRAME_PREV, pli).tobytes(), c)
         got.append("%08x" % c)
     assert got == want["crc32"]
+
+
+def _pp_inputs(rng, st, smooth):
+    """A picture with block structure (so that the de-blocking conditions fire), per-fragment quantiser indices and
+    the two post-processing tables (decode.c:397-408, quant.c:88)."""
+    for pli in range(3):
+        g = st.planes[pli]
+        if smooth:   # flat blocks with small steps between them: every edge passes the flimit / qstep tests
+            base = rng.integers(60, 200, (g["nvfrags"], g["nhfrags"]))
+            img = np.kron(base, np.ones((8, 8), np.int64)) + rng.integers(-1, 2, (g["height"], g["width"]))
+        else:
+            img = rng.integers(0, 256, (g["height"], g["width"]))
+        st.set_plane(oracle.FRAME_PREV, pli, np.clip(img, 0, 255).astype(np.uint8))
+    dc_qis = rng.integers(0, 64, st.nfrags).astype(np.uint8)
+    frag_qi = rng.integers(0, 64, st.nfrags).astype(np.uint8)
+    pp_dc_scale = np.sort(rng.integers(1, 90, 64))[::-1].astype(np.int32)
+    pp_sharp_mod = -rng.integers(0, 6, 64).astype(np.int32)
+    return dc_qis, frag_qi, pp_dc_scale, pp_sharp_mod
+
+
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (48, 80, 3), (80, 64, 2), (16, 16, 0), (176, 144, 0)])
+def test_postprocessing_is_independent_of_the_mcu_chunking(w, h, fmt):
+    """oc_dec_deblock_frag_rows / oc_dec_dering_frag_rows are called MCU by MCU with one-row delays
+    (decode.c:2895-2911); a device backend runs them once over the whole frame.  The restatement driven the
+    reference's way equals the same functions called once per plane over all fragment rows -- pictures and
+    variances -- for every level, with and without the loop-filter delay."""
+    rng = np.random.default_rng(w + h + fmt)
+    L = oracle.lib()
+    for smooth in (True, False):
+        st = oracle.State(w, h, fmt)
+        st.set_ref_idx(0, 0, 0)
+        dc_qis, frag_qi, dcs, shm = _pp_inputs(rng, st, smooth)
+        for level in range(2, 8):
+            for lf in (0, 1):
+                got, var = st.postprocess(oracle.FRAME_PREV, level, lf, dc_qis, frag_qi, dcs, shm)
+                for pli in range(3):
+                    g = st.planes[pli]
+                    src = st.get_plane(oracle.FRAME_PREV, pli)
+                    if level < 2 + 3 * (pli != 0):
+                        assert np.array_equal(got[pli], src)
+                        continue
+                    dst = np.zeros_like(src)
+                    v = np.zeros(g["nfrags"], np.int32)
+                    lo = g["froffset"]
+                    L.orc_pp_deblock_frag_rows(dst.ctypes.data, g["width"], src.ctypes.data, g["width"], g["width"], g["height"],
+                                               g["nhfrags"], g["nvfrags"], v.ctypes.data,
+                                               np.ascontiguousarray(dc_qis[lo:lo + g["nfrags"]]).ctypes.data, dcs.ctypes.data,
+                                               0, g["nvfrags"])
+                    if level >= 3 + 3 * (pli != 0):
+                        L.orc_pp_dering_frag_rows(dst.ctypes.data, g["width"], g["width"], g["height"], g["nhfrags"], v.ctypes.data,
+                                                  np.ascontiguousarray(frag_qi[lo:lo + g["nfrags"]]).ctypes.data, dcs.ctypes.data,
+                                                  shm.ctypes.data, int(level >= (7 if pli else 4)), pli, 0, g["nvfrags"])
+                    assert np.array_equal(got[pli], dst), (smooth, level, lf, pli)
+                    assert np.array_equal(var[lo:lo + g["nfrags"]], v), (smooth, level, lf, pli)
+        # the filters do something on this content
+        got, var = st.postprocess(oracle.FRAME_PREV, 7, 1, dc_qis, frag_qi, dcs, shm)
+        assert any(not np.array_equal(got[p], st.get_plane(oracle.FRAME_PREV, p)) for p in range(3))
+        st.close()

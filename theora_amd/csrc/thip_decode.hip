@@ -54,6 +54,7 @@ using namespace thip;
   } while (0)
 
 #include "thip_kernels.h"
+#include "thip_postproc.h"
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -105,6 +106,13 @@ struct thip_state {
   uint16_t *h_dq, *d_dq;
   size_t tok_cap;
   int enq_ntok, enq_tok_slots, enq_dense_slots;
+  // out-of-loop post-processing (thip_state_postprocess): the post-processed picture, the per-fragment
+  // variances and quantiser indices, which planes of which decoded frame the picture holds
+  uint8_t *pp_frame;
+  int *pp_var;
+  uint8_t *pp_qis;          // device, 2 * nfrags: dc_qis, then frag_qi
+  int64_t pp_serial;        // frame_serial of the frame pp_frame was made from, -1 if none
+  int pp_active[3];
 };
 
 namespace {
@@ -338,6 +346,7 @@ int thip_state_create_on(thip_state **out, int device, int frame_width, int fram
   st->out_serial = -1;
   st->buf_serial[0] = st->buf_serial[1] = st->buf_serial[2] = -1;
   st->map_serial[0] = st->map_serial[1] = -1;
+  st->pp_serial = -1;
   *out = st;
   return THIP_OK;
 }
@@ -362,6 +371,9 @@ void thip_state_free(thip_state *st) {
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
   if (st->d_slot0) (void)hipFree(st->d_slot0);
   if (st->d_dc) (void)hipFree(st->d_dc);
+  if (st->pp_frame) (void)hipFree(st->pp_frame);
+  if (st->pp_var) (void)hipFree(st->pp_var);
+  if (st->pp_qis) (void)hipFree(st->pp_qis);
   if (st->d_dc_in) (void)hipFree(st->d_dc_in);
   if (st->h_dc) (void)hipHostFree(st->h_dc);
   if (st->h_flags) (void)hipHostFree(st->h_flags);
@@ -447,7 +459,7 @@ int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *hos
 // The finished frame -> pinned host memory in display order.  One thread moves 8 bytes (plane
 // widths are multiples of 8); a wave writes 512 contiguous bytes.
 struct OutK {
-  const uint8_t *src;
+  const uint8_t *src[3];   // per plane: the decoded frame, or the post-processed picture (thip_state_postprocess)
   uint8_t *dst;
   int width[3], height[3], stride[3], src_off[3], dst_off[3], unit_end[3];
 };
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(256) void k_frame_out(const OutK K) {
   const int wu = K.width[p] >> 3;
   const int y = v / wu, x = v - y * wu;
   // the device keeps row 0 at the bottom of the picture (decode.c:2988-2992 flips pointers instead)
-  const uint2 val = *reinterpret_cast<const uint2 *>(K.src + K.src_off[p] + (size_t)(K.height[p] - 1 - y) * K.stride[p] + x * 8);
+  const uint2 val = *reinterpret_cast<const uint2 *>(K.src[p] + K.src_off[p] + (size_t)(K.height[p] - 1 - y) * K.stride[p] + x * 8);
   *reinterpret_cast<uint2 *>(K.dst + K.dst_off[p] + (size_t)y * K.width[p] + x * 8) = val;
 }
 
@@ -494,7 +506,8 @@ static int launch_frame_out(thip_state *st, hipStream_t s) {
   if (!st->h_out[nb]) HIP_TRY(hipHostMalloc((void **)&st->h_out[nb], st->frame_bytes, hipHostMallocDefault));
   if (!st->ev_out) HIP_TRY(hipEventCreateWithFlags(&st->ev_out, hipEventDisableTiming));
   OutK K;
-  K.src = st->frames[st->last_decoded];
+  const bool pp = st->pp_serial == st->frame_serial;
+  for (int p = 0; p < 3; p++) K.src[p] = pp && st->pp_active[p] ? st->pp_frame : st->frames[st->last_decoded];
   K.dst = st->h_out[nb];
   int units = 0, off = 0;
   for (int p = 0; p < 3; p++) {
@@ -892,6 +905,84 @@ int thip_state_set_device_dc(thip_state *st, int on) {
     for (int pli = 0; pli < 3; pli++)
       if (st->geom[pli].nvfrags > kDcMaxRows) return THIP_EIMPL;
   st->device_dc = on ? 1 : 0;
+  return THIP_OK;
+}
+
+// th_decode_packetin's out-of-loop post-processing (decode.c:2893-2911) of the frame just decoded.
+int thip_state_postprocess(thip_state *st, int level, const uint8_t *dc_qis, const uint8_t *frag_qi, const int32_t pp_dc_scale[64],
+                           const int32_t pp_sharp_mod[64]) {
+  if (!st || !dc_qis || !frag_qi || !pp_dc_scale || !pp_sharp_mod) return THIP_EFAULT;
+  if (level < 0 || level > 7 || st->last_decoded < 0) return THIP_EINVAL;
+  if (level < 2) {           // levels 0 and 1 change no pixel (decode.c:1208-1253)
+    st->pp_serial = -1;
+    return THIP_OK;
+  }
+  DeviceGuard dg(st->device);
+  if (!st->pp_frame) {
+    HIP_TRY(hipMalloc((void **)&st->pp_frame, st->frame_bytes + 256));
+    HIP_TRY(hipMalloc((void **)&st->pp_var, sizeof(int) * (size_t)st->nfrags));
+    HIP_TRY(hipMalloc((void **)&st->pp_qis, 2 * (size_t)st->nfrags));
+  }
+  hipStream_t s = st->last_stream;
+  HIP_TRY(hipMemcpyAsync(st->pp_qis, dc_qis, (size_t)st->nfrags, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(st->pp_qis + st->nfrags, frag_qi, (size_t)st->nfrags, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(st->pp_var, 0, sizeof(int) * (size_t)st->nfrags, s));
+  PpK K;
+  memset(&K, 0, sizeof(K));
+  int max_w = 0, max_nv = 0, max_h = 0;
+  for (int pli = 0; pli < 3; pli++) {
+    const thip_plane_geom &g = st->geom[pli];
+    PpPlaneK &p = K.p[pli];
+    p.src = st->frames[st->last_decoded] + g.plane_off;
+    p.dst = st->pp_frame + g.plane_off;
+    p.stride = g.stride;
+    p.width = g.width;
+    p.height = g.height;
+    p.nh = g.nhfrags;
+    p.nv = g.nvfrags;
+    p.variances = st->pp_var + g.froffset;
+    p.dc_qis = st->pp_qis + g.froffset;
+    p.frag_qi = st->pp_qis + st->nfrags + g.froffset;
+    const int off = 3 * (pli != 0);   // decode.c:2894: chroma takes the same steps three levels later
+    K.active[pli] = level >= 2 + off;
+    K.dering[pli] = level >= 3 + off;
+    K.strong[pli] = level >= 4 + off;
+    st->pp_active[pli] = K.active[pli];
+    if (K.active[pli]) {
+      if (g.width > max_w) max_w = g.width;
+      if (g.nvfrags > max_nv) max_nv = g.nvfrags;
+      if (g.height > max_h) max_h = g.height;
+    }
+  }
+  for (int i = 0; i < 64; i++) {
+    K.dc_scale[i] = pp_dc_scale[i];
+    K.sharp_mod[i] = pp_sharp_mod[i];
+  }
+  hipLaunchKernelGGL(k_pp_hedge, dim3((unsigned)((max_w / 4 + 63) / 64), (unsigned)(max_nv + 1), 3), dim3(64), 0, s, K);
+  hipLaunchKernelGGL(k_pp_vedge, dim3((unsigned)((max_h + 63) / 64), 1, 3), dim3(64), 0, s, K);
+  for (int pli = 0; pli < 3; pli++) {
+    if (!K.dering[pli]) continue;
+    const int gnx = (K.p[pli].nh + kPpGroup - 1) / kPpGroup, gny = (K.p[pli].nv + kPpGroup - 1) / kPpGroup;
+    for (int d = 0; d < gnx + gny - 1; d++) {
+      const int n = (d < gnx ? d : gnx - 1) - (d - (gny - 1) > 0 ? d - (gny - 1) : 0) + 1;   // groups on this anti-diagonal
+      hipLaunchKernelGGL(k_pp_dering, dim3((unsigned)n), dim3(64), 0, s, K, pli, d);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  st->pp_serial = st->frame_serial;
+  st->out_serial = -1;       // the host image (if any) shows the frame before post-processing
+  return THIP_OK;
+}
+
+// The post-processed picture's planes (device, bitstream row order), for tests and on-device consumers.
+int thip_state_read_pp_plane(thip_state *st, int pli, uint8_t *host_out) {
+  if (!st || !host_out) return THIP_EFAULT;
+  if (pli < 0 || pli > 2 || st->pp_serial != st->frame_serial) return THIP_EINVAL;
+  const thip_plane_geom &g = st->geom[pli];
+  DeviceGuard dg(st->device);
+  HIP_TRY(hipDeviceSynchronize());
+  const uint8_t *src = (st->pp_active[pli] ? st->pp_frame : st->frames[st->last_decoded]) + g.plane_off;
+  HIP_TRY(hipMemcpy2D(host_out, g.width, src, g.stride, g.width, g.height, hipMemcpyDeviceToHost));
   return THIP_OK;
 }
 

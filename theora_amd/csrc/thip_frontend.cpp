@@ -206,6 +206,11 @@ struct th_dec_ctx {
   int granpos_bias;
   bool have_frame;
   bool device_dc;   // DC un-prediction left to the backend (THIP_FE_DEVICE_DC=1, or TH_DECCTL_THIP_SET_DEVICE_DC)
+  // out-of-loop post-processing (TH_DECCTL_SET_PPLEVEL; decode.c:1203-1325)
+  int pp_level;
+  bool dc_qis_tracked;
+  std::vector<uint8_t> dc_qis, frag_qi;
+  int32_t pp_dc_scale[64], pp_sharp_mod[64];
   bool device_tokens;   // token -> coefficient expansion and AC dequantisation left to the backend (THIP_FE_DEVICE_TOKENS=1, ctl)
   std::vector<uint8_t> mirror[3];
   th_stripe_callback stripe_cb;
@@ -961,6 +966,30 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
     for (int p = 0; p < 3; p++)
       for (int qti = 0; qti < 2; qti++)
         compute_qmat(d->setup.qp, qti, p, qi, &d->dequant[(((size_t)qi * 3 + p) * 2 + qti) * 64]);
+  // post-processing tables: pp_dc_scale as oc_dequant_tables_init leaves it (quant.c:88 -- every (qti, pli) pass
+  // overwrites it, the inter / Cr pass is the last), pp_sharp_mod from decode.c:398-409
+  for (int qi = 0; qi < 64; qi++) {
+    const QuantParams &q = d->setup.qp;
+    const int qti = 1, p = 2;
+    int qri = 0, qistart = 0;
+    while (qri < q.nqrs[qti][p] - 1 && qi > qistart + q.qrsizes[qti][p][qri]) {
+      qistart += q.qrsizes[qti][p][qri];
+      qri++;
+    }
+    const int size = q.qrsizes[qti][p][qri], qiend = qistart + size;
+    const int bmi = q.bms[(size_t)q.qrbmis[qti][p][qri] * 64], bmj = q.bms[(size_t)q.qrbmis[qti][p][qri + 1] * 64];
+    const uint32_t base0 = (uint32_t)((2 * (qiend - qi) * bmi + 2 * (qi - qistart) * bmj + size) / (2 * size)) & 0xFFu;
+    d->pp_dc_scale[qi] = (int32_t)(((uint32_t)q.dcscale[qi] * base0) / 160u);
+    int qsum = 0;
+    for (int t = 0; t < 2; t++)
+      for (int pl = 0; pl < 3; pl++) {
+        const uint16_t *dq = &d->dequant[(((size_t)qi * 3 + pl) * 2 + t) * 64];
+        qsum += (dq[12] + dq[17] + dq[18] + dq[24]) << (pl == 0);
+      }
+    d->pp_sharp_mod[qi] = -(qsum >> 11);
+  }
+  d->pp_level = 0;
+  d->dc_qis_tracked = false;
   d->coded.assign(d->nfrags, 0);
   d->refi.assign(d->nfrags, 0);
   d->qii.assign(d->nfrags, 0);
@@ -1004,12 +1033,19 @@ int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
     case TH_DECCTL_GET_PPLEVEL_MAX:
       if (!d || !buf) return TH_EFAULT;
       if (buf_sz != sizeof(int)) return TH_EINVAL;
-      *(int *)buf = 0;   // out-of-loop post-processing is not provided
+      *(int *)buf = 7;   // OC_PP_LEVEL_MAX, decode.c:48
       return 0;
-    case TH_DECCTL_SET_PPLEVEL:
+    case TH_DECCTL_SET_PPLEVEL: {
       if (!d || !buf) return TH_EFAULT;
       if (buf_sz != sizeof(int)) return TH_EINVAL;
-      return *(int *)buf == 0 ? 0 : TH_EINVAL;
+      const int lvl = *(int *)buf;
+      if (lvl < 0 || lvl > 7) return TH_EINVAL;   // decode.c:1994
+      d->pp_level = lvl;
+      // every frame is sent to its host image by the decoding launch itself -- unless a post-processed one
+      // is going to replace it: then the image is made when th_decode_ycbcr_out asks
+      if (d->hip) thip_state_set_eager_output(d->hip, lvl < 2);
+      return 0;
+    }
     case TH_DECCTL_SET_GRANPOS: {
       if (!d || !buf) return TH_EFAULT;
       if (buf_sz != sizeof(int64_t)) return TH_EINVAL;
@@ -1264,10 +1300,12 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   }
   d->prof.lap(FE_MODES);
   // ---- 7.6 block-level qi ---------------------------------------------------------------------------
-  memset(d->qii.data(), 0, (size_t)N);
   {
     const size_t nc = d->cl_start[3];
     const int *cl = d->clist.data();
+    // only the coded blocks get a new qii (decode.c:913-917): an uncoded block keeps the one it was last coded
+    // with, which the de-ringing filter reads (decode.c:1926)
+    for (size_t i = 0; i < nc; i++) d->qii[cl[i]] = 0;
     std::vector<uint8_t> &bits = d->qi_bits;
     for (int q = 0; q + 1 < d->nqis; q++) {
       size_t nb = 0;
@@ -1510,6 +1548,33 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   if (!d->trace) {
     rc = thip_frame_flush(d->hip);
     if (rc < 0) return TH_EFAULT;
+  }
+  // ---- out-of-loop post-processing (decode.c:1203-1325, :2893-2911), on the backend -----------------------
+  if (!d->trace) {
+    if (d->pp_level <= 0) {
+      d->dc_qis_tracked = false;                                  // decode.c:1209-1219
+    } else if (!d->dc_qis_tracked) {
+      if (d->frame_type == THIP_INTRA_FRAME) {                     // "no point in starting now" otherwise, decode.c:1221-1227
+        d->dc_qis.assign((size_t)N, (uint8_t)d->qis[0]);
+        d->dc_qis_tracked = true;
+      }
+    } else {
+      const size_t nc = d->cl_start[3];
+      const int *cl = d->clist.data();
+      for (size_t i = 0; i < nc; i++) d->dc_qis[cl[i]] = (uint8_t)d->qis[0];   // decode.c:1236-1243
+    }
+    int lvl = d->dc_qis_tracked ? d->pp_level : 0;
+    if (lvl >= 2) {
+      d->frag_qi.resize((size_t)N);
+      // decode.c:1926, as it is: an uncoded block's stale qii indexes THIS frame's qis[] (entries beyond nqis are older still)
+      for (int f = 0; f < N; f++) d->frag_qi[f] = (uint8_t)d->qis[d->qii[f]];
+      if (thip_state_postprocess(d->hip, lvl, d->dc_qis.data(), d->frag_qi.data(), d->pp_dc_scale, d->pp_sharp_mod) < 0)
+        return TH_EFAULT;
+    } else {
+      static const uint8_t none = 0;
+      static const int32_t zeros[64] = {0};
+      (void)thip_state_postprocess(d->hip, 0, &none, &none, zeros, zeros);   // th_decode_ycbcr_out shows the decoded frame
+    }
   }
   d->prof.lap(FE_FLUSH);
   d->prof.frames++;
