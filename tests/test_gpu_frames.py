@@ -277,6 +277,24 @@ def test_fused_walk_variant(hip, waves, groups):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_fused_super_tile_variant(hip):
+    """THIP_FUSE=2 selects k_recon_st + k_lf_st_seams: one work group per super tile of 2 x 4 tiles, the filter
+    cells inside it closed in LDS, the left edge handed from group to group through L2, the frame written once; the
+    second kernel filters the cell rows between two super-tile rows.  The sequence tests of this file (all formats
+    and sizes, slots, batches, DUP frames, the grey start, four 4K streams in one call, DC values from the
+    device) in a child process with the switch on."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, THIP_FUSE="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sel = ("(sequence or enqueue or batched or grey or dup or lane_shared or static_background or four_concurrent "
+           "or dc_unprediction) and not elision and not fused")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q", "-k", sel],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_static_block_elision_forced_on_every_frame(hip):
     """THIP_SKIP_STATIC=2 lifts the "most of the frame is uncoded" condition, so that every inter frame of
     the sequence tests of this file (scattered uncoded blocks, all content classes, the slots, batches, DUP

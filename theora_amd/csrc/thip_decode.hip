@@ -95,6 +95,8 @@ struct thip_state {
   int lf_y0[3], lf_y1[3], lf_rows_custom;
   // DC un-prediction on the device (thip_frame_desc.dc_tokens / thip_state_set_device_dc)
   int16_t *d_dc;        // device, nfrags: un-predicted DC values of the frame being decoded
+  uint8_t *d_edge;      // device, fused path: kStEdgeRec bytes per super tile (k_recon_st's left-edge hand-off)
+  uint32_t edge_epoch;  // serial number of the last k_recon_st launch for this state (0 = never: the records are zero); 31 bits
   int device_dc, enq_device_dc;
   int16_t *h_dc, *d_dc_in;   // enqueue path: token DC values staged per fragment (pinned) and their device copy
   uint8_t *h_flags, *d_flags;   // ... and the fragments' coded | refi << 1 in fragment-index order (the staged command
@@ -219,7 +221,7 @@ int walk_groups_per_launch() {   // default: what is resident at once -- CUs x (
 
 // Fills the per-plane kernel geometry and the cumulative tile / cell counts.
 void fill_stream_geom(StreamK &K, const thip_state *st) {
-  int tiles = 0, cells = 0, rsc = 0;
+  int tiles = 0, cells = 0, rsc = 0, sts = 0, ssc = 0;
   for (int pli = 0; pli < 3; pli++) {
     const thip_plane_geom &g = st->geom[pli];
     PlaneK &k = K.pl[pli];
@@ -239,6 +241,13 @@ void fill_stream_geom(StreamK &K, const thip_state *st) {
     k.rs_rows = g.nvfrags / 4 + 1;                              // cell rows m = 0, 4, ... (k_lf_seams)
     rsc += (k.rs_rows * (g.nhfrags + 1) + 63) & ~63;
     K.rs_end[pli] = rsc;
+    k.st_x = (k.tiles_x + kStW - 1) / kStW;
+    k.st_y = (k.tiles_y + kStH - 1) / kStH;
+    sts += k.st_x * k.st_y;
+    K.st_end[pli] = sts;
+    // seam cells: the rows between two super-tile rows
+    ssc += ((k.st_y - 1) * (g.nhfrags + 1) + 63) & ~63;
+    K.ss_end[pli] = ssc;
   }
 }
 }  // namespace
@@ -371,6 +380,7 @@ void thip_state_free(thip_state *st) {
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
   if (st->d_slot0) (void)hipFree(st->d_slot0);
   if (st->d_dc) (void)hipFree(st->d_dc);
+  if (st->d_edge) (void)hipFree(st->d_edge);
   if (st->pp_frame) (void)hipFree(st->pp_frame);
   if (st->pp_var) (void)hipFree(st->pp_var);
   if (st->pp_qis) (void)hipFree(st->pp_qis);
@@ -618,6 +628,20 @@ int thip_profile_read(int64_t launches[THIP_NKERNELS], double ms[THIP_NKERNELS])
   return THIP_OK;
 }
 
+// More than 64 KB of dynamic LDS has to be allowed per kernel and per device, once.
+static hipError_t set_dynamic_lds(const void *kernel, int bytes, int which) {
+  static std::mutex mu;
+  static bool done[2][kMaxDevices];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev >= 0 && dev < kMaxDevices && done[which][dev]) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && dev >= 0 && dev < kMaxDevices) done[which][dev] = true;
+  return e;
+}
+
 // Launch one chunk of <= THIP_MAX_BATCH streams.
 static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs, int n, hipStream_t s,
                         int32_t *results) {
@@ -736,7 +760,35 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   // re-read.  Frames that leave static blocks in place (skip_ok) keep the two-pass path, whose first
   // kernel knows how to skip whole tiles.
   static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 0;
-  if (fuse && any_lf && !any_skip) {
+  if (fuse == 2 && any_lf && !any_skip) {
+    // super tiles: one kernel closes all filter cells but the rows between two super-tile rows (left edges travel
+    // between neighbouring groups), the second filters those rows and seven short columns
+    int max_st = 0, max_ss = 0;
+    for (int j = 0; j < nlive; j++) max_st = std::max(max_st, (B.s[j].st_end[2] + 7) & ~7);
+    for (int j = 0; j < nlive; j++) {
+      thip_state *st = states[live_state[j]];
+      StreamK &K = B.s[j];
+      if (!st->d_edge) {
+        HIP_TRY(hipMalloc((void **)&st->d_edge, (size_t)K.st_end[2] * kStEdgeRec));
+        HIP_TRY(hipMemsetAsync(st->d_edge, 0, (size_t)K.st_end[2] * kStEdgeRec, s));
+      }
+      K.edge = st->d_edge;
+      st->edge_epoch = (st->edge_epoch + 1) & 0x7FFFFFFFu;
+      if (!st->edge_epoch) st->edge_epoch = 1;
+      K.epoch = st->edge_epoch;
+      K.st_nband = max_st >> 3;
+      max_ss = std::max(max_ss, ((K.ss_end[2] + 7 * 64 + 255) / 256 + 7) & ~7);
+    }
+    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_recon_st), kStLds, 0));
+    {
+      ScopedTimer t(s, THIP_KERNEL_RECON);
+      hipLaunchKernelGGL(k_recon_st, dim3(max_st, nlive), dim3(64 * kStWaves), (size_t)kStLds, s, B);
+    }
+    {
+      ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
+      hipLaunchKernelGGL(k_lf_st_seams, dim3(max_ss, nlive), dim3(256), 0, s, B);
+    }
+  } else if (fuse && any_lf && !any_skip) {
     // one launch = one round of resident work groups: the streams share them equally
     int ng = (walk_groups_per_launch() / nlive) & ~7;
     if (ng < 8) ng = 8;
@@ -748,16 +800,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       const int swg = ((K.rs_end[2] + 64 * n + 255) / 256 + 7) & ~7;
       if (swg > max_swg) max_swg = swg;
     }
-    static std::mutex attr_mu;
-    static bool attr_set = false;
-    {
-      std::lock_guard<std::mutex> alk(attr_mu);
-      if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_recon_walk), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    16 * kWalkWaveLds));
-        attr_set = true;
-      }
-    }
+    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_recon_walk), 16 * kWalkWaveLds, 1));
     {
       ScopedTimer t(s, THIP_KERNEL_RECON);
       hipLaunchKernelGGL(k_recon_walk, dim3(ng, nlive), dim3(64 * walk_waves()), (size_t)walk_waves() * kWalkWaveLds, s, B);

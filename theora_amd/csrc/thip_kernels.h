@@ -40,6 +40,7 @@ struct PlaneK {
   float rcp_cx;      // 1/(nh+1)
   int tiles_y;       // tile rows
   int rs_rows;       // cell rows left to k_lf_seams: m = 0, 4, ..., 4*(nv/4)
+  int st_x, st_y;    // super tiles across / down (k_recon_st)
 };
 
 struct StreamK {
@@ -65,6 +66,11 @@ struct StreamK {
   // fused reconstruction + loop filter (k_recon_walk / k_lf_seams)
   int walk_wgs;           // work groups of k_recon_walk for this stream: group g walks tiles [g*n/walk_wgs, (g+1)*n/walk_wgs)
   int rs_end[3];          // cumulative row-seam cell counts per plane, each plane padded to 64
+  int st_end[3];          // cumulative super-tile counts per plane (k_recon_st: one work group per super tile)
+  int ss_end[3];          // cumulative row-seam cell counts per plane, each plane padded to 64 (k_lf_st_seams)
+  int st_nband;           // work groups per XCD band of the k_recon_st launch (its gridDim.x / 8)
+  uint8_t *edge;          // kStEdgeRec bytes per super tile: a group's last block column for its right neighbour
+  uint32_t epoch;         // serial number that marks the edge records of this launch
   PlaneK pl[3];
 };
 
@@ -395,13 +401,13 @@ struct ReconPlane {               // wave-uniform
 
 // ---- k_recon in three parts, so that the residual can be computed by ALL lanes of the wave ------
 __device__ __forceinline__ void recon_issue(const ReconPlane &R, const ReconLane &L, PredWin &Q, bool &inter,
-                                            const uint8_t *&ref) {
+                                            const uint8_t *&ref, bool write_map = true) {
   const int refi = L.coded ? (int)((L.flags >> THIP_INFO_REFI_SHIFT) & 3u) : THIP_FRAME_PREV;
   inter = refi != THIP_FRAME_SELF && !(R.debug & 2);
   ref = refi == THIP_FRAME_PREV ? R.prev : R.gold;
   Q.border = false;
   if (inter) pred_issue(Q, ref, R.stride, R.nh * 8, R.nv * 8, L.x0, L.y0, L.coded ? L.flags : 0u, R.qpx, R.qpy);
-  R.coded_map[(L.y0 >> 3) * R.nh + (L.x0 >> 3)] = L.coded ? 1 : 0;
+  if (write_map) R.coded_map[(L.y0 >> 3) * R.nh + (L.x0 >> 3)] = L.coded ? 1 : 0;
 }
 
 // The eight reconstructed rows of this lane's block: predictor (fragment.c:49-80: 128, one block, or the
@@ -1116,6 +1122,371 @@ __global__ __launch_bounds__(256) void k_lf_seams(const BatchK B) {
     k = 16 * t;
     m = 4 * sby + 1 + lane;
     if (m > nv) return;
+  }
+  CellPix C;
+  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
+  bool a, b, c, d;
+  lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
+  const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
+  lf_cell_pin(C);
+  lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_recon_st + k_lf_st_seams (K1+K2+nine tenths of K3 in one pass): super tiles
+// ---------------------------------------------------------------------------------------
+// Filter cells are independent of each other (see lf_cell_ops): the cell on corner (k, m) needs the
+// UNFILTERED reconstruction of the four blocks around that corner and nothing else.  A work group takes a
+// super tile of kStW x kStH tiles (32 x 16 blocks, 256 x 128 pixels): its eight waves reconstruct one
+// tile each exactly as k_recon does and leave the pixels in LDS (each wave in its own coefficient staging
+// area, which is free by then); one barrier, and the waves become the 32 x 16 cells on the corners
+// (X0..X0+31, Y0..Y0+15).  All of them are closed -- their four blocks are in LDS -- except the first
+// column and the first row, whose left / upper blocks belong to the neighbour groups: 47 of 512.  The
+// group filters and stores the closed ones, final pixels, and stores its own quadrants of the others
+// unfiltered; k_lf_st_seams then filters the cells on the super-tile boundaries in place -- a sixteenth of
+// the lines and every fourth 64-byte piece of the rest instead of the whole frame a second time.  (The cells
+// on the plane's own border need no neighbour and are closed here.  The cells on the group's right and
+// bottom boundary -- the neighbours' first column / row, or the plane's border cells k = nh, m = nv -- are 49
+// more, taken by the last wave.)
+// Measured on the way: the boundary blocks reconstructed a second time instead (a "halo": 49 blocks, seven
+// neighbouring tiles, per-lane slot lookup by ballots over those tiles' command words) so that every cell
+// is closed and there is no second kernel.  As a ninth wave of the group: 85 us (the halo wave's scattered
+// loads make it the straggler of every barrier, and nine waves spread 3-2-2-2 over the SIMDs).  As a kernel
+// of its own in front: 19 us for a ninth of the blocks, because a block's eight 16-byte coefficient pieces and
+// a column block's nine predictor rows each cost a whole 64-byte fetch -- 50 MB for 12 MB of data.
+constexpr int kStW = 2, kStH = 4;                       // tiles per super tile, across / down
+static_assert(kStW >= 2, "the last wave's own cells must not include the first column");
+constexpr int kStBx = 16 * kStW, kStBy = 4 * kStH;      // 32 x 16 blocks
+constexpr int kStWaves = kStW * kStH;
+constexpr int kStPitch = 128;                           // LDS image row of a tile
+constexpr int kStMetaOff = 8192;                        // 64 dwords for residual_shared
+constexpr int kStWaveLds = 8448;                        // per wave: 8 KB staging / image, meta
+constexpr int kStFlagOff = kStWaves * kStWaveLds;       // coded flags of the blocks, work-group wide
+constexpr int kStFlagPitch = kStBx + 4;
+constexpr int kStLds = kStFlagOff + (kStBy + 2) * kStFlagPitch;
+// A group's last block column for its right neighbour (StreamK::edge, one record per super tile): for each of
+// the 8 rows of its kStBy blocks a pair {the row's right 4 bytes, tag}, tag = 2 * serial number of the launch +
+// the block's coded flag.  A pair is one 8-byte store, so it needs no flag behind it: whoever reads a pair with
+// this launch's serial number has the data.
+constexpr int kStEdgeRec = kStBy * 8 * 8;
+
+// LDS byte offset of block (lx, ly) of the super tile's image (clamped: blocks outside do not exist or are
+// the neighbours'; what is read for them is not used)
+__device__ __forceinline__ int st_block(int lx, int ly) {
+  const int cx = min(max(lx, 0), kStBx - 1), cy = min(max(ly, 0), kStBy - 1);
+  return ((cy >> 2) * kStW + (cx >> 4)) * kStWaveLds + ((cy & 3) * 8) * kStPitch + (cx & 15) * 8;
+}
+
+// What a cell of the group's first column takes from the left neighbour's edge record: rows 4..7 of its block
+// ly-1 (nothing for ly = 0: that half is the upper neighbours'), rows 0..3 of its block ly (nothing for ly = kStBy),
+// and those blocks' coded flags.
+struct StEdge {
+  uint32_t up[4], dn[4];
+  bool fa, fc;
+};
+// (device-scope loads: past the CU's L1, served by the L2 both groups share.)  False when a pair is not there yet.
+__device__ __forceinline__ bool st_edge_load(StEdge &E, const uint8_t *rec, int ly, uint32_t epoch) {
+  const int ua = max(ly - 1, 0), uc = min(ly, kStBy - 1);
+  const unsigned long long *e = reinterpret_cast<const unsigned long long *>(rec);
+  unsigned long long pu[4], pd[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    pu[r] = __hip_atomic_load(e + ua * 8 + 4 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pd[r] = __hip_atomic_load(e + uc * 8 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  bool ok = true;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    E.up[r] = (uint32_t)pu[r];
+    E.dn[r] = (uint32_t)pd[r];
+    ok = ok && (uint32_t)(pu[r] >> 33) == epoch && (uint32_t)(pd[r] >> 33) == epoch;
+  }
+  E.fa = ((pu[0] >> 32) & 1ull) != 0;
+  E.fc = ((pd[0] >> 32) & 1ull) != 0;
+  return ok;
+}
+
+// The cell on corner (X0 + lx, Y0 + ly): pixels from the LDS images, filter, store.  A cell in the first
+// column / row of a super tile that has a left / upper neighbour is a seam cell: the quadrants that are
+// this group's are stored as they are.
+__device__ __forceinline__ void st_cell(const uint8_t *lds, uint8_t *plane, int stride, int nh, int nv, int X0, int Y0,
+                                        int lx, int ly, bool active, int L2, int fy0, int fy1, bool edge, const StEdge &E) {
+  const int k = X0 + lx, mm = Y0 + ly;
+  active = active && k <= nh && mm <= nv;
+  const bool seam_l = lx == 0 && X0 > 0 && !edge, seam_u = ly == 0 && Y0 > 0;   // the left / upper half is a neighbour's
+  const bool seam_r = lx == kStBx && k < nh, seam_d = ly == kStBy && mm < nv;   // the right / lower half is
+  const int oa = st_block(lx - 1, ly - 1), ob = st_block(lx, ly - 1), oc = st_block(lx - 1, ly), od = st_block(lx, ly);
+  CellPix C;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    C.lo[r] = *reinterpret_cast<const uint32_t *>(lds + oa + (4 + r) * kStPitch + 4);
+    C.hi[r] = *reinterpret_cast<const uint32_t *>(lds + ob + (4 + r) * kStPitch);
+    C.lo[4 + r] = *reinterpret_cast<const uint32_t *>(lds + oc + r * kStPitch + 4);
+    C.hi[4 + r] = *reinterpret_cast<const uint32_t *>(lds + od + r * kStPitch);
+  }
+  const uint8_t *fl = lds + kStFlagOff + ly * kStFlagPitch + lx;   // flag of block (lx-1, ly-1)
+  bool a = fl[0] != 0, b = fl[1] != 0, c = fl[kStFlagPitch] != 0, d = fl[kStFlagPitch + 1] != 0;
+  if (edge && lx == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      C.lo[r] = E.up[r];
+      C.lo[4 + r] = E.dn[r];
+    }
+    a = E.fa;
+    c = E.fc;
+  }
+  uint32_t ops = lf_cell_ops(k, mm, nh, nv, a, b, c, d, fy0, fy1);
+  if (L2 == 0 || !active || seam_l || seam_u || seam_r || seam_d) ops = 0;
+  lf_cell_apply_pk(C, ops, L2);
+  // which halves exist in the plane, and which are this group's to store
+  const bool lo_ok = active && k >= 1 && !seam_l, hi_ok = active && k <= nh - 1 && !seam_r;
+  const bool up_ok = mm >= 1 && !seam_u, dn_ok = mm <= nv - 1 && !seam_d;
+  uint8_t *base = plane + (ptrdiff_t)(8 * mm - 4) * stride + (8 * k - 4);
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    uint8_t *p = base + (ptrdiff_t)r * stride;
+    if (r < 4 ? up_ok : dn_ok) {
+      if (lo_ok & hi_ok) {
+        Pix8 o;
+        o.x = C.lo[r];
+        o.y = C.hi[r];
+        *reinterpret_cast<Pix8 *>(p) = o;
+      } else if (lo_ok) {
+        *reinterpret_cast<uint32_t *>(p) = C.lo[r];
+      } else if (hi_ok) {
+        *reinterpret_cast<uint32_t *>(p + 4) = C.hi[r];
+      }
+    }
+  }
+}
+
+#ifndef THIP_ST_WAVES_PER_EU
+#define THIP_ST_WAVES_PER_EU 4   // two groups of eight waves per CU (LDS): four waves per SIMD, 128 VGPRs
+#endif
+__global__ __launch_bounds__(64 * kStWaves, THIP_ST_WAVES_PER_EU) void k_recon_st(const BatchK B) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_st[];
+  const StreamK &S = B.s[blockIdx.y];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = (int)threadIdx.x & 63;
+  const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, see k_recon
+  const uint2 *info_p = S.info;
+  const int4 *coeffs_p = S.coeffs;
+  const uint32_t *slot0_p = S.tile_slot0;
+  uint8_t *self = S.self;
+  const uint8_t *prev = S.prev, *gold = S.gold;
+  uint8_t *coded_map = S.coded_map;
+  const int16_t *dc_p = S.dc;
+  const int se0 = S.st_end[0], se1 = S.st_end[1], se2 = S.st_end[2], te0 = S.tile_end[0], te1 = S.tile_end[1];
+  const int sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
+  uint8_t *edge_p = S.edge;
+  const uint32_t epoch = S.epoch;
+  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map), "s"(dc_p),
+               "s"(se0), "s"(se1), "s"(se2), "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2), "s"(edge_p), "s"(epoch));
+  if (wg >= se2) return;                                  // (the whole group)
+  const int pli = (wg >= se0 ? 1 : 0) + (wg >= se1 ? 1 : 0);
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.tiles_y), "s"(G.fro), "s"(G.st_x),
+               "s"(fy0), "s"(fy1));
+  const int rel = wg - (pli == 0 ? 0 : (pli == 1 ? se0 : se1));
+  const int sty = rel / G.st_x, stx = rel - sty * G.st_x;
+  const int X0 = stx * kStBx, Y0 = sty * kStBy;
+  const int tile_base = pli == 0 ? 0 : (pli == 1 ? te0 : te1);
+  const int nh = G.nh, nv = G.nv;
+  // The left neighbour in the plane is group wg-1: same XCD band -- same L2, dispatched before this one -- unless
+  // this group opens its band.  Inside a band the left edge comes over through the edge records and the cells
+  // on the boundary are closed by the group on their right; at the start of a band they stay seam cells.
+  const int jb = (int)blockIdx.x >> 3, nband = (int)gridDim.x >> 3;
+  const bool consume = stx > 0 && jb > 0;
+  const bool publish = stx < G.st_x - 1 && jb < nband - 1;   // ... and the right neighbour consumes
+  ReconPlane R;
+  R.self = self + G.off;
+  R.prev = prev + G.off;
+  R.gold = gold + G.off;
+  R.coded_map = coded_map + G.fro;
+  R.nh = nh;
+  R.nv = nv;
+  R.stride = G.stride;
+  R.qpx = pli != 0 && sqpx;
+  R.qpy = pli != 0 && sqpy;
+  R.debug = 0;
+  R.tr = nullptr;
+  uint8_t *const mine = s_st + wave * kStWaveLds;
+  uint4 *const lds_wave = reinterpret_cast<uint4 *>(mine);
+  uint32_t *const lds_dw = reinterpret_cast<uint32_t *>(mine);
+  uint32_t *const meta = reinterpret_cast<uint32_t *>(mine + kStMetaOff);
+
+  // ---- 1. this lane's block, its command word, the tile's first slot -------------------------------
+  const int hh = lane & 15;
+  const int lx = (lane >> 4) * 4 + hilb_col(hh), ly = hilb_row(hh);
+  const int tx = kStW * stx + (wave % kStW), ty = kStH * sty + (wave / kStW);
+  const bool exists = tx < G.tiles_x && ty < G.tiles_y;
+  const int lxs = (wave % kStW) * 16 + lx, lys = (wave / kStW) * 4 + ly;
+  const int bx = X0 + lxs, by = Y0 + lys;
+  const bool valid = exists && bx < nh && by < nv;
+  uint2 info = make_uint2(0u, 0u);
+  uint32_t slot0 = 0;
+  if (exists) {
+    const int u = tile_base + ty * G.tiles_x + tx;
+    slot0 = slot0_p[u];
+    info = info_p[(size_t)u * THIP_TILE_FRAGS + lane];
+  }
+  uint32_t dcv = 0;   // the block's un-predicted DC when it does not travel in the command stream
+  if (dc_p) dcv = 0x10000u | (uint16_t)dc_p[G.fro + min(by, nv - 1) * nh + min(bx, nh - 1)];
+  asm volatile("" ::"s"(slot0), "v"(info.x), "v"(dcv));
+  ReconLane L;
+  L.flags = valid ? info.x : 0u;
+  L.dcq = info.y >> 16;
+  L.dcraw = dcv;
+  L.dcp = ((uint32_t)(((int)(int16_t)((dcv ? dcv : info.y) & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;
+  L.coded = (L.flags & THIP_INFO_CODED) != 0;
+  L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
+  L.has_coeff = L.coded && !L.dc_only;
+  L.x0 = bx * 8;
+  L.y0 = by * 8;
+
+  // ---- 2. coefficients + predictor: k_recon's second round trip -----------------------------------
+  const uint64_t mask = __ballot(L.has_coeff);
+  const int nown = __popcll(mask);
+  const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  PredWin Q;
+  Q.border = false;
+  bool inter = false;
+  const uint8_t *ref = nullptr;
+  const uint32_t fill = L.dc_only ? L.dcp : 0u;   // DC-only: the rounded value (state.c:972); uncoded: zero residual
+  uint32_t Y[32];
+  if (nown == 0) {
+    if (valid) recon_issue(R, L, Q, inter, ref);
+  } else if (nown <= 16) {
+    int4 Wc[1][2];
+    residual_shared_load<4>(coeffs_p, slot0, nown, lane, Wc);
+    if (valid) recon_issue(R, L, Q, inter, ref);
+    residual_shared<4>(Wc, lds_dw, meta, lane, L, prefix, Y);
+  } else if (nown <= 32) {
+    int4 Wc[2][2];
+    residual_shared_load<2>(coeffs_p, slot0, nown, lane, Wc);
+    if (valid) recon_issue(R, L, Q, inter, ref);
+    residual_shared<2>(Wc, lds_dw, meta, lane, L, prefix, Y);
+  } else {
+    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
+    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
+                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
+    if (valid) recon_issue(R, L, Q, inter, ref);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)
+    residual_per_lane(lds_wave + lane, L, Y);
+  }
+  if (!L.has_coeff) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) Y[i] = fill;
+  }
+  uint2 rows[8];
+  recon_rows(R, Q, inter, Y, rows);
+
+  // ---- 3. the block into the LDS image, its coded flag -------------------------------------------
+  lds_settle();                                   // every lane is done with the staging area
+  if (valid) {
+    uint8_t *img = mine + (ly * 8) * kStPitch + lx * 8;
+#pragma unroll
+    for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(img + r * kStPitch) = rows[r];
+  }
+  s_st[kStFlagOff + (lys + 1) * kStFlagPitch + lxs + 1] = (valid && L.coded) ? 1 : 0;
+  uint8_t *const myrec = edge_p + (size_t)wg * kStEdgeRec;
+  if (publish && lxs == kStBx - 1) {              // the last block column: its right halves, straight from the registers
+    unsigned long long *e = reinterpret_cast<unsigned long long *>(myrec) + lys * 8;
+    const unsigned long long tag = (unsigned long long)(2u * epoch + ((valid && L.coded) ? 1u : 0u)) << 32;
+#pragma unroll
+    // (plain stores: they stop in the L2 the neighbour reads from; a device-scope store goes through to memory, 8 bytes
+    //  at a time -- 200 k DRAM accesses per launch, measured +14 us)
+    for (int r = 0; r < 8; r++) __hip_atomic_store(e + r, tag | rows[r].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  // The left neighbour's record -- it runs in step with this group, so its pairs arrive about now: wave kStWaves-2 asks
+  // for them BEFORE the barrier, filters its own cells like the others, and then, as a second pass, the group's first
+  // cell column (0, 0..kStBy), by which time the pairs are there (it looks again until they are).
+  const bool edge_wave = consume && wave == kStWaves - 2;
+  const uint8_t *lrec = myrec - kStEdgeRec;
+  StEdge E;
+#pragma unroll
+  for (int r = 0; r < 4; r++) E.up[r] = E.dn[r] = 0;
+  E.fa = E.fc = false;
+  bool have_edge = true;
+  if (edge_wave) have_edge = st_edge_load(E, lrec, min(lane, kStBy), epoch) || lane > kStBy;
+  // (LDS only: the barrier must not wait for the loads and stores just issued)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+
+  // ---- 4. the cells ---------------------------------------------------------------------------------
+  {
+    const int clx = (wave % kStW) * 16 + (lane & 15);
+    st_cell(s_st, R.self, R.stride, nh, nv, X0, Y0, clx, (wave / kStW) * 4 + (lane >> 4), !(consume && clx == 0), L2, fy0, fy1, false, E);
+  }
+  if (edge_wave) {
+    // (bounded: groups are dispatched in order, so the left neighbour is resident or done; if that ever fails,
+    //  a wrong picture is a failed test, a hang is a dead GPU)
+    for (int spins = 0; spins < (1 << 20) && __any(!have_edge); spins++) {
+      if (spins) __builtin_amdgcn_s_sleep(2);
+      if (!have_edge) have_edge = st_edge_load(E, lrec, min(lane, kStBy), epoch);
+    }
+    st_cell(s_st, R.self, R.stride, nh, nv, X0, Y0, 0, min(lane, kStBy), lane <= kStBy, L2, fy0, fy1, true, E);
+  }
+  // The cells on the group's right and bottom boundary: the neighbour group's (this group's halves are stored as
+  // they are) or, when the plane ends exactly where the super tile does, the plane's border cells.
+  // (when the right neighbour closes the cells of the shared boundary, the column is all its)
+  if (wave == kStWaves - 1) {
+    const bool col = lane <= kStBy;
+    const int cx = col ? kStBx : lane - (kStBy + 1), cy = col ? lane : kStBy;
+    st_cell(s_st, R.self, R.stride, nh, nv, X0, Y0, cx, cy, lane < kStBy + 1 + kStBx && !(col && publish) && !(consume && cx == 0), L2, fy0,
+            fy1, false, E);
+  }
+}
+
+// The seam cells k_recon_st leaves: per plane the rows m = kStBy, 2*kStBy, ... (every column 0..nh); then, one
+// wave each, the first cell column of the group that opens XCD band 1..7 (st_nband groups per band) when that
+// group has a left neighbour in its plane -- the rows of it that are not among the seam rows.  Filtered in place.
+__global__ __launch_bounds__(256) void k_lf_st_seams(const BatchK B) {
+  const StreamK &S = B.s[blockIdx.y];
+  const int lane = (int)threadIdx.x & 63;
+  const int wgb = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, like k_recon_st
+  const int wbase = __builtin_amdgcn_readfirstlane(wgb * 256 + (int)(threadIdx.x & ~63u));
+  uint8_t *self = S.self;
+  const uint8_t *cmap = S.coded_map;
+  const int ce0 = S.ss_end[0], ce1 = S.ss_end[1], ce2 = S.ss_end[2], L2 = S.flimit2;
+  const int se0 = S.st_end[0], se1 = S.st_end[1], se2 = S.st_end[2], nband = S.st_nband;
+  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2), "s"(se0), "s"(se1), "s"(se2), "s"(nband));
+  if (L2 == 0) return;
+  int pli, wg = 0;
+  if (wbase < ce2) {
+    pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
+  } else {
+    const int band = (wbase - ce2) / 64 + 1;
+    wg = band * nband;
+    if (band > 7 || wg >= se2) return;
+    pli = (wg >= se0 ? 1 : 0) + (wg >= se1 ? 1 : 0);
+  }
+  const PlaneK G = S.pl[pli];
+  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
+  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(G.st_x), "s"(G.st_y), "s"(fy0),
+               "s"(fy1));
+  const int nh = G.nh, nv = G.nv;
+  int k, m;
+  if (wbase < ce2) {
+    const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
+    if (rel >= (G.st_y - 1) * (nh + 1)) return;
+    uint32_t mu, ku;
+    divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
+    k = (int)ku;
+    m = ((int)mu + 1) * kStBy;
+  } else {
+    const int rel = wg - (pli == 0 ? 0 : (pli == 1 ? se0 : se1));
+    const int sty = rel / G.st_x, stx = rel - sty * G.st_x;
+    if (stx == 0) return;                             // the band opens with a row of the plane: no left neighbour
+    k = stx * kStBx;
+    m = sty * kStBy + lane;                           // the group's cells (0, 0..kStBy-1), and (0, kStBy) when the plane ends there
+    const bool seam_row = m % kStBy == 0 && m > 0 && m < nv;
+    if (lane > kStBy || m > nv || seam_row || (lane == kStBy && m != nv)) return;
   }
   CellPix C;
   lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);

@@ -1,17 +1,18 @@
 #!/bin/bash
 # Refreshes the round-2 numbers kept under profiles/: bench lines, rocprofv3 kernel stats, FETCH / WRITE PMC passes
-# (one counter per pass), for the default two-pass path and for the fused path (THIP_FUSE=1).
+# (one counter per pass), for the default two-pass path and for the fused paths (THIP_FUSE=1: walk, THIP_FUSE=2: super tiles).
 # usage (GPU box, repo root): bash tools/prof_round2.sh ; then here: python tools/collect_profiles2.py
 export TMPDIR=/tmp
 o=gpurun_out/r02
 mkdir -p $o
 python bench.py > $o/bench_default.json 2> $o/bench_default.err
 THIP_FUSE=1 python bench.py --no-cpu-baseline > $o/bench_fused.json 2>/dev/null
+THIP_FUSE=2 python bench.py --no-cpu-baseline > $o/bench_fused_st.json 2>/dev/null
 python bench.py --size 1080p --streams-per-gpu 1 --no-cpu-baseline --second-content "" > $o/bench_1080p_single.json 2>/dev/null
 python bench.py --size 1080p --streams-per-gpu 1 --gop-parallel 16 --no-cpu-baseline --parity-frames 70 > $o/bench_1080p_single_gop16.json 2>/dev/null
 python bench.py --size 1080p --no-cpu-baseline --second-content "" > $o/bench_1080p_4streams.json 2>/dev/null
 python bench.py --mode enc 2>/dev/null | grep '^{' > $o/bench_enc.jsonl
-for fuse in 0 1; do
+for fuse in ${FUSES:-0 1 2}; do
   THIP_FUSE=$fuse THIP_LANES=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_lanes1_fuse$fuse -- python bench.py --steps 64 --repeats 2 --min-time 0 --no-cpu-baseline --no-parity --no-profile --second-content "" > $o/stats_lanes1_fuse$fuse.log 2>&1
   THIP_FUSE=$fuse timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_default_fuse$fuse -- python bench.py --steps 64 --repeats 2 --min-time 0 --no-cpu-baseline --no-parity --no-profile --second-content "" > $o/stats_default_fuse$fuse.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
