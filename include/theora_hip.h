@@ -229,6 +229,37 @@ int thip_frame_flush(thip_state *st);
 int thip_frame_dequant_table(thip_state *st, int sel, const uint16_t dequant[64]);
 int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const uint32_t *toks, int ntoks,
                                  int16_t dc, int last_zzi, uint16_t dc_quant, int dqsel, int refi, int16_t mv);
+
+/* The whole step between the entropy decoder and the pixel path on the device (SURVEY section 8f rank 1 in its
+   parallel form; decode.c:1511-1587 with the lists of decode.c:993-1139 as input, DC un-prediction
+   decode.c:1392-1500 included): the caller hands over the frame's DCT tokens as the entropy decoder leaves them
+   -- one list per (plane, zig-zag index) -- plus one word per coded fragment, and the backend finds each
+   fragment's tokens (two prefix sums per index over the arrivals and over what the tokens consume,
+   k_tok_assign), expands and dequantises them, un-predicts the DC values (k_dc_unpredict), builds the command
+   stream and decodes the frame.  Stands for thip_frame_begin ... thip_frame_flush of one frame.
+   tokens: 32-bit words, all lists concatenated: bits 0-15 the value (two's complement; 0 for a pure zero run),
+   bits 16-22 the zeros before it, bit 23 set for an EOB token, whose run length is bits 0-15 | bits 24-31 << 16
+   (the part of a run that reaches past its list is the later lists' eob_carry).
+   list_off / list_len: first token and length of list [plane][zzi].  eob_carry[plane][zzi]: fragments ended at
+   that index by a run from an earlier list.  arrivals[plane][zzi]: fragments open at that index (carry included).
+   coded: the coded fragments in coded order, plane after plane (ncoded per plane); frag_meta per coded fragment:
+   refi | dequantisation table << 2 | (mvx & 255) << 8 | (mvy & 255) << 16 | plane << 24, table = (plane * 3 + qii)
+   * 2 + qti into dequant[18][64] (zig-zag order, decode.c:1537-1538).  dc_quant[plane][qti] as the slot's _dc_quant.
+   Returns 0, THIP_DUPFRAME (nothing coded), or THIP_EIMPL when a plane has more than 49152 coded fragments or more
+   than 1024 fragment rows (the caller falls back to the slots); all pointers are host memory, read before return. */
+typedef struct thip_token_lists {
+  int32_t frame_type;          /* THIP_INTRA_FRAME / THIP_INTER_FRAME */
+  int32_t flimit;              /* loop_filter_limits[qis[0]] */
+  const uint32_t *tokens;
+  int64_t ntokens;
+  uint32_t list_off[3][64], list_len[3][64], eob_carry[3][64], arrivals[3][64];
+  const int32_t *coded;
+  const uint32_t *frag_meta;
+  int32_t ncoded[3];
+  const uint16_t *dequant;     /* [18][64] */
+  uint16_t dc_quant[3][2];
+} thip_token_lists;
+int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl);
 /* on != 0: the DC coefficient handed to thip_state_frag_recon (dct_coeffs[0]) is the value decoded from
    the tokens, NOT yet un-predicted: the caller skips its oc_dec_dc_unpredict_mcu_plane calls
    (decode.c:2869) and thip_frame_flush undoes the prediction on the device before reconstructing

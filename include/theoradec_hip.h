@@ -142,6 +142,12 @@ typedef struct {
    (thip_state_frag_recon_tokens / k_expand_tokens), and 4 bytes per non-zero coefficient cross PCIe
    instead of 128 per block.  THIP_FE_DEVICE_TOKENS=1 sets it for every new context. */
 #define TH_DECCTL_THIP_SET_DEVICE_TOKENS (0x7103)
+/* Extension: buf = int.  Non-zero: th_decode_packetin stops behind the entropy decoder -- the frame's token lists
+   (one per plane and zig-zag index, decode.c:993-1139), the coded-fragment list and one word per fragment go to the
+   GPU, which finds each fragment's tokens, expands and dequantises them, un-predicts the DC values and decodes
+   the frame (thip_state_decode_token_lists).  Frames with a plane of more than 49152 coded fragments (beyond
+   1080p) keep the host path.  THIP_FE_DEVICE_LISTS=1 sets it for every new context. */
+#define TH_DECCTL_THIP_SET_DEVICE_LISTS (0x7104)
 typedef struct thip_slot_trace {
   int64_t ncoded;           /* state_frag_recon calls, in call (= coded) order */
   const int32_t *fragi;     /* _fragi */

@@ -12,7 +12,7 @@ from tests import streamgen, util
 pytestmark = pytest.mark.gpu
 
 
-def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=False, device_tokens=False):
+def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=False, device_tokens=False, device_lists=False):
     import ctypes as C
     from theora_amd.decoder import Decoder
     st = streamgen.Stream(w, h, fmt, seed, trees=trees)
@@ -23,6 +23,9 @@ def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=Fa
     if device_tokens:   # TH_DECCTL_THIP_SET_DEVICE_TOKENS: token expansion + AC dequantisation on the GPU
         on = C.c_int(1)
         assert dec._L.th_decode_ctl(dec._dec, 0x7103, C.byref(on), C.sizeof(on)) == 0
+    if device_lists:   # TH_DECCTL_THIP_SET_DEVICE_LISTS: everything behind the entropy decoder on the GPU
+        on = C.c_int(1)
+        assert dec._L.th_decode_ctl(dec._dec, 0x7104, C.byref(on), C.sizeof(on)) == 0
     assert dec.info.frame_width == w and dec.info.frame_height == h and dec.info.pixel_fmt == fmt
     assert dec.comment.vendor == b"theora-hip streamgen"
     ost = oracle.State(w, h, fmt)
@@ -66,6 +69,17 @@ def test_packets_decode_bit_exact_with_token_expansion_on_the_gpu(hip, w, h, fmt
     un-prediction on the GPU."""
     assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_dc=device_dc,
                       device_tokens=True) >= 3
+
+
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (336, 32, 0),
+                                     (1280, 720, 0), (1920, 1088, 0)])
+def test_packets_decode_bit_exact_with_the_token_lists_on_the_gpu(hip, w, h, fmt):
+    """The same streams with everything behind the entropy decoder left to the backend
+    (thip_state_decode_token_lists): the token lists per (plane, zig-zag index) go to the GPU as they are; which
+    token belongs to which fragment (EOB runs crossing lists and planes included), expansion, dequantisation,
+    DC un-prediction, command words and coefficient slots are the device's (k_tok_assign, k_tok_slots,
+    k_tok_write, k_dc_unpredict)."""
+    assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_lists=True) >= 3
 
 
 def test_packets_decode_bit_exact_720p(hip):

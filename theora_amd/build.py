@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtheora_hip.so")
 SOURCES = ["thip_decode.hip", "thip_slots.hip", "thip_frontend.cpp", "thip_ogg.cpp"]
-HEADERS = ["thip_device.h", "thip_kernels.h", "thip_postproc.h", os.path.join("..", "..", "include", "theora_hip.h"),
+HEADERS = ["thip_device.h", "thip_kernels.h", "thip_postproc.h", "thip_tokens.h", os.path.join("..", "..", "include", "theora_hip.h"),
            os.path.join("..", "..", "include", "theoradec_hip.h"), os.path.join("..", "..", "include", "thip_ogg.h")]
 
 

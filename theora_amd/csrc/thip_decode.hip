@@ -55,6 +55,7 @@ using namespace thip;
 
 #include "thip_kernels.h"
 #include "thip_postproc.h"
+#include "thip_tokens.h"
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -108,6 +109,13 @@ struct thip_state {
   uint16_t *h_dq, *d_dq;
   size_t tok_cap;
   int enq_ntok, enq_tok_slots, enq_dense_slots;
+  // token lists expanded on the device (thip_state_decode_token_lists): pinned staging, its device copy, work arrays
+  uint32_t *h_tl, *d_tl;
+  size_t tl_cap;            // bytes of each
+  int16_t *d_tl_tmp;        // [nfrags][64]
+  uint8_t *d_tl_last;       // [nfrags]
+  uint32_t *d_tl_slot;      // [nfrags]
+  int32_t *d_frag_pos;      // [nfrags], uploaded once
   // out-of-loop post-processing (thip_state_postprocess): the post-processed picture, the per-fragment
   // variances and quantiser indices, which planes of which decoded frame the picture holds
   uint8_t *pp_frame;
@@ -381,6 +389,12 @@ void thip_state_free(thip_state *st) {
   if (st->d_slot0) (void)hipFree(st->d_slot0);
   if (st->d_dc) (void)hipFree(st->d_dc);
   if (st->d_edge) (void)hipFree(st->d_edge);
+  if (st->h_tl) (void)hipHostFree(st->h_tl);
+  if (st->d_tl) (void)hipFree(st->d_tl);
+  if (st->d_tl_tmp) (void)hipFree(st->d_tl_tmp);
+  if (st->d_tl_last) (void)hipFree(st->d_tl_last);
+  if (st->d_tl_slot) (void)hipFree(st->d_tl_slot);
+  if (st->d_frag_pos) (void)hipFree(st->d_frag_pos);
   if (st->pp_frame) (void)hipFree(st->pp_frame);
   if (st->pp_var) (void)hipFree(st->pp_var);
   if (st->pp_qis) (void)hipFree(st->pp_qis);
@@ -631,7 +645,7 @@ int thip_profile_read(int64_t launches[THIP_NKERNELS], double ms[THIP_NKERNELS])
 // More than 64 KB of dynamic LDS has to be allowed per kernel and per device, once.
 static hipError_t set_dynamic_lds(const void *kernel, int bytes, int which) {
   static std::mutex mu;
-  static bool done[2][kMaxDevices];
+  static bool done[3][kMaxDevices];
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -1056,7 +1070,7 @@ static int ensure_staging(thip_state *st) {
   HIP_TRY(hipHostMalloc((void **)&st->h_slot0, (size_t)st->tiles.ntiles * 4, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void **)&st->d_info, npos * 8));
   HIP_TRY(hipMalloc((void **)&st->d_coeffs, ngroups * THIP_SLOT_GROUP_BYTES));
-  HIP_TRY(hipMalloc((void **)&st->d_slot0, (size_t)st->tiles.ntiles * 4));
+  HIP_TRY(hipMalloc((void **)&st->d_slot0, (((size_t)st->tiles.ntiles + 3) & ~(size_t)3) * 4));   // (zero-filled 16 bytes at a time)
   st->enq_last_lane = (int32_t *)malloc(sizeof(int32_t) * (size_t)st->tiles.ntiles);
   if (!st->enq_last_lane) return THIP_EFAULT;
   st->staging_ready = 1;
@@ -1088,7 +1102,7 @@ int thip_frame_begin(thip_state *st, int frame_type) {
   st->enq_device_dc = st->device_dc;
   if (st->enq_device_dc) {
     if (!st->h_dc) HIP_TRY(hipHostMalloc((void **)&st->h_dc, sizeof(int16_t) * (size_t)st->nfrags, hipHostMallocDefault));
-    if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * (size_t)st->nfrags));
+    if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * (((size_t)st->nfrags + 7) & ~(size_t)7)));
     if (!st->h_flags) HIP_TRY(hipHostMalloc((void **)&st->h_flags, (size_t)st->nfrags, hipHostMallocDefault));
     if (!st->d_flags) HIP_TRY(hipMalloc((void **)&st->d_flags, (size_t)st->nfrags));
     memset(st->h_flags, 0, (size_t)st->nfrags);   // everything uncoded
@@ -1338,6 +1352,149 @@ int thip_frame_flush(thip_state *st) {
   if (rc < 0) return rc;
   if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(st->ev_staging, s));
+  return res;
+}
+
+// ---- the frame's token lists, expanded on the device (thip_tokens.h) ---------------------------------------
+int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
+  if (!st || !tl) return THIP_EFAULT;
+  if (st->enq_active) return THIP_EINVAL;   // a frame is being enqueued through the slots
+  if (tl->frame_type != THIP_INTRA_FRAME && tl->frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
+  if (tl->flimit < 0 || tl->flimit > 127 || tl->ntokens < 0) return THIP_EINVAL;
+  int64_t ncoded = 0;
+  for (int p = 0; p < 3; p++) {
+    const thip_plane_geom &g = st->geom[p];
+    if (tl->ncoded[p] < 0 || tl->ncoded[p] > g.nhfrags * g.nvfrags) return THIP_EINVAL;
+    if (tl->ncoded[p] > kTlMaxFrags || g.nvfrags > kDcMaxRows) return THIP_EIMPL;
+    ncoded += tl->ncoded[p];
+  }
+  if (ncoded && (!tl->tokens || !tl->coded || !tl->frag_meta || !tl->dequant)) return THIP_EFAULT;
+  if (tl->ntokens > (int64_t)st->nfrags * 64 + 192) return THIP_EINVAL;
+  // the lists lie inside the token array; what they consume is the device's business (a list that asks for more
+  // than it has finds its fragments ended, a longer one has its surplus ignored)
+  for (int p = 0; p < 3; p++)
+    for (int z = 0; z < 64; z++) {
+      if ((int64_t)tl->list_off[p][z] + tl->list_len[p][z] > tl->ntokens) return THIP_EINVAL;
+      if (tl->arrivals[p][z] > (uint32_t)tl->ncoded[p] || tl->eob_carry[p][z] > tl->arrivals[p][z]) return THIP_EINVAL;
+    }
+  {
+    int64_t c = 0;
+    for (int p = 0; p < 3; p++) {
+      const thip_plane_geom &g = st->geom[p];
+      const int64_t lo = g.froffset, hi = lo + (int64_t)g.nhfrags * g.nvfrags;
+      int32_t prev_pos = -1;
+      for (int64_t i = 0; i < tl->ncoded[p]; i++, c++) {
+        const int32_t f = tl->coded[c];
+        if (f < lo || f >= hi) return THIP_EINVAL;
+        const int32_t pos = st->frag_pos[f];
+        if (pos <= prev_pos) return THIP_EINVAL;                 // coded order == tile/lane order, no fragment twice
+        prev_pos = pos;
+        const uint32_t m = tl->frag_meta[c];
+        if ((m & 3u) > 2u || ((m >> 2) & 31u) >= 18u || ((m >> 24) & 3u) != (uint32_t)p) return THIP_EINVAL;
+      }
+    }
+  }
+  DeviceGuard dg(st->device);
+  int rc = ensure_lanes(st->device);
+  if (rc) return rc;
+  rc = ensure_staging(st);
+  if (rc) return rc;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (st->lane < 0) st->lane = g_next_lane[st->device]++ % g_nlanes;
+  }
+  hipStream_t s = g_lanes[st->device][st->lane];
+  thip_frame_desc d;
+  memset(&d, 0, sizeof(d));
+  d.frame_type = tl->frame_type;
+  d.flimit = tl->flimit;
+  if (ncoded) {
+    // staging layout (16-byte sections): header tables | coded list | fragment words | dequantisation tables | tokens
+    const size_t nf = ((size_t)st->nfrags + 7) & ~(size_t)7;   // (whole 16-byte units of every element size used)
+    const size_t o_cl = THIP_TL_HDR, o_meta = o_cl + nf, o_dq = o_meta + nf, o_tok = o_dq + 18 * 64 / 2;
+    if (!st->h_tl) {
+      st->tl_cap = (o_tok + (size_t)st->nfrags * 64 + 192 + 4) * 4;
+      HIP_TRY(hipHostMalloc((void **)&st->h_tl, st->tl_cap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc((void **)&st->d_tl, st->tl_cap));
+      HIP_TRY(hipMalloc((void **)&st->d_tl_tmp, (size_t)st->nfrags * 128));
+      HIP_TRY(hipMalloc((void **)&st->d_tl_last, nf));
+      HIP_TRY(hipMalloc((void **)&st->d_tl_slot, nf * 4));
+      HIP_TRY(hipMalloc((void **)&st->d_frag_pos, nf * 4));
+      HIP_TRY(hipMemcpy(st->d_frag_pos, st->frag_pos, (size_t)st->nfrags * 4, hipMemcpyHostToDevice));
+    }
+    if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * nf));
+    // the previous frame's kernels must have read the staging buffer before it is reused
+    if (st->ev_staging && wait_event(st->ev_staging) < 0) return THIP_EFAULT;
+    uint32_t *h = st->h_tl;
+    memcpy(h + THIP_TL_OFF, tl->list_off, sizeof(tl->list_off));
+    memcpy(h + THIP_TL_LEN, tl->list_len, sizeof(tl->list_len));
+    memcpy(h + THIP_TL_CARRY, tl->eob_carry, sizeof(tl->eob_carry));
+    memcpy(h + THIP_TL_ARRIVE, tl->arrivals, sizeof(tl->arrivals));
+    for (int p = 0; p < 3; p++)
+      for (int q = 0; q < 2; q++) h[THIP_TL_DCQ + p * 2 + q] = tl->dc_quant[p][q];
+    h[THIP_TL_DCQ + 6] = h[THIP_TL_DCQ + 7] = 0;
+    memcpy(h + o_cl, tl->coded, (size_t)ncoded * 4);
+    memcpy(h + o_meta, tl->frag_meta, (size_t)ncoded * 4);
+    memcpy(h + o_dq, tl->dequant, 18 * 64 * 2);
+    memcpy(h + o_tok, tl->tokens, (size_t)tl->ntokens * 4);
+    const size_t npos = (size_t)st->tiles.ntiles * THIP_TILE_FRAGS;
+    TlPrepK P;
+    P.src = reinterpret_cast<const int4 *>(st->h_tl);
+    P.dst = reinterpret_cast<int4 *>(st->d_tl);
+    P.ncopy = (o_tok + (size_t)tl->ntokens + 3) / 4;
+    P.z[0] = reinterpret_cast<int4 *>(st->d_tl_tmp);
+    P.nz[0] = (size_t)ncoded * 8;
+    P.z[1] = reinterpret_cast<int4 *>(st->d_info);
+    P.nz[1] = npos / 2;
+    P.z[2] = reinterpret_cast<int4 *>(st->d_slot0);
+    P.nz[2] = ((size_t)st->tiles.ntiles + 3) / 4;
+    P.z[3] = reinterpret_cast<int4 *>(st->d_dc_in);
+    P.nz[3] = nf / 8;
+    hipLaunchKernelGGL(k_tok_prepare, dim3(256), dim3(256), 0, s, P);
+    TlK K;
+    memset(&K, 0, sizeof(K));
+    K.hdr = st->d_tl;
+    K.clist = reinterpret_cast<const int32_t *>(st->d_tl + o_cl);
+    K.meta = st->d_tl + o_meta;
+    K.dq = reinterpret_cast<const uint16_t *>(st->d_tl + o_dq);
+    K.tok = st->d_tl + o_tok;
+    K.frag_pos = st->d_frag_pos;
+    K.tmp = st->d_tl_tmp;
+    K.last_zzi = st->d_tl_last;
+    K.slot = st->d_tl_slot;
+    K.dc_in = st->d_dc_in;
+    K.info = st->d_info;
+    K.slot0 = st->d_slot0;
+    K.coeffs = reinterpret_cast<int4 *>(st->d_coeffs);
+    K.ncoded = (int)ncoded;
+    int c0 = 0, nmax = 0;
+    for (int p = 0; p < 3; p++) {
+      K.p[p].n = tl->ncoded[p];
+      K.p[p].c0 = c0;
+      c0 += tl->ncoded[p];
+      nmax = std::max(nmax, (int)tl->ncoded[p]);
+    }
+    const int lds = ((nmax + 15) & ~15) + 2 * nmax + 16;
+    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign), ((kTlMaxFrags + 15) & ~15) + 2 * kTlMaxFrags + 16, 2));
+    hipLaunchKernelGGL(k_tok_assign, dim3(3), dim3(1024), (size_t)lds, s, K);
+    hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
+    hipLaunchKernelGGL(k_tok_write, dim3((unsigned)(((size_t)ncoded * 8 + 255) / 256)), dim3(256), 0, s, K);
+    HIP_TRY(hipGetLastError());
+    d.frag_info = st->d_info;
+    d.coeffs = st->d_coeffs;
+    d.tile_slot0 = st->d_slot0;
+    d.nslots = (int)ncoded;      // (an upper bound: the device knows the number)
+    d.ncoded = (int)ncoded;
+    d.dc_tokens = st->d_dc_in;
+  }
+  int32_t res = 0;
+  thip_state *sp = st;
+  rc = thip_decode_frames(&sp, &d, 1, nullptr, &res);
+  if (rc < 0) return rc;
+  if (ncoded) {
+    if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(st->ev_staging, s));
+  }
   return res;
 }
 

@@ -212,6 +212,12 @@ struct th_dec_ctx {
   std::vector<uint8_t> dc_qis, frag_qi;
   int32_t pp_dc_scale[64], pp_sharp_mod[64];
   bool device_tokens;   // token -> coefficient expansion and AC dequantisation left to the backend (THIP_FE_DEVICE_TOKENS=1, ctl)
+  // everything behind the entropy decoder left to the backend: the token lists go to the device as they are
+  // (THIP_FE_DEVICE_LISTS=1, TH_DECCTL_THIP_SET_DEVICE_LISTS; thip_state_decode_token_lists)
+  bool device_lists;
+  uint32_t arrivals[3][64];          // fragments open at every (plane, index) of the current frame
+  std::vector<uint32_t> tl_tokens, tl_meta;
+  std::vector<int32_t> tl_coded;
   std::vector<uint8_t> mirror[3];
   th_stripe_callback stripe_cb;
   // slot-trace mode (THIP_FE_TRACE_BACKEND=1 at th_decode_alloc): no device state exists; the
@@ -960,6 +966,7 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   if (d->hip && getenv("THIP_FE_DEVICE_DC") && atoi(getenv("THIP_FE_DEVICE_DC")) != 0)
     d->device_dc = thip_state_set_device_dc(d->hip, 1) == 0;   // (refused for planes of more than 1024 fragment rows)
   d->device_tokens = d->hip && getenv("THIP_FE_DEVICE_TOKENS") && atoi(getenv("THIP_FE_DEVICE_TOKENS")) != 0;
+  d->device_lists = d->hip && getenv("THIP_FE_DEVICE_LISTS") && atoi(getenv("THIP_FE_DEVICE_LISTS")) != 0;
   build_geometry(d);
   d->dequant.resize((size_t)64 * 3 * 2 * 64);
   for (int qi = 0; qi < 64; qi++)
@@ -1075,6 +1082,13 @@ int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
       if (buf_sz != sizeof(int)) return TH_EINVAL;
       if (d->trace || !d->hip) return TH_EINVAL;
       d->device_tokens = *(int *)buf != 0;
+      return 0;
+    }
+    case TH_DECCTL_THIP_SET_DEVICE_LISTS: {
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(int)) return TH_EINVAL;
+      if (d->trace || !d->hip) return TH_EINVAL;
+      d->device_lists = *(int *)buf != 0;
       return 0;
     }
     case TH_DECCTL_THIP_GET_SLOT_TRACE: {
@@ -1339,6 +1353,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
       const int hg = z == 0 ? 0 : z <= 5 ? 1 : z <= 14 ? 2 : z <= 27 ? 3 : 4;
       for (int p = 0; p < 3; p++) {
         size_t n = left[p][z];
+        d->arrivals[p][z] = (uint32_t)n;
         // an EOB run still open from an earlier list ends the first blocks of this one
         if (eobs) {
           const uint32_t take = eobs < n ? eobs : (uint32_t)n;
@@ -1362,6 +1377,63 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     }
   }
   d->prof.lap(FE_TOKENS);
+  // ---- everything from here to the pictures on the device, when asked for and possible ------------------
+  bool lists_done = false;
+  if (d->device_lists && !d->trace) {
+    thip_token_lists tl;
+    memset(&tl, 0, sizeof(tl));
+    tl.frame_type = d->frame_type;
+    tl.flimit = d->setup.qp.lflims[d->qis[0]];
+    size_t nt = 0;
+    for (int p = 0; p < 3; p++)
+      for (int z = 0; z < 64; z++) nt += d->ntoks[p][z];
+    d->tl_tokens.resize(nt + 1);
+    uint32_t *o = d->tl_tokens.data();
+    size_t at = 0;
+    for (int p = 0; p < 3; p++)
+      for (int z = 0; z < 64; z++) {
+        tl.list_off[p][z] = (uint32_t)at;
+        tl.list_len[p][z] = (uint32_t)d->ntoks[p][z];
+        tl.eob_carry[p][z] = d->eob_carry[p][z];
+        tl.arrivals[p][z] = d->arrivals[p][z];
+        const Tok *t = d->toks[p][z].data();
+        for (size_t k = 0; k < d->ntoks[p][z]; k++) {
+          const uint32_t run = t[k].eob > 0xFFFFFFu ? 0xFFFFFFu : t[k].eob;   // (more than any plane the backend takes has)
+          o[at++] = t[k].eob ? (0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24)
+                             : ((uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16);
+        }
+      }
+    const size_t nc = d->cl_start[3];
+    d->tl_meta.resize(nc + 1);
+    d->tl_coded.resize(nc + 1);
+    for (int p = 0; p < 3; p++) {
+      tl.ncoded[p] = (int32_t)(d->cl_start[p + 1] - d->cl_start[p]);
+      for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
+        const int f = d->clist[ci];
+        const uint32_t qti = d->mbmode_of_frag[f] != MODE_INTRA;
+        d->tl_coded[ci] = f;
+        d->tl_meta[ci] = (uint32_t)d->refi[f] | ((uint32_t)(p * 3 + d->qii[f]) * 2u + qti) << 2 |
+                         ((uint32_t)d->mvx[f] & 0xFFu) << 8 | ((uint32_t)d->mvy[f] & 0xFFu) << 16 | (uint32_t)p << 24;
+      }
+      for (int qti = 0; qti < 2; qti++) tl.dc_quant[p][qti] = d->dequant[(((size_t)d->qis[0] * 3 + p) * 2 + qti) * 64];
+    }
+    uint16_t dq[18 * 64];
+    memset(dq, 0, sizeof(dq));
+    for (int p = 0; p < 3; p++)
+      for (int qii = 0; qii < d->nqis; qii++)
+        for (int qti = 0; qti < 2; qti++)
+          memcpy(dq + ((p * 3 + qii) * 2 + qti) * 64, &d->dequant[(((size_t)d->qis[qii] * 3 + p) * 2 + qti) * 64], 128);
+    tl.tokens = d->tl_tokens.data();
+    tl.ntokens = (int64_t)nt;
+    tl.coded = d->tl_coded.data();
+    tl.frag_meta = d->tl_meta.data();
+    tl.dequant = dq;
+    const int lrc = thip_state_decode_token_lists(d->hip, &tl);
+    if (lrc >= 0) lists_done = true;
+    else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
+    d->prof.lap(FE_EXPAND);
+  }
+  if (!lists_done) {
   // ---- 7.8 undo DC prediction (the DC token values are the first coefficient of each block) -----------
   // first pull the DC values out of the zzi == 0 lists: token by token over the coded blocks in order
   {
@@ -1549,6 +1621,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     rc = thip_frame_flush(d->hip);
     if (rc < 0) return TH_EFAULT;
   }
+  }   // (!lists_done)
   // ---- out-of-loop post-processing (decode.c:1203-1325, :2893-2911), on the backend -----------------------
   if (!d->trace) {
     if (d->pp_level <= 0) {
