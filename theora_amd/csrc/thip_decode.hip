@@ -645,7 +645,7 @@ int thip_profile_read(int64_t launches[THIP_NKERNELS], double ms[THIP_NKERNELS])
 // More than 64 KB of dynamic LDS has to be allowed per kernel and per device, once.
 static hipError_t set_dynamic_lds(const void *kernel, int bytes, int which) {
   static std::mutex mu;
-  static bool done[3][kMaxDevices];
+  static bool done[4][kMaxDevices];
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -743,7 +743,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   {
     DcBatchK D;
     memset(&D, 0, sizeof(D));
-    int ndc = 0, max_rows = 0;
+    int ndc = 0, max_rows = 0, max_dc_frags = 0;
     for (int j = 0; j < nlive; j++) {
       thip_state *st = states[live_state[j]];
       const thip_frame_desc &d = descs[live_state[j]];
@@ -762,11 +762,17 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
         p.tiles_x = st->tiles.tiles_x[pli];
         p.tile_base = st->tiles.tile_off[pli];
         if (g.nvfrags > max_rows) max_rows = g.nvfrags;
+        max_dc_frags = std::max(max_dc_frags, g.nhfrags * g.nvfrags);
       }
       ndc++;
     }
     if (ndc) {
-      hipLaunchKernelGGL(k_dc_unpredict, dim3(3, ndc), dim3((max_rows + 63) & ~63), 0, s, D);
+      if (max_dc_frags <= kDcLdsMaxFrags && !getenv("THIP_DC_GLOBAL")) {
+        HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_dc_unpredict_lds), 3 * ((kDcLdsMaxFrags + 7) & ~7), 3));
+        hipLaunchKernelGGL(k_dc_unpredict_lds, dim3(3, ndc), dim3((max_rows + 63) & ~63), (size_t)3 * ((max_dc_frags + 7) & ~7), s, D);
+      } else {
+        hipLaunchKernelGGL(k_dc_unpredict, dim3(3, ndc), dim3((max_rows + 63) & ~63), 0, s, D);
+      }
       HIP_TRY(hipGetLastError());
     }
   }
@@ -950,7 +956,12 @@ int thip_dc_unpredict_plane(int16_t *dc, const uint8_t *flags, int nhfrags, int 
   p.flags = flags;
   p.nh = nhfrags;
   p.nv = nvfrags;
-  hipLaunchKernelGGL(k_dc_unpredict, dim3(1, 1), dim3((nvfrags + 63) & ~63), 0, 0, D);
+  if ((int64_t)nhfrags * nvfrags <= kDcLdsMaxFrags && !getenv("THIP_DC_GLOBAL")) {
+    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_dc_unpredict_lds), 3 * ((kDcLdsMaxFrags + 7) & ~7), 3));
+    hipLaunchKernelGGL(k_dc_unpredict_lds, dim3(1, 1), dim3((nvfrags + 63) & ~63), (size_t)3 * ((nhfrags * nvfrags + 7) & ~7), 0, D);
+  } else {
+    hipLaunchKernelGGL(k_dc_unpredict, dim3(1, 1), dim3((nvfrags + 63) & ~63), 0, 0, D);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   return THIP_OK;
