@@ -350,6 +350,9 @@ __device__ __forceinline__ void pred_finish(const PredWin &Q, int W, uint2 pred[
 }
 
 #ifndef THIP_RECON_WAVES
+#ifndef THIP_COEF_CPOL
+#define THIP_COEF_CPOL 0   // cache policy of the coefficient loads (experiment: 2 = non-temporal)
+#endif
 #define THIP_RECON_WAVES 4
 #endif
 // Waves per workgroup of k_recon.  Waves never cooperate, and a workgroup's wave slots and
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
 #pragma unroll
       for (int q = 0; q < 8; q++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
-                                         (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, THIP_COEF_CPOL);
     }
     if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
