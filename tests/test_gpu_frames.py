@@ -110,6 +110,15 @@ def test_full_size_sequences(hip, w, h, fmt, content, n):
     assert not rep, rep[:3]
 
 
+@pytest.mark.parametrize("w,h,fmt", [(7680, 4320, PF_420), (8192, 16, PF_444), (16, 8192, PF_422)])
+def test_beyond_4k_and_extreme_shapes(hip, w, h, fmt):
+    """Larger than BASELINE.json's largest size (8K: 64 800 luma tiles, plane offsets beyond 32 MB) and the two
+    degenerate shapes -- one tile row 512 tiles wide, 1024 fragment rows one partial tile wide: key frame + two inter
+    frames, every plane against the oracle."""
+    rep = util.run_sequence(hip, w, h, fmt, nframes=3, content="mixed", seed=w + h, kf_interval=16)
+    assert not rep, rep[:3]
+
+
 def test_sequence_1080p_smooth(hip):
     rep = util.run_sequence(hip, 1920, 1088, PF_420, nframes=4, content="smooth", seed=4, kf_interval=64)
     assert not rep, rep[:3]

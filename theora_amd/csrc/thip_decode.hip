@@ -1028,13 +1028,16 @@ int thip_state_postprocess(thip_state *st, int level, const uint8_t *dc_qis, con
   }
   hipLaunchKernelGGL(k_pp_hedge, dim3((unsigned)((max_w / 4 + 63) / 64), (unsigned)(max_nv + 1), 3), dim3(64), 0, s, K);
   hipLaunchKernelGGL(k_pp_vedge, dim3((unsigned)((max_h + 63) / 64), 1, 3), dim3(64), 0, s, K);
-  for (int pli = 0; pli < 3; pli++) {
-    if (!K.dering[pli]) continue;
-    const int gnx = (K.p[pli].nh + kPpGroup - 1) / kPpGroup, gny = (K.p[pli].nv + kPpGroup - 1) / kPpGroup;
-    for (int d = 0; d < gnx + gny - 1; d++) {
-      const int n = (d < gnx ? d : gnx - 1) - (d - (gny - 1) > 0 ? d - (gny - 1) : 0) + 1;   // groups on this anti-diagonal
-      hipLaunchKernelGGL(k_pp_dering, dim3((unsigned)n), dim3(64), 0, s, K, pli, d);
+  {
+    // one launch per anti-diagonal of the group grids, the three planes side by side (blockIdx.y)
+    int nd = 0, gmax = 0;
+    for (int pli = 0; pli < 3; pli++) {
+      if (!K.dering[pli]) continue;
+      const int gnx = (K.p[pli].nh + kPpGroup - 1) / kPpGroup, gny = (K.p[pli].nv + kPpGroup - 1) / kPpGroup;
+      nd = std::max(nd, gnx + gny - 1);
+      gmax = std::max(gmax, std::min(gnx, gny));
     }
+    for (int d = 0; d < nd; d++) hipLaunchKernelGGL(k_pp_dering, dim3((unsigned)gmax, 3), dim3(64 * kPpGroup), 0, s, K, d);
   }
   HIP_TRY(hipGetLastError());
   st->pp_serial = st->frame_serial;

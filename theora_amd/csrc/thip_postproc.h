@@ -150,72 +150,81 @@ __global__ __launch_bounds__(64) void k_pp_vedge(const PpK K) {
   }
 }
 
-constexpr int kPpGroup = 4;                       // blocks per group side
-constexpr int kPpRegion = kPpGroup * 8 + 2;       // pixels per side with the halo
+constexpr int kPpGroup = 8;                       // blocks per group side
+constexpr int kPpPitch = kPpGroup * 8 + 8;        // LDS row: 3 spare bytes, the left halo, 64 pixels (dword aligned), the right halo, 3 spare
+constexpr int kPpRows = kPpGroup * 8 + 2;         // with the halo rows
+constexpr int kPpX0 = 4;                          // column of the group's first pixel in an LDS row
 #define THIP_DERING_THRESH1 384
 #define THIP_DERING_THRESH2 (4 * THIP_DERING_THRESH1)
 #define THIP_DERING_THRESH3 (5 * THIP_DERING_THRESH1)
 #define THIP_DERING_THRESH4 (10 * THIP_DERING_THRESH1)
 
-// one pass of oc_dering_block on block (lbx, lby) of the region in LDS; lane = pixel (px, py)
-__device__ __forceinline__ void pp_dering_pass(uint8_t *reg, int lbx, int lby, int dc_scale, int sharp_mod, int strong, int lane) {
-  const int px = lane & 7, py = lane >> 3;
-  uint8_t *c = reg + (1 + lby * 8 + py) * kPpRegion + (1 + lbx * 8 + px);
-  const int mod_hi = min(3 * dc_scale, strong ? 32 : 24), sh = strong ? 0 : 1;
-  const int me = c[0], up = c[-kPpRegion], dn = c[kPpRegion], lf = c[-1], rt = c[1];
-  auto modf = [&](int d) {
-    const int mod = 32 + dc_scale - (pp_abs(d) << sh);
-    return mod < -64 ? sharp_mod : min(max(mod, 0), mod_hi);
-  };
-  const int w_up = modf(me - up), w_dn = modf(dn - me), w_lf = modf(me - lf), w_rt = modf(rt - me);   // from the block as it is before the pass
-  const int a = 128 - w_up - w_dn - w_lf - w_rt;
-  // pixel after pixel in raster order: new left and upper neighbour, old right and lower one -> anti-diagonals
-  for (int t = 0; t < 15; t++) {
-    if (px + py == t) {
-      const int nl = c[-1], nu = c[-kPpRegion];          // already new when they lie inside the block
-      const int b = 64 + w_lf * nl + w_up * nu + w_dn * dn + w_rt * rt;
-      c[0] = (uint8_t)min(max((a * me + b) >> 7, 0), 255);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+__device__ __forceinline__ void pp_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// grid: (groups on anti-diagonal d of the plane's group grid); one wave per group
-__global__ __launch_bounds__(64) void k_pp_dering(const PpK K, int pli, int d) {
+// oc_dering_block (decode.c:1795-1890) filters a block in place, pixel after pixel in raster order -- a pixel sees
+// the NEW left and upper neighbour and the OLD right and lower one, its weights come from the block as it was before
+// the call -- and the blocks of a plane one after the other in raster order, each up to three times in a row.  A
+// block reads its four neighbours' border pixels only, so the blocks on an anti-diagonal of the block grid are
+// independent, and so are the pixels on an anti-diagonal of a block.  One work group of eight waves takes a group of
+// 8 x 8 blocks (its pixels and a one-pixel halo in LDS; the halo clamped into the plane is what the reference's border
+// cases amount to) and walks the group's 15 block diagonals, wave w filtering the diagonal's block in block row w:
+// all 64 lanes work out, for their pixel, what does not depend on the order (the weights and the terms of the old
+// neighbours), then lanes 0..7 run the recurrence over the block's 15 pixel diagonals in registers, handing the new
+// values from lane to lane (DPP).  Groups on an anti-diagonal of the group grid are independent: one launch per group
+// diagonal, all planes.
+__global__ __launch_bounds__(64 * kPpGroup) void k_pp_dering(const PpK K, int d) {
+  const int pli = (int)blockIdx.y;
+  if (!K.dering[pli]) return;
   const PpPlaneK &P = K.p[pli];
-  __shared__ uint8_t s_reg[kPpRegion * kPpRegion + 4];
+  __shared__ __attribute__((aligned(16))) uint8_t s_reg[kPpRows * kPpPitch];
+  __shared__ int2 s_pre[kPpGroup][64];             // per wave, per pixel: k0, w_lf | w_up << 16
   const int gnx = (P.nh + kPpGroup - 1) / kPpGroup, gny = (P.nv + kPpGroup - 1) / kPpGroup;
+  if (d >= gnx + gny - 1) return;
   const int gx0 = max(0, d - (gny - 1));
   const int gx = gx0 + (int)blockIdx.x, gy = d - gx;
   if (gx >= gnx || gy < 0 || gy >= gny) return;
-  const int lane = (int)threadIdx.x;
+  const int tid = (int)threadIdx.x, lane = tid & 63, T = 64 * kPpGroup;
+  const int b = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's block row in the group
   const int X0 = gx * kPpGroup * 8, Y0 = gy * kPpGroup * 8;
-  // region with halo, coordinates clamped into the plane (= the reference's border cases, decode.c:1803-1826)
-  for (int i = lane; i < kPpRegion * kPpRegion; i += 64) {
-    const int ry = i / kPpRegion, rx = i - ry * kPpRegion;
-    const int x = min(max(X0 - 1 + rx, 0), P.width - 1), y = min(max(Y0 - 1 + ry, 0), P.height - 1);
-    s_reg[i] = P.dst[(size_t)y * P.stride + x];
+  // the region: rows Y0-1 .. Y0+64 clamped into the plane; the 64 pixels as dwords (plane widths are multiples of 8),
+  // the two halo columns as bytes, clamped
+  for (int i = tid; i < kPpRows * 16; i += T) {
+    const int ry = i >> 4, c4 = (i & 15) * 4;
+    const int y = min(max(Y0 - 1 + ry, 0), P.height - 1), x = X0 + c4;
+    if (x < P.width) *reinterpret_cast<uint32_t *>(s_reg + ry * kPpPitch + kPpX0 + c4) = *reinterpret_cast<const uint32_t *>(P.dst + (size_t)y * P.stride + x);
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
+  for (int i = tid; i < kPpRows * 2; i += T) {
+    const int ry = i >> 1, right = i & 1;
+    const int y = min(max(Y0 - 1 + ry, 0), P.height - 1);
+    const int x = right ? min(X0 + kPpGroup * 8, P.width - 1) : max(X0 - 1, 0);
+    s_reg[ry * kPpPitch + (right ? kPpX0 + kPpGroup * 8 : kPpX0 - 1)] = P.dst[(size_t)y * P.stride + x];
+  }
+  __syncthreads();
   const int strong_plane = K.strong[pli];
   const int sthresh = pli ? THIP_DERING_THRESH4 : THIP_DERING_THRESH3;
-  bool touched = false;
-  for (int lby = 0; lby < kPpGroup; lby++)
-    for (int lbx = 0; lbx < kPpGroup; lbx++) {
-      const int fx = gx * kPpGroup + lbx, fy = gy * kPpGroup + lby;
-      if (fx >= P.nh || fy >= P.nv) continue;                                   // (wave-uniform)
+  const int i8 = lane & 7;
+  const int qx = lane & 7, qy = lane >> 3;         // the pixel this lane prepares
+  int any_touched = 0;
+  for (int D = 0; D < 2 * kPpGroup - 1; D++) {
+    const int lby = b, lbx = D - b;
+    const int fx = gx * kPpGroup + lbx, fy = gy * kPpGroup + lby;
+    const bool blk = lbx >= 0 && lbx < kPpGroup && fx < P.nh && fy < P.nv;   // (wave-uniform)
+    int passes = 0, strong = 1, dcs = 0, shm = 0;
+    bool eL = false, eR = false, eT = false, eB = false;
+    if (blk) {
       const int fi = fy * P.nh + fx;
       const int var = P.variances[fi], qi = P.frag_qi[fi];
-      const int dcs = K.dc_scale[qi], shm = K.sharp_mod[qi];
-      // a block at the plane's edge whose halo is a copy of its own pixels: refresh the halo from the block after each
-      // pass?  Not needed: the clamped halo is only read through differences with / weights on the same pixel
-      // -- but its VALUE is used (b += w * neighbour), and the neighbour is the block's own, possibly new, pixel.
-      const bool eL = fx == 0, eR = fx == P.nh - 1, eT = fy == 0, eB = fy == P.nv - 1;
-      int passes = 0, strong = 1;
-      if (strong_plane && var > sthresh) {
+      dcs = K.dc_scale[qi];
+      shm = K.sharp_mod[qi];
+      eL = fx == 0;
+      eR = fx == P.nh - 1;
+      eT = fy == 0;
+      eB = fy == P.nv - 1;
+      if (strong_plane && var > sthresh) {         // decode.c:1926-1950
         passes = 1;
         if (pli || (!eL && P.variances[fi - 1] > THIP_DERING_THRESH4) || (!eR && P.variances[fi + 1] > THIP_DERING_THRESH4) ||
             (!eT && P.variances[fi - P.nh] > THIP_DERING_THRESH4) || (!eB && P.variances[fi + P.nh] > THIP_DERING_THRESH4))
@@ -226,28 +235,66 @@ __global__ __launch_bounds__(64) void k_pp_dering(const PpK K, int pli, int d) {
         passes = 1;
         strong = 0;
       }
-      for (int pss = 0; pss < passes; pss++) {
-        // the clamped halo of a block on the plane's edge mirrors the block's own border pixels AS THEY ARE NOW
-        // (the reference reads the pixel itself there): bring it up to date before every pass
-        if (eL | eR | eT | eB) {
-          if (lane < 8) {
-            uint8_t *b0 = s_reg + (1 + lby * 8) * kPpRegion + (1 + lbx * 8);
-            if (eL) b0[lane * kPpRegion - 1] = b0[lane * kPpRegion];
-            if (eR) b0[lane * kPpRegion + 8] = b0[lane * kPpRegion + 7];
-            if (eT) b0[-kPpRegion + lane] = b0[lane];
-            if (eB) b0[8 * kPpRegion + lane] = b0[7 * kPpRegion + lane];
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_wave_barrier();
-        }
-        pp_dering_pass(s_reg, lbx, lby, dcs, shm, strong, lane);
-        touched = true;
-      }
     }
-  if (!touched) return;
-  for (int i = lane; i < kPpGroup * 8 * kPpGroup * 8; i += 64) {
-    const int ry = i / (kPpGroup * 8), rx = i - ry * (kPpGroup * 8);
-    const int x = X0 + rx, y = Y0 + ry;
-    if (x < P.width && y < P.height) P.dst[(size_t)y * P.stride + x] = s_reg[(1 + ry) * kPpRegion + 1 + rx];
+    uint8_t *const b0 = s_reg + (1 + lby * 8) * kPpPitch + kPpX0 + lbx * 8;   // the block's first pixel
+    const int mod_hi = min(3 * dcs, strong ? 32 : 24), sh = strong ? 0 : 1;
+    if (passes) any_touched = 1;
+    for (int pss = 0; pss < passes; pss++) {       // (the waves of a diagonal do not read each other's blocks: no group barrier inside)
+      // the clamped halo of a block on the plane's edge mirrors the block's own border pixels AS THEY ARE NOW
+      // (the reference reads the pixel itself there): bring it up to date before every pass
+      if (lane < 8) {
+        if (eL) b0[lane * kPpPitch - 1] = b0[lane * kPpPitch];
+        if (eR) b0[lane * kPpPitch + 8] = b0[lane * kPpPitch + 7];
+        if (eT) b0[-kPpPitch + lane] = b0[lane];
+        if (eB) b0[8 * kPpPitch + lane] = b0[7 * kPpPitch + lane];
+      }
+      pp_wave_sync();
+      // What does not depend on the order, every lane for its pixel, from the block as it is before the pass:
+      // new = (k0 + w_lf * new_left + w_up * new_up) >> 7 with k0 = a * me + 64 + w_dn * dn + w_rt * rt (the lower and
+      // right neighbours are still the old ones when a pixel's turn comes).  A left / upper neighbour outside the block
+      // does not change during the pass either: its term goes into k0 and its weight to zero.
+      {
+        const uint8_t *c = b0 + qy * kPpPitch + qx;
+        const int me = c[0], up = c[-kPpPitch], dn = c[kPpPitch], lf = c[-1], rt = c[1];
+        auto modf = [&](int dd) {
+          const int mod = 32 + dcs - (pp_abs(dd) << sh);
+          return mod < -64 ? shm : min(max(mod, 0), mod_hi);
+        };
+        const int w_up = modf(me - up), w_dn = modf(dn - me), w_lf = modf(me - lf), w_rt = modf(rt - me);
+        const int k0 = (128 - w_up - w_dn - w_lf - w_rt) * me + 64 + w_dn * dn + w_rt * rt + (qx == 0 ? w_lf * lf : 0) + (qy == 0 ? w_up * up : 0);
+        s_pre[b][lane] = make_int2(k0, ((qx == 0 ? 0 : w_lf) & 0xFFFF) | (qy == 0 ? 0 : w_up) << 16);
+      }
+      pp_wave_sync();   // every lane has read the block before anybody writes
+      // The pixel diagonals, lanes 0..7, in registers: on the way down (t <= 7) lane i holds column i -- the new upper
+      // neighbour is its own previous result, the new left one its left lane's; on the way out (t >= 8) lane i holds row
+      // 7 - i -- the new left neighbour is its own previous result, the new upper one the next lane's.
+      int2 pre[15];
+#pragma unroll
+      for (int t = 0; t < 15; t++) {
+        const int px = (t > 7 ? t - 7 : 0) + i8, py = t - px;
+        pre[t] = s_pre[b][(min(max(py, 0), 7)) * 8 + min(px, 7)];
+      }
+      int prev = 0;
+#pragma unroll
+      for (int t = 0; t < 15; t++) {
+        const int px = (t > 7 ? t - 7 : 0) + i8, py = t - px;
+        const int other = t <= 7 ? __builtin_amdgcn_update_dpp(0, prev, 0x111, 0xF, 0xF, true)    // row_shr:1: lane i reads lane i-1
+                                 : __builtin_amdgcn_update_dpp(0, prev, 0x101, 0xF, 0xF, true);   // row_shl:1: lane i reads lane i+1
+        const int nl = t <= 7 ? other : prev, nu = t <= 7 ? prev : other;
+        if (lane < 8 && px <= 7 && py >= 0) {
+          prev = min(max((pre[t].x + (int)(int16_t)(pre[t].y & 0xFFFF) * nl + (pre[t].y >> 16) * nu) >> 7, 0), 255);
+          b0[py * kPpPitch + px] = (uint8_t)prev;
+        }
+      }
+      pp_wave_sync();
+    }
+    __syncthreads();   // the diagonal is done before the next one reads its borders
+  }
+  if (!__syncthreads_or(any_touched)) return;
+  for (int i = tid; i < kPpGroup * 8 * 16; i += T) {
+    const int ry = i >> 4, c4 = (i & 15) * 4;
+    const int x = X0 + c4, y = Y0 + ry;
+    if (x < P.width && y < P.height)
+      *reinterpret_cast<uint32_t *>(P.dst + (size_t)y * P.stride + x) = *reinterpret_cast<const uint32_t *>(s_reg + (1 + ry) * kPpPitch + kPpX0 + c4);
   }
 }
