@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 SIZES = {"4k": (3840, 2160), "1080p": (1920, 1088), "720p": (1280, 720), "cif": (352, 288), "qcif": (176, 144)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec peak
 FUSED = os.environ.get("THIP_FUSE", "0")
-KERNEL_NAMES = {"1": ("k_recon_walk", "k_lf_seams"), "2": ("k_recon_st", "k_lf_st_seams"), "3": ("k_step", "k_lf_rows")}.get(FUSED, ("k_recon", "k_loopfilter"))
+KERNEL_NAMES = {"1": ("k_recon_walk", "k_lf_seams"), "2": ("k_recon_st", "k_lf_st_seams")}.get(FUSED, ("k_recon", "k_loopfilter"))
 TRAFFIC_PROFILE = "profiles/r02_pmc_traffic.json"
 KF_INTERVAL = 64
 

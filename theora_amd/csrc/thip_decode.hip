@@ -109,12 +109,6 @@ struct thip_state {
   uint16_t *h_dq, *d_dq;
   size_t tok_cap;
   int enq_ntok, enq_tok_slots, enq_dense_slots;
-  // k_step (THIP_FUSE=3): the state's task lists per XCD, chunk tables and counters, the cell rows left to k_lf_rows
-  int step_ready;
-  uint2 *d_step_tasks, *d_step_chunk_info;
-  uint32_t *d_step_done, *d_step_seams;
-  int step_task_off[9], step_nseam, step_max_nh;
-  uint32_t step_epoch;
   // token lists expanded on the device (thip_state_decode_token_lists): pinned staging, its device copy, work arrays
   uint32_t *h_tl, *d_tl;
   size_t tl_cap;            // bytes of each
@@ -395,10 +389,6 @@ void thip_state_free(thip_state *st) {
   if (st->d_slot0) (void)hipFree(st->d_slot0);
   if (st->d_dc) (void)hipFree(st->d_dc);
   if (st->d_edge) (void)hipFree(st->d_edge);
-  if (st->d_step_tasks) (void)hipFree(st->d_step_tasks);
-  if (st->d_step_chunk_info) (void)hipFree(st->d_step_chunk_info);
-  if (st->d_step_done) (void)hipFree(st->d_step_done);
-  if (st->d_step_seams) (void)hipFree(st->d_step_seams);
   if (st->h_tl) (void)hipHostFree(st->h_tl);
   if (st->d_tl) (void)hipFree(st->d_tl);
   if (st->d_tl_tmp) (void)hipFree(st->d_tl_tmp);
@@ -666,106 +656,6 @@ static hipError_t set_dynamic_lds(const void *kernel, int bytes, int which) {
   return e;
 }
 
-// k_step's per-state tables (thip_kernels.h): the tile rows dealt to the 8 XCDs, cut into chunks, turned into the
-// eight task lists R(c0) R(c1) L(c0) R(c2) L(c1) ... L(cn).
-static int ensure_step_tables(thip_state *st) {
-  if (st->step_ready) return THIP_OK;
-  static const int chunk_kb = getenv("THIP_STEP_CHUNK_KB") ? std::max(16, atoi(getenv("THIP_STEP_CHUNK_KB"))) : 256;
-  struct Row { int p, ty, w; };
-  std::vector<Row> rows;
-  int64_t N = 0;
-  for (int p = 0; p < 3; p++)
-    for (int ty = 0; ty < st->tiles.tiles_y[p]; ty++) {
-      rows.push_back({p, ty, st->tiles.tiles_x[p]});
-      N += st->tiles.tiles_x[p];
-    }
-  std::vector<int> xcd_of(rows.size());
-  {
-    int64_t cum = 0;
-    int last = 0;
-    for (size_t i = 0; i < rows.size(); i++) {
-      int x = (int)(((cum + rows[i].w / 2) * 8) / N);
-      x = std::min(7, std::max(last, x));
-      xcd_of[i] = last = x;
-      cum += rows[i].w;
-    }
-  }
-  std::vector<uint2> tasks, cinfo;
-  std::vector<uint32_t> seams;
-  int off[9];
-  size_t i = 0;
-  for (int x = 0; x < 8; x++) {
-    off[x] = (int)tasks.size();
-    // the chunks of this XCD, in tile order
-    struct Chunk { int id, p, ty0, ty1; bool first; };
-    std::vector<Chunk> ch;
-    while (i < rows.size() && xcd_of[i] == x) {
-      const int p = rows[i].p, piece0 = rows[i].ty;
-      size_t j = i;
-      while (j < rows.size() && xcd_of[j] == x && rows[j].p == p) j++;
-      const int piece1 = rows[j - 1].ty + 1;
-      const int row_bytes = st->geom[p].nhfrags * 8 * 32;
-      const int CH = std::max(1, (chunk_kb * 1024 + row_bytes / 2) / row_bytes);
-      for (int ty0 = piece0; ty0 < piece1; ty0 += CH) ch.push_back({0, p, ty0, std::min(ty0 + CH, piece1), ty0 == piece0});
-      i = j;
-    }
-    auto emit_r = [&](Chunk &c) {
-      c.id = (int)cinfo.size();
-      const thip_plane_geom &g = st->geom[c.p];
-      const int tx = st->tiles.tiles_x[c.p], r0 = 4 * c.ty0, r1 = std::min(4 * c.ty1, g.nvfrags);
-      const int m1 = r1 >= g.nvfrags ? g.nvfrags : r1 - 1;
-      cinfo.push_back(make_uint2((uint32_t)(tx * (c.ty1 - c.ty0)), (uint32_t)c.p << 28 | (uint32_t)((m1 + 1) * (g.nhfrags + 1))));
-      if (c.first && r0 > 0) seams.push_back((uint32_t)c.p << 28 | (uint32_t)r0);
-      for (int ty = c.ty0; ty < c.ty1; ty++)
-        for (int t = 0; t < tx; t++)
-          tasks.push_back(make_uint2((uint32_t)(st->tiles.tile_off[c.p] + ty * tx + t), (uint32_t)c.id << 8));
-    };
-    auto emit_l = [&](const Chunk &c) {
-      const thip_plane_geom &g = st->geom[c.p];
-      const int r0 = 4 * c.ty0;
-      const int m0 = r0 == 0 ? 0 : (c.first ? r0 + 1 : r0);
-      const uint32_t rel0 = (uint32_t)(m0 * (g.nhfrags + 1)), rel_end = cinfo[c.id].y & 0x0FFFFFFFu;
-      for (uint32_t r = rel0; r < rel_end; r += 64)
-        tasks.push_back(make_uint2(r, 1u | (c.first ? 0u : 2u) | (uint32_t)c.id << 8));
-    };
-    for (size_t k = 0; k < ch.size(); k++) {
-      emit_r(ch[k]);
-      if (k > 0) emit_l(ch[k - 1]);
-    }
-    if (!ch.empty()) emit_l(ch.back());
-  }
-  off[8] = (int)tasks.size();
-  if (seams.empty()) seams.push_back(0);   // (never read: nseam is 0)
-  HIP_TRY(hipMalloc((void **)&st->d_step_tasks, tasks.size() * sizeof(uint2)));
-  HIP_TRY(hipMalloc((void **)&st->d_step_chunk_info, cinfo.size() * sizeof(uint2)));
-  HIP_TRY(hipMalloc((void **)&st->d_step_done, cinfo.size() * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc((void **)&st->d_step_seams, seams.size() * sizeof(uint32_t)));
-  HIP_TRY(hipMemcpy(st->d_step_tasks, tasks.data(), tasks.size() * sizeof(uint2), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(st->d_step_chunk_info, cinfo.data(), cinfo.size() * sizeof(uint2), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(st->d_step_done, 0, cinfo.size() * sizeof(uint32_t)));
-  HIP_TRY(hipMemcpy(st->d_step_seams, seams.data(), seams.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  for (int x = 0; x < 9; x++) st->step_task_off[x] = off[x];
-  st->step_nseam = 0;
-  for (uint32_t v : seams) st->step_nseam += v != 0;
-  st->step_max_nh = st->geom[0].nhfrags;
-  st->step_epoch = 0;
-  st->step_ready = 1;
-  return THIP_OK;
-}
-
-// per device and lane: k_step's task counters, two sets (a launch zeroes the set of the next one)
-static uint32_t *g_step_next[kMaxDevices][kMaxLanes];
-static uint32_t g_step_launches[kMaxDevices][kMaxLanes];
-static int step_waves_per_launch() {
-  static const int n = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int per_cu = getenv("THIP_STEP_WAVES") ? std::max(1, atoi(getenv("THIP_STEP_WAVES"))) : 16;
-    return cus * per_cu;
-  }();
-  return n;
-}
-
 // Launch one chunk of <= THIP_MAX_BATCH streams.
 static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs, int n, hipStream_t s,
                         int32_t *results) {
@@ -890,49 +780,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   // re-read.  Frames that leave static blocks in place (skip_ok) keep the two-pass path, whose first
   // kernel knows how to skip whole tiles.
   static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 0;
-  if (fuse == 3 && any_lf) {
-    // one persistent launch: reconstruction and loop filter as tasks, the frame through the XCDs' L2s; then the few
-    // cell rows between two XCDs' pieces
-    int dev = 0, lane_i = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    for (int l = 0; l < g_nlanes; l++)
-      if (g_lanes[dev][l] == s) lane_i = l;
-    const size_t ctr_set = (size_t)8 * (kStepQueues + 1) * kStepCtrStride;   // dwords
-    if (!g_step_next[dev][lane_i]) {
-      HIP_TRY(hipMalloc((void **)&g_step_next[dev][lane_i], 2 * ctr_set * sizeof(uint32_t)));
-      HIP_TRY(hipMemsetAsync(g_step_next[dev][lane_i], 0, 2 * ctr_set * sizeof(uint32_t), s));
-    }
-    int max_seam = 0, max_nh = 0;
-    for (int j = 0; j < nlive; j++) {
-      thip_state *st = states[live_state[j]];
-      const int rc = ensure_step_tables(st);
-      if (rc) return rc;
-      StreamK &K = B.s[j];
-      K.tasks = st->d_step_tasks;
-      for (int x = 0; x < 9; x++) K.task_off[x] = st->step_task_off[x];
-      K.chunk_info = st->d_step_chunk_info;
-      K.chunk_done = st->d_step_done;
-      K.step_epoch = ++st->step_epoch;
-      K.seam_rows = st->d_step_seams;
-      K.nseam = st->step_nseam;
-      max_seam = std::max(max_seam, st->step_nseam);
-      max_nh = std::max(max_nh, st->step_max_nh);
-    }
-    StepK Q;
-    const uint32_t par = g_step_launches[dev][lane_i]++ & 1u;
-    Q.ctr = g_step_next[dev][lane_i] + ctr_set * par;
-    Q.ctr_nxt = g_step_next[dev][lane_i] + ctr_set * (par ^ 1u);
-    Q.nlive = nlive;
-    {
-      ScopedTimer t(s, THIP_KERNEL_RECON);
-      hipLaunchKernelGGL(k_step, dim3(step_waves_per_launch()), dim3(64), 0, s, B, Q);
-    }
-    if (max_seam) {
-      const int wpr = (max_nh + 1 + 63) / 64;
-      ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
-      hipLaunchKernelGGL(k_lf_rows, dim3((unsigned)((max_seam * wpr + 3) / 4), nlive), dim3(256), 0, s, B, wpr);
-    }
-  } else if (fuse == 2 && any_lf && !any_skip) {
+  if (fuse == 2 && any_lf && !any_skip) {
     // super tiles: one kernel closes all filter cells but the rows between two super-tile rows (left edges travel
     // between neighbouring groups), the second filters those rows and seven short columns
     int max_st = 0, max_ss = 0;

@@ -71,14 +71,6 @@ struct StreamK {
   int st_nband;           // work groups per XCD band of the k_recon_st launch (its gridDim.x / 8)
   uint8_t *edge;          // kStEdgeRec bytes per super tile: a group's last block column for its right neighbour
   uint32_t epoch;         // serial number that marks the edge records of this launch
-  // k_step: the state's task lists (one per XCD), chunk tables, chunk counters; the rows left to k_lf_rows
-  const uint2 *tasks;
-  int task_off[9];
-  const uint2 *chunk_info;
-  uint32_t *chunk_done;   // counts up by the chunk's tile count every k_step launch of this state ...
-  uint32_t step_epoch;    // ... of which this is the step_epoch-th
-  const uint32_t *seam_rows;
-  int nseam;
   PlaneK pl[3];
 };
 
@@ -570,7 +562,7 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32
 // waits.  Everything read from the kernel arguments is wave-uniform and is forced into
 // scalar registers (readfirstlane on the tile number), so the per-plane table lookups are
 // scalar loads, not dependent vector loads.
-// One tile of one stream: k_recon's wave, also a task of k_step.  lds_wave: the wave's 8 KB of LDS, meta: its 64
+// One tile of one stream: k_recon's wave.  lds_wave: the wave's 8 KB of LDS, meta: its 64
 // dwords for residual_shared.  (Lanes leave at different places; the caller gets the whole wave back.)
 __device__ __forceinline__ void recon_tile(const StreamK &S, const int unit, const int lane, uint4 *const lds_wave,
                                            uint32_t *const meta, unsigned long long *tr) {
@@ -1861,8 +1853,7 @@ __global__ __launch_bounds__(256) void k_expand_tokens(const TokK K) {
 #ifndef THIP_LF_WG
 #define THIP_LF_WG 256   // threads per workgroup of k_loopfilter
 #endif
-// The cell of plane-relative index rel (row-major over the (nh+1) x (nv+1) corners) of plane pli: k_loopfilter's
-// lane, also a task of k_step.
+// The cell of plane-relative index rel (row-major over the (nh+1) x (nv+1) corners) of plane pli: k_loopfilter's lane.
 __device__ __forceinline__ void lf_wave(const StreamK &S, const int pli, const int rel, const int rel_end) {
   uint8_t *self = S.self;
   const uint8_t *cmap = S.coded_map;
@@ -1913,126 +1904,6 @@ __global__ __launch_bounds__(THIP_LF_WG) void k_loopfilter(const BatchK B) {
   const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
   lf_wave(S, pli, rel, (S.pl[pli].nh + 1) * (S.pl[pli].nv + 1));
 }
-
-// ---------------------------------------------------------------------------------------
-// k_step + k_lf_rows: reconstruction and loop filter as tasks of ONE launch, the frame through L2 (THIP_FUSE=3)
-// ---------------------------------------------------------------------------------------
-// Nothing of a kernel's output is still in L2 when the next kernel starts, so the second
-// pass re-reads every pixel from HBM and writes it back: a third of the traffic.  Inside one kernel it is
-// different: an XCD's L2 keeps what that XCD's waves wrote a few hundred microseconds of traffic ago.  So here a
-// persistent grid of single-wave groups takes TASKS from a per-XCD list (HW_REG_XCC_ID tells a wave where it runs):
-//   * every plane's tile rows are dealt to the 8 XCDs in contiguous pieces of equal tile count, a piece is cut into
-//     CHUNKS of a few tile rows (about a quarter megabyte of pixels);
-//   * an R task is one tile of a chunk -- recon_tile(), i.e. k_recon's wave, unchanged -- and counts itself done in the
-//     chunk's counter once its stores are in L2; an L task is 64 filter cells of a chunk -- lf_wave(), k_loopfilter's
-//     wave -- and first waits until the chunk's (and the previous chunk's) tiles are all done;
-//   * the list of an XCD reads R(c0) R(c1) L(c0) R(c2) L(c1) ... for every stream in turn, dealt round-robin to 32 queues;
-//     a wave takes the next entry of its queue with one atomic add (and helps the next queue when its own is empty).  A task
-//     that is taken is being run and an R task never waits, so the earliest task not yet taken can always be taken and
-//     everything an L task waits for has a smaller list index: no deadlock; and by the time L(c) comes up R(c) was handed
-//     out a chunk of tasks ago.
-// The pixels an L task reads were written by the same XCD a chunk earlier and the pixels it writes replace lines that are
-// still dirty in that L2: the frame goes to HBM once.  What is left for k_lf_rows are the cell rows on the boundaries
-// between two XCDs' pieces (at most 7 per plane-piece boundary), whose upper blocks sit in another L2.
-// task word: x = tile (R) or first cell of the wave, plane-relative (L); y = type | (wait for the previous chunk too) << 1 |
-// chunk << 8.  chunk_info[c] = {tiles in the chunk, plane << 28 | end of its cell range}.
-constexpr int kStepQueues = 32;        // task queues per XCD: task i of an XCD's list sits in queue i % 32 (one counter for
-                                       // 576 waves costs 130 ns a task: the whole launch ten times over)
-constexpr int kStepCtrStride = 256;    // dwords between two counters (1 KB: different L2 channels)
-struct StepK {
-  uint32_t *ctr;      // [8][kStepQueues + 1] counters, kStepCtrStride apart, zero at launch: next position per queue; arrivals
-  uint32_t *ctr_nxt;  // the counters of the next launch, zeroed by this one
-  int nlive;
-};
-// Counters shared by the waves of ONE XCD: the add is done by that XCD's L2 (a device-scope atomic goes out to memory:
-// measured 130 ns apiece and the whole launch ten times over), the poll likewise.
-__device__ __forceinline__ uint32_t step_add(uint32_t *p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// (a device-scope LOAD of a word the L2 keeps adding to goes to memory behind the L2's back -- measured: 70 us apiece --,
-//  so the poll is an atomic OR of nothing, answered by the L2 itself)
-__device__ __forceinline__ uint32_t step_ld(const uint32_t *p) {   // (wave-uniform p: one lane asks)
-  uint32_t v = 0;
-  const uint32_t zero = 0;
-  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
-    asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(zero) : "memory");
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
-__global__ __launch_bounds__(64, THIP_RECON_WAVES) void k_step(const BatchK B, const StepK Q) {
-  __shared__ uint4 s_coef[8 * 64];
-  __shared__ uint32_t s_meta[64];
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const int xcd = (int)(xcc & 7u);
-  for (int i = (int)(blockIdx.x * 64 + threadIdx.x); i < 8 * (kStepQueues + 1); i += (int)(gridDim.x * 64))
-    Q.ctr_nxt[(size_t)i * kStepCtrStride] = 0;
-  uint32_t *const myctr = Q.ctr + (size_t)xcd * (kStepQueues + 1) * kStepCtrStride;
-  uint32_t total = 0;
-  for (int s = 0; s < Q.nlive; s++) total += (uint32_t)(B.s[s].task_off[xcd + 1] - B.s[s].task_off[xcd]);
-  // this wave's home queue: by order of arrival on its XCD
-  uint32_t q = 0;
-  if (threadIdx.x == 0) q = step_add(myctr + (size_t)kStepQueues * kStepCtrStride);
-  q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q) % kStepQueues;
-  int dry = 0;                           // queues found empty in a row
-  while (dry < kStepQueues) {
-    // (the lane number opaque per task: otherwise everything that depends on it alone is hoisted out of the loop
-    //  and kept in registers across both task bodies)
-    int lane = (int)threadIdx.x;
-    asm volatile("" : "+v"(lane));
-    uint32_t pos = 0;
-    if (lane == 0) pos = step_add(myctr + (size_t)q * kStepCtrStride);
-    pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-    uint32_t i = pos * kStepQueues + q;
-    if (i >= total) {                    // this queue is empty: help the next one
-      q = (q + 1) % kStepQueues;
-      dry++;
-      continue;
-    }
-    dry = 0;
-    int s = 0;
-    for (; s < Q.nlive - 1; s++) {
-      const uint32_t cnt = (uint32_t)(B.s[s].task_off[xcd + 1] - B.s[s].task_off[xcd]);
-      if (i < cnt) break;
-      i -= cnt;
-    }
-    const StreamK &S = B.s[s];
-    const uint2 task = S.tasks[S.task_off[xcd] + (int)i];
-    const uint32_t tx = (uint32_t)__builtin_amdgcn_readfirstlane((int)task.x), ty = (uint32_t)__builtin_amdgcn_readfirstlane((int)task.y);
-    const uint32_t chunk = ty >> 8;
-    if ((ty & 1u) == 0) {
-      recon_tile(S, (int)tx, lane, s_coef, s_meta, nullptr);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile's pixels and flags are in L2
-      if (lane == 0) (void)step_add(S.chunk_done + chunk);
-    } else {
-      const uint2 ci = S.chunk_info[chunk];
-      const uint32_t need = S.step_epoch * ci.x;
-      // (bounded: a wrong picture is a failed test, a hang is a dead GPU)
-      for (int spins = 0; spins < (1 << 22) && (int)(step_ld(S.chunk_done + chunk) - need) < 0; spins++) __builtin_amdgcn_s_sleep(32);
-      if (ty & 2u) {
-        const uint32_t need0 = S.step_epoch * S.chunk_info[chunk - 1].x;
-        for (int spins = 0; spins < (1 << 22) && (int)(step_ld(S.chunk_done + chunk - 1) - need0) < 0; spins++) __builtin_amdgcn_s_sleep(32);
-      }
-      asm volatile("" ::: "memory");
-      lf_wave(S, (int)(ci.y >> 28), (int)tx + lane, (int)(ci.y & 0x0FFFFFFFu));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS areas are free for the next task
-  }
-}
-
-// The cell rows k_step leaves: seam_rows[j] = plane << 28 | cell row, nseam of them; one wave per 64 cells of a row.
-__global__ __launch_bounds__(256) void k_lf_rows(const BatchK B, int waves_per_row) {
-  const StreamK &S = B.s[blockIdx.y];
-  const int lane = (int)threadIdx.x & 63;
-  const int w = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
-  const int j = __builtin_amdgcn_readfirstlane(w / waves_per_row), wr = w - j * waves_per_row;
-  if (j >= S.nseam || S.flimit2 == 0) return;
-  const uint32_t sr = S.seam_rows[j];
-  const int pli = (int)(sr >> 28), m = (int)(sr & 0x0FFFFFFFu);
-  const int nh = S.pl[pli].nh;
-  const int k = wr * 64 + lane;
-  if (k > nh) return;
-  lf_wave(S, pli, m * (nh + 1) + k, (m + 1) * (nh + 1));
-}
-
 
 // plane-level entry for the slot parity test (thip_loop_filter_plane)
 __global__ __launch_bounds__(256) void k_loopfilter_plane(uint8_t *plane, int stride, int nh, int nv,
