@@ -681,7 +681,7 @@ __device__ __forceinline__ void recon_tile(const StreamK &S, const int unit, con
     residual_shared_load<2>(coeffs_p, slot0, nown, lane, W);
     if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
-    residual_shared<2>(W, lds_dw, meta, lane, L, prefix, Y);
+    residual_shared<2, true>(W, lds_dw, meta, lane, L, prefix, Y);   // (results over the exchange: 4 KB, the meta words behind)
     THIP_TR(R.tr, 3);
   } else {
     // ---- many owners: one lane per block.  Coefficients go global -> LDS directly (LDS address
@@ -738,10 +738,11 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
 #ifndef THIP_RECON_LDS_PAD
 #define THIP_RECON_LDS_PAD 0
 #endif
+  // 8 KB per wave and not a byte more -- 20 waves are 160 KB, a CU's LDS: the paths that need the meta words
+  // (residual_shared) use the first 4 KB only and find them at 4 KB
   __shared__ uint4 s_coef[THIP_RECON_WG_WAVES * 8 * 64 + THIP_RECON_LDS_PAD / 16];   // [wave][piece][lane]: 8 KB per wave, wave-private
-  __shared__ uint32_t s_meta[THIP_RECON_WG_WAVES * 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  recon_tile(S, unit, lane, s_coef + wave * 512, s_meta + wave * 64, tr);
+  recon_tile(S, unit, lane, s_coef + wave * 512, reinterpret_cast<uint32_t *>(s_coef + wave * 512) + 1024, tr);
 }
 
 // ---------------------------------------------------------------------------------------
