@@ -263,47 +263,6 @@ def test_parity_check_has_teeth(hip):
     assert util.planes_equal(ost, gst), "comparison failed to notice a different filter limit"
 
 
-@pytest.mark.parametrize("waves,groups", [(8, 0), (16, 64), (1, 8), (3, 40), (5, 2048)])
-def test_fused_walk_variant(hip, waves, groups):
-    """THIP_FUSE=1 selects k_recon_walk + k_lf_seams: the waves of a work group deal out a range of tiles,
-    hand the tile edges to each other through LDS, filter every cell that does not lie on a tile-row
-    boundary and write the frame once; the second kernel filters the boundary rows and the cells on the
-    cuts between two groups' ranges.  The sequence tests of this file in a child process with the switch
-    on, for several shapes: the default, a single wave walking alone, few large ranges, more groups
-    than tiles (cuts everywhere)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, THIP_FUSE="1", THIP_WALK_WAVES=str(waves))
-    if groups:
-        env["THIP_WALK_WGS"] = str(groups)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sel = "(sequence or enqueue or batched or grey or dup or lane_shared or static_background) and not elision and not fused"
-    if groups:
-        sel = "(sequence_small or sequence_1080p or enqueue or batched or lane_shared) and not elision and not fused"
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q", "-k", sel],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-def test_fused_super_tile_variant(hip):
-    """THIP_FUSE=2 selects k_recon_st + k_lf_st_seams: one work group per super tile of 2 x 4 tiles, the filter
-    cells inside it closed in LDS, the left edge handed from group to group through L2, the frame written once; the
-    second kernel filters the cell rows between two super-tile rows.  The sequence tests of this file (all formats
-    and sizes, slots, batches, DUP frames, the grey start, four 4K streams in one call, DC values from the
-    device) in a child process with the switch on."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, THIP_FUSE="2")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sel = ("(sequence or enqueue or batched or grey or dup or lane_shared or static_background or four_concurrent "
-           "or dc_unprediction) and not elision and not fused")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q", "-k", sel],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_static_block_elision_forced_on_every_frame(hip):
     """THIP_SKIP_STATIC=2 lifts the "most of the frame is uncoded" condition, so that every inter frame of
     the sequence tests of this file (scattered uncoded blocks, all content classes, the slots, batches, DUP
