@@ -75,6 +75,7 @@ struct thip_state {
   int ref_idx[3];       // THIP_FRAME_* -> buffer index
   int last_decoded;     // buffer index of the most recently completed frame, -1 if none
   int lane;             // library-owned HIP stream this state is bound to, -1 until first use
+  int ctx_lane;         // ... when it is fed through the enqueue slots: its context stream, -1 until first use
   int32_t *frag_pos;    // host: raster fragment index -> tile*256+lane
   // host-enqueue staging (allocated on first use)
   int staging_ready;
@@ -82,6 +83,7 @@ struct thip_state {
   int16_t *h_coeffs, *d_coeffs;
   uint32_t *h_slot0, *d_slot0;
   hipEvent_t ev_staging;     // recorded behind the kernels that read the staging buffers (enqueue path)
+  hipEvent_t ev_order;       // orders a frame behind the previous one when the two go down different streams
   hipStream_t last_stream;   // stream of the most recent launch for this state (ycbcr_out copies on it)
   // Output to the host: k_frame_out writes the finished frame, top row first and tightly packed,
   // straight into one of two pinned images (the kernel's stores cross PCIe; no DMA call, no flip
@@ -136,6 +138,13 @@ hipStream_t g_lanes[kMaxDevices][kMaxLanes];   // per device, created on first u
 int g_lanes_ready[kMaxDevices];
 int g_nlanes = 0;                              // lanes per device (THIP_LANES, default 2)
 int g_next_lane[kMaxDevices];
+// Streams for the states that are fed through the enqueue slots (one th_decode_* context each): their GPU work is a
+// chain of small dependent launches per frame (longer with post-processing or the device-side front-end stages), so
+// contexts on different host threads want chains of their own rather than two lanes between them.  THIP_CTX_LANES
+// (default 8, 0 = the lanes above).
+constexpr int kCtxLanes = 16;
+hipStream_t g_ctx_lanes[kMaxDevices][kCtxLanes];
+int g_ctx_ready[kMaxDevices], g_next_ctx[kMaxDevices];
 
 // Makes `device` current for the calling host thread for the lifetime of the object (HIP's current
 // device is per thread) and puts the previous one back: a state may live on any GPU of the node
@@ -204,6 +213,29 @@ struct ScopedTimer {
     }
   }
 };
+
+// The stream of an enqueue-fed state (device current).
+int context_stream(thip_state *st, hipStream_t *out) {
+  static const int nctx = [] {
+    const int v = getenv("THIP_CTX_LANES") ? atoi(getenv("THIP_CTX_LANES")) : 8;
+    return v < 0 ? 0 : (v > kCtxLanes ? kCtxLanes : v);
+  }();
+  int rc = ensure_lanes(st->device);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (nctx == 0) {
+    if (st->lane < 0) st->lane = g_next_lane[st->device]++ % g_nlanes;
+    *out = g_lanes[st->device][st->lane];
+    return THIP_OK;
+  }
+  if (!g_ctx_ready[st->device]) {
+    for (int i = 0; i < nctx; i++) HIP_TRY(hipStreamCreateWithFlags(&g_ctx_lanes[st->device][i], hipStreamNonBlocking));
+    g_ctx_ready[st->device] = 1;
+  }
+  if (st->ctx_lane < 0) st->ctx_lane = g_next_ctx[st->device]++ % nctx;
+  *out = g_ctx_lanes[st->device][st->ctx_lane];
+  return THIP_OK;
+}
 
 // Fused path (k_recon_walk): waves per work group, and how many groups one launch spreads over the chip.
 int walk_waves() {
@@ -359,6 +391,7 @@ int thip_state_create_on(thip_state **out, int device, int frame_width, int fram
   st->ref_idx[0] = st->ref_idx[1] = st->ref_idx[2] = -1;   // state.c:658-663
   st->last_decoded = -1;
   st->lane = -1;
+  st->ctx_lane = -1;
   st->out_cur = -1;
   st->out_serial = -1;
   st->buf_serial[0] = st->buf_serial[1] = st->buf_serial[2] = -1;
@@ -388,6 +421,7 @@ void thip_state_free(thip_state *st) {
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
   if (st->d_slot0) (void)hipFree(st->d_slot0);
   if (st->d_dc) (void)hipFree(st->d_dc);
+  if (st->ev_order) (void)hipEventDestroy(st->ev_order);
   if (st->d_edge) (void)hipFree(st->d_edge);
   if (st->h_tl) (void)hipHostFree(st->h_tl);
   if (st->d_tl) (void)hipFree(st->d_tl);
@@ -598,6 +632,8 @@ int thip_synchronize(void) {
     if (!g_lanes_ready[d]) continue;
     DeviceGuard dg(d);
     for (int i = 0; i < g_nlanes; i++) HIP_TRY(hipStreamSynchronize(g_lanes[d][i]));
+    for (int i = 0; i < kCtxLanes; i++)
+      if (g_ctx_ready[d] && g_ctx_lanes[d][i]) HIP_TRY(hipStreamSynchronize(g_ctx_lanes[d][i]));
   }
   return THIP_OK;
 }
@@ -673,6 +709,12 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     if (d.flimit < 0 || d.flimit > 127) return THIP_EINVAL;
     if (d.frame_type != THIP_INTRA_FRAME && d.frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
     if (d.frame_type == THIP_INTRA_FRAME && d.ncoded != st->nfrags) return THIP_EINVAL;
+    // a state whose previous frame went down another stream (frame calls and enqueue calls mixed): this one waits for it
+    if (st->last_stream && st->last_stream != s) {
+      if (!st->ev_order) HIP_TRY(hipEventCreateWithFlags(&st->ev_order, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(st->ev_order, st->last_stream));
+      HIP_TRY(hipStreamWaitEvent(s, st->ev_order, 0));
+    }
     // decode.c:2757-2762: an inter frame without references decodes against mid-grey
     if (d.frame_type != THIP_INTRA_FRAME &&
         (st->ref_idx[THIP_FRAME_GOLD] < 0 || st->ref_idx[THIP_FRAME_PREV] < 0)) {
@@ -1304,13 +1346,9 @@ int thip_frame_flush(thip_state *st) {
   // every fragment must have been reconstructed or copied exactly once
   if (st->enq_ncoded && (int64_t)st->enq_ncoded + st->enq_nuncoded != st->nfrags) return THIP_EINVAL;
   DeviceGuard dg(st->device);
-  int rc = ensure_lanes(st->device);
+  hipStream_t s;
+  int rc = context_stream(st, &s);
   if (rc) return rc;
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (st->lane < 0) st->lane = g_next_lane[st->device]++ % g_nlanes;
-  }
-  hipStream_t s = g_lanes[st->device][st->lane];
   const size_t ngroups = ((size_t)st->enq_nslots + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
   static const int zerocopy = getenv("THIP_ZEROCOPY") ? atoi(getenv("THIP_ZEROCOPY")) : 1;
   if (st->enq_ncoded && !zerocopy) {
@@ -1360,7 +1398,7 @@ int thip_frame_flush(thip_state *st) {
   }
   int32_t res = 0;
   thip_state *sp = st;
-  rc = thip_decode_frames(&sp, &d, 1, nullptr, &res);
+  rc = thip_decode_frames(&sp, &d, 1, (void *)s, &res);
   st->lf_rows_custom = 0;
   st->flush_flags = 0;
   if (rc < 0) return rc;
@@ -1409,15 +1447,11 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
     }
   }
   DeviceGuard dg(st->device);
-  int rc = ensure_lanes(st->device);
+  hipStream_t s;
+  int rc = context_stream(st, &s);
   if (rc) return rc;
   rc = ensure_staging(st);
   if (rc) return rc;
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (st->lane < 0) st->lane = g_next_lane[st->device]++ % g_nlanes;
-  }
-  hipStream_t s = g_lanes[st->device][st->lane];
   thip_frame_desc d;
   memset(&d, 0, sizeof(d));
   d.frame_type = tl->frame_type;
@@ -1503,7 +1537,7 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
   }
   int32_t res = 0;
   thip_state *sp = st;
-  rc = thip_decode_frames(&sp, &d, 1, nullptr, &res);
+  rc = thip_decode_frames(&sp, &d, 1, (void *)s, &res);
   if (rc < 0) return rc;
   if (ncoded) {
     if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));
