@@ -135,6 +135,16 @@ def test_enqueue_path_matches(hip):
     assert not rep, rep[:3]
 
 
+def test_frame_calls_and_enqueue_calls_by_turns_on_one_state(hip):
+    """A state fed through the enqueue slots runs on a context stream, one decoded with thip_decode_frames on a batch
+    lane: frames of ONE state that alternate between the two are ordered behind each other with an event (every
+    inter frame reads what the call before it, on the other stream, wrote).  Compared every fourth frame only.  (The
+    Python-driven slots are far slower than the GPU, so this checks the path, not the race.)"""
+    rep = util.run_sequence(hip, 336, 272, PF_420, nframes=16, content="mixed", seed=21, kf_interval=8, enqueue="alternate",
+                            check_every=4)
+    assert not rep, rep[:3]
+
+
 def test_start_on_inter_frame_uses_grey_dummy(hip):
     """decode.c:2757-2762 / :2053-2080: no keyframe yet -> references are 0x80."""
     w, h = 96, 64

@@ -26,8 +26,10 @@ def planes_equal(ost, gst, slot=oracle.FRAME_PREV):
     return bad
 
 
-def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, enqueue=False):
-    """Decode nframes synthetic frames on both sides; returns list of mismatch reports."""
+def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, enqueue=False, check_every=1):
+    """Decode nframes synthetic frames on both sides; returns list of mismatch reports.  enqueue: False (frame calls),
+    True (the enqueue slots) or "alternate" (by turns, on the same state); check_every: compare every n-th frame only,
+    so that the frames in between are in flight behind each other."""
     geom = synth.Geometry(w, h, fmt)
     rng = np.random.default_rng(seed)
     ost = oracle.State(w, h, fmt)
@@ -38,7 +40,7 @@ def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, e
         ftype = theora_amd.INTRA_FRAME if f % kf_interval == 0 else theora_amd.INTER_FRAME
         fr = synth.gen_frame(geom, rng, ftype, content)
         rc_o = oracle_apply(ost, fr)
-        if enqueue:
+        if enqueue is True or (enqueue == "alternate" and f % 2 == 0):
             rc_g = enqueue_frame(theora_amd, gst, geom, fr)
         else:
             desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
@@ -46,9 +48,10 @@ def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, e
             rc_g = theora_amd.decode_frames([gst], [desc])[0]
         assert rc_o == rc_g, (f, rc_o, rc_g)
         assert ost.ref_frame_idx == [gst.ref_idx(k) for k in range(3)], f
-        bad = planes_equal(ost, gst)
-        if bad:
-            reports.append((f, bad))
+        if (f + 1) % check_every == 0 or f == nframes - 1:
+            bad = planes_equal(ost, gst)
+            if bad:
+                reports.append((f, bad))
     theora_amd.synchronize()
     return reports
 
