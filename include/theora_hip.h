@@ -225,7 +225,9 @@ int thip_frame_flush(thip_state *st);
    dct_coeffs[0] would carry it; dqsel names one of the frame's AC dequantisation tables
    (thip_frame_dequant_table: 64 entries in zig-zag order, the reference's dequant[pli][qii][qti],
    decode.c:1537-1538; sel 0..17, valid until the flush).  4 bytes per non-zero coefficient cross PCIe
-   instead of 128 per block.  Fragments of one frame may arrive through either form. */
+   instead of 128 per block.  One form per frame for the blocks that need a coefficient slot (last_zzi >= 2): once a
+   frame has received such a block through one entry point, the other refuses them with THIP_EINVAL and leaves
+   the frame as it was; DC-only blocks (last_zzi < 2) own no slot and may arrive through either. */
 int thip_frame_dequant_table(thip_state *st, int sel, const uint16_t dequant[64]);
 int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const uint32_t *toks, int ntoks,
                                  int16_t dc, int last_zzi, uint16_t dc_quant, int dqsel, int refi, int16_t mv);

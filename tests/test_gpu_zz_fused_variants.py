@@ -49,3 +49,22 @@ def test_fused_super_tile_variant(hip):
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q", "-k", sel],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fused_single_wave_tiles_variant(hip):
+    """THIP_FUSE=3 selects k_recon_lf (theora_amd/csrc/thip_fused.h): one wave per tile reconstructs it, hands its last block
+    column and block row to the tiles on its right and below through per-tile records in L2 (device-scope stores where the
+    reader sits on another XCD's band), takes its left / upper neighbours' edges the same way and closes all 64 filter cells
+    of its region -- the frame is written once and there is no second kernel.  The sequence tests of test_gpu_frames.py (all
+    formats and sizes from 16x16 to 8K, ragged tiles, slots, batches, DUP frames, the grey start, four 4K streams in one
+    call, DC values from the device, the loop-filter row ranges of the enqueue slot) in a child process with the switch on."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, THIP_FUSE="3")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sel = ("(sequence or enqueue or batched or grey or dup or lane_shared or static_background or four_concurrent "
+           "or dc_unprediction or beyond_4k or frame_calls) and not elision and not fused")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q", "-k", sel],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -54,6 +54,7 @@ using namespace thip;
   } while (0)
 
 #include "thip_kernels.h"
+#include "thip_fused.h"
 #include "thip_postproc.h"
 #include "thip_tokens.h"
 
@@ -110,10 +111,12 @@ struct thip_state {
   uint32_t *h_slot_tok, *d_slot_tok;
   uint16_t *h_dq, *d_dq;
   size_t tok_cap;
+  int tok_ready;             // all six token staging buffers exist
   int enq_ntok, enq_tok_slots, enq_dense_slots;
   // token lists expanded on the device (thip_state_decode_token_lists): pinned staging, its device copy, work arrays
   uint32_t *h_tl, *d_tl;
   size_t tl_cap;            // bytes of each
+  int tl_ready;             // all of the buffers below exist and d_frag_pos is filled
   int16_t *d_tl_tmp;        // [nfrags][64]
   uint8_t *d_tl_last;       // [nfrags]
   uint32_t *d_tl_slot;      // [nfrags]
@@ -257,6 +260,64 @@ int walk_groups_per_launch() {   // default: what is resident at once -- CUs x (
     return cus * per_cu;
   }();
   return n;
+}
+
+// k_recon_lf hands tile edges from work group to work group through the L2 of ONE XCD, which is only right if
+// work group i of a launch runs on XCD i mod 8 (how the eight XCDs of this chip share a dispatch).  Checked once
+// per device with a probe launch; on any other answer the fused kernel is not used.
+__global__ void k_xcc_probe(uint32_t *out) {
+  uint32_t xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) out[blockIdx.x] = xcc & 15u;
+}
+bool xcd_round_robin(int device) {   // the device must be current
+  static std::mutex mu;
+  static int known[kMaxDevices];     // 0 = not probed, 1 = round robin over 8, -1 = anything else
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || device >= kMaxDevices) return false;
+  if (!known[device]) {
+    known[device] = -1;
+    constexpr int kN = 2048;
+    uint32_t *d = nullptr;
+    std::vector<uint32_t> h(kN, 0xFFu);
+    if (hipMalloc((void **)&d, kN * sizeof(uint32_t)) == hipSuccess) {
+      hipLaunchKernelGGL(k_xcc_probe, dim3(kN), dim3(64), 0, 0, d);
+      if (hipMemcpy(h.data(), d, kN * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+        bool ok = true;
+        for (int i = 0; i < kN && ok; i++) ok = h[i] == h[i & 7];
+        for (int i = 0; i < 8 && ok; i++)
+          for (int j = 0; j < i; j++) ok = ok && h[i] != h[j];
+        known[device] = ok ? 1 : -1;
+      }
+      (void)hipFree(d);
+    }
+  }
+  return known[device] == 1;
+}
+
+// k_recon_lf: the stream's tile rows dealt to 8 bands of (nearly) equal tile counts; returns the longest band.
+int fill_bands(StreamK &K, const thip_state *st) {
+  const int total = K.tile_end[2];
+  int row_start[3 * 4096 + 1], nrows = 0, u = 0;
+  for (int pli = 0; pli < 3; pli++)
+    for (int y = 0; y < st->tiles.tiles_y[pli] && nrows < 3 * 4096; y++) {
+      row_start[nrows++] = u;
+      u += st->tiles.tiles_x[pli];
+    }
+  row_start[nrows] = total;
+  K.band_u0[0] = 0;
+  K.band_u0[8] = total;
+  int r = 0;
+  for (int b = 1; b < 8; b++) {
+    const long long target = (long long)b * total / 8;
+    while (r < nrows && row_start[r + 1] <= target) r++;           // row_start[r] <= target < row_start[r+1]
+    const int lo = row_start[r], hi = row_start[r + 1];
+    K.band_u0[b] = (target - lo <= hi - target) ? lo : hi;          // the nearer row boundary
+    if (K.band_u0[b] < K.band_u0[b - 1]) K.band_u0[b] = K.band_u0[b - 1];
+  }
+  int longest = 0;
+  for (int b = 0; b < 8; b++) longest = std::max(longest, K.band_u0[b + 1] - K.band_u0[b]);
+  return longest;
 }
 
 // Fills the per-plane kernel geometry and the cumulative tile / cell counts.
@@ -822,7 +883,25 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   // re-read.  Frames that leave static blocks in place (skip_ok) keep the two-pass path, whose first
   // kernel knows how to skip whole tiles.
   static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 0;
-  if (fuse == 2 && any_lf && !any_skip) {
+  if (fuse == 3 && any_lf && !any_skip && xcd_round_robin(states[live_state[0]]->device)) {
+    // one wave per tile, reconstruction and every filter cell in one pass (thip_fused.h)
+    int longest = 1;
+    for (int j = 0; j < nlive; j++) {
+      thip_state *st = states[live_state[j]];
+      StreamK &K = B.s[j];
+      if (st->tiles.tiles_y[0] > 4096) return THIP_EIMPL;
+      longest = std::max(longest, fill_bands(K, st));
+      if (!st->d_edge) {
+        HIP_TRY(hipMalloc((void **)&st->d_edge, (size_t)K.tile_end[2] * kTfRec));
+        HIP_TRY(hipMemsetAsync(st->d_edge, 0, (size_t)K.tile_end[2] * kTfRec, s));
+      }
+      K.edge = st->d_edge;
+      st->edge_epoch = st->edge_epoch % 4095u + 1u;   // 12 bits in a record's flag word, never 0
+      K.epoch = st->edge_epoch;
+    }
+    ScopedTimer t(s, THIP_KERNEL_RECON);
+    hipLaunchKernelGGL(k_recon_lf, dim3(8 * longest, nlive), dim3(64), 0, s, B);
+  } else if (fuse == 2 && any_lf && !any_skip) {
     // super tiles: one kernel closes all filter cells but the rows between two super-tile rows (left edges travel
     // between neighbouring groups), the second filters those rows and seven short columns
     int max_st = 0, max_ss = 0;
@@ -1028,11 +1107,9 @@ int thip_state_postprocess(thip_state *st, int level, const uint8_t *dc_qis, con
     return THIP_OK;
   }
   DeviceGuard dg(st->device);
-  if (!st->pp_frame) {
-    HIP_TRY(hipMalloc((void **)&st->pp_frame, st->frame_bytes + 256));
-    HIP_TRY(hipMalloc((void **)&st->pp_var, sizeof(int) * (size_t)st->nfrags));
-    HIP_TRY(hipMalloc((void **)&st->pp_qis, 2 * (size_t)st->nfrags));
-  }
+  if (!st->pp_frame) HIP_TRY(hipMalloc((void **)&st->pp_frame, st->frame_bytes + 256));
+  if (!st->pp_var) HIP_TRY(hipMalloc((void **)&st->pp_var, sizeof(int) * (size_t)st->nfrags));
+  if (!st->pp_qis) HIP_TRY(hipMalloc((void **)&st->pp_qis, 2 * (size_t)st->nfrags));
   hipStream_t s = st->last_stream;
   HIP_TRY(hipMemcpyAsync(st->pp_qis, dc_qis, (size_t)st->nfrags, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(st->pp_qis + st->nfrags, frag_qi, (size_t)st->nfrags, hipMemcpyHostToDevice, s));
@@ -1191,12 +1268,13 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
     // from the tile's first slot and a prefix count, so arrival must not jump backwards
     // inside a tile.
     const int tile = pos / THIP_TILE_FRAGS, lane = pos % THIP_TILE_FRAGS;
+    if (st->enq_tok_slots) return THIP_EINVAL;   // the frame's coefficient slots come from the token form (expanded on the device)
     if (lane <= st->enq_last_lane[tile]) return THIP_EINVAL;
+    if (st->enq_last_lane[tile] >= 0 && st->enq_last_tile != tile) return THIP_EINVAL;   // a tile's slots must be contiguous
+    // (every refusal is above this line: a refused call leaves the tile bookkeeping as it was)
     if (st->enq_last_lane[tile] < 0) st->h_slot0[tile] = (uint32_t)st->enq_nslots;
-    else if (st->enq_last_tile != tile) return THIP_EINVAL;   // a tile's slots must be contiguous
     st->enq_last_lane[tile] = lane;
     st->enq_last_tile = tile;
-    if (st->enq_tok_slots) return THIP_EINVAL;   // the frame's coefficient slots come from the token form (expanded on the device)
     st->enq_dense_slots++;
     const int slot = st->enq_nslots++;
     // piece q = 2*j+h of the block: columns c = 4h..4h+3 as pairs { x[2j][c], x[2j+1][c] }, i.e. the
@@ -1225,16 +1303,22 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
 }
 
 static int ensure_token_staging(thip_state *st) {
-  if (st->h_tok) return THIP_OK;
-  st->tok_cap = (size_t)st->nfrags * 63;   // every coefficient of every block non-zero
+  if (st->tok_ready) return THIP_OK;
+  // A slot stages the raw DC plus up to 63 AC tokens: 64 words per block when every coefficient of every
+  // block is non-zero (the slot refuses a token that would not fit, below).
+  st->tok_cap = (size_t)st->nfrags * 64;
   const size_t ngroups = ((size_t)st->nfrags + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
-  HIP_TRY(hipHostMalloc((void **)&st->h_tok, st->tok_cap * 4 + 64 * 4, hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void **)&st->h_slot_tok, ngroups * 64 * 8, hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void **)&st->h_dq, 18 * 64 * 2, hipHostMallocDefault));
-  HIP_TRY(hipMalloc((void **)&st->d_tok, st->tok_cap * 4 + 64 * 4));
-  HIP_TRY(hipMalloc((void **)&st->d_slot_tok, ngroups * 64 * 8));
-  HIP_TRY(hipMalloc((void **)&st->d_dq, 18 * 64 * 2));
-  memset(st->h_dq, 0, 18 * 64 * 2);
+  // each buffer on its own: a failed allocation leaves the others to a later call, and nothing is used before all exist
+  if (!st->h_tok) HIP_TRY(hipHostMalloc((void **)&st->h_tok, st->tok_cap * 4 + 64 * 4, hipHostMallocDefault));
+  if (!st->h_slot_tok) HIP_TRY(hipHostMalloc((void **)&st->h_slot_tok, ngroups * 64 * 8, hipHostMallocDefault));
+  if (!st->h_dq) {
+    HIP_TRY(hipHostMalloc((void **)&st->h_dq, 18 * 64 * 2, hipHostMallocDefault));
+    memset(st->h_dq, 0, 18 * 64 * 2);
+  }
+  if (!st->d_tok) HIP_TRY(hipMalloc((void **)&st->d_tok, st->tok_cap * 4 + 64 * 4));
+  if (!st->d_slot_tok) HIP_TRY(hipMalloc((void **)&st->d_slot_tok, ngroups * 64 * 8));
+  if (!st->d_dq) HIP_TRY(hipMalloc((void **)&st->d_dq, 18 * 64 * 2));
+  st->tok_ready = 1;
   return THIP_OK;
 }
 
@@ -1267,15 +1351,16 @@ int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const
     flags |= THIP_INFO_DC_ONLY;
     word1 |= (uint32_t)(uint16_t)dc;
   } else {
-    if (!st->h_tok) {
+    if (!st->tok_ready) {
       DeviceGuard dg(st->device);
       const int rc = ensure_token_staging(st);
       if (rc) return rc;
     }
+    if ((size_t)st->enq_ntok + (size_t)ntoks + 1 > st->tok_cap) return THIP_EINVAL;   // more tokens than the frame has coefficients
     const int tile = pos / THIP_TILE_FRAGS, lane = pos % THIP_TILE_FRAGS;
     if (lane <= st->enq_last_lane[tile]) return THIP_EINVAL;
+    if (st->enq_last_lane[tile] >= 0 && st->enq_last_tile != tile) return THIP_EINVAL;   // a tile's slots must be contiguous
     if (st->enq_last_lane[tile] < 0) st->h_slot0[tile] = (uint32_t)st->enq_nslots;
-    else if (st->enq_last_tile != tile) return THIP_EINVAL;   // a tile's slots must be contiguous
     st->enq_last_lane[tile] = lane;
     st->enq_last_tile = tile;
     const int slot = st->enq_nslots++;
@@ -1460,15 +1545,16 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
     // staging layout (16-byte sections): header tables | coded list | fragment words | dequantisation tables | tokens
     const size_t nf = ((size_t)st->nfrags + 7) & ~(size_t)7;   // (whole 16-byte units of every element size used)
     const size_t o_cl = THIP_TL_HDR, o_meta = o_cl + nf, o_dq = o_meta + nf, o_tok = o_dq + 18 * 64 / 2;
-    if (!st->h_tl) {
+    if (!st->tl_ready) {   // (each buffer on its own: a failed allocation is retried by the next call, nothing is used before all exist)
       st->tl_cap = (o_tok + (size_t)st->nfrags * 64 + 192 + 4) * 4;
-      HIP_TRY(hipHostMalloc((void **)&st->h_tl, st->tl_cap, hipHostMallocDefault));
-      HIP_TRY(hipMalloc((void **)&st->d_tl, st->tl_cap));
-      HIP_TRY(hipMalloc((void **)&st->d_tl_tmp, (size_t)st->nfrags * 128));
-      HIP_TRY(hipMalloc((void **)&st->d_tl_last, nf));
-      HIP_TRY(hipMalloc((void **)&st->d_tl_slot, nf * 4));
-      HIP_TRY(hipMalloc((void **)&st->d_frag_pos, nf * 4));
+      if (!st->h_tl) HIP_TRY(hipHostMalloc((void **)&st->h_tl, st->tl_cap, hipHostMallocDefault));
+      if (!st->d_tl) HIP_TRY(hipMalloc((void **)&st->d_tl, st->tl_cap));
+      if (!st->d_tl_tmp) HIP_TRY(hipMalloc((void **)&st->d_tl_tmp, (size_t)st->nfrags * 128));
+      if (!st->d_tl_last) HIP_TRY(hipMalloc((void **)&st->d_tl_last, nf));
+      if (!st->d_tl_slot) HIP_TRY(hipMalloc((void **)&st->d_tl_slot, nf * 4));
+      if (!st->d_frag_pos) HIP_TRY(hipMalloc((void **)&st->d_frag_pos, nf * 4));
       HIP_TRY(hipMemcpy(st->d_frag_pos, st->frag_pos, (size_t)st->nfrags * 4, hipMemcpyHostToDevice));
+      st->tl_ready = 1;
     }
     if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * nf));
     // the previous frame's kernels must have read the staging buffer before it is reused

@@ -70,7 +70,9 @@ struct StreamK {
   int ss_end[3];          // cumulative row-seam cell counts per plane, each plane padded to 64 (k_lf_st_seams)
   int st_nband;           // work groups per XCD band of the k_recon_st launch (its gridDim.x / 8)
   uint8_t *edge;          // kStEdgeRec bytes per super tile: a group's last block column for its right neighbour
+                          // (k_recon_lf: kTfRec bytes per tile, thip_fused.h)
   uint32_t epoch;         // serial number that marks the edge records of this launch
+  int band_u0[9];         // k_recon_lf: first tile of each of the 8 XCD bands (whole tile rows), [8] = number of tiles
   PlaneK pl[3];
 };
 
@@ -226,6 +228,12 @@ __device__ __forceinline__ void lf_cell_finish(const CellPix &Cin, uint8_t *plan
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     const int y = 8 * m - 4 + r;
+    // A row the filter left as it was is not written back: lflim() is zero for |R| >= 2L, i.e. across every
+    // real edge in the picture (with the usual limits of 2..4 most pairs on textured content), and a store
+    // that changes nothing still costs its bytes on the way to memory.
+#ifndef THIP_LF_ALWAYS_STORE
+    if (C.lo[r] == Cin.lo[r] && C.hi[r] == Cin.hi[r]) continue;
+#endif
     if (y >= 0 && y < H) {
       uint8_t *p = base + (ptrdiff_t)r * stride;
       if (lo_ok & hi_ok) {
