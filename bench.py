@@ -32,9 +32,9 @@ if ROOT not in sys.path:
 
 SIZES = {"4k": (3840, 2160), "1080p": (1920, 1088), "720p": (1280, 720), "cif": (352, 288), "qcif": (176, 144)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec peak
-FUSED = os.environ.get("THIP_FUSE", "0")
-KERNEL_NAMES = {"1": ("k_recon_walk", "k_lf_seams"), "2": ("k_recon_st", "k_lf_st_seams")}.get(FUSED, ("k_recon", "k_loopfilter"))
-TRAFFIC_PROFILE = "profiles/r02_pmc_traffic.json"
+FUSED = os.environ.get("THIP_FUSE", "3")
+KERNEL_NAMES = {"0": ("k_recon", "k_loopfilter"), "1": ("k_recon_walk", "k_lf_seams"), "2": ("k_recon_st", "k_lf_st_seams")}.get(FUSED, ("k_recon_lf", None))
+TRAFFIC_PROFILE = "profiles/r03_pmc_traffic.json"
 KF_INTERVAL = 64
 
 
@@ -178,6 +178,16 @@ def main_enc():
         assert np.array_equal(v.cpu().numpy()[:ncpu].view(np.uint32), wv)
         results.append(dict(kernel="oc_enc_frag_" + op, units=src_offs.size, unit="(block,candidate)", seconds=t,
                             bytes_per_unit=bpu, cpu_rate=ncpu / tc))
+    # --- the same candidates through the motion-search form (one reference position + the 9 sites per block) -----
+    d_base = torch.from_numpy(base).cuda()
+    for op, bpu in (("sad", 132), ("satd", 136)):
+        call = lambda: theora_amd.enc_metric_sites_batch(op, d_cur, d_prev, stride, d_base, d_base, sites)   # noqa: E731
+        t = timed(call)
+        v, dc = call()
+        want_v, _ = theora_amd.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)
+        assert torch.equal(v.reshape(-1), want_v)      # candidate-major = the order of the pair list above (checked against the oracle there)
+        results.append(dict(kernel="oc_enc_frag_%s, motion-search form (thip_enc_frag_metric_sites_batch)" % op, units=src_offs.size,
+                            unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=float("nan")))
     for r in results:
         gbs = r["units"] * r["bytes_per_unit"] / r["seconds"] / 1e9
         print(json.dumps({
@@ -186,7 +196,8 @@ def main_enc():
             "ms_per_call": round(1e3 * r["seconds"], 4), "dtype": "u8/i16", "data": "synthetic", "bit_exact_vs_oracle": True,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "alg_bytes_per_unit": r["bytes_per_unit"]},
-            "cpu_baseline": {"value": round(r["cpu_rate"] / 1e6, 3), "unit": "M%s/s" % r["unit"], "cores": 1, "kind": "port"}}))
+            "cpu_baseline": ({"value": round(r["cpu_rate"] / 1e6, 3), "unit": "M%s/s" % r["unit"], "cores": 1, "kind": "port"}
+                             if r["cpu_rate"] == r["cpu_rate"] else None)}))
 
 
 
@@ -599,8 +610,8 @@ def main():
                                # rocprofv3 around it): null here, the rocprofv3 --pmc passes of this workload are under profiles/
                                "traffic": None, "traffic_profile": TRAFFIC_PROFILE,
                                "avg_launch_us": round(1e3 * kms[0] / max(launches[0], 1), 3),
-                               "second_kernel": KERNEL_NAMES[1],
-                               "second_kernel_avg_launch_us": round(1e3 * kms[1] / max(launches[1], 1), 3),
+                               "second_kernel": KERNEL_NAMES[1] if launches[1] else None,
+                               "second_kernel_avg_launch_us": round(1e3 * kms[1] / max(launches[1], 1), 3) if launches[1] else None,
                                "alg_bytes_per_launch": int(prof_b_alg / max(launches[0], 1)),
                                "measured": "HIP events around every launch, separate instrumented pass of %d steps on one "
                                            "stream (ms_per_step there: %.5f)" % (prof_steps, 1e3 * elapsed_b / prof_steps)}

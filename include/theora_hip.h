@@ -311,6 +311,17 @@ int thip_enc_frag_metric_batch(int op, uint32_t *out, int32_t *dc_out, const uin
                                const uint8_t *ref_plane, int ystride, const int32_t *src_offs,
                                const int32_t *ref_offs, const int32_t *ref2_offs,
                                uint32_t thresh, int64_t n);
+/* The motion-search form of oc_enc_frag_sad (encfrag.c:42) / oc_enc_frag_satd (encfrag.c:317): every block i against
+   nsites candidate positions around ONE reference position, candidate c = ref_plane + ref_offs[i] + site_dy[c]*ystride
+   + site_dx[c] with site_dx, site_dy in {-1, 0, 1} (the square pattern of mcenc.c:50-53, any subset, any order, no
+   position twice).  What the reference does with nsites calls per block -- oc_mcenc_ysad_check_mbcandidate_fullpel /
+   oc_mcenc_ysatd_check_mbcandidate_fullpel, mcenc.c:267-330 -- is one launch here: the source block and the ten
+   reference rows a column of candidates shares are fetched and prepared once.  Results candidate-major:
+   out[c*nblocks + i] (and dc_out, SATD only, may be null).  op: THIP_ENC_SAD or THIP_ENC_SATD. */
+int thip_enc_frag_metric_sites_batch(int op, uint32_t *out, int32_t *dc_out, const uint8_t *src_plane,
+                                     const uint8_t *ref_plane, int ystride, const int32_t *src_offs,
+                                     const int32_t *ref_offs, const int8_t *site_dx, const int8_t *site_dy,
+                                     int nsites, int64_t nblocks);
 /* oc_enc_frag_border_ssd (encfrag.c:352): per-block 64-bit pixel masks (state.h:285-292). */
 int thip_enc_frag_border_ssd_batch(uint32_t *out, const uint8_t *src_plane,
                                    const uint8_t *ref_plane, int ystride,

@@ -176,6 +176,48 @@ def test_enc_metrics(hip, op):
             assert np.array_equal(want_dc, got_dc.cpu().numpy()), op
 
 
+@pytest.mark.parametrize("op", ["sad", "satd"])
+def test_enc_metric_sites(hip, op):
+    """The motion-search form (thip_enc_frag_metric_sites_batch): every block against candidate positions in {-1,0,1}^2 around
+    one reference position, results candidate-major -- against the oracle called once per (block, candidate) as the
+    reference calls oc_enc_frag_sad / oc_enc_frag_satd from mcenc.c:267-330.  The full square pattern in the reference's
+    order, a subset in another order, a single candidate; reference positions of every byte alignment; flat, saturated and
+    random pictures (the largest coefficients a block can have)."""
+    from theora_amd import _lib
+    rng = np.random.default_rng(11 + len(op))
+    stride, H = 272, 136
+    src = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    ref = np.clip(src.astype(np.int32) + rng.integers(-20, 21, (H, stride)), 0, 255).astype(np.uint8)
+    ref[:40] = rng.integers(0, 256, (40, stride))
+    src[40:56] = 255
+    ref[40:56] = 0                                   # every difference +255: the largest DC
+    src[56:72] = (np.indices((16, stride)).sum(0) & 1) * 255
+    ref[56:72] = 255 - src[56:72]                    # checkerboard of +-255: the largest AC coefficient
+    n = 4000
+    so = (rng.integers(0, H - 8, n) * stride + rng.integers(0, stride - 8, n)).astype(np.int32)
+    ro = (rng.integers(1, H - 9, n) * stride + rng.integers(1, stride - 9, n)).astype(np.int32)
+    full = [(0, 0), (-1, -1), (0, -1), (1, -1), (-1, 0), (1, 0), (-1, 1), (0, 1), (1, 1)]   # mcenc.c:50-53
+    for sites in (full, [(1, 1), (-1, 0), (0, -1), (0, 1)], [(-1, 1)], [(1, 0)]):
+        got, got_dc = hip.enc_metric_sites_batch(op, dev(src), dev(ref), stride, dev(so), dev(ro), sites)
+        for c, (dx, dy) in enumerate(sites):
+            want, want_dc = oracle.enc_metric_batch(op, src, ref, stride, so, (ro + dy * stride + dx).astype(np.int32), ro, 0)
+            assert np.array_equal(want, got[c].cpu().numpy().view(np.uint32)), (op, sites, c)
+            if op == "satd":
+                assert np.array_equal(want_dc, got_dc[c].cpu().numpy()), (op, sites, c)
+    # argument errors: a position outside the pattern, a position twice, too many candidates, an operation without this form
+    L = _lib.load()
+    o = dev(np.zeros(9 * n, np.int32))
+
+    def call(opc, dx, dy):
+        dx, dy = np.array(dx, np.int8), np.array(dy, np.int8)
+        return L.thip_enc_frag_metric_sites_batch(opc, o.data_ptr(), None, dev(src).data_ptr(), dev(ref).data_ptr(), stride, dev(so).data_ptr(),
+                                                  dev(ro).data_ptr(), dx.ctypes.data, dy.ctypes.data, len(dx), n)
+    assert call(_lib.ENC_OPS["sad"], [2], [0]) == _lib.EINVAL
+    assert call(_lib.ENC_OPS["sad"], [0, 0], [1, 1]) == _lib.EINVAL
+    assert call(_lib.ENC_OPS["sad"], [0] * 10, [0] * 10) == _lib.EINVAL
+    assert call(_lib.ENC_OPS["ssd"], [0], [0]) == _lib.EINVAL
+
+
 def test_enc_fdct(hip):
     rng = np.random.default_rng(8)
     n = 20000
@@ -424,6 +466,12 @@ def test_enc_kernels_at_config5_size(hip):
         assert np.array_equal(v.cpu().numpy().view(np.uint32)[msample], wv), op
         if "satd" in op:
             assert np.array_equal(dc.cpu().numpy()[msample], wdc), op
+        if op in ("sad", "satd"):   # the same 881 280 pairs through the motion-search form: one launch, candidate-major = the order above
+            d_base = dev(base)
+            sv, sdc = hip.enc_metric_sites_batch(op, d_cur, d_prev, stride, d_base, d_base, sites)
+            assert torch.equal(sv.reshape(-1), v), op
+            if op == "satd":
+                assert torch.equal(sdc.reshape(-1), dc), op
 
 
 def _dc_case(rng, w, h, fmt, density, refmix, big):

@@ -1,5 +1,7 @@
-"""The opt-in fused reconstruction + loop-filter kernels (THIP_FUSE=1: k_recon_walk + k_lf_seams, THIP_FUSE=2: k_recon_st +
-k_lf_st_seams): the sequence tests of test_gpu_frames.py in child processes with the switch on.  In a file of their own,
+"""The launch shapes that are not the default: the two passes k_recon + k_loopfilter (THIP_FUSE=0; the default is k_recon_lf, which
+every other GPU test file exercises, and which hands frames with static blocks to the two passes) and the earlier fused designs
+(THIP_FUSE=1: k_recon_walk + k_lf_seams, THIP_FUSE=2: k_recon_st + k_lf_st_seams): the sequence tests of test_gpu_frames.py in
+child processes with the switch set.  In a file of their own,
 collected last: these kernels hand data between concurrently running work groups (bounded waits), and a failure here must not
 keep the rest of the suite from running under `pytest -x`."""
 import numpy as np
@@ -62,6 +64,21 @@ def test_fused_single_wave_tiles_variant(hip):
     import subprocess
     import sys
     env = dict(os.environ, THIP_FUSE="3")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sel = ("(sequence or enqueue or batched or grey or dup or lane_shared or static_background or four_concurrent "
+           "or dc_unprediction or beyond_4k or frame_calls) and not elision and not fused")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "-m", "gpu", "-x", "-q", "-k", sel],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_two_pass_variant(hip):
+    """THIP_FUSE=0: k_recon + k_loopfilter for every frame (the default uses them only for frames that leave static blocks in
+    place or have no loop filter).  The sequence tests of test_gpu_frames.py in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, THIP_FUSE="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sel = ("(sequence or enqueue or batched or grey or dup or lane_shared or static_background or four_concurrent "
            "or dc_unprediction or beyond_4k or frame_calls) and not elision and not fused")

@@ -272,3 +272,20 @@ def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None,
         _lib.ENC_OPS[op], _ptr(out), _ptr(dc), _ptr(src_plane), _ptr(ref_plane), ystride, _ptr(src_offs),
         _ptr(ref_offs), _ptr(ref2_offs), thresh, n), "enc_frag_metric_batch")
     return out, dc
+
+
+def enc_metric_sites_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs, sites):
+    """thip_enc_frag_metric_sites_batch: every block against the candidate positions `sites` = [(dx, dy), ...] around its
+    reference position.  Returns (values, dc), both [len(sites), nblocks] (candidate-major)."""
+    import numpy as np
+    import torch
+    n = src_offs.numel()
+    ns = len(sites)
+    out = torch.empty((ns, n), dtype=torch.int32, device=src_offs.device)
+    dc = torch.zeros((ns, n), dtype=torch.int32, device=src_offs.device)
+    dx = np.array([s[0] for s in sites], np.int8)
+    dy = np.array([s[1] for s in sites], np.int8)
+    _lib.check(_lib.load().thip_enc_frag_metric_sites_batch(
+        _lib.ENC_OPS[op], _ptr(out), _ptr(dc), _ptr(src_plane), _ptr(ref_plane), ystride, _ptr(src_offs), _ptr(ref_offs),
+        dx.ctypes.data, dy.ctypes.data, ns, n), "enc_frag_metric_sites_batch")
+    return out, dc

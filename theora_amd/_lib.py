@@ -82,6 +82,7 @@ SYMBOLS = [
     ("thip_frame_dequant_table", _I, [_P, _I, _P]),
     ("thip_state_frag_recon_tokens", _I, [_P, C.c_ssize_t, _I, _P, _I, C.c_int16, _I, C.c_uint16, _I, _I, C.c_int16]),
     ("thip_enc_frag_metric_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _U32, _I64]),
+    ("thip_enc_frag_metric_sites_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I64]),
     ("thip_enc_frag_border_ssd_batch", _I, [_P, _P, _P, _I, _P, _P, _P, _I64]),
     ("thip_enc_frag_sub_batch", _I, [_P, _P, _P, _I, _P, _P, _I64]),
     ("thip_enc_frag_copy2_batch", _I, [_P, _P, _I, _P, _P, _P, _I64]),

@@ -879,10 +879,11 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       HIP_TRY(hipGetLastError());
     }
   }
-  // THIP_FUSE=1: the fused path (k_recon_walk + k_lf_seams): no vertical seams, a quarter of the lines
-  // re-read.  Frames that leave static blocks in place (skip_ok) keep the two-pass path, whose first
-  // kernel knows how to skip whole tiles.
-  static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 0;
+  // Default (THIP_FUSE=3): k_recon_lf, reconstruction and the whole loop filter in one pass (thip_fused.h).
+  // THIP_FUSE=0: the two passes k_recon + k_loopfilter.  Frames that leave static blocks in place (skip_ok) and frames
+  // without a loop filter always take the two-pass path, whose first kernel knows how to skip whole tiles.
+  // (THIP_FUSE=1 / 2: the earlier fused designs k_recon_walk + k_lf_seams and k_recon_st + k_lf_st_seams.)
+  static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 3;
   if (fuse == 3 && any_lf && !any_skip && xcd_round_robin(states[live_state[0]]->device)) {
     // one wave per tile, reconstruction and every filter cell in one pass (thip_fused.h)
     int longest = 1;

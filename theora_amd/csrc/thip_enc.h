@@ -1,0 +1,251 @@
+// thip_enc.h -- the encoder's block metrics (oc_enc_opt_vtable: SAD, SATD, SSD families, encfrag.c:42-378) for gfx950.
+// Included by thip_slots.hip only.
+//
+// A block stays what memory gives: eight rows of eight bytes (uint2), never 64 integers.
+//   * SAD family: v_sad_u8 takes four byte pairs per instruction (|a-b| summed into an accumulator), a row is two
+//     instructions; the half-pel average of two references is v_lerp_u8 (encfrag.c:79).
+//   * SSD: sum (a-b)^2 = sum a^2 + sum b^2 - 2 sum a b, three v_dot4_u32_u8 per four pixels, exact in 32-bit
+//     modular arithmetic (the result is < 2^23).
+//   * SATD family: the 8x8 Hadamard transform of the difference is a 64-point transform over the six index bits
+//     (row bits r2 r1 r0, column bits c2 c1 c0), one butterfly level per bit IN ANY ORDER, and the sum of absolute
+//     values does not care where an output lands.  The column bit c0 is taken first, on the bytes: a register
+//     holds {x[2j] + x[2j+1], x[2j] - x[2j+1]} (two v_perm_b32 and one v_pk_mad_i16 per pixel pair, done once for
+//     the source block and once per reference row, whatever the number of candidates that use them); the
+//     difference of two such registers is the same level of the difference block (the transform is linear);
+//     c1, c2, r2, r1 are 16 packed add/sub pairs each between whole registers -- no shuffles anywhere; and the
+//     last level r0 is never computed: |p + q| + |p - q| = 2 max(|p|, |q|).  Every intermediate fits 16 bits
+//     (|coefficient| <= 64 * 255), which is also why the reference's int16 buffer between its two passes
+//     (encfrag.c:147-154) changes nothing for pixel input.  The DC coefficient (the sum of all differences)
+//     is the one output the reference leaves out of the sum and returns separately (encfrag.c:302,312).
+//   * motion search (k_enc_sites): the candidates of a block are positions (dx, dy) in {-1,0,1}^2 around one
+//     reference position (the square pattern of mcenc.c:50-53).  A lane takes one block and one dx: the ten
+//     reference rows it needs are loaded and prepared once and serve its three dy; results are stored candidate
+//     by candidate (out[c * nblocks + block]).
+#pragma once
+
+namespace thip {
+
+__device__ __forceinline__ void load_rows8(uint2 r[8], const uint8_t *p, int ystride) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) r[i] = load_row8(p + (ptrdiff_t)i * ystride);
+}
+__device__ __forceinline__ uint2 avg_row(uint2 a, uint2 b) { return make_uint2(avg4_trunc(a.x, b.x), avg4_trunc(a.y, b.y)); }
+
+// sum |a - b| over one row, added to acc
+__device__ __forceinline__ uint32_t sad_row(uint2 a, uint2 b, uint32_t acc) {
+  return __builtin_amdgcn_sad_u8(a.y, b.y, __builtin_amdgcn_sad_u8(a.x, b.x, acc));
+}
+// encfrag.c:42-86: whole-block SAD; with a threshold the rows after the one that crosses it are not added
+template <bool THRESH>
+__device__ __forceinline__ uint32_t sad_rows(const uint2 a[8], const uint2 b[8], uint32_t thresh) {
+  uint32_t v = 0;
+  bool live = true;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const uint32_t nv = sad_row(a[r], b[r], v);
+    if (!THRESH) {
+      v = nv;
+    } else {
+      v = live ? nv : v;
+      live = live && v <= thresh;
+    }
+  }
+  return v;
+}
+// encfrag.c:88-107: SAD against the block's rounded mean
+__device__ __forceinline__ uint32_t intra_sad_rows(const uint2 a[8]) {
+  uint32_t sum = 0;
+  const uint2 z = make_uint2(0u, 0u);
+#pragma unroll
+  for (int r = 0; r < 8; r++) sum = sad_row(a[r], z, sum);
+  const uint32_t m = ((sum + 32) >> 6) * 0x01010101u;
+  const uint2 mm = make_uint2(m, m);
+  uint32_t v = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) v = sad_row(a[r], mm, v);
+  return v;
+}
+// encfrag.c:338-350
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_dot4_u32_u8 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t ssd_rows(const uint2 a[8], const uint2 b[8]) {
+  uint32_t sq = 0, ab = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    sq = dot4(a[r].x, a[r].x, sq);
+    sq = dot4(a[r].y, a[r].y, sq);
+    sq = dot4(b[r].x, b[r].x, sq);
+    sq = dot4(b[r].y, b[r].y, sq);
+    ab = dot4(a[r].x, b[r].x, ab);
+    ab = dot4(a[r].y, b[r].y, ab);
+  }
+  return sq - 2u * ab;
+}
+
+// ---- SATD -------------------------------------------------------------------------------------------------------
+// one row of pixels -> four registers {x[2j] + x[2j+1], x[2j] - x[2j+1]}, j = 0..3 (the c0 level)
+__device__ __forceinline__ pk16 pair_sd(uint32_t w, bool upper) {
+  const pk16 e = as_pk(__builtin_amdgcn_perm(0u, w, upper ? 0x0c020c02u : 0x0c000c00u));   // {even, even}
+  const pk16 o = as_pk(__builtin_amdgcn_perm(0u, w, upper ? 0x0c030c03u : 0x0c010c01u));   // {odd, odd}
+  const pk16 k = {(short)1, (short)-1};
+  return o * k + e;
+}
+__device__ __forceinline__ void row_sd(pk16 out[4], uint2 row) {
+  out[0] = pair_sd(row.x, false);
+  out[1] = pair_sd(row.x, true);
+  out[2] = pair_sd(row.y, false);
+  out[3] = pair_sd(row.y, true);
+}
+__device__ __forceinline__ void bfly(pk16 &a, pk16 &b) {
+  const pk16 s = a + b;
+  b = a - b;
+  a = s;
+}
+__device__ __forceinline__ pk16 pk_abs(pk16 x) {
+  const pk16 z = {0, 0};
+  return __builtin_elementwise_max(x, z - x);
+}
+__device__ __forceinline__ uint32_t sum2_u16(pk16 m, uint32_t acc) {   // acc + m.lo + m.hi, both halves unsigned
+  uint32_t d;
+  asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(as_u32(m)), "v"(0x00010001u), "v"(acc));
+  return d;
+}
+// D[r][j]: the c0 level of the difference block (row r, pixel pair j).  Returns sum |coefficient| without the DC term;
+// dc = the DC coefficient = the sum of all differences (encfrag.c:264-315).
+__device__ __forceinline__ uint32_t satd_sd(pk16 D[8][4], int &dc) {
+#pragma unroll
+  for (int r = 0; r < 8; r++) {   // c1, c2
+    bfly(D[r][0], D[r][1]);
+    bfly(D[r][2], D[r][3]);
+    bfly(D[r][0], D[r][2]);
+    bfly(D[r][1], D[r][3]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {   // r2, r1
+#pragma unroll
+    for (int r = 0; r < 4; r++) bfly(D[r][j], D[r + 4][j]);
+    bfly(D[0][j], D[2][j]);
+    bfly(D[1][j], D[3][j]);
+    bfly(D[4][j], D[6][j]);
+    bfly(D[5][j], D[7][j]);
+  }
+  // r0: |p + q| + |p - q| = 2 max(|p|, |q|); the all-plus output p + q of pair (D[0][0], D[1][0]), lower half, is the DC
+  dc = (int)D[0][0].x + (int)D[1][0].x;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r += 2)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc = sum2_u16(__builtin_elementwise_max(pk_abs(D[r][j]), pk_abs(D[r + 1][j])), acc);
+  return 2u * acc - (uint32_t)(dc < 0 ? -dc : dc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the vtable's metrics on lists of (source block, reference block[, second reference block]): one pair per lane
+// ---------------------------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(256) void k_enc_metric(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
+                                                   int ystride, const int32_t *src_offs, const int32_t *ref_offs,
+                                                   const int32_t *ref2_offs, uint32_t thresh, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  constexpr bool kHasRef = OP != THIP_ENC_INTRA_SAD && OP != THIP_ENC_INTRA_SATD;
+  constexpr bool kTwo = OP == THIP_ENC_SAD2_THRESH || OP == THIP_ENC_SATD2;
+  uint2 s[8], p[8];
+  load_rows8(s, src_plane + src_offs[i], ystride);
+  if (kHasRef) {
+    load_rows8(p, ref_plane + ref_offs[i], ystride);
+    if (kTwo) {
+      uint2 q[8];
+      load_rows8(q, ref_plane + ref2_offs[i], ystride);
+#pragma unroll
+      for (int r = 0; r < 8; r++) p[r] = avg_row(p[r], q[r]);   // encfrag.c:79,172
+    }
+  }
+  uint32_t v;
+  int dc = 0;
+  if (OP == THIP_ENC_SAD) {
+    v = sad_rows<false>(s, p, 0u);
+  } else if (OP == THIP_ENC_SAD_THRESH || OP == THIP_ENC_SAD2_THRESH) {
+    v = sad_rows<true>(s, p, thresh);
+  } else if (OP == THIP_ENC_INTRA_SAD) {
+    v = intra_sad_rows(s);
+  } else if (OP == THIP_ENC_SSD) {
+    v = ssd_rows(s, p);
+  } else {   // SATD family, encfrag.c:317-336
+    pk16 D[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      row_sd(D[r], s[r]);
+      if (kHasRef) {
+        pk16 B[4];
+        row_sd(B, p[r]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) D[r][j] = D[r][j] - B[j];
+      }
+    }
+    v = satd_sd(D, dc);
+  }
+  out[i] = v;
+  if (dc_out) dc_out[i] = dc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// motion search: every block against the candidates (dx, dy) in {-1,0,1}^2 around its reference position
+// ---------------------------------------------------------------------------------------------------------------
+struct SitesK {
+  int8_t site_of[9];   // candidate number of (dy + 1) * 3 + (dx + 1), -1 if that position is not asked for
+  int nsites;
+};
+// unit u = 3 * block + dxi: the lane's candidates are (dxi - 1, dy), dy = -1..1
+template <int OP>
+__global__ __launch_bounds__(256) void k_enc_sites(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
+                                                  int ystride, const int32_t *src_offs, const int32_t *ref_offs, const SitesK K,
+                                                  int64_t nblocks) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= 3 * nblocks) return;
+  const int64_t i = u / 3;
+  const int dxi = (int)(u - 3 * i);
+  int c[3];
+#pragma unroll
+  for (int dyi = 0; dyi < 3; dyi++) c[dyi] = K.site_of[dyi * 3 + dxi];
+  if ((c[0] & c[1] & c[2]) < 0) return;   // none of this column's positions is a candidate
+  uint2 s[8], e[10];
+  load_rows8(s, src_plane + src_offs[i], ystride);
+  const uint8_t *rp = ref_plane + ref_offs[i] - ystride + (dxi - 1);
+#pragma unroll
+  for (int r = 0; r < 10; r++) e[r] = load_row8(rp + (ptrdiff_t)r * ystride);
+  if (OP == THIP_ENC_SAD) {
+#pragma unroll
+    for (int dyi = 0; dyi < 3; dyi++) {
+      if (c[dyi] < 0) continue;
+      uint32_t v = 0;
+#pragma unroll
+      for (int r = 0; r < 8; r++) v = sad_row(s[r], e[r + dyi], v);
+      out[(int64_t)c[dyi] * nblocks + i] = v;
+    }
+  } else {
+    pk16 S[8][4], B[10][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) row_sd(S[r], s[r]);
+#pragma unroll
+    for (int r = 0; r < 10; r++) row_sd(B[r], e[r]);
+#pragma unroll
+    for (int dyi = 0; dyi < 3; dyi++) {
+      if (c[dyi] < 0) continue;
+      pk16 D[8][4];
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) D[r][j] = S[r][j] - B[r + dyi][j];
+      int dc;
+      const uint32_t v = satd_sd(D, dc);
+      out[(int64_t)c[dyi] * nblocks + i] = v;
+      if (dc_out) dc_out[(int64_t)c[dyi] * nblocks + i] = dc;
+    }
+  }
+}
+
+}  // namespace thip

@@ -39,7 +39,11 @@ constexpr int kTfX0 = 8;                       // byte offset of pixel column 0 
 constexpr int kTfImgRows = 40;                 // pixel rows -4 .. 35 (upper neighbour's last 4, the tile, lower neighbour's first 4)
 constexpr int kTfFlagOff = kTfImgRows * kTfPitch;   // coded flags: 6 rows (block rows -1..4) of kTfFlagPitch bytes
 constexpr int kTfFlagPitch = 20;               // [0] block column -1, [1..16] the tile, [17] column 16
-static_assert(kTfFlagOff + 6 * kTfFlagPitch <= 8192, "the image lives in the wave's 8 KB staging area");
+// The wave's LDS: 7 KB, not 8.  This chip hands LDS out in 1280-byte granules, so 8 KB costs 8960 bytes and a CU holds 18 such
+// waves; 7 KB costs 7680 and it holds the 20 the registers allow.  Seven of a tile's eight 1-KB coefficient pieces are staged
+// here (LDS-DMA), the eighth stays in registers.
+constexpr int kTfLds = 7168;
+static_assert(kTfFlagOff + 6 * kTfFlagPitch <= kTfLds, "the image lives in the wave's staging area");
 // a tile's record in StreamK::edge
 constexpr int kTfBot = 0;                      // pixel rows 28..31: 4 x 128 bytes
 constexpr int kTfRight = 512;                  // pixel columns 124..127: 32 rows x 4 bytes
@@ -122,35 +126,44 @@ __device__ __forceinline__ void tf_cell(const uint8_t *lds, uint8_t *plane, int 
   }
 }
 
-// Polls up to three neighbours' flag words (lane i < 3 looks at recs[i] when need[i]) until all carry this
-// launch's serial number; returns the words in w[0..2], the second word of recs[0] in w[3] (wave-uniform).
-__device__ __forceinline__ void tf_wait(const uint8_t *rec0, const uint8_t *rec1, const uint8_t *rec2, bool need0, bool need1, bool need2,
-                                        uint32_t ep, int lane, uint32_t w[4]) {
+// The neighbours' flag words: lane i < 3 looks at recs[i] when need[i].  tf_poll asks once (the answer travels while the
+// wave does something else), tf_wait takes that answer and keeps asking until all carry this launch's serial number;
+// returns the words in w[0..2], the second word of recs[0] in w[3] (wave-uniform).
+struct TfPoll {
+  const uint8_t *rec;
+  bool need;
+  uint2 f;
+};
+// (every lane loads -- the lanes with nothing to ask read the wave's own record: a load under a condition would be
+//  merged with a default value behind it, and the merge waits for the data on the spot)
+__device__ __forceinline__ void tf_poll(TfPoll &P, const uint8_t *rec0, const uint8_t *rec1, const uint8_t *rec2, bool need0, bool need1,
+                                        bool need2, int lane, const uint8_t *myrec) {
   const uint8_t *rec = lane == 0 ? rec0 : (lane == 1 ? rec1 : rec2);
-  const bool need = lane == 0 ? need0 : (lane == 1 ? need1 : (lane == 2 ? need2 : false));
-  uint32_t word = 0, word1 = 0;
-  bool ok = !need;
-  for (int spins = 0; spins < (1 << 20); spins++) {
-    if (!ok) {
-      const uint2 f = tf_load64(rec + kTfFlag);
-      word = f.x;
-      word1 = f.y;
-      ok = (word >> 20) == ep;
-    }
-    if (__all(ok)) break;
+  P.need = lane == 0 ? need0 : (lane == 1 ? need1 : (lane == 2 ? need2 : false));
+  P.rec = P.need ? rec : myrec;
+  P.f = tf_load64(P.rec + kTfFlag);
+}
+__device__ __forceinline__ void tf_wait(const TfPoll &P, uint32_t ep, uint32_t w[4]) {
+  uint2 f = P.f;
+  bool ok = !P.need || (f.x >> 20) == ep;
+  for (int spins = 0; spins < (1 << 20) && !__all(ok); spins++) {
     __builtin_amdgcn_s_sleep(2);
+    if (!ok) {
+      f = tf_load64(P.rec + kTfFlag);
+      ok = (f.x >> 20) == ep;
+    }
   }
-  w[0] = (uint32_t)__builtin_amdgcn_readlane((int)word, 0);
-  w[1] = (uint32_t)__builtin_amdgcn_readlane((int)word, 1);
-  w[2] = (uint32_t)__builtin_amdgcn_readlane((int)word, 2);
-  w[3] = (uint32_t)__builtin_amdgcn_readlane((int)word1, 0);   // second flag word of rec0
+  w[0] = (uint32_t)__builtin_amdgcn_readlane((int)f.x, 0);
+  w[1] = (uint32_t)__builtin_amdgcn_readlane((int)f.x, 1);
+  w[2] = (uint32_t)__builtin_amdgcn_readlane((int)f.x, 2);
+  w[3] = (uint32_t)__builtin_amdgcn_readlane((int)f.y, 0);   // second flag word of rec0
 }
 
 #ifndef THIP_TF_WAVES_PER_EU
 #define THIP_TF_WAVES_PER_EU 5    // 96 VGPRs; with 8 KB of LDS per wave that is 20 waves per CU
 #endif
 __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const BatchK B) {
-  __shared__ uint4 s_tf[512];   // 8 KB, wave-private (one wave per work group): coefficient staging, then the tile image
+  __shared__ uint4 s_tf[kTfLds / 16];   // wave-private (one wave per work group): coefficient staging, then the tile image
   const StreamK &S = B.s[blockIdx.y];
   const int lane = (int)threadIdx.x & 63;
   const int band = (int)blockIdx.x & 7, jb = (int)blockIdx.x >> 3;
@@ -171,6 +184,17 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
                "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2), "s"(ep), "s"(bu0), "s"(bu1));
   const int u = bu0 + jb;
   if (u >= bu1) return;
+  [[maybe_unused]] unsigned long long *tr = nullptr;   // tools/lf_trace.py: lane 0 stamps the phases of the wave's life (THIP_TRACE builds only)
+#ifdef THIP_TRACE
+  if (g_trace_buf && lane == 0) {
+    tr = g_trace_buf + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+    tr[9] = hwid;
+    tr[10] = (unsigned long long)xcc | (unsigned long long)u << 8;
+  }
+#endif
+  THIP_TR(tr, 0);
   const int pli = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
   const PlaneK G = S.pl[pli];
   const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
@@ -195,6 +219,9 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   uint32_t dcv = 0;   // the block's un-predicted DC when it does not travel in the command stream
   if (dc_p) dcv = 0x10000u | (uint16_t)dc_p[G.fro + min(by, nv - 1) * nh + min(bx, nh - 1)];
   asm volatile("" ::"s"(slot0), "v"(info.x), "v"(dcv));
+#ifdef THIP_TRACE
+  THIP_TR(tr, 1);   // command words are here
+#endif
   ReconLane L;
   L.flags = valid ? info.x : 0u;
   L.dcq = info.y >> 16;
@@ -247,12 +274,14 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
     const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
 #pragma unroll
-    for (int q = 0; q < 8; q++)
+    for (int q = 0; q < 7; q++)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
                                        (__attribute__((address_space(3))) void *)(s_tf + q * 64), 16, 0, 0);
+    const int4 w7i = tp[7 * 64];
     if (valid) recon_issue(R, L, Q, inter, ref);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)
-    residual_per_lane(s_tf + lane, L, Y);
+    const uint4 w7 = make_uint4((uint32_t)w7i.x, (uint32_t)w7i.y, (uint32_t)w7i.z, (uint32_t)w7i.w);
+    residual_per_lane(s_tf + lane, L, Y, &w7);
   }
   if (!L.has_coeff) {
 #pragma unroll
@@ -260,6 +289,10 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   }
   uint2 rows[8];
   recon_rows(R, Q, inter, Y, rows);
+#ifdef THIP_TRACE
+  asm volatile("" : "+v"(rows[0].x), "+v"(rows[7].y));
+  THIP_TR(tr, 2);   // pixels done (coefficients and predictor windows had arrived)
+#endif
 
   // ---- 3. publish the edges (from the registers), ask for the neighbours' flag words, image into LDS ----------
   uint8_t *const myrec = edge_p + (size_t)u * kTfRec;
@@ -269,6 +302,9 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     tf_publish<0>(myrec, rows, lx, ly, valid, false);
   const uint8_t *const rec_up = myrec - (ptrdiff_t)tiles_x * kTfRec, *const rec_left = myrec - kTfRec;
   const uint8_t *const rec_ul = rec_up - kTfRec;
+  const bool need_ul = up_in && has_left;
+  TfPoll poll;                                    // first look at the neighbours' flag words: in flight with the record stores
+  tf_poll(poll, rec_up, rec_left, rec_ul, up_in, has_left, need_ul, lane, myrec);
   lds_settle();                                   // every lane is done with the staging area
   if (valid) {
     uint8_t *img = lds + (ly * 8 + 4) * kTfPitch + kTfX0 + lx * 8;
@@ -283,6 +319,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
                              : (lane < 20 ? (lane - 16 + 1) * kTfFlagPitch + 16 : (lane >= 32 && lane < 48 ? kTfFlagPitch + (lane - 32) + 1 : 0));
     const bool fb = (lane < 20 || (lane >= 32 && lane < 48)) && lds[kTfFlagOff + fi] != 0;
     const uint64_t fm = __ballot(fb);
+    THIP_TR(tr, 3);   // edges on their way, image in LDS
     // the flag word goes out when the record is in place: stores are acknowledged by the L2 (or by memory)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
@@ -292,13 +329,14 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
       else
         tf_store64<0>(myrec + kTfFlag, w0, w1);
     }
+    THIP_TR(tr, 4);   // record acknowledged, flag word out
   }
 
   // ---- 4. the neighbours' edges into the image margins --------------------------------------------------
   {
-    const bool need_ul = up_in && has_left;
     uint32_t w[4];
-    tf_wait(rec_up, rec_left, rec_ul, up_in, has_left, need_ul, ep, lane, w);
+    tf_wait(poll, ep, w);
+    THIP_TR(tr, 5);   // the neighbours' records are there
     // lanes 0..31: the upper tile's rows 28..31, 16 bytes each; 32..39: the left tile's columns 124..127, four rows each;
     // 40: the upper-left tile's corner (rows 28..31 of its column record)
     const uint8_t *src = nullptr;
@@ -333,10 +371,12 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     else if (lane == 20)
       lds[kTfFlagOff] = (uint8_t)((w[2] >> 19) & 1u);
     lds_settle();
+    THIP_TR(tr, 6);   // ... and in the margins
   }
 
   // ---- 5. the cells: lane (kx, m) on corner (16t + kx, 4 sby + m) ---------------------------------------------
   tf_cell(lds, R.self, R.stride, nh, nv, t, sby, lane & 15, lane >> 4, !(xb_up && lane < 16), L2, fy0, fy1);
+  THIP_TR(tr, 7);   // cells filtered, stores issued
 
   // ---- 6. a 17th cell column where the plane ends on this tile's right boundary (k = nh), a 5th cell row where the plane
   //         ends on its lower boundary (m = nv) or where the tile below belongs to another band ----------------------------
@@ -346,7 +386,9 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     if (xb_dn) {
       const uint8_t *const rec_dn = myrec + (ptrdiff_t)tiles_x * kTfRec, *const rec_dl = rec_dn - kTfRec;
       uint32_t w[4];
-      tf_wait(rec_dn, rec_dl, rec_dl, true, has_left, false, ep, lane, w);
+      TfPoll pd;
+      tf_poll(pd, rec_dn, rec_dl, rec_dl, true, has_left, false, lane, myrec);
+      tf_wait(pd, ep, w);
       const uint8_t *src = nullptr;
       if (lane < 32)
         src = rec_dn + kTfTop + lane * 16;          // the lower tile's rows 0..3
@@ -381,4 +423,5 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     const bool act = rowl ? (extra_row && (lane < 16 || extra_col)) : (coll && extra_col && !(xb_up && m == 0));
     tf_cell(lds, R.self, R.stride, nh, nv, t, sby, kx, m, act, L2, fy0, fy1);
   }
+  THIP_TR(tr, 8);
 }

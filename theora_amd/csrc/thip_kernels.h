@@ -178,15 +178,21 @@ __device__ __forceinline__ void lf_vert_pk(CellPix &C, int r0, int L2) {
     C.hi[r + 1] = __builtin_amdgcn_perm(n4, C.hi[r + 1], 0x03020105u);
   }
 }
+// The operations of one cell in an order equivalent to T1..T8 with six slots instead of eight.  Only a vertical-edge and a
+// horizontal-edge operation share pixels (Vlo / Vhi with Hl / Hr); Vlo and Vhi, Hl and Hr never do.  A cell has at most one
+// of T1 / T3 (both are Vlo), of T2 / T5 (Hl), of T4 / T8 (Hr), of T6 / T7 (Vhi), so all that has to be kept is, for each
+// of the four V-H pairs, which of the two comes first:  Hl precedes Vlo only as T2 before T3;  Vlo (T1, T3) always
+// precedes Hr (T4, T8);  Hl (T2, T5) always precedes Vhi (T6, T7);  Hr precedes Vhi only as T4 (then Vhi is T6).
 __device__ __forceinline__ void lf_cell_apply_pk(CellPix &C, uint32_t t, int L2) {
-  if (__any(t & 1u)) { if (t & 1u) lf_vert_pk(C, 0, L2); }
-  if (__any(t & 2u)) { if (t & 2u) lf_horz_pk(C, 0, L2); }
-  if (__any(t & 4u)) { if (t & 4u) lf_vert_pk(C, 0, L2); }
-  if (__any(t & 8u)) { if (t & 8u) lf_horz_pk(C, 1, L2); }
-  if (__any(t & 16u)) { if (t & 16u) lf_horz_pk(C, 0, L2); }
-  if (__any(t & 32u)) { if (t & 32u) lf_vert_pk(C, 4, L2); }
-  if (__any(t & 64u)) { if (t & 64u) lf_vert_pk(C, 4, L2); }
-  if (__any(t & 128u)) { if (t & 128u) lf_horz_pk(C, 1, L2); }
+  const bool hl_first = (t & 6u) == 6u;                 // T2 and T3: the horizontal edge first
+  const bool vlo = (t & 5u) != 0, hl_late = (t & 18u) != 0 && !hl_first;
+  const bool hr_first = (t & 8u) != 0, vhi = (t & 96u) != 0, hr_late = (t & 128u) != 0;
+  if (__any(hl_first)) { if (hl_first) lf_horz_pk(C, 0, L2); }
+  if (__any(vlo)) { if (vlo) lf_vert_pk(C, 0, L2); }
+  if (__any(hl_late)) { if (hl_late) lf_horz_pk(C, 0, L2); }
+  if (__any(hr_first)) { if (hr_first) lf_horz_pk(C, 1, L2); }
+  if (__any(vhi)) { if (vhi) lf_vert_pk(C, 4, L2); }
+  if (__any(hr_late)) { if (hr_late) lf_horz_pk(C, 1, L2); }
 }
 __device__ __forceinline__ void lf_cell_load(CellPix &C, const uint8_t *plane, int stride, int nh, int nv, int k,
                                              int m) {
@@ -447,11 +453,12 @@ __device__ __forceinline__ void recon_finish(const ReconPlane &R, const ReconLan
 
 // Residual of the lanes that own coefficients, one block per lane (the whole wave executes the
 // 16 one-dimensional transforms whether 1 lane or 64 need them).
-__device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const ReconLane &L, uint32_t Y[32]) {
+// (last: piece 7 when it did not go through LDS -- k_recon_lf stages seven pieces, 7 KB, and takes the eighth in registers)
+__device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const ReconLane &L, uint32_t Y[32], const uint4 *last = nullptr) {
   uint32_t P[32];
 #pragma unroll
   for (int q = 0; q < 8; q++) {
-    const uint4 w = lds_coef[q * 64];
+    const uint4 w = (q == 7 && last) ? *last : lds_coef[q * 64];
     P[q * 4 + 0] = w.x;
     P[q * 4 + 1] = w.y;
     P[q * 4 + 2] = w.z;

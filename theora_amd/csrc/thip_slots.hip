@@ -13,6 +13,7 @@
 
 #include "../../include/theora_hip.h"
 #include "thip_device.h"
+#include "thip_enc.h"
 
 using namespace thip;
 
@@ -167,104 +168,6 @@ __device__ __forceinline__ void load_pixels(int p[64], const uint8_t *s, int yst
       p[r * 8 + 4 + q] = byte_of(w.y, q);
     }
   }
-}
-
-// 8-point Hadamard butterflies in the reference's output order -- encfrag.c:122-154
-__device__ __forceinline__ void hadamard8(int &a0, int &a1, int &a2, int &a3, int &a4, int &a5, int &a6,
-                                          int &a7) {
-  int t0 = a0 + a4, t4 = a0 - a4, t1 = a1 + a5, t5 = a1 - a5;
-  int t2 = a2 + a6, t6 = a2 - a6, t3 = a3 + a7, t7 = a3 - a7;
-  int r;
-  r = t0; t0 += t2; t2 = r - t2;
-  r = t1; t1 += t3; t3 = r - t3;
-  r = t4; t4 += t6; t6 = r - t6;
-  r = t5; t5 += t7; t7 = r - t7;
-  a0 = t0 + t1; a1 = t0 - t1; a2 = t2 + t3; a3 = t2 - t3;
-  a4 = t4 + t5; a5 = t4 - t5; a6 = t6 + t7; a7 = t6 - t7;
-}
-
-// SATD of a difference block d[64] (row-major): rows first with an int16 store
-// (encfrag.c:147-154), then the other axis, summing |.| without the DC term
-// (encfrag.c:264-315).  *dc = sum of the first-stage DC outputs = sum of all differences.
-__device__ __forceinline__ unsigned satd_of(int d[64], int &dc) {
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    hadamard8(d[r * 8 + 0], d[r * 8 + 1], d[r * 8 + 2], d[r * 8 + 3], d[r * 8 + 4], d[r * 8 + 5],
-              d[r * 8 + 6], d[r * 8 + 7]);
-#pragma unroll
-    for (int k = 0; k < 8; k++) d[r * 8 + k] = sx16(d[r * 8 + k]);
-  }
-  // the reference stores row r's k-th output at buf[k*8+r] and then transforms rows of
-  // buf, i.e. for each k it combines d[r*8+k] over r
-  dc = 0;
-#pragma unroll
-  for (int r = 0; r < 8; r++) dc += d[r * 8 + 0];
-  unsigned sad = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    int c0 = d[0 * 8 + k], c1 = d[1 * 8 + k], c2 = d[2 * 8 + k], c3 = d[3 * 8 + k];
-    int c4 = d[4 * 8 + k], c5 = d[5 * 8 + k], c6 = d[6 * 8 + k], c7 = d[7 * 8 + k];
-    hadamard8(c0, c1, c2, c3, c4, c5, c6, c7);
-    if (k > 0) sad += abs(c0);
-    sad += abs(c1) + abs(c2) + abs(c3) + abs(c4) + abs(c5) + abs(c6) + abs(c7);
-  }
-  return sad;
-}
-
-template <int OP>
-__global__ __launch_bounds__(256) void k_enc_metric(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane,
-                                                   const uint8_t *ref_plane, int ystride,
-                                                   const int32_t *src_offs, const int32_t *ref_offs,
-                                                   const int32_t *ref2_offs, uint32_t thresh, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int s[64];
-  load_pixels(s, src_plane + src_offs[i], ystride);
-  constexpr bool kHasRef = OP != THIP_ENC_INTRA_SAD && OP != THIP_ENC_INTRA_SATD;
-  constexpr bool kTwo = OP == THIP_ENC_SAD2_THRESH || OP == THIP_ENC_SATD2;
-  int p[64];
-  if (kHasRef) {
-    load_pixels(p, ref_plane + ref_offs[i], ystride);
-    if (kTwo) {
-      int q[64];
-      load_pixels(q, ref_plane + ref2_offs[i], ystride);
-#pragma unroll
-      for (int k = 0; k < 64; k++) p[k] = (p[k] + q[k]) >> 1;   // encfrag.c:79,172
-    }
-  }
-  unsigned v = 0;
-  int dc = 0;
-  if (OP == THIP_ENC_SAD || OP == THIP_ENC_SAD_THRESH || OP == THIP_ENC_SAD2_THRESH) {
-    // row-granular early out of encfrag.c:64,80: rows after the one that crosses the
-    // threshold are not added
-    bool live = true;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      unsigned rs = 0;
-#pragma unroll
-      for (int k = 0; k < 8; k++) rs += abs(s[r * 8 + k] - p[r * 8 + k]);
-      if (live) v += rs;
-      if (OP != THIP_ENC_SAD && v > thresh) live = false;
-    }
-  } else if (OP == THIP_ENC_INTRA_SAD) {   // encfrag.c:88-107
-    int sum = 0;
-#pragma unroll
-    for (int k = 0; k < 64; k++) sum += s[k];
-    const int mean = (sum + 32) >> 6;
-#pragma unroll
-    for (int k = 0; k < 64; k++) v += abs(s[k] - mean);
-  } else if (OP == THIP_ENC_SSD) {   // encfrag.c:338-350
-#pragma unroll
-    for (int k = 0; k < 64; k++) v += (unsigned)((s[k] - p[k]) * (s[k] - p[k]));
-  } else {   // SATD family, encfrag.c:317-336
-    if (kHasRef) {
-#pragma unroll
-      for (int k = 0; k < 64; k++) s[k] -= p[k];
-    }
-    v = satd_of(s, dc);
-  }
-  out[i] = v;
-  if (dc_out) dc_out[i] = dc;
 }
 
 __global__ __launch_bounds__(256) void k_enc_border_ssd(uint32_t *out, const uint8_t *src_plane,
@@ -593,6 +496,32 @@ int thip_enc_frag_metric_batch(int op, uint32_t *out, int32_t *dc_out, const uin
     LAUNCH_METRIC(THIP_ENC_SSD)
   }
 #undef LAUNCH_METRIC
+  HIP_TRY(hipGetLastError());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
+  return THIP_OK;
+}
+
+int thip_enc_frag_metric_sites_batch(int op, uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
+                                     int ystride, const int32_t *src_offs, const int32_t *ref_offs, const int8_t *site_dx,
+                                     const int8_t *site_dy, int nsites, int64_t nblocks) {
+  if (!out || !src_plane || !ref_plane || !src_offs || !ref_offs || !site_dx || !site_dy) return THIP_EFAULT;
+  if ((op != THIP_ENC_SAD && op != THIP_ENC_SATD) || nsites < 1 || nsites > 9 || nblocks < 0) return THIP_EINVAL;
+  SitesK K;
+  for (int k = 0; k < 9; k++) K.site_of[k] = -1;
+  K.nsites = nsites;
+  for (int c = 0; c < nsites; c++) {
+    if (site_dx[c] < -1 || site_dx[c] > 1 || site_dy[c] < -1 || site_dy[c] > 1) return THIP_EINVAL;
+    int8_t &slot = K.site_of[(site_dy[c] + 1) * 3 + (site_dx[c] + 1)];
+    if (slot >= 0) return THIP_EINVAL;   // a position asked for twice
+    slot = (int8_t)c;
+  }
+  if (nblocks == 0) return THIP_OK;
+  if (op == THIP_ENC_SAD)
+    hipLaunchKernelGGL(k_enc_sites<THIP_ENC_SAD>, grid_for(3 * nblocks), dim3(256), 0, g_batch_stream, out, dc_out, src_plane, ref_plane,
+                       ystride, src_offs, ref_offs, K, nblocks);
+  else
+    hipLaunchKernelGGL(k_enc_sites<THIP_ENC_SATD>, grid_for(3 * nblocks), dim3(256), 0, g_batch_stream, out, dc_out, src_plane, ref_plane,
+                       ystride, src_offs, ref_offs, K, nblocks);
   HIP_TRY(hipGetLastError());
   if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
