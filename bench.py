@@ -76,6 +76,116 @@ def _cpu_worker(job):
     return t
 
 
+# Frame-39 CRC32s of streams 0..3 of the default workload (4K dense, pool 6, kf 64): the same on every run, every world
+# size and every launch shape since round 2 -- a cheap end-to-end regression check of the timed batch.
+COMMITTED_CRC_FRAME39 = ["78bed3bc", "a82eb830", "ee6d99cc", "3ad204b2"]
+
+
+def measure_pmc_traffic(args, kernels):
+    """HBM bytes per launch of the timed kernels from the L2's fabric-side counters: this script re-executed under
+    rocprofv3 --pmc, ONE counter per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md), one lane so
+    that every launch has the shape of the instrumented pass; FETCH_SIZE doubled (gfx950 reports half the bytes of wide
+    coalesced reads, same guide), WRITE_SIZE as reported, both in KiB.  Returns a dict or None (no rocprofv3, a failed pass)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(td, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "24", "--warmup", "4", "--repeats", "1", "--min-time", "0", "--no-cpu-baseline", "--no-parity",
+                   "--no-profile", "--no-pmc", "--second-content", "", "--content", args.content, "--size", args.size,
+                   "--streams-per-gpu", str(args.streams_per_gpu), "--pool", str(args.pool)]
+            env = dict(os.environ, THIP_LANES="1", TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            try:
+                r = subprocess.run(cmd, env=env, cwd=td, capture_output=True, text=True, timeout=240)
+            except (OSError, subprocess.TimeoutExpired):
+                return None
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter:
+                    acc.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+            out[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+    res = {}
+    for k in kernels:
+        if k and k in out["FETCH_SIZE"]:
+            f, w = out["FETCH_SIZE"][k], out["WRITE_SIZE"].get(k, 0.0)
+            res[k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "hbm_bytes_per_launch": int(round((2 * f + w) * 1024))}
+    return res or None
+
+
+def system_libtheora_baseline(size="720p", nframes=24):
+    """if the box has a system libtheoradec, time it on generated packets (one thread) and report it as
+    "system libtheora"; otherwise say so.  The packets are tests/streamgen.py's (typical content, matched Huffman trees)."""
+    import ctypes as C
+    import ctypes.util
+    name = None
+    for cand in ("libtheoradec.so.1", "libtheoradec.so", ctypes.util.find_library("theoradec")):
+        if not cand:
+            continue
+        try:
+            lib = C.CDLL(cand, mode=getattr(os, "RTLD_LOCAL", 0))
+            name = cand
+            break
+        except OSError:
+            continue
+    if not name:
+        return {"kind": "system libtheora", "available": False, "note": "no libtheoradec.so on this box (dlopen failed)"}
+    try:
+        from tests import streamgen
+        from theora_amd import _lib
+        from theora_amd._lib import ThImgPlane
+        from theora_amd.decoder import _packet
+        w, h = SIZES[size]
+        content = dict(density=0.35, p_dc_only=0.45, p_empty=0.4)
+        st = streamgen.Stream(w, h, 0, seed=99, trees="matched", probe_kwargs=content)
+        hdr = st.header_packets()
+        pkts = [st.frame(0 if f % 8 == 0 else 1, **content)[0] for f in range(8)]
+        info, tc, setup = _lib.ThInfo(), _lib.ThComment(), C.c_void_p()
+        lib.th_decode_alloc.restype = C.c_void_p
+        lib.th_decode_alloc.argtypes = [C.c_void_p, C.c_void_p]
+        lib.th_decode_packetin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.th_decode_ycbcr_out.argtypes = [C.c_void_p, C.c_void_p]
+        lib.th_decode_free.argtypes = [C.c_void_p]
+        lib.th_setup_free.argtypes = [C.c_void_p]
+        lib.th_info_init(C.byref(info))
+        lib.th_comment_init(C.byref(tc))
+        for k, hp in enumerate(hdr):
+            op, keep = _packet(hp, bos=1 if k == 0 else 0, packetno=k)
+            if lib.th_decode_headerin(C.byref(info), C.byref(tc), C.byref(setup), C.byref(op)) <= 0:
+                raise RuntimeError("th_decode_headerin refused header %d" % k)
+        dec = lib.th_decode_alloc(C.byref(info), setup)
+        lib.th_setup_free(setup)
+        if not dec:
+            raise RuntimeError("th_decode_alloc failed")
+        buf = (ThImgPlane * 3)()
+        ops = [_packet(p, packetno=3 + k) for k, p in enumerate(pkts)]
+        t0 = time.perf_counter()
+        n = 0
+        while n < nframes:
+            for op, keep in ops:
+                gp = C.c_int64()
+                if lib.th_decode_packetin(dec, C.byref(op), C.byref(gp)) < 0:
+                    raise RuntimeError("th_decode_packetin failed")
+                lib.th_decode_ycbcr_out(dec, buf)
+                n += 1
+        dt = time.perf_counter() - t0
+        lib.th_decode_free(dec)
+        return {"kind": "system libtheora", "available": True, "library": name, "value": round(n / dt, 2), "unit": "frames/s", "cores": 1,
+                "sample": "%d packets of a generated %s 4:2:0 stream (typical content), th_decode_packetin + th_decode_ycbcr_out" % (n, size)}
+    except Exception as e:   # a library that is there but does not behave: say so, never fail the bench
+        return {"kind": "system libtheora", "available": True, "library": name, "error": str(e)[:200]}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="decode", choices=["decode", "enc", "e2e"])
@@ -98,6 +208,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-process-per-core leg of the CPU baseline")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-execute under rocprofv3 --pmc for roofline.traffic (N = 1 only)")
     return ap.parse_known_args()
 
 
@@ -207,12 +318,20 @@ def main_e2e(main_args, argv):
     ap.add_argument("--loops", type=int, default=5)
     ap.add_argument("--no-output", action="store_true", help="skip th_decode_ycbcr_out (no D2H)")
     ap.add_argument("--threads", type=int, default=1, help="host threads, one independent stream each")
+    ap.add_argument("--e2e-size", default="", choices=["", "720p", "1080p", "4k", "cif", "qcif"], help="picture size of the generated packets")
+    ap.add_argument("--no-native", action="store_true", help="skip the dump_video_hip / decode_bench legs")
     ap.add_argument("--trees", choices=["matched", "random"], default="matched")
     ap.add_argument("--packets", choices=["dense", "typical"], default="dense",
                     help="dense: 70 %% of the super blocks coded, 30 %% of the coded blocks with AC coefficients "
                          "(~80 KB per 720p frame); typical: 35 %% / 15 %% (closer to SURVEY section 6's statistics, ~30 KB)")
     args = ap.parse_args(argv)
-    args.size = main_args.size if main_args.size != "4k" else "720p"   # the generator is Python: keep it small
+    # --size as given when it is given; the mode's default is 720p (bench.py's own default, 4K, costs the Python packet
+    # generator about 15 s of set-up and 5 s a frame: ask for it with --e2e-size 4k)
+    args.size = args.e2e_size or (main_args.size if main_args.size != "4k" else "720p")
+    if args.size == "4k":
+        args.frames = min(args.frames, 6)
+    elif args.size == "1080p":
+        args.frames = min(args.frames, 8)
     import torch
     from tests import streamgen
     from theora_amd.decoder import Decoder
@@ -269,7 +388,7 @@ def main_e2e(main_args, argv):
         dec.close()
     # the same packets in an Ogg file through the C program (examples/dump_video_hip.c): no Python between the calls
     exe = os.path.join(ROOT, "examples", "dump_video_hip")
-    if os.path.exists(exe):
+    if os.path.exists(exe) and not args.no_native:
         import subprocess
         import tempfile
         from tests import oggmux
@@ -602,13 +721,20 @@ def main():
                        "ms_per_step_max": round(1e3 * max(blocks) / args.steps, 5),
                        "ms_per_step_first_block": round(1e3 * blocks[0] / args.steps, 5)},
         }
+        # HBM bytes per launch from the PMC counters of THIS workload: two more passes of this script under rocprofv3
+        traffic, traffic_bytes = None, None
+        if world == 1 and not args.no_pmc and profiling and G == 1:
+            traffic = measure_pmc_traffic(args, KERNEL_NAMES)
+            if traffic and KERNEL_NAMES[0] in traffic:
+                traffic_bytes = traffic[KERNEL_NAMES[0]]["hbm_bytes_per_launch"]
         if profiling and kms[0] > 0:
             gbs = prof_b_alg / (kms[0] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAMES[0], "achieved": round(gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                               # HBM bytes per launch cannot be sampled from inside this process (PMC counters need
-                               # rocprofv3 around it): null here, the rocprofv3 --pmc passes of this workload are under profiles/
-                               "traffic": None, "traffic_profile": TRAFFIC_PROFILE,
+                               # HBM bytes per launch of this kernel: FETCH_SIZE x 2 + WRITE_SIZE from two rocprofv3 --pmc passes
+                               # of this very workload (measure_pmc_traffic; null when rocprofv3 is missing, at N > 1, or with
+                               # --no-pmc); the committed passes of the round are under profiles/
+                               "traffic": traffic_bytes, "traffic_detail": traffic, "traffic_profile": TRAFFIC_PROFILE,
                                "avg_launch_us": round(1e3 * kms[0] / max(launches[0], 1), 3),
                                "second_kernel": KERNEL_NAMES[1] if launches[1] else None,
                                "second_kernel_avg_launch_us": round(1e3 * kms[1] / max(launches[1], 1), 3) if launches[1] else None,
@@ -621,9 +747,16 @@ def main():
         if second:
             out["second_content"] = second
         if cpu_baseline:
+            cpu_baseline["system_libtheora"] = system_libtheora_baseline()
             out["cpu_baseline"] = cpu_baseline
         if parity:
             parity["stream_crc32_at_frame_%d" % (nparity - 1)] = ["%08x" % c for c in parity_crcs]
+            if (args.size, args.content, args.pool, nparity, G) == ("4k", "dense", 6, 40, 1) and S >= 4:
+                # streams [0, 4) are the same pictures at every world size and under every launch shape
+                got39 = ["%08x" % c for c in parity_crcs[:4]]
+                if got39 != COMMITTED_CRC_FRAME39:
+                    raise SystemExit("bench: frame-39 CRCs of streams 0..3 %s differ from the committed %s" % (got39, COMMITTED_CRC_FRAME39))
+                parity["matches_committed_crc32"] = True
             out["parity"] = parity
         out["stream_crc32"] = ["%08x" % c for c in crcs]
         out["setup_s"] = round(t_gen, 1)

@@ -404,6 +404,35 @@ int thip_profile_reset(void);
 
 const char *thip_version_string(void);
 
+/* ------------------------------------------------------------------------------------
+ * Run-time options.  One table inside the library: the environment is read ONCE, when the first
+ * option is looked up (THIP_<NAME> in upper case = integer value; THIP_DEVICE also takes "rr"), and
+ * thip_set_option changes a value from then on.  Options are read where they are used -- a change
+ * takes effect with the next call -- except "lanes" and "ctx_lanes", which size stream pools created when
+ * a device is first used.  thip_option_name enumerates the table (NULL past its end) with a one-line
+ * description of each entry:
+ *   fuse         3 (default) k_recon_lf: reconstruction + loop filter in one pass; 0 the two passes
+ *   lanes        library-owned HIP streams per device for thip_decode_frames (default 2)
+ *   ctx_lanes    HIP streams shared by the enqueue-fed states, i.e. th_decode_* contexts (default 8; 0 = the lanes)
+ *   chunk        streams per kernel launch (default THIP_MAX_BATCH)
+ *   skip_static  leave static blocks in place: 0 never, 1 when most of the frame is uncoded (default), 2 whenever possible
+ *   lf_sparse    k_loopfilter reads the coded flags first: -1 by coded fraction (default), 0 never, 1 always
+ *   zerocopy     enqueue path: kernels read the pinned staging across PCIe (default 1)
+ *   wait_spin    wait for a frame in hipEventSynchronize instead of polling with short sleeps (default 0)
+ *   dc_global    DC un-prediction through memory even where the LDS kernel fits (default 0)
+ *   debug        k_recon ablation switches (profiling)
+ *   fe_device_dc, fe_device_tokens, fe_device_lists   th_decode_*: front-end stages on the device (default 0; also
+ *                TH_DECCTL_THIP_SET_DEVICE_* per context)
+ *   fe_trace_backend, fe_prof   th_decode_*: record slot calls instead of running them (tests); per-stage host timing
+ *   device       th_decode_alloc: -1 the calling thread's current device (default), n that device, -2 round robin
+ * Returns THIP_EINVAL for a name the table does not have.
+ * ---------------------------------------------------------------------------------- */
+int thip_set_option(const char *name, int value);
+int thip_get_option(const char *name, int *value);
+const char *thip_option_name(int index, const char **help);
+/* (internal shorthand of thip_get_option for the library's own translation units: 0 for an unknown name) */
+int thip_option(const char *name);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,3 +110,37 @@ def test_integration_shim_compiles(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-c", src, "-o", str(tmp_path / "shim.o")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_options_table():
+    """thip_set_option / thip_get_option / thip_option_name (include/theora_hip.h): every documented name exists with its
+    documented default (when the environment does not say otherwise), values round-trip, unknown names are refused."""
+    import ctypes as C
+    from theora_amd import _lib
+    L = _lib.load()
+    names, i = [], 0
+    while True:
+        hlp = C.c_char_p()
+        nm = L.thip_option_name(i, C.byref(hlp))
+        if nm is None:
+            break
+        assert hlp.value
+        names.append(nm.decode())
+        i += 1
+    hdr = open(os.path.join(ROOT, "include", "theora_hip.h")).read()
+    for nm in names:
+        assert (" " + nm) in hdr, nm          # documented in the header
+    for nm in ("fuse", "lanes", "ctx_lanes", "chunk", "skip_static", "lf_sparse", "zerocopy", "wait_spin", "dc_global", "debug",
+               "fe_device_dc", "fe_device_tokens", "fe_device_lists", "fe_trace_backend", "fe_prof", "device"):
+        assert nm in names, nm
+    defaults = dict(fuse=3, lanes=2, ctx_lanes=8, skip_static=1, lf_sparse=-1, zerocopy=1, device=-1)
+    for nm, dv in defaults.items():
+        if "THIP_" + nm.upper() not in os.environ:
+            v = C.c_int(12345)
+            assert L.thip_get_option(nm.encode(), C.byref(v)) == 0 and v.value == dv, (nm, v.value)
+    v = C.c_int()
+    assert L.thip_set_option(b"lf_sparse", 1) == 0 and L.thip_get_option(b"lf_sparse", C.byref(v)) == 0 and v.value == 1
+    assert L.thip_set_option(b"lf_sparse", -1) == 0 and L.thip_option(b"lf_sparse") == -1
+    assert L.thip_set_option(b"no_such_option", 1) == _lib.EINVAL
+    assert L.thip_get_option(b"no_such_option", C.byref(v)) == _lib.EINVAL
+    assert L.thip_set_option(None, 1) == _lib.EINVAL

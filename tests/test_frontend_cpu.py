@@ -15,13 +15,14 @@ from tests import streamgen
 
 @pytest.fixture()
 def trace_env():
-    old = os.environ.get("THIP_FE_TRACE_BACKEND")
-    os.environ["THIP_FE_TRACE_BACKEND"] = "1"
+    """Contexts allocated inside the test record the slot calls instead of running them (option fe_trace_backend, the
+    THIP_FE_TRACE_BACKEND of the environment): no device needed."""
+    from theora_amd import _lib
+    L = _lib.load()
+    old = L.thip_option(b"fe_trace_backend")
+    assert L.thip_set_option(b"fe_trace_backend", 1) == 0
     yield
-    if old is None:
-        del os.environ["THIP_FE_TRACE_BACKEND"]
-    else:
-        os.environ["THIP_FE_TRACE_BACKEND"] = old
+    L.thip_set_option(b"fe_trace_backend", old)
 
 
 @pytest.mark.parametrize("trees", ["random", "matched"])

@@ -124,6 +124,47 @@ def test_sequence_1080p_smooth(hip):
     assert not rep, rep[:3]
 
 
+def test_config3_as_written(hip):
+    """BASELINE.json config 3 literally: 1920x1080 (coded 1920x1088) 4:2:0, key-frame interval 64, 130 frames (two interval
+    boundaries), ONE stream on one state, the frames in flight behind each other; every 8th frame and the last are
+    compared with the oracle."""
+    assert util.run_sequence(hip, 1920, 1088, PF_420, 130, "smooth", seed=1080, kf_interval=64, check_every=8) == []
+
+
+def test_gop_parallel_through_the_c_abi(hip):
+    """A stream's key-frame intervals are independent (a key frame resets both references, decode.c:2947-2955), so a caller
+    may decode G of them side by side on G states -- bench.py --gop-parallel, DESIGN.md section 5c.  Here through the C ABI:
+    12 intervals of 9 frames, G = 4 states, state g takes intervals g, g + 4, g + 8 (three rounds, i.e. every state crosses two
+    interval boundaries), the four states' frames of a step in ONE thip_decode_frames call; every frame of every interval
+    against ONE oracle that decodes the stream sequentially."""
+    import zlib
+    w, h, K, G, rounds = 336, 272, 9, 4, 3
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(4242)
+    ost = oracle.State(w, h, PF_420)
+    frames, want = [], []
+    for i in range(G * rounds * K):
+        fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if i % K == 0 else hip.INTER_FRAME, ["mixed", "smooth", "dense"][(i // K) % 3])
+        util.oracle_apply(ost, fr)
+        frames.append(fr)
+        want.append([ost.get_plane(oracle.FRAME_PREV, p).copy() for p in range(3)])
+    states = [hip.State(w, h, PF_420) for _ in range(G)]
+    keep = []
+    for r in range(rounds):
+        for j in range(K):
+            idx = [(r * G + g) * K + j for g in range(G)]          # frame j of interval r*G + g for state g
+            descs = []
+            for i in idx:
+                d, ka = synth.upload_frame(synth.pack_frame(geom, frames[i]))
+                keep.append(ka)
+                descs.append(d)
+            assert list(hip.decode_frames(states, descs)) == [0] * G
+            for g, i in enumerate(idx):
+                for p in range(3):
+                    got = states[g].read_plane(states[g].ref_idx(hip.FRAME_PREV), p)
+                    assert np.array_equal(got, want[i][p]), (r, j, g, p)
+
+
 def test_enqueue_path_matches(hip):
     """The one-fragment-at-a-time vtable slots (thip_state_frag_recon, thip_frag_copy_list,
     thip_state_loop_filter_frag_rows) driven in the reference's MCU order."""

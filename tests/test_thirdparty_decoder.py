@@ -59,15 +59,14 @@ def make_clip(w, h, seed, nframes, lflim, max_mag, grey, force_qis=None, fmt=3, 
     st.max_mag = max_mag
     st.chroma_empty = grey
     hdr = st.header_packets()
-    old = os.environ.get("THIP_FE_TRACE_BACKEND")
-    os.environ["THIP_FE_TRACE_BACKEND"] = "1"
+    from theora_amd import _lib
+    L = _lib.load()
+    old = L.thip_option(b"fe_trace_backend")
+    L.thip_set_option(b"fe_trace_backend", 1)
     try:
         dec = Decoder(hdr)                              # slot-trace context: only used for the granule positions
     finally:
-        if old is None:
-            del os.environ["THIP_FE_TRACE_BACKEND"]
-        else:
-            os.environ["THIP_FE_TRACE_BACKEND"] = old
+        L.thip_set_option(b"fe_trace_backend", old)
     ost = oracle.State(w, h, fmt)
     ls = oggmux.LogicalStream(0x7E0 + seed)
     for k, p in enumerate(hdr):

@@ -113,6 +113,10 @@ SYMBOLS = [
     ("thip_profile_read", _I, [C.POINTER(_I64), C.POINTER(C.c_double)]),
     ("thip_profile_reset", _I, []),
     ("thip_version_string", C.c_char_p, []),
+    ("thip_set_option", _I, [C.c_char_p, _I]),
+    ("thip_get_option", _I, [C.c_char_p, C.POINTER(_I)]),
+    ("thip_option_name", C.c_char_p, [_I, C.POINTER(C.c_char_p)]),
+    ("thip_option", _I, [C.c_char_p]),
 ]
 
 # ---- th_decode_* API (include/theoradec_hip.h) ----------------------------------------------

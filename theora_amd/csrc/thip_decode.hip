@@ -53,8 +53,82 @@ using namespace thip;
     }                                                                                    \
   } while (0)
 
+// ---------------------------------------------------------------------------------------
+// run-time options: one table, one parser (include/theora_hip.h: thip_set_option)
+// ---------------------------------------------------------------------------------------
+namespace {
+struct Option {
+  const char *name;
+  int value;
+  const char *help;
+};
+Option g_options[] = {
+    {"fuse", 3, "3: k_recon_lf, reconstruction + loop filter in one pass (default); 0: the two passes k_recon + k_loopfilter"},
+    {"lanes", 2, "library-owned HIP streams per device for thip_decode_frames (1..4); read when a device is first used"},
+    {"ctx_lanes", 8, "HIP streams shared by the enqueue-fed states (th_decode_* contexts), 0 = use the lanes; read at first use"},
+    {"chunk", THIP_MAX_BATCH, "streams per kernel launch (1..THIP_MAX_BATCH)"},
+    {"skip_static", 1, "leave static blocks where they are: 0 never, 1 when most of the frame is uncoded, 2 whenever possible (tests)"},
+    {"lf_sparse", -1, "k_loopfilter reads the coded flags first: -1 by coded fraction, 0 never, 1 always"},
+    {"zerocopy", 1, "enqueue path: kernels read the pinned staging buffers across PCIe (0: hipMemcpyAsync into device copies)"},
+    {"wait_spin", 0, "wait for a frame with hipEventSynchronize instead of polling with 20 us sleeps"},
+    {"dc_global", 0, "DC un-prediction with the work-group kernel that goes through memory (planes beyond k_dc_wave's LDS take it anyway)"},
+    {"debug", 0, "k_recon ablation switches for profiling"},
+    {"fe_device_dc", 0, "th_decode_*: DC un-prediction on the device"},
+    {"fe_device_tokens", 0, "th_decode_*: token expansion + dequantisation on the device (host-delimited tokens)"},
+    {"fe_device_lists", 0, "th_decode_*: the token lists themselves on the device"},
+    {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
+    {"fe_prof", 0, "th_decode_*: per-stage host timing"},
+    {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
+};
+constexpr int kNumOptions = (int)(sizeof(g_options) / sizeof(g_options[0]));
+std::once_flag g_options_once;
+// The environment is read ONCE, here: THIP_<NAME> (upper case) = integer; THIP_DEVICE also takes "rr".
+void options_from_env() {
+  for (int i = 0; i < kNumOptions; i++) {
+    char env[64] = "THIP_";
+    size_t k = 5;
+    for (const char *c = g_options[i].name; *c && k + 1 < sizeof(env); c++) env[k++] = (char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+    env[k] = 0;
+    const char *v = getenv(env);
+    if (!v || !*v) continue;
+    if (!strcmp(g_options[i].name, "device") && !strcmp(v, "rr")) g_options[i].value = -2;
+    else g_options[i].value = atoi(v);
+  }
+}
+Option *find_option(const char *name) {
+  std::call_once(g_options_once, options_from_env);
+  if (!name) return nullptr;
+  for (int i = 0; i < kNumOptions; i++)
+    if (!strcmp(g_options[i].name, name)) return &g_options[i];
+  return nullptr;
+}
+}  // namespace
+// (internal accessor, also used by thip_frontend.cpp)
+extern "C" int thip_option(const char *name) {
+  const Option *o = find_option(name);
+  return o ? o->value : 0;
+}
+extern "C" int thip_set_option(const char *name, int value) {
+  Option *o = find_option(name);
+  if (!o) return THIP_EINVAL;
+  o->value = value;
+  return THIP_OK;
+}
+extern "C" int thip_get_option(const char *name, int *value) {
+  const Option *o = find_option(name);
+  if (!o || !value) return o ? THIP_EFAULT : THIP_EINVAL;
+  *value = o->value;
+  return THIP_OK;
+}
+extern "C" const char *thip_option_name(int index, const char **help) {
+  if (index < 0 || index >= kNumOptions) return nullptr;
+  if (help) *help = g_options[index].help;
+  return g_options[index].name;
+}
+
 #include "thip_kernels.h"
 #include "thip_fused.h"
+#include "thip_dc.h"
 #include "thip_postproc.h"
 #include "thip_tokens.h"
 
@@ -99,8 +173,10 @@ struct thip_state {
   int lf_y0[3], lf_y1[3], lf_rows_custom;
   // DC un-prediction on the device (thip_frame_desc.dc_tokens / thip_state_set_device_dc)
   int16_t *d_dc;        // device, nfrags: un-predicted DC values of the frame being decoded
-  uint8_t *d_edge;      // device, fused path: kStEdgeRec bytes per super tile (k_recon_st's left-edge hand-off)
-  uint32_t edge_epoch;  // serial number of the last k_recon_st launch for this state (0 = never: the records are zero); 31 bits
+  uint4 *d_dc_ent;      // device, nfrags: k_dc_prepare's per-fragment entries
+  uint8_t *d_dc_rowhas; // device, one byte per fragment row of every plane
+  uint8_t *d_edge;      // device, k_recon_lf: kTfRec bytes per tile (the tiles' edges for their neighbours)
+  uint32_t edge_epoch;  // serial number of the last k_recon_lf launch for this state (0 = never: the records are zero); 12 bits
   int device_dc, enq_device_dc;
   int16_t *h_dc, *d_dc_in;   // enqueue path: token DC values staged per fragment (pinned) and their device copy
   uint8_t *h_flags, *d_flags;   // ... and the fragments' coded | refi << 1 in fragment-index order (the staged command
@@ -163,7 +239,6 @@ struct DeviceGuard {
   }
 };
 int g_profile = 0;
-const int g_debug = getenv("THIP_DEBUG") ? atoi(getenv("THIP_DEBUG")) : 0;
 struct EvPair { hipEvent_t a, b; int kernel; };
 std::vector<EvPair> g_events;
 std::vector<hipEvent_t> g_pool;
@@ -173,7 +248,7 @@ int ensure_lanes(int device) {   // the device must be current; callable from an
   std::lock_guard<std::mutex> lk(g_lanes_mu);
   if (device < 0 || device >= kMaxDevices) return THIP_EINVAL;
   if (g_lanes_ready[device]) return 0;
-  int n = getenv("THIP_LANES") ? atoi(getenv("THIP_LANES")) : 2;
+  int n = thip_option("lanes");
   if (n < 1) n = 1;
   if (n > kMaxLanes) n = kMaxLanes;
   for (int i = 0; i < n; i++) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[device][i], hipStreamNonBlocking));
@@ -219,8 +294,8 @@ struct ScopedTimer {
 
 // The stream of an enqueue-fed state (device current).
 int context_stream(thip_state *st, hipStream_t *out) {
-  static const int nctx = [] {
-    const int v = getenv("THIP_CTX_LANES") ? atoi(getenv("THIP_CTX_LANES")) : 8;
+  static const int nctx = [] {   // (streams are created once: read at first use)
+    const int v = thip_option("ctx_lanes");
     return v < 0 ? 0 : (v > kCtxLanes ? kCtxLanes : v);
   }();
   int rc = ensure_lanes(st->device);
@@ -238,28 +313,6 @@ int context_stream(thip_state *st, hipStream_t *out) {
   if (st->ctx_lane < 0) st->ctx_lane = g_next_ctx[st->device]++ % nctx;
   *out = g_ctx_lanes[st->device][st->ctx_lane];
   return THIP_OK;
-}
-
-// Fused path (k_recon_walk): waves per work group, and how many groups one launch spreads over the chip.
-int walk_waves() {
-  static const int w = [] {
-    int v = getenv("THIP_WALK_WAVES") ? atoi(getenv("THIP_WALK_WAVES")) : 8;
-    return v < 1 ? 1 : (v > 16 ? 16 : v);
-  }();
-  return w;
-}
-int walk_groups_per_launch() {   // default: what is resident at once -- CUs x (groups that fit a CU's LDS)
-  static const int n = [] {
-    if (getenv("THIP_WALK_WGS")) return atoi(getenv("THIP_WALK_WGS")) < 8 ? 8 : atoi(getenv("THIP_WALK_WGS"));
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int per_cu = (160 * 1024) / (walk_waves() * kWalkWaveLds);
-    constexpr int kWavesPerCu = THIP_WALK_MAXTHREADS >= 1024 ? 16 : 12;   // four (three) waves per SIMD: the register cap the launch bound implies
-    if (per_cu * walk_waves() > kWavesPerCu) per_cu = kWavesPerCu / walk_waves();
-    if (per_cu < 1) per_cu = 1;
-    return cus * per_cu;
-  }();
-  return n;
 }
 
 // k_recon_lf hands tile edges from work group to work group through the L2 of ONE XCD, which is only right if
@@ -322,7 +375,7 @@ int fill_bands(StreamK &K, const thip_state *st) {
 
 // Fills the per-plane kernel geometry and the cumulative tile / cell counts.
 void fill_stream_geom(StreamK &K, const thip_state *st) {
-  int tiles = 0, cells = 0, rsc = 0, sts = 0, ssc = 0;
+  int tiles = 0, cells = 0;
   for (int pli = 0; pli < 3; pli++) {
     const thip_plane_geom &g = st->geom[pli];
     PlaneK &k = K.pl[pli];
@@ -339,16 +392,6 @@ void fill_stream_geom(StreamK &K, const thip_state *st) {
     cells += ((g.nhfrags + 1) * (g.nvfrags + 1) + 63) & ~63;   // whole waves per plane (k_loopfilter)
     K.cell_end[pli] = cells;
     k.tiles_y = st->tiles.tiles_y[pli];
-    k.rs_rows = g.nvfrags / 4 + 1;                              // cell rows m = 0, 4, ... (k_lf_seams)
-    rsc += (k.rs_rows * (g.nhfrags + 1) + 63) & ~63;
-    K.rs_end[pli] = rsc;
-    k.st_x = (k.tiles_x + kStW - 1) / kStW;
-    k.st_y = (k.tiles_y + kStH - 1) / kStH;
-    sts += k.st_x * k.st_y;
-    K.st_end[pli] = sts;
-    // seam cells: the rows between two super-tile rows
-    ssc += ((k.st_y - 1) * (g.nhfrags + 1) + 63) & ~63;
-    K.ss_end[pli] = ssc;
   }
 }
 }  // namespace
@@ -482,6 +525,8 @@ void thip_state_free(thip_state *st) {
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
   if (st->d_slot0) (void)hipFree(st->d_slot0);
   if (st->d_dc) (void)hipFree(st->d_dc);
+  if (st->d_dc_ent) (void)hipFree(st->d_dc_ent);
+  if (st->d_dc_rowhas) (void)hipFree(st->d_dc_rowhas);
   if (st->ev_order) (void)hipEventDestroy(st->ev_order);
   if (st->d_edge) (void)hipFree(st->d_edge);
   if (st->h_tl) (void)hipHostFree(st->h_tl);
@@ -600,8 +645,7 @@ __global__ __launch_bounds__(256) void k_frame_out(const OutK K) {
 // measured on 16 cores with 16 / 32 / 64 decoder threads: 11.6 / 9.6 / 6.1 k frames/s spinning,
 // 11.7 / 10.9 / 10.0 k sleeping (tools/wait_modes.sh).
 static int wait_event(hipEvent_t ev) {
-  static const int spin = getenv("THIP_WAIT_SPIN") ? atoi(getenv("THIP_WAIT_SPIN")) : 0;
-  if (spin) {
+  if (thip_option("wait_spin")) {
     HIP_TRY(hipEventSynchronize(ev));
     return THIP_OK;
   }
@@ -759,7 +803,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   BatchK B;
   memset(&B, 0, sizeof(B));
   int max_wg = 0, max_seam_wg = 0, any_lf = 0, nlive = 0;
-  int max_swg = 0, any_skip = 0;   // fused path
+  int any_skip = 0;
   int live_state[THIP_MAX_BATCH];
   for (int i = 0; i < n; i++) {
     thip_state *st = states[i];
@@ -807,7 +851,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     // previous frame is the PREV reference, and the previous frame's flags are at hand to tell that
     // it did not touch the block (k_recon).  THIP_SKIP_STATIC=0 switches the elision off, 2 applies it to
     // every frame with an uncoded block (tests).
-    static const int skip_static = getenv("THIP_SKIP_STATIC") ? atoi(getenv("THIP_SKIP_STATIC")) : 1;
+    const int skip_static = thip_option("skip_static");
     const int64_t serial = st->frame_serial + 1;   // of the frame being decoded
     const int pm = st->map_serial[0] == serial - 1 ? 0 : (st->map_serial[1] == serial - 1 ? 1 : -1);
     const int cm = pm == 0 ? 1 : 0;
@@ -820,9 +864,9 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     st->map_serial[cm] = serial;
     st->buf_serial[bufi] = serial;
     K.flimit2 = 2 * d.flimit;
-    K.debug = g_debug;
+    K.debug = thip_option("debug");
     // flags-first loop filter when at least a tenth of the frame is uncoded (THIP_LF_SPARSE=0/1 forces)
-    static const int lf_sparse_env = getenv("THIP_LF_SPARSE") ? atoi(getenv("THIP_LF_SPARSE")) : -1;
+    const int lf_sparse_env = thip_option("lf_sparse");
     K.lf_sparse = lf_sparse_env >= 0 ? lf_sparse_env : (int64_t)d.ncoded * 10 < (int64_t)st->nfrags * 9;
     K.qpx = st->hdec;
     K.qpy = st->vdec;
@@ -846,16 +890,24 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   {
     DcBatchK D;
     memset(&D, 0, sizeof(D));
-    int ndc = 0, max_rows = 0, max_dc_frags = 0;
+    int ndc = 0, max_rows = 0, max_nh = 0;
     for (int j = 0; j < nlive; j++) {
       thip_state *st = states[live_state[j]];
       const thip_frame_desc &d = descs[live_state[j]];
       if (!d.dc_tokens) continue;
       if (!st->d_dc) HIP_TRY(hipMalloc((void **)&st->d_dc, sizeof(int16_t) * (size_t)st->nfrags));
-      B.s[j].dc = st->d_dc;          // k_recon / k_recon_walk take every block's DC from here
+      if (!st->d_dc_ent) HIP_TRY(hipMalloc((void **)&st->d_dc_ent, sizeof(uint4) * (size_t)st->nfrags));
+      const int rows_total = st->geom[0].nvfrags + st->geom[1].nvfrags + st->geom[2].nvfrags;
+      if (!st->d_dc_rowhas) HIP_TRY(hipMalloc((void **)&st->d_dc_rowhas, (size_t)rows_total + 16));
+      B.s[j].dc = st->d_dc;          // k_recon / k_recon_lf take every block's DC from here
+      int row0 = 0;
       for (int pli = 0; pli < 3; pli++) {
         const thip_plane_geom &g = st->geom[pli];
         DcPlaneK &p = D.p[ndc][pli];
+        p.ent = st->d_dc_ent + g.froffset;
+        p.rowhas = st->d_dc_rowhas + row0;
+        row0 += g.nvfrags;
+        max_nh = std::max(max_nh, g.nhfrags);
         p.in = d.dc_tokens + g.froffset;
         p.out = st->d_dc + g.froffset;
         p.flags = st->flush_flags ? st->d_flags + g.froffset : nullptr;
@@ -865,25 +917,34 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
         p.tiles_x = st->tiles.tiles_x[pli];
         p.tile_base = st->tiles.tile_off[pli];
         if (g.nvfrags > max_rows) max_rows = g.nvfrags;
-        max_dc_frags = std::max(max_dc_frags, g.nhfrags * g.nvfrags);
       }
       ndc++;
     }
     if (ndc) {
-      if (max_dc_frags <= kDcLdsMaxFrags && !getenv("THIP_DC_GLOBAL")) {
-        HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_dc_unpredict_lds), 3 * ((kDcLdsMaxFrags + 7) & ~7), 3));
-        hipLaunchKernelGGL(k_dc_unpredict_lds, dim3(3, ndc), dim3((max_rows + 63) & ~63), (size_t)3 * ((max_dc_frags + 7) & ~7), s, D);
+      // one wave per plane with the rows in flight in LDS (thip_dc.h); planes too large for that -- beyond 4K -- keep the
+      // work-group version that goes through memory
+      int lds = 0;
+      bool fits = true;
+      for (int j = 0; j < ndc && fits; j++)
+        for (int pli = 0; pli < 3 && fits; pli++) {
+          fits = dcw_fits(D.p[j][pli].nh, D.p[j][pli].nv);
+          if (fits) lds = std::max(lds, dcw_layout(D.p[j][pli].nh, D.p[j][pli].nv).bytes);
+        }
+      const int dc_global = thip_option("dc_global");
+      if (fits && !dc_global) {
+        HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_dc_wave), kDcwLdsMax, 3));
+        hipLaunchKernelGGL(k_dc_prepare, dim3(max_rows, 3, ndc), dim3((max_nh + 63) & ~63), 0, s, D);
+        hipLaunchKernelGGL(k_dc_wave, dim3(3, ndc), dim3(64), (size_t)lds, s, D);
       } else {
         hipLaunchKernelGGL(k_dc_unpredict, dim3(3, ndc), dim3((max_rows + 63) & ~63), 0, s, D);
       }
       HIP_TRY(hipGetLastError());
     }
   }
-  // Default (THIP_FUSE=3): k_recon_lf, reconstruction and the whole loop filter in one pass (thip_fused.h).
-  // THIP_FUSE=0: the two passes k_recon + k_loopfilter.  Frames that leave static blocks in place (skip_ok) and frames
-  // without a loop filter always take the two-pass path, whose first kernel knows how to skip whole tiles.
-  // (THIP_FUSE=1 / 2: the earlier fused designs k_recon_walk + k_lf_seams and k_recon_st + k_lf_st_seams.)
-  static const int fuse = getenv("THIP_FUSE") ? atoi(getenv("THIP_FUSE")) : 3;
+  // Default (option "fuse" = 3): k_recon_lf, reconstruction and the whole loop filter in one pass (thip_fused.h); 0: the two
+  // passes k_recon + k_loopfilter.  Frames that leave static blocks in place (skip_ok) and frames without a loop filter
+  // always take the two passes, whose first kernel knows how to skip whole tiles.
+  const int fuse = thip_option("fuse");
   if (fuse == 3 && any_lf && !any_skip && xcd_round_robin(states[live_state[0]]->device)) {
     // one wave per tile, reconstruction and every filter cell in one pass (thip_fused.h)
     int longest = 1;
@@ -902,55 +963,6 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     }
     ScopedTimer t(s, THIP_KERNEL_RECON);
     hipLaunchKernelGGL(k_recon_lf, dim3(8 * longest, nlive), dim3(64), 0, s, B);
-  } else if (fuse == 2 && any_lf && !any_skip) {
-    // super tiles: one kernel closes all filter cells but the rows between two super-tile rows (left edges travel
-    // between neighbouring groups), the second filters those rows and seven short columns
-    int max_st = 0, max_ss = 0;
-    for (int j = 0; j < nlive; j++) max_st = std::max(max_st, (B.s[j].st_end[2] + 7) & ~7);
-    for (int j = 0; j < nlive; j++) {
-      thip_state *st = states[live_state[j]];
-      StreamK &K = B.s[j];
-      if (!st->d_edge) {
-        HIP_TRY(hipMalloc((void **)&st->d_edge, (size_t)K.st_end[2] * kStEdgeRec));
-        HIP_TRY(hipMemsetAsync(st->d_edge, 0, (size_t)K.st_end[2] * kStEdgeRec, s));
-      }
-      K.edge = st->d_edge;
-      st->edge_epoch = (st->edge_epoch + 1) & 0x7FFFFFFFu;
-      if (!st->edge_epoch) st->edge_epoch = 1;
-      K.epoch = st->edge_epoch;
-      K.st_nband = max_st >> 3;
-      max_ss = std::max(max_ss, ((K.ss_end[2] + 7 * 64 + 255) / 256 + 7) & ~7);
-    }
-    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_recon_st), kStLds, 0));
-    {
-      ScopedTimer t(s, THIP_KERNEL_RECON);
-      hipLaunchKernelGGL(k_recon_st, dim3(max_st, nlive), dim3(64 * kStWaves), (size_t)kStLds, s, B);
-    }
-    {
-      ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
-      hipLaunchKernelGGL(k_lf_st_seams, dim3(max_ss, nlive), dim3(256), 0, s, B);
-    }
-  } else if (fuse && any_lf && !any_skip) {
-    // one launch = one round of resident work groups: the streams share them equally
-    int ng = (walk_groups_per_launch() / nlive) & ~7;
-    if (ng < 8) ng = 8;
-    for (int j = 0; j < nlive; j++) {
-      StreamK &K = B.s[j];
-      int n = ng;
-      while (n > 8 && K.tile_end[2] < n * walk_waves()) n -= 8;   // small pictures: at least a tile per wave
-      K.walk_wgs = n;
-      const int swg = ((K.rs_end[2] + 64 * n + 255) / 256 + 7) & ~7;
-      if (swg > max_swg) max_swg = swg;
-    }
-    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_recon_walk), 16 * kWalkWaveLds, 1));
-    {
-      ScopedTimer t(s, THIP_KERNEL_RECON);
-      hipLaunchKernelGGL(k_recon_walk, dim3(ng, nlive), dim3(64 * walk_waves()), (size_t)walk_waves() * kWalkWaveLds, s, B);
-    }
-    {
-      ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
-      hipLaunchKernelGGL(k_lf_seams, dim3(max_swg, nlive), dim3(256), 0, s, B);
-    }
   } else {
     {
       ScopedTimer t(s, THIP_KERNEL_RECON);
@@ -1024,8 +1036,8 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
   }
   // group by device, then by lane (order inside a lane preserved), launch chunk by chunk
   // (THIP_CHUNK: streams per launch)
-  static const int chunk_max = [] {
-    const int v = getenv("THIP_CHUNK") ? atoi(getenv("THIP_CHUNK")) : THIP_MAX_BATCH;
+  const int chunk_max = [] {
+    const int v = thip_option("chunk");
     return v < 1 ? 1 : (v > THIP_MAX_BATCH ? THIP_MAX_BATCH : v);
   }();
   uint32_t devmask = 0;
@@ -1078,14 +1090,22 @@ int thip_dc_unpredict_plane(int16_t *dc, const uint8_t *flags, int nhfrags, int 
   p.flags = flags;
   p.nh = nhfrags;
   p.nv = nvfrags;
-  if ((int64_t)nhfrags * nvfrags <= kDcLdsMaxFrags && !getenv("THIP_DC_GLOBAL")) {
-    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_dc_unpredict_lds), 3 * ((kDcLdsMaxFrags + 7) & ~7), 3));
-    hipLaunchKernelGGL(k_dc_unpredict_lds, dim3(1, 1), dim3((nvfrags + 63) & ~63), (size_t)3 * ((nhfrags * nvfrags + 7) & ~7), 0, D);
+  void *scratch = nullptr;
+  if (dcw_fits(nhfrags, nvfrags) && !thip_option("dc_global")) {
+    const size_t nf = (size_t)nhfrags * nvfrags;
+    HIP_TRY(hipMalloc(&scratch, nf * sizeof(uint4) + (size_t)nvfrags + 16));
+    p.ent = (uint4 *)scratch;
+    p.rowhas = (uint8_t *)scratch + nf * sizeof(uint4);
+    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_dc_wave), kDcwLdsMax, 3));
+    hipLaunchKernelGGL(k_dc_prepare, dim3(nvfrags, 1, 1), dim3((nhfrags + 63) & ~63), 0, 0, D);
+    hipLaunchKernelGGL(k_dc_wave, dim3(1, 1), dim3(64), (size_t)dcw_layout(nhfrags, nvfrags).bytes, 0, D);
   } else {
     hipLaunchKernelGGL(k_dc_unpredict, dim3(1, 1), dim3((nvfrags + 63) & ~63), 0, 0, D);
   }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  const hipError_t le = hipGetLastError(), se = hipDeviceSynchronize();
+  if (scratch) (void)hipFree(scratch);
+  HIP_TRY(le);
+  HIP_TRY(se);
   return THIP_OK;
 }
 
@@ -1436,7 +1456,7 @@ int thip_frame_flush(thip_state *st) {
   int rc = context_stream(st, &s);
   if (rc) return rc;
   const size_t ngroups = ((size_t)st->enq_nslots + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
-  static const int zerocopy = getenv("THIP_ZEROCOPY") ? atoi(getenv("THIP_ZEROCOPY")) : 1;
+  const int zerocopy = thip_option("zerocopy");
   if (st->enq_ncoded && !zerocopy) {
     HIP_TRY(hipMemcpyAsync(st->d_info, st->h_info, (size_t)st->tiles.ntiles * THIP_TILE_FRAGS * 8,
                            hipMemcpyHostToDevice, s));

@@ -66,11 +66,9 @@ __device__ __forceinline__ uint32_t intra_sad_rows(const uint2 a[8]) {
   return v;
 }
 // encfrag.c:338-350
-__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t d;
-  asm("v_dot4_u32_u8 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
+// (the builtin, not inline assembly: the dot instructions have issue hazards against their neighbours that only the compiler
+//  can pad when it knows what the instruction is)
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 __device__ __forceinline__ uint32_t ssd_rows(const uint2 a[8], const uint2 b[8]) {
   uint32_t sq = 0, ab = 0;
 #pragma unroll
@@ -108,10 +106,10 @@ __device__ __forceinline__ pk16 pk_abs(pk16 x) {
   const pk16 z = {0, 0};
   return __builtin_elementwise_max(x, z - x);
 }
+typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t sum2_u16(pk16 m, uint32_t acc) {   // acc + m.lo + m.hi, both halves unsigned
-  uint32_t d;
-  asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(as_u32(m)), "v"(0x00010001u), "v"(acc));
-  return d;
+  const upk16 one = {(unsigned short)1, (unsigned short)1};
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(upk16, m), one, acc, false);
 }
 // D[r][j]: the c0 level of the difference block (row r, pixel pair j).  Returns sum |coefficient| without the DC term;
 // dc = the DC coefficient = the sum of all differences (encfrag.c:264-315).
@@ -201,7 +199,7 @@ struct SitesK {
 };
 // unit u = 3 * block + dxi: the lane's candidates are (dxi - 1, dy), dy = -1..1
 template <int OP>
-__global__ __launch_bounds__(256) void k_enc_sites(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
+__global__ __launch_bounds__(256, OP == THIP_ENC_SATD ? 5 : 1) void k_enc_sites(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
                                                   int ystride, const int32_t *src_offs, const int32_t *ref_offs, const SitesK K,
                                                   int64_t nblocks) {
   const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -227,19 +225,23 @@ __global__ __launch_bounds__(256) void k_enc_sites(uint32_t *out, int32_t *dc_ou
       out[(int64_t)c[dyi] * nblocks + i] = v;
     }
   } else {
-    pk16 S[8][4], B[10][4];
+    // (the reference rows stay bytes, 20 registers, and are taken apart once per candidate: with the source block's 32 and the
+    //  difference block's 32 that is under 96 registers, five waves per SIMD -- which is what lets a 1080p 4:4:4 frame's
+    //  4 590 waves run as ONE round of resident waves instead of a full round and a nearly empty one)
+    pk16 S[8][4];
 #pragma unroll
     for (int r = 0; r < 8; r++) row_sd(S[r], s[r]);
-#pragma unroll
-    for (int r = 0; r < 10; r++) row_sd(B[r], e[r]);
 #pragma unroll
     for (int dyi = 0; dyi < 3; dyi++) {
       if (c[dyi] < 0) continue;
       pk16 D[8][4];
 #pragma unroll
-      for (int r = 0; r < 8; r++)
+      for (int r = 0; r < 8; r++) {
+        pk16 Bt[4];
+        row_sd(Bt, e[r + dyi]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) D[r][j] = S[r][j] - B[r + dyi][j];
+        for (int j = 0; j < 4; j++) D[r][j] = S[r][j] - Bt[j];
+      }
       int dc;
       const uint32_t v = satd_sd(D, dc);
       out[(int64_t)c[dyi] * nblocks + i] = v;

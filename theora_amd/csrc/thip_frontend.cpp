@@ -937,14 +937,14 @@ th_dec_ctx *th_decode_alloc(const th_info *info, const th_setup_info *setup) { r
 
 th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, int device) {
   if (!info || !setup) return nullptr;
-  if (device < 0) {
-    const char *e = getenv("THIP_DEVICE");
-    if (e && !strcmp(e, "rr")) {
+  if (device < 0) {   // option "device" (THIP_DEVICE=<n>|rr): -1 the current device, -2 round robin over the node's devices
+    const int e = thip_option("device");
+    if (e == -2) {
       static std::atomic<unsigned> next{0};
       const int n = thip_device_count();
       device = n > 0 ? (int)(next.fetch_add(1) % (unsigned)n) : -1;
-    } else if (e && *e) {
-      device = atoi(e);
+    } else if (e >= 0) {
+      device = e;
     }
   }
   if ((info->frame_width & 15) || (info->frame_height & 15) || !info->frame_width || !info->frame_height ||
@@ -954,7 +954,7 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   d->info = *info;
   d->setup = *setup;
   d->hip = nullptr;
-  d->trace = getenv("THIP_FE_TRACE_BACKEND") != nullptr && atoi(getenv("THIP_FE_TRACE_BACKEND")) != 0;
+  d->trace = thip_option("fe_trace_backend") != 0;
   d->tr_flimit = 0;
   if (!d->trace &&
       thip_state_create_on(&d->hip, device, (int)info->frame_width, (int)info->frame_height, (int)info->pixel_fmt) < 0) {
@@ -963,10 +963,10 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   }
   if (d->hip) thip_state_set_eager_output(d->hip, 1);   // every frame is wanted on the host (th_decode_ycbcr_out)
   d->device_dc = false;
-  if (d->hip && getenv("THIP_FE_DEVICE_DC") && atoi(getenv("THIP_FE_DEVICE_DC")) != 0)
+  if (d->hip && thip_option("fe_device_dc") != 0)
     d->device_dc = thip_state_set_device_dc(d->hip, 1) == 0;   // (refused for planes of more than 1024 fragment rows)
-  d->device_tokens = d->hip && getenv("THIP_FE_DEVICE_TOKENS") && atoi(getenv("THIP_FE_DEVICE_TOKENS")) != 0;
-  d->device_lists = d->hip && getenv("THIP_FE_DEVICE_LISTS") && atoi(getenv("THIP_FE_DEVICE_LISTS")) != 0;
+  d->device_tokens = d->hip && thip_option("fe_device_tokens") != 0;
+  d->device_lists = d->hip && thip_option("fe_device_lists") != 0;
   build_geometry(d);
   d->dequant.resize((size_t)64 * 3 * 2 * 64);
   for (int qi = 0; qi < 64; qi++)
@@ -1016,7 +1016,7 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   d->stripe_cb.ctx = nullptr;
   d->stripe_cb.stripe_decoded = nullptr;
   memset(&d->prof, 0, sizeof(d->prof));
-  d->prof.on = getenv("THIP_FE_PROF") != nullptr;
+  d->prof.on = thip_option("fe_prof") != 0;
   for (int p = 0; p < 3; p++) d->mirror[p].assign((size_t)d->nh[p] * 8 * d->nv[p] * 8, 0);
   return d;
 }

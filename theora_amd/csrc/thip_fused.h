@@ -34,7 +34,10 @@
 // fragment-row range of the enqueue slot (state.c:1066) is honoured the same way as in k_loopfilter.
 #pragma once
 
-constexpr int kTfPitch = 144;                  // LDS image row: 8-byte left margin (4 used), 128 pixels, 8 spare
+#ifndef THIP_TF_PITCH
+#define THIP_TF_PITCH 144
+#endif
+constexpr int kTfPitch = THIP_TF_PITCH;                  // LDS image row: 8-byte left margin (4 used), 128 pixels, 8 spare
 constexpr int kTfX0 = 8;                       // byte offset of pixel column 0 in an image row
 constexpr int kTfImgRows = 40;                 // pixel rows -4 .. 35 (upper neighbour's last 4, the tile, lower neighbour's first 4)
 constexpr int kTfFlagOff = kTfImgRows * kTfPitch;   // coded flags: 6 rows (block rows -1..4) of kTfFlagPitch bytes

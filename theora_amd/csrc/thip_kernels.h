@@ -1,6 +1,6 @@
 // thip_kernels.h -- device side of the frame-scope path: the geometry constants shared with the
-// host, the per-stream kernel-argument tables, and the kernels k_recon, k_recon_walk, k_lf_seams,
-// k_loopfilter, k_loopfilter_plane.  Included by thip_decode.hip only (which holds the host
+// host, the per-stream kernel-argument tables, and the kernels k_recon, k_loopfilter, k_loopfilter_plane,
+// k_dc_unpredict, k_expand_tokens (k_recon_lf: thip_fused.h, k_dc_wave: thip_dc.h).  Included by thip_decode.hip only (which holds the host
 // side and the C ABI); see the header comment there for the overall picture.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -39,8 +39,6 @@ struct PlaneK {
   int fro;           // raster index of the plane's first fragment
   float rcp_cx;      // 1/(nh+1)
   int tiles_y;       // tile rows
-  int rs_rows;       // cell rows left to k_lf_seams: m = 0, 4, ..., 4*(nv/4)
-  int st_x, st_y;    // super tiles across / down (k_recon_st)
 };
 
 struct StreamK {
@@ -63,16 +61,10 @@ struct StreamK {
   int lf_y0[3], lf_y1[3]; // fragment-row range whose filter operations are applied
   int debug;              // ablation switches for profiling (THIP_DEBUG env), 0 in production
   int lf_sparse;          // k_loopfilter reads the coded flags first and skips waves without a coded block
-  // fused reconstruction + loop filter (k_recon_walk / k_lf_seams)
-  int walk_wgs;           // work groups of k_recon_walk for this stream: group g walks tiles [g*n/walk_wgs, (g+1)*n/walk_wgs)
-  int rs_end[3];          // cumulative row-seam cell counts per plane, each plane padded to 64
-  int st_end[3];          // cumulative super-tile counts per plane (k_recon_st: one work group per super tile)
-  int ss_end[3];          // cumulative row-seam cell counts per plane, each plane padded to 64 (k_lf_st_seams)
-  int st_nband;           // work groups per XCD band of the k_recon_st launch (its gridDim.x / 8)
-  uint8_t *edge;          // kStEdgeRec bytes per super tile: a group's last block column for its right neighbour
-                          // (k_recon_lf: kTfRec bytes per tile, thip_fused.h)
+  // reconstruction + loop filter in one pass (k_recon_lf, thip_fused.h)
+  uint8_t *edge;          // kTfRec bytes per tile: the tile's edges for its neighbours
   uint32_t epoch;         // serial number that marks the edge records of this launch
-  int band_u0[9];         // k_recon_lf: first tile of each of the 8 XCD bands (whole tile rows), [8] = number of tiles
+  int band_u0[9];         // first tile of each of the 8 XCD bands (whole tile rows), [8] = number of tiles
   PlaneK pl[3];
 };
 
@@ -184,6 +176,17 @@ __device__ __forceinline__ void lf_vert_pk(CellPix &C, int r0, int L2) {
 // of the four V-H pairs, which of the two comes first:  Hl precedes Vlo only as T2 before T3;  Vlo (T1, T3) always
 // precedes Hr (T4, T8);  Hl (T2, T5) always precedes Vhi (T6, T7);  Hr precedes Vhi only as T4 (then Vhi is T6).
 __device__ __forceinline__ void lf_cell_apply_pk(CellPix &C, uint32_t t, int L2) {
+#ifdef THIP_LF_8SLOTS   // (A/B: the eight slots T1..T8 as they come)
+  if (__any(t & 1u)) { if (t & 1u) lf_vert_pk(C, 0, L2); }
+  if (__any(t & 2u)) { if (t & 2u) lf_horz_pk(C, 0, L2); }
+  if (__any(t & 4u)) { if (t & 4u) lf_vert_pk(C, 0, L2); }
+  if (__any(t & 8u)) { if (t & 8u) lf_horz_pk(C, 1, L2); }
+  if (__any(t & 16u)) { if (t & 16u) lf_horz_pk(C, 0, L2); }
+  if (__any(t & 32u)) { if (t & 32u) lf_vert_pk(C, 4, L2); }
+  if (__any(t & 64u)) { if (t & 64u) lf_vert_pk(C, 4, L2); }
+  if (__any(t & 128u)) { if (t & 128u) lf_horz_pk(C, 1, L2); }
+  return;
+#endif
   const bool hl_first = (t & 6u) == 6u;                 // T2 and T3: the horizontal edge first
   const bool vlo = (t & 5u) != 0, hl_late = (t & 18u) != 0 && !hl_first;
   const bool hr_first = (t & 8u) != 0, vhi = (t & 96u) != 0, hr_late = (t & 128u) != 0;
@@ -760,767 +763,7 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   recon_tile(S, unit, lane, s_coef + wave * 512, reinterpret_cast<uint32_t *>(s_coef + wave * 512) + 1024, tr);
 }
 
-// ---------------------------------------------------------------------------------------
-// k_recon_walk (K1+K2+three quarters of K3): work groups walk through the tiles
-// ---------------------------------------------------------------------------------------
-// The second pass over the frame (k_loopfilter) costs a read and a write of every pixel.  What a
-// second pass can fix CHEAPLY is a horizontal seam -- eight whole rows, contiguous memory -- and
-// what it cannot is a vertical one: an 8-byte column piece per row touches every cache line of the
-// frame.  So this kernel leaves (almost) no vertical seam.  A stream's tiles, in tile order (plane by
-// plane, tile row by tile row, left to right), are cut into walk_wgs equal ranges, one per work group,
-// and dealt round-robin to the group's waves: wave j takes tiles u0+j, u0+j+W, ...  The tile to the
-// left of a tile is the previous one in that order, so it belongs to the neighbour wave (or to this
-// wave's previous round), and its last four pixel columns -- unfiltered, 32 rows x 4 bytes -- come
-// over through LDS with a pair of counters; there is no work-group barrier.  A wave
-//   1. reconstructs its tile exactly as k_recon does (the two memory round trips; the command words
-//      of its NEXT tile are requested first, so from the second tile on there is one round trip),
-//   2. writes the 128x32 image into its LDS area (the coefficient staging area, free by then),
-//      publishes the right edge, waits for the left neighbour's,
-//   3. becomes 16 x 4 filter cells (cells are independent): lane (kx, m) takes
-//      the cell centred on corner (16t + kx, 4*sby + m) for m = 1..3 and filters it; the lanes with
-//      m = 0 carry the tile's pixel rows 28..31 and 0..3 unfiltered.  The cells are shifted by half a
-//      block against the tile, so what the wave stores is the frame region [128t-4, 128t+124) x
-//      [32*sby, 32*sby+32): 128 contiguous bytes per row, every byte of the frame exactly once.
-// k_lf_seams then filters the cell rows on tile-row boundaries (m = 0 mod 4) -- a quarter of the
-// lines instead of all of them -- and the three cells on each CUT, the place where one group's range
-// ends in the middle of a tile row (walk_wgs - 1 places per stream; both sides store their halves of
-// those cells unfiltered).  Equal ranges are what makes this a balanced single round of resident
-// groups: one group per tile row (30 tiles of luma, 15 of chroma, 408 groups for 256 CUs) measured 65 us
-// against 43 for k_recon, half of the CUs carrying twice the load of the others.
-// The order of operations inside every cell is the reference's (state.c:1055-1105), as in
-// k_loopfilter; both kernels honour the row range of the slot.
-constexpr int kWalkPitch = 144;                  // LDS image row: 8-byte left margin (4 used), 128 pixels, 8 spare
-constexpr int kWalkImgX0 = 8;                    // byte offset of pixel column 0 in an image row
-constexpr int kWalkFlagOff = 32 * kWalkPitch;    // coded flags: 4 rows of kWalkFlagPitch bytes
-constexpr int kWalkFlagPitch = 20;               // [0] left neighbour's column 15, [1..16] the tile, [17] column 16 (never coded)
-constexpr int kWalkMetaOff = 8192;               // 64 dwords for residual_shared
-constexpr int kWalkEdgeOff = 8448;               // published right edge: 2 buffers x 32 dwords (column bytes 124..127 per row)
-constexpr int kWalkEFlagOff = 8704;              // 2 dwords: coded flags of block column 15, one byte per block row
-constexpr int kWalkPubOff = 8712;                // tiles this wave has published
-constexpr int kWalkConsOff = 8716;               // tiles of this wave its right neighbour has consumed
-constexpr int kWalkWaveLds = 8832;               // per wave, multiple of 16
-
 __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// Waits until *ctr >= need.  Waves of one work group are co-resident, so the producer always makes
-// progress; the spin is bounded all the same (a wrong picture is a failed test, a hang is a dead GPU).
-__device__ __forceinline__ void lds_wait_ge(const uint32_t *ctr, uint32_t need) {
-  for (int spins = 0; spins < (1 << 22); spins++) {
-    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// One filter cell of the walk: corner column kx (0..16) of the tile, cell row m (0..3); reads the LDS
-// image, filters (m >= 1, unless the cell lies on a cut), stores to the frame.  The cell's upper half
-// is image rows (8m-4 .. 8m-1) mod 32 and its lower half rows 8m .. 8m+3: for m = 0 the former wraps to
-// rows 28..31, which is how the m = 0 lanes come to carry the tile's first and last four rows.
-__device__ __forceinline__ void walk_cell(const uint8_t *mine, uint8_t *plane, int stride, int nh, int nv, int t, int sby,
-                                          int kx, int m, bool active, int L2, int fy0, int fy1, bool unfiltered,
-                                          bool lo_mine, bool hi_mine) {
-  const int k = 16 * t + kx, mm = 4 * sby + m;
-  const bool lo_ok = active && lo_mine && k >= 1 && k <= nh, hi_ok = active && hi_mine && k <= nh - 1;
-  const int row_up = (8 * m - 4) & 31, row_dn = 8 * m;   // first image row of each half
-  CellPix C;
-  const uint8_t *img_up = mine + kWalkImgX0 + 8 * kx - 4 + row_up * kWalkPitch;
-  const uint8_t *img_dn = mine + kWalkImgX0 + 8 * kx - 4 + row_dn * kWalkPitch;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const uint32_t *qu = reinterpret_cast<const uint32_t *>(img_up + r * kWalkPitch);
-    const uint32_t *qd = reinterpret_cast<const uint32_t *>(img_dn + r * kWalkPitch);
-    C.lo[r] = qu[0];
-    C.hi[r] = qu[1];
-    C.lo[4 + r] = qd[0];
-    C.hi[4 + r] = qd[1];
-  }
-  const uint8_t *fl = mine + kWalkFlagOff + kx;    // fl[row * pitch + 0] = column kx-1, [+1] = column kx
-  const int ma = max(m - 1, 0);
-  const bool a = fl[ma * kWalkFlagPitch] != 0, b = fl[ma * kWalkFlagPitch + 1] != 0;
-  const bool c = fl[m * kWalkFlagPitch] != 0, d = fl[m * kWalkFlagPitch + 1] != 0;
-  uint32_t ops = lf_cell_ops(k, mm, nh, nv, a, b, c, d, fy0, fy1);
-  if (m == 0 || L2 == 0 || unfiltered || !(lo_ok || hi_ok)) ops = 0;
-  lf_cell_apply_pk(C, ops, L2);
-  const int H = nv * 8;
-  uint8_t *p_up = plane + (ptrdiff_t)(32 * sby + row_up) * stride + (8 * k - 4);
-  uint8_t *p_dn = plane + (ptrdiff_t)(32 * sby + row_dn) * stride + (8 * k - 4);
-  // (plane heights are multiples of 8 and the halves are 4 rows: a half is inside the plane or outside)
-  const bool up_ok = 32 * sby + row_up < H, dn_ok = 32 * sby + row_dn < H;
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    uint8_t *p = (r < 4 ? p_up : p_dn) + (ptrdiff_t)(r & 3) * stride;
-    if (r < 4 ? up_ok : dn_ok) {
-      if (lo_ok & hi_ok) {
-        Pix8 o;
-        o.x = C.lo[r];
-        o.y = C.hi[r];
-        *reinterpret_cast<Pix8 *>(p) = o;
-      } else if (lo_ok) {
-        *reinterpret_cast<uint32_t *>(p) = C.lo[r];
-      } else if (hi_ok) {
-        *reinterpret_cast<uint32_t *>(p + 4) = C.hi[r];
-      }
-    }
-  }
-}
-
-// first tile of group g's range when n tiles are cut into ng equal ranges
-__host__ __device__ inline int walk_cut(int g, int n, int ng) { return (int)(((long long)g * n) / ng); }
-
-#ifndef THIP_WALK_MAXTHREADS
-#define THIP_WALK_MAXTHREADS 1024   // launch bound = register cap: 1024 -> 128 VGPRs (4 waves per SIMD)
-#endif
-__global__ __launch_bounds__(THIP_WALK_MAXTHREADS) void k_recon_walk(const BatchK B) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_walk[];
-  const StreamK &S = B.s[blockIdx.y];
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int W = (int)blockDim.x >> 6;
-  const int g = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, see k_recon
-  const uint2 *info_p = S.info;
-  const int4 *coeffs_p = S.coeffs;
-  const uint32_t *slot0_p = S.tile_slot0;
-  uint8_t *self = S.self;
-  const uint8_t *prev = S.prev, *gold = S.gold;
-  uint8_t *coded_map = S.coded_map;
-  const int16_t *dc_p = S.dc;
-  const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2], ng = S.walk_wgs;
-  const int sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
-  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
-               "s"(te0), "s"(te1), "s"(te2), "s"(ng), "s"(sqpx), "s"(sqpy), "s"(L2));
-  uint8_t *const mine = s_walk + wave * kWalkWaveLds;
-  // the hand-off counters start at zero before any wave of the group looks at a neighbour's
-  if (((int)threadIdx.x & 63) == 0) {
-    *reinterpret_cast<uint32_t *>(mine + kWalkPubOff) = 0;
-    *reinterpret_cast<uint32_t *>(mine + kWalkConsOff) = 0;
-  }
-  __syncthreads();
-  if (g >= ng) return;
-  const int u0 = walk_cut(g, te2, ng), u1 = walk_cut(g + 1, te2, ng);   // this group's tiles
-  int u = u0 + wave;
-  if (u >= u1) return;                                                   // (no barrier below: spare waves just leave)
-  const uint8_t *const left = s_walk + (wave == 0 ? W - 1 : wave - 1) * kWalkWaveLds;   // the wave that holds tile u-1
-
-  ReconPlane R;
-  R.debug = 0;
-  R.tr = nullptr;
-  uint4 *const lds_wave = reinterpret_cast<uint4 *>(mine);
-  uint32_t *const lds_dw = reinterpret_cast<uint32_t *>(mine);
-  uint32_t *const meta = reinterpret_cast<uint32_t *>(mine + kWalkMetaOff);
-
-  uint32_t slot0 = slot0_p[u];
-  uint2 info = info_p[(size_t)u * THIP_TILE_FRAGS + ((int)threadIdx.x & 63)];
-  int cur_pli = -1, tiles_x = 1, tile_base = 0, fy0 = 0, fy1 = 0;
-  for (int it = 0; u < u1; it++, u += W) {
-    // The lane number is made opaque once per tile: left alone, the compiler hoists everything that
-    // depends on the lane only (addresses, masks, predicates of all three transform paths and of the
-    // cells) out of the tile loop and ends up with 250 live registers.
-    int lane = (int)threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));
-    // ---- the next tile's command words: requested now, used after this tile is done --------------
-    const int un = min(u + W, u1 - 1);
-    const uint32_t slot0_n = slot0_p[un];
-    const uint2 info_n = info_p[(size_t)un * THIP_TILE_FRAGS + lane];
-
-    // ---- where this tile is (scalar); the plane's geometry is re-read when the walk enters a plane ----
-    const int pli = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
-    if (pli != cur_pli) {
-      const PlaneK &G = S.pl[pli];
-      R.self = self + G.off;
-      R.prev = prev + G.off;
-      R.gold = gold + G.off;
-      R.coded_map = coded_map + G.fro;
-      R.nh = G.nh;
-      R.nv = G.nv;
-      R.stride = G.stride;
-      R.qpx = pli != 0 && sqpx;
-      R.qpy = pli != 0 && sqpy;
-      tiles_x = G.tiles_x;
-      tile_base = pli == 0 ? 0 : (pli == 1 ? te0 : te1);
-      fy0 = S.lf_y0[pli];
-      fy1 = S.lf_y1[pli];
-      cur_pli = pli;
-    }
-#ifdef THIP_TRACE
-    // tools/walk_trace.py: lane 0 stamps the phases of every tile (record = stream's tile number)
-    unsigned long long *tr = nullptr;
-    if (g_trace_buf && lane == 0) {
-      tr = g_trace_buf + ((size_t)blockIdx.y * te2 + u) * 8;
-      unsigned hwid;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-      tr[7] = (unsigned long long)hwid | (unsigned long long)it << 32 | (unsigned long long)wave << 40 | (unsigned long long)g << 48;
-    }
-    THIP_TR(tr, 0);   // tile begins
-#endif
-    const int rel = u - tile_base;
-    const int sby = rel / tiles_x, t = rel - sby * tiles_x;
-    const bool has_left = u > u0;                      // a wave of this group holds tile u-1: its edge gets consumed
-    const bool cut_left = !has_left && t > 0;          // the left neighbour belongs to another group
-    const bool row_end = t == tiles_x - 1;
-    const bool cut_right = u == u1 - 1 && !row_end;    // the right neighbour belongs to another group
-
-    const int h = lane & 15;
-    const int lx = (lane >> 4) * 4 + hilb_col(h), ly = hilb_row(h);   // fragment inside the tile
-    const int bx = t * 16 + lx, by = sby * 4 + ly;
-    uint8_t *const img = mine + (ly * 8) * kWalkPitch + kWalkImgX0 + lx * 8;   // this lane's block in the tile image
-    const bool valid = bx < R.nh && by < R.nv;
-    uint32_t dcv = 0;   // the block's un-predicted DC when it does not travel in the command stream
-    if (dc_p) dcv = 0x10000u | (uint16_t)dc_p[(int)(R.coded_map - coded_map) + min(by, R.nv - 1) * R.nh + min(bx, R.nh - 1)];
-    ReconLane L;
-    L.flags = valid ? info.x : 0u;
-    L.dcq = info.y >> 16;
-    L.dcraw = dcv;
-    L.dcp = ((uint32_t)(((int)(int16_t)((dcv ? dcv : info.y) & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;
-    L.coded = (L.flags & THIP_INFO_CODED) != 0;
-    L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
-    L.has_coeff = L.coded && !L.dc_only;
-    L.x0 = bx * 8;
-    L.y0 = by * 8;
-
-    // ---- coefficients + predictor: k_recon's second round trip ------------------------------------
-    const uint64_t mask = __ballot(L.has_coeff);
-    const int nown = __popcll(mask);
-    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    // Every register of the predictor windows and of the residual is DEFINED here, for every lane: a
-    // value that only some lanes (or some paths) assign is carried around the tile loop by the
-    // compiler as if the previous tile's mattered -- sixty registers of nothing.
-    PredWin Q;
-#pragma unroll
-    for (int r = 0; r < 9; r++) Q.w[r].a = Q.w[r].b = Q.w[r].c = 0u;
-    Q.sx = Q.sy = Q.mx2 = Q.my2 = 0;
-    Q.border = false;
-    bool inter = false;
-    const uint8_t *ref = nullptr;
-    const uint32_t fill = L.dc_only ? L.dcp : 0u;   // DC-only: the rounded value (state.c:972); uncoded: zero residual
-    uint32_t Y[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) Y[i] = fill;
-    if (nown == 0) {
-      if (valid) recon_issue(R, L, Q, inter, ref);
-    } else if (nown <= 16) {
-      int4 Wc[1][2];
-      residual_shared_load<4>(coeffs_p, slot0, nown, lane, Wc);
-      if (valid) recon_issue(R, L, Q, inter, ref);
-      residual_shared<4>(Wc, lds_dw, meta, lane, L, prefix, Y);
-    } else if (nown <= 32) {
-      int4 Wc[2][2];
-      residual_shared_load<2>(coeffs_p, slot0, nown, lane, Wc);
-      if (valid) recon_issue(R, L, Q, inter, ref);
-      residual_shared<2>(Wc, lds_dw, meta, lane, L, prefix, Y);
-    } else {
-      const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
-      const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
-#pragma unroll
-      for (int q = 0; q < 8; q++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
-                                         (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
-      if (valid) recon_issue(R, L, Q, inter, ref);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)
-      residual_per_lane(lds_wave + lane, L, Y);
-      if (!L.has_coeff) {
-#pragma unroll
-        for (int i = 0; i < 32; i++) Y[i] = fill;
-      }
-    }
-#ifdef THIP_TRACE
-    asm volatile("" : "+v"(Y[0]), "+v"(Y[31]));
-    THIP_TR(tr, 1);   // residual done (coefficients had arrived)
-#endif
-    uint2 rows[8];
-    recon_rows(R, Q, inter, Y, rows);
-#ifdef THIP_TRACE
-    asm volatile("" : "+v"(rows[0].x), "+v"(rows[7].y));
-    THIP_TR(tr, 2);   // pixels done (predictor windows had arrived)
-#endif
-
-    // ---- the tile image, its coded flags, the right edge for the neighbour -------------------------
-    lds_settle();                                   // every lane is done with the staging area
-    if (valid) {
-#pragma unroll
-      for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(img + r * kWalkPitch) = rows[r];
-    }
-    mine[kWalkFlagOff + ly * kWalkFlagPitch + 1 + lx] = (valid && L.coded) ? 1 : 0;
-    if (lane < 4) mine[kWalkFlagOff + lane * kWalkFlagPitch + 17] = 0;   // "column 16": the next tile's, never ours to filter
-    if (it >= 2) lds_wait_ge(reinterpret_cast<const uint32_t *>(mine + kWalkConsOff), (uint32_t)(it - 1));   // buffer it&1 is free again
-    lds_settle();
-    if (lane < 32)
-      reinterpret_cast<uint32_t *>(mine + kWalkEdgeOff)[(it & 1) * 32 + lane] =
-          *reinterpret_cast<const uint32_t *>(mine + lane * kWalkPitch + kWalkImgX0 + 124);
-    else if (lane == 32)
-      reinterpret_cast<uint32_t *>(mine + kWalkEFlagOff)[it & 1] =
-          (uint32_t)mine[kWalkFlagOff + 16] | (uint32_t)mine[kWalkFlagOff + kWalkFlagPitch + 16] << 8 |
-          (uint32_t)mine[kWalkFlagOff + 2 * kWalkFlagPitch + 16] << 16 | (uint32_t)mine[kWalkFlagOff + 3 * kWalkFlagPitch + 16] << 24;
-    lds_settle();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0)
-      __hip_atomic_store(reinterpret_cast<uint32_t *>(mine + kWalkPubOff), (uint32_t)(it + 1), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_WORKGROUP);
-
-#ifdef THIP_TRACE
-    THIP_TR(tr, 3);   // image in LDS, edge published
-#endif
-    // ---- tile u-1's edge into the image margin.  It is consumed (and acknowledged) even when tile u
-    //      starts a row and has no use for it: the producer waits for the acknowledgement before it
-    //      re-uses the buffer. -----------------------------------------------------------------------
-    if (has_left) {
-      const int il = wave == 0 ? it - 1 : it;       // the round in which the left wave did tile u-1
-      lds_wait_ge(reinterpret_cast<const uint32_t *>(left + kWalkPubOff), (uint32_t)(il + 1));
-      if (lane < 32)
-        *reinterpret_cast<uint32_t *>(mine + lane * kWalkPitch + kWalkImgX0 - 4) =
-            reinterpret_cast<const uint32_t *>(left + kWalkEdgeOff)[(il & 1) * 32 + lane];
-      else if (lane < 36)
-        mine[kWalkFlagOff + (lane - 32) * kWalkFlagPitch] =
-            t > 0 ? (uint8_t)(reinterpret_cast<const uint32_t *>(left + kWalkEFlagOff)[il & 1] >> (8 * (lane - 32))) : (uint8_t)0;
-      lds_settle();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0)
-        __hip_atomic_store(const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(left + kWalkConsOff)), (uint32_t)(il + 1),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-      if (lane >= 32 && lane < 36) mine[kWalkFlagOff + (lane - 32) * kWalkFlagPitch] = 0;
-      lds_settle();
-    }
-
-#ifdef THIP_TRACE
-    THIP_TR(tr, 4);   // left edge consumed
-#endif
-    // ---- 16 x 4 filter cells.  Column kx = 0 on a cut is stored unfiltered, right half only (k_lf_seams
-    //      filters it); a 17th column -- left half only -- exists where the tile ends the row of a plane
-    //      whose width is a whole number of tiles (cell column k = nh: the horizontal edges reach the
-    //      plane's border) and on the other side of a cut. ----------------------------------------------
-    {
-      const int kx = lane & 15;
-      const bool on_cut = cut_left && kx == 0;
-      walk_cell(mine, R.self, R.stride, R.nh, R.nv, t, sby, kx, lane >> 4, true, L2, fy0, fy1, on_cut, !on_cut, true);
-    }
-    if (cut_right || (row_end && (R.nh & 15) == 0))
-      walk_cell(mine, R.self, R.stride, R.nh, R.nv, t, sby, 16, lane & 3, lane < 4, L2, fy0, fy1, cut_right, true, false);
-    lds_settle();                                   // the image is read; the next tile may overwrite it
-#ifdef THIP_TRACE
-    THIP_TR(tr, 5);   // cells filtered, stores issued
-#endif
-    slot0 = slot0_n;
-    info = info_n;
-  }
-}
-
-// What k_recon_walk leaves: the cell rows m = 0, 4, 8, ..., 4*(nv/4), every column (m = nv is among them
-// when nv is a multiple of 4; otherwise it lies inside the last tile row and the walk has done it), and,
-// one wave each, the three cells m = 1..3 on every cut between two groups' ranges.
-__global__ __launch_bounds__(256) void k_lf_seams(const BatchK B) {
-  const StreamK &S = B.s[blockIdx.y];
-  const int lane = (int)threadIdx.x & 63;
-  // XCD bands over the work groups, like the kernel whose rows these are
-  const int wgb = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
-  const int wbase = __builtin_amdgcn_readfirstlane(wgb * 256 + (int)(threadIdx.x & ~63u));
-  uint8_t *self = S.self;
-  const uint8_t *cmap = S.coded_map;
-  const int ce0 = S.rs_end[0], ce1 = S.rs_end[1], ce2 = S.rs_end[2], L2 = S.flimit2;
-  const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2], ng = S.walk_wgs;
-  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2), "s"(te0), "s"(te1), "s"(te2), "s"(ng));
-  if (L2 == 0) return;
-  int pli, k, m;
-  if (wbase < ce2) {
-    pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
-  } else {
-    const int cut = (wbase - ce2) / 64 + 1;         // cut between group cut-1 and group cut
-    if (cut >= ng) return;
-    const int u = walk_cut(cut, te2, ng);
-    pli = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
-  }
-  const PlaneK G = S.pl[pli];
-  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
-  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(G.rs_rows), "s"(G.tiles_x),
-               "s"(fy0), "s"(fy1));
-  const int nh = G.nh, nv = G.nv;
-  if (wbase < ce2) {
-    const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
-    if (rel >= G.rs_rows * (nh + 1)) return;
-    uint32_t mu, ku;
-    divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
-    k = (int)ku;
-    m = (int)mu * 4;
-  } else {
-    const int cut = (wbase - ce2) / 64 + 1;
-    const int rel = walk_cut(cut, te2, ng) - (pli == 0 ? 0 : (pli == 1 ? te0 : te1));
-    const int sby = rel / G.tiles_x, t = rel - sby * G.tiles_x;
-    if (t == 0 || lane >= 3) return;                // the range starts with a tile row: no vertical seam
-    k = 16 * t;
-    m = 4 * sby + 1 + lane;
-    if (m > nv) return;
-  }
-  CellPix C;
-  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
-  bool a, b, c, d;
-  lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
-  const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
-  lf_cell_pin(C);
-  lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
-}
-
-// ---------------------------------------------------------------------------------------
-// k_recon_st + k_lf_st_seams (K1+K2+nine tenths of K3 in one pass): super tiles
-// ---------------------------------------------------------------------------------------
-// Filter cells are independent of each other (see lf_cell_ops): the cell on corner (k, m) needs the
-// UNFILTERED reconstruction of the four blocks around that corner and nothing else.  A work group takes a
-// super tile of kStW x kStH tiles (32 x 16 blocks, 256 x 128 pixels): its eight waves reconstruct one
-// tile each exactly as k_recon does and leave the pixels in LDS (each wave in its own coefficient staging
-// area, which is free by then); one barrier, and the waves become the 32 x 16 cells on the corners
-// (X0..X0+31, Y0..Y0+15).  All of them are closed -- their four blocks are in LDS -- except the first
-// column and the first row, whose left / upper blocks belong to the neighbour groups: 47 of 512.  The
-// group filters and stores the closed ones, final pixels, and stores its own quadrants of the others
-// unfiltered; k_lf_st_seams then filters the cells on the super-tile boundaries in place -- a sixteenth of
-// the lines and every fourth 64-byte piece of the rest instead of the whole frame a second time.  (The cells
-// on the plane's own border need no neighbour and are closed here.  The cells on the group's right and
-// bottom boundary -- the neighbours' first column / row, or the plane's border cells k = nh, m = nv -- are 49
-// more, taken by the last wave.)
-// Measured on the way: the boundary blocks reconstructed a second time instead (a "halo": 49 blocks, seven
-// neighbouring tiles, per-lane slot lookup by ballots over those tiles' command words) so that every cell
-// is closed and there is no second kernel.  As a ninth wave of the group: 85 us (the halo wave's scattered
-// loads make it the straggler of every barrier, and nine waves spread 3-2-2-2 over the SIMDs).  As a kernel
-// of its own in front: 19 us for a ninth of the blocks, because a block's eight 16-byte coefficient pieces and
-// a column block's nine predictor rows each cost a whole 64-byte fetch -- 50 MB for 12 MB of data.
-constexpr int kStW = 2, kStH = 4;                       // tiles per super tile, across / down
-static_assert(kStW >= 2, "the last wave's own cells must not include the first column");
-constexpr int kStBx = 16 * kStW, kStBy = 4 * kStH;      // 32 x 16 blocks
-constexpr int kStWaves = kStW * kStH;
-constexpr int kStPitch = 128;                           // LDS image row of a tile
-constexpr int kStMetaOff = 8192;                        // 64 dwords for residual_shared
-constexpr int kStWaveLds = 8448;                        // per wave: 8 KB staging / image, meta
-constexpr int kStFlagOff = kStWaves * kStWaveLds;       // coded flags of the blocks, work-group wide
-constexpr int kStFlagPitch = kStBx + 4;
-constexpr int kStLds = kStFlagOff + (kStBy + 2) * kStFlagPitch;
-// A group's last block column for its right neighbour (StreamK::edge, one record per super tile): for each of
-// the 8 rows of its kStBy blocks a pair {the row's right 4 bytes, tag}, tag = 2 * serial number of the launch +
-// the block's coded flag.  A pair is one 8-byte store, so it needs no flag behind it: whoever reads a pair with
-// this launch's serial number has the data.
-constexpr int kStEdgeRec = kStBy * 8 * 8;
-
-// LDS byte offset of block (lx, ly) of the super tile's image (clamped: blocks outside do not exist or are
-// the neighbours'; what is read for them is not used)
-__device__ __forceinline__ int st_block(int lx, int ly) {
-  const int cx = min(max(lx, 0), kStBx - 1), cy = min(max(ly, 0), kStBy - 1);
-  return ((cy >> 2) * kStW + (cx >> 4)) * kStWaveLds + ((cy & 3) * 8) * kStPitch + (cx & 15) * 8;
-}
-
-// What a cell of the group's first column takes from the left neighbour's edge record: rows 4..7 of its block
-// ly-1 (nothing for ly = 0: that half is the upper neighbours'), rows 0..3 of its block ly (nothing for ly = kStBy),
-// and those blocks' coded flags.
-struct StEdge {
-  uint32_t up[4], dn[4];
-  bool fa, fc;
-};
-// (device-scope loads: past the CU's L1, served by the L2 both groups share.)  False when a pair is not there yet.
-__device__ __forceinline__ bool st_edge_load(StEdge &E, const uint8_t *rec, int ly, uint32_t epoch) {
-  const int ua = max(ly - 1, 0), uc = min(ly, kStBy - 1);
-  const unsigned long long *e = reinterpret_cast<const unsigned long long *>(rec);
-  unsigned long long pu[4], pd[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    pu[r] = __hip_atomic_load(e + ua * 8 + 4 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pd[r] = __hip_atomic_load(e + uc * 8 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  bool ok = true;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    E.up[r] = (uint32_t)pu[r];
-    E.dn[r] = (uint32_t)pd[r];
-    ok = ok && (uint32_t)(pu[r] >> 33) == epoch && (uint32_t)(pd[r] >> 33) == epoch;
-  }
-  E.fa = ((pu[0] >> 32) & 1ull) != 0;
-  E.fc = ((pd[0] >> 32) & 1ull) != 0;
-  return ok;
-}
-
-// The cell on corner (X0 + lx, Y0 + ly): pixels from the LDS images, filter, store.  A cell in the first
-// column / row of a super tile that has a left / upper neighbour is a seam cell: the quadrants that are
-// this group's are stored as they are.
-__device__ __forceinline__ void st_cell(const uint8_t *lds, uint8_t *plane, int stride, int nh, int nv, int X0, int Y0,
-                                        int lx, int ly, bool active, int L2, int fy0, int fy1, bool edge, const StEdge &E) {
-  const int k = X0 + lx, mm = Y0 + ly;
-  active = active && k <= nh && mm <= nv;
-  const bool seam_l = lx == 0 && X0 > 0 && !edge, seam_u = ly == 0 && Y0 > 0;   // the left / upper half is a neighbour's
-  const bool seam_r = lx == kStBx && k < nh, seam_d = ly == kStBy && mm < nv;   // the right / lower half is
-  const int oa = st_block(lx - 1, ly - 1), ob = st_block(lx, ly - 1), oc = st_block(lx - 1, ly), od = st_block(lx, ly);
-  CellPix C;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    C.lo[r] = *reinterpret_cast<const uint32_t *>(lds + oa + (4 + r) * kStPitch + 4);
-    C.hi[r] = *reinterpret_cast<const uint32_t *>(lds + ob + (4 + r) * kStPitch);
-    C.lo[4 + r] = *reinterpret_cast<const uint32_t *>(lds + oc + r * kStPitch + 4);
-    C.hi[4 + r] = *reinterpret_cast<const uint32_t *>(lds + od + r * kStPitch);
-  }
-  const uint8_t *fl = lds + kStFlagOff + ly * kStFlagPitch + lx;   // flag of block (lx-1, ly-1)
-  bool a = fl[0] != 0, b = fl[1] != 0, c = fl[kStFlagPitch] != 0, d = fl[kStFlagPitch + 1] != 0;
-  if (edge && lx == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      C.lo[r] = E.up[r];
-      C.lo[4 + r] = E.dn[r];
-    }
-    a = E.fa;
-    c = E.fc;
-  }
-  uint32_t ops = lf_cell_ops(k, mm, nh, nv, a, b, c, d, fy0, fy1);
-  if (L2 == 0 || !active || seam_l || seam_u || seam_r || seam_d) ops = 0;
-  lf_cell_apply_pk(C, ops, L2);
-  // which halves exist in the plane, and which are this group's to store
-  const bool lo_ok = active && k >= 1 && !seam_l, hi_ok = active && k <= nh - 1 && !seam_r;
-  const bool up_ok = mm >= 1 && !seam_u, dn_ok = mm <= nv - 1 && !seam_d;
-  uint8_t *base = plane + (ptrdiff_t)(8 * mm - 4) * stride + (8 * k - 4);
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    uint8_t *p = base + (ptrdiff_t)r * stride;
-    if (r < 4 ? up_ok : dn_ok) {
-      if (lo_ok & hi_ok) {
-        Pix8 o;
-        o.x = C.lo[r];
-        o.y = C.hi[r];
-        *reinterpret_cast<Pix8 *>(p) = o;
-      } else if (lo_ok) {
-        *reinterpret_cast<uint32_t *>(p) = C.lo[r];
-      } else if (hi_ok) {
-        *reinterpret_cast<uint32_t *>(p + 4) = C.hi[r];
-      }
-    }
-  }
-}
-
-#ifndef THIP_ST_WAVES_PER_EU
-#define THIP_ST_WAVES_PER_EU 4   // two groups of eight waves per CU (LDS): four waves per SIMD, 128 VGPRs
-#endif
-__global__ __launch_bounds__(64 * kStWaves, THIP_ST_WAVES_PER_EU) void k_recon_st(const BatchK B) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_st[];
-  const StreamK &S = B.s[blockIdx.y];
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int lane = (int)threadIdx.x & 63;
-  const int wg = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, see k_recon
-  const uint2 *info_p = S.info;
-  const int4 *coeffs_p = S.coeffs;
-  const uint32_t *slot0_p = S.tile_slot0;
-  uint8_t *self = S.self;
-  const uint8_t *prev = S.prev, *gold = S.gold;
-  uint8_t *coded_map = S.coded_map;
-  const int16_t *dc_p = S.dc;
-  const int se0 = S.st_end[0], se1 = S.st_end[1], se2 = S.st_end[2], te0 = S.tile_end[0], te1 = S.tile_end[1];
-  const int sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
-  uint8_t *edge_p = S.edge;
-  const uint32_t epoch = S.epoch;
-  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map), "s"(dc_p),
-               "s"(se0), "s"(se1), "s"(se2), "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2), "s"(edge_p), "s"(epoch));
-  if (wg >= se2) return;                                  // (the whole group)
-  const int pli = (wg >= se0 ? 1 : 0) + (wg >= se1 ? 1 : 0);
-  const PlaneK G = S.pl[pli];
-  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
-  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.tiles_y), "s"(G.fro), "s"(G.st_x),
-               "s"(fy0), "s"(fy1));
-  const int rel = wg - (pli == 0 ? 0 : (pli == 1 ? se0 : se1));
-  const int sty = rel / G.st_x, stx = rel - sty * G.st_x;
-  const int X0 = stx * kStBx, Y0 = sty * kStBy;
-  const int tile_base = pli == 0 ? 0 : (pli == 1 ? te0 : te1);
-  const int nh = G.nh, nv = G.nv;
-  // The left neighbour in the plane is group wg-1: same XCD band -- same L2, dispatched before this one -- unless
-  // this group opens its band.  Inside a band the left edge comes over through the edge records and the cells
-  // on the boundary are closed by the group on their right; at the start of a band they stay seam cells.
-  const int jb = (int)blockIdx.x >> 3, nband = (int)gridDim.x >> 3;
-  const bool consume = stx > 0 && jb > 0;
-  const bool publish = stx < G.st_x - 1 && jb < nband - 1;   // ... and the right neighbour consumes
-  ReconPlane R;
-  R.self = self + G.off;
-  R.prev = prev + G.off;
-  R.gold = gold + G.off;
-  R.coded_map = coded_map + G.fro;
-  R.nh = nh;
-  R.nv = nv;
-  R.stride = G.stride;
-  R.qpx = pli != 0 && sqpx;
-  R.qpy = pli != 0 && sqpy;
-  R.debug = 0;
-  R.tr = nullptr;
-  uint8_t *const mine = s_st + wave * kStWaveLds;
-  uint4 *const lds_wave = reinterpret_cast<uint4 *>(mine);
-  uint32_t *const lds_dw = reinterpret_cast<uint32_t *>(mine);
-  uint32_t *const meta = reinterpret_cast<uint32_t *>(mine + kStMetaOff);
-
-  // ---- 1. this lane's block, its command word, the tile's first slot -------------------------------
-  const int hh = lane & 15;
-  const int lx = (lane >> 4) * 4 + hilb_col(hh), ly = hilb_row(hh);
-  const int tx = kStW * stx + (wave % kStW), ty = kStH * sty + (wave / kStW);
-  const bool exists = tx < G.tiles_x && ty < G.tiles_y;
-  const int lxs = (wave % kStW) * 16 + lx, lys = (wave / kStW) * 4 + ly;
-  const int bx = X0 + lxs, by = Y0 + lys;
-  const bool valid = exists && bx < nh && by < nv;
-  uint2 info = make_uint2(0u, 0u);
-  uint32_t slot0 = 0;
-  if (exists) {
-    const int u = tile_base + ty * G.tiles_x + tx;
-    slot0 = slot0_p[u];
-    info = info_p[(size_t)u * THIP_TILE_FRAGS + lane];
-  }
-  uint32_t dcv = 0;   // the block's un-predicted DC when it does not travel in the command stream
-  if (dc_p) dcv = 0x10000u | (uint16_t)dc_p[G.fro + min(by, nv - 1) * nh + min(bx, nh - 1)];
-  asm volatile("" ::"s"(slot0), "v"(info.x), "v"(dcv));
-  ReconLane L;
-  L.flags = valid ? info.x : 0u;
-  L.dcq = info.y >> 16;
-  L.dcraw = dcv;
-  L.dcp = ((uint32_t)(((int)(int16_t)((dcv ? dcv : info.y) & 0xFFFFu) * (int)L.dcq + 15) >> 5) & 0xFFFFu) * 0x00010001u;
-  L.coded = (L.flags & THIP_INFO_CODED) != 0;
-  L.dc_only = L.coded && (L.flags & THIP_INFO_DC_ONLY) != 0;
-  L.has_coeff = L.coded && !L.dc_only;
-  L.x0 = bx * 8;
-  L.y0 = by * 8;
-
-  // ---- 2. coefficients + predictor: k_recon's second round trip -----------------------------------
-  const uint64_t mask = __ballot(L.has_coeff);
-  const int nown = __popcll(mask);
-  const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-  PredWin Q;
-  Q.border = false;
-  bool inter = false;
-  const uint8_t *ref = nullptr;
-  const uint32_t fill = L.dc_only ? L.dcp : 0u;   // DC-only: the rounded value (state.c:972); uncoded: zero residual
-  uint32_t Y[32];
-  if (nown == 0) {
-    if (valid) recon_issue(R, L, Q, inter, ref);
-  } else if (nown <= 16) {
-    int4 Wc[1][2];
-    residual_shared_load<4>(coeffs_p, slot0, nown, lane, Wc);
-    if (valid) recon_issue(R, L, Q, inter, ref);
-    residual_shared<4>(Wc, lds_dw, meta, lane, L, prefix, Y);
-  } else if (nown <= 32) {
-    int4 Wc[2][2];
-    residual_shared_load<2>(coeffs_p, slot0, nown, lane, Wc);
-    if (valid) recon_issue(R, L, Q, inter, ref);
-    residual_shared<2>(Wc, lds_dw, meta, lane, L, prefix, Y);
-  } else {
-    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
-    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
-                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, 0);
-    if (valid) recon_issue(R, L, Q, inter, ref);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)
-    residual_per_lane(lds_wave + lane, L, Y);
-  }
-  if (!L.has_coeff) {
-#pragma unroll
-    for (int i = 0; i < 32; i++) Y[i] = fill;
-  }
-  uint2 rows[8];
-  recon_rows(R, Q, inter, Y, rows);
-
-  // ---- 3. the block into the LDS image, its coded flag -------------------------------------------
-  lds_settle();                                   // every lane is done with the staging area
-  if (valid) {
-    uint8_t *img = mine + (ly * 8) * kStPitch + lx * 8;
-#pragma unroll
-    for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(img + r * kStPitch) = rows[r];
-  }
-  s_st[kStFlagOff + (lys + 1) * kStFlagPitch + lxs + 1] = (valid && L.coded) ? 1 : 0;
-  uint8_t *const myrec = edge_p + (size_t)wg * kStEdgeRec;
-  if (publish && lxs == kStBx - 1) {              // the last block column: its right halves, straight from the registers
-    unsigned long long *e = reinterpret_cast<unsigned long long *>(myrec) + lys * 8;
-    const unsigned long long tag = (unsigned long long)(2u * epoch + ((valid && L.coded) ? 1u : 0u)) << 32;
-#pragma unroll
-    // (plain stores: they stop in the L2 the neighbour reads from; a device-scope store goes through to memory, 8 bytes
-    //  at a time -- 200 k DRAM accesses per launch, measured +14 us)
-    for (int r = 0; r < 8; r++) __hip_atomic_store(e + r, tag | rows[r].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  // The left neighbour's record -- it runs in step with this group, so its pairs arrive about now: wave kStWaves-2 asks
-  // for them BEFORE the barrier, filters its own cells like the others, and then, as a second pass, the group's first
-  // cell column (0, 0..kStBy), by which time the pairs are there (it looks again until they are).
-  const bool edge_wave = consume && wave == kStWaves - 2;
-  const uint8_t *lrec = myrec - kStEdgeRec;
-  StEdge E;
-#pragma unroll
-  for (int r = 0; r < 4; r++) E.up[r] = E.dn[r] = 0;
-  E.fa = E.fc = false;
-  bool have_edge = true;
-  if (edge_wave) have_edge = st_edge_load(E, lrec, min(lane, kStBy), epoch) || lane > kStBy;
-  // (LDS only: the barrier must not wait for the loads and stores just issued)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-
-  // ---- 4. the cells ---------------------------------------------------------------------------------
-  {
-    const int clx = (wave % kStW) * 16 + (lane & 15);
-    st_cell(s_st, R.self, R.stride, nh, nv, X0, Y0, clx, (wave / kStW) * 4 + (lane >> 4), !(consume && clx == 0), L2, fy0, fy1, false, E);
-  }
-  if (edge_wave) {
-    // (bounded: groups are dispatched in order, so the left neighbour is resident or done; if that ever fails,
-    //  a wrong picture is a failed test, a hang is a dead GPU)
-    for (int spins = 0; spins < (1 << 20) && __any(!have_edge); spins++) {
-      if (spins) __builtin_amdgcn_s_sleep(2);
-      if (!have_edge) have_edge = st_edge_load(E, lrec, min(lane, kStBy), epoch);
-    }
-    st_cell(s_st, R.self, R.stride, nh, nv, X0, Y0, 0, min(lane, kStBy), lane <= kStBy, L2, fy0, fy1, true, E);
-  }
-  // The cells on the group's right and bottom boundary: the neighbour group's (this group's halves are stored as
-  // they are) or, when the plane ends exactly where the super tile does, the plane's border cells.
-  // (when the right neighbour closes the cells of the shared boundary, the column is all its)
-  if (wave == kStWaves - 1) {
-    const bool col = lane <= kStBy;
-    const int cx = col ? kStBx : lane - (kStBy + 1), cy = col ? lane : kStBy;
-    st_cell(s_st, R.self, R.stride, nh, nv, X0, Y0, cx, cy, lane < kStBy + 1 + kStBx && !(col && publish) && !(consume && cx == 0), L2, fy0,
-            fy1, false, E);
-  }
-}
-
-// The seam cells k_recon_st leaves: per plane the rows m = kStBy, 2*kStBy, ... (every column 0..nh); then, one
-// wave each, the first cell column of the group that opens XCD band 1..7 (st_nband groups per band) when that
-// group has a left neighbour in its plane -- the rows of it that are not among the seam rows.  Filtered in place.
-__global__ __launch_bounds__(256) void k_lf_st_seams(const BatchK B) {
-  const StreamK &S = B.s[blockIdx.y];
-  const int lane = (int)threadIdx.x & 63;
-  const int wgb = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // XCD bands, like k_recon_st
-  const int wbase = __builtin_amdgcn_readfirstlane(wgb * 256 + (int)(threadIdx.x & ~63u));
-  uint8_t *self = S.self;
-  const uint8_t *cmap = S.coded_map;
-  const int ce0 = S.ss_end[0], ce1 = S.ss_end[1], ce2 = S.ss_end[2], L2 = S.flimit2;
-  const int se0 = S.st_end[0], se1 = S.st_end[1], se2 = S.st_end[2], nband = S.st_nband;
-  asm volatile("" ::"s"(self), "s"(cmap), "s"(ce0), "s"(ce1), "s"(ce2), "s"(L2), "s"(se0), "s"(se1), "s"(se2), "s"(nband));
-  if (L2 == 0) return;
-  int pli, wg = 0;
-  if (wbase < ce2) {
-    pli = (wbase >= ce0 ? 1 : 0) + (wbase >= ce1 ? 1 : 0);
-  } else {
-    const int band = (wbase - ce2) / 64 + 1;
-    wg = band * nband;
-    if (band > 7 || wg >= se2) return;
-    pli = (wg >= se0 ? 1 : 0) + (wg >= se1 ? 1 : 0);
-  }
-  const PlaneK G = S.pl[pli];
-  const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
-  asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.fro), "s"(G.rcp_cx), "s"(G.st_x), "s"(G.st_y), "s"(fy0),
-               "s"(fy1));
-  const int nh = G.nh, nv = G.nv;
-  int k, m;
-  if (wbase < ce2) {
-    const int rel = wbase - (pli == 0 ? 0 : (pli == 1 ? ce0 : ce1)) + lane;
-    if (rel >= (G.st_y - 1) * (nh + 1)) return;
-    uint32_t mu, ku;
-    divmod_u24((uint32_t)rel, (uint32_t)(nh + 1), G.rcp_cx, mu, ku);
-    k = (int)ku;
-    m = ((int)mu + 1) * kStBy;
-  } else {
-    const int rel = wg - (pli == 0 ? 0 : (pli == 1 ? se0 : se1));
-    const int sty = rel / G.st_x, stx = rel - sty * G.st_x;
-    if (stx == 0) return;                             // the band opens with a row of the plane: no left neighbour
-    k = stx * kStBx;
-    m = sty * kStBy + lane;                           // the group's cells (0, 0..kStBy-1), and (0, kStBy) when the plane ends there
-    const bool seam_row = m % kStBy == 0 && m > 0 && m < nv;
-    if (lane > kStBy || m > nv || seam_row || (lane == kStBy && m != nv)) return;
-  }
-  CellPix C;
-  lf_cell_load(C, self + G.off, G.stride, nh, nv, k, m);
-  bool a, b, c, d;
-  lf_cell_flags(cmap + G.fro, nh, nv, k, m, a, b, c, d);
-  const uint32_t t = lf_cell_ops(k, m, nh, nv, a, b, c, d, fy0, fy1);
-  lf_cell_pin(C);
-  lf_cell_finish(C, self + G.off, G.stride, nh, nv, k, m, t, L2);
-}
 
 // ---------------------------------------------------------------------------------------
 // k_dc_unpredict: oc_dec_dc_unpredict_mcu_plane (decode.c:1392-1500) on the device
@@ -1545,6 +788,8 @@ struct DcPlaneK {
   const uint8_t *flags;     // raster flags (bit 0 coded, bits 1-2 refi) -- or null:
   const uint32_t *info;     // ... the stream's tile-ordered command words (word 0 of each pair)
   int nh, nv, tiles_x, tile_base;
+  uint4 *ent;               // k_dc_prepare -> k_dc_wave: 16 bytes per fragment (thip_dc.h)
+  uint8_t *rowhas;          // ... and per fragment row which references it has (bit r)
 };
 struct DcBatchK {
   DcPlaneK p[THIP_MAX_BATCH][3];
@@ -1657,147 +902,6 @@ __global__ __launch_bounds__(kDcMaxRows) void k_dc_unpredict(const DcBatchK B) {
     if (active) s_prog[cur ^ 1][y] = x;
     __syncthreads();   // stores of this step are complete and the progress is published before anyone reads either
   }
-}
-
-// The same wavefront with the plane in LDS -- the fragments' flags and DC values, 3 bytes each, planes up to
-// kDcLdsMaxFrags fragments (beyond 1080p luma) -- and with pred_last resolved exactly: which fragment is "the last
-// one with this reference frame in raster order" follows from the flags alone (per row the last x of every
-// reference, per row the nearest row at or above it that has one: two small tables built before the walk), so a
-// fragment without a usable neighbour waits for THAT fragment, not for the whole row above.  A step is then a handful
-// of LDS reads and a barrier instead of dependent trips to L2, and mixed-reference frames keep their wavefront:
-// 720p luma 0.44 -> 0.07 ms on a key frame, 12 -> 0.2 ms with random references (tools/dc_wavefront_time.py).
-constexpr int kDcLdsMaxFrags = 45056;
-__global__ __launch_bounds__(kDcMaxRows) void k_dc_unpredict_lds(const DcBatchK B) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_dcl[];
-  const DcPlaneK &P = B.p[blockIdx.y][blockIdx.x];
-  const int nh = P.nh, nv = P.nv;
-  if (nh <= 0 || nv <= 0) return;
-  const int n = nh * nv;
-  int16_t *dcv = reinterpret_cast<int16_t *>(s_dcl);          // token value, then the final DC (in place)
-  uint8_t *flg = s_dcl + 2 * ((n + 7) & ~7);                   // coded | refi << 1, 0 = does not count
-  __shared__ int s_prog[2][kDcMaxRows];
-  __shared__ short s_lastx[kDcMaxRows][4];                     // x of the row's last fragment with each reference, -1
-  __shared__ short s_srcrow[kDcMaxRows][4];                    // nearest row <= y that has one, -1
-  const int y = (int)threadIdx.x, T = (int)blockDim.x;
-  const bool active = y < nv;
-  for (int i = y; i < n; i += T) {
-    const int fy = i / nh, fx = i - fy * nh;
-    flg[i] = (uint8_t)dc_flag(P, fx, fy);
-    dcv[i] = P.in[i];
-  }
-  s_prog[0][y] = active ? 0 : nh;
-  s_prog[1][y] = active ? 0 : nh;
-  __syncthreads();
-  if (active) {
-    int l0 = -1, l1 = -1, l2 = -1;
-    for (int x = 0; x < nh; x++) {
-      const uint32_t f = flg[y * nh + x];
-      if (f & 1u) {
-        const int r = (int)(f >> 1);
-        if (r == 0) l0 = x;
-        else if (r == 1) l1 = x;
-        else l2 = x;
-      }
-    }
-    s_lastx[y][0] = (short)l0;
-    s_lastx[y][1] = (short)l1;
-    s_lastx[y][2] = (short)l2;
-  }
-  __syncthreads();
-  if (y < 3) {
-    int cur = -1;
-    for (int yy = 0; yy < nv; yy++) {
-      if (s_lastx[yy][y] >= 0) cur = yy;
-      s_srcrow[yy][y] = (short)cur;
-    }
-  }
-  __syncthreads();
-  int x = 0;
-  uint32_t f_l = 0, f_ul = 0, f_u = 0, f_ur = 0;
-  int d_l = 0, d_ul = 0, d_u = 0, d_ur = 0;
-  int pl0 = 0, pl1 = 0, pl2 = 0;
-  uint32_t plv = 0;
-  const int up = (y > 0 ? y - 1 : 0) * nh, own = (active ? y : 0) * nh;
-  const long long max_steps = (long long)nh * nv + 2 * nv + 8;
-  for (long long step = 0; step < max_steps; step++) {
-    const int cur = (int)(step & 1);
-    if (s_prog[cur][nv - 1] >= nh) break;
-    int xn = x;
-    if (active && x < nh) {
-      const int above = y > 0 ? s_prog[cur][y - 1] : nh;
-      if (above >= min(x + 2, nh)) {
-        if (y > 0) {
-          if (x == 0) {
-            f_u = flg[up];
-            d_u = dcv[up];
-          }
-          if (x + 1 < nh) {
-            f_ur = flg[up + x + 1];
-            d_ur = dcv[up + x + 1];
-          } else {
-            f_ur = 0;
-          }
-        }
-        const uint32_t f = flg[own + x];
-        bool done = true;
-        int dc = 0;
-        if (f & 1u) {
-          const int r = (int)(f >> 1);
-          const int mask = (f_l == f ? 1 : 0) | (f_ul == f ? 2 : 0) | (f_u == f ? 4 : 0) | (f_ur == f ? 8 : 0);
-          int pred = 0;
-          switch (mask) {                                       // decode.c:1450-1485
-            case 0:
-              if (plv >> r & 1u) pred = r == 0 ? pl0 : (r == 1 ? pl1 : pl2);
-              else if (y > 0) {                                 // (y == 0: pred_last starts at 0, decode.c:1367)
-                const int ys = s_srcrow[y - 1][r];
-                if (ys >= 0) {
-                  const int xs = s_lastx[ys][r];
-                  if (s_prog[cur][ys] > xs) pred = dcv[ys * nh + xs];
-                  else done = false;                            // that fragment is not final yet
-                }
-              }
-              break;
-            case 1: case 3: pred = d_l; break;
-            case 2: pred = d_ul; break;
-            case 4: case 6: case 12: pred = d_u; break;
-            case 5: pred = (d_l + d_u) / 2; break;
-            case 8: pred = d_ur; break;
-            case 9: case 11: case 13: pred = (75 * d_l + 53 * d_ur) / 128; break;
-            case 10: pred = (d_ul + d_ur) / 2; break;
-            case 14: pred = (3 * (d_ul + d_ur) + 10 * d_u) / 16; break;
-            default:   // 7, 15
-              pred = (29 * (d_l + d_u) - 26 * d_ul) / 32;
-              if (abs(pred - d_u) > 128) pred = d_u;
-              else if (abs(pred - d_l) > 128) pred = d_l;
-              else if (abs(pred - d_ul) > 128) pred = d_ul;
-              break;
-          }
-          if (done) {
-            dc = (int)(short)(dcv[own + x] + pred);   // a signed 16-bit bit-field in the reference (state.h:321)
-            dcv[own + x] = (int16_t)dc;
-            if (r == 0) pl0 = dc;
-            else if (r == 1) pl1 = dc;
-            else pl2 = dc;
-            plv |= 1u << r;
-          }
-        }
-        if (done) {
-          f_l = f;
-          d_l = dc;
-          f_ul = f_u;
-          d_ul = d_u;
-          f_u = f_ur;
-          d_u = d_ur;
-          xn = x + 1;
-        }
-      }
-    }
-    x = xn;
-    if (active) s_prog[cur ^ 1][y] = x;
-    __syncthreads();
-  }
-  __syncthreads();
-  for (int i = y; i < n; i += T) P.out[i] = dcv[i];
 }
 
 // ---------------------------------------------------------------------------------------
