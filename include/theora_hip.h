@@ -247,8 +247,8 @@ int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const
    coded: the coded fragments in coded order, plane after plane (ncoded per plane); frag_meta per coded fragment:
    refi | dequantisation table << 2 | (mvx & 255) << 8 | (mvy & 255) << 16 | plane << 24, table = (plane * 3 + qii)
    * 2 + qti into dequant[18][64] (zig-zag order, decode.c:1537-1538).  dc_quant[plane][qti] as the slot's _dc_quant.
-   Returns 0, THIP_DUPFRAME (nothing coded), or THIP_EIMPL when a plane has more than 49152 coded fragments or more
-   than 1024 fragment rows (the caller falls back to the slots); all pointers are host memory, read before return. */
+   Returns 0, THIP_DUPFRAME (nothing coded), or THIP_EIMPL when a plane has more than 147456 coded fragments (beyond 4K) or
+   more than 1024 fragment rows (the caller falls back to the slots); all pointers are host memory, read before return. */
 typedef struct thip_token_lists {
   int32_t frame_type;          /* THIP_INTRA_FRAME / THIP_INTER_FRAME */
   int32_t flimit;              /* loop_filter_limits[qis[0]] */

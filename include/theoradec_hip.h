@@ -145,8 +145,8 @@ typedef struct {
 /* Extension: buf = int.  Non-zero: th_decode_packetin stops behind the entropy decoder -- the frame's token lists
    (one per plane and zig-zag index, decode.c:993-1139), the coded-fragment list and one word per fragment go to the
    GPU, which finds each fragment's tokens, expands and dequantises them, un-predicts the DC values and decodes
-   the frame (thip_state_decode_token_lists).  Frames with a plane of more than 49152 coded fragments (beyond
-   1080p) keep the host path.  THIP_FE_DEVICE_LISTS=1 sets it for every new context. */
+   the frame (thip_state_decode_token_lists).  Frames with a plane of more than 147456 coded fragments (beyond
+   4K) keep the host path.  THIP_FE_DEVICE_LISTS=1 sets it for every new context. */
 #define TH_DECCTL_THIP_SET_DEVICE_LISTS (0x7104)
 typedef struct thip_slot_trace {
   int64_t ncoded;           /* state_frag_recon calls, in call (= coded) order */

@@ -92,8 +92,8 @@ def test_packets_decode_bit_exact_720p(hip):
 def test_packets_decode_bit_exact_4k(hip, mode):
     """BASELINE.json's 4K size (3840x2160 4:2:0, 194 400 fragments) through th_decode_*: a key frame and two inter frames with
     matched Huffman trees, by the host front end, with the DC un-prediction on the GPU (k_dc_wave: 480 x 270 luma fragments, the
-    64 rows in flight in LDS), and with TH_DECCTL_THIP_SET_DEVICE_LISTS asked for -- whose token assignment holds planes of up
-    to 49 152 coded fragments, so that the key frame (129 600 in luma) takes the documented fallback to the host walk."""
+    64 rows in flight in LDS), and with TH_DECCTL_THIP_SET_DEVICE_LISTS: the token lists themselves on the GPU, the key frame's luma
+    plane (129 600 coded fragments) with k_tok_assign's rank -> fragment map in memory instead of LDS."""
     assert run_stream(hip, 3840, 2160, 0, seed=2160, nframes=3, kf=3, trees="matched", device_dc=(mode == "device_dc"),
                       device_lists=(mode == "device_lists")) == 3
 

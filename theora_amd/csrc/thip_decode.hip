@@ -196,6 +196,7 @@ struct thip_state {
   int16_t *d_tl_tmp;        // [nfrags][64]
   uint8_t *d_tl_last;       // [nfrags]
   uint32_t *d_tl_slot;      // [nfrags]
+  uint32_t *d_tl_arr;       // [nfrags] k_tok_assign's rank -> fragment map for planes beyond its LDS
   int32_t *d_frag_pos;      // [nfrags], uploaded once
   // out-of-loop post-processing (thip_state_postprocess): the post-processed picture, the per-fragment
   // variances and quantiser indices, which planes of which decoded frame the picture holds
@@ -534,6 +535,7 @@ void thip_state_free(thip_state *st) {
   if (st->d_tl_tmp) (void)hipFree(st->d_tl_tmp);
   if (st->d_tl_last) (void)hipFree(st->d_tl_last);
   if (st->d_tl_slot) (void)hipFree(st->d_tl_slot);
+  if (st->d_tl_arr) (void)hipFree(st->d_tl_arr);
   if (st->d_frag_pos) (void)hipFree(st->d_frag_pos);
   if (st->pp_frame) (void)hipFree(st->pp_frame);
   if (st->pp_var) (void)hipFree(st->pp_var);
@@ -1573,6 +1575,7 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
       if (!st->d_tl_tmp) HIP_TRY(hipMalloc((void **)&st->d_tl_tmp, (size_t)st->nfrags * 128));
       if (!st->d_tl_last) HIP_TRY(hipMalloc((void **)&st->d_tl_last, nf));
       if (!st->d_tl_slot) HIP_TRY(hipMalloc((void **)&st->d_tl_slot, nf * 4));
+      if (!st->d_tl_arr) HIP_TRY(hipMalloc((void **)&st->d_tl_arr, nf * 4));
       if (!st->d_frag_pos) HIP_TRY(hipMalloc((void **)&st->d_frag_pos, nf * 4));
       HIP_TRY(hipMemcpy(st->d_frag_pos, st->frag_pos, (size_t)st->nfrags * 4, hipMemcpyHostToDevice));
       st->tl_ready = 1;
@@ -1617,6 +1620,7 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
     K.tmp = st->d_tl_tmp;
     K.last_zzi = st->d_tl_last;
     K.slot = st->d_tl_slot;
+    K.arr = st->d_tl_arr;
     K.dc_in = st->d_dc_in;
     K.info = st->d_info;
     K.slot0 = st->d_slot0;
@@ -1629,9 +1633,15 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
       c0 += tl->ncoded[p];
       nmax = std::max(nmax, (int)tl->ncoded[p]);
     }
-    const int lds = ((nmax + 15) & ~15) + 2 * nmax + 16;
-    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign), ((kTlMaxFrags + 15) & ~15) + 2 * kTlMaxFrags + 16, 2));
-    hipLaunchKernelGGL(k_tok_assign, dim3(3), dim3(1024), (size_t)lds, s, K);
+    if (nmax <= kTlLdsFrags) {
+      const int lds = ((nmax + 15) & ~15) + 2 * nmax + 16;
+      HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<false>), ((kTlLdsFrags + 15) & ~15) + 2 * kTlLdsFrags + 16, 2));
+      hipLaunchKernelGGL(k_tok_assign<false>, dim3(3), dim3(1024), (size_t)lds, s, K);
+    } else {   // (4K luma: the rank -> fragment map in memory, the positions alone in LDS)
+      const int lds = ((nmax + 15) & ~15) + 16;
+      HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<true>), kTlMaxFrags + 32, 1));
+      hipLaunchKernelGGL(k_tok_assign<true>, dim3(3), dim3(1024), (size_t)lds, s, K);
+    }
     hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
     hipLaunchKernelGGL(k_tok_write, dim3((unsigned)(((size_t)ncoded * 8 + 255) / 256)), dim3(256), 0, s, K);
     HIP_TRY(hipGetLastError());

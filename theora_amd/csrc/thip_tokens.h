@@ -49,6 +49,7 @@ struct TlK {
   int16_t *dc_in;           // [nfrags] DC token values, fragment order (zeroed)
   uint32_t *info;           // command words (zeroed)
   uint32_t *slot0;          // first slot of every tile (zeroed)
+  uint32_t *arr;            // [ncoded] scratch: rank -> fragment map of planes too large to keep it in LDS
   int4 *coeffs;             // coefficient slots, tile layout
   int ncoded;
   TlPlaneK p[3];
@@ -85,7 +86,11 @@ __device__ __forceinline__ int tl_nat(int zzi) {   // natural-order position of 
 
 // One work group per plane.  LDS: pos[n] bytes (the index a fragment arrives at next; 64 + z = finished, the
 // last index it arrived at was z), arr[n] 16-bit (rank among this index's arrivals -> fragment), 16 dwords.
-constexpr int kTlMaxFrags = 49152;   // per plane: 3 bytes of LDS per fragment
+// BIG: planes of more than kTlLdsFrags coded fragments (4K luma: 129 600) keep the rank -> fragment map in memory instead
+// (K.arr, 32-bit entries, read back past the L1 after the work-group barrier): one byte of LDS per fragment.
+constexpr int kTlLdsFrags = 49152;   // per plane with the map in LDS: 3 bytes of LDS per fragment
+constexpr int kTlMaxFrags = 147456;  // per plane at all: 1 byte of LDS per fragment
+template <bool BIG>
 __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_tl[];
   __shared__ uint16_t s_dq[18 * 64];
@@ -94,6 +99,7 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
   if (n == 0) return;
   uint8_t *pos = s_tl;
   uint16_t *arr = reinterpret_cast<uint16_t *>(s_tl + ((n + 15) & ~15));
+  uint32_t *garr = K.arr + c0;
   const int t = (int)threadIdx.x, T = (int)blockDim.x;
   for (int i = t; i < 18 * 64; i += T) s_dq[i] = K.dq[i];
   const int Kf = (n + T - 1) / T;
@@ -109,7 +115,10 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
     uint32_t narr;
     uint32_t r = tl_exscan(cnt, s_scr, narr);
     for (int i = f0; i < f1; i++)
-      if (pos[i] == z) arr[r++] = (uint16_t)i;
+      if (pos[i] == z) {
+        if (BIG) garr[r++] = (uint32_t)i;
+        else arr[r++] = (uint16_t)i;
+      }
     // ---- what the tokens of the list consume ----------------------------------------------------------
     const uint32_t off = hdr[THIP_TL_OFF + z], m = hdr[THIP_TL_LEN + z], carry = hdr[THIP_TL_CARRY + z];
     const uint32_t Kt = (m + (uint32_t)T - 1u) / (uint32_t)T;
@@ -120,6 +129,7 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
       use += (tk & THIP_TOK_EOB) ? ((tk & 0xFFFFu) | (tk >> 24) << 16) : 1u;
     }
     uint32_t dummy;
+    if (BIG) __threadfence_block();                      // the map's stores are done before the barriers below let anyone read it
     uint32_t S = carry + tl_exscan(use, s_scr, dummy);   // (its barriers also publish arr)
     // ---- every token that is not an EOB token serves the arrival of rank S ------------------------------
     for (uint32_t j = j0; j < j1; j++) {
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
         continue;
       }
       if (S < narr) {   // (a list longer than its arrivals: a malformed stream; the surplus is ignored)
-        const int i = arr[S];
+        const int i = BIG ? (int)__hip_atomic_load(garr + S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (int)arr[S];
         const int skip = (int)((tk >> 16) & 127u);
         const int value = (int)(int16_t)(tk & 0xFFFFu);
         const int at = z + skip;
