@@ -191,7 +191,10 @@ typedef struct thip_frame_desc {
    results[i] (optional, host) receives 0 or THIP_DUPFRAME per stream. */
 int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, int nstreams,
                        void *stream, int32_t *results);
-/* Wait for everything submitted on the library's own stream. */
+/* Wait for everything submitted on the library's own streams.  Returns THIP_EFAULT (once) if a kernel reported that one of
+   its bounded waits ran out since the last call -- k_recon_lf hands tile edges between concurrently running work groups
+   and relies on their being dispatched in order; a wait that gives up leaves a wrong picture, and this is how the caller
+   learns of it (thip_state_ycbcr_map / _out and thip_state_read_plane report it too).  It has never been observed. */
 int thip_synchronize(void);
 
 /* ------------------------------------------------------------------------------------

@@ -4,6 +4,11 @@
  * PARITY UNPINNED: not validated against a reference binary (the reference does not
  * build in this image: <ogg/ogg.h> is missing) and the reference ships no golden
  * vectors for this path.  Each function cites the reference lines it restates.
+ * The inverse DCT, reconstruction, motion-vector, loop-filter and encoder parts are restructured
+ * restatements; the out-of-loop post-processing part (orc_pp_*, near the end) follows
+ * decode.c:1610-1957 statement by statement on purpose -- that filter is non-normative, has no
+ * specification text to restate it from, and the point of this file is to be the checker.  It is
+ * test infrastructure under oracle/: nothing in theora_amd/ or include/ uses it.
  */
 #include "theora_oracle.h"
 #include <stdlib.h>

@@ -160,6 +160,7 @@ struct thip_state {
   hipEvent_t ev_staging;     // recorded behind the kernels that read the staging buffers (enqueue path)
   hipEvent_t ev_order;       // orders a frame behind the previous one when the two go down different streams
   hipStream_t last_stream;   // stream of the most recent launch for this state (ycbcr_out copies on it)
+  int order_recorded;        // ev_order already marks the end of that launch (it went down a caller-owned stream)
   // Output to the host: k_frame_out writes the finished frame, top row first and tightly packed,
   // straight into one of two pinned images (the kernel's stores cross PCIe; no DMA call, no flip
   // on the host).  frame_serial counts finished frames, out_serial is the frame h_out[out_cur] holds.
@@ -203,6 +204,8 @@ struct thip_state {
   uint8_t *pp_frame;
   int *pp_var;
   uint8_t *pp_qis;          // device, 2 * nfrags: dc_qis, then frag_qi
+  uint8_t *h_pp_qis;        // pinned staging of the same
+  hipEvent_t ev_pp;         // recorded behind the copy out of h_pp_qis
   int64_t pp_serial;        // frame_serial of the frame pp_frame was made from, -1 if none
   int pp_active[3];
 };
@@ -240,6 +243,30 @@ struct DeviceGuard {
   }
 };
 int g_profile = 0;
+// One pinned host word per device that kernels set when a bounded wait ran out (k_recon_lf's hand-over).  Checked by the
+// calls that synchronise with the device; sticky until thip_synchronize reports it.
+uint32_t *g_fault[kMaxDevices];
+std::mutex g_fault_mu;
+uint32_t *fault_word(int device) {   // the device must be current
+  if (device < 0 || device >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lk(g_fault_mu);
+  if (!g_fault[device]) {
+    uint32_t *p = nullptr;
+    if (hipHostMalloc((void **)&p, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+    *p = 0;
+    g_fault[device] = p;
+  }
+  return g_fault[device];
+}
+int check_fault(int device) {
+  if (device < 0 || device >= kMaxDevices || !g_fault[device]) return THIP_OK;
+  if (*(volatile uint32_t *)g_fault[device]) {
+    fprintf(stderr, "theora_hip: a kernel's bounded wait for a neighbouring tile ran out on device %d: the frames decoded since the "
+                    "last synchronisation are not to be trusted (set option fuse = 0 to take the two-pass path)\n", device);
+    return THIP_EFAULT;
+  }
+  return THIP_OK;
+}
 struct EvPair { hipEvent_t a, b; int kernel; };
 std::vector<EvPair> g_events;
 std::vector<hipEvent_t> g_pool;
@@ -313,6 +340,56 @@ int context_stream(thip_state *st, hipStream_t *out) {
   }
   if (st->ctx_lane < 0) st->ctx_lane = g_next_ctx[st->device]++ % nctx;
   *out = g_ctx_lanes[st->device][st->ctx_lane];
+  return THIP_OK;
+}
+
+// Is `s` one of the library's own streams of this device (never destroyed)?  (lanes / context streams)
+bool is_library_stream(int device, hipStream_t s) {
+  if (device < 0 || device >= kMaxDevices) return false;
+  for (int i = 0; i < kMaxLanes; i++)
+    if (g_lanes[device][i] == s && s) return true;
+  for (int i = 0; i < kCtxLanes; i++)
+    if (g_ctx_lanes[device][i] == s && s) return true;
+  return false;
+}
+// A state whose previous frame went down another stream (frame calls and enqueue calls mixed, or a caller-owned stream):
+// everything queued on `s` from here on waits for that frame.  Called before the FIRST enqueue of a frame on `s`.  When the
+// previous stream was the caller's, the event was recorded right behind that frame's launch (order_mark): the stream may be
+// gone by now.
+int order_behind_previous(thip_state *st, hipStream_t s) {
+  if (!st->last_stream || st->last_stream == s) return THIP_OK;
+  if (!st->ev_order) HIP_TRY(hipEventCreateWithFlags(&st->ev_order, hipEventDisableTiming));
+  if (!st->order_recorded) HIP_TRY(hipEventRecord(st->ev_order, st->last_stream));
+  HIP_TRY(hipStreamWaitEvent(s, st->ev_order, 0));
+  return THIP_OK;
+}
+// A live stream for work that follows the state's last frame (output copy, post-processing): the stream that frame went
+// down if it is the library's, else the state's context stream, ordered behind the frame through ev_order.
+int followup_stream(thip_state *st, hipStream_t *out);
+
+// ... and behind a frame's launch on `s`: a caller-owned stream gets its event now (a library stream lives as long as the library).
+int order_mark(thip_state *st, hipStream_t s) {
+  st->last_stream = s;
+  st->order_recorded = 0;
+  if (!is_library_stream(st->device, s)) {
+    if (!st->ev_order) HIP_TRY(hipEventCreateWithFlags(&st->ev_order, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(st->ev_order, s));
+    st->order_recorded = 1;
+  }
+  return THIP_OK;
+}
+
+int followup_stream(thip_state *st, hipStream_t *out) {
+  if (st->last_stream && is_library_stream(st->device, st->last_stream)) {
+    *out = st->last_stream;
+    return THIP_OK;
+  }
+  hipStream_t s;
+  int rc = context_stream(st, &s);
+  if (rc) return rc;
+  rc = order_behind_previous(st, s);
+  if (rc) return rc;
+  *out = s;
   return THIP_OK;
 }
 
@@ -540,6 +617,8 @@ void thip_state_free(thip_state *st) {
   if (st->pp_frame) (void)hipFree(st->pp_frame);
   if (st->pp_var) (void)hipFree(st->pp_var);
   if (st->pp_qis) (void)hipFree(st->pp_qis);
+  if (st->h_pp_qis) (void)hipHostFree(st->h_pp_qis);
+  if (st->ev_pp) (void)hipEventDestroy(st->ev_pp);
   if (st->d_dc_in) (void)hipFree(st->d_dc_in);
   if (st->h_dc) (void)hipHostFree(st->h_dc);
   if (st->h_flags) (void)hipHostFree(st->h_flags);
@@ -606,7 +685,7 @@ int thip_state_read_plane(thip_state *st, int bufi, int pli, uint8_t *host_out) 
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy2D(host_out, g.width, st->frames[bufi] + g.plane_off, g.stride, g.width, g.height,
                       hipMemcpyDeviceToHost));
-  return THIP_OK;
+  return check_fault(st->device);
 }
 
 int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *host_in) {
@@ -705,10 +784,18 @@ int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strid
   if (st->last_decoded < 0) return THIP_EINVAL;
   DeviceGuard dg(st->device);
   if (st->out_serial != st->frame_serial) {   // not copied yet (no eager output, or the frame came from write_plane)
-    const int rc = launch_frame_out(st, st->last_stream);
+    hipStream_t fs;
+    int rc = followup_stream(st, &fs);
     if (rc < 0) return rc;
+    rc = launch_frame_out(st, fs);
+    if (rc < 0) return rc;
+    if (fs != st->last_stream) {
+      rc = order_mark(st, fs);
+      if (rc < 0) return rc;
+    }
   }
   if (wait_event(st->ev_out) < 0) return THIP_EFAULT;
+  if (check_fault(st->device) < 0) return THIP_EFAULT;
   int off = 0;
   for (int p = 0; p < 3; p++) {
     planes[p] = st->h_out[st->out_cur] + off;
@@ -735,14 +822,19 @@ int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t ds
 }
 
 int thip_synchronize(void) {
+  int rc = THIP_OK;
   for (int d = 0; d < kMaxDevices; d++) {
     if (!g_lanes_ready[d]) continue;
     DeviceGuard dg(d);
     for (int i = 0; i < g_nlanes; i++) HIP_TRY(hipStreamSynchronize(g_lanes[d][i]));
     for (int i = 0; i < kCtxLanes; i++)
       if (g_ctx_ready[d] && g_ctx_lanes[d][i]) HIP_TRY(hipStreamSynchronize(g_ctx_lanes[d][i]));
+    if (check_fault(d) < 0) {
+      rc = THIP_EFAULT;
+      *(volatile uint32_t *)g_fault[d] = 0;   // reported
+    }
   }
-  return THIP_OK;
+  return rc;
 }
 
 #ifdef THIP_TRACE
@@ -804,6 +896,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
                         int32_t *results) {
   BatchK B;
   memset(&B, 0, sizeof(B));
+  B.fault = fault_word(states[0] ? states[0]->device : -1);
   int max_wg = 0, max_seam_wg = 0, any_lf = 0, nlive = 0;
   int any_skip = 0;
   int live_state[THIP_MAX_BATCH];
@@ -817,10 +910,9 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     if (d.frame_type != THIP_INTRA_FRAME && d.frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
     if (d.frame_type == THIP_INTRA_FRAME && d.ncoded != st->nfrags) return THIP_EINVAL;
     // a state whose previous frame went down another stream (frame calls and enqueue calls mixed): this one waits for it
-    if (st->last_stream && st->last_stream != s) {
-      if (!st->ev_order) HIP_TRY(hipEventCreateWithFlags(&st->ev_order, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(st->ev_order, st->last_stream));
-      HIP_TRY(hipStreamWaitEvent(s, st->ev_order, 0));
+    {
+      const int orc = order_behind_previous(st, s);
+      if (orc < 0) return orc;
     }
     // decode.c:2757-2762: an inter frame without references decodes against mid-grey
     if (d.frame_type != THIP_INTRA_FRAME &&
@@ -829,6 +921,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       st->ref_idx[0] = st->ref_idx[1] = st->ref_idx[2] = 0;
       st->last_decoded = 0;
       st->last_stream = s;
+      st->order_recorded = 0;
       st->frame_serial++;
       st->buf_serial[0] = st->buf_serial[1] = st->buf_serial[2] = -1;
     }
@@ -983,12 +1076,13 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     if (descs[live_state[j]].frame_type == THIP_INTRA_FRAME) st->ref_idx[THIP_FRAME_GOLD] = self;
     st->ref_idx[THIP_FRAME_PREV] = self;
     st->last_decoded = self;
-    st->last_stream = s;
     st->frame_serial++;
     if (st->eager_out) {
       const int rc = launch_frame_out(st, s);
       if (rc < 0) return rc;
     }
+    const int orc = order_mark(st, s);   // (behind the frame's last launch on s)
+    if (orc < 0) return orc;
   }
   return THIP_OK;
 }
@@ -1133,9 +1227,20 @@ int thip_state_postprocess(thip_state *st, int level, const uint8_t *dc_qis, con
   if (!st->pp_frame) HIP_TRY(hipMalloc((void **)&st->pp_frame, st->frame_bytes + 256));
   if (!st->pp_var) HIP_TRY(hipMalloc((void **)&st->pp_var, sizeof(int) * (size_t)st->nfrags));
   if (!st->pp_qis) HIP_TRY(hipMalloc((void **)&st->pp_qis, 2 * (size_t)st->nfrags));
-  hipStream_t s = st->last_stream;
-  HIP_TRY(hipMemcpyAsync(st->pp_qis, dc_qis, (size_t)st->nfrags, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(st->pp_qis + st->nfrags, frag_qi, (size_t)st->nfrags, hipMemcpyHostToDevice, s));
+  hipStream_t s;
+  {
+    const int rc = followup_stream(st, &s);
+    if (rc < 0) return rc;
+  }
+  // The caller's arrays are pageable and rewritten by the next packet: they are staged through a pinned buffer of the state's
+  // (a copy from pageable memory makes the call a host synchronisation point), guarded by an event behind the copy.
+  if (!st->h_pp_qis) HIP_TRY(hipHostMalloc((void **)&st->h_pp_qis, 2 * (size_t)st->nfrags, hipHostMallocDefault));
+  if (!st->ev_pp) HIP_TRY(hipEventCreateWithFlags(&st->ev_pp, hipEventDisableTiming));
+  else if (wait_event(st->ev_pp) < 0) return THIP_EFAULT;   // the previous frame's copy has read the buffer
+  memcpy(st->h_pp_qis, dc_qis, (size_t)st->nfrags);
+  memcpy(st->h_pp_qis + st->nfrags, frag_qi, (size_t)st->nfrags);
+  HIP_TRY(hipMemcpyAsync(st->pp_qis, st->h_pp_qis, 2 * (size_t)st->nfrags, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipEventRecord(st->ev_pp, s));
   HIP_TRY(hipMemsetAsync(st->pp_var, 0, sizeof(int) * (size_t)st->nfrags, s));
   PpK K;
   memset(&K, 0, sizeof(K));
@@ -1184,6 +1289,10 @@ int thip_state_postprocess(thip_state *st, int level, const uint8_t *dc_qis, con
   HIP_TRY(hipGetLastError());
   st->pp_serial = st->frame_serial;
   st->out_serial = -1;       // the host image (if any) shows the frame before post-processing
+  if (s != st->last_stream) {   // (the frame went down a caller-owned stream: the next one waits for these kernels too)
+    const int rc = order_mark(st, s);
+    if (rc < 0) return rc;
+  }
   return THIP_OK;
 }
 
@@ -1457,6 +1566,8 @@ int thip_frame_flush(thip_state *st) {
   hipStream_t s;
   int rc = context_stream(st, &s);
   if (rc) return rc;
+  rc = order_behind_previous(st, s);   // before the first copy or kernel of this frame goes onto s
+  if (rc) return rc;
   const size_t ngroups = ((size_t)st->enq_nslots + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
   const int zerocopy = thip_option("zerocopy");
   if (st->enq_ncoded && !zerocopy) {
@@ -1557,6 +1668,8 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
   DeviceGuard dg(st->device);
   hipStream_t s;
   int rc = context_stream(st, &s);
+  if (rc) return rc;
+  rc = order_behind_previous(st, s);   // before the first copy or kernel of this frame goes onto s
   if (rc) return rc;
   rc = ensure_staging(st);
   if (rc) return rc;

@@ -146,7 +146,9 @@ __device__ __forceinline__ void tf_poll(TfPoll &P, const uint8_t *rec0, const ui
   P.rec = P.need ? rec : myrec;
   P.f = tf_load64(P.rec + kTfFlag);
 }
-__device__ __forceinline__ void tf_wait(const TfPoll &P, uint32_t ep, uint32_t w[4]) {
+// (fault: the device's pinned host word.  A wait that runs out -- it cannot, as long as work groups are dispatched in order --
+//  leaves a wrong picture behind; the word turns that into an error the next synchronising call of the ABI returns.)
+__device__ __forceinline__ void tf_wait(const TfPoll &P, uint32_t ep, uint32_t w[4], uint32_t *fault) {
   uint2 f = P.f;
   bool ok = !P.need || (f.x >> 20) == ep;
   for (int spins = 0; spins < (1 << 20) && !__all(ok); spins++) {
@@ -156,6 +158,7 @@ __device__ __forceinline__ void tf_wait(const TfPoll &P, uint32_t ep, uint32_t w
       ok = (f.x >> 20) == ep;
     }
   }
+  if (!__all(ok) && fault && !ok) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   w[0] = (uint32_t)__builtin_amdgcn_readlane((int)f.x, 0);
   w[1] = (uint32_t)__builtin_amdgcn_readlane((int)f.x, 1);
   w[2] = (uint32_t)__builtin_amdgcn_readlane((int)f.x, 2);
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   // ---- 4. the neighbours' edges into the image margins --------------------------------------------------
   {
     uint32_t w[4];
-    tf_wait(poll, ep, w);
+    tf_wait(poll, ep, w, B.fault);
     THIP_TR(tr, 5);   // the neighbours' records are there
     // lanes 0..31: the upper tile's rows 28..31, 16 bytes each; 32..39: the left tile's columns 124..127, four rows each;
     // 40: the upper-left tile's corner (rows 28..31 of its column record)
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
       uint32_t w[4];
       TfPoll pd;
       tf_poll(pd, rec_dn, rec_dl, rec_dl, true, has_left, false, lane, myrec);
-      tf_wait(pd, ep, w);
+      tf_wait(pd, ep, w, B.fault);
       const uint8_t *src = nullptr;
       if (lane < 32)
         src = rec_dn + kTfTop + lane * 16;          // the lower tile's rows 0..3

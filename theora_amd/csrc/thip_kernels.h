@@ -70,6 +70,7 @@ struct StreamK {
 
 struct BatchK {
   StreamK s[THIP_MAX_BATCH];
+  uint32_t *fault;   // pinned host word of the device: set by a kernel whose bounded wait ran out (k_recon_lf's hand-over)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -132,16 +133,18 @@ struct __attribute__((aligned(4))) Pix8 {
 // ---- the filter on the packed image: two pixels per register -------------------------------------
 // f = P2 - P5 + 3*(P4 - P3), R = (f+4)>>3, lflim(R), P3 += ., P4 -= . (state.c:1002-1031) in
 // 16-bit lanes: |f| <= 1020, every intermediate fits; the final clamp is v_sat_pk_u8_i16.
+// lflim without the detour over |R| and the sign: for R >= 0 it is max(min(R, 2L - R), 0) and the mirror image for R < 0, and
+// each of the two expressions is 0 on the other side, so lflim(R) = max(min(R, 2L - R), 0) + min(max(R, -2L - R), 0): seven
+// packed operations; 3 * (P4 - P3) + (P2 - P5) is one v_pk_mad_i16.
 __device__ __forceinline__ pk16 pk_lf_delta(pk16 p2, pk16 p3, pk16 p4, pk16 p5, int L2) {
-  const pk16 d = p4 - p3;
-  const pk16 f = p2 - p5 + d + d + d;
+  const pk16 three = {(short)3, (short)3};
+  const pk16 f = (p4 - p3) * three + (p2 - p5);
   const pk16 R = (f + (short)4) >> 3;
-  const pk16 a = __builtin_elementwise_max(R, -R);
   const pk16 l2 = {(short)L2, (short)L2};
   const pk16 z = {0, 0};
-  const pk16 m = __builtin_elementwise_min(a, __builtin_elementwise_max(l2 - a, z));
-  const pk16 s = R >> 15;                      // 0 or -1 per half
-  return as_pk(as_u32(m) ^ as_u32(s)) - s;     // R < 0 ? -m : m
+  const pk16 pos = __builtin_elementwise_max(__builtin_elementwise_min(R, l2 - R), z);
+  const pk16 neg = __builtin_elementwise_min(__builtin_elementwise_max(R, z - l2 - R), z);
+  return pos + neg;
 }
 // horizontal edge y = 4 of the cell, columns 0..3 (half 0: the lo dwords) or 4..7 (half 1)
 __device__ __forceinline__ void lf_horz_pk(CellPix &C, int half, int L2) {

@@ -220,41 +220,40 @@ __global__ __launch_bounds__(256) void k_enc_copy2(uint8_t *dst_plane, const uin
   }
 }
 
-// 1-D forward DCT, in place -- lib/fdct.c:28-120.  Outputs are truncated to int16 by the
-// reference's stores into ogg_int16_t _y[8].
+// 1-D forward DCT, in place (the arithmetic of lib/fdct.c:28-120, whose rounding constants make the
+// transform the exact inverse partner of the decoder's; outputs truncate to int16 where the reference stores
+// into ogg_int16_t).  Written as the three kinds of step it consists of:
+//   fd_scale(v, bias)        v * (1 + 27146/65536) rounded with `bias`, nudged away from zero: the sqrt(2)-ish
+//                            scalings of the even part and of the two middle odd terms;
+//   fd_rot(a, b, ca, cb, k)  the first output of a plane rotation, (ca*a + cb*b + k) >> 16, nudged by b != 0;
+//   fd_back(u, c, x, m, k, s) the second output recovered from the first: r = +-(c*u >> 16 - x), then
+//                            r * (1 + m / 2^s) rounded with k, nudged away from zero.
+__device__ __forceinline__ int fd_nz(int v) { return v != 0 ? 1 : 0; }
+__device__ __forceinline__ int fd_scale(int v, int bias) { return ((27146 * v + bias) >> 16) + v + fd_nz(v); }
+__device__ __forceinline__ int fd_rot(int a, int b, int ca, int cb, int k) { return ((ca * a + cb * b + k) >> 16) + fd_nz(b); }
+__device__ __forceinline__ int fd_back(int r, int m, int k, int s) { return ((r * m + k) >> s) + r + fd_nz(r); }
 __device__ __forceinline__ void fdct8(int &x0, int &x1, int &x2, int &x3, int &x4, int &x5, int &x6,
                                       int &x7) {
-  int t0 = x0 + x7, t7 = x0 - x7, t1 = x1 + x6, t6 = x1 - x6;
-  int t2 = x2 + x5, t5 = x2 - x5, t3 = x3 + x4, t4 = x3 - x4;
-  int r, s, u, v;
-  r = t0 + t3; t3 = t0 - t3; t0 = r;
-  r = t1 + t2; t2 = t1 - t2; t1 = r;
-  r = t6 + t5; t5 = t6 - t5; t6 = r;
-  s = (((27146 * t5 + 0xB500) >> 16) + t5 + (t5 != 0)) >> 1;   // fdct.c:87
-  r = t4 + s; t5 = t4 - s; t4 = r;
-  s = (((27146 * t6 + 0xB500) >> 16) + t6 + (t6 != 0)) >> 1;   // fdct.c:91
-  r = t7 + s; t6 = t7 - s; t7 = r;
-  r = ((27146 * t0 + 0x4000) >> 16) + t0 + (t0 != 0);          // fdct.c:96
-  s = ((27146 * t1 + 0xB500) >> 16) + t1 + (t1 != 0);
-  u = (r + s) >> 1;
-  v = r - u;
-  x0 = sx16(u);
-  x4 = sx16(v);
-  u = ((kC6 * t2 + kC2 * t3 + 0x6CB7) >> 16) + (t3 != 0);      // fdct.c:102
-  s = ((kC6 * u) >> 16) - t2;
-  v = ((s * 21600 + 0x2800) >> 18) + s + (s != 0);
-  x2 = sx16(u);
-  x6 = sx16(v);
-  u = ((kC5 * t6 + kC3 * t5 + 0x0E3D) >> 16) + (t5 != 0);      // fdct.c:108
-  s = t6 - ((kC5 * u) >> 16);
-  v = ((s * 26568 + 0x3400) >> 17) + s + (s != 0);
-  x5 = sx16(u);
-  x3 = sx16(v);
-  u = ((kC7 * t4 + kC1 * t7 + 0x7B1B) >> 16) + (t7 != 0);      // fdct.c:114
-  s = ((kC7 * u) >> 16) - t4;
-  v = ((s * 20539 + 0x3000) >> 20) + s + (s != 0);
-  x1 = sx16(u);
-  x7 = sx16(v);
+  // stage 1: mirror sums and differences; stage 2: the even half folds once more
+  const int s07 = x0 + x7, d07 = x0 - x7, s16 = x1 + x6, d16 = x1 - x6;
+  const int s25 = x2 + x5, d25 = x2 - x5, s34 = x3 + x4, d34 = x3 - x4;
+  const int e0 = s07 + s34, e3 = s07 - s34, e1 = s16 + s25, e2 = s16 - s25;
+  // even outputs 0 and 4 (fdct.c:96-100), 2 and 6 (fdct.c:102-106)
+  const int p = ((27146 * e0 + 0x4000) >> 16) + e0 + fd_nz(e0), q = fd_scale(e1, 0xB500);
+  const int y0 = (p + q) >> 1, y4 = p - y0;
+  const int y2 = fd_rot(e2, e3, kC6, kC2, 0x6CB7);
+  const int y6 = fd_back(((kC6 * y2) >> 16) - e2, 21600, 0x2800, 18);
+  // odd half: the two middle differences are rotated by pi/4 first (fdct.c:87-93)
+  const int ms = d16 + d25, md = d16 - d25;
+  const int h5 = fd_scale(md, 0xB500) >> 1, h6 = fd_scale(ms, 0xB500) >> 1;
+  const int o4 = d34 + h5, o5 = d34 - h5, o7 = d07 + h6, o6 = d07 - h6;
+  // odd outputs 5 and 3 (fdct.c:108-112), 1 and 7 (fdct.c:114-118)
+  const int y5 = fd_rot(o6, o5, kC5, kC3, 0x0E3D);
+  const int y3 = fd_back(o6 - ((kC5 * y5) >> 16), 26568, 0x3400, 17);
+  const int y1 = fd_rot(o4, o7, kC7, kC1, 0x7B1B);
+  const int y7 = fd_back(((kC7 * y1) >> 16) - o4, 20539, 0x3000, 20);
+  x0 = sx16(y0); x1 = sx16(y1); x2 = sx16(y2); x3 = sx16(y3);
+  x4 = sx16(y4); x5 = sx16(y5); x6 = sx16(y6); x7 = sx16(y7);
 }
 
 // natural position of zig-zag index i -- lib/internal.c:27 (first 64 entries)
