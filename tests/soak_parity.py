@@ -13,7 +13,7 @@ bad = 0
 t0 = time.time()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 cases = 0
-while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 120:
+while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 120):
     w = int(rng.choice([64, 176, 336, 640, 1280, 1920])); h = int(rng.choice([48, 144, 272, 368, 720, 1088]))
     fmt = int(rng.choice([0, 2, 3]))
     cls = str(rng.choice(["mixed", "smooth", "dense", "static_bg", "static_1pct"]))

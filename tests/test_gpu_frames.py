@@ -244,6 +244,29 @@ def test_batched_streams(hip):
             assert not util.planes_equal(osts[i], gsts[i]), (f, i)
 
 
+def test_batched_streams_of_mixed_formats_and_sizes(hip):
+    """One thip_decode_frames call over streams that share nothing: 1080p 4:2:0 next to a single-tile 16x16 4:4:4, a 4:2:2 picture,
+    one tile row (2048x16), one tile column (16x1040), 640x480 -- every stream with its own XCD bands (some of them empty), its own
+    loop-filter limit (0 included) and content class, over a key frame and five inter frames."""
+    cases = [(1920, 1088, PF_420, "smooth"), (16, 16, PF_444, "dense"), (336, 272, PF_422, "mixed"), (2048, 16, PF_420, "mixed"),
+             (16, 1040, PF_444, "smooth"), (640, 480, PF_420, "dense")]
+    geoms = [synth.Geometry(w, h, f) for w, h, f, _ in cases]
+    rngs = [np.random.default_rng(900 + i) for i in range(len(cases))]
+    osts = [oracle.State(w, h, f) for w, h, f, _ in cases]
+    gsts = [hip.State(w, h, f) for w, h, f, _ in cases]
+    for f in range(6):
+        descs, keep = [], []
+        for i, c in enumerate(cases):
+            fr = synth.gen_frame(geoms[i], rngs[i], hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, c[3], flimit=[2, 0, 63, 4, 15, 7][(i + f) % 6])
+            util.oracle_apply(osts[i], fr)
+            d, ka = synth.upload_frame(synth.pack_frame(geoms[i], fr))
+            descs.append(d)
+            keep.append(ka)
+        hip.decode_frames(gsts, descs)
+        for i in range(len(cases)):
+            assert not util.planes_equal(osts[i], gsts[i]), (f, i)
+
+
 def test_ycbcr_out_is_top_down(hip):
     w, h = 64, 48
     geom = synth.Geometry(w, h, PF_420)
