@@ -7,15 +7,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtheora_hip.so")
 SOURCES = ["thip_decode.hip", "thip_slots.hip", "thip_frontend.cpp", "thip_ogg.cpp"]
-HEADERS = ["thip_device.h", "thip_kernels.h", "thip_postproc.h", "thip_tokens.h", os.path.join("..", "..", "include", "theora_hip.h"),
-           os.path.join("..", "..", "include", "theoradec_hip.h"), os.path.join("..", "..", "include", "thip_ogg.h")]
-
+# every header under csrc/ and include/ is a dependency (a list kept by hand went stale once: thip_fused.h was edited and the
+# library was not rebuilt)
+def _headers():
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h")))
 
 def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in SOURCES] + _headers() + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

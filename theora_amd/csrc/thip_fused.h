@@ -6,16 +6,21 @@
 // four blocks around its corner and nothing else, so a wave that has just reconstructed a tile
 // (16 x 4 blocks, 128 x 32 pixels) can close every cell whose four blocks it holds -- and the cells on its
 // left and upper boundary too, if the neighbour tiles hand over their last block column / block row.
-// They do, through L2:
-//   * every tile PUBLISHES, straight from its registers, its last four pixel rows, its last four pixel
-//     columns (and, where the tile above belongs to another XCD's band, its first four rows) into a
-//     1.25-KB record of its own, waits for those stores to be acknowledged and sets the record's flag
-//     word to the launch's serial number (+ the coded flags of the blocks on those edges);
-//   * the tile to the right / below CONSUMES: it polls the flag words of its left, upper and upper-left
-//     neighbours, copies their edges into the margins of its LDS image and becomes 16 x 4 filter cells
-//     shifted by half a block: lane (kx, m) takes the cell on corner (16t + kx, 4 sby + m).  The wave
-//     therefore stores the region [128t-4, 128t+124) x [32sby-4, 32sby+28): every byte of the frame is
-//     written exactly once, final, and there is no second kernel.
+// They do, through L2, in self-validating 16-byte UNITS -- 12 bytes of pixels and a tag word {launch serial << 20 | coded flags
+// of the edge blocks} -- so that data and "it is there" arrive in the same access:
+//   * every tile PUBLISHES its last four pixel rows (43 units), its last four pixel columns (11 units) and, where the tile
+//     above belongs to another XCD's band, its first four rows: one 16-byte store per lane, assembled from the tile image in
+//     LDS, no wait for an acknowledgement, no separate flag;
+//   * the tile to the right / below CONSUMES: 56 lanes load one unit each of the left, upper and upper-left neighbours' records
+//     (past the CU's L1) and look again until every tag carries this launch's serial number -- one round trip when the
+//     neighbour was done first -- then scatter the pixels into the margins of the LDS image and the wave becomes 16 x 4 filter
+//     cells shifted by half a block: lane (kx, m) takes the cell on corner (16t + kx, 4 sby + m).  The wave therefore stores
+//     the region [128t-4, 128t+124) x [32sby-4, 32sby+28): every byte of the frame is written exactly once, final, and there
+//     is no second kernel.
+// (A unit is one aligned 16-byte access of one lane: a single request to the L2 that owns the line, which is what makes the
+//  tag vouch for the twelve bytes in front of it.  Round 3's first version kept data and a flag word apart: the producer
+//  waited for its stores to be acknowledged before it set the flag, the consumer polled the flag and then fetched the data --
+//  two more dependent round trips in a wave's life, which is what bounds the kernel on content that is not byte-bound.)
 // Who waits for whom: tiles are numbered plane by plane, tile row by tile row, left to right; the
 // launch gives XCD x (work-group id mod 8) the x-th contiguous BAND of whole tile rows (StreamK::band_u0)
 // and hands the tiles of a band out in order.  Left, upper and upper-left neighbours of a tile inside
@@ -47,47 +52,77 @@ constexpr int kTfFlagPitch = 20;               // [0] block column -1, [1..16] t
 // here (LDS-DMA), the eighth stays in registers.
 constexpr int kTfLds = 7168;
 static_assert(kTfFlagOff + 6 * kTfFlagPitch <= kTfLds, "the image lives in the wave's staging area");
-// a tile's record in StreamK::edge
-constexpr int kTfBot = 0;                      // pixel rows 28..31: 4 x 128 bytes
-constexpr int kTfRight = 512;                  // pixel columns 124..127: 32 rows x 4 bytes
-constexpr int kTfTop = 640;                    // pixel rows 0..3: 4 x 128 bytes (tiles that open a band only)
-constexpr int kTfFlag = 1152;                  // 8 bytes: {serial << 20 | right4 << 16 | bottom16, top16}
-constexpr int kTfRec = 1280;
+// a tile's record in StreamK::edge: units of 16 bytes = 3 dwords of pixels + tag
+constexpr int kTfUnit = 16;
+constexpr int kTfBotUnits = 43, kTfRightUnits = 11;      // 512 and 128 bytes of pixels
+constexpr int kTfBot = 0;                      // pixel rows 28..31 (4 x 128 bytes, row-major), tag flags: right4 << 16 | bottom16
+constexpr int kTfRight = 704;                  // pixel columns 124..127 (32 rows x 4 bytes), same tag flags
+constexpr int kTfTop = 896;                    // pixel rows 0..3 (tiles that open a band only), tag flags: top16
+constexpr int kTfRec = 1600;
 
-// scope of the record stores: 0 = this XCD's L2 is enough, 1 = through to memory (a reader on another XCD)
-template <int AGENT>
-__device__ __forceinline__ void tf_store64(uint8_t *p, uint32_t lo, uint32_t hi) {
-  const unsigned long long v = (unsigned long long)hi << 32 | lo;
-  if (AGENT)
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// A unit goes out with one 16-byte store (through to memory where the reader sits on another XCD) and comes in with one
+// 16-byte load that bypasses the CU's L1.  Inline assembly: there is no 16-byte atomic to ask the compiler for, and the
+// cache-policy bits are the point.
+typedef uint32_t tf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tf_store_unit(uint8_t *p, uint4 v, bool through) {
+  if (through) {
+    const tf_u32x4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+  } else {
+    *reinterpret_cast<uint4 *>(p) = v;
+  }
 }
-// (device scope: past the CU's L1 -- served by the L2 when the producer is on this XCD, by memory otherwise)
-__device__ __forceinline__ uint2 tf_load64(const uint8_t *p) {
-  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+__device__ __forceinline__ uint4 tf_load_unit(const uint8_t *p) {
+  tf_u32x4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(p) : "memory");
+  return make_uint4(w.x, w.y, w.z, w.w);
 }
 
-template <int AGENT>
-__device__ __forceinline__ void tf_publish(uint8_t *rec, const uint2 rows[8], int lx, int ly, bool valid, bool pub_top) {
-  // rows 28..31 / 0..3: the lanes of block row 3 / 0, four 8-byte pieces each
-  const bool bot = ly == 3, top = ly == 0 && pub_top;
-  if (bot || top) {
-    uint8_t *p = rec + (bot ? kTfBot : kTfTop) + lx * 8;
+// Where dword `idx` of a 4 x 128-byte row block / of a 32-row column lies in the LDS image (byte offsets), given the image
+// row of its first row.
+__device__ __forceinline__ int tf_rows_at(int idx, int ri0) { return (ri0 + (idx >> 5)) * kTfPitch + kTfX0 + (idx & 31) * 4; }
+__device__ __forceinline__ int tf_col_at(int idx, int ri0, int x) { return (ri0 + idx) * kTfPitch + kTfX0 + x; }
+
+// Lanes 0..42 assemble the units of a 4-row block whose first row is image row ri0, lanes 43..53 (when `right`) the units of
+// the column at pixel x = 124; everything out of the LDS image.
+__device__ __forceinline__ void tf_publish_units(const uint8_t *lds, uint8_t *rec_rows, uint8_t *rec_right, int ri0, bool right, uint32_t tag,
+                                                 int lane, bool through) {
+  uint32_t d[3] = {0u, 0u, 0u};
+  uint8_t *dst = nullptr;
+  if (lane < kTfBotUnits) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const uint2 v = bot ? rows[4 + r] : rows[r];
-      tf_store64<AGENT>(p + r * 128, v.x, v.y);
+    for (int j = 0; j < 3; j++) {
+      const int idx = 3 * lane + j;
+      if (idx < 128) d[j] = *reinterpret_cast<const uint32_t *>(lds + tf_rows_at(idx, ri0));
     }
-  }
-  // columns 124..127: the lanes of block column 15, their rows' upper dwords two by two
-  if (lx == 15) {
-    uint8_t *p = rec + kTfRight + ly * 32;
+    dst = rec_rows + lane * kTfUnit;
+  } else if (right && lane < kTfBotUnits + kTfRightUnits) {
+    const int v = lane - kTfBotUnits;
 #pragma unroll
-    for (int r = 0; r < 4; r++) tf_store64<AGENT>(p + r * 8, rows[2 * r].y, rows[2 * r + 1].y);
+    for (int j = 0; j < 3; j++) {
+      const int idx = 3 * v + j;
+      if (idx < 32) d[j] = *reinterpret_cast<const uint32_t *>(lds + tf_col_at(idx, 4, 124));
+    }
+    dst = rec_right + v * kTfUnit;
   }
-  (void)valid;
+  if (dst) tf_store_unit(dst, make_uint4(d[0], d[1], d[2], tag), through);
+}
+
+// The consumer's side: every lane with a source loads its unit and looks again until its tag carries the launch's serial
+// number (bounded: see tf header; `fault` is the device's pinned host word).  Returns the unit.
+__device__ __forceinline__ uint4 tf_fetch_unit(const uint8_t *src, uint32_t ep, uint32_t *fault) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  bool ok = src == nullptr;
+  for (int spins = 0; spins < (1 << 20); spins++) {
+    if (!ok) {
+      v = tf_load_unit(src);
+      ok = (v.w >> 20) == ep;
+    }
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (!ok && fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return v;
 }
 
 // One filter cell out of the LDS image: corner column kx (0..16) of the tile, cell row m (0..4).
@@ -129,42 +164,6 @@ __device__ __forceinline__ void tf_cell(const uint8_t *lds, uint8_t *plane, int 
   }
 }
 
-// The neighbours' flag words: lane i < 3 looks at recs[i] when need[i].  tf_poll asks once (the answer travels while the
-// wave does something else), tf_wait takes that answer and keeps asking until all carry this launch's serial number;
-// returns the words in w[0..2], the second word of recs[0] in w[3] (wave-uniform).
-struct TfPoll {
-  const uint8_t *rec;
-  bool need;
-  uint2 f;
-};
-// (every lane loads -- the lanes with nothing to ask read the wave's own record: a load under a condition would be
-//  merged with a default value behind it, and the merge waits for the data on the spot)
-__device__ __forceinline__ void tf_poll(TfPoll &P, const uint8_t *rec0, const uint8_t *rec1, const uint8_t *rec2, bool need0, bool need1,
-                                        bool need2, int lane, const uint8_t *myrec) {
-  const uint8_t *rec = lane == 0 ? rec0 : (lane == 1 ? rec1 : rec2);
-  P.need = lane == 0 ? need0 : (lane == 1 ? need1 : (lane == 2 ? need2 : false));
-  P.rec = P.need ? rec : myrec;
-  P.f = tf_load64(P.rec + kTfFlag);
-}
-// (fault: the device's pinned host word.  A wait that runs out -- it cannot, as long as work groups are dispatched in order --
-//  leaves a wrong picture behind; the word turns that into an error the next synchronising call of the ABI returns.)
-__device__ __forceinline__ void tf_wait(const TfPoll &P, uint32_t ep, uint32_t w[4], uint32_t *fault) {
-  uint2 f = P.f;
-  bool ok = !P.need || (f.x >> 20) == ep;
-  for (int spins = 0; spins < (1 << 20) && !__all(ok); spins++) {
-    __builtin_amdgcn_s_sleep(2);
-    if (!ok) {
-      f = tf_load64(P.rec + kTfFlag);
-      ok = (f.x >> 20) == ep;
-    }
-  }
-  if (!__all(ok) && fault && !ok) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  w[0] = (uint32_t)__builtin_amdgcn_readlane((int)f.x, 0);
-  w[1] = (uint32_t)__builtin_amdgcn_readlane((int)f.x, 1);
-  w[2] = (uint32_t)__builtin_amdgcn_readlane((int)f.x, 2);
-  w[3] = (uint32_t)__builtin_amdgcn_readlane((int)f.y, 0);   // second flag word of rec0
-}
-
 #ifndef THIP_TF_WAVES_PER_EU
 #define THIP_TF_WAVES_PER_EU 5    // 96 VGPRs; with 8 KB of LDS per wave that is 20 waves per CU
 #endif
@@ -183,7 +182,8 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   const int16_t *dc_p = S.dc;
   uint8_t *edge_p = S.edge;
   const int te0 = S.tile_end[0], te1 = S.tile_end[1];
-  const int sqpx = S.qpx, sqpy = S.qpy, L2 = S.flimit2;
+  const int sqpx = S.qpx, sqpy = S.qpy;
+  const int L2 = (S.debug & 256) ? 0 : S.flimit2;   // (ablation switch for profiling, option debug = 256: cells copy, no filtering)
   const uint32_t ep = S.epoch;
   const int bu0 = S.band_u0[band], bu1 = S.band_u0[band + 1];
   asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map), "s"(dc_p), "s"(edge_p),
@@ -300,17 +300,11 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   THIP_TR(tr, 2);   // pixels done (coefficients and predictor windows had arrived)
 #endif
 
-  // ---- 3. publish the edges (from the registers), ask for the neighbours' flag words, image into LDS ----------
+  // ---- 3. the tile image into LDS, its edges out as units ---------------------------------------------------------
   uint8_t *const myrec = edge_p + (size_t)u * kTfRec;
-  if (xb_up)
-    tf_publish<1>(myrec, rows, lx, ly, valid, true);
-  else
-    tf_publish<0>(myrec, rows, lx, ly, valid, false);
   const uint8_t *const rec_up = myrec - (ptrdiff_t)tiles_x * kTfRec, *const rec_left = myrec - kTfRec;
   const uint8_t *const rec_ul = rec_up - kTfRec;
   const bool need_ul = up_in && has_left;
-  TfPoll poll;                                    // first look at the neighbours' flag words: in flight with the record stores
-  tf_poll(poll, rec_up, rec_left, rec_ul, up_in, has_left, need_ul, lane, myrec);
   lds_settle();                                   // every lane is done with the staging area
   if (valid) {
     uint8_t *img = lds + (ly * 8 + 4) * kTfPitch + kTfX0 + lx * 8;
@@ -319,63 +313,62 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   }
   lds[kTfFlagOff + (ly + 1) * kTfFlagPitch + lx + 1] = (valid && L.coded) ? 1 : 0;
   lds_settle();
-  // the coded flags of the published edges, one ballot: bits 0..15 block row 3, 16..19 block column 15, 32..47 block row 0
   {
+    // the coded flags of the published edges, one ballot: bits 0..15 block row 3, 16..19 block column 15, 32..47 block row 0
     const int fi = lane < 16 ? 4 * kTfFlagPitch + lane + 1
                              : (lane < 20 ? (lane - 16 + 1) * kTfFlagPitch + 16 : (lane >= 32 && lane < 48 ? kTfFlagPitch + (lane - 32) + 1 : 0));
     const bool fb = (lane < 20 || (lane >= 32 && lane < 48)) && lds[kTfFlagOff + fi] != 0;
     const uint64_t fm = __ballot(fb);
-    THIP_TR(tr, 3);   // edges on their way, image in LDS
-    // the flag word goes out when the record is in place: stores are acknowledged by the L2 (or by memory)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) {
-      const uint32_t w0 = ep << 20 | (uint32_t)(fm & 0xFFFFFu), w1 = (uint32_t)(fm >> 32) & 0xFFFFu;
-      if (xb_up)
-        tf_store64<1>(myrec + kTfFlag, w0, w1);
-      else
-        tf_store64<0>(myrec + kTfFlag, w0, w1);
-    }
-    THIP_TR(tr, 4);   // record acknowledged, flag word out
+    tf_publish_units(lds, myrec + kTfBot, myrec + kTfRight, 32, true, ep << 20 | (uint32_t)(fm & 0xFFFFFu), lane, xb_up);
+    if (xb_up) tf_publish_units(lds, myrec + kTfTop, nullptr, 4, false, ep << 20 | ((uint32_t)(fm >> 32) & 0xFFFFu), lane, true);
+    THIP_TR(tr, 3);   // image in LDS, edges on their way
+    THIP_TR(tr, 4);
   }
 
-  // ---- 4. the neighbours' edges into the image margins --------------------------------------------------
+  // ---- 4. the neighbours' edges into the image margins: lanes 0..42 the upper tile's rows 28..31, 43..53 the left tile's
+  //         columns 124..127, 54 and 55 the upper-left tile's corner (dwords 28..31 of its column: units 9 and 10) ---------
   {
-    uint32_t w[4];
-    tf_wait(poll, ep, w, B.fault);
-    THIP_TR(tr, 5);   // the neighbours' records are there
-    // lanes 0..31: the upper tile's rows 28..31, 16 bytes each; 32..39: the left tile's columns 124..127, four rows each;
-    // 40: the upper-left tile's corner (rows 28..31 of its column record)
     const uint8_t *src = nullptr;
-    if (lane < 32) {
-      if (up_in) src = rec_up + kTfBot + lane * 16;
-    } else if (lane < 40) {
-      if (has_left) src = rec_left + kTfRight + (lane - 32) * 16;
-    } else if (lane == 40) {
-      if (need_ul) src = rec_ul + kTfRight + 112;
+    if (lane < kTfBotUnits) {
+      if (up_in) src = rec_up + kTfBot + lane * kTfUnit;
+    } else if (lane < kTfBotUnits + kTfRightUnits) {
+      if (has_left) src = rec_left + kTfRight + (lane - kTfBotUnits) * kTfUnit;
+    } else if (lane < kTfBotUnits + kTfRightUnits + 2) {
+      if (need_ul) src = rec_ul + kTfRight + (9 + lane - (kTfBotUnits + kTfRightUnits)) * kTfUnit;
     }
-    uint2 d0 = make_uint2(0u, 0u), d1 = d0;
-    if (src) {
-      d0 = tf_load64(src);
-      d1 = tf_load64(src + 8);
+    const uint4 un = tf_fetch_unit(src, ep, B.fault);
+    THIP_TR(tr, 5);   // the neighbours' units are there
+    const uint32_t d[3] = {un.x, un.y, un.z};
+    if (lane < kTfBotUnits) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int idx = 3 * lane + j;
+        if (idx < 128) *reinterpret_cast<uint32_t *>(lds + tf_rows_at(idx, 0)) = d[j];
+      }
+    } else if (lane < kTfBotUnits + kTfRightUnits) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int idx = 3 * (lane - kTfBotUnits) + j;
+        if (idx < 32) *reinterpret_cast<uint32_t *>(lds + tf_col_at(idx, 4, -4)) = d[j];
+      }
+    } else if (lane < kTfBotUnits + kTfRightUnits + 2) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int idx = 3 * (9 + lane - (kTfBotUnits + kTfRightUnits)) + j;      // 27 .. 32
+        if (idx >= 28 && idx < 32) *reinterpret_cast<uint32_t *>(lds + tf_col_at(idx - 28, 0, -4)) = d[j];
+      }
     }
-    if (lane < 32) {
-      uint8_t *p = lds + (lane >> 3) * kTfPitch + kTfX0 + (lane & 7) * 16;
-      *reinterpret_cast<uint2 *>(p) = d0;
-      *reinterpret_cast<uint2 *>(p + 8) = d1;
-    } else if (lane <= 40) {
-      uint8_t *p = lds + (lane == 40 ? 0 : 4 + 4 * (lane - 32)) * kTfPitch + kTfX0 - 4;
-      *reinterpret_cast<uint32_t *>(p) = d0.x;
-      *reinterpret_cast<uint32_t *>(p + kTfPitch) = d0.y;
-      *reinterpret_cast<uint32_t *>(p + 2 * kTfPitch) = d1.x;
-      *reinterpret_cast<uint32_t *>(p + 3 * kTfPitch) = d1.y;
-    }
-    // their coded flags: block row -1 (columns 0..15), block column -1 (rows 0..3), block (-1, -1)
+    // their coded flags (the tags of the first unit of each record): block row -1 (columns 0..15), block column -1 (rows 0..3),
+    // block (-1, -1)
+    const uint32_t w_up = (uint32_t)__builtin_amdgcn_readlane((int)un.w, 0);
+    const uint32_t w_left = (uint32_t)__builtin_amdgcn_readlane((int)un.w, kTfBotUnits);
+    const uint32_t w_ul = (uint32_t)__builtin_amdgcn_readlane((int)un.w, kTfBotUnits + kTfRightUnits);
     if (lane < 16)
-      lds[kTfFlagOff + lane + 1] = (uint8_t)((w[0] >> lane) & 1u);
+      lds[kTfFlagOff + lane + 1] = (uint8_t)((w_up >> lane) & 1u);
     else if (lane < 20)
-      lds[kTfFlagOff + (lane - 16 + 1) * kTfFlagPitch] = (uint8_t)((w[1] >> lane) & 1u);
+      lds[kTfFlagOff + (lane - 16 + 1) * kTfFlagPitch] = (uint8_t)((w_left >> lane) & 1u);
     else if (lane == 20)
-      lds[kTfFlagOff] = (uint8_t)((w[2] >> 19) & 1u);
+      lds[kTfFlagOff] = (uint8_t)((w_ul >> 19) & 1u);
     lds_settle();
     THIP_TR(tr, 6);   // ... and in the margins
   }
@@ -390,37 +383,34 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   const bool extra_row = xb_dn || (!has_dn && (nv & 3) == 0);
   if (extra_col || extra_row) {
     if (xb_dn) {
+      // the tile below ran at the start of the launch: its first four rows (lanes 0..42) and the lower-left tile's corner
+      // (dwords 0..3 of its column: units 0 and 1, lanes 43 and 44), into image rows 36..39
       const uint8_t *const rec_dn = myrec + (ptrdiff_t)tiles_x * kTfRec, *const rec_dl = rec_dn - kTfRec;
-      uint32_t w[4];
-      TfPoll pd;
-      tf_poll(pd, rec_dn, rec_dl, rec_dl, true, has_left, false, lane, myrec);
-      tf_wait(pd, ep, w, B.fault);
       const uint8_t *src = nullptr;
-      if (lane < 32)
-        src = rec_dn + kTfTop + lane * 16;          // the lower tile's rows 0..3
-      else if (lane == 32 && has_left)
-        src = rec_dl + kTfRight;                    // the lower-left tile's corner (rows 0..3 of its column record)
-      uint2 d0 = make_uint2(0u, 0u), d1 = d0;
-      if (src) {
-        d0 = tf_load64(src);
-        d1 = tf_load64(src + 8);
+      if (lane < kTfBotUnits) src = rec_dn + kTfTop + lane * kTfUnit;
+      else if (lane < kTfBotUnits + 2 && has_left) src = rec_dl + kTfRight + (lane - kTfBotUnits) * kTfUnit;
+      const uint4 un = tf_fetch_unit(src, ep, B.fault);
+      const uint32_t d[3] = {un.x, un.y, un.z};
+      if (lane < kTfBotUnits) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int idx = 3 * lane + j;
+          if (idx < 128) *reinterpret_cast<uint32_t *>(lds + tf_rows_at(idx, 36)) = d[j];
+        }
+      } else if (lane < kTfBotUnits + 2) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int idx = 3 * (lane - kTfBotUnits) + j;      // 0 .. 5
+          if (idx < 4) *reinterpret_cast<uint32_t *>(lds + tf_col_at(idx, 36, -4)) = d[j];
+        }
       }
-      if (lane < 32) {
-        uint8_t *p = lds + (36 + (lane >> 3)) * kTfPitch + kTfX0 + (lane & 7) * 16;
-        *reinterpret_cast<uint2 *>(p) = d0;
-        *reinterpret_cast<uint2 *>(p + 8) = d1;
-      } else if (lane == 32) {
-        uint8_t *p = lds + 36 * kTfPitch + kTfX0 - 4;
-        *reinterpret_cast<uint32_t *>(p) = d0.x;
-        *reinterpret_cast<uint32_t *>(p + kTfPitch) = d0.y;
-        *reinterpret_cast<uint32_t *>(p + 2 * kTfPitch) = d1.x;
-        *reinterpret_cast<uint32_t *>(p + 3 * kTfPitch) = d1.y;
-      }
-      // block row 4: the lower tile's first block row (word 1 of its flags), the lower-left tile's block (15, 0)
+      // block row 4: the lower tile's first block row (its top units' tags), the lower-left tile's block (15, 0)
+      const uint32_t w_dn = (uint32_t)__builtin_amdgcn_readlane((int)un.w, 0);
+      const uint32_t w_dl = (uint32_t)__builtin_amdgcn_readlane((int)un.w, kTfBotUnits);
       if (lane < 16)
-        lds[kTfFlagOff + 5 * kTfFlagPitch + lane + 1] = (uint8_t)((w[3] >> lane) & 1u);
+        lds[kTfFlagOff + 5 * kTfFlagPitch + lane + 1] = (uint8_t)((w_dn >> lane) & 1u);
       else if (lane == 16)
-        lds[kTfFlagOff + 5 * kTfFlagPitch] = (uint8_t)((w[1] >> 16) & 1u);
+        lds[kTfFlagOff + 5 * kTfFlagPitch] = (uint8_t)((w_dl >> 16) & 1u);
       lds_settle();
     }
     // lanes 0..16: cells (lane, 4); lanes 32..35: cells (16, lane - 32)
