@@ -164,13 +164,6 @@ __device__ __forceinline__ void tf_cell(const uint8_t *lds, uint8_t *plane, int 
   }
 }
 
-// Wave priorities (THIP_TF_PRIO=1): a wave asks for issue priority while it is on the path others wait on or that gets its own
-// memory requests out -- from its start until the second round trip's loads are issued, and from its pixels until its edge units
-// are stored -- and gives it back for the long arithmetic stretches (transform, reconstruction, cells).
-#ifndef THIP_TF_PRIO
-#define THIP_TF_PRIO 0
-#endif
-#define TF_PRIO(n) do { if (THIP_TF_PRIO) __builtin_amdgcn_s_setprio(n); } while (0)
 #ifndef THIP_TF_WAVES_PER_EU
 #define THIP_TF_WAVES_PER_EU 5    // 96 VGPRs; with 8 KB of LDS per wave that is 20 waves per CU
 #endif
@@ -178,7 +171,6 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   __shared__ uint4 s_tf[kTfLds / 16];   // wave-private (one wave per work group): coefficient staging, then the tile image
   const StreamK &S = B.s[blockIdx.y];
   const int lane = (int)threadIdx.x & 63;
-  TF_PRIO(3);
   const int band = (int)blockIdx.x & 7, jb = (int)blockIdx.x >> 3;
   // scalar batch 1 (see recon_tile)
   const uint2 *info_p = S.info;
@@ -274,18 +266,15 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   uint32_t Y[32];
   if (nown == 0) {
     if (valid) recon_issue(R, L, Q, inter, ref);
-    TF_PRIO(0);
   } else if (nown <= 16) {
     int4 Wc[1][2];
     residual_shared_load<4>(coeffs_p, slot0, nown, lane, Wc);
     if (valid) recon_issue(R, L, Q, inter, ref);
-    TF_PRIO(0);
     residual_shared<4>(Wc, lds_dw, meta, lane, L, prefix, Y);
   } else if (nown <= 32) {
     int4 Wc[2][2];
     residual_shared_load<2>(coeffs_p, slot0, nown, lane, Wc);
     if (valid) recon_issue(R, L, Q, inter, ref);
-    TF_PRIO(0);
     residual_shared<2, true>(Wc, lds_dw, meta, lane, L, prefix, Y);
   } else {
     const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
@@ -296,7 +285,6 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
                                        (__attribute__((address_space(3))) void *)(s_tf + q * 64), 16, 0, 0);
     const int4 w7i = tp[7 * 64];
     if (valid) recon_issue(R, L, Q, inter, ref);
-    TF_PRIO(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)
     const uint4 w7 = make_uint4((uint32_t)w7i.x, (uint32_t)w7i.y, (uint32_t)w7i.z, (uint32_t)w7i.w);
     residual_per_lane(s_tf + lane, L, Y, &w7);
@@ -307,7 +295,6 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   }
   uint2 rows[8];
   recon_rows(R, Q, inter, Y, rows);
-  TF_PRIO(2);
 #ifdef THIP_TRACE
   asm volatile("" : "+v"(rows[0].x), "+v"(rows[7].y));
   THIP_TR(tr, 2);   // pixels done (coefficients and predictor windows had arrived)
@@ -334,7 +321,6 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     const uint64_t fm = __ballot(fb);
     tf_publish_units(lds, myrec + kTfBot, myrec + kTfRight, 32, true, ep << 20 | (uint32_t)(fm & 0xFFFFFu), lane, xb_up);
     if (xb_up) tf_publish_units(lds, myrec + kTfTop, nullptr, 4, false, ep << 20 | ((uint32_t)(fm >> 32) & 0xFFFFu), lane, true);
-    TF_PRIO(0);
     THIP_TR(tr, 3);   // image in LDS, edges on their way
     THIP_TR(tr, 4);
   }
