@@ -19,8 +19,8 @@ os.environ.setdefault("THIP_LANES", "1")
 os.environ["THIP_FUSE"] = "3"
 from wave_trace import build_trace_lib   # noqa: E402
 
-PHASES = ["start->command words", "->pixels (coefficients, windows, transform)", "->edges published, image in LDS",
-          "->record acknowledged, flag out", "->neighbours' flags seen", "->margins filled", "->cells, stores issued",
+PHASES = ["start->command words", "->pixels (coefficients, windows, transform)", "->image in LDS, edge units stored",
+          "->(nothing: the units need no acknowledgement)", "->neighbours' units there", "->margins filled", "->cells, stores issued",
           "->extra cells / end"]
 
 
