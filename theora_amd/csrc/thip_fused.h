@@ -8,15 +8,21 @@
 // left and upper boundary too, if the neighbour tiles hand over their last block column / block row.
 // They do, through L2, in self-validating 16-byte UNITS -- 12 bytes of pixels and a tag word {launch serial << 20 | coded flags
 // of the edge blocks} -- so that data and "it is there" arrive in the same access:
-//   * every tile PUBLISHES its last four pixel rows (43 units), its last four pixel columns (11 units) and, where the tile
-//     above belongs to another XCD's band, its first four rows: one 16-byte store per lane, assembled from the tile image in
+//   * every tile PUBLISHES its last TWO pixel rows (22 units), its last four pixel columns (11 units) and, where the tile
+//     above belongs to another XCD's band, its first two rows: one 16-byte store per lane, assembled from the tile image in
 //     LDS, no wait for an acknowledgement, no separate flag;
-//   * the tile to the right / below CONSUMES: 56 lanes load one unit each of the left, upper and upper-left neighbours' records
+//   * the tile to the right / below CONSUMES: 34 lanes load one unit each of the left, upper and upper-left neighbours' records
 //     (past the CU's L1) and look again until every tag carries this launch's serial number -- one round trip when the
 //     neighbour was done first -- then scatter the pixels into the margins of the LDS image and the wave becomes 16 x 4 filter
 //     cells shifted by half a block: lane (kx, m) takes the cell on corner (16t + kx, 4 sby + m).  The wave therefore stores
-//     the region [128t-4, 128t+124) x [32sby-4, 32sby+28): every byte of the frame is written exactly once, final, and there
+//     the region [128t-4, 128t+124) x [32sby-2, 32sby+30): every byte of the frame is written exactly once, final, and there
 //     is no second kernel.
+// Two rows, not the four a cell has above its corner: the horizontal edge at the tile boundary reads two rows on either side
+// and changes one, so rows 28 and 29 of a tile are touched by vertical edges only -- row by row, no order to keep -- and the
+// tile finishes them itself (the cells of its last cell row run their lower half's vertical edge over one more row pair,
+// tf_cell's `ext`), while the cells on the tile's upper boundary own their rows 2..7 only.  Every byte not handed over is a
+// byte not written to and read from memory: the records cost 13 MB of a 4 x 4K step's 227 MB this way, 22 MB with four rows
+// (measured before it was built, with a build that simply dropped half the units: the step time follows the bytes).
 // (A unit is one aligned 16-byte access of one lane: a single request to the L2 that owns the line, which is what makes the
 //  tag vouch for the twelve bytes in front of it.  Round 3's first version kept data and a flag word apart: the producer
 //  waited for its stores to be acknowledged before it set the flag, the consumer polled the flag and then fetched the data --
@@ -31,9 +37,9 @@
 // the CU's L1 and find them.
 // Band boundaries: the first tile row of band x (D tiles) runs at the START of the launch, the last row of
 // band x-1 (U tiles) at its END, so there the hand-over runs upwards: a D tile publishes its first four rows
-// with device-scope stores (through to memory: the reader sits on another XCD), leaves the cells on
-// its upper boundary alone, and the U tile above -- last of the two by construction -- closes them
-// as a 17th cell row.  The same extra pass closes the plane's own border cells (k = nh, m = nv) where
+// with device-scope stores (through to memory: the reader sits on another XCD), runs only the vertical
+// edge of its rows 2 and 3 in the cells on its upper boundary, and the U tile above -- last of the two by
+// construction -- closes the boundary (its rows 30, 31 and the D tile's rows 0, 1) as a 17th cell row.  The same extra pass closes the plane's own border cells (k = nh, m = nv) where
 // the plane ends exactly on a tile boundary.
 // Order of operations inside every cell: the reference's (state.c:1055-1105), via lf_cell_ops; the
 // fragment-row range of the enqueue slot (state.c:1066) is honoured the same way as in k_loopfilter.
@@ -54,11 +60,11 @@ constexpr int kTfLds = 7168;
 static_assert(kTfFlagOff + 6 * kTfFlagPitch <= kTfLds, "the image lives in the wave's staging area");
 // a tile's record in StreamK::edge: units of 16 bytes = 3 dwords of pixels + tag
 constexpr int kTfUnit = 16;
-constexpr int kTfBotUnits = 43, kTfRightUnits = 11;      // 512 and 128 bytes of pixels
-constexpr int kTfBot = 0;                      // pixel rows 28..31 (4 x 128 bytes, row-major), tag flags: right4 << 16 | bottom16
-constexpr int kTfRight = 704;                  // pixel columns 124..127 (32 rows x 4 bytes), same tag flags
-constexpr int kTfTop = 896;                    // pixel rows 0..3 (tiles that open a band only), tag flags: top16
-constexpr int kTfRec = 1600;
+constexpr int kTfBotUnits = 22, kTfRightUnits = 11;      // 256 and 128 bytes of pixels
+constexpr int kTfBot = 0;                      // pixel rows 30, 31 (2 x 128 bytes, row-major), tag flags: right4 << 16 | bottom16
+constexpr int kTfRight = 352;                  // pixel columns 124..127 (32 rows x 4 bytes), same tag flags
+constexpr int kTfTop = 528;                    // pixel rows 0, 1 (tiles that open a band only), tag flags: top16
+constexpr int kTfRec = 896;
 
 // A unit goes out with one 16-byte store (through to memory where the reader sits on another XCD) and comes in with one
 // 16-byte load that bypasses the CU's L1.  Inline assembly: there is no 16-byte atomic to ask the compiler for, and the
@@ -83,7 +89,7 @@ __device__ __forceinline__ uint4 tf_load_unit(const uint8_t *p) {
 __device__ __forceinline__ int tf_rows_at(int idx, int ri0) { return (ri0 + (idx >> 5)) * kTfPitch + kTfX0 + (idx & 31) * 4; }
 __device__ __forceinline__ int tf_col_at(int idx, int ri0, int x) { return (ri0 + idx) * kTfPitch + kTfX0 + x; }
 
-// Lanes 0..42 assemble the units of a 4-row block whose first row is image row ri0, lanes 43..53 (when `right`) the units of
+// Lanes 0..21 assemble the units of the two pixel rows that start at image row ri0, lanes 22..32 (when `right`) the units of
 // the column at pixel x = 124; everything out of the LDS image.
 __device__ __forceinline__ void tf_publish_units(const uint8_t *lds, uint8_t *rec_rows, uint8_t *rec_right, int ri0, bool right, uint32_t tag,
                                                  int lane, bool through) {
@@ -93,7 +99,7 @@ __device__ __forceinline__ void tf_publish_units(const uint8_t *lds, uint8_t *re
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int idx = 3 * lane + j;
-      if (idx < 128) d[j] = *reinterpret_cast<const uint32_t *>(lds + tf_rows_at(idx, ri0));
+      if (idx < 64) d[j] = *reinterpret_cast<const uint32_t *>(lds + tf_rows_at(idx, ri0));
     }
     dst = rec_rows + lane * kTfUnit;
   } else if (right && lane < kTfBotUnits + kTfRightUnits) {
@@ -125,9 +131,14 @@ __device__ __forceinline__ uint4 tf_fetch_unit(const uint8_t *src, uint32_t ep, 
   return v;
 }
 
-// One filter cell out of the LDS image: corner column kx (0..16) of the tile, cell row m (0..4).
+// One filter cell out of the LDS image: corner column kx (0..16) of the tile, cell row m (0..4).  Of its eight rows the
+// cell stores [r_lo, r_hi) -- a tile hands only its last TWO pixel rows down, so a cell on the tile's upper boundary owns its
+// rows 2..7 (6, 7 where the tile above belongs to another band and closes the boundary itself) and applies `opmask` of its
+// operations; `ext` cells (cell row 3) own the two rows below them as well, pixel rows 28 and 29 of the tile: nothing touches
+// those but the vertical edge of the cell's lower half (Vhi, one more row pair of the same operation), so they need not wait
+// for the tile below.
 __device__ __forceinline__ void tf_cell(const uint8_t *lds, uint8_t *plane, int stride, int nh, int nv, int t, int sby, int kx, int m,
-                                        bool active, int L2, int fy0, int fy1) {
+                                        bool active, int L2, int fy0, int fy1, int r_lo, int r_hi, uint32_t opmask, bool ext) {
   const int k = 16 * t + kx, mm = 4 * sby + m;
   active = active && k <= nh && mm <= nv;
   CellPix C;
@@ -138,27 +149,44 @@ __device__ __forceinline__ void tf_cell(const uint8_t *lds, uint8_t *plane, int 
     C.lo[r] = q[0];
     C.hi[r] = q[1];
   }
+  uint32_t xlo[2] = {0u, 0u}, xhi[2] = {0u, 0u};
+  const bool any_ext = __any(ext);
+  if (any_ext) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(img + (8 + r) * kTfPitch);
+      xlo[r] = q[0];
+      xhi[r] = q[1];
+    }
+  }
   const uint8_t *fl = lds + kTfFlagOff + m * kTfFlagPitch + kx;   // flag of block (kx-1, m-1)
   const bool a = fl[0] != 0, b = fl[1] != 0, c = fl[kTfFlagPitch] != 0, d = fl[kTfFlagPitch + 1] != 0;
-  uint32_t ops = lf_cell_ops(k, mm, nh, nv, a, b, c, d, fy0, fy1);
+  uint32_t ops = lf_cell_ops(k, mm, nh, nv, a, b, c, d, fy0, fy1) & opmask;
   if (L2 == 0 || !active) ops = 0;
   lf_cell_apply_pk(C, ops, L2);
+  if (any_ext) {
+    const bool vx = ext && (ops & 96u) != 0;
+    if (__any(vx)) { if (vx) lf_vert_pair(xlo[0], xlo[1], xhi[0], xhi[1], L2); }
+  }
   const bool lo_ok = active && k >= 1, hi_ok = active && k <= nh - 1;
   const bool up_ok = mm >= 1, dn_ok = mm <= nv - 1;
   uint8_t *base = plane + (ptrdiff_t)(8 * mm - 4) * stride + (8 * k - 4);
 #pragma unroll
-  for (int r = 0; r < 8; r++) {
+  for (int r = 0; r < 10; r++) {
     uint8_t *p = base + (ptrdiff_t)r * stride;
-    if (r < 4 ? up_ok : dn_ok) {
+    if (r >= 8 && !any_ext) break;
+    const bool row_ok = r < 8 ? (r >= r_lo && r < r_hi && (r < 4 ? up_ok : dn_ok)) : (ext && dn_ok);
+    const uint32_t vlo = r < 8 ? C.lo[r] : xlo[r - 8], vhi = r < 8 ? C.hi[r] : xhi[r - 8];
+    if (row_ok) {
       if (lo_ok & hi_ok) {
         Pix8 o;
-        o.x = C.lo[r];
-        o.y = C.hi[r];
+        o.x = vlo;
+        o.y = vhi;
         *reinterpret_cast<Pix8 *>(p) = o;
       } else if (lo_ok) {
-        *reinterpret_cast<uint32_t *>(p) = C.lo[r];
+        *reinterpret_cast<uint32_t *>(p) = vlo;
       } else if (hi_ok) {
-        *reinterpret_cast<uint32_t *>(p + 4) = C.hi[r];
+        *reinterpret_cast<uint32_t *>(p + 4) = vhi;
       }
     }
   }
@@ -319,22 +347,22 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
                              : (lane < 20 ? (lane - 16 + 1) * kTfFlagPitch + 16 : (lane >= 32 && lane < 48 ? kTfFlagPitch + (lane - 32) + 1 : 0));
     const bool fb = (lane < 20 || (lane >= 32 && lane < 48)) && lds[kTfFlagOff + fi] != 0;
     const uint64_t fm = __ballot(fb);
-    tf_publish_units(lds, myrec + kTfBot, myrec + kTfRight, 32, true, ep << 20 | (uint32_t)(fm & 0xFFFFFu), lane, xb_up);
+    tf_publish_units(lds, myrec + kTfBot, myrec + kTfRight, 34, true, ep << 20 | (uint32_t)(fm & 0xFFFFFu), lane, xb_up);
     if (xb_up) tf_publish_units(lds, myrec + kTfTop, nullptr, 4, false, ep << 20 | ((uint32_t)(fm >> 32) & 0xFFFFu), lane, true);
     THIP_TR(tr, 3);   // image in LDS, edges on their way
     THIP_TR(tr, 4);
   }
 
-  // ---- 4. the neighbours' edges into the image margins: lanes 0..42 the upper tile's rows 28..31, 43..53 the left tile's
-  //         columns 124..127, 54 and 55 the upper-left tile's corner (dwords 28..31 of its column: units 9 and 10) ---------
+  // ---- 4. the neighbours' edges into the image margins: lanes 0..21 the upper tile's rows 30, 31, 22..32 the left tile's
+  //         columns 124..127, 33 the upper-left tile's corner (dwords 30, 31 of its column: unit 10) ------------------------
   {
     const uint8_t *src = nullptr;
     if (lane < kTfBotUnits) {
       if (up_in) src = rec_up + kTfBot + lane * kTfUnit;
     } else if (lane < kTfBotUnits + kTfRightUnits) {
       if (has_left) src = rec_left + kTfRight + (lane - kTfBotUnits) * kTfUnit;
-    } else if (lane < kTfBotUnits + kTfRightUnits + 2) {
-      if (need_ul) src = rec_ul + kTfRight + (9 + lane - (kTfBotUnits + kTfRightUnits)) * kTfUnit;
+    } else if (lane == kTfBotUnits + kTfRightUnits) {
+      if (need_ul) src = rec_ul + kTfRight + 10 * kTfUnit;
     }
     const uint4 un = tf_fetch_unit(src, ep, B.fault);
     THIP_TR(tr, 5);   // the neighbours' units are there
@@ -343,7 +371,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const int idx = 3 * lane + j;
-        if (idx < 128) *reinterpret_cast<uint32_t *>(lds + tf_rows_at(idx, 0)) = d[j];
+        if (idx < 64) *reinterpret_cast<uint32_t *>(lds + tf_rows_at(idx, 2)) = d[j];
       }
     } else if (lane < kTfBotUnits + kTfRightUnits) {
 #pragma unroll
@@ -351,12 +379,9 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
         const int idx = 3 * (lane - kTfBotUnits) + j;
         if (idx < 32) *reinterpret_cast<uint32_t *>(lds + tf_col_at(idx, 4, -4)) = d[j];
       }
-    } else if (lane < kTfBotUnits + kTfRightUnits + 2) {
+    } else if (lane == kTfBotUnits + kTfRightUnits) {
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const int idx = 3 * (9 + lane - (kTfBotUnits + kTfRightUnits)) + j;      // 27 .. 32
-        if (idx >= 28 && idx < 32) *reinterpret_cast<uint32_t *>(lds + tf_col_at(idx - 28, 0, -4)) = d[j];
-      }
+      for (int j = 0; j < 2; j++) *reinterpret_cast<uint32_t *>(lds + tf_col_at(2 + j, 0, -4)) = d[j];   // dwords 30, 31
     }
     // their coded flags (the tags of the first unit of each record): block row -1 (columns 0..15), block column -1 (rows 0..3),
     // block (-1, -1)
@@ -374,7 +399,14 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   }
 
   // ---- 5. the cells: lane (kx, m) on corner (16t + kx, 4 sby + m) ---------------------------------------------
-  tf_cell(lds, R.self, R.stride, nh, nv, t, sby, lane & 15, lane >> 4, !(xb_up && lane < 16), L2, fy0, fy1);
+  // (cell row 0 below a tile of this band: rows 2..7, the two above them are the upper tile's; below another band's tile: only
+  //  the lower half's vertical edge, rows 6 and 7 -- the upper tile closes the rest as its 17th..20th pixel rows, see 6.)
+  const int top_lo = has_up ? (xb_up ? 6 : 2) : 0;
+  const uint32_t top_mask = xb_up ? 96u : 0xFFu;
+  {
+    const int m = lane >> 4;
+    tf_cell(lds, R.self, R.stride, nh, nv, t, sby, lane & 15, m, true, L2, fy0, fy1, m == 0 ? top_lo : 0, 8, m == 0 ? top_mask : 0xFFu, m == 3);
+  }
   THIP_TR(tr, 7);   // cells filtered, stores issued
 
   // ---- 6. a 17th cell column where the plane ends on this tile's right boundary (k = nh), a 5th cell row where the plane
@@ -383,26 +415,23 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   const bool extra_row = xb_dn || (!has_dn && (nv & 3) == 0);
   if (extra_col || extra_row) {
     if (xb_dn) {
-      // the tile below ran at the start of the launch: its first four rows (lanes 0..42) and the lower-left tile's corner
-      // (dwords 0..3 of its column: units 0 and 1, lanes 43 and 44), into image rows 36..39
+      // the tile below ran at the start of the launch: its first two rows (lanes 0..21) and the lower-left tile's corner
+      // (dwords 0, 1 of its column: unit 0, lane 22), into image rows 36, 37
       const uint8_t *const rec_dn = myrec + (ptrdiff_t)tiles_x * kTfRec, *const rec_dl = rec_dn - kTfRec;
       const uint8_t *src = nullptr;
       if (lane < kTfBotUnits) src = rec_dn + kTfTop + lane * kTfUnit;
-      else if (lane < kTfBotUnits + 2 && has_left) src = rec_dl + kTfRight + (lane - kTfBotUnits) * kTfUnit;
+      else if (lane == kTfBotUnits && has_left) src = rec_dl + kTfRight;
       const uint4 un = tf_fetch_unit(src, ep, B.fault);
       const uint32_t d[3] = {un.x, un.y, un.z};
       if (lane < kTfBotUnits) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
           const int idx = 3 * lane + j;
-          if (idx < 128) *reinterpret_cast<uint32_t *>(lds + tf_rows_at(idx, 36)) = d[j];
+          if (idx < 64) *reinterpret_cast<uint32_t *>(lds + tf_rows_at(idx, 36)) = d[j];
         }
-      } else if (lane < kTfBotUnits + 2) {
+      } else if (lane == kTfBotUnits) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const int idx = 3 * (lane - kTfBotUnits) + j;      // 0 .. 5
-          if (idx < 4) *reinterpret_cast<uint32_t *>(lds + tf_col_at(idx, 36, -4)) = d[j];
-        }
+        for (int j = 0; j < 2; j++) *reinterpret_cast<uint32_t *>(lds + tf_col_at(j, 36, -4)) = d[j];
       }
       // block row 4: the lower tile's first block row (its top units' tags), the lower-left tile's block (15, 0)
       const uint32_t w_dn = (uint32_t)__builtin_amdgcn_readlane((int)un.w, 0);
@@ -416,8 +445,10 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     // lanes 0..16: cells (lane, 4); lanes 32..35: cells (16, lane - 32)
     const bool rowl = lane <= 16, coll = lane >= 32 && lane < 36;
     const int kx = rowl ? lane : 16, m = rowl ? 4 : (lane - 32) & 3;
-    const bool act = rowl ? (extra_row && (lane < 16 || extra_col)) : (coll && extra_col && !(xb_up && m == 0));
-    tf_cell(lds, R.self, R.stride, nh, nv, t, sby, kx, m, act, L2, fy0, fy1);
+    const bool act = rowl ? (extra_row && (lane < 16 || extra_col)) : (coll && extra_col);
+    // row cells: pixel rows 30, 31 and, of another band's tile below, its rows 0 and 1 (28 and 29 went out with cell row 3)
+    tf_cell(lds, R.self, R.stride, nh, nv, t, sby, kx, m, act, L2, fy0, fy1, rowl ? 2 : (m == 0 ? top_lo : 0), rowl ? (xb_dn ? 6 : 8) : 8,
+            (!rowl && m == 0) ? top_mask : 0xFFu, !rowl && m == 3);
   }
   THIP_TR(tr, 8);
 }

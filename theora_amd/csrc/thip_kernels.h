@@ -158,20 +158,21 @@ __device__ __forceinline__ void lf_horz_pk(CellPix &C, int half, int L2) {
 }
 // vertical edge x = 4 of the cell, rows r0..r0+3: columns 2,3 are bytes 2,3 of lo, columns 4,5
 // bytes 0,1 of hi; two rows per register
+__device__ __forceinline__ void lf_vert_pair(uint32_t &lo0, uint32_t &lo1, uint32_t &hi0, uint32_t &hi1, int L2) {
+  const pk16 p2 = as_pk(__builtin_amdgcn_perm(lo1, lo0, 0x0c060c02u));
+  const pk16 p3 = as_pk(__builtin_amdgcn_perm(lo1, lo0, 0x0c070c03u));
+  const pk16 p4 = as_pk(__builtin_amdgcn_perm(hi1, hi0, 0x0c040c00u));
+  const pk16 p5 = as_pk(__builtin_amdgcn_perm(hi1, hi0, 0x0c050c01u));
+  const pk16 d = pk_lf_delta(p2, p3, p4, p5, L2);
+  const uint32_t n3 = sat_pk_u8(p3 + d), n4 = sat_pk_u8(p4 - d);   // byte 0: first row, byte 1: second row
+  lo0 = __builtin_amdgcn_perm(n3, lo0, 0x04020100u);               // byte 3 <- n3.byte0
+  lo1 = __builtin_amdgcn_perm(n3, lo1, 0x05020100u);
+  hi0 = __builtin_amdgcn_perm(n4, hi0, 0x03020104u);               // byte 0 <- n4.byte0
+  hi1 = __builtin_amdgcn_perm(n4, hi1, 0x03020105u);
+}
 __device__ __forceinline__ void lf_vert_pk(CellPix &C, int r0, int L2) {
 #pragma unroll
-  for (int r = r0; r < r0 + 4; r += 2) {
-    const pk16 p2 = as_pk(__builtin_amdgcn_perm(C.lo[r + 1], C.lo[r], 0x0c060c02u));
-    const pk16 p3 = as_pk(__builtin_amdgcn_perm(C.lo[r + 1], C.lo[r], 0x0c070c03u));
-    const pk16 p4 = as_pk(__builtin_amdgcn_perm(C.hi[r + 1], C.hi[r], 0x0c040c00u));
-    const pk16 p5 = as_pk(__builtin_amdgcn_perm(C.hi[r + 1], C.hi[r], 0x0c050c01u));
-    const pk16 d = pk_lf_delta(p2, p3, p4, p5, L2);
-    const uint32_t n3 = sat_pk_u8(p3 + d), n4 = sat_pk_u8(p4 - d);   // byte 0: row r, byte 1: row r+1
-    C.lo[r] = __builtin_amdgcn_perm(n3, C.lo[r], 0x04020100u);       // byte 3 <- n3.byte0
-    C.lo[r + 1] = __builtin_amdgcn_perm(n3, C.lo[r + 1], 0x05020100u);
-    C.hi[r] = __builtin_amdgcn_perm(n4, C.hi[r], 0x03020104u);       // byte 0 <- n4.byte0
-    C.hi[r + 1] = __builtin_amdgcn_perm(n4, C.hi[r + 1], 0x03020105u);
-  }
+  for (int r = r0; r < r0 + 4; r += 2) lf_vert_pair(C.lo[r], C.lo[r + 1], C.hi[r], C.hi[r + 1], L2);
 }
 // The operations of one cell in an order equivalent to T1..T8 with six slots instead of eight.  Only a vertical-edge and a
 // horizontal-edge operation share pixels (Vlo / Vhi with Hl / Hr); Vlo and Vhi, Hl and Hr never do.  A cell has at most one
