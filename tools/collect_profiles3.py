@@ -5,7 +5,8 @@ import csv, glob, json, os, shutil, sys
 SRC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03"
 DST = "profiles"
 for name in ("bench_default.json", "bench_twopass.json", "bench_1080p_single.json", "bench_1080p_single_gop16.json",
-             "bench_1080p_4streams.json", "lf_trace_dense.txt", "lf_trace_smooth.txt"):
+             "bench_1080p_4streams.json", "lf_trace_dense.txt", "lf_trace_smooth.txt", "hbm_ceiling.txt", "fe_stages_720p_dense.txt",
+             "fe_stages_720p_typical.txt"):
     p = os.path.join(SRC, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(DST, "r03_" + name))

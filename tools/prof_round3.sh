@@ -28,4 +28,10 @@ if [ -f tools/_build/libtheora_hip_alwaysstore.so ]; then
 fi
 python tools/lf_trace.py --content dense 2>&1 | grep -v amdgpu.ids > $o/lf_trace_dense.txt
 python tools/lf_trace.py --content smooth 2>&1 | grep -v amdgpu.ids > $o/lf_trace_smooth.txt
+# what the memory system gives: linear streams at several read:write mixes, and k_recon's access pattern (row-major and tiled frames)
+{ for m in 60 200 400; do timeout 120 tools/_build/hbm_ceiling $m; done; timeout 120 tools/_build/tile_pattern; } > $o/hbm_ceiling.txt 2>&1
+# the host side of th_decode_packetin by stage (option fe_prof)
+for k in dense typical; do
+  THIP_FE_PROF=1 timeout 300 python bench.py --mode e2e --e2e-size 720p --packets $k --no-native --loops 8 2>&1 | grep -v "^{\|amdgpu.ids" > $o/fe_stages_720p_$k.txt
+done
 tail -c 700 $o/bench_default.json
