@@ -299,11 +299,31 @@ def main_enc():
         assert torch.equal(v.reshape(-1), want_v)      # candidate-major = the order of the pair list above (checked against the oracle there)
         results.append(dict(kernel="oc_enc_frag_%s, motion-search form (thip_enc_frag_metric_sites_batch)" % op, units=src_offs.size,
                             unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=float("nan")))
+    # --- ... and over several frames in one call (a single frame is one round of waves: its launch ramp, first loads and tail
+    #     are a third of the call; an encoder with more than one stream to search hands them over together) -------------------
+    for F in (2, 4):
+        prevF = rng.integers(0, 256, (H * planes * F + 16, W + 16)).astype(np.uint8)
+        curF = np.clip(np.roll(prevF, (1, 3), (0, 1)).astype(np.int32) + rng.integers(-6, 7, prevF.shape), 0, 255).astype(np.uint8)
+        byF, bxF = np.mgrid[0:H * planes * F // 8, 0:W // 8]
+        baseF = ((byF * 8 + 8) * stride + bxF * 8 + 8).reshape(-1).astype(np.int32)
+        d_prevF, d_curF, d_baseF = torch.from_numpy(prevF).cuda(), torch.from_numpy(curF).cuda(), torch.from_numpy(baseF).cuda()
+        for op, bpu in (("sad", 132), ("satd", 136)):
+            call = lambda: theora_amd.enc_metric_sites_batch(op, d_curF, d_prevF, stride, d_baseF, d_baseF, sites)   # noqa: E731
+            t = timed(call)
+            v, dc = call()
+            ncpu = 20000
+            sel = rng.integers(0, baseF.size, ncpu)
+            for si, (dx, dy) in enumerate(sites[:3]):
+                wv, _ = oracle.enc_metric_batch(op, curF, prevF, stride, baseF[sel], (baseF[sel] + dy * stride + dx).astype(np.int32),
+                                                baseF[sel], 0)
+                assert np.array_equal(v.reshape(len(sites), -1)[si].cpu().numpy()[sel].view(np.uint32), wv)
+            results.append(dict(kernel="oc_enc_frag_%s, motion-search form, %d frames per call" % (op, F), units=baseF.size * len(sites),
+                                unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=float("nan")))
     for r in results:
         gbs = r["units"] * r["bytes_per_unit"] / r["seconds"] / 1e9
         print(json.dumps({
             "metric": r["kernel"] + " throughput", "value": round(r["units"] / r["seconds"] / 1e6, 1), "unit": "M%s/s" % r["unit"],
-            "config": {"workload": "1920x1088 4:4:4, %d %s per call, 9-site square pattern" % (r["units"], r["unit"])},
+            "config": {"workload": "1920x1088 4:4:4%s, %d %s per call, 9-site square pattern" % (" x %s frames" % r["kernel"].split(", ")[-1].split()[0] if "frames per call" in r["kernel"] else "", r["units"], r["unit"])},
             "ms_per_call": round(1e3 * r["seconds"], 4), "dtype": "u8/i16", "data": "synthetic", "bit_exact_vs_oracle": True,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "alg_bytes_per_unit": r["bytes_per_unit"]},

@@ -267,7 +267,7 @@ def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None,
     import torch
     n = src_offs.numel()
     out = torch.empty(n, dtype=torch.int32, device=src_offs.device)
-    dc = torch.zeros(n, dtype=torch.int32, device=src_offs.device)
+    dc = torch.empty(n, dtype=torch.int32, device=src_offs.device)   # (the kernel writes every element: 0 for the SAD family)
     _lib.check(_lib.load().thip_enc_frag_metric_batch(
         _lib.ENC_OPS[op], _ptr(out), _ptr(dc), _ptr(src_plane), _ptr(ref_plane), ystride, _ptr(src_offs),
         _ptr(ref_offs), _ptr(ref2_offs), thresh, n), "enc_frag_metric_batch")
@@ -276,13 +276,13 @@ def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None,
 
 def enc_metric_sites_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs, sites):
     """thip_enc_frag_metric_sites_batch: every block against the candidate positions `sites` = [(dx, dy), ...] around its
-    reference position.  Returns (values, dc), both [len(sites), nblocks] (candidate-major)."""
+    reference position.  Returns (values, dc), both [len(sites), nblocks] (candidate-major); dc is None for "sad"."""
     import numpy as np
     import torch
     n = src_offs.numel()
     ns = len(sites)
     out = torch.empty((ns, n), dtype=torch.int32, device=src_offs.device)
-    dc = torch.zeros((ns, n), dtype=torch.int32, device=src_offs.device)
+    dc = torch.empty((ns, n), dtype=torch.int32, device=src_offs.device) if op == "satd" else None
     dx = np.array([s[0] for s in sites], np.int8)
     dy = np.array([s[1] for s in sites], np.int8)
     _lib.check(_lib.load().thip_enc_frag_metric_sites_batch(
