@@ -205,6 +205,8 @@ struct thip_state {
   int *pp_var;
   uint8_t *pp_qis;          // device, 2 * nfrags: dc_qis, then frag_qi
   uint8_t *h_pp_qis;        // pinned staging of the same
+  uint32_t *pp_done;        // de-ringing: per group of blocks, the launch that finished it (k_pp_dering)
+  uint32_t pp_run;          // serial number of the last de-ringing launch
   hipEvent_t ev_pp;         // recorded behind the copy out of h_pp_qis
   int64_t pp_serial;        // frame_serial of the frame pp_frame was made from, -1 if none
   int pp_active[3];
@@ -617,6 +619,7 @@ void thip_state_free(thip_state *st) {
   if (st->pp_frame) (void)hipFree(st->pp_frame);
   if (st->pp_var) (void)hipFree(st->pp_var);
   if (st->pp_qis) (void)hipFree(st->pp_qis);
+  if (st->pp_done) (void)hipFree(st->pp_done);
   if (st->h_pp_qis) (void)hipHostFree(st->h_pp_qis);
   if (st->ev_pp) (void)hipEventDestroy(st->ev_pp);
   if (st->d_dc_in) (void)hipFree(st->d_dc_in);
@@ -1276,15 +1279,30 @@ int thip_state_postprocess(thip_state *st, int level, const uint8_t *dc_qis, con
   hipLaunchKernelGGL(k_pp_hedge, dim3((unsigned)((max_w / 4 + 63) / 64), (unsigned)(max_nv + 1), 3), dim3(64), 0, s, K);
   hipLaunchKernelGGL(k_pp_vedge, dim3((unsigned)((max_h + 63) / 64), 1, 3), dim3(64), 0, s, K);
   {
-    // one launch per anti-diagonal of the group grids, the three planes side by side (blockIdx.y)
+    // ONE launch: the anti-diagonals of the group grids along blockIdx.z (dispatched in that order), the three planes side
+    // by side along blockIdx.y; a group waits for its left and upper neighbours' entries in pp_done (thip_postproc.h)
     int nd = 0, gmax = 0;
+    size_t ngroups = 0, goff[3];
     for (int pli = 0; pli < 3; pli++) {
-      if (!K.dering[pli]) continue;
       const int gnx = (K.p[pli].nh + kPpGroup - 1) / kPpGroup, gny = (K.p[pli].nv + kPpGroup - 1) / kPpGroup;
+      goff[pli] = ngroups;
+      ngroups += (size_t)gnx * gny;
+      if (!K.dering[pli]) continue;
       nd = std::max(nd, gnx + gny - 1);
       gmax = std::max(gmax, std::min(gnx, gny));
     }
-    for (int d = 0; d < nd; d++) hipLaunchKernelGGL(k_pp_dering, dim3((unsigned)gmax, 3), dim3(64 * kPpGroup), 0, s, K, d);
+    if (nd > 65535) return THIP_EIMPL;
+    if (nd) {
+      if (!st->pp_done) {
+        HIP_TRY(hipMalloc((void **)&st->pp_done, ngroups * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(st->pp_done, 0, ngroups * sizeof(uint32_t), s));
+      }
+      for (int pli = 0; pli < 3; pli++) K.done[pli] = st->pp_done + goff[pli];
+      st->pp_run = st->pp_run == 0xFFFFFFFFu ? 1u : st->pp_run + 1u;
+      K.serial = st->pp_run;
+      K.fault = fault_word(st->device);
+      hipLaunchKernelGGL(k_pp_dering, dim3((unsigned)gmax, 3, (unsigned)nd), dim3(64 * kPpGroup), 0, s, K);
+    }
   }
   HIP_TRY(hipGetLastError());
   st->pp_serial = st->frame_serial;

@@ -15,10 +15,11 @@
 //   k_pp_dering  oc_dering_block (decode.c:1788-1890) works IN PLACE, block after block in raster order and,
 //                inside a block, pixel after pixel: a pixel sees the new value of its left and upper
 //                neighbours and the old value of its right and lower ones.  Blocks on an anti-diagonal are
-//                independent, and so are the pixels on an anti-diagonal of a block: one wave per group of 4x4
-//                blocks (its 32x32 pixels plus a one-pixel halo in LDS; the halo clamped to the plane is what
-//                the reference's border cases amount to), one launch per anti-diagonal of groups, 16 blocks in
-//                raster order inside, 15 pixel steps per pass.
+//                independent, and so are the pixels on an anti-diagonal of a block: one work group of eight waves
+//                per group of 8x8 blocks (its 64x64 pixels plus a one-pixel halo in LDS; the halo clamped to the
+//                plane is what the reference's border cases amount to), ONE launch for the three planes: a group
+//                waits for its left and upper neighbour groups (see k_pp_dering), 15 block diagonals inside,
+//                15 pixel steps per pass.
 // Variances (decode.c:1636-1637, :1679-1680) are integer sums: any order of addition gives the reference's.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -36,6 +37,10 @@ struct PpK {
   int active[3];        // plane is post-processed at this level
   int dering[3], strong[3];
   int dc_scale[64], sharp_mod[64];
+  // de-ringing as ONE launch: a group of blocks waits for its left and upper neighbour groups (k_pp_dering)
+  uint32_t *done[3];    // per plane, per group: the serial number of the launch that finished it
+  uint32_t serial;      // of this launch (never 0)
+  uint32_t *fault;      // the device's pinned host word: set when a bounded wait runs out
 };
 
 __device__ __forceinline__ int pp_abs(int v) { return v < 0 ? -v : v; }
@@ -174,9 +179,28 @@ __device__ __forceinline__ void pp_wave_sync() {
 // cases amount to) and walks the group's 15 block diagonals, wave w filtering the diagonal's block in block row w:
 // all 64 lanes work out, for their pixel, what does not depend on the order (the weights and the terms of the old
 // neighbours), then lanes 0..7 run the recurrence over the block's 15 pixel diagonals in registers, handing the new
-// values from lane to lane (DPP).  Groups on an anti-diagonal of the group grid are independent: one launch per group
-// diagonal, all planes.
-__global__ __launch_bounds__(64 * kPpGroup) void k_pp_dering(const PpK K, int d) {
+// values from lane to lane (DPP).  Groups on an anti-diagonal of the group grid are independent, and a group needs its left
+// and upper neighbour groups finished (their new border pixels; and they have read this group's old ones by then) and
+// nothing else.  ONE launch: grid (groups on the longest diagonal, 3 planes, diagonals), so that the dispatcher hands the
+// diagonals out in order -- blockIdx.z is the slowest index -- and a group's two predecessors were dispatched before it: it
+// waits for their entries in K.done to carry this launch's serial number (bounded; they depend on nothing that comes later,
+// so the wait cannot deadlock).  Producer and consumer may sit on different XCDs: a group writes its pixels through to
+// memory (sc0 sc1) before it sets its entry, and reads the two halo lines its predecessors wrote past its own L2.
+__device__ __forceinline__ uint32_t pp_load_through(const uint32_t *p) {
+  uint32_t v;
+  asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t pp_load_byte_through(const uint8_t *p) {
+  uint32_t v;
+  asm volatile("global_load_ubyte %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void pp_store_through(uint32_t *p, uint32_t v) {
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__global__ __launch_bounds__(64 * kPpGroup) void k_pp_dering(const PpK K) {
+  const int d = (int)blockIdx.z;
   const int pli = (int)blockIdx.y;
   if (!K.dering[pli]) return;
   const PpPlaneK &P = K.p[pli];
@@ -190,18 +214,39 @@ __global__ __launch_bounds__(64 * kPpGroup) void k_pp_dering(const PpK K, int d)
   const int tid = (int)threadIdx.x, lane = tid & 63, T = 64 * kPpGroup;
   const int b = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's block row in the group
   const int X0 = gx * kPpGroup * 8, Y0 = gy * kPpGroup * 8;
+  uint32_t *const done = K.done[pli];
+  // the predecessors: lanes 0 and 1 of the first wave look until both entries carry this launch's number
+  if (tid < 64) {
+    const uint32_t *src = nullptr;
+    if (tid == 0 && gx > 0) src = done + gy * gnx + gx - 1;
+    if (tid == 1 && gy > 0) src = done + (gy - 1) * gnx + gx;
+    bool ok = src == nullptr;
+    for (int spins = 0; spins < (1 << 22); spins++) {
+      if (!ok) ok = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == K.serial;
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok && K.fault) __hip_atomic_store(K.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
   // the region: rows Y0-1 .. Y0+64 clamped into the plane; the 64 pixels as dwords (plane widths are multiples of 8),
-  // the two halo columns as bytes, clamped
+  // the two halo columns as bytes, clamped.  The upper halo row and the left halo column are this launch's work (when
+  // those groups exist): read past L2.
   for (int i = tid; i < kPpRows * 16; i += T) {
     const int ry = i >> 4, c4 = (i & 15) * 4;
     const int y = min(max(Y0 - 1 + ry, 0), P.height - 1), x = X0 + c4;
-    if (x < P.width) *reinterpret_cast<uint32_t *>(s_reg + ry * kPpPitch + kPpX0 + c4) = *reinterpret_cast<const uint32_t *>(P.dst + (size_t)y * P.stride + x);
+    if (x < P.width) {
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(P.dst + (size_t)y * P.stride + x);
+      *reinterpret_cast<uint32_t *>(s_reg + ry * kPpPitch + kPpX0 + c4) = (ry == 0 && gy > 0) ? pp_load_through(src) : *src;
+    }
   }
   for (int i = tid; i < kPpRows * 2; i += T) {
     const int ry = i >> 1, right = i & 1;
     const int y = min(max(Y0 - 1 + ry, 0), P.height - 1);
     const int x = right ? min(X0 + kPpGroup * 8, P.width - 1) : max(X0 - 1, 0);
-    s_reg[ry * kPpPitch + (right ? kPpX0 + kPpGroup * 8 : kPpX0 - 1)] = P.dst[(size_t)y * P.stride + x];
+    const uint8_t *src = P.dst + (size_t)y * P.stride + x;
+    // (left column: the left group's; its row -1 the upper-left group's, finished before the left one could start)
+    s_reg[ry * kPpPitch + (right ? kPpX0 + kPpGroup * 8 : kPpX0 - 1)] = (!right && gx > 0) ? (uint8_t)pp_load_byte_through(src) : *src;
   }
   __syncthreads();
   const int strong_plane = K.strong[pli];
@@ -290,11 +335,16 @@ __global__ __launch_bounds__(64 * kPpGroup) void k_pp_dering(const PpK K, int d)
     }
     __syncthreads();   // the diagonal is done before the next one reads its borders
   }
-  if (!__syncthreads_or(any_touched)) return;
-  for (int i = tid; i < kPpGroup * 8 * 16; i += T) {
-    const int ry = i >> 4, c4 = (i & 15) * 4;
-    const int x = X0 + c4, y = Y0 + ry;
-    if (x < P.width && y < P.height)
-      *reinterpret_cast<uint32_t *>(P.dst + (size_t)y * P.stride + x) = *reinterpret_cast<const uint32_t *>(s_reg + (1 + ry) * kPpPitch + kPpX0 + c4);
+  if (__syncthreads_or(any_touched)) {
+    for (int i = tid; i < kPpGroup * 8 * 16; i += T) {
+      const int ry = i >> 4, c4 = (i & 15) * 4;
+      const int x = X0 + c4, y = Y0 + ry;
+      if (x < P.width && y < P.height)
+        pp_store_through(reinterpret_cast<uint32_t *>(P.dst + (size_t)y * P.stride + x),
+                         *reinterpret_cast<const uint32_t *>(s_reg + (1 + ry) * kPpPitch + kPpX0 + c4));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pixels have arrived
   }
+  __syncthreads();                                      // ... and every wave's
+  if (tid == 0) __hip_atomic_store(done + gy * gnx + gx, K.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
