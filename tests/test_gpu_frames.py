@@ -560,7 +560,7 @@ def _pp_case(rng, w, h, fmt, smooth):
 
 
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, PF_420), (48, 80, PF_444), (80, 64, PF_422), (16, 16, PF_420), (176, 144, PF_420),
-                                     (336, 272, PF_420), (1280, 720, PF_420)])
+                                     (336, 272, PF_420), (1280, 720, PF_420), (3840, 2160, PF_420)])
 def test_postprocessing(hip, w, h, fmt):
     """TH_DECCTL_SET_PPLEVEL's filters on the device (thip_state_postprocess: k_pp_hedge, k_pp_vedge, k_pp_dering;
     decode.c:1608-1957) against the oracle driven MCU by MCU as th_decode_packetin drives them: every level, flat
