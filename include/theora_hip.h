@@ -250,6 +250,10 @@ int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const
    coded: the coded fragments in coded order, plane after plane (ncoded per plane); frag_meta per coded fragment:
    refi | dequantisation table << 2 | (mvx & 255) << 8 | (mvy & 255) << 16 | plane << 24, table = (plane * 3 + qii)
    * 2 + qti into dequant[18][64] (zig-zag order, decode.c:1537-1538).  dc_quant[plane][qti] as the slot's _dc_quant.
+   dc: NULL -- the DC token values are un-predicted on the device (one wave per plane walks the chain of decode.c:1392-1500:
+   exact, and slow when neighbouring fragments differ in their reference frames) -- or the UN-PREDICTED DC value of every coded
+   fragment, in the order of `coded`: the caller has run oc_dec_dc_unpredict_mcu_plane itself (a few nanoseconds a fragment on
+   a host core) and the device does everything else.
    Returns 0, THIP_DUPFRAME (nothing coded), or THIP_EIMPL when a plane has more than 147456 coded fragments (beyond 4K) or
    more than 1024 fragment rows (the caller falls back to the slots); all pointers are host memory, read before return. */
 typedef struct thip_token_lists {
@@ -263,6 +267,7 @@ typedef struct thip_token_lists {
   int32_t ncoded[3];
   const uint16_t *dequant;     /* [18][64] */
   uint16_t dc_quant[3][2];
+  const int16_t *dc;           /* NULL, or the un-predicted DC of every coded fragment (order of `coded`) */
 } thip_token_lists;
 int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl);
 /* on != 0: the DC coefficient handed to thip_state_frag_recon (dct_coeffs[0]) is the value decoded from

@@ -144,8 +144,9 @@ typedef struct {
 #define TH_DECCTL_THIP_SET_DEVICE_TOKENS (0x7103)
 /* Extension: buf = int.  Non-zero: th_decode_packetin stops behind the entropy decoder -- the frame's token lists
    (one per plane and zig-zag index, decode.c:993-1139), the coded-fragment list and one word per fragment go to the
-   GPU, which finds each fragment's tokens, expands and dequantises them, un-predicts the DC values and decodes
-   the frame (thip_state_decode_token_lists).  Frames with a plane of more than 147456 coded fragments (beyond
+   GPU, which finds each fragment's tokens, expands and dequantises them and decodes the frame
+   (thip_state_decode_token_lists).  The DC prediction is still undone in th_decode_packetin (a chain through the plane in
+   raster order: nanoseconds a fragment on a host core) unless TH_DECCTL_THIP_SET_DEVICE_DC asks for the GPU there too.  Frames with a plane of more than 147456 coded fragments (beyond
    4K) keep the host path.  THIP_FE_DEVICE_LISTS=1 sets it for every new context. */
 #define TH_DECCTL_THIP_SET_DEVICE_LISTS (0x7104)
 typedef struct thip_slot_trace {

@@ -71,15 +71,17 @@ def test_packets_decode_bit_exact_with_token_expansion_on_the_gpu(hip, w, h, fmt
                       device_tokens=True) >= 3
 
 
+@pytest.mark.parametrize("device_dc", [False, True])
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (336, 32, 0),
                                      (1280, 720, 0), (1920, 1088, 0)])
-def test_packets_decode_bit_exact_with_the_token_lists_on_the_gpu(hip, w, h, fmt):
+def test_packets_decode_bit_exact_with_the_token_lists_on_the_gpu(hip, w, h, fmt, device_dc):
     """The same streams with everything behind the entropy decoder left to the backend
     (thip_state_decode_token_lists): the token lists per (plane, zig-zag index) go to the GPU as they are; which
     token belongs to which fragment (EOB runs crossing lists and planes included), expansion, dequantisation,
-    DC un-prediction, command words and coefficient slots are the device's (k_tok_assign, k_tok_slots,
-    k_tok_write, k_dc_unpredict)."""
-    assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_lists=True) >= 3
+    command words and coefficient slots are the device's (k_tok_assign, k_tok_slots, k_tok_write); the DC
+    prediction undone by the front end (thip_token_lists.dc) or, device_dc, on the GPU too (k_dc_wave)."""
+    assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_lists=True,
+                      device_dc=device_dc) >= 3
 
 
 def test_packets_decode_bit_exact_720p(hip):
@@ -88,14 +90,14 @@ def test_packets_decode_bit_exact_720p(hip):
     assert run_stream(hip, 1280, 720, 0, seed=720, nframes=4, kf=3, trees="matched") >= 3
 
 
-@pytest.mark.parametrize("mode", ["host", "device_dc", "device_lists"])
+@pytest.mark.parametrize("mode", ["host", "device_dc", "device_lists", "device_lists_dc"])
 def test_packets_decode_bit_exact_4k(hip, mode):
     """BASELINE.json's 4K size (3840x2160 4:2:0, 194 400 fragments) through th_decode_*: a key frame and two inter frames with
     matched Huffman trees, by the host front end, with the DC un-prediction on the GPU (k_dc_wave: 480 x 270 luma fragments, the
     64 rows in flight in LDS), and with TH_DECCTL_THIP_SET_DEVICE_LISTS: the token lists themselves on the GPU, the key frame's luma
     plane (129 600 coded fragments) with k_tok_assign's rank -> fragment map in memory instead of LDS."""
-    assert run_stream(hip, 3840, 2160, 0, seed=2160, nframes=3, kf=3, trees="matched", device_dc=(mode == "device_dc"),
-                      device_lists=(mode == "device_lists")) == 3
+    assert run_stream(hip, 3840, 2160, 0, seed=2160, nframes=3, kf=3, trees="matched", device_dc=mode in ("device_dc", "device_lists_dc"),
+                      device_lists=mode in ("device_lists", "device_lists_dc")) == 3
 
 
 def test_empty_packet_is_dup_frame(hip):

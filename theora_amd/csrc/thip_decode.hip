@@ -1696,9 +1696,9 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
   d.frame_type = tl->frame_type;
   d.flimit = tl->flimit;
   if (ncoded) {
-    // staging layout (16-byte sections): header tables | coded list | fragment words | dequantisation tables | tokens
+    // staging layout (16-byte sections): header tables | coded list | fragment words | the caller's DC values | dequantisation tables | tokens
     const size_t nf = ((size_t)st->nfrags + 7) & ~(size_t)7;   // (whole 16-byte units of every element size used)
-    const size_t o_cl = THIP_TL_HDR, o_meta = o_cl + nf, o_dq = o_meta + nf, o_tok = o_dq + 18 * 64 / 2;
+    const size_t o_cl = THIP_TL_HDR, o_meta = o_cl + nf, o_dcv = o_meta + nf, o_dq = o_dcv + nf / 2, o_tok = o_dq + 18 * 64 / 2;
     if (!st->tl_ready) {   // (each buffer on its own: a failed allocation is retried by the next call, nothing is used before all exist)
       st->tl_cap = (o_tok + (size_t)st->nfrags * 64 + 192 + 4) * 4;
       if (!st->h_tl) HIP_TRY(hipHostMalloc((void **)&st->h_tl, st->tl_cap, hipHostMallocDefault));
@@ -1724,6 +1724,7 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
     h[THIP_TL_DCQ + 6] = h[THIP_TL_DCQ + 7] = 0;
     memcpy(h + o_cl, tl->coded, (size_t)ncoded * 4);
     memcpy(h + o_meta, tl->frag_meta, (size_t)ncoded * 4);
+    if (tl->dc) memcpy(h + o_dcv, tl->dc, (size_t)ncoded * 2);
     memcpy(h + o_dq, tl->dequant, 18 * 64 * 2);
     memcpy(h + o_tok, tl->tokens, (size_t)tl->ntokens * 4);
     const size_t npos = (size_t)st->tiles.ntiles * THIP_TILE_FRAGS;
@@ -1753,6 +1754,7 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
     K.slot = st->d_tl_slot;
     K.arr = st->d_tl_arr;
     K.dc_in = st->d_dc_in;
+    K.dc_host = tl->dc ? reinterpret_cast<const int16_t *>(st->d_tl + o_dcv) : nullptr;
     K.info = st->d_info;
     K.slot0 = st->d_slot0;
     K.coeffs = reinterpret_cast<int4 *>(st->d_coeffs);
@@ -1765,13 +1767,13 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
       nmax = std::max(nmax, (int)tl->ncoded[p]);
     }
     if (nmax <= kTlLdsFrags) {
-      const int lds = ((nmax + 15) & ~15) + 2 * nmax + 16;
-      HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<false>), ((kTlLdsFrags + 15) & ~15) + 2 * kTlLdsFrags + 16, 2));
-      hipLaunchKernelGGL(k_tok_assign<false>, dim3(3), dim3(1024), (size_t)lds, s, K);
+      const int lds = 2 * ((nmax + 31) & ~31) + 2 * nmax + 16;
+      HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<false>), 2 * ((kTlLdsFrags + 31) & ~31) + 2 * kTlLdsFrags + 16, 2));
+      hipLaunchKernelGGL(k_tok_assign<false>, dim3(3), dim3(tl_threads(nmax)), (size_t)lds, s, K);
     } else {   // (4K luma: the rank -> fragment map in memory, the positions alone in LDS)
-      const int lds = ((nmax + 15) & ~15) + 16;
+      const int lds = ((nmax + 31) & ~31) + 16;
       HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<true>), kTlMaxFrags + 32, 1));
-      hipLaunchKernelGGL(k_tok_assign<true>, dim3(3), dim3(1024), (size_t)lds, s, K);
+      hipLaunchKernelGGL(k_tok_assign<true>, dim3(3), dim3(tl_threads(nmax)), (size_t)lds, s, K);
     }
     hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
     hipLaunchKernelGGL(k_tok_write, dim3((unsigned)(((size_t)ncoded * 8 + 255) / 256)), dim3(256), 0, s, K);
@@ -1781,7 +1783,7 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
     d.tile_slot0 = st->d_slot0;
     d.nslots = (int)ncoded;      // (an upper bound: the device knows the number)
     d.ncoded = (int)ncoded;
-    d.dc_tokens = st->d_dc_in;
+    d.dc_tokens = tl->dc ? nullptr : st->d_dc_in;
   }
   int32_t res = 0;
   thip_state *sp = st;

@@ -217,6 +217,7 @@ struct th_dec_ctx {
   bool device_lists;
   uint32_t arrivals[3][64];          // fragments open at every (plane, index) of the current frame
   std::vector<uint32_t> tl_tokens, tl_meta;
+  std::vector<int16_t> tl_dc;            // the un-predicted DC values in coded order (token-list path with the DC chain on the host)
   std::vector<int32_t> tl_coded;
   std::vector<uint8_t> mirror[3];
   th_stripe_callback stripe_cb;
@@ -1377,64 +1378,11 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     }
   }
   d->prof.lap(FE_TOKENS);
-  // ---- everything from here to the pictures on the device, when asked for and possible ------------------
-  bool lists_done = false;
-  if (d->device_lists && !d->trace) {
-    thip_token_lists tl;
-    memset(&tl, 0, sizeof(tl));
-    tl.frame_type = d->frame_type;
-    tl.flimit = d->setup.qp.lflims[d->qis[0]];
-    size_t nt = 0;
-    for (int p = 0; p < 3; p++)
-      for (int z = 0; z < 64; z++) nt += d->ntoks[p][z];
-    d->tl_tokens.resize(nt + 1);
-    uint32_t *o = d->tl_tokens.data();
-    size_t at = 0;
-    for (int p = 0; p < 3; p++)
-      for (int z = 0; z < 64; z++) {
-        tl.list_off[p][z] = (uint32_t)at;
-        tl.list_len[p][z] = (uint32_t)d->ntoks[p][z];
-        tl.eob_carry[p][z] = d->eob_carry[p][z];
-        tl.arrivals[p][z] = d->arrivals[p][z];
-        const Tok *t = d->toks[p][z].data();
-        for (size_t k = 0; k < d->ntoks[p][z]; k++) {
-          const uint32_t run = t[k].eob > 0xFFFFFFu ? 0xFFFFFFu : t[k].eob;   // (more than any plane the backend takes has)
-          o[at++] = t[k].eob ? (0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24)
-                             : ((uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16);
-        }
-      }
-    const size_t nc = d->cl_start[3];
-    d->tl_meta.resize(nc + 1);
-    d->tl_coded.resize(nc + 1);
-    for (int p = 0; p < 3; p++) {
-      tl.ncoded[p] = (int32_t)(d->cl_start[p + 1] - d->cl_start[p]);
-      for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
-        const int f = d->clist[ci];
-        const uint32_t qti = d->mbmode_of_frag[f] != MODE_INTRA;
-        d->tl_coded[ci] = f;
-        d->tl_meta[ci] = (uint32_t)d->refi[f] | ((uint32_t)(p * 3 + d->qii[f]) * 2u + qti) << 2 |
-                         ((uint32_t)d->mvx[f] & 0xFFu) << 8 | ((uint32_t)d->mvy[f] & 0xFFu) << 16 | (uint32_t)p << 24;
-      }
-      for (int qti = 0; qti < 2; qti++) tl.dc_quant[p][qti] = d->dequant[(((size_t)d->qis[0] * 3 + p) * 2 + qti) * 64];
-    }
-    uint16_t dq[18 * 64];
-    memset(dq, 0, sizeof(dq));
-    for (int p = 0; p < 3; p++)
-      for (int qii = 0; qii < d->nqis; qii++)
-        for (int qti = 0; qti < 2; qti++)
-          memcpy(dq + ((p * 3 + qii) * 2 + qti) * 64, &d->dequant[(((size_t)d->qis[qii] * 3 + p) * 2 + qti) * 64], 128);
-    tl.tokens = d->tl_tokens.data();
-    tl.ntokens = (int64_t)nt;
-    tl.coded = d->tl_coded.data();
-    tl.frag_meta = d->tl_meta.data();
-    tl.dequant = dq;
-    const int lrc = thip_state_decode_token_lists(d->hip, &tl);
-    if (lrc >= 0) lists_done = true;
-    else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
-    d->prof.lap(FE_EXPAND);
-  }
-  if (!lists_done) {
   // ---- 7.8 undo DC prediction (the DC token values are the first coefficient of each block) -----------
+  // (a function of its own: the token-list path below wants the values before it hands the frame over)
+  bool dc_done = false;
+  auto undo_dc = [&]() {
+    dc_done = true;
   // first pull the DC values out of the zzi == 0 lists: token by token over the coded blocks in order
   {
     for (int p = 0; p < 3; p++) {
@@ -1508,6 +1456,75 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
       }
     }
   }
+  };
+  // ---- everything from here to the pictures on the device, when asked for and possible ------------------
+  bool lists_done = false;
+  if (d->device_lists && !d->trace) {
+    thip_token_lists tl;
+    memset(&tl, 0, sizeof(tl));
+    tl.frame_type = d->frame_type;
+    tl.flimit = d->setup.qp.lflims[d->qis[0]];
+    size_t nt = 0;
+    for (int p = 0; p < 3; p++)
+      for (int z = 0; z < 64; z++) nt += d->ntoks[p][z];
+    d->tl_tokens.resize(nt + 1);
+    uint32_t *o = d->tl_tokens.data();
+    size_t at = 0;
+    for (int p = 0; p < 3; p++)
+      for (int z = 0; z < 64; z++) {
+        tl.list_off[p][z] = (uint32_t)at;
+        tl.list_len[p][z] = (uint32_t)d->ntoks[p][z];
+        tl.eob_carry[p][z] = d->eob_carry[p][z];
+        tl.arrivals[p][z] = d->arrivals[p][z];
+        const Tok *t = d->toks[p][z].data();
+        for (size_t k = 0; k < d->ntoks[p][z]; k++) {
+          const uint32_t run = t[k].eob > 0xFFFFFFu ? 0xFFFFFFu : t[k].eob;   // (more than any plane the backend takes has)
+          o[at++] = t[k].eob ? (0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24)
+                             : ((uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16);
+        }
+      }
+    const size_t nc = d->cl_start[3];
+    d->tl_meta.resize(nc + 1);
+    d->tl_coded.resize(nc + 1);
+    // DC un-prediction stays on this side unless the device is asked for that too (option fe_device_dc): a chain through the
+    // plane in raster order, a few nanoseconds a fragment here, a dependent step of a wave there
+    if (!d->device_dc) {
+      d->prof.lap(FE_EXPAND);
+      undo_dc();
+      d->prof.lap(FE_DC);
+      d->tl_dc.resize(nc + 1);
+      for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
+      tl.dc = d->tl_dc.data();
+    }
+    for (int p = 0; p < 3; p++) {
+      tl.ncoded[p] = (int32_t)(d->cl_start[p + 1] - d->cl_start[p]);
+      for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
+        const int f = d->clist[ci];
+        const uint32_t qti = d->mbmode_of_frag[f] != MODE_INTRA;
+        d->tl_coded[ci] = f;
+        d->tl_meta[ci] = (uint32_t)d->refi[f] | ((uint32_t)(p * 3 + d->qii[f]) * 2u + qti) << 2 |
+                         ((uint32_t)d->mvx[f] & 0xFFu) << 8 | ((uint32_t)d->mvy[f] & 0xFFu) << 16 | (uint32_t)p << 24;
+      }
+      for (int qti = 0; qti < 2; qti++) tl.dc_quant[p][qti] = d->dequant[(((size_t)d->qis[0] * 3 + p) * 2 + qti) * 64];
+    }
+    uint16_t dq[18 * 64];
+    memset(dq, 0, sizeof(dq));
+    for (int p = 0; p < 3; p++)
+      for (int qii = 0; qii < d->nqis; qii++)
+        for (int qti = 0; qti < 2; qti++)
+          memcpy(dq + ((p * 3 + qii) * 2 + qti) * 64, &d->dequant[(((size_t)d->qis[qii] * 3 + p) * 2 + qti) * 64], 128);
+    tl.tokens = d->tl_tokens.data();
+    tl.ntokens = (int64_t)nt;
+    tl.coded = d->tl_coded.data();
+    tl.frag_meta = d->tl_meta.data();
+    tl.dequant = dq;
+    const int lrc = thip_state_decode_token_lists(d->hip, &tl);
+    if (lrc >= 0) lists_done = true;
+    else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
+    d->prof.lap(FE_EXPAND);
+  }
+  if (!lists_done) {
+  if (!dc_done) undo_dc();
   d->prof.lap(FE_DC);
   // ---- 7.9 reconstruction through the backend's vtable slots -------------------------------------------
   int rc = 0;

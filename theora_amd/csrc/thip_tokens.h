@@ -47,6 +47,7 @@ struct TlK {
   uint8_t *last_zzi;        // [ncoded]
   uint32_t *slot;           // [ncoded] coefficient slot of a fragment that has one
   int16_t *dc_in;           // [nfrags] DC token values, fragment order (zeroed)
+  const int16_t *dc_host;   // [ncoded] un-predicted DC values from the caller, coded order, or null (then dc_in is un-predicted on the device)
   uint32_t *info;           // command words (zeroed)
   uint32_t *slot0;          // first slot of every tile (zeroed)
   uint32_t *arr;            // [ncoded] scratch: rank -> fragment map of planes too large to keep it in LDS
@@ -84,81 +85,274 @@ __device__ __forceinline__ int tl_nat(int zzi) {   // natural-order position of 
   return T[zzi];
 }
 
-// One work group per plane.  LDS: pos[n] bytes (the index a fragment arrives at next; 64 + z = finished, the
-// last index it arrived at was z), arr[n] 16-bit (rank among this index's arrivals -> fragment), 16 dwords.
+// One work group per plane.  LDS: pos[] bytes (the index a fragment arrives at next; 64 + z = finished, the
+// last index it arrived at was z; 0xFF padding up to whole dwords), qs[n] bytes (its dequantisation table), arr[n] 16-bit
+// (rank among this index's arrivals -> fragment), the header tables, 2 x 2 x 16 dwords for the scans.
 // BIG: planes of more than kTlLdsFrags coded fragments (4K luma: 129 600) keep the rank -> fragment map in memory instead
-// (K.arr, 32-bit entries, read back past the L1 after the work-group barrier): one byte of LDS per fragment.
-constexpr int kTlLdsFrags = 49152;   // per plane with the map in LDS: 3 bytes of LDS per fragment
+// (K.arr, 32-bit entries, read back past the L1 after the work-group barrier) and read the table number from the fragment
+// words: one byte of LDS per fragment.
+// The kernel lives on ONE compute unit and is bound by the instructions that unit can issue, so a round (one index) is
+// kept short: a thread looks at its fragments four at a time (`pos` as dwords, the bytes equal to z found with three
+// integer operations and counted with one), both prefix sums of the index share one scan, done in registers (DPP) inside a
+// wave and by sixteen lanes across the waves, the list's header words are in LDS, a thread's first tokens of the NEXT list are
+// requested before it serves this list's and summed after -- three work-group barriers, no exposed memory round trip -- and
+// the work group is no larger than the plane needs (the per-round cost of a wave that has nothing to do is the same as that
+// of one that has): 256 threads up to 16 K coded fragments, 512 up to 48 K, 1024 beyond.
+constexpr int kTlLdsFrags = 36864;   // per plane with the map in LDS: 4 bytes of LDS per fragment (1080p luma: 32 640)
 constexpr int kTlMaxFrags = 147456;  // per plane at all: 1 byte of LDS per fragment
+constexpr int kTlPrefetch = 4;       // tokens of the next list a thread asks for a round ahead
+__host__ __device__ inline int tl_threads(int nmax) { return nmax <= 16384 ? 256 : (nmax <= 49152 ? 512 : 1024); }   // (a thread: up to kTlGroups x 32 fragments)
+
+// Work-group barrier that waits for this wave's LDS traffic only.  __syncthreads() also waits for every global store to be
+// acknowledged -- a round trip per round for stores (the coefficients, the DC values) nobody in this kernel reads back.
+__device__ __forceinline__ void tl_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// inclusive prefix sum over the 64 lanes of a wave, in registers (row_shr 1, 2, 4, 8 inside the rows of 16, then the last lane
+// of a row to the rows behind it)
+__device__ __forceinline__ uint32_t tl_wave_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+// exclusive prefix sums of two values at once over the work group (at most 16 waves); scr: 2 x 16 dwords nobody else writes
+// before the next barrier
+__device__ __forceinline__ void tl_exscan2(uint32_t a, uint32_t b, uint32_t (*scr)[16], uint32_t &ea, uint32_t &ta, uint32_t &eb) {
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), nw = (int)blockDim.x >> 6;
+  const uint32_t ia = tl_wave_scan(a), ib = tl_wave_scan(b);
+  if (lane == 63) {
+    scr[0][wave] = ia;
+    scr[1][wave] = ib;
+  }
+  tl_barrier_lds();
+  uint32_t wa = lane < nw ? scr[0][lane & 15] : 0u, wb = lane < nw ? scr[1][lane & 15] : 0u;   // the waves' totals, lanes 0..15
+  wa += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wa, 0x111, 0xF, 0xF, true);
+  wb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wb, 0x111, 0xF, 0xF, true);
+  wa += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wa, 0x112, 0xF, 0xF, true);
+  wb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wb, 0x112, 0xF, 0xF, true);
+  wa += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wa, 0x114, 0xF, 0xF, true);
+  wb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wb, 0x114, 0xF, 0xF, true);
+  wa += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wa, 0x118, 0xF, 0xF, true);
+  wb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wb, 0x118, 0xF, 0xF, true);
+  const uint32_t upto_a = (uint32_t)__builtin_amdgcn_readlane((int)wa, wave), upto_b = (uint32_t)__builtin_amdgcn_readlane((int)wb, wave);
+  const uint32_t mine_a = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63), mine_b = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+  ta = (uint32_t)__builtin_amdgcn_readlane((int)wa, 15);
+  ea = upto_a - mine_a + ia - a;
+  eb = upto_b - mine_b + ib - b;
+}
+__device__ __forceinline__ uint32_t tl_cost(uint32_t tk) { return (tk & THIP_TOK_EOB) ? ((tk & 0xFFFFu) | (tk >> 24) << 16) : 1u; }
+// bit 7 of every byte of w that equals the byte in zz (zz = z * 0x01010101)
+__device__ __forceinline__ uint32_t tl_eq_bytes(uint32_t w, uint32_t zz) {
+  const uint32_t x = w ^ zz;
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+
+constexpr int kTlGroups = 5;         // groups of 32 fragments a thread looks after, at most (147 456 fragments / 32 / 1024 threads)
+// one bit per fragment of a group of 32: set where the byte of `pos` equals z (zz = z * 0x01010101)
+__device__ __forceinline__ uint32_t tl_group_mask(const uint32_t *posw, int g, uint32_t zz) {
+  const uint4 a = *reinterpret_cast<const uint4 *>(posw + 8 * g), b = *reinterpret_cast<const uint4 *>(posw + 8 * g + 4);
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t m = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) m |= ((((tl_eq_bytes(w[j], zz) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * j);   // bits 0, 8, 16, 24 -> a nibble
+  return m;
+}
+
 template <bool BIG>
 __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_tl[];
   __shared__ uint16_t s_dq[18 * 64];
-  __shared__ uint32_t s_scr[16];
+  __shared__ uint32_t s_scr[2][2][16];
+  __shared__ uint32_t s_hdr[4][64];                      // first token, tokens, carry, arrivals of every list of the plane
+  __shared__ uint8_t s_nat[64];                          // zig-zag index -> natural position
   const int p = (int)blockIdx.x, n = K.p[p].n, c0 = K.p[p].c0;
   if (n == 0) return;
+  const int n32 = (n + 31) & ~31;
   uint8_t *pos = s_tl;
-  uint16_t *arr = reinterpret_cast<uint16_t *>(s_tl + ((n + 15) & ~15));
+  uint32_t *posw = reinterpret_cast<uint32_t *>(s_tl);
+  uint8_t *qsl = s_tl + n32;                             // (!BIG)
+  uint16_t *arr = reinterpret_cast<uint16_t *>(s_tl + 2 * n32);
   uint32_t *garr = K.arr + c0;
   const int t = (int)threadIdx.x, T = (int)blockDim.x;
+  const int lgT = 31 - __clz(T);                         // (the work group is 256, 512 or 1024 threads: shifts, not divisions)
   for (int i = t; i < 18 * 64; i += T) s_dq[i] = K.dq[i];
-  const int Kf = (n + T - 1) / T;
-  const int f0 = min(t * Kf, n), f1 = min(f0 + Kf, n);   // this thread's fragments
-  for (int i = f0; i < f1; i++) pos[i] = 0;
+  if (t < 256) s_hdr[t >> 6][t & 63] = K.hdr[(t >> 6) * 192 + p * 64 + (t & 63)];   // THIP_TL_OFF / _LEN / _CARRY / _ARRIVE
+  if (t < 64) s_nat[t] = (uint8_t)tl_nat(t);
+  const int G = n32 >> 5;                                // groups of 32 fragments
+  const int Kg = (G + T - 1) >> lgT;                     // <= kTlGroups
+  const int g0 = min(t * Kg, G), g1 = min(g0 + Kg, G);   // this thread's fragments: 32 g0 .. 32 g1 - 1
+  for (int i = t; i < n32 / 4; i += T) {
+    const int left = n - 4 * i;                          // fragments in this dword (the rest is padding that never matches)
+    posw[i] = left >= 4 ? 0u : (left <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8 * left)));
+  }
+  if (!BIG)
+    for (int i = t; i < n; i += T) qsl[i] = (uint8_t)((K.meta[c0 + i] >> 2) & 31u);
   __syncthreads();
-  const uint32_t *hdr = K.hdr + p * 64;
-  for (int z = 0; z < 64; z++) {
-    if (hdr[THIP_TL_ARRIVE + z] == 0) continue;          // (uniform) nobody gets this far
-    // ---- the arrivals at z, ranked in coded order --------------------------------------------------
-    uint32_t cnt = 0;
-    for (int i = f0; i < f1; i++) cnt += pos[i] == z ? 1u : 0u;
-    uint32_t narr;
-    uint32_t r = tl_exscan(cnt, s_scr, narr);
-    for (int i = f0; i < f1; i++)
-      if (pos[i] == z) {
-        if (BIG) garr[r++] = (uint32_t)i;
+  // this thread's share [j0, j1) of a list's tokens
+  auto share = [&](int z, uint32_t &off, uint32_t &j0, uint32_t &j1) {
+    off = s_hdr[0][z];
+    const uint32_t m = s_hdr[1][z];
+    const uint32_t Kt = (m + (uint32_t)T - 1u) >> lgT;
+    j0 = min((uint32_t)t * Kt, m);
+    j1 = min(j0 + Kt, m);
+  };
+#ifdef THIP_TL_PROF
+  unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = 0, t_begin = 0;
+  int rounds = 0;
+#define TLP(k) { unsigned long long now_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); tp[k] += now_ - tq; tq = now_; }
+#else
+#define TLP(k)
+#endif
+  // Four tokens served: the arrival of rank S gets a token that is not an EOB token.  Stage by stage for the four at once,
+  // so that the dependent LDS reads of one token (rank -> fragment -> table -> factor) overlap with the others'.
+  auto serve4 = [&](const uint32_t tk[kTlPrefetch], uint32_t jb, uint32_t jend, int z, uint32_t &S, uint32_t narr) {
+    bool live[kTlPrefetch];
+    uint32_t Sq[kTlPrefetch];
+#pragma unroll
+    for (int q = 0; q < kTlPrefetch; q++) {
+      const bool valid = jb + (uint32_t)q < jend;
+      const bool eob = (tk[q] & THIP_TOK_EOB) != 0;
+      Sq[q] = S;
+      live[q] = valid && !eob && S < narr;               // (a list longer than its arrivals: a malformed stream; the surplus is ignored)
+      S += valid ? tl_cost(tk[q]) : 0u;
+    }
+    int fi[kTlPrefetch];
+#pragma unroll
+    for (int q = 0; q < kTlPrefetch; q++)
+      fi[q] = !live[q] ? 0 : (BIG ? (int)__hip_atomic_load(garr + Sq[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (int)arr[Sq[q]]);
+    asm volatile("" ::"v"(fi[0]), "v"(fi[1]), "v"(fi[2]), "v"(fi[3]));
+    TLP(6)
+    uint32_t qs[kTlPrefetch], nat[kTlPrefetch];
+    int at[kTlPrefetch], cf[kTlPrefetch];
+#pragma unroll
+    for (int q = 0; q < kTlPrefetch; q++) {
+      at[q] = z + (int)((tk[q] >> 16) & 127u);
+      qs[q] = !live[q] ? 0u : (BIG ? (K.meta[c0 + fi[q]] >> 2) & 31u : (uint32_t)qsl[fi[q]]);
+      nat[q] = s_nat[at[q] & 63];
+      cf[q] = (live[q] && at[q] == 0 && (tk[q] & 0xFFFFu)) ? K.clist[c0 + fi[q]] : 0;   // (DC tokens: the fragment's number)
+    }
+    int fac[kTlPrefetch];
+#pragma unroll
+    for (int q = 0; q < kTlPrefetch; q++) fac[q] = (int)s_dq[qs[q] * 64 + (uint32_t)(at[q] & 63)];
+    asm volatile("" ::"v"(fac[0]), "v"(fac[1]), "v"(fac[2]), "v"(fac[3]), "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]));
+    TLP(7)
+#pragma unroll
+    for (int q = 0; q < kTlPrefetch; q++) {
+      if (!live[q]) continue;
+      const int value = (int)(int16_t)(tk[q] & 0xFFFFu);
+      if (value != 0) {
+        if (at[q] == 0) K.dc_in[cf[q]] = (int16_t)value;   // the DC token value (un-predicted later, or the caller's is used)
+        else if (at[q] <= 63) K.tmp[(size_t)(c0 + fi[q]) * 64 + nat[q]] = (int16_t)(value * fac[q]);   // decode.c:1573
+      }
+      const int np = at[q] + (value != 0 ? 1 : 0);
+      pos[fi[q]] = (uint8_t)(np < 64 ? np : 64 + z);   // (np <= 63 + 64)
+    }
+    TLP(8)
+  };
+  int z = 0;
+  while (z < 64 && s_hdr[3][z] == 0) z++;                // (uniform) the first index anybody arrives at
+  uint32_t off = 0, j0 = 0, j1 = 0, use = 0, cur[kTlPrefetch];
+#pragma unroll
+  for (int q = 0; q < kTlPrefetch; q++) cur[q] = 0u;
+  if (z < 64) {
+    share(z, off, j0, j1);
+#pragma unroll
+    for (int q = 0; q < kTlPrefetch; q++) cur[q] = j0 + (uint32_t)q < j1 ? K.tok[off + j0 + (uint32_t)q] : 0u;
+#pragma unroll
+    for (int q = 0; q < kTlPrefetch; q++) use += j0 + (uint32_t)q < j1 ? tl_cost(cur[q]) : 0u;
+    for (uint32_t j = j0 + kTlPrefetch; j < j1; j++) use += tl_cost(K.tok[off + j]);
+  }
+  int buf = 0;
+#ifdef THIP_TL_PROF
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq));
+  t_begin = tq;
+#endif
+  while (z < 64) {
+    int zn = z + 1;
+    while (zn < 64 && s_hdr[3][zn] == 0) zn++;
+    // ---- the next list's first tokens are asked for now; they are looked at before this round's first store goes out (this
+    //      chip counts loads and stores in one in-order counter: a load behind a store waits for the store's acknowledgement) ----
+    uint32_t offn = 0, j0n = 0, j1n = 0, nx[kTlPrefetch];
+#pragma unroll
+    for (int q = 0; q < kTlPrefetch; q++) nx[q] = 0u;
+    if (zn < 64) {
+      share(zn, offn, j0n, j1n);
+#pragma unroll
+      for (int q = 0; q < kTlPrefetch; q++)
+        if (j0n + (uint32_t)q < j1n) nx[q] = K.tok[offn + j0n + (uint32_t)q];
+    }
+    // ---- the arrivals at z, ranked in coded order; what the tokens before this thread's consume ----------------
+    const uint32_t zz = (uint32_t)z * 0x01010101u;
+    uint32_t cnt = 0, gm[kTlGroups];
+#pragma unroll
+    for (int k = 0; k < kTlGroups; k++) {
+      gm[k] = g0 + k < g1 ? tl_group_mask(posw, g0 + k, zz) : 0u;
+      cnt += (uint32_t)__popc(gm[k]);
+    }
+    uint32_t r, narr, S;
+    TLP(0)
+    tl_exscan2(cnt, use, s_scr[buf], r, narr, S);
+    TLP(1)
+    buf ^= 1;
+    S += s_hdr[2][z];
+#pragma unroll
+    for (int k = 0; k < kTlGroups; k++) {
+      uint32_t m = gm[k];
+      const uint32_t base = (uint32_t)(g0 + k) * 32u;
+      while (m) {
+        const uint32_t i = base + (uint32_t)(__ffs((int)m) - 1);
+        m &= m - 1u;
+        if (BIG) garr[r++] = i;
         else arr[r++] = (uint16_t)i;
       }
-    // ---- what the tokens of the list consume ----------------------------------------------------------
-    const uint32_t off = hdr[THIP_TL_OFF + z], m = hdr[THIP_TL_LEN + z], carry = hdr[THIP_TL_CARRY + z];
-    const uint32_t Kt = (m + (uint32_t)T - 1u) / (uint32_t)T;
-    const uint32_t j0 = min((uint32_t)t * Kt, m), j1 = min(j0 + Kt, m);
-    uint32_t use = 0;
-    for (uint32_t j = j0; j < j1; j++) {
-      const uint32_t tk = K.tok[off + j];
-      use += (tk & THIP_TOK_EOB) ? ((tk & 0xFFFFu) | (tk >> 24) << 16) : 1u;
     }
-    uint32_t dummy;
-    if (BIG) __threadfence_block();                      // the map's stores are done before the barriers below let anyone read it
-    uint32_t S = carry + tl_exscan(use, s_scr, dummy);   // (its barriers also publish arr)
-    // ---- every token that is not an EOB token serves the arrival of rank S ------------------------------
-    for (uint32_t j = j0; j < j1; j++) {
-      const uint32_t tk = K.tok[off + j];
-      if (tk & THIP_TOK_EOB) {
-        S += (tk & 0xFFFFu) | (tk >> 24) << 16;
-        continue;
-      }
-      if (S < narr) {   // (a list longer than its arrivals: a malformed stream; the surplus is ignored)
-        const int i = BIG ? (int)__hip_atomic_load(garr + S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (int)arr[S];
-        const int skip = (int)((tk >> 16) & 127u);
-        const int value = (int)(int16_t)(tk & 0xFFFFu);
-        const int at = z + skip;
-        if (value != 0) {
-          if (at == 0) K.dc_in[K.clist[c0 + i]] = (int16_t)value;   // the DC token value (un-predicted later)
-          else if (at <= 63) {
-            const uint32_t qs = (K.meta[c0 + i] >> 2) & 31u;
-            K.tmp[(size_t)(c0 + i) * 64 + tl_nat(at)] = (int16_t)(value * (int)s_dq[qs * 64 + at]);   // decode.c:1573
-          }
-        }
-        const int np = at + (value != 0 ? 1 : 0);
-        pos[i] = (uint8_t)(np < 64 ? np : 64 + z);   // (np <= 63 + 64)
-      }
-      S += 1;
+    if (BIG) {
+      __threadfence_block();                             // the map's stores are done before the barrier lets anyone read it
+      __syncthreads();
+    } else {
+      tl_barrier_lds();                                  // the map is there
     }
-    __syncthreads();   // pos as the next index finds it
+    TLP(2)
+    // ---- the next list's share of the scan ------------------------------------------------------------------
+    uint32_t usen = 0;
+    if (zn < 64) {
+#pragma unroll
+      for (int q = 0; q < kTlPrefetch; q++) usen += j0n + (uint32_t)q < j1n ? tl_cost(nx[q]) : 0u;
+      for (uint32_t j = j0n + kTlPrefetch; j < j1n; j++) usen += tl_cost(K.tok[offn + j]);
+    }
+    TLP(3)
+    // ---- the tokens of this list, four at a time (the first four have been in registers since the round before) ---------
+    serve4(cur, j0, j1, z, S, narr);
+    for (uint32_t jb = j0 + kTlPrefetch; jb < j1; jb += kTlPrefetch) {   // (long lists: four loads, then their stores)
+      uint32_t tk[kTlPrefetch];
+#pragma unroll
+      for (int q = 0; q < kTlPrefetch; q++) tk[q] = jb + (uint32_t)q < j1 ? K.tok[off + jb + (uint32_t)q] : 0u;
+      serve4(tk, jb, j1, z, S, narr);
+    }
+    TLP(4)
+    tl_barrier_lds();  // pos as the next index finds it
+    TLP(5)
+#ifdef THIP_TL_PROF
+    rounds++;
+#endif
+    z = zn;
+    off = offn;
+    j0 = j0n;
+    j1 = j1n;
+    use = usen;
+#pragma unroll
+    for (int q = 0; q < kTlPrefetch; q++) cur[q] = nx[q];
   }
+#ifdef THIP_TL_PROF
+  if (t == 0 && p == 0)
+    printf("k_tok_assign plane 0: n %d T %d rounds %d | setup %llu | count %llu scan %llu rank+barrier %llu nextuse %llu serve-rest %llu endbarrier %llu | serve: ranks %llu tables %llu stores %llu (10 ns ticks)\n", n, T, rounds,
+           0ull, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8]);
+#endif
   // last_zzi (decode.c:1545: the index the fragment's last token -- or the run that ended it -- was met at)
-  for (int i = f0; i < f1; i++) K.last_zzi[c0 + i] = (uint8_t)(pos[i] < 64 ? pos[i] : pos[i] - 64);
+  for (int i = t; i < n; i += T) K.last_zzi[c0 + i] = (uint8_t)(pos[i] < 64 ? pos[i] : pos[i] - 64);
 }
 
 // Slots are handed out in coded order to the fragments that need one (last_zzi >= 2, state.c:967).  One group.
@@ -194,13 +388,16 @@ __global__ __launch_bounds__(256) void k_tok_write(const TlK K) {
                      ((m >> 8) & 0xFFu) << THIP_INFO_MVX_SHIFT | ((m >> 16) & 0xFFu) << THIP_INFO_MVY_SHIFT;
     if (lz < 2) flags |= THIP_INFO_DC_ONLY;
     K.info[2 * (size_t)pos] = flags;
-    K.info[2 * (size_t)pos + 1] = dcq << 16;   // (the DC itself comes from the DC array: StreamK::dc)
+    // (the DC itself comes from the DC array, StreamK::dc, unless the caller has un-predicted it: then it travels as it does
+    //  from the slots -- in the command word of a block without coefficients, as coefficient 0 of one with)
+    K.info[2 * (size_t)pos + 1] = dcq << 16 | (K.dc_host ? (uint32_t)(uint16_t)K.dc_host[i] : 0u);
     // the first coded fragment of a tile: the slots handed out before it are the tile's first slot number
     if (i == 0 || (K.frag_pos[K.clist[i - 1]] >> 6) != (pos >> 6)) K.slot0[pos >> 6] = slot;
   }
   if (lz >= 2) {
     const int j = q >> 1, h = q & 1;
-    const uint2 a = *reinterpret_cast<const uint2 *>(K.tmp + (size_t)i * 64 + (2 * j) * 8 + 4 * h);
+    uint2 a = *reinterpret_cast<const uint2 *>(K.tmp + (size_t)i * 64 + (2 * j) * 8 + 4 * h);
+    if (q == 0 && K.dc_host) a.x = (a.x & 0xFFFF0000u) | (uint32_t)(uint16_t)K.dc_host[i];
     const uint2 b = *reinterpret_cast<const uint2 *>(K.tmp + (size_t)i * 64 + (2 * j + 1) * 8 + 4 * h);
     int4 o;
     o.x = (int)__builtin_amdgcn_perm(b.x, a.x, 0x05040100u);   // {a0, b0}
