@@ -171,23 +171,33 @@ __device__ __forceinline__ void tf_cell(const uint8_t *lds, uint8_t *plane, int 
   const bool lo_ok = active && k >= 1, hi_ok = active && k <= nh - 1;
   const bool up_ok = mm >= 1, dn_ok = mm <= nv - 1;
   uint8_t *base = plane + (ptrdiff_t)(8 * mm - 4) * stride + (8 * k - 4);
+  // the rows this lane stores, one bit each (0..7 the cell, 8 and 9 the two rows below it)
+  uint32_t rows = (0xFFu >> (8 - r_hi)) & (0xFFu << r_lo) & ((up_ok ? 0x0Fu : 0u) | (dn_ok ? 0xF0u : 0u));
+  if (ext && dn_ok) rows |= 0x300u;
+  // Three cases, each entered by the wave once: both halves (every lane away from the plane's left and right border), the
+  // left half only, the right half only.
+  if (lo_ok && hi_ok) {
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
-    uint8_t *p = base + (ptrdiff_t)r * stride;
-    if (r >= 8 && !any_ext) break;
-    const bool row_ok = r < 8 ? (r >= r_lo && r < r_hi && (r < 4 ? up_ok : dn_ok)) : (ext && dn_ok);
-    const uint32_t vlo = r < 8 ? C.lo[r] : xlo[r - 8], vhi = r < 8 ? C.hi[r] : xhi[r - 8];
-    if (row_ok) {
-      if (lo_ok & hi_ok) {
+    for (int r = 0; r < 10; r++) {
+      if (r >= 8 && !any_ext) break;
+      if (rows >> r & 1u) {
         Pix8 o;
-        o.x = vlo;
-        o.y = vhi;
-        *reinterpret_cast<Pix8 *>(p) = o;
-      } else if (lo_ok) {
-        *reinterpret_cast<uint32_t *>(p) = vlo;
-      } else if (hi_ok) {
-        *reinterpret_cast<uint32_t *>(p + 4) = vhi;
+        o.x = r < 8 ? C.lo[r] : xlo[r - 8];
+        o.y = r < 8 ? C.hi[r] : xhi[r - 8];
+        *reinterpret_cast<Pix8 *>(base + (ptrdiff_t)r * stride) = o;
       }
+    }
+  } else if (lo_ok) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+      if (r >= 8 && !any_ext) break;
+      if (rows >> r & 1u) *reinterpret_cast<uint32_t *>(base + (ptrdiff_t)r * stride) = r < 8 ? C.lo[r] : xlo[r - 8];
+    }
+  } else if (hi_ok) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+      if (r >= 8 && !any_ext) break;
+      if (rows >> r & 1u) *reinterpret_cast<uint32_t *>(base + (ptrdiff_t)r * stride + 4) = r < 8 ? C.hi[r] : xhi[r - 8];
     }
   }
 }
