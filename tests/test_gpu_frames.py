@@ -176,6 +176,58 @@ def test_enqueue_path_matches(hip):
     assert not rep, rep[:3]
 
 
+@pytest.mark.parametrize("w,h,fmt", [(336, 272, PF_420), (176, 144, PF_444), (1280, 720, PF_420)])
+def test_partial_loop_filter_row_ranges_through_the_fused_pass(hip, w, h, fmt):
+    """thip_state_loop_filter_frag_rows with a fragment-row range that is NOT the whole plane (state.c:1066: only the edges the
+    fragments of rows [fragy0, fragy_end) trigger), on frames that take k_recon_lf: the range reaches the cells as lf_y0 / lf_y1,
+    including the cells a tile finishes for the tile above (its rows 30, 31) and the row pair a tile's last cell row adds below
+    itself (rows 28, 29), and the cells on XCD band boundaries.  Oracle: the frame decoded without the filter, then
+    oc_state_loop_filter_frag_rows over the same ranges."""
+    geom = synth.Geometry(w, h, fmt)
+    rng = np.random.default_rng(w * 7 + h + fmt)
+    ost = oracle.State(w, h, fmt)
+    gst = hip.State(w, h, fmt)
+    buf = np.zeros(128, np.int16)
+    for f in range(4):
+        ftype = hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME
+        fr = synth.gen_frame(geom, rng, ftype, "mixed" if f % 2 else "smooth", flimit=[3, 1, 7, 2][f])
+        ranges = []
+        for pli in range(3):
+            nv = geom.nv[pli]
+            a = int(rng.integers(0, nv))
+            b = int(rng.integers(a, nv + 1))
+            ranges.append([(0, nv), (a, b), (0, b), (a, nv)][f] if nv > 1 else (0, nv))
+        # oracle: no filter, then the ranges
+        fl = fr["flimit"]
+        fr0 = dict(fr)
+        fr0["flimit"] = 0
+        assert util.oracle_apply(ost, fr0) == 0
+        for pli in range(3):
+            if ranges[pli][1] > ranges[pli][0]:
+                ost.loop_filter_rows(fl, oracle.FRAME_PREV, pli, ranges[pli][0], ranges[pli][1])
+            ost.set_plane(oracle.FRAME_PREV, pli, ost.get_plane(oracle.FRAME_PREV, pli))   # (the borders again, now of the filtered picture)
+        # device: the enqueue slots, one loop-filter call per plane with the range
+        gst.frame_begin(fr["frame_type"])
+        coded = np.zeros(geom.nfrags, bool)
+        coded[fr["coded_fragis"]] = True
+        for slot, fi in enumerate(fr["coded_fragis"]):
+            fi = int(fi)
+            pli = 0 if fi < geom.froffset[1] else (1 if fi < geom.froffset[2] else 2)
+            buf[:64] = fr["coeffs"][slot]
+            mv = int((int(fr["mvx"][fi]) & 0xFF) | (int(fr["mvy"][fi]) << 8))
+            mv = (mv + 0x8000) % 0x10000 - 0x8000
+            gst.frag_recon(fi, pli, buf, int(fr["last_zzi"][slot]), int(fr["dc_quant"][slot]), int(fr["refi"][fi]), mv)
+        unc = np.nonzero(~coded)[0]
+        if unc.size:
+            gst.frag_copy_list(unc)
+        for pli in range(3):
+            if ranges[pli][1] > ranges[pli][0]:
+                gst.loop_filter_frag_rows(fl, hip.FRAME_SELF, pli, ranges[pli][0], ranges[pli][1])
+        assert gst.frame_flush() == 0
+        bad = util.planes_equal(ost, gst)
+        assert not bad, (f, ranges, bad)
+
+
 def test_frame_calls_and_enqueue_calls_by_turns_on_one_state(hip):
     """A state fed through the enqueue slots runs on a context stream, one decoded with thip_decode_frames on a batch
     lane: frames of ONE state that alternate between the two are ordered behind each other with an event (every
