@@ -331,6 +331,10 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
 #pragma unroll
     for (int i = 0; i < 32; i++) Y[i] = fill;
   }
+#ifdef THIP_TRACE
+  asm volatile("" : "+v"(Y[0]), "+v"(Y[31]));
+  THIP_TR(tr, 11);  // residual there (coefficients had arrived, transform done); the predictor windows may still be on their way
+#endif
   uint2 rows[8];
   recon_rows(R, Q, inter, Y, rows);
 #ifdef THIP_TRACE

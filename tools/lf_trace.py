@@ -72,6 +72,11 @@ def main():
     for i, name in enumerate(PHASES):
         d = T[:, i + 1] - T[:, i]
         print("  %-46s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % (name, d.mean(), *np.percentile(d, [10, 50, 90]), d.max()))
+    tres = (t[:, 11].astype(np.float64) - t0) / 100.0
+    d = tres - T[:, 1]
+    print("    of the pixels: command words -> residual (coefficient round trip, transform)  mean %6.2f  p50 %6.2f" % (d.mean(), np.percentile(d, 50)))
+    d = T[:, 2] - tres
+    print("                   residual -> pixels (predictor windows awaited, prediction)      mean %6.2f  p50 %6.2f" % (d.mean(), np.percentile(d, 50)))
     life = T[:, 8] - T[:, 0]
     print("  %-46s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % ("whole life", life.mean(), *np.percentile(life, [10, 50, 90]), life.max()))
     grid = np.arange(0, T[:, 8].max(), 1.0)
