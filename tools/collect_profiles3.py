@@ -14,14 +14,14 @@ LABEL = {3: "fused", 0: "twopass"}
 for fuse in (3, 0):
     for d in ("stats_lanes1", "stats_default"):
         f = glob.glob(os.path.join(SRC, "%s_fuse%d" % (d, fuse), "**", "*kernel_stats.csv"), recursive=True)
-        if f:
-            shutil.copy(f[0], os.path.join(DST, "r03_4k_dense_%s_%s_kernel_stats.csv" % (d.split("_")[1], LABEL[fuse])))
+        if f:   # (gpurun_out/ keeps the files of earlier runs: the newest one)
+            shutil.copy(max(f, key=os.path.getmtime), os.path.join(DST, "r03_4k_dense_%s_%s_kernel_stats.csv" % (d.split("_")[1], LABEL[fuse])))
 
 
 def per_kernel(dirname, counter):
     f = glob.glob(os.path.join(SRC, dirname, "**", "*counter_collection.csv"), recursive=True)
     acc = {}
-    for row in csv.DictReader(open(f[0])):
+    for row in csv.DictReader(open(max(f, key=os.path.getmtime))):
         if row["Counter_Name"] != counter:
             continue
         acc.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
