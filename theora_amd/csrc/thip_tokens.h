@@ -199,8 +199,9 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
     j0 = min((uint32_t)t * Kt, m);
     j1 = min(j0 + Kt, m);
   };
+  // (-DTHIP_TL_PROF: thread 0 of plane 0 adds up, phase by phase over the rounds, where the time goes and prints it)
 #ifdef THIP_TL_PROF
-  unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = 0, t_begin = 0;
+  unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
   int rounds = 0;
 #define TLP(k) { unsigned long long now_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); tp[k] += now_ - tq; tq = now_; }
 #else
@@ -268,7 +269,6 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
   int buf = 0;
 #ifdef THIP_TL_PROF
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq));
-  t_begin = tq;
 #endif
   while (z < 64) {
     int zn = z + 1;
@@ -348,12 +348,13 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
   }
 #ifdef THIP_TL_PROF
   if (t == 0 && p == 0)
-    printf("k_tok_assign plane 0: n %d T %d rounds %d | setup %llu | count %llu scan %llu rank+barrier %llu nextuse %llu serve-rest %llu endbarrier %llu | serve: ranks %llu tables %llu stores %llu (10 ns ticks)\n", n, T, rounds,
-           0ull, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8]);
+    printf("k_tok_assign plane 0: n %d T %d rounds %d | count %llu scan %llu rank+barrier %llu nextuse %llu serve-rest %llu endbarrier %llu | serve: ranks %llu tables %llu stores %llu (10 ns ticks)\n", n, T, rounds,
+           tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8]);
 #endif
   // last_zzi (decode.c:1545: the index the fragment's last token -- or the run that ended it -- was met at)
   for (int i = t; i < n; i += T) K.last_zzi[c0 + i] = (uint8_t)(pos[i] < 64 ? pos[i] : pos[i] - 64);
 }
+#undef TLP
 
 // Slots are handed out in coded order to the fragments that need one (last_zzi >= 2, state.c:967).  One group.
 __global__ __launch_bounds__(1024) void k_tok_slots(const TlK K) {
