@@ -270,6 +270,14 @@ typedef struct thip_token_lists {
   const int16_t *dc;           /* NULL, or the un-predicted DC of every coded fragment (order of `coded`) */
 } thip_token_lists;
 int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl);
+/* The same in two steps, for a caller that un-predicts the DC values itself: _begin takes everything but `dc` (which it
+   ignores) and starts the device on the token lists; the caller runs oc_dec_dc_unpredict_mcu_plane meanwhile -- the device
+   needs the DC values last, when it writes the command words -- and hands them to _finish (NULL: un-predict on the device),
+   which returns what thip_state_decode_token_lists returns.  Nothing else may be done with the state in between (THIP_EINVAL
+   from _begin and from the enqueue slots while a frame is pending).  thip_state_decode_token_lists(st, tl) is
+   _begin(st, tl) followed by _finish(st, tl->dc). */
+int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl);
+int thip_state_token_lists_finish(thip_state *st, const int16_t *dc);
 /* on != 0: the DC coefficient handed to thip_state_frag_recon (dct_coeffs[0]) is the value decoded from
    the tokens, NOT yet un-predicted: the caller skips its oc_dec_dc_unpredict_mcu_plane calls
    (decode.c:2869) and thip_frame_flush undoes the prediction on the device before reconstructing
@@ -429,8 +437,11 @@ const char *thip_version_string(void);
  *   wait_spin    wait for a frame in hipEventSynchronize instead of polling with short sleeps (default 0)
  *   dc_global    DC un-prediction through memory even where the LDS kernel fits (default 0)
  *   debug        k_recon ablation switches (profiling)
- *   fe_device_dc, fe_device_tokens, fe_device_lists   th_decode_*: front-end stages on the device (default 0; also
- *                TH_DECCTL_THIP_SET_DEVICE_* per context)
+ *   fe_device_dc, fe_device_tokens   th_decode_*: front-end stages on the device (default 0; also TH_DECCTL_THIP_SET_DEVICE_*
+ *                per context)
+ *   fe_device_lists   th_decode_*: the token lists go to the device as the entropy decoder leaves them: 1 on, 0 off, -1 (default)
+ *                on while at most four decoder contexts are alive in the process and neither of the two above is set (one to
+ *                four streams decode a fifth faster that way, sixteen slower); TH_DECCTL_THIP_SET_DEVICE_LISTS per context
  *   fe_trace_backend, fe_prof   th_decode_*: record slot calls instead of running them (tests); per-stage host timing
  *   device       th_decode_alloc: -1 the calling thread's current device (default), n that device, -2 round robin
  * Returns THIP_EINVAL for a name the table does not have.

@@ -28,6 +28,8 @@ int thip_state_set_eager_output(thip_state *, int) { return -1; }
 int thip_state_create_on(thip_state **, int, int, int, int) { return -1; }
 int thip_state_postprocess(thip_state *, int, const uint8_t *, const uint8_t *, const int32_t *, const int32_t *) { return -1; }
 int thip_state_decode_token_lists(thip_state *, const thip_token_lists *) { return -1; }
+int thip_state_token_lists_begin(thip_state *, const thip_token_lists *) { return -1; }
+int thip_state_token_lists_finish(thip_state *, const int16_t *) { return -1; }
 int thip_device_count(void) { return 0; }
 int thip_option(const char *name) { return (name && !strcmp(name, "device")) ? -1 : 0; }
 int thip_state_set_device_dc(thip_state *, int) { return -1; }

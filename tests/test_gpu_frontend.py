@@ -23,8 +23,8 @@ def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=Fa
     if device_tokens:   # TH_DECCTL_THIP_SET_DEVICE_TOKENS: token expansion + AC dequantisation on the GPU
         on = C.c_int(1)
         assert dec._L.th_decode_ctl(dec._dec, 0x7103, C.byref(on), C.sizeof(on)) == 0
-    if device_lists:   # TH_DECCTL_THIP_SET_DEVICE_LISTS: everything behind the entropy decoder on the GPU
-        on = C.c_int(1)
+    if device_lists is not None:   # TH_DECCTL_THIP_SET_DEVICE_LISTS: everything behind the entropy decoder on the GPU, or (0) the
+        on = C.c_int(int(bool(device_lists)))   # host's own token walk; None leaves the choice to the library (few contexts: the lists)
         assert dec._L.th_decode_ctl(dec._dec, 0x7104, C.byref(on), C.sizeof(on)) == 0
     assert dec.info.frame_width == w and dec.info.frame_height == h and dec.info.pixel_fmt == fmt
     assert dec.comment.vendor == b"theora-hip streamgen"
@@ -84,10 +84,12 @@ def test_packets_decode_bit_exact_with_the_token_lists_on_the_gpu(hip, w, h, fmt
                       device_dc=device_dc) >= 3
 
 
-def test_packets_decode_bit_exact_720p(hip):
+@pytest.mark.parametrize("lists", [False, None])
+def test_packets_decode_bit_exact_720p(hip, lists):
     """BASELINE.json's 720p size through the whole API (key frame + inter frames of three densities),
-    with Huffman trees matched to the content: the short-code fast path of the token loop at scale."""
-    assert run_stream(hip, 1280, 720, 0, seed=720, nframes=4, kf=3, trees="matched") >= 3
+    with Huffman trees matched to the content: the short-code fast path of the token loop at scale; on the host path and as the
+    library chooses by itself (one context alive: the token lists on the device)."""
+    assert run_stream(hip, 1280, 720, 0, seed=720, nframes=4, kf=3, trees="matched", device_lists=lists) >= 3
 
 
 @pytest.mark.parametrize("mode", ["host", "device_dc", "device_lists", "device_lists_dc"])

@@ -75,7 +75,7 @@ Option g_options[] = {
     {"debug", 0, "k_recon ablation switches for profiling"},
     {"fe_device_dc", 0, "th_decode_*: DC un-prediction on the device"},
     {"fe_device_tokens", 0, "th_decode_*: token expansion + dequantisation on the device (host-delimited tokens)"},
-    {"fe_device_lists", 0, "th_decode_*: the token lists themselves on the device"},
+    {"fe_device_lists", -1, "th_decode_*: the token lists themselves on the device (1 on, 0 off, -1 on while at most four decoder contexts are alive)"},
     {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
     {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
@@ -198,6 +198,13 @@ struct thip_state {
   uint8_t *d_tl_last;       // [nfrags]
   uint32_t *d_tl_slot;      // [nfrags]
   uint32_t *d_tl_arr;       // [nfrags] k_tok_assign's rank -> fragment map for planes beyond its LDS
+  // a frame handed over with thip_state_token_lists_begin and not yet finished
+  int tl_pending;
+  TlK tl_K;
+  thip_frame_desc tl_desc;
+  int64_t tl_ncoded;
+  size_t tl_o_dcv;          // where the caller's DC values go in h_tl / d_tl (dwords)
+  hipStream_t tl_stream;
   int32_t *d_frag_pos;      // [nfrags], uploaded once
   // out-of-loop post-processing (thip_state_postprocess): the post-processed picture, the per-fragment
   // variances and quantiser indices, which planes of which decoded frame the picture holds
@@ -1363,6 +1370,7 @@ static int ensure_staging(thip_state *st) {
 int thip_frame_begin(thip_state *st, int frame_type) {
   if (!st) return THIP_EFAULT;
   if (frame_type != THIP_INTRA_FRAME && frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
+  if (st->tl_pending) return THIP_EINVAL;   // a frame handed over with thip_state_token_lists_begin waits for its finish
   DeviceGuard dg(st->device);
   int rc = ensure_staging(st);
   if (rc) return rc;
@@ -1645,9 +1653,9 @@ int thip_frame_flush(thip_state *st) {
 }
 
 // ---- the frame's token lists, expanded on the device (thip_tokens.h) ---------------------------------------
-int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
+int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl) {
   if (!st || !tl) return THIP_EFAULT;
-  if (st->enq_active) return THIP_EINVAL;   // a frame is being enqueued through the slots
+  if (st->enq_active || st->tl_pending) return THIP_EINVAL;   // a frame is being enqueued through the slots, or one is waiting for its finish
   if (tl->frame_type != THIP_INTRA_FRAME && tl->frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
   if (tl->flimit < 0 || tl->flimit > 127 || tl->ntokens < 0) return THIP_EINVAL;
   int64_t ncoded = 0;
@@ -1724,7 +1732,6 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
     h[THIP_TL_DCQ + 6] = h[THIP_TL_DCQ + 7] = 0;
     memcpy(h + o_cl, tl->coded, (size_t)ncoded * 4);
     memcpy(h + o_meta, tl->frag_meta, (size_t)ncoded * 4);
-    if (tl->dc) memcpy(h + o_dcv, tl->dc, (size_t)ncoded * 2);
     memcpy(h + o_dq, tl->dequant, 18 * 64 * 2);
     memcpy(h + o_tok, tl->tokens, (size_t)tl->ntokens * 4);
     const size_t npos = (size_t)st->tiles.ntiles * THIP_TILE_FRAGS;
@@ -1754,7 +1761,7 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
     K.slot = st->d_tl_slot;
     K.arr = st->d_tl_arr;
     K.dc_in = st->d_dc_in;
-    K.dc_host = tl->dc ? reinterpret_cast<const int16_t *>(st->d_tl + o_dcv) : nullptr;
+    K.dc_host = nullptr;   // (thip_state_token_lists_finish sets it)
     K.info = st->d_info;
     K.slot0 = st->d_slot0;
     K.coeffs = reinterpret_cast<int4 *>(st->d_coeffs);
@@ -1776,24 +1783,58 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
       hipLaunchKernelGGL(k_tok_assign<true>, dim3(3), dim3(tl_threads(nmax)), (size_t)lds, s, K);
     }
     hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
-    hipLaunchKernelGGL(k_tok_write, dim3((unsigned)(((size_t)ncoded * 8 + 255) / 256)), dim3(256), 0, s, K);
     HIP_TRY(hipGetLastError());
     d.frag_info = st->d_info;
     d.coeffs = st->d_coeffs;
     d.tile_slot0 = st->d_slot0;
     d.nslots = (int)ncoded;      // (an upper bound: the device knows the number)
     d.ncoded = (int)ncoded;
-    d.dc_tokens = tl->dc ? nullptr : st->d_dc_in;
+    st->tl_K = K;
+    st->tl_o_dcv = o_dcv;
+  }
+  st->tl_desc = d;
+  st->tl_ncoded = ncoded;
+  st->tl_stream = s;
+  st->tl_pending = 1;
+  return THIP_OK;
+}
+
+int thip_state_token_lists_finish(thip_state *st, const int16_t *dc) {
+  if (!st) return THIP_EFAULT;
+  if (!st->tl_pending) return THIP_EINVAL;
+  st->tl_pending = 0;
+  DeviceGuard dg(st->device);
+  hipStream_t s = st->tl_stream;
+  thip_frame_desc d = st->tl_desc;
+  const int64_t ncoded = st->tl_ncoded;
+  if (ncoded) {
+    TlK K = st->tl_K;
+    if (dc) {   // the caller's un-predicted values: behind k_tok_prepare's copy of the staging buffer, into the same place
+      memcpy(st->h_tl + st->tl_o_dcv, dc, (size_t)ncoded * 2);
+      HIP_TRY(hipMemcpyAsync(st->d_tl + st->tl_o_dcv, st->h_tl + st->tl_o_dcv, (((size_t)ncoded * 2) + 15) & ~(size_t)15, hipMemcpyHostToDevice, s));
+      K.dc_host = reinterpret_cast<const int16_t *>(st->d_tl + st->tl_o_dcv);
+    } else {
+      K.dc_host = nullptr;
+    }
+    hipLaunchKernelGGL(k_tok_write, dim3((unsigned)(((size_t)ncoded * 8 + 255) / 256)), dim3(256), 0, s, K);
+    HIP_TRY(hipGetLastError());
+    d.dc_tokens = dc ? nullptr : st->d_dc_in;
   }
   int32_t res = 0;
   thip_state *sp = st;
-  rc = thip_decode_frames(&sp, &d, 1, (void *)s, &res);
+  int rc = thip_decode_frames(&sp, &d, 1, (void *)s, &res);
   if (rc < 0) return rc;
   if (ncoded) {
     if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(st->ev_staging, s));
   }
   return res;
+}
+
+int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl) {
+  const int rc = thip_state_token_lists_begin(st, tl);
+  if (rc < 0) return rc;
+  return thip_state_token_lists_finish(st, tl->dc);
 }
 
 }  // extern "C"

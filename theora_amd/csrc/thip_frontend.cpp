@@ -161,6 +161,9 @@ static inline double fe_now() {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+// decoder contexts alive in the process (the token-list path is chosen by default while there are few)
+static std::atomic<int> g_fe_contexts{0};
+constexpr int kFeListsAutoContexts = 4;
 struct FeProf {
   bool on;
   double acc[FE_NSEC], t;
@@ -213,8 +216,10 @@ struct th_dec_ctx {
   int32_t pp_dc_scale[64], pp_sharp_mod[64];
   bool device_tokens;   // token -> coefficient expansion and AC dequantisation left to the backend (THIP_FE_DEVICE_TOKENS=1, ctl)
   // everything behind the entropy decoder left to the backend: the token lists go to the device as they are
-  // (THIP_FE_DEVICE_LISTS=1, TH_DECCTL_THIP_SET_DEVICE_LISTS; thip_state_decode_token_lists)
-  bool device_lists;
+  // (option fe_device_lists, TH_DECCTL_THIP_SET_DEVICE_LISTS; thip_state_token_lists_begin / _finish).  1 on, 0 off, -1 (the
+  // default) on while few decoder contexts are alive: the device side of a frame is 0.3 ms of small dependent kernels -- a gain
+  // of a fifth for one to four streams, a queue for sixteen.
+  int device_lists;
   uint32_t arrivals[3][64];          // fragments open at every (plane, index) of the current frame
   std::vector<uint32_t> tl_tokens, tl_meta;
   std::vector<int16_t> tl_dc;            // the un-predicted DC values in coded order (token-list path with the DC chain on the host)
@@ -967,7 +972,8 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   if (d->hip && thip_option("fe_device_dc") != 0)
     d->device_dc = thip_state_set_device_dc(d->hip, 1) == 0;   // (refused for planes of more than 1024 fragment rows)
   d->device_tokens = d->hip && thip_option("fe_device_tokens") != 0;
-  d->device_lists = d->hip && thip_option("fe_device_lists") != 0;
+  d->device_lists = d->hip ? thip_option("fe_device_lists") : 0;
+  g_fe_contexts.fetch_add(1, std::memory_order_relaxed);
   build_geometry(d);
   d->dequant.resize((size_t)64 * 3 * 2 * 64);
   for (int qi = 0; qi < 64; qi++)
@@ -1033,6 +1039,7 @@ void th_decode_free(th_dec_ctx *d) {
               100.0 * d->prof.acc[s] / tot);
   }
   if (d->hip) thip_state_free(d->hip);
+  g_fe_contexts.fetch_sub(1, std::memory_order_relaxed);
   delete d;
 }
 
@@ -1089,7 +1096,7 @@ int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
       if (!d || !buf) return TH_EFAULT;
       if (buf_sz != sizeof(int)) return TH_EINVAL;
       if (d->trace || !d->hip) return TH_EINVAL;
-      d->device_lists = *(int *)buf != 0;
+      d->device_lists = *(int *)buf != 0 ? 1 : 0;
       return 0;
     }
     case TH_DECCTL_THIP_GET_SLOT_TRACE: {
@@ -1459,7 +1466,10 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   };
   // ---- everything from here to the pictures on the device, when asked for and possible ------------------
   bool lists_done = false;
-  if (d->device_lists && !d->trace) {
+  const bool lists_now = !d->trace && d->hip &&
+                         (d->device_lists > 0 || (d->device_lists < 0 && !d->device_dc && !d->device_tokens &&
+                                                  g_fe_contexts.load(std::memory_order_relaxed) <= kFeListsAutoContexts));
+  if (lists_now) {
     thip_token_lists tl;
     memset(&tl, 0, sizeof(tl));
     tl.frame_type = d->frame_type;
@@ -1476,26 +1486,22 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         tl.list_len[p][z] = (uint32_t)d->ntoks[p][z];
         tl.eob_carry[p][z] = d->eob_carry[p][z];
         tl.arrivals[p][z] = d->arrivals[p][z];
-        const Tok *t = d->toks[p][z].data();
-        for (size_t k = 0; k < d->ntoks[p][z]; k++) {
-          const uint32_t run = t[k].eob > 0xFFFFFFu ? 0xFFFFFFu : t[k].eob;   // (more than any plane the backend takes has)
-          o[at++] = t[k].eob ? (0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24)
-                             : ((uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16);
+        // (branch-free, one list at a time: the compiler vectorises it)
+        const Tok *__restrict t = d->toks[p][z].data();
+        uint32_t *__restrict w = o + at;
+        const size_t nk = d->ntoks[p][z];
+        for (size_t k = 0; k < nk; k++) {
+          const uint32_t e = t[k].eob;
+          const uint32_t run = e > 0xFFFFFFu ? 0xFFFFFFu : e;   // (more than any plane the backend takes has)
+          const uint32_t we = 0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24;
+          const uint32_t wv = (uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16;
+          w[k] = e ? we : wv;
         }
+        at += nk;
       }
     const size_t nc = d->cl_start[3];
     d->tl_meta.resize(nc + 1);
     d->tl_coded.resize(nc + 1);
-    // DC un-prediction stays on this side unless the device is asked for that too (option fe_device_dc): a chain through the
-    // plane in raster order, a few nanoseconds a fragment here, a dependent step of a wave there
-    if (!d->device_dc) {
-      d->prof.lap(FE_EXPAND);
-      undo_dc();
-      d->prof.lap(FE_DC);
-      d->tl_dc.resize(nc + 1);
-      for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
-      tl.dc = d->tl_dc.data();
-    }
     for (int p = 0; p < 3; p++) {
       tl.ncoded[p] = (int32_t)(d->cl_start[p + 1] - d->cl_start[p]);
       for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
@@ -1518,7 +1524,22 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     tl.coded = d->tl_coded.data();
     tl.frag_meta = d->tl_meta.data();
     tl.dequant = dq;
-    const int lrc = thip_state_decode_token_lists(d->hip, &tl);
+    // The device starts on the lists; the DC prediction is undone on this side meanwhile unless the device is asked for that
+    // too (option fe_device_dc) -- a chain through the plane in raster order, a few nanoseconds a fragment here, a dependent
+    // step of a wave there -- and the values follow with the second call: the device needs them last.
+    int lrc = thip_state_token_lists_begin(d->hip, &tl);
+    if (lrc >= 0) {
+      const int16_t *dcv = nullptr;
+      if (!d->device_dc) {
+        d->prof.lap(FE_EXPAND);
+        undo_dc();
+        d->tl_dc.resize(nc + 1);
+        for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
+        dcv = d->tl_dc.data();
+        d->prof.lap(FE_DC);
+      }
+      lrc = thip_state_token_lists_finish(d->hip, dcv);
+    }
     if (lrc >= 0) lists_done = true;
     else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
     d->prof.lap(FE_EXPAND);
