@@ -147,7 +147,9 @@ typedef struct {
    GPU, which finds each fragment's tokens, expands and dequantises them and decodes the frame
    (thip_state_decode_token_lists).  The DC prediction is still undone in th_decode_packetin (a chain through the plane in
    raster order: nanoseconds a fragment on a host core) unless TH_DECCTL_THIP_SET_DEVICE_DC asks for the GPU there too.  Frames with a plane of more than 147456 coded fragments (beyond
-   4K) keep the host path.  THIP_FE_DEVICE_LISTS=1 sets it for every new context. */
+   4K) keep the host path.  Zero: the host's own token walk.  Without this call a context follows the option
+   fe_device_lists (THIP_FE_DEVICE_LISTS in the environment): 1 / 0, or -1, the default: this path while at most four
+   decoder contexts are alive in the process. */
 #define TH_DECCTL_THIP_SET_DEVICE_LISTS (0x7104)
 typedef struct thip_slot_trace {
   int64_t ncoded;           /* state_frag_recon calls, in call (= coded) order */
