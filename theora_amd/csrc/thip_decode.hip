@@ -157,7 +157,10 @@ struct thip_state {
   uint32_t *h_info, *d_info;
   int16_t *h_coeffs, *d_coeffs;
   uint32_t *h_slot0, *d_slot0;
+  hipStream_t ctx_stream_cached;   // context_stream()'s answer, once it has given one
   hipEvent_t ev_staging;     // recorded behind the kernels that read the staging buffers (enqueue path)
+  int64_t staging_serial;    // frame_serial of the frame ev_staging stands behind
+  int64_t out_done_serial;   // frame_serial of the newest frame whose output copy a host wait has seen complete (ev_out)
   hipEvent_t ev_order;       // orders a frame behind the previous one when the two go down different streams
   hipStream_t last_stream;   // stream of the most recent launch for this state (ycbcr_out copies on it)
   int order_recorded;        // ev_order already marks the end of that launch (it went down a caller-owned stream)
@@ -331,6 +334,10 @@ struct ScopedTimer {
 
 // The stream of an enqueue-fed state (device current).
 int context_stream(thip_state *st, hipStream_t *out) {
+  if (st->ctx_stream_cached) {   // (a context keeps its stream: no locks on the per-frame path)
+    *out = st->ctx_stream_cached;
+    return THIP_OK;
+  }
   static const int nctx = [] {   // (streams are created once: read at first use)
     const int v = thip_option("ctx_lanes");
     return v < 0 ? 0 : (v > kCtxLanes ? kCtxLanes : v);
@@ -349,6 +356,7 @@ int context_stream(thip_state *st, hipStream_t *out) {
   }
   if (st->ctx_lane < 0) st->ctx_lane = g_next_ctx[st->device]++ % nctx;
   *out = g_ctx_lanes[st->device][st->ctx_lane];
+  st->ctx_stream_cached = *out;
   return THIP_OK;
 }
 
@@ -740,6 +748,11 @@ static int wait_event(hipEvent_t ev) {
     HIP_TRY(hipEventSynchronize(ev));
     return THIP_OK;
   }
+  // Look continuously for the first 60 microseconds -- what is left of a frame's kernels when the host gets here is usually
+  // shorter than the shortest sleep the kernel grants (a 20-us nanosleep returns after 70) --, then in short sleeps: a context
+  // that waits longer must not hold a core other contexts' entropy decoders want.
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int polls = 0;; polls++) {
     const hipError_t e = hipEventQuery(ev);
     if (e == hipSuccess) return THIP_OK;
@@ -748,8 +761,15 @@ static int wait_event(hipEvent_t ev) {
       return THIP_EFAULT;
     }
     if (polls >= 8) {
-      timespec ts = {0, 20000};
-      nanosleep(&ts, nullptr);
+      timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      const long long ns = (long long)(t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec);
+      if (ns > 60000) {
+        timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+      } else {
+        __builtin_ia32_pause();
+      }
     }
   }
 }
@@ -805,6 +825,7 @@ int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strid
     }
   }
   if (wait_event(st->ev_out) < 0) return THIP_EFAULT;
+  st->out_done_serial = st->out_serial;
   if (check_fault(st->device) < 0) return THIP_EFAULT;
   int off = 0;
   for (int p = 0; p < 3; p++) {
@@ -1367,6 +1388,17 @@ static int ensure_staging(thip_state *st) {
   return THIP_OK;
 }
 
+// The staging buffers are free again once the kernels of the frame that used them have read them.  The event that says so is
+// the LAST thing queued for that frame, and the runtime submits a trailing marker lazily: asking for it costs a flush and one
+// or two hundred microseconds of polling even when the work finished long ago.  The caller has usually waited for that very
+// frame's output copy already (thip_state_ycbcr_map), which stands behind the same kernels on the same stream: then no question
+// is asked at all.
+static int wait_staging_free(thip_state *st) {
+  if (!st->ev_staging) return THIP_OK;
+  if (st->out_done_serial >= st->staging_serial) return THIP_OK;
+  return wait_event(st->ev_staging);
+}
+
 int thip_frame_begin(thip_state *st, int frame_type) {
   if (!st) return THIP_EFAULT;
   if (frame_type != THIP_INTRA_FRAME && frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
@@ -1376,7 +1408,7 @@ int thip_frame_begin(thip_state *st, int frame_type) {
   if (rc) return rc;
   // the previous frame's kernels must have read the staging buffers before they are reused;
   // only this stream's own work is waited for, so contexts on other host threads keep going
-  if (st->ev_staging && wait_event(st->ev_staging) < 0) return THIP_EFAULT;
+  if (wait_staging_free(st) < 0) return THIP_EFAULT;
   memset(st->h_info, 0, (size_t)st->tiles.ntiles * THIP_TILE_FRAGS * 8);   // everything uncoded
   memset(st->h_slot0, 0, (size_t)st->tiles.ntiles * 4);
   for (int t = 0; t < st->tiles.ntiles; t++) st->enq_last_lane[t] = -1;
@@ -1649,6 +1681,7 @@ int thip_frame_flush(thip_state *st) {
   if (rc < 0) return rc;
   if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(st->ev_staging, s));
+  st->staging_serial = st->frame_serial;
   return res;
 }
 
@@ -1721,7 +1754,7 @@ int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl) {
     }
     if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * nf));
     // the previous frame's kernels must have read the staging buffer before it is reused
-    if (st->ev_staging && wait_event(st->ev_staging) < 0) return THIP_EFAULT;
+    if (wait_staging_free(st) < 0) return THIP_EFAULT;
     uint32_t *h = st->h_tl;
     memcpy(h + THIP_TL_OFF, tl->list_off, sizeof(tl->list_off));
     memcpy(h + THIP_TL_LEN, tl->list_len, sizeof(tl->list_len));
@@ -1827,6 +1860,7 @@ int thip_state_token_lists_finish(thip_state *st, const int16_t *dc) {
   if (ncoded) {
     if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(st->ev_staging, s));
+    st->staging_serial = st->frame_serial;
   }
   return res;
 }

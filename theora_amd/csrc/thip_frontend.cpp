@@ -153,9 +153,11 @@ struct MacroBlock {
 };
 
 // THIP_FE_PROF=1: wall time per section of th_decode_packetin, printed by th_decode_free
-enum { FE_FLAGS, FE_MODES, FE_QI, FE_TOKENS, FE_DC, FE_EXPAND, FE_FLUSH, FE_OUT, FE_NSEC };
+enum { FE_FLAGS, FE_MODES, FE_QI, FE_TOKENS, FE_DC, FE_EXPAND, FE_FLUSH, FE_OUT, FE_LPACK, FE_LMETA, FE_LBEGIN, FE_LFINISH, FE_NSEC };
 static const char *const kFeNames[FE_NSEC] = {"header+coded flags", "modes+MVs", "block qi", "DCT tokens", "DC unpredict",
-                                              "expand+dequant+stage", "flush (H2D, launch, sync)", "ycbcr_out (D2H)"};
+                                              "expand+dequant+stage", "flush (H2D, launch, sync)", "ycbcr_out (D2H)",
+                                              "lists: tokens packed", "lists: fragment words", "lists: begin (stage, launch)",
+                                              "lists: finish (launch)"};
 static inline double fe_now() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -165,7 +167,7 @@ static inline double fe_now() {
 static std::atomic<int> g_fe_contexts{0};
 constexpr int kFeListsAutoContexts = 4;
 struct FeProf {
-  bool on;
+  bool on, warmed;   // (the first frames carry one-time costs -- streams, allocations -- and are dropped from the sums)
   double acc[FE_NSEC], t;
   long frames, tokens;
   void start() { if (on) t = fe_now(); }
@@ -1499,6 +1501,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         }
         at += nk;
       }
+    d->prof.lap(FE_LPACK);
     const size_t nc = d->cl_start[3];
     d->tl_meta.resize(nc + 1);
     d->tl_coded.resize(nc + 1);
@@ -1527,11 +1530,12 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     // The device starts on the lists; the DC prediction is undone on this side meanwhile unless the device is asked for that
     // too (option fe_device_dc) -- a chain through the plane in raster order, a few nanoseconds a fragment here, a dependent
     // step of a wave there -- and the values follow with the second call: the device needs them last.
+    d->prof.lap(FE_LMETA);
     int lrc = thip_state_token_lists_begin(d->hip, &tl);
+    d->prof.lap(FE_LBEGIN);
     if (lrc >= 0) {
       const int16_t *dcv = nullptr;
       if (!d->device_dc) {
-        d->prof.lap(FE_EXPAND);
         undo_dc();
         d->tl_dc.resize(nc + 1);
         for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
@@ -1539,6 +1543,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         d->prof.lap(FE_DC);
       }
       lrc = thip_state_token_lists_finish(d->hip, dcv);
+      d->prof.lap(FE_LFINISH);
     }
     if (lrc >= 0) lists_done = true;
     else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
@@ -1689,6 +1694,12 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   }
   d->prof.lap(FE_FLUSH);
   d->prof.frames++;
+  if (d->prof.on && !d->prof.warmed && d->prof.frames == 4) {
+    memset(d->prof.acc, 0, sizeof(d->prof.acc));
+    d->prof.frames = 0;
+    d->prof.tokens = 0;
+    d->prof.warmed = true;
+  }
   d->have_frame = true;
   d->curframe_num++;
   if (granpos) *granpos = d->granpos;
