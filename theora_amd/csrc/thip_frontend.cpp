@@ -1422,7 +1422,8 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
       for (int y = 0; y < nv; y++) {
         const int f0 = d->fro[p] + y * nh;
         uint8_t *kr = &key[(size_t)(y + 1) * W + 1];
-        for (int x = 0; x < nh; x++) kr[x] = d->coded[f0 + x] ? d->refi[f0 + x] : 0xFF;
+        const uint8_t *__restrict cd = d->coded.data() + f0, *__restrict rf = d->refi.data() + f0;
+        for (int x = 0; x < nh; x++) kr[x] = (uint8_t)(rf[x] | (uint8_t)(cd[x] - 1));   // (coded is 0 or 1: 0xFF where it is 0)
       }
       // weights and divisors of Table 7.47, indexed by which neighbours are available (bit 0 left,
       // 1 up-left, 2 up, 3 up-right); the divisors are powers of two, the division truncates
@@ -1436,15 +1437,23 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         const int f0 = d->fro[p] + y * nh;
         const uint8_t *kr = &key[(size_t)(y + 1) * W + 1];
         int16_t *vr = &val[(size_t)(y + 1) * W + 1];
+        // (the left neighbour's key and value travel in registers: the value is what the next block waits for, and through
+        //  memory it would wait for the store to come back as well)
+        const uint8_t *const ku = kr - W;
+        const int16_t *const vu = vr - W;
+        int lk = 0xFF, lv = 0;
         for (int x = 0; x < nh; x++) {
           const int r = kr[x];
-          if (r == 0xFF) continue;
-          const int mask = (kr[x - 1] == r) | (kr[x - W - 1] == r) << 1 | (kr[x - W] == r) << 2 | (kr[x - W + 1] == r) << 3;
+          if (r == 0xFF) {
+            lk = 0xFF;
+            continue;
+          }
+          const int mask = (lk == r) | (ku[x - 1] == r) << 1 | (ku[x] == r) << 2 | (ku[x + 1] == r) << 3;
           int pred;
           if ((mask & 7) == 7) {
             // L, UL and U all present (every interior block of a key frame): (29 L - 26 UL + 29 U) / 32
             // whether or not UR is, then the outlier clamp (7.8.1 step 5)
-            const int l = vr[x - 1], ul = vr[x - W - 1], u = vr[x - W];
+            const int l = lv, ul = vu[x - 1], u = vu[x];
             const int num = 29 * (l + u) - 26 * ul;
             pred = (num + ((num >> 31) & 31)) >> 5;   // num / 32, towards zero
             if (abs(pred - u) > 128) pred = u;
@@ -1452,7 +1461,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
             else if (abs(pred - ul) > 128) pred = ul;
           } else if (mask == 0) pred = last[r];
           else {
-            const int l = vr[x - 1], ul = vr[x - W - 1], u = vr[x - W], ur = vr[x - W + 1];
+            const int l = lv, ul = vu[x - 1], u = vu[x], ur = vu[x + 1];
             const int num = Wt[mask][0] * l + Wt[mask][1] * ul + Wt[mask][2] * u + Wt[mask][3] * ur;
             const int sh = Dsh[mask];
             pred = (num + ((num >> 31) & ((1 << sh) - 1))) >> sh;   // num / 2^sh, towards zero
@@ -1461,6 +1470,8 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
           d->dc[f0 + x] = v;
           vr[x] = v;
           last[r] = v;
+          lk = r;
+          lv = v;
         }
       }
     }
