@@ -194,6 +194,7 @@ struct th_dec_ctx {
   std::vector<uint16_t> dequant;         // [qi][pli][qti][zzi]
   // per frame
   std::vector<uint8_t> coded, refi, qii, mbmode_of_frag;
+  bool qii_dirty;                // some entry of qii may be non-zero
   std::vector<int8_t> mvx, mvy;
   std::vector<int16_t> dc;
   std::vector<int> clist;        // coded blocks (raster fragment index) in coded order; plane p is [cl_start[p], cl_start[p+1])
@@ -1009,6 +1010,7 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   d->coded.assign(d->nfrags, 0);
   d->refi.assign(d->nfrags, 0);
   d->qii.assign(d->nfrags, 0);
+  d->qii_dirty = false;
   d->mvx.assign(d->nfrags, 0);
   d->mvy.assign(d->nfrags, 0);
   d->dc.assign(d->nfrags, 0);
@@ -1329,7 +1331,12 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     const int *cl = d->clist.data();
     // only the coded blocks get a new qii (decode.c:913-917): an uncoded block keeps the one it was last coded
     // with, which the de-ringing filter reads (decode.c:1926)
-    for (size_t i = 0; i < nc; i++) d->qii[cl[i]] = 0;
+    // (with one qi in every frame since the last key frame nothing is anything but zero: the pass over the coded blocks is skipped)
+    if (d->nqis > 1 || d->qii_dirty) {
+      for (size_t i = 0; i < nc; i++) d->qii[cl[i]] = 0;
+      if (d->frame_type == THIP_INTRA_FRAME) d->qii_dirty = false;   // every block was coded: every entry is zero now
+    }
+    if (d->nqis > 1) d->qii_dirty = true;
     std::vector<uint8_t> &bits = d->qi_bits;
     for (int q = 0; q + 1 < d->nqis; q++) {
       size_t nb = 0;
