@@ -57,6 +57,9 @@ def test_argument_validation_without_gpu():
     assert L.thip_frame_begin(None, 0) == _lib.EFAULT
     assert L.thip_decode_frames(None, None, 0, None, None) == _lib.EFAULT
     assert L.thip_state_ref_idx(None, 0) == _lib.EINVAL
+    assert L.thip_state_decode_token_lists(None, None) == _lib.EFAULT
+    assert L.thip_state_token_lists_begin(None, None) == _lib.EFAULT
+    assert L.thip_state_token_lists_finish(None, None) == _lib.EFAULT
 
 
 def test_loop_filter_init_slot_matches_oracle_table():
@@ -133,7 +136,7 @@ def test_options_table():
     for nm in ("fuse", "lanes", "ctx_lanes", "chunk", "skip_static", "lf_sparse", "zerocopy", "wait_spin", "dc_global", "debug",
                "fe_device_dc", "fe_device_tokens", "fe_device_lists", "fe_trace_backend", "fe_prof", "device"):
         assert nm in names, nm
-    defaults = dict(fuse=3, lanes=2, ctx_lanes=8, skip_static=1, lf_sparse=-1, zerocopy=1, device=-1)
+    defaults = dict(fuse=3, lanes=2, ctx_lanes=8, skip_static=1, lf_sparse=-1, zerocopy=1, device=-1, fe_device_lists=-1, fe_device_dc=0)
     for nm, dv in defaults.items():
         if "THIP_" + nm.upper() not in os.environ:
             v = C.c_int(12345)
