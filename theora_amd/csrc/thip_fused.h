@@ -36,11 +36,11 @@
 // dead GPU).  Producer and consumer share one L2: plain stores stop there, device-scope loads go past
 // the CU's L1 and find them.
 // Band boundaries: the first tile row of band x (D tiles) runs at the START of the launch, the last row of
-// band x-1 (U tiles) at its END, so there the hand-over runs upwards: a D tile publishes its first four rows
+// band x-1 (U tiles) at its END, so there the hand-over runs upwards: a D tile publishes its first two rows
 // with device-scope stores (through to memory: the reader sits on another XCD), runs only the vertical
 // edge of its rows 2 and 3 in the cells on its upper boundary, and the U tile above -- last of the two by
-// construction -- closes the boundary (its rows 30, 31 and the D tile's rows 0, 1) as a 17th cell row.  The same extra pass closes the plane's own border cells (k = nh, m = nv) where
-// the plane ends exactly on a tile boundary.
+// construction -- closes the boundary (its rows 30, 31 and the D tile's rows 0, 1) as a 17th cell row.  The same extra
+// pass closes the plane's own border cells (k = nh, m = nv) where the plane ends exactly on a tile boundary.
 // Order of operations inside every cell: the reference's (state.c:1055-1105), via lf_cell_ops; the
 // fragment-row range of the enqueue slot (state.c:1066) is honoured the same way as in k_loopfilter.
 #pragma once
@@ -50,7 +50,7 @@
 #endif
 constexpr int kTfPitch = THIP_TF_PITCH;                  // LDS image row: 8-byte left margin (4 used), 128 pixels, 8 spare
 constexpr int kTfX0 = 8;                       // byte offset of pixel column 0 in an image row
-constexpr int kTfImgRows = 40;                 // pixel rows -4 .. 35 (upper neighbour's last 4, the tile, lower neighbour's first 4)
+constexpr int kTfImgRows = 40;                 // pixel rows -4 .. 35 (of the upper neighbour's rows only -2, -1 are filled, of the lower one's 32, 33)
 constexpr int kTfFlagOff = kTfImgRows * kTfPitch;   // coded flags: 6 rows (block rows -1..4) of kTfFlagPitch bytes
 constexpr int kTfFlagPitch = 20;               // [0] block column -1, [1..16] the tile, [17] column 16
 // The wave's LDS: 7 KB, not 8.  This chip hands LDS out in 1280-byte granules, so 8 KB costs 8960 bytes and a CU holds 18 such
