@@ -156,15 +156,40 @@ int64_t thip_state_frag_pos(const thip_state *st, int64_t fragi);
  *             x86state.c:44-64).  Allocate whole groups of 64 slots.
  *  tile_slot0 per tile: slot number of its first non-dc_only coded fragment; the kernel
  *             finds the others with a ballot / prefix count over the tile's lanes.
+ *
+ * The LEVELS form of the same stream (coeff_format = THIP_COEFFS_LEVELS): what decode.c:1573-1574 does between the
+ * tokens and the slot -- `(ogg_int16_t)(coeff*ac_quant[zzi])` -- moves into the reconstruction kernel, and the
+ * coefficient slots shrink to the quantised LEVELS the tokens carry (eight bits cover almost every stream; the largest term
+ * of a dense frame's traffic halves):
+ *  frag_info  word0 additionally carries qii (bits 4-5: the block's index into the frame's qi list, oc_fragment.qii,
+ *             state.h:307); the table a block is dequantised with is dequant[pli][qii][qti], qti = (refi != SELF)
+ *             (decode.c:1537-1538).  word1 bits 0-15 carry the raw DC of EVERY coded block (no DC in the slots).
+ *  dequant    device, 18 tables of 64 uint16, table (pli*3 + qii)*2 + qti, each in SLOT ORDER: entry (j*8 + c)*2 + p
+ *             is ac_quant for natural position (2j+p, c) (thip_pack_dequant_table converts a zig-zag-ordered table);
+ *             the DC entry is ignored.
+ *  coeffs     counted in 64-byte UNITS, groups of 64 units (4096 bytes): piece q (0..3) of unit u at
+ *             (u/64)*4096 + q*1024 + (u%64)*16.  A block of a NARROW tile owns one unit of int8 levels: piece j is row
+ *             pair j, its dword d the bytes { x[2j][2d], x[2j][2d+1], x[2j+1][2d], x[2j+1][2d+1] }.  A tile in which
+ *             some level does not fit eight bits is WIDE: each of its blocks owns two consecutive units holding the
+ *             eight int16 pieces described above (pieces 0-3 in the first unit, 4-7 in the second) -- int16 LEVELS,
+ *             still multiplied by the table.
+ *  tile_slot0 per tile: its first unit | THIP_SLOT_WIDE for a wide tile.
+ *  nslots     units in total.
  * ---------------------------------------------------------------------------------- */
 #define THIP_INFO_CODED 0x1u
 #define THIP_INFO_REFI_SHIFT 1
 #define THIP_INFO_DC_ONLY 0x8u
+#define THIP_INFO_QII_SHIFT 4 /* levels form: oc_fragment.qii, two bits */
 #define THIP_INFO_LAST_ZZI_SHIFT 8
 #define THIP_INFO_MVX_SHIFT 16
 #define THIP_INFO_MVY_SHIFT 24
 #define THIP_SLOT_GROUP 64
 #define THIP_SLOT_GROUP_BYTES 8192
+#define THIP_COEFFS_DEQUANT16 0 /* slots of dequantised int16 coefficients: what oc_state_frag_recon receives */
+#define THIP_COEFFS_LEVELS 1    /* units of quantised levels + the frame's dequantisation tables */
+#define THIP_UNIT_BYTES 64
+#define THIP_UNIT_GROUP_BYTES 4096
+#define THIP_SLOT_WIDE 0x80000000u
 
 typedef struct thip_frame_desc {
   const uint32_t *frag_info;  /* device, 2*64*ntiles words */
@@ -181,7 +206,12 @@ typedef struct thip_frame_desc {
      anti-diagonal wavefront per plane) and the reconstruction takes every block's DC from its result; the
      DC fields of frag_info / coeffs are then ignored.  Planes of more than 1024 fragment rows: TH_EIMPL. */
   const int16_t *dc_tokens;
+  int32_t coeff_format;       /* THIP_COEFFS_DEQUANT16 (0) or THIP_COEFFS_LEVELS */
+  const uint16_t *dequant;    /* THIP_COEFFS_LEVELS: device, 18 x 64 entries in slot order (see above) */
 } thip_frame_desc;
+/* One AC dequantisation table from the reference's order (zig-zag index, dequant[pli][qii][qti], decode.c:1537) into the
+   order the kernels multiply a slot with: out[(j*8 + c)*2 + p] = zz[zig-zag index of natural position (2j+p, c)]. */
+void thip_pack_dequant_table(uint16_t out[64], const uint16_t zz[64]);
 
 /* One frame of each of nstreams independent streams, all inputs resident in HBM:
    reconstruct coded fragments (oc_state_frag_recon, state.c:959), copy uncoded ones

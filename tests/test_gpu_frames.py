@@ -60,9 +60,7 @@ def test_static_background_through_the_slots_and_across_dup_frames(hip):
     for f in range(12):
         fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, content)
         if f in (4, 5, 9):   # nothing coded
-            fr = dict(fr)
-            fr.update(coded_fragis=np.zeros(0, np.int64), ncoded=[0, 0, 0], uncoded_fragis=geom.coded_order[::-1].copy(),
-                      coeffs=np.zeros((0, 64), np.int16), last_zzi=np.zeros(0, np.uint8), dc_quant=np.zeros(0, np.uint16))
+            fr = synth.nothing_coded(geom, fr)
         rc_o = util.oracle_apply(ost, fr)
         desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
         assert hip.decode_frames([gst], [desc])[0] == rc_o
@@ -264,10 +262,7 @@ def test_dup_frame_leaves_state_alone(hip):
     desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
     hip.decode_frames([gst], [desc])
     before = [gst.ref_idx(k) for k in range(3)]
-    empty = dict(fr)
-    empty.update(frame_type=hip.INTER_FRAME, coded_fragis=np.zeros(0, np.int64), ncoded=[0, 0, 0],
-                 uncoded_fragis=geom.coded_order[::-1].copy(), coeffs=np.zeros((0, 64), np.int16),
-                 last_zzi=np.zeros(0, np.uint8), dc_quant=np.zeros(0, np.uint16))
+    empty = synth.nothing_coded(geom, fr, hip.INTER_FRAME)
     assert util.oracle_apply(ost, empty) == 1
     desc2, ka2 = synth.upload_frame(synth.pack_frame(geom, empty))
     assert hip.decode_frames([gst], [desc2]) == [hip.DUPFRAME]
@@ -361,10 +356,7 @@ def test_ycbcr_map_pinned_images(hip, w, h, fmt, eager):
                 assert np.array_equal(prev_view[pli], prev_want[pli])   # the older image is untouched
         prev_view, prev_want = view, want
     # nothing coded: DUP frame, the picture and its image stay (decode.c:2764-2772)
-    empty = dict(fr)
-    empty.update(frame_type=hip.INTER_FRAME, coded_fragis=np.zeros(0, np.int64), ncoded=[0, 0, 0],
-                 uncoded_fragis=geom.coded_order[::-1].copy(), coeffs=np.zeros((0, 64), np.int16),
-                 last_zzi=np.zeros(0, np.uint8), dc_quant=np.zeros(0, np.uint16))
+    empty = synth.nothing_coded(geom, fr, hip.INTER_FRAME)
     desc2, ka2 = synth.upload_frame(synth.pack_frame(geom, empty))
     assert hip.decode_frames([gst], [desc2]) == [hip.DUPFRAME]
     view2 = gst.ycbcr_map()

@@ -26,10 +26,11 @@ def planes_equal(ost, gst, slot=oracle.FRAME_PREV):
     return bad
 
 
-def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, enqueue=False, check_every=1):
+def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, enqueue=False, check_every=1, form=None):
     """Decode nframes synthetic frames on both sides; returns list of mismatch reports.  enqueue: False (frame calls),
     True (the enqueue slots) or "alternate" (by turns, on the same state); check_every: compare every n-th frame only,
-    so that the frames in between are in flight behind each other."""
+    so that the frames in between are in flight behind each other; form: the coefficient form of the frame calls
+    ("levels", the default, "dequant16", or "alternate": by turns on the same state)."""
     geom = synth.Geometry(w, h, fmt)
     rng = np.random.default_rng(seed)
     ost = oracle.State(w, h, fmt)
@@ -43,7 +44,8 @@ def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, e
         if enqueue is True or (enqueue == "alternate" and f % 2 == 0):
             rc_g = enqueue_frame(theora_amd, gst, geom, fr)
         else:
-            desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+            fm = ("levels", "dequant16")[f % 2] if form == "alternate" else form
+            desc, ka = synth.upload_frame(synth.pack_frame(geom, fr, fm))
             keep.append(ka)
             rc_g = theora_amd.decode_frames([gst], [desc])[0]
         assert rc_o == rc_g, (f, rc_o, rc_g)

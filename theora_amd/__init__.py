@@ -12,8 +12,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import (DUPFRAME, FRAME_GOLD, FRAME_PREV, FRAME_SELF, INTER_FRAME, INTRA_FRAME,  # noqa: F401
-                   MAX_BATCH, SLOT_GROUP, SLOT_GROUP_BYTES, TILE_FRAGS, FrameDesc, PlaneGeom, TheoraHipError,
-                   TileGeom)
+                   COEFFS_DEQUANT16, COEFFS_LEVELS, MAX_BATCH, SLOT_GROUP, SLOT_GROUP_BYTES, SLOT_WIDE, TILE_FRAGS, FrameDesc,
+                   PlaneGeom, TheoraHipError, TileGeom)
 
 TILE_BLOCKS = SLOT_GROUP   # slots per coefficient group
 
@@ -36,21 +36,23 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------
 # host-side packing of a frame's fragment command stream (layout of include/theora_hip.h)
 # ---------------------------------------------------------------------------------------
-def info_words(npos, pos, refi, last_zzi, mvx, mvy, dc, dc_quant):
+def info_words(npos, pos, refi, last_zzi, mvx, mvy, dc, dc_quant, qii=None):
     """[npos,2] uint32 frag_info array (include/theora_hip.h): coded fragments at tile
     positions `pos`; every other position stays 0 (uncoded / outside the plane).  dc is the raw
     DC coefficient (used for the DC-only fragments, whose value has no coefficient slot),
     dc_quant the per-fragment DC quantiser: the dequantisation itself (state.c:967-979) is the
-    kernel's."""
+    kernel's.  qii given: the LEVELS form -- word 0 carries it, word 1 the raw DC of every block."""
     out = np.zeros((npos, 2), np.uint32)
     lz = np.asarray(last_zzi, np.uint32)
     w0 = np.uint32(_lib.INFO_CODED) | ((np.asarray(refi, np.uint32) & 3) << 1) | (lz << 8)
     w0 |= np.where(lz < 2, np.uint32(_lib.INFO_DC_ONLY), np.uint32(0))
     w0 |= (np.asarray(mvx, np.int32).astype(np.uint32) & 0xFF) << 16
     w0 |= (np.asarray(mvy, np.int32).astype(np.uint32) & 0xFF) << 24
+    if qii is not None:
+        w0 |= (np.asarray(qii, np.uint32) & 3) << _lib.INFO_QII_SHIFT
     out[pos, 0] = w0
     w1 = (np.asarray(dc_quant, np.int64).astype(np.uint32) & 0xFFFF) << 16
-    w1 |= np.where(lz < 2, np.asarray(dc, np.int32).astype(np.uint32) & 0xFFFF, 0).astype(np.uint32)
+    w1 |= np.where((lz < 2) | (qii is not None), np.asarray(dc, np.int32).astype(np.uint32) & 0xFFFF, 0).astype(np.uint32)
     out[pos, 1] = w1
     return out
 
@@ -67,6 +69,46 @@ def pack_tiles(coeffs):
     # [tile, lane, j, half, h, cc] -> [tile, j, h, lane, cc, half]
     t = pad.reshape(ntiles, TILE_BLOCKS, 4, 2, 2, 4).transpose(0, 2, 4, 1, 5, 3)
     return np.ascontiguousarray(t).reshape(-1)
+
+
+def pack_units(levels, wide, first_unit, nunits):
+    """The LEVELS form's slot array (include/theora_hip.h): levels [n,64] natural-order int16, wide [n] bool (the block's
+    tile is wide), first_unit [n] the block's first 64-byte unit.  Returns the array as uint8, whole groups of 64 units."""
+    lv = np.asarray(levels, np.int16).reshape(-1, 8, 8)
+    wide = np.asarray(wide, bool)
+    first_unit = np.asarray(first_unit, np.int64)
+    ngroups = (int(nunits) + 63) // 64
+    out = np.zeros(ngroups * 4096, np.uint8)
+
+    def addr(unit, piece):     # byte address of a unit's piece
+        return (unit >> 6) * 4096 + piece * 1024 + (unit & 63) * 16
+    nar = np.nonzero(~wide)[0]
+    if nar.size:
+        # piece j, dword d: bytes x[2j][2d], x[2j][2d+1], x[2j+1][2d], x[2j+1][2d+1]
+        b = lv[nar].astype(np.int8).reshape(-1, 4, 2, 4, 2).transpose(0, 1, 3, 2, 4)      # [n, j, d, parity, e]
+        b = np.ascontiguousarray(b).reshape(-1, 4, 16).view(np.uint8)
+        for j in range(4):
+            a = addr(first_unit[nar], j)
+            out[(a[:, None] + np.arange(16)[None, :]).reshape(-1)] = b[:, j].reshape(-1)
+    wd = np.nonzero(wide)[0]
+    if wd.size:
+        # piece q = 2j+h: the int16 pairs {x[2j][c], x[2j+1][c]}, c = 4h..4h+3; pieces 0-3 in the first unit, 4-7 in the second
+        t = lv[wd].reshape(-1, 4, 2, 2, 4).transpose(0, 1, 3, 4, 2)                        # [n, j, h, cc, parity]
+        t = np.ascontiguousarray(t).reshape(-1, 8, 8).view(np.uint8).reshape(-1, 8, 16)
+        for q in range(8):
+            a = addr(first_unit[wd] + (q >> 2), q & 3)
+            out[(a[:, None] + np.arange(16)[None, :]).reshape(-1)] = t[:, q].reshape(-1)
+    return out
+
+
+def pack_dequant_tables(dequant):
+    """[3][3][2][64] zig-zag-ordered uint16 tables -> the 18 x 64 slot-order array the kernels multiply with
+    (what thip_pack_dequant_table does for one table): out[(j*8 + c)*2 + p] = table[zig-zag index of (2j+p, c)]."""
+    from .synth import FZIG_ZAG
+    dq = np.ascontiguousarray(dequant, np.uint16).reshape(18, 64)
+    nat = np.zeros((18, 64), np.uint16)
+    nat[:, FZIG_ZAG] = dq
+    return np.ascontiguousarray(nat.reshape(18, 4, 2, 8).transpose(0, 1, 3, 2)).reshape(18, 64)
 
 
 def unpack_tiles(tiles, n):
@@ -214,9 +256,10 @@ def synchronize():
     _lib.check(_lib.load().thip_synchronize(), "thip_synchronize")
 
 
-def make_desc(info_dev, coeffs_dev, slot0_dev, nslots, ncoded, frame_type, flimit, dc_tokens_dev=None):
+def make_desc(info_dev, coeffs_dev, slot0_dev, nslots, ncoded, frame_type, flimit, dc_tokens_dev=None, dequant_dev=None):
+    """dequant_dev given: the LEVELS form (coeffs_dev = units, slot0 = first units | SLOT_WIDE, nslots = units)."""
     return FrameDesc(_ptr(info_dev), _ptr(coeffs_dev), _ptr(slot0_dev), nslots, ncoded, frame_type, flimit,
-                     _ptr(dc_tokens_dev))
+                     _ptr(dc_tokens_dev), COEFFS_LEVELS if dequant_dev is not None else COEFFS_DEQUANT16, _ptr(dequant_dev))
 
 
 def profile_enable(on):

@@ -16,7 +16,9 @@ INTRA_FRAME, INTER_FRAME = 0, 1
 MAX_BATCH = 8
 TILE_FRAGS = 64
 SLOT_GROUP, SLOT_GROUP_BYTES = 64, 8192
-INFO_CODED, INFO_DC_ONLY = 0x1, 0x8
+INFO_CODED, INFO_DC_ONLY, INFO_QII_SHIFT = 0x1, 0x8, 4
+COEFFS_DEQUANT16, COEFFS_LEVELS = 0, 1
+UNIT_BYTES, UNIT_GROUP_BYTES, SLOT_WIDE = 64, 4096, 0x80000000
 KERNEL_RECON, KERNEL_LOOPFILTER, NKERNELS = 0, 1, 2
 
 ENC_OPS = dict(sad=0, sad_thresh=1, sad2_thresh=2, intra_sad=3, satd=4, satd2=5, intra_satd=6, ssd=7)
@@ -31,7 +33,7 @@ class PlaneGeom(C.Structure):
 class FrameDesc(C.Structure):
     _fields_ = [("frag_info", C.c_void_p), ("coeffs", C.c_void_p), ("tile_slot0", C.c_void_p),
                 ("nslots", C.c_int32), ("ncoded", C.c_int32), ("frame_type", C.c_int32),
-                ("flimit", C.c_int32), ("dc_tokens", C.c_void_p)]
+                ("flimit", C.c_int32), ("dc_tokens", C.c_void_p), ("coeff_format", C.c_int32), ("dequant", C.c_void_p)]
 
 
 class TileGeom(C.Structure):
@@ -82,6 +84,7 @@ SYMBOLS = [
     ("thip_dc_unpredict_plane", _I, [_P, _P, _I, _I]),
     ("thip_state_set_device_dc", _I, [_P, _I]),
     ("thip_frame_dequant_table", _I, [_P, _I, _P]),
+    ("thip_pack_dequant_table", None, [_P, _P]),
     ("thip_state_frag_recon_tokens", _I, [_P, C.c_ssize_t, _I, _P, _I, C.c_int16, _I, C.c_uint16, _I, _I, C.c_int16]),
     ("thip_enc_frag_metric_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _U32, _I64]),
     ("thip_enc_frag_metric_sites_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I64]),

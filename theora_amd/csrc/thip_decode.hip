@@ -931,12 +931,17 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   int max_wg = 0, max_seam_wg = 0, any_lf = 0, nlive = 0;
   int any_skip = 0;
   int live_state[THIP_MAX_BATCH];
+  const bool levels = n > 0 && descs[0].coeff_format == THIP_COEFFS_LEVELS;   // (the callers cut chunks where the form changes)
   for (int i = 0; i < n; i++) {
     thip_state *st = states[i];
     const thip_frame_desc &d = descs[i];
     if (!st) return THIP_EFAULT;
-    if (d.ncoded < 0 || d.nslots < 0 || d.nslots > d.ncoded || d.ncoded > st->nfrags) return THIP_EINVAL;
+    if (d.coeff_format != THIP_COEFFS_DEQUANT16 && d.coeff_format != THIP_COEFFS_LEVELS) return THIP_EINVAL;
+    if ((d.coeff_format == THIP_COEFFS_LEVELS) != levels) return THIP_EINVAL;
+    // (nslots counts slots, or units in the levels form: at most two per coded fragment)
+    if (d.ncoded < 0 || d.nslots < 0 || d.nslots > (d.coeff_format == THIP_COEFFS_LEVELS ? 2 : 1) * (int64_t)d.ncoded || d.ncoded > st->nfrags) return THIP_EINVAL;
     if (d.ncoded && (!d.frag_info || !d.tile_slot0 || (d.nslots && !d.coeffs))) return THIP_EFAULT;
+    if (d.ncoded && d.coeff_format == THIP_COEFFS_LEVELS && !d.dequant) return THIP_EFAULT;
     if (d.flimit < 0 || d.flimit > 127) return THIP_EINVAL;
     if (d.frame_type != THIP_INTRA_FRAME && d.frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
     if (d.frame_type == THIP_INTRA_FRAME && d.ncoded != st->nfrags) return THIP_EINVAL;
@@ -968,6 +973,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     K.info = reinterpret_cast<const uint2 *>(d.frag_info);
     K.coeffs = reinterpret_cast<const int4 *>(d.coeffs);
     K.tile_slot0 = d.tile_slot0;
+    K.dequant = d.coeff_format == THIP_COEFFS_LEVELS ? reinterpret_cast<const uint4 *>(d.dequant) : nullptr;
     K.self = st->frames[bufi];
     K.prev = st->ref_idx[THIP_FRAME_PREV] >= 0 ? st->frames[st->ref_idx[THIP_FRAME_PREV]] : st->frames[bufi];
     K.gold = st->ref_idx[THIP_FRAME_GOLD] >= 0 ? st->frames[st->ref_idx[THIP_FRAME_GOLD]] : st->frames[bufi];
@@ -1088,11 +1094,13 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       K.epoch = st->edge_epoch;
     }
     ScopedTimer t(s, THIP_KERNEL_RECON);
-    hipLaunchKernelGGL(k_recon_lf, dim3(8 * longest, nlive), dim3(64), 0, s, B);
+    if (levels) hipLaunchKernelGGL(k_recon_lf<true>, dim3(8 * longest, nlive), dim3(64), 0, s, B);
+    else hipLaunchKernelGGL(k_recon_lf<false>, dim3(8 * longest, nlive), dim3(64), 0, s, B);
   } else {
     {
       ScopedTimer t(s, THIP_KERNEL_RECON);
-      hipLaunchKernelGGL(k_recon, dim3(max_wg, nlive), dim3(64 * THIP_RECON_WG_WAVES), 0, s, B);
+      if (levels) hipLaunchKernelGGL(k_recon<true>, dim3(max_wg, nlive), dim3(64 * THIP_RECON_WG_WAVES), 0, s, B);
+      else hipLaunchKernelGGL(k_recon<false>, dim3(max_wg, nlive), dim3(64 * THIP_RECON_WG_WAVES), 0, s, B);
     }
     if (any_lf) {
       ScopedTimer t(s, THIP_KERNEL_LOOPFILTER);
@@ -1125,8 +1133,11 @@ static int validate_frames(thip_state *const *states, const thip_frame_desc *des
     const thip_state *st = states[i];
     const thip_frame_desc &d = descs[i];
     if (!st) return THIP_EFAULT;
-    if (d.ncoded < 0 || d.nslots < 0 || d.nslots > d.ncoded || d.ncoded > st->nfrags) return THIP_EINVAL;
+    if (d.coeff_format != THIP_COEFFS_DEQUANT16 && d.coeff_format != THIP_COEFFS_LEVELS) return THIP_EINVAL;
+    // (nslots counts slots, or units in the levels form: at most two per coded fragment)
+    if (d.ncoded < 0 || d.nslots < 0 || d.nslots > (d.coeff_format == THIP_COEFFS_LEVELS ? 2 : 1) * (int64_t)d.ncoded || d.ncoded > st->nfrags) return THIP_EINVAL;
     if (d.ncoded && (!d.frag_info || !d.tile_slot0 || (d.nslots && !d.coeffs))) return THIP_EFAULT;
+    if (d.ncoded && d.coeff_format == THIP_COEFFS_LEVELS && !d.dequant) return THIP_EFAULT;
     if (d.flimit < 0 || d.flimit > 127) return THIP_EINVAL;
     if (d.frame_type != THIP_INTRA_FRAME && d.frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
     if (d.frame_type == THIP_INTRA_FRAME && d.ncoded != st->nfrags) return THIP_EINVAL;
@@ -1154,10 +1165,12 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
       if (states[i]->device != states[0]->device) return THIP_EINVAL;
     if (!nstreams) return THIP_OK;
     DeviceGuard dg(states[0]->device);
-    for (int i = 0; i < nstreams; i += THIP_MAX_BATCH) {
-      const int n = nstreams - i < THIP_MAX_BATCH ? nstreams - i : THIP_MAX_BATCH;
+    for (int i = 0; i < nstreams;) {
+      int n = 1;   // (a chunk holds one coefficient form: k_recon / k_recon_lf exist once per form)
+      while (i + n < nstreams && n < THIP_MAX_BATCH && descs[i + n].coeff_format == descs[i].coeff_format) n++;
       rc = launch_chunk(states + i, descs + i, n, s, results ? results + i : nullptr);
       if (rc < 0) return rc;
+      i += n;
     }
     return THIP_OK;
   }
@@ -1179,14 +1192,15 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
         std::lock_guard<std::mutex> lk(g_mu);
         states[i]->lane = g_next_lane[dev]++ % g_nlanes;
       }
-    for (int lane = 0; lane < g_nlanes; lane++) {
+    for (int lane = 0; lane < g_nlanes; lane++)
+     for (int form = 0; form < 2; form++) {   // (a chunk holds one coefficient form)
       thip_state *ls[THIP_MAX_BATCH];
       thip_frame_desc ld[THIP_MAX_BATCH];
       int32_t lr[THIP_MAX_BATCH];
       int li[THIP_MAX_BATCH];
       int n = 0;
       for (int i = 0; i <= nstreams; i++) {
-        if (i < nstreams && states[i]->device == dev && states[i]->lane == lane) {
+        if (i < nstreams && states[i]->device == dev && states[i]->lane == lane && (descs[i].coeff_format == THIP_COEFFS_LEVELS) == (form == 1)) {
           ls[n] = states[i];
           ld[n] = descs[i];
           li[n] = i;
@@ -1510,6 +1524,14 @@ static int ensure_token_staging(thip_state *st) {
   if (!st->d_dq) HIP_TRY(hipMalloc((void **)&st->d_dq, 18 * 64 * 2));
   st->tok_ready = 1;
   return THIP_OK;
+}
+
+void thip_pack_dequant_table(uint16_t out[64], const uint16_t zz[64]) {
+  uint16_t nat[64];
+  for (int i = 0; i < 64; i++) nat[fzig_zag(i)] = zz[i];
+  for (int j = 0; j < 4; j++)
+    for (int c = 0; c < 8; c++)
+      for (int p = 0; p < 2; p++) out[(j * 8 + c) * 2 + p] = nat[(2 * j + p) * 8 + c];
 }
 
 int thip_frame_dequant_table(thip_state *st, int sel, const uint16_t dequant[64]) {

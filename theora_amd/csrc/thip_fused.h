@@ -54,10 +54,12 @@ constexpr int kTfImgRows = 40;                 // pixel rows -4 .. 35 (of the up
 constexpr int kTfFlagOff = kTfImgRows * kTfPitch;   // coded flags: 6 rows (block rows -1..4) of kTfFlagPitch bytes
 constexpr int kTfFlagPitch = 20;               // [0] block column -1, [1..16] the tile, [17] column 16
 // The wave's LDS: 7 KB, not 8.  This chip hands LDS out in 1280-byte granules, so 8 KB costs 8960 bytes and a CU holds 18 such
-// waves; 7 KB costs 7680 and it holds the 20 the registers allow.  Seven of a tile's eight 1-KB coefficient pieces are staged
-// here (LDS-DMA), the eighth stays in registers.
+// waves; 7 KB costs 7680 and it holds the 20 the registers allow.  Seven of a tile's eight 1-KB int16 coefficient pieces are staged
+// here (LDS-DMA), the eighth stays in registers; in the levels form the four 1-KB pieces of int8 units (six of the eight of a
+// wide tile) and, at kLdsTabOff, the plane's dequantisation tables.
 constexpr int kTfLds = 7168;
 static_assert(kTfFlagOff + 6 * kTfFlagPitch <= kTfLds, "the image lives in the wave's staging area");
+static_assert(kLdsTabOff + 768 <= kTfLds && kLdsTabOff >= 6 * 1024, "the tables sit behind six staged pieces");
 // a tile's record in StreamK::edge: units of 16 bytes = 3 dwords of pixels + tag
 constexpr int kTfUnit = 16;
 constexpr int kTfBotUnits = 22, kTfRightUnits = 11;      // 256 and 128 bytes of pixels
@@ -205,6 +207,7 @@ __device__ __forceinline__ void tf_cell(const uint8_t *lds, uint8_t *plane, int 
 #ifndef THIP_TF_WAVES_PER_EU
 #define THIP_TF_WAVES_PER_EU 5    // 96 VGPRs; with 8 KB of LDS per wave that is 20 waves per CU
 #endif
+template <bool LEVELS>
 __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const BatchK B) {
   __shared__ uint4 s_tf[kTfLds / 16];   // wave-private (one wave per work group): coefficient staging, then the tile image
   const StreamK &S = B.s[blockIdx.y];
@@ -218,13 +221,14 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   const uint8_t *prev = S.prev, *gold = S.gold;
   uint8_t *coded_map = S.coded_map;
   const int16_t *dc_p = S.dc;
+  const uint4 *dq_p = S.dequant;
   uint8_t *edge_p = S.edge;
   const int te0 = S.tile_end[0], te1 = S.tile_end[1];
   const int sqpx = S.qpx, sqpy = S.qpy;
   const int L2 = (S.debug & 256) ? 0 : S.flimit2;   // (ablation switch for profiling, option debug = 256: cells copy, no filtering)
   const uint32_t ep = S.epoch;
   const int bu0 = S.band_u0[band], bu1 = S.band_u0[band + 1];
-  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map), "s"(dc_p), "s"(edge_p),
+  asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map), "s"(dc_p), "s"(dq_p), "s"(edge_p),
                "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2), "s"(ep), "s"(bu0), "s"(bu1));
   const int u = bu0 + jb;
   if (u >= bu1) return;
@@ -240,6 +244,8 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
 #endif
   THIP_TR(tr, 0);
   const int pli = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
+  constexpr bool levels = LEVELS;   // (one kernel per coefficient form: each is straight-line code for its own)
+  if (levels) tables_to_lds(dq_p, pli, lane, s_tf);   // (first: whoever has its command word has the tables)
   const PlaneK G = S.pl[pli];
   const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
   asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.tiles_y), "s"(G.fro), "s"(fy0), "s"(fy1));
@@ -258,14 +264,16 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   const int bx = t * 16 + lx, by = sby * 4 + ly;
   const bool valid = bx < nh && by < nv;
   // ---- 1. command word + first slot of the tile ------------------------------------------------------
-  const uint32_t slot0 = slot0_p[u];
+  const uint32_t slot0w = slot0_p[u];
   const uint2 info = info_p[(size_t)u * THIP_TILE_FRAGS + lane];
   uint32_t dcv = 0;   // the block's un-predicted DC when it does not travel in the command stream
   if (dc_p) dcv = 0x10000u | (uint16_t)dc_p[G.fro + min(by, nv - 1) * nh + min(bx, nh - 1)];
-  asm volatile("" ::"s"(slot0), "v"(info.x), "v"(dcv));
+  asm volatile("" ::"s"(slot0w), "v"(info.x), "v"(dcv));
 #ifdef THIP_TRACE
   THIP_TR(tr, 1);   // command words are here
 #endif
+  if (levels && !dc_p) dcv = 0x10000u | (info.y & 0xFFFFu);   // levels form: every coded block's raw DC rides in command word 1
+  const CoefForm F = coef_form(slot0w, levels);
   ReconLane L;
   L.flags = valid ? info.x : 0u;
   L.dcq = info.y >> 16;
@@ -306,26 +314,20 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     if (valid) recon_issue(R, L, Q, inter, ref);
   } else if (nown <= 16) {
     int4 Wc[1][2];
-    residual_shared_load<4>(coeffs_p, slot0, nown, lane, Wc);
+    residual_shared_load<4>(coeffs_p, F, nown, lane, Wc);
     if (valid) recon_issue(R, L, Q, inter, ref);
-    residual_shared<4>(Wc, lds_dw, meta, lane, L, prefix, Y);
+    residual_shared<4>(Wc, F, lds_dw, meta, lane, L, prefix, Y);
   } else if (nown <= 32) {
     int4 Wc[2][2];
-    residual_shared_load<2>(coeffs_p, slot0, nown, lane, Wc);
+    residual_shared_load<2>(coeffs_p, F, nown, lane, Wc);
     if (valid) recon_issue(R, L, Q, inter, ref);
-    residual_shared<2, true>(Wc, lds_dw, meta, lane, L, prefix, Y);
+    residual_shared<2, true>(Wc, F, lds_dw, meta, lane, L, prefix, Y);
   } else {
-    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
-    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
-#pragma unroll
-    for (int q = 0; q < 7; q++)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
-                                       (__attribute__((address_space(3))) void *)(s_tf + q * 64), 16, 0, 0);
-    const int4 w7i = tp[7 * 64];
+    int4 w7;
+    dense_issue<7>(coeffs_p, F, L.has_coeff, prefix, s_tf, w7);
     if (valid) recon_issue(R, L, Q, inter, ref);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)
-    const uint4 w7 = make_uint4((uint32_t)w7i.x, (uint32_t)w7i.y, (uint32_t)w7i.z, (uint32_t)w7i.w);
-    residual_per_lane(s_tf + lane, L, Y, &w7);
+    dense_finish<7>(coeffs_p, F, L.has_coeff, prefix, s_tf, lane, L, w7, Y);
   }
   if (!L.has_coeff) {
 #pragma unroll

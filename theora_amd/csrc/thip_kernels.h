@@ -52,6 +52,10 @@ struct StreamK {
   const uint8_t *coded_prev;   // the same map of the previous frame of this stream (two maps alternate)
   const int16_t *dc;      // null, or the un-predicted DC of every fragment (fragment-index order, k_dc_unpredict's
                           // output): used instead of the DC fields of the command words / coefficient slots
+  const uint4 *dequant;   // null: the slots hold dequantised int16 coefficients (THIP_COEFFS_DEQUANT16).  Else THIP_COEFFS_LEVELS: the
+                          // slots hold quantised LEVELS (64-byte int8 units; two units of int16 per block in the tiles whose
+                          // tile_slot0 carries THIP_SLOT_WIDE) and this is the frame's 18 AC dequantisation tables in slot order
+                          // (thip_pack_dequant_table): the multiplication of decode.c:1573 happens in the kernel
   int skip_ok;            // the buffer this frame goes to holds the frame before the previous one: an uncoded
                           // block that was not touched in the previous frame either is already in place
   int flimit2;            // 2*flimit
@@ -409,7 +413,7 @@ __device__ __forceinline__ uint32_t dequant_dc_lo(uint32_t w, uint32_t dcq, uint
 
 struct ReconLane {
   uint32_t flags, dcp, dcq;       // command word 0 (0 past the ragged edge), DC-only value {p,p}, dc_quant
-  uint32_t dcraw;                 // bit 16 set: bits 0-15 are the block's raw DC (StreamK::dc), to be used instead of x[0][0] of its slot
+  uint32_t dcraw;                 // bit 16 set: bits 0-15 are the block's raw DC (StreamK::dc, or command word 1 in the levels form), to be used instead of x[0][0] of its slot
   bool coded, dc_only, has_coeff;
   int x0, y0;                     // pixel position of the block in its plane
 };
@@ -422,6 +426,53 @@ struct ReconPlane {               // wave-uniform
   int debug;
   unsigned long long *tr;         // THIP_TRACE: this wave's record (lane 0 only), else null
 };
+
+// ---- the two coefficient forms (include/theora_hip.h: THIP_COEFFS_*) ---------------------------------------------------------
+// DEQUANT16: one 128-byte slot per block, int16, AC already dequantised by the caller (what oc_state_frag_recon receives).
+// LEVELS: the quantised values as the tokens carry them plus the frame's dequantisation tables; the kernel does
+// `(ogg_int16_t)(coeff*ac_quant[zzi])` (decode.c:1573-1574, the table picked as decode.c:1537-1538 does: plane, qii,
+// qti = the block is not intra) -- half the bytes of the largest term of a dense frame.  The slot array is then counted in
+// 64-byte UNITS (groups of 64 units = 4 KB, piece-major like the int16 groups): a block of a narrow tile owns one unit, four
+// 16-byte pieces, piece j = row pair j: for d = 0..3 the bytes { x[2j][2d], x[2j][2d+1], x[2j+1][2d], x[2j+1][2d+1] } (two
+// packed shifts turn a dword into the two int16 pairs the row pass wants); a block of a WIDE tile (some level of the tile
+// does not fit eight bits: tile_slot0 bit 31) owns two consecutive units holding the eight int16 pieces of the other form.
+constexpr uint32_t kSlotWide = THIP_SLOT_WIDE;
+constexpr int kLdsTabOff = 6144;       // the plane's six tables (768 bytes) in a wave's LDS area, behind anything the loads stage
+struct CoefForm {                      // wave-uniform
+  bool levels, wide;
+  uint32_t slot0;                      // first slot (DEQUANT16) / first unit (LEVELS) of the tile
+};
+__device__ __forceinline__ CoefForm coef_form(uint32_t slot0_word, bool levels) {
+  CoefForm F;
+  F.levels = levels;
+  F.wide = levels && (slot0_word & kSlotWide) != 0;
+  F.slot0 = levels ? slot0_word & ~kSlotWide : slot0_word;
+  return F;
+}
+// piece q (0..3) of unit `unit`
+__device__ __forceinline__ const int4 *unit_piece(const int4 *coeffs, uint32_t unit, int q) {
+  return coeffs + ((size_t)(unit >> 6) * 256 + (size_t)q * 64 + (unit & 63));
+}
+// piece q (0..7) of the wide block that starts at unit `unit`
+__device__ __forceinline__ const int4 *wide_piece(const int4 *coeffs, uint32_t unit, int q) { return unit_piece(coeffs, unit + (uint32_t)(q >> 2), q & 3); }
+// four int8 levels -> the pairs { x[2j][c], x[2j+1][c] } of an even and an odd column
+__device__ __forceinline__ void unpack_levels(uint32_t w, uint32_t &even, uint32_t &odd) {
+  const pk16 v = as_pk(w);
+  odd = as_u32(v >> 8);            // bytes 1 and 3, sign-extended (v_pk_ashrrev_i16)
+  even = as_u32((v << 8) >> 8);    // bytes 0 and 2
+}
+__device__ __forceinline__ uint32_t pk_mul_lo(uint32_t a, uint32_t b) { return as_u32(as_pk(a) * as_pk(b)); }   // low 16 bits of each product: the (ogg_int16_t) cast
+// the dequantisation table of a block inside its plane's six: qii * 2 + qti (decode.c:1537-1538)
+__device__ __forceinline__ uint32_t table_of(uint32_t flags) {
+  return ((flags >> THIP_INFO_QII_SHIFT) & 3u) * 2u + (((flags >> THIP_INFO_REFI_SHIFT) & 3u) != (uint32_t)THIP_FRAME_SELF ? 1u : 0u);
+}
+// The plane's six tables into the wave's LDS (LDS-DMA, lanes 0..47 one 16-byte piece each).  Issued BEFORE the command words are
+// requested: loads come back in order, so whoever has its command word also has the tables.
+__device__ __forceinline__ void tables_to_lds(const uint4 *dequant, int pli, int lane, uint4 *lds_wave) {
+  if (lane < 48)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dequant + pli * 48 + lane),
+                                     (__attribute__((address_space(3))) void *)(lds_wave + kLdsTabOff / 16), 16, 0, 0);
+}
 
 // ---- k_recon in three parts, so that the residual can be computed by ALL lanes of the wave ------
 __device__ __forceinline__ void recon_issue(const ReconPlane &R, const ReconLane &L, PredWin &Q, bool &inter,
@@ -458,18 +509,100 @@ __device__ __forceinline__ void recon_finish(const ReconPlane &R, const ReconLan
   }
 }
 
-// Residual of the lanes that own coefficients, one block per lane (the whole wave executes the
-// 16 one-dimensional transforms whether 1 lane or 64 need them).
-// (last: piece 7 when it did not go through LDS -- k_recon_lf stages seven pieces, 7 KB, and takes the eighth in registers)
-__device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const ReconLane &L, uint32_t Y[32], const uint4 *last = nullptr) {
-  uint32_t P[32];
+// ---- one block per lane (more than 32 lanes of the tile own coefficients) ----------------------------------------------------
+// The loads: coefficients go global -> LDS directly (LDS address = wave-uniform base + lane * 16: no VGPRs are tied up and
+// nothing can make the compiler touch -- i.e. wait for -- the data before the predictor loads are out); every lane loads (lanes
+// without coefficients re-read the tile's first slot: same cache lines).  NLDS of the eight int16 pieces are staged (k_recon: 8;
+// k_recon_lf: 7, its LDS area is 7 KB), six of a wide tile's (the tables sit behind them), the rest stays in registers; the
+// four pieces of a narrow unit all go through LDS.
+template <int NLDS>
+__device__ __forceinline__ void dense_issue(const int4 *coeffs_p, const CoefForm &F, bool has_coeff, uint32_t prefix, uint4 *lds_wave, int4 &w7) {
+  w7 = make_int4(0, 0, 0, 0);
+  if (!F.levels) {
+    const uint32_t slot = F.slot0 + (has_coeff ? prefix : 0u);
+    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const uint4 w = (q == 7 && last) ? *last : lds_coef[q * 64];
-    P[q * 4 + 0] = w.x;
-    P[q * 4 + 1] = w.y;
-    P[q * 4 + 2] = w.z;
-    P[q * 4 + 3] = w.w;
+    for (int q = 0; q < NLDS; q++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
+                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, THIP_COEF_CPOL);
+    if (NLDS < 8) w7 = tp[7 * 64];
+  } else if (!F.wide) {
+    const uint32_t unit = F.slot0 + (has_coeff ? prefix : 0u);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)unit_piece(coeffs_p, unit, q),
+                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, THIP_COEF_CPOL);
+  } else {
+    // a wide tile (rare): six pieces now -- the tables sit behind them --, the last two in a second round (dense_finish)
+    const uint32_t unit = F.slot0 + (has_coeff ? 2u * prefix : 0u);
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)wide_piece(coeffs_p, unit, q),
+                                       (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, THIP_COEF_CPOL);
+  }
+}
+
+// Residual of the lanes that own coefficients, one block per lane (the whole wave executes the
+// 16 one-dimensional transforms whether 1 lane or 64 need them).  Call it behind `s_waitcnt vmcnt(0)` (LDS-DMA data has landed).
+template <int NLDS>
+__device__ __forceinline__ void dense_finish(const int4 *coeffs_p, const CoefForm &F, bool has_coeff, uint32_t prefix, uint4 *lds_wave, int lane,
+                                             const ReconLane &L, const int4 &w7, uint32_t Y[32]) {
+  const uint4 *lds_coef = lds_wave + lane;
+  const uint4 *tab = lds_wave + kLdsTabOff / 16 + table_of(L.flags) * 8;   // (levels form)
+  uint32_t P[32];
+  if (F.levels && !F.wide) {
+    // row pair by row pair: its 16 levels, its two table pieces, `(ogg_int16_t)(coeff * ac_quant[zzi])` (decode.c:1573).  The
+    // fences keep the scheduler from fetching all eight table pieces ahead of the first product -- 32 registers the wave does
+    // not have next to its predictor windows (it spilled them, and waited for them first).
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint4 w = lds_coef[j * 64];
+      const uint4 t0 = tab[2 * j], t1 = tab[2 * j + 1];
+      uint32_t e, o;
+      unpack_levels(w.x, e, o);
+      P[j * 8 + 0] = pk_mul_lo(e, t0.x);
+      P[j * 8 + 1] = pk_mul_lo(o, t0.y);
+      unpack_levels(w.y, e, o);
+      P[j * 8 + 2] = pk_mul_lo(e, t0.z);
+      P[j * 8 + 3] = pk_mul_lo(o, t0.w);
+      unpack_levels(w.z, e, o);
+      P[j * 8 + 4] = pk_mul_lo(e, t1.x);
+      P[j * 8 + 5] = pk_mul_lo(o, t1.y);
+      unpack_levels(w.w, e, o);
+      P[j * 8 + 6] = pk_mul_lo(e, t1.z);
+      P[j * 8 + 7] = pk_mul_lo(o, t1.w);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    const int nlds = F.levels ? 6 : NLDS;   // (compile time)
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (q == 6 && F.levels) {   // the wide tile's second round: pieces 6 and 7 over pieces 0 and 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t unit = F.slot0 + (has_coeff ? 2u * prefix : 0u);
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)wide_piece(coeffs_p, unit, 6 + k),
+                                           (__attribute__((address_space(3))) void *)(lds_wave + k * 64), 16, 0, THIP_COEF_CPOL);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      uint4 w;
+      if (q < nlds) w = lds_coef[q * 64];
+      else if (F.levels) w = lds_coef[(q - 6) * 64];
+      else w = make_uint4((uint32_t)w7.x, (uint32_t)w7.y, (uint32_t)w7.z, (uint32_t)w7.w);
+      if (F.levels) {   // int16 levels of a wide tile
+        const uint4 t = tab[q];
+        w.x = pk_mul_lo(w.x, t.x);
+        w.y = pk_mul_lo(w.y, t.y);
+        w.z = pk_mul_lo(w.z, t.z);
+        w.w = pk_mul_lo(w.w, t.w);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      P[q * 4 + 0] = w.x;
+      P[q * 4 + 1] = w.y;
+      P[q * 4 + 2] = w.z;
+      P[q * 4 + 3] = w.w;
+    }
   }
   P[0] = dequant_dc_lo(P[0], L.dcq, L.dcraw);   // x[0][0] arrives raw
   const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
@@ -479,42 +612,50 @@ __device__ __forceinline__ void residual_per_lane(const uint4 *lds_coef, const R
   pk_idct8x8(P, Y, all_zz10);
 }
 
-// The same residuals when at most 64/LPB lanes of the wave own coefficients (the usual case
+// ---- at most 64/LPB lanes of the wave own coefficients (the usual case
 // outside synthetic worst cases: SURVEY section 6 has 80 % of the coded blocks DC-only): LPB lanes
 // (4 or 2) share a block -- lane LPB*g+j takes row pairs j*NP..j*NP+NP-1 (NP = 4/LPB) of the
 // g-th owner for the row pass and the same column pairs for the column pass, the transpose
 // between goes through the wave's LDS area (free once the coefficients are in registers) -- so
-// the wave executes 2*NP packed 1-D transforms instead of 8.  Bit-exact with residual_per_lane:
+// the wave executes 2*NP packed 1-D transforms instead of 8.  Bit-exact with dense_finish:
 // the same operations on the same values.  Must be called by all 64 lanes.
 // lds = the wave's 8 KB area as dwords; meta = 64 dwords of LDS (two words per owner rank, up to 32 owners).
 // The g-th owner's coefficients sit in slot slot0+g (slots are numbered in lane order inside a
 // tile), so the sharing lanes fetch their own row pairs straight from the slot -- 32*NP bytes per
-// lane instead of the whole wave staging 8 KB of which a fraction is used.
+// lane (16*NP of a narrow unit) instead of the whole wave staging 8 KB of which a fraction is used.
 template <int LPB>
-__device__ __forceinline__ void residual_shared_load(const int4 *coeffs, uint32_t slot0, int nown, int lane,
+__device__ __forceinline__ void residual_shared_load(const int4 *coeffs, const CoefForm &F, int nown, int lane,
                                                      int4 W[4 / LPB][2]) {
   constexpr int NP = 4 / LPB;
   const int g = min(lane / LPB, nown - 1), j = lane % LPB;   // surplus groups re-read the last owner's slot
-  const uint32_t slot = slot0 + (uint32_t)g;
-  const int4 *tp = coeffs + ((size_t)(slot >> 6) * 512 + (slot & 63));
 #pragma unroll
   for (int n = 0; n < NP; n++) {
     const int rp = j * NP + n;
-    W[n][0] = tp[(2 * rp) * 64];
-    W[n][1] = tp[(2 * rp + 1) * 64];
+    if (!F.levels) {
+      const uint32_t slot = F.slot0 + (uint32_t)g;
+      const int4 *tp = coeffs + ((size_t)(slot >> 6) * 512 + (slot & 63));
+      W[n][0] = tp[(2 * rp) * 64];
+      W[n][1] = tp[(2 * rp + 1) * 64];
+    } else if (!F.wide) {
+      W[n][0] = *unit_piece(coeffs, F.slot0 + (uint32_t)g, rp);
+      W[n][1] = make_int4(0, 0, 0, 0);
+    } else {
+      W[n][0] = *wide_piece(coeffs, F.slot0 + 2u * (uint32_t)g, 2 * rp);
+      W[n][1] = *wide_piece(coeffs, F.slot0 + 2u * (uint32_t)g, 2 * rp + 1);
+    }
   }
 }
 
 // COMPACT: the results go where the exchange was (4 KB of LDS instead of 8 for LPB = 2): every lane
 // collects all its column pairs first, the wave's LDS traffic settles, then results are written.
 template <int LPB, bool COMPACT = false>
-__device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32_t *lds, uint32_t *meta, int lane,
+__device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], const CoefForm &F, uint32_t *lds, uint32_t *meta, int lane,
                                                 const ReconLane &L, uint32_t prefix, uint32_t Y[32]) {
   constexpr int NP = 4 / LPB;                        // row pairs (and column pairs) per lane
   const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
   if (L.has_coeff) {
-    meta[prefix] = (uint32_t)last_zzi | (L.dcq << 16);   // rank -> last_zzi, dc_quant of that owner
-    meta[32 + prefix] = L.dcraw;                          // ... and its raw DC when that comes from the DC array
+    meta[prefix] = (uint32_t)last_zzi | table_of(L.flags) << 8 | (L.dcq << 16);   // rank -> last_zzi, table, dc_quant of that owner
+    meta[32 + prefix] = L.dcraw;                          // ... and its raw DC when that does not come from the slot
   }
   const int g = lane / LPB, j = lane % LPB;
   const uint32_t mg = meta[g];                      // (garbage for g >= number of owners: results unused)
@@ -522,19 +663,38 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32
   const int lz = (int)(mg & 0x7Fu);
   const uint32_t dcq_g = j == 0 ? mg >> 16 : 1u;    // the lane holding row pair 0 dequantises x[0][0]
   const bool c3 = lz <= 3, c10 = lz <= 10;
+  const uint4 *tab = reinterpret_cast<const uint4 *>(lds) + kLdsTabOff / 16 + ((mg >> 8) & 7u) * 8;   // (levels form)
   pk16 Rr[NP][8];
 #pragma unroll
   for (int n = 0; n < NP; n++) {
     const int rp = j * NP + n;                       // row pair: rows 2rp, 2rp+1
     const int4 w0 = W[n][0], w1 = W[n][1];
-    const uint32_t P8[8] = {n == 0 ? dequant_dc_lo((uint32_t)w0.x, dcq_g, j == 0 ? dcraw_g : 0u) : (uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w,
-                            (uint32_t)w1.x, (uint32_t)w1.y, (uint32_t)w1.z, (uint32_t)w1.w};   // {x[2rp][c], x[2rp+1][c]}, c = 0..7
+    uint32_t X[8] = {(uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w,
+                     (uint32_t)w1.x, (uint32_t)w1.y, (uint32_t)w1.z, (uint32_t)w1.w};   // {x[2rp][c], x[2rp+1][c]}, c = 0..7
+    if (F.levels) {
+      if (!F.wide) {
+        unpack_levels((uint32_t)w0.x, X[0], X[1]);
+        unpack_levels((uint32_t)w0.y, X[2], X[3]);
+        unpack_levels((uint32_t)w0.z, X[4], X[5]);
+        unpack_levels((uint32_t)w0.w, X[6], X[7]);
+      }
+      const uint4 t0 = tab[2 * rp], t1 = tab[2 * rp + 1];   // decode.c:1573
+      X[0] = pk_mul_lo(X[0], t0.x);
+      X[1] = pk_mul_lo(X[1], t0.y);
+      X[2] = pk_mul_lo(X[2], t0.z);
+      X[3] = pk_mul_lo(X[3], t0.w);
+      X[4] = pk_mul_lo(X[4], t1.x);
+      X[5] = pk_mul_lo(X[5], t1.y);
+      X[6] = pk_mul_lo(X[6], t1.z);
+      X[7] = pk_mul_lo(X[7], t1.w);
+    }
+    if (n == 0) X[0] = dequant_dc_lo(X[0], dcq_g, j == 0 ? dcraw_g : 0u);
     // what the variant selected by last_zzi does not read is zero (pk_mask_by_last_zzi)
 #pragma unroll
     for (int c = 0; c < 8; c++) {
       const uint32_t m10 = ((2 * rp + c <= 3) ? 0x0000FFFFu : 0u) | ((2 * rp + 1 + c <= 3) ? 0xFFFF0000u : 0u);
       const uint32_t m3 = ((rp == 0 && c <= 1) ? 0x0000FFFFu : 0u) | ((rp == 0 && c == 0) ? 0xFFFF0000u : 0u);
-      Rr[n][c] = as_pk(P8[c] & (c3 ? m3 : (c10 ? m10 : 0xFFFFFFFFu)));
+      Rr[n][c] = as_pk(X[c] & (c3 ? m3 : (c10 ? m10 : 0xFFFFFFFFu)));
     }
     pk_idct8(Rr[n][0], Rr[n][1], Rr[n][2], Rr[n][3], Rr[n][4], Rr[n][5], Rr[n][6], Rr[n][7]);
   }
@@ -586,6 +746,7 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], uint32
 // scalar loads, not dependent vector loads.
 // One tile of one stream: k_recon's wave.  lds_wave: the wave's 8 KB of LDS, meta: its 64
 // dwords for residual_shared.  (Lanes leave at different places; the caller gets the whole wave back.)
+template <bool LEVELS>
 __device__ __forceinline__ void recon_tile(const StreamK &S, const int unit, const int lane, uint4 *const lds_wave,
                                            uint32_t *const meta, unsigned long long *tr) {
   // scalar batch 1: the stream's pointers and the plane boundaries (pinned by the empty asm:
@@ -599,12 +760,15 @@ __device__ __forceinline__ void recon_tile(const StreamK &S, const int unit, con
   uint8_t *coded_map = S.coded_map;
   const uint8_t *coded_prev = S.coded_prev;
   const int16_t *dc_p = S.dc;
+  const uint4 *dq_p = S.dequant;
   const int te0 = S.tile_end[0], te1 = S.tile_end[1], te2 = S.tile_end[2];
   const int debug = S.debug, sqpx = S.qpx, sqpy = S.qpy, skip_ok = S.skip_ok;
   asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map),
-               "s"(coded_prev), "s"(dc_p), "s"(te0), "s"(te1), "s"(te2), "s"(debug), "s"(sqpx), "s"(sqpy), "s"(skip_ok));
+               "s"(coded_prev), "s"(dc_p), "s"(dq_p), "s"(te0), "s"(te1), "s"(te2), "s"(debug), "s"(sqpx), "s"(sqpy), "s"(skip_ok));
   if (unit >= te2) return;
   const int pli = (unit >= te0 ? 1 : 0) + (unit >= te1 ? 1 : 0);
+  constexpr bool levels = LEVELS;   // (one kernel per coefficient form: each is straight-line code for its own)
+  if (levels) tables_to_lds(dq_p, pli, lane, lds_wave);   // (first: whoever has its command word has the tables)
   // scalar batch 2: the plane's geometry
   const PlaneK G = S.pl[pli];
   asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.fro));
@@ -618,7 +782,7 @@ __device__ __forceinline__ void recon_tile(const StreamK &S, const int unit, con
   const bool valid = bx < G.nh && by < G.nv;
 
   // ---- 1. command word + first slot of the tile (one round trip) -------------------------------
-  const uint32_t slot0 = slot0_p[unit];
+  const uint32_t slot0w = slot0_p[unit];
   const uint2 info = info_p[(size_t)unit * THIP_TILE_FRAGS + lane];
   // ... and, when the frame may leave blocks where they are (skip_ok, wave-uniform), what the
   // previous frame did to this block and to the four blocks it shares an edge with: if none of
@@ -637,10 +801,12 @@ __device__ __forceinline__ void recon_tile(const StreamK &S, const int unit, con
   if (dc_p) dcv = 0x10000u | (uint16_t)dc_p[G.fro + min(by, G.nv - 1) * G.nh + min(bx, G.nh - 1)];
   // all loads are consumed here as far as the compiler can tell, so the scalar load is issued
   // next to the vector loads instead of being sunk behind the wait for them
-  asm volatile("" ::"s"(slot0), "v"(info.x), "v"(touched), "v"(dcv));
+  asm volatile("" ::"s"(slot0w), "v"(info.x), "v"(touched), "v"(dcv));
 #ifdef THIP_TRACE
   THIP_TR(tr, 1);   // first round trip done
 #endif
+  if (levels && !dc_p) dcv = 0x10000u | (info.y & 0xFFFFu);   // levels form: every coded block's raw DC rides in command word 1
+  const CoefForm F = coef_form(slot0w, levels);
 
   ReconLane L;
   L.flags = valid ? info.x : 0u;
@@ -693,38 +859,29 @@ __device__ __forceinline__ void recon_tile(const StreamK &S, const int unit, con
   } else if (nown <= 16 && !(debug & 32)) {
     // ---- few owners: four lanes per block, pieces straight from the slots ------------------------
     int4 W[1][2];
-    residual_shared_load<4>(coeffs_p, slot0, nown, lane, W);
+    residual_shared_load<4>(coeffs_p, F, nown, lane, W);
     if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
-    residual_shared<4>(W, lds_dw, meta, lane, L, prefix, Y);
+    residual_shared<4>(W, F, lds_dw, meta, lane, L, prefix, Y);
     THIP_TR(R.tr, 3);
   } else if (nown <= 32 && !(debug & 32)) {
     int4 W[2][2];
-    residual_shared_load<2>(coeffs_p, slot0, nown, lane, W);
+    residual_shared_load<2>(coeffs_p, F, nown, lane, W);
     if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
-    residual_shared<2, true>(W, lds_dw, meta, lane, L, prefix, Y);   // (results over the exchange: 4 KB, the meta words behind)
+    residual_shared<2, true>(W, F, lds_dw, meta, lane, L, prefix, Y);   // (results over the exchange: 4 KB, the meta words behind)
     THIP_TR(R.tr, 3);
   } else {
-    // ---- many owners: one lane per block.  Coefficients go global -> LDS directly (LDS address
-    //      = wave-uniform base + lane*16): no VGPRs are tied up and nothing can make the compiler
-    //      touch the data before the predictor loads are out.  Every lane loads (lanes without
-    //      coefficients re-read the tile's first slot: same cache lines). ---------------------------
-    const uint32_t slot = slot0 + (L.has_coeff ? prefix : 0u);
-    const int4 *tp = coeffs_p + ((size_t)(slot >> 6) * 512 + (slot & 63));
-    if (!(debug & 64)) {   // (ablation: transforms on whatever the LDS holds)
-#pragma unroll
-      for (int q = 0; q < 8; q++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tp + q * 64),
-                                         (__attribute__((address_space(3))) void *)(lds_wave + q * 64), 16, 0, THIP_COEF_CPOL);
-    }
+    // ---- many owners: one lane per block, coefficients global -> LDS directly (dense_issue) -------
+    int4 w7;
+    dense_issue<8>(coeffs_p, F, L.has_coeff, prefix, lds_wave, w7);
     if (work) recon_issue(R, L, Q, inter, ref);
     THIP_TR(R.tr, 2);
     // The LDS-DMA loads above are counted by vmcnt; the compiler's own wait before the LDS reads
     // below is not something to rely on (it vanished when the loads moved into a conditional
     // block and the reads returned stale LDS), so it is stated.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    residual_per_lane(lds_wave + lane, L, Y);
+    dense_finish<8>(coeffs_p, F, L.has_coeff, prefix, lds_wave, lane, L, w7, Y);
     THIP_TR(R.tr, 3);
   }
   if (!work) return;
@@ -737,6 +894,7 @@ __device__ __forceinline__ void recon_tile(const StreamK &S, const int unit, con
   THIP_TR(R.tr, 4);
 }
 
+template <bool LEVELS>
 __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_recon(const BatchK B) {
   const StreamK &S = B.s[blockIdx.y];
   const int lane = (int)threadIdx.x & 63;
@@ -764,7 +922,7 @@ __global__ __launch_bounds__(64 * THIP_RECON_WG_WAVES, THIP_RECON_WAVES) void k_
   // (residual_shared) use the first 4 KB only and find them at 4 KB
   __shared__ uint4 s_coef[THIP_RECON_WG_WAVES * 8 * 64 + THIP_RECON_LDS_PAD / 16];   // [wave][piece][lane]: 8 KB per wave, wave-private
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  recon_tile(S, unit, lane, s_coef + wave * 512, reinterpret_cast<uint32_t *>(s_coef + wave * 512) + 1024, tr);
+  recon_tile<LEVELS>(S, unit, lane, s_coef + wave * 512, reinterpret_cast<uint32_t *>(s_coef + wave * 512) + 1024, tr);
 }
 
 __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -929,7 +1087,7 @@ struct TokK {
   int nslots;
 };
 // natural position of zig-zag index i (internal.c:27, OC_FZIG_ZAG), four per dword
-__device__ __forceinline__ int fzig_zag(int i) {
+__host__ __device__ __forceinline__ int fzig_zag(int i) {
   constexpr uint8_t T[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};

@@ -2,8 +2,10 @@
 
 Generates, for a given coded frame size, what libtheora's front end hands to the
 reconstruction path for one frame: coded / uncoded fragment lists in coded order, the
-per-fragment reference index and motion vector, dequantised coefficients with the raw DC,
-last_zzi, dc_quant and the loop-filter limit.  Used by tests (against the oracle) and by
+per-fragment reference index and motion vector, the quantised LEVELS of every coded block with the
+frame's dequantisation tables and each block's qii -- and their product, the dequantised coefficients
+with the raw DC that oc_state_frag_recon receives (decode.c:1573) --, last_zzi, dc_quant and the
+loop-filter limit.  Used by tests (against the oracle) and by
 bench.py.  Pure numpy; no oracle and no device code in here.
 """
 import numpy as np
@@ -83,7 +85,7 @@ CLASSES = {
     "smooth": dict(p_coded=0.66, intra=0.039, golden=0.003, zeromv=0.086, halfpel=0.025, p_dc_only=0.80,
                    p_zz10=0.15, amp=24, edge_mv=0.0, extreme=0.0),
     "mixed": dict(p_coded=0.6, intra=0.15, golden=0.15, zeromv=0.15, halfpel=0.4, p_dc_only=0.3,
-                  p_zz10=0.3, amp=300, edge_mv=0.3, extreme=0.02),
+                  p_zz10=0.3, amp=300, edge_mv=0.3, extreme=0.02, big_levels=0.002),
     # a quarter of the picture changes (smooth statistics inside), the rest is a static background
     "static_bg": dict(p_coded=0.9, intra=0.039, golden=0.003, zeromv=0.086, halfpel=0.025, p_dc_only=0.80,
                       p_zz10=0.15, amp=24, edge_mv=0.0, extreme=0.0, window=0.25),
@@ -158,16 +160,32 @@ def gen_frame(geom, rng, frame_type, content="mixed", flimit=None, global_mv=Non
     uncoded_fragis = order[~is_coded][::-1].copy()        # the reference stores them reversed (state.h:423-426)
     ncoded = [int(coded[geom.froffset[p]:geom.froffset[p] + geom.pl_nfrags[p]].sum()) for p in range(3)]
     n = coded_fragis.size
-    # --- coefficients -------------------------------------------------------------------
+    # --- coefficients: quantised levels x the frame's dequantisation tables (decode.c:1537-1538, 1573) ----------------
     u = rng.random(n)
     ncoef = np.where(u < P["p_dc_only"], 1,
                      np.where(u < P["p_dc_only"] + P["p_zz10"], rng.integers(2, 11, n), rng.integers(11, 65, n)))
     if content == "dense":
         ncoef[:] = 64
     zz = np.arange(64)
+    # tables: dequant[plane][qii][qti][zig-zag index], falling with the index like the amplitudes the classes ask for
+    # (amp / (1 + zz/4)); one to three qi per frame (nqis), the finer ones with smaller factors; inter tables a bit flatter
+    nqis = int(rng.integers(1, 4))
     amp = np.maximum(P["amp"] / (1.0 + 0.25 * zz), 1.0)
+    dequant = np.zeros((3, 3, 2, 64), np.uint16)
+    for pl_ in range(3):
+        for qi_ in range(3):
+            for qt_ in range(2):
+                f = (1.0 + 0.15 * pl_) * (1.0 - 0.3 * qi_) * (1.0 - 0.2 * qt_)
+                dequant[pl_, qi_, qt_] = np.clip(np.rint(amp * f), 1, 65535)
+    qti = (refi[coded_fragis] != FRAME_SELF).astype(np.int64)
+    pl = geom.plane_of[coded_fragis].astype(np.int64)
+    qii = rng.integers(0, nqis, n).astype(np.int64)
+    # levels: small integers (products of two draws, -9..9), now and then a large one (a level beyond eight bits makes its
+    # tile a wide one in the levels form)
     Z = rng.integers(-3, 4, (n, 64)).astype(np.int32) * rng.integers(1, 4, (n, 64))
-    Z = (Z * amp).astype(np.int32)
+    if P.get("big_levels"):
+        big = rng.random((n, 64)) < P["big_levels"]
+        Z = np.where(big, Z * rng.integers(8, 64, (n, 64)), Z)
     Z[zz[None, :] >= ncoef[:, None]] = 0
     last_zzi = np.minimum(ncoef, 63).astype(np.uint8)
     dc_only_eob0 = (ncoef == 1) & (rng.random(n) < 0.5)
@@ -178,10 +196,14 @@ def gen_frame(geom, rng, frame_type, content="mixed", flimit=None, global_mv=Non
         # blocks whose last_zzi claims fewer coefficients than are present: the reference's
         # iDCT variants ignore the rest (idct.c:234-277)
         last_zzi[ex] = rng.integers(0, 64, int(ex.sum()))
+        if rng.random() < 0.5:
+            dequant[1, 0, 1, 1:] = rng.integers(1, 65536, 63)     # the whole 16-bit range of factors
+    levels = np.zeros((n, 64), np.int16)
+    levels[:, FZIG_ZAG] = Z.astype(np.int16)
+    # what the reference's token expansion hands to the slot: (ogg_int16_t)(coeff * ac_quant[zzi]), decode.c:1573
+    prod = (Z.astype(np.int64) * dequant[pl, qii, qti].astype(np.int64)).astype(np.int16)
     coeffs = np.zeros((n, 64), np.int16)
-    coeffs[:, FZIG_ZAG] = Z.astype(np.int16)
-    qti = (refi[coded_fragis] != FRAME_SELF).astype(np.int64)
-    pl = geom.plane_of[coded_fragis].astype(np.int64)
+    coeffs[:, FZIG_ZAG] = prod
     dq_table = rng.integers(8, 120, (3, 2)).astype(np.uint16)
     if P["extreme"]:
         dq_table[2, 1] = 65535
@@ -193,29 +215,80 @@ def gen_frame(geom, rng, frame_type, content="mixed", flimit=None, global_mv=Non
     if P["extreme"]:
         exd = rng.random(n) < P["extreme"]
         coeffs[exd, 0] = rng.integers(-32768, 32768, int(exd.sum()))
+    levels[:, 0] = coeffs[:, 0]
     if flimit is None:
         flimit = int(rng.choice([0, 2, 4, 15, 63]))
     return dict(frame_type=frame_type, coded_fragis=coded_fragis.astype(np.int64), ncoded=ncoded,
                 uncoded_fragis=uncoded_fragis.astype(np.int64), refi=refi, mvx=mvx, mvy=mvy,
-                coeffs=coeffs, last_zzi=last_zzi, dc_quant=dc_quant.astype(np.uint16), flimit=flimit)
+                coeffs=coeffs, last_zzi=last_zzi, dc_quant=dc_quant.astype(np.uint16), flimit=flimit,
+                levels=levels, qii=qii.astype(np.uint8), dequant=dequant)
 
 
-def pack_frame(geom, frame):
-    """numpy command stream -> the device layout of include/theora_hip.h (host arrays)."""
-    from . import info_words, pack_tiles
+def nothing_coded(geom, frame, frame_type=None):
+    """The frame with no coded fragment at all (decode.c:2764-2772: a duplicate of the previous frame)."""
+    out = dict(frame)
+    out.update(coded_fragis=np.zeros(0, np.int64), ncoded=[0, 0, 0], uncoded_fragis=geom.coded_order[::-1].copy(),
+               coeffs=np.zeros((0, 64), np.int16), last_zzi=np.zeros(0, np.uint8), dc_quant=np.zeros(0, np.uint16),
+               levels=np.zeros((0, 64), np.int16), qii=np.zeros(0, np.uint8))
+    if frame_type is not None:
+        out["frame_type"] = frame_type
+    return out
+
+
+def dequantise(geom, frame):
+    """The slot's dequantised coefficients from a frame's levels, qii and tables: (ogg_int16_t)(coeff * ac_quant[zzi]) with
+    ac_quant = dequant[plane][qii][qti], qti = the block is not intra (decode.c:1537-1538, 1573); the DC stays raw."""
+    cf = frame["coded_fragis"]
+    qti = (frame["refi"][cf] != FRAME_SELF).astype(np.int64)
+    pl = geom.plane_of[cf].astype(np.int64)
+    tab = np.asarray(frame["dequant"], np.int64)[pl, np.asarray(frame["qii"], np.int64), qti]      # [n, 64] zig-zag order
+    lv = np.asarray(frame["levels"], np.int64).reshape(-1, 64)
+    co = np.zeros_like(lv)
+    co[:, FZIG_ZAG] = lv[:, FZIG_ZAG] * tab
+    co = co.astype(np.int16)
+    co[:, 0] = lv[:, 0].astype(np.int16)
+    return co
+
+
+def pack_frame(geom, frame, form=None):
+    """numpy command stream -> the device layout of include/theora_hip.h (host arrays).  form: "levels" (the quantised
+    levels + the dequantisation tables, the default when the frame carries them) or "dequant16" (the slot's dequantised
+    int16 coefficients)."""
+    from . import SLOT_WIDE, info_words, pack_dequant_tables, pack_tiles, pack_units
+    if form is None:
+        form = "levels" if "levels" in frame else "dequant16"
     cf = frame["coded_fragis"]
     pos = geom.frag_pos[cf]
     assert (np.diff(pos) > 0).all(), "coded order must equal tile/lane order"
     lz = frame["last_zzi"]
     co = np.asarray(frame["coeffs"], np.int16).reshape(-1, 64)   # AC dequantised, DC raw (the slot's _dct_coeffs)
     has = lz >= 2
+    common = dict(ncoded=int(cf.size), frame_type=frame["frame_type"], flimit=frame["flimit"])
+    if form == "dequant16":
+        info = info_words(geom.ntiles * 64, pos, frame["refi"][cf], lz, frame["mvx"][cf], frame["mvy"][cf], co[:, 0],
+                          frame["dc_quant"])
+        # first slot of every tile: number of coefficient-carrying fragments in earlier tiles
+        per_tile = np.bincount(pos[has] >> 6, minlength=geom.ntiles)
+        slot0 = np.concatenate([[0], np.cumsum(per_tile)[:-1]]).astype(np.uint32)
+        return dict(info=info, coeffs=pack_tiles(co[has]), slot0=slot0, nslots=int(has.sum()), **common)
+    assert form == "levels"
+    lv = np.asarray(frame["levels"], np.int16).reshape(-1, 64).copy()
+    lv[:, 0] = 0                                                  # the DC rides in command word 1
     info = info_words(geom.ntiles * 64, pos, frame["refi"][cf], lz, frame["mvx"][cf], frame["mvy"][cf], co[:, 0],
-                      frame["dc_quant"])
-    # first slot of every tile: number of coefficient-carrying fragments in earlier tiles
-    per_tile = np.bincount(pos[has] >> 6, minlength=geom.ntiles)
-    slot0 = np.concatenate([[0], np.cumsum(per_tile)[:-1]]).astype(np.uint32)
-    return dict(info=info, coeffs=pack_tiles(co[has]), slot0=slot0, nslots=int(has.sum()), ncoded=int(cf.size),
-                frame_type=frame["frame_type"], flimit=frame["flimit"])
+                      frame["dc_quant"], qii=frame["qii"])
+    tile = pos[has] >> 6
+    big = (np.abs(lv[has].astype(np.int32)) > 127).any(axis=1) | (lv[has] == -128).any(axis=1)   # (-128 fits, but keep the range symmetric)
+    wide_tile = np.zeros(geom.ntiles, bool)
+    wide_tile[tile[big]] = True
+    per_tile = np.bincount(tile, minlength=geom.ntiles) * np.where(wide_tile, 2, 1)          # units
+    unit0 = np.concatenate([[0], np.cumsum(per_tile)[:-1]]).astype(np.int64)
+    rank = np.arange(tile.size) - np.searchsorted(tile, tile, side="left")                   # rank of a block inside its tile
+    wide = wide_tile[tile]
+    first_unit = unit0[tile] + rank * np.where(wide, 2, 1)
+    nunits = int(per_tile.sum())
+    slot0 = (unit0.astype(np.uint32) | np.where(wide_tile, np.uint32(SLOT_WIDE), np.uint32(0))).astype(np.uint32)
+    return dict(info=info, coeffs=pack_units(lv[has], wide, first_unit, nunits), slot0=slot0, nslots=nunits,
+                dequant=pack_dequant_tables(frame["dequant"]), wide_tiles=int(wide_tile.sum()), **common)
 
 
 def upload_frame(packed, device="cuda"):
@@ -229,11 +302,12 @@ def upload_frame(packed, device="cuda"):
             return None
         return torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(device)
     info = dev(packed["info"].reshape(-1), np.int32)
-    coeffs = dev(packed["coeffs"], np.int16)
+    coeffs = dev(packed["coeffs"], np.uint8 if "dequant" in packed else np.int16)
     slot0 = dev(packed["slot0"], np.int32)
+    dq = dev(packed["dequant"].reshape(-1), np.int16) if "dequant" in packed else None
     desc = make_desc(info, coeffs, slot0, packed["nslots"], packed["ncoded"], packed["frame_type"],
-                     packed["flimit"])
-    return desc, (info, coeffs, slot0)
+                     packed["flimit"], dequant_dev=dq)
+    return desc, (info, coeffs, slot0, dq)
 
 
 def algorithmic_bytes(geom, frame):
