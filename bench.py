@@ -33,8 +33,17 @@ if ROOT not in sys.path:
 SIZES = {"4k": (3840, 2160), "1080p": (1920, 1088), "720p": (1280, 720), "cif": (352, 288), "qcif": (176, 144)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec peak
 FUSED = os.environ.get("THIP_FUSE", "3")
-KERNEL_NAMES = {"0": ("k_recon", "k_loopfilter"), "1": ("k_recon_walk", "k_lf_seams"), "2": ("k_recon_st", "k_lf_st_seams")}.get(FUSED, ("k_recon_lf", None))
-TRAFFIC_PROFILE = "profiles/r03_pmc_traffic.json"
+# option "fuse": 3 = k_recon_lf (reconstruction + loop filter in one pass), anything else = the two passes
+KERNEL_NAMES = ("k_recon_lf", None) if FUSED == "3" else ("k_recon", "k_loopfilter")
+TRAFFIC_PROFILE = "profiles/r04_pmc_traffic.json"
+
+
+def _kernel_base_name(name):
+    """'void k_recon_lf<true>(BatchK)' -> 'k_recon_lf' (the kernels exist once per coefficient form)."""
+    n = name.split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
 KF_INTERVAL = 64
 
 
@@ -77,8 +86,11 @@ def _cpu_worker(job):
 
 
 # Frame-39 CRC32s of streams 0..3 of the default workload (4K dense, pool 6, kf 64): the same on every run, every world
-# size and every launch shape since round 2 -- a cheap end-to-end regression check of the timed batch.
-COMMITTED_CRC_FRAME39 = ["78bed3bc", "a82eb830", "ee6d99cc", "3ad204b2"]
+# size and every launch shape -- a cheap end-to-end regression check of the timed batch.  Rounds 2 and 3 had
+# 78bed3bc a82eb830 ee6d99cc 3ad204b2; round 4 changed the GENERATOR (theora_amd/synth.py: a frame is now quantised levels x
+# dequantisation tables, as a real stream is, where it used to be free-form products that no table factors), so the pictures
+# are different pictures; the oracle decodes the new ones to these values (checked by this script before it compares).
+COMMITTED_CRC_FRAME39 = ["b4858401", "1f7f36d9", "83b0e5ba", "726f206f"]
 
 
 def measure_pmc_traffic(args, kernels):
@@ -100,7 +112,7 @@ def measure_pmc_traffic(args, kernels):
             d = os.path.join(td, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "24", "--warmup", "4", "--repeats", "1", "--min-time", "0", "--no-cpu-baseline", "--no-parity",
-                   "--no-profile", "--no-pmc", "--second-content", "", "--content", args.content, "--size", args.size,
+                   "--no-profile", "--no-pmc", "--no-1080p", "--second-content", "", "--content", args.content, "--size", args.size,
                    "--streams-per-gpu", str(args.streams_per_gpu), "--pool", str(args.pool)]
             env = dict(os.environ, THIP_LANES="1", TMPDIR=os.environ.get("TMPDIR", "/tmp"))
             try:
@@ -113,7 +125,7 @@ def measure_pmc_traffic(args, kernels):
             acc = {}
             for row in csv.DictReader(open(files[0])):
                 if row["Counter_Name"] == counter:
-                    acc.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+                    acc.setdefault(_kernel_base_name(row["Kernel_Name"]), []).append(float(row["Counter_Value"]))
             out[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
     res = {}
     for k in kernels:
@@ -208,6 +220,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-process-per-core leg of the CPU baseline")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-1080p", action="store_true", help="skip the 1080p keyed entries (single stream, four streams)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-execute under rocprofv3 --pmc for roofline.traffic (N = 1 only)")
     return ap.parse_known_args()
 
@@ -616,19 +629,22 @@ def main():
         t0 = time.perf_counter()
         run(args.steps, first=step0)
         sync()
-        barrier()
-        dt = time.perf_counter() - t0
+        dt = time.perf_counter() - t0      # this rank's K steps, start aligned by the barrier; the MAX over ranks is taken below
+        barrier()                          # (outside the clock: a trailing collective would add its own latency to every 0.8 ms block)
         elapsed_blocks.append(dt)
         total_t += dt
         step0 += args.steps
         if dist.is_initialized():   # every rank must run the same number of blocks
             total_t = shard.reduce_max([total_t], torch.device("cuda", local_rank))[0]
-    # Pass B: steps with every kernel bracketed by HIP events on the stream it runs on -> per-kernel
-    # durations for the roofline.  Kept out of pass A because four event records per step cost ~15 % of
-    # the step, and run on ONE stream so that a kernel's duration is not stretched by another lane's
-    # kernel sharing the GPU (pass A overlaps two lanes).
+    # Pass B: steps with every kernel bracketed by HIP events on the stream it runs on -> per-kernel durations for the
+    # roofline.  Kept out of pass A because four event records per step cost ~15 % of the step.  Two shapes:
+    #   (1) ONE stream, one launch per step carrying all S streams: the kernel has the chip to itself -- the roofline of the
+    #       kernel proper (`roofline`), what `rocprofv3 --kernel-trace --stats` of a THIP_LANES=1 run shows;
+    #   (2) the TIMED shape: the library's lanes, S/lanes streams per launch, launches of different lanes overlapping
+    #       (`roofline.timed_shape`: a launch takes longer there because it shares the chip with the other lane's).
     profiling = not args.no_profile
     launches, kms, elapsed_b = [0, 0], [0.0, 0.0], 0.0
+    launches_t, kms_t = [0, 0], [0.0, 0.0]
     prof_steps = max(args.steps, 256)
     if profiling:
         theora_amd.profile_reset()
@@ -640,8 +656,13 @@ def main():
         pstream.synchronize()
         sync()
         elapsed_b = time.perf_counter() - t0
-        theora_amd.profile_enable(False)
         launches, kms = theora_amd.profile_read()
+        step0 += prof_steps
+        theora_amd.profile_reset()
+        run(prof_steps, first=step0)                               # the timed shape
+        sync()
+        theora_amd.profile_enable(False)
+        launches_t, kms_t = theora_amd.profile_read()
         step0 += prof_steps
 
     # checksum of each stream's final frame (all planes): gathered over ranks, printed
@@ -657,6 +678,7 @@ def main():
     if nparity:
         _, parity_crcs = shard.reduce_results(0.0, parity_crcs, dev)
     kms = shard.reduce_max(kms, dev)
+    kms_t = shard.reduce_max(kms_t, dev)
     elapsed = float(np.median(blocks))
 
     # ---- the same measurement on the content class SURVEY section 8d defines from the reference's own
@@ -691,8 +713,8 @@ def main():
             t0 = time.perf_counter()
             run2(K2, KF_INTERVAL + rep * K2)
             sync()
-            barrier()
             b2.append(time.perf_counter() - t0)
+            barrier()
         b2 = shard.reduce_max(b2, dev)
         e2 = float(np.median(b2))
         steps2 = [KF_INTERVAL + i for i in range(K2)]
@@ -705,6 +727,59 @@ def main():
                   "alg_GBps_per_gpu": round(alg2 / e2 / 1e9, 1),
                   "note": "same streams, states and launch shape; parity of this class: tests/test_gpu_frames.py"}
 
+    # ---- the other size the metric names: 1080p (BASELINE.json config 3: ONE 1080p stream, kf 64 -- launches that leave the
+    #      chip half empty -- and four streams in one call), same content class, same clock ------------------------------------
+    other_size = None
+    if args.size == "4k" and not args.no_1080p and G == 1:
+        w2, h2 = SIZES["1080p"]
+        geom2 = synth.Geometry(w2, h2)
+        other_size = {}
+        for label, S2 in (("single_stream", 1), ("four_streams", 4)):
+            descs3, balg3, keep3 = [], [], []
+            for gid in shard.stream_ids(rank, world, S2):
+                rng = np.random.default_rng(shard.stream_seed(777, gid))
+                frames = [synth.gen_frame(geom2, rng, theora_amd.INTRA_FRAME, args.content, flimit=2)]
+                for _ in range(args.pool):
+                    frames.append(synth.gen_frame(geom2, rng, theora_amd.INTER_FRAME, args.content, flimit=2))
+                row = []
+                for f in frames:
+                    d, ka = synth.upload_frame(synth.pack_frame(geom2, f))
+                    keep3.append(ka)
+                    row.append(d)
+                descs3.append(row)
+                balg3.append([synth.algorithmic_bytes(geom2, f) for f in frames])
+            states3 = [theora_amd.State(w2, h2) for _ in range(S2)]
+            plans3 = [theora_amd.BatchPlan(states3, [descs3[s][j] for s in range(S2)]) for j in range(args.pool + 1)]
+            K3 = max(args.steps, 128)
+
+            def run3(n, first):
+                for i in range(first, first + n):
+                    plans3[frame_of_step(i)].submit(None)
+            run3(KF_INTERVAL, 0)
+            sync()
+            b3 = []
+            for rep in range(max(5, min(args.repeats, 15))):
+                sync()
+                barrier()
+                t0 = time.perf_counter()
+                run3(K3, KF_INTERVAL + rep * K3)
+                sync()
+                b3.append(time.perf_counter() - t0)
+                barrier()
+            b3 = shard.reduce_max(b3, dev)
+            e3 = float(np.median(b3))
+            steps3 = [KF_INTERVAL + i for i in range(K3)]
+            read3 = sum(balg3[s][frame_of_step(i)][1] for i in steps3 for s in range(S2))
+            other_size[label] = {"value": round(K3 * S2 * world / e3, 2), "unit": "frames/s", "streams_per_gpu": S2, "steps": K3,
+                                 "ms_per_step": round(1e3 * e3 / K3, 5),
+                                 "pipeline_read_roofline_frac": round(read3 / e3 / 1e9 / HBM_PEAK_GBS, 4)}
+            for st3 in states3:
+                st3.close()
+            del keep3, descs3
+        other_size["note"] = ("1080p (1920x1088 coded) 4:2:0, kf %d, content class '%s', frames decoded one after the other through "
+                              "thip_decode_frames; parity of these shapes: tests/test_gpu_frames.py::test_config3_as_written, "
+                              "::test_full_size_sequences" % (KF_INTERVAL, args.content))
+
     if rank == 0:
         first_timed = nparity + args.warmup
         med_i = int(np.argsort(blocks)[len(blocks) // 2])
@@ -713,6 +788,7 @@ def main():
         steps_b_read = sum(alg_of_step(i, 1) for i in rng_steps)
         first_prof = first_timed + len(blocks) * args.steps
         prof_b_alg = sum(alg_of_step(i, 0) for i in range(first_prof, first_prof + prof_steps))
+        prof_t_alg = sum(alg_of_step(i, 0) for i in range(first_prof + prof_steps, first_prof + 2 * prof_steps))
         total_frames = args.steps * S * G * world
         fps = total_frames / elapsed
         out = {
@@ -759,13 +835,27 @@ def main():
                                "second_kernel": KERNEL_NAMES[1] if launches[1] else None,
                                "second_kernel_avg_launch_us": round(1e3 * kms[1] / max(launches[1], 1), 3) if launches[1] else None,
                                "alg_bytes_per_launch": int(prof_b_alg / max(launches[0], 1)),
+                               "shape": "one launch per step carrying all %d streams, alone on the chip" % (S * G),
                                "measured": "HIP events around every launch, separate instrumented pass of %d steps on one "
                                            "stream (ms_per_step there: %.5f)" % (prof_steps, 1e3 * elapsed_b / prof_steps)}
+            if launches_t[0]:
+                # the timed shape: launches of the library's lanes overlap, so a launch is longer than its share of a step;
+                # sum of the durations / (steps x ms_per_step) = how many launches are in flight on average
+                lt_us = 1e3 * kms_t[0] / launches_t[0]
+                per_step = launches_t[0] / prof_steps
+                out["roofline"]["timed_shape"] = {
+                    "launches_per_step": round(per_step, 2), "avg_launch_us": round(lt_us, 3),
+                    "alg_bytes_per_launch": int(prof_t_alg / launches_t[0]),
+                    "per_launch_GBps": round(prof_t_alg / launches_t[0] / (lt_us * 1e-6) / 1e9, 1),
+                    "launches_in_flight": round(per_step * lt_us * 1e-3 / (1e3 * elapsed / args.steps), 2),
+                    "note": "per_launch_GBps x launches_in_flight = pipeline.alg_GBps_per_gpu (the driver-clocked figure)"}
         # whole pipeline (recon + loop filter + launch gaps) against the HBM-read roofline of BASELINE.md section 3
         out["pipeline"] = {"read_roofline_frac": round((steps_b_read / elapsed) / 1e9 / HBM_PEAK_GBS, 4),
                            "alg_GBps_per_gpu": round(steps_b_alg / elapsed / 1e9, 1)}
         if second:
             out["second_content"] = second
+        if other_size:
+            out["size_1080p"] = other_size
         if cpu_baseline:
             cpu_baseline["system_libtheora"] = system_libtheora_baseline()
             out["cpu_baseline"] = cpu_baseline

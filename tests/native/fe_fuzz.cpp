@@ -1,6 +1,7 @@
 // Fuzz driver for the th_decode_* front end (tests/test_frontend_fuzz.py builds it with
 // -fsanitize=address,undefined and links it against theora_amd/csrc/thip_frontend.cpp).
-// The HIP backend is not linked: contexts run in slot-trace mode (THIP_FE_TRACE_BACKEND=1), so
+// The HIP backend is not linked: contexts run in slot-trace mode (option fe_trace_backend, which the stub of thip_option below
+// answers with 1), so
 // the whole host path -- headers, flags, modes, vectors, tokens, DC prediction, dequantisation --
 // is exercised on mutated packets.  Any sanitizer report or crash fails the test.
 //   fe_fuzz <packet file> <iterations> <seed>
@@ -31,7 +32,12 @@ int thip_state_decode_token_lists(thip_state *, const thip_token_lists *) { retu
 int thip_state_token_lists_begin(thip_state *, const thip_token_lists *) { return -1; }
 int thip_state_token_lists_finish(thip_state *, const int16_t *) { return -1; }
 int thip_device_count(void) { return 0; }
-int thip_option(const char *name) { return (name && !strcmp(name, "device")) ? -1 : 0; }
+int thip_option(const char *name) {   // the library's option table is not linked: trace mode on, everything else at its default
+  if (name && !strcmp(name, "device")) return -1;
+  if (name && !strcmp(name, "fe_trace_backend")) return 1;
+  if (name && !strcmp(name, "fe_device_lists")) return 0;
+  return 0;
+}
 int thip_state_set_device_dc(thip_state *, int) { return -1; }
 int thip_frame_dequant_table(thip_state *, int, const uint16_t *) { return -1; }
 int thip_state_frag_recon_tokens(thip_state *, ptrdiff_t, int, const uint32_t *, int, int16_t, int, uint16_t, int, int, int16_t) {
@@ -67,7 +73,6 @@ static ogg_packet as_packet(Pkt &p, int bos) {
 
 int main(int argc, char **argv) {
   if (argc < 4) return 2;
-  setenv("THIP_FE_TRACE_BACKEND", "1", 1);
   FILE *f = fopen(argv[1], "rb");
   if (!f) return 2;
   unsigned nh = 0, np = 0;

@@ -47,3 +47,9 @@ def test_mutated_packets_never_crash(fuzz_bin, tmp_path, w, h, fmt, seed):
     r = subprocess.run([fuzz_bin, str(path), "300", str(seed)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-500:] + r.stderr[-3000:])
     assert "fe_fuzz: 300 iterations" in r.stdout
+    # a run in which every header set is refused decodes nothing and proves nothing (round 3's harness did exactly that
+    # after the option table replaced the environment variable): packets must have gone through the whole host path
+    import re
+    m = re.search(r"fe_fuzz: 300 iterations, (\d+) packets decoded, (\d+) rejected, (\d+) header sets rejected", r.stdout)
+    assert m, r.stdout[-300:]
+    assert int(m.group(1)) > 300 and int(m.group(3)) < 250, r.stdout[-300:]

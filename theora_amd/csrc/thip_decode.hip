@@ -35,6 +35,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -59,7 +60,7 @@ using namespace thip;
 namespace {
 struct Option {
   const char *name;
-  int value;
+  std::atomic<int> value;   // written by thip_set_option, read per frame by the decoding threads (relaxed: a change takes effect "with the next call")
   const char *help;
 };
 Option g_options[] = {
@@ -91,8 +92,8 @@ void options_from_env() {
     env[k] = 0;
     const char *v = getenv(env);
     if (!v || !*v) continue;
-    if (!strcmp(g_options[i].name, "device") && !strcmp(v, "rr")) g_options[i].value = -2;
-    else g_options[i].value = atoi(v);
+    if (!strcmp(g_options[i].name, "device") && !strcmp(v, "rr")) g_options[i].value.store(-2, std::memory_order_relaxed);
+    else g_options[i].value.store(atoi(v), std::memory_order_relaxed);
   }
 }
 Option *find_option(const char *name) {
@@ -103,21 +104,23 @@ Option *find_option(const char *name) {
   return nullptr;
 }
 }  // namespace
-// (internal accessor, also used by thip_frontend.cpp)
+// (internal accessor by name, for thip_frontend.cpp's per-context lookups)
 extern "C" int thip_option(const char *name) {
   const Option *o = find_option(name);
-  return o ? o->value : 0;
+  return o ? o->value.load(std::memory_order_relaxed) : 0;
 }
+// ... and for this translation unit's per-frame reads: the entry is looked up once per call site, a read is one relaxed load
+#define THIP_OPT(name) ([]() -> int { static const Option *const o_ = find_option(name); return o_ ? o_->value.load(std::memory_order_relaxed) : 0; }())
 extern "C" int thip_set_option(const char *name, int value) {
   Option *o = find_option(name);
   if (!o) return THIP_EINVAL;
-  o->value = value;
+  o->value.store(value, std::memory_order_relaxed);
   return THIP_OK;
 }
 extern "C" int thip_get_option(const char *name, int *value) {
   const Option *o = find_option(name);
   if (!o || !value) return o ? THIP_EFAULT : THIP_EINVAL;
-  *value = o->value;
+  *value = o->value.load(std::memory_order_relaxed);
   return THIP_OK;
 }
 extern "C" const char *thip_option_name(int index, const char **help) {
@@ -288,7 +291,7 @@ int ensure_lanes(int device) {   // the device must be current; callable from an
   std::lock_guard<std::mutex> lk(g_lanes_mu);
   if (device < 0 || device >= kMaxDevices) return THIP_EINVAL;
   if (g_lanes_ready[device]) return 0;
-  int n = thip_option("lanes");
+  int n = THIP_OPT("lanes");
   if (n < 1) n = 1;
   if (n > kMaxLanes) n = kMaxLanes;
   for (int i = 0; i < n; i++) HIP_TRY(hipStreamCreateWithFlags(&g_lanes[device][i], hipStreamNonBlocking));
@@ -339,7 +342,7 @@ int context_stream(thip_state *st, hipStream_t *out) {
     return THIP_OK;
   }
   static const int nctx = [] {   // (streams are created once: read at first use)
-    const int v = thip_option("ctx_lanes");
+    const int v = THIP_OPT("ctx_lanes");
     return v < 0 ? 0 : (v > kCtxLanes ? kCtxLanes : v);
   }();
   int rc = ensure_lanes(st->device);
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(256) void k_frame_out(const OutK K) {
 // measured on 16 cores with 16 / 32 / 64 decoder threads: 11.6 / 9.6 / 6.1 k frames/s spinning,
 // 11.7 / 10.9 / 10.0 k sleeping (tools/wait_modes.sh).
 static int wait_event(hipEvent_t ev) {
-  if (thip_option("wait_spin")) {
+  if (THIP_OPT("wait_spin")) {
     HIP_TRY(hipEventSynchronize(ev));
     return THIP_OK;
   }
@@ -983,7 +986,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     // previous frame is the PREV reference, and the previous frame's flags are at hand to tell that
     // it did not touch the block (k_recon).  THIP_SKIP_STATIC=0 switches the elision off, 2 applies it to
     // every frame with an uncoded block (tests).
-    const int skip_static = thip_option("skip_static");
+    const int skip_static = THIP_OPT("skip_static");
     const int64_t serial = st->frame_serial + 1;   // of the frame being decoded
     const int pm = st->map_serial[0] == serial - 1 ? 0 : (st->map_serial[1] == serial - 1 ? 1 : -1);
     const int cm = pm == 0 ? 1 : 0;
@@ -996,9 +999,9 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     st->map_serial[cm] = serial;
     st->buf_serial[bufi] = serial;
     K.flimit2 = 2 * d.flimit;
-    K.debug = thip_option("debug");
+    K.debug = THIP_OPT("debug");
     // flags-first loop filter when at least a tenth of the frame is uncoded (THIP_LF_SPARSE=0/1 forces)
-    const int lf_sparse_env = thip_option("lf_sparse");
+    const int lf_sparse_env = THIP_OPT("lf_sparse");
     K.lf_sparse = lf_sparse_env >= 0 ? lf_sparse_env : (int64_t)d.ncoded * 10 < (int64_t)st->nfrags * 9;
     K.qpx = st->hdec;
     K.qpy = st->vdec;
@@ -1062,7 +1065,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
           fits = dcw_fits(D.p[j][pli].nh, D.p[j][pli].nv);
           if (fits) lds = std::max(lds, dcw_layout(D.p[j][pli].nh, D.p[j][pli].nv).bytes);
         }
-      const int dc_global = thip_option("dc_global");
+      const int dc_global = THIP_OPT("dc_global");
       if (fits && !dc_global) {
         HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_dc_wave), kDcwLdsMax, 3));
         hipLaunchKernelGGL(k_dc_prepare, dim3(max_rows, 3, ndc), dim3((max_nh + 63) & ~63), 0, s, D);
@@ -1076,7 +1079,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   // Default (option "fuse" = 3): k_recon_lf, reconstruction and the whole loop filter in one pass (thip_fused.h); 0: the two
   // passes k_recon + k_loopfilter.  Frames that leave static blocks in place (skip_ok) and frames without a loop filter
   // always take the two passes, whose first kernel knows how to skip whole tiles.
-  const int fuse = thip_option("fuse");
+  const int fuse = THIP_OPT("fuse");
   if (fuse == 3 && any_lf && !any_skip && xcd_round_robin(states[live_state[0]]->device)) {
     // one wave per tile, reconstruction and every filter cell in one pass (thip_fused.h)
     int longest = 1;
@@ -1177,7 +1180,7 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
   // group by device, then by lane (order inside a lane preserved), launch chunk by chunk
   // (THIP_CHUNK: streams per launch)
   const int chunk_max = [] {
-    const int v = thip_option("chunk");
+    const int v = THIP_OPT("chunk");
     return v < 1 ? 1 : (v > THIP_MAX_BATCH ? THIP_MAX_BATCH : v);
   }();
   uint32_t devmask = 0;
@@ -1232,7 +1235,7 @@ int thip_dc_unpredict_plane(int16_t *dc, const uint8_t *flags, int nhfrags, int 
   p.nh = nhfrags;
   p.nv = nvfrags;
   void *scratch = nullptr;
-  if (dcw_fits(nhfrags, nvfrags) && !thip_option("dc_global")) {
+  if (dcw_fits(nhfrags, nvfrags) && !THIP_OPT("dc_global")) {
     const size_t nf = (size_t)nhfrags * nvfrags;
     HIP_TRY(hipMalloc(&scratch, nf * sizeof(uint4) + (size_t)nvfrags + 16));
     p.ent = (uint4 *)scratch;
@@ -1551,7 +1554,6 @@ int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const
       last_zzi < 0 || last_zzi > 64 || ntoks < 0 || ntoks > 63 || dqsel < 0 || dqsel >= 18 ||
       (int64_t)st->enq_ncoded + st->enq_nuncoded >= st->nfrags)
     return THIP_EINVAL;
-  if (st->enq_dense_slots) return THIP_EINVAL;   // (see thip_state_frag_recon: one form per frame for the coefficient slots)
   const int32_t pos = st->frag_pos[fragi];
   if (st->h_info[2 * (size_t)pos] & THIP_INFO_CODED) return THIP_EINVAL;   // fragment enqueued twice
   uint32_t flags = THIP_INFO_CODED | ((uint32_t)refi << THIP_INFO_REFI_SHIFT) |
@@ -1568,6 +1570,7 @@ int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const
       const int rc = ensure_token_staging(st);
       if (rc) return rc;
     }
+    if (st->enq_dense_slots) return THIP_EINVAL;   // (see thip_state_frag_recon: one form per frame for the blocks that own a coefficient slot)
     if ((size_t)st->enq_ntok + (size_t)ntoks + 1 > st->tok_cap) return THIP_EINVAL;   // more tokens than the frame has coefficients
     const int tile = pos / THIP_TILE_FRAGS, lane = pos % THIP_TILE_FRAGS;
     if (lane <= st->enq_last_lane[tile]) return THIP_EINVAL;
@@ -1649,7 +1652,7 @@ int thip_frame_flush(thip_state *st) {
   rc = order_behind_previous(st, s);   // before the first copy or kernel of this frame goes onto s
   if (rc) return rc;
   const size_t ngroups = ((size_t)st->enq_nslots + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
-  const int zerocopy = thip_option("zerocopy");
+  const int zerocopy = THIP_OPT("zerocopy");
   if (st->enq_ncoded && !zerocopy) {
     HIP_TRY(hipMemcpyAsync(st->d_info, st->h_info, (size_t)st->tiles.ntiles * THIP_TILE_FRAGS * 8,
                            hipMemcpyHostToDevice, s));
