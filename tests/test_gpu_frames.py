@@ -644,3 +644,53 @@ def test_postprocessing(hip, w, h, fmt):
             want7, var = ost.postprocess(oracle.FRAME_PREV, 7, 1, dc_qis, frag_qi, dcs, shm)
             assert (var > 5 * 384).any() and (var > 384).any()   # the strong and the three-pass branches were taken
         ost.close()
+
+
+def test_a_failed_hand_over_is_decoded_again(hip, capfd):
+    """k_recon_lf hands tile edges between concurrently running work groups and bounds every wait; a wait that runs out sets the
+    state's pinned fault word (thip_fused.h).  Option debug = 512 makes tile 1 of every stream tag its units with the wrong serial
+    number, so its neighbours give up: a frame that came through the enqueue slots (its command stream lives in the state's own
+    staging) is then decoded again with the two passes by the next synchronising call and the picture is still bit-exact; a frame
+    whose descriptors are the caller's cannot be, and the call says THIP_EFAULT -- once."""
+    L = hip._lib.load()
+    import ctypes as C
+    w, h = 512, 256
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(321)
+    ost = oracle.State(w, h, PF_420)
+    gst = hip.State(w, h, PF_420)
+    n0 = C.c_int()
+    L.thip_get_option(b"faults_recovered", C.byref(n0))
+    try:
+        for f in range(4):
+            fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "dense", flimit=3)
+            util.oracle_apply(ost, fr)
+            L.thip_set_option(b"debug", 512 if f in (1, 2) else 0)
+            util.enqueue_frame(hip, gst, geom, fr)
+            if f == 2:
+                outs = gst.ycbcr_out()     # (this path notices it, too, and sends the right picture)
+                for pli in range(3):
+                    assert np.array_equal(outs[pli], ost.get_plane(oracle.FRAME_PREV, pli)[::-1]), (f, pli)
+            assert not util.planes_equal(ost, gst), f
+        n1 = C.c_int()
+        L.thip_get_option(b"faults_recovered", C.byref(n1))
+        assert n1.value - n0.value == 2
+        assert "decoding the frame again" in capfd.readouterr().err
+        # the caller's descriptors: no second attempt, THIP_EFAULT once, then the state carries on (from a key frame)
+        fr = synth.gen_frame(geom, rng, hip.INTER_FRAME, "dense", flimit=3)
+        desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+        L.thip_set_option(b"debug", 512)
+        hip.decode_frames([gst], [desc])
+        L.thip_set_option(b"debug", 0)
+        with pytest.raises(hip.TheoraHipError):
+            gst.read_plane(gst.ref_idx(hip.FRAME_PREV), 0)
+        gst.read_plane(gst.ref_idx(hip.FRAME_PREV), 0)            # reported once
+        ost2 = oracle.State(w, h, PF_420)
+        for f in range(2):
+            fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "mixed", flimit=3)
+            util.oracle_apply(ost2, fr)
+            desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+            hip.decode_frames([gst], [desc])
+            assert not util.planes_equal(ost2, gst), f
+    finally:
+        L.thip_set_option(b"debug", 0)

@@ -80,6 +80,7 @@ Option g_options[] = {
     {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
     {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
+    {"faults_recovered", 0, "(counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf had run out"},
 };
 constexpr int kNumOptions = (int)(sizeof(g_options) / sizeof(g_options[0]));
 std::once_flag g_options_once;
@@ -182,6 +183,18 @@ struct thip_state {
   int16_t *d_dc;        // device, nfrags: un-predicted DC values of the frame being decoded
   uint4 *d_dc_ent;      // device, nfrags: k_dc_prepare's per-fragment entries
   uint8_t *d_dc_rowhas; // device, one byte per fragment row of every plane
+  uint32_t *fault;      // pinned host word: bit 0 set by k_recon_lf, bit 1 by k_pp_dering, when a bounded wait ran out
+  // the state's most recent frame, kept so that it can be decoded again with the two passes if its hand-over failed
+  // (recover_fault); only frames whose command stream lives in the state's own staging buffers (enqueue slots, token lists)
+  struct {
+    int valid;
+    thip_frame_desc d;
+    int ring[3];            // ref_idx before the frame
+    int lf_custom, lf_y0[3], lf_y1[3];
+    int flush_flags;
+    int64_t serial;         // frame_serial after the frame
+  } redo;
+  int redo_owned;       // set by the callers whose descriptors point into the state's own buffers, around their thip_decode_frames call
   uint8_t *d_edge;      // device, k_recon_lf: kTfRec bytes per tile (the tiles' edges for their neighbours)
   uint32_t edge_epoch;  // serial number of the last k_recon_lf launch for this state (0 = never: the records are zero); 12 bits
   int device_dc, enq_device_dc;
@@ -225,6 +238,11 @@ struct thip_state {
   int pp_active[3];
 };
 
+// 0: the state's fault word is clear; 1: a failed hand-over was noticed and the frame has been decoded again with the two
+// passes; THIP_EFAULT: a bounded wait ran out and the frame could not be decoded again (reported once).  The state's device
+// must be current.  (Defined behind launch_chunk.)
+static int check_fault(thip_state *st);
+
 namespace {
 std::mutex g_mu;
 // Library-owned HIP streams ("lanes").  Every thip_state is bound to one lane for life, so
@@ -258,30 +276,11 @@ struct DeviceGuard {
   }
 };
 int g_profile = 0;
-// One pinned host word per device that kernels set when a bounded wait ran out (k_recon_lf's hand-over).  Checked by the
-// calls that synchronise with the device; sticky until thip_synchronize reports it.
-uint32_t *g_fault[kMaxDevices];
-std::mutex g_fault_mu;
-uint32_t *fault_word(int device) {   // the device must be current
-  if (device < 0 || device >= kMaxDevices) return nullptr;
-  std::lock_guard<std::mutex> lk(g_fault_mu);
-  if (!g_fault[device]) {
-    uint32_t *p = nullptr;
-    if (hipHostMalloc((void **)&p, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
-    *p = 0;
-    g_fault[device] = p;
-  }
-  return g_fault[device];
-}
-int check_fault(int device) {
-  if (device < 0 || device >= kMaxDevices || !g_fault[device]) return THIP_OK;
-  if (*(volatile uint32_t *)g_fault[device]) {
-    fprintf(stderr, "theora_hip: a kernel's bounded wait for a neighbouring tile ran out on device %d: the frames decoded since the "
-                    "last synchronisation are not to be trusted (set option fuse = 0 to take the two-pass path)\n", device);
-    return THIP_EFAULT;
-  }
-  return THIP_OK;
-}
+// Every state has a pinned host word that kernels set when a bounded wait ran out (k_recon_lf's hand-over: bit 0; the
+// de-ringing's: bit 1).  The calls that synchronise with a state look at it (check_fault, below launch_chunk): a frame whose
+// hand-over failed is decoded again with the two passes where that is possible, else the call returns THIP_EFAULT once.
+std::mutex g_states_mu;
+std::vector<thip_state *> g_states;   // every live state (thip_synchronize looks at all of them)
 struct EvPair { hipEvent_t a, b; int kernel; };
 std::vector<EvPair> g_events;
 std::vector<hipEvent_t> g_pool;
@@ -585,6 +584,8 @@ int thip_state_create_on(thip_state **out, int device, int frame_width, int fram
   for (int b = 0; b < 3 && err == hipSuccess; b++) err = hipMalloc((void **)&st->frames[b], st->frame_bytes + 256);
   if (err == hipSuccess) err = hipMalloc((void **)&st->coded_map, 2 * (size_t)st->nfrags);
   if (err == hipSuccess) err = hipMemset(st->coded_map, 0, 2 * (size_t)st->nfrags);
+  if (err == hipSuccess) err = hipHostMalloc((void **)&st->fault, 64, hipHostMallocMapped);
+  if (err == hipSuccess) *st->fault = 0;
   if (err != hipSuccess) {
     fprintf(stderr, "theora_hip: thip_state_create: device allocation failed: %s\n", hipGetErrorString(err));
     thip_state_free(st);
@@ -599,6 +600,10 @@ int thip_state_create_on(thip_state **out, int device, int frame_width, int fram
   st->buf_serial[0] = st->buf_serial[1] = st->buf_serial[2] = -1;
   st->map_serial[0] = st->map_serial[1] = -1;
   st->pp_serial = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_states_mu);
+    g_states.push_back(st);
+  }
   *out = st;
   return THIP_OK;
 }
@@ -607,8 +612,18 @@ int thip_state_device(const thip_state *st) { return st ? st->device : THIP_EFAU
 
 void thip_state_free(thip_state *st) {
   if (!st) return;
+  {
+    std::lock_guard<std::mutex> lk(g_states_mu);
+    for (size_t i = 0; i < g_states.size(); i++)
+      if (g_states[i] == st) {
+        g_states[i] = g_states.back();
+        g_states.pop_back();
+        break;
+      }
+  }
   DeviceGuard dg(st->device);
   (void)hipDeviceSynchronize();
+  if (st->fault) (void)hipHostFree(st->fault);
   for (int b = 0; b < 3; b++)
     if (st->frames[b]) (void)hipFree(st->frames[b]);
   if (st->coded_map) (void)hipFree(st->coded_map);
@@ -704,9 +719,11 @@ int thip_state_read_plane(thip_state *st, int bufi, int pli, uint8_t *host_out) 
   const thip_plane_geom &g = st->geom[pli];
   DeviceGuard dg(st->device);
   HIP_TRY(hipDeviceSynchronize());
+  const int frc = check_fault(st);   // (a frame decoded again is complete when this returns)
+  if (frc < 0) return frc;
   HIP_TRY(hipMemcpy2D(host_out, g.width, st->frames[bufi] + g.plane_off, g.stride, g.width, g.height,
                       hipMemcpyDeviceToHost));
-  return check_fault(st->device);
+  return THIP_OK;
 }
 
 int thip_state_write_plane(thip_state *st, int bufi, int pli, const uint8_t *host_in) {
@@ -816,20 +833,25 @@ int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strid
   if (!st || !planes || !strides) return THIP_EFAULT;
   if (st->last_decoded < 0) return THIP_EINVAL;
   DeviceGuard dg(st->device);
-  if (st->out_serial != st->frame_serial) {   // not copied yet (no eager output, or the frame came from write_plane)
-    hipStream_t fs;
-    int rc = followup_stream(st, &fs);
-    if (rc < 0) return rc;
-    rc = launch_frame_out(st, fs);
-    if (rc < 0) return rc;
-    if (fs != st->last_stream) {
-      rc = order_mark(st, fs);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (st->out_serial != st->frame_serial) {   // not copied yet (no eager output, or the frame came from write_plane)
+      hipStream_t fs;
+      int rc = followup_stream(st, &fs);
       if (rc < 0) return rc;
+      rc = launch_frame_out(st, fs);
+      if (rc < 0) return rc;
+      if (fs != st->last_stream) {
+        rc = order_mark(st, fs);
+        if (rc < 0) return rc;
+      }
     }
+    if (wait_event(st->ev_out) < 0) return THIP_EFAULT;
+    st->out_done_serial = st->out_serial;
+    const int frc = check_fault(st);
+    if (frc < 0) return frc;
+    if (frc == 0) break;
+    // the frame has been decoded again: once more, for the right picture
   }
-  if (wait_event(st->ev_out) < 0) return THIP_EFAULT;
-  st->out_done_serial = st->out_serial;
-  if (check_fault(st->device) < 0) return THIP_EFAULT;
   int off = 0;
   for (int p = 0; p < 3; p++) {
     planes[p] = st->h_out[st->out_cur] + off;
@@ -858,15 +880,22 @@ int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t ds
 int thip_synchronize(void) {
   int rc = THIP_OK;
   for (int d = 0; d < kMaxDevices; d++) {
-    if (!g_lanes_ready[d]) continue;
+    if (!g_lanes_ready[d] && !g_ctx_ready[d]) continue;
     DeviceGuard dg(d);
-    for (int i = 0; i < g_nlanes; i++) HIP_TRY(hipStreamSynchronize(g_lanes[d][i]));
+    for (int i = 0; i < g_nlanes && g_lanes_ready[d]; i++) HIP_TRY(hipStreamSynchronize(g_lanes[d][i]));
     for (int i = 0; i < kCtxLanes; i++)
       if (g_ctx_ready[d] && g_ctx_lanes[d][i]) HIP_TRY(hipStreamSynchronize(g_ctx_lanes[d][i]));
-    if (check_fault(d) < 0) {
-      rc = THIP_EFAULT;
-      *(volatile uint32_t *)g_fault[d] = 0;   // reported
-    }
+  }
+  // every state's fault word, whichever stream its frames went down (a caller-owned stream is the caller's to synchronise)
+  std::vector<thip_state *> all;
+  {
+    std::lock_guard<std::mutex> lk(g_states_mu);
+    all = g_states;
+  }
+  for (thip_state *st : all) {
+    if (!st->fault || !*(volatile uint32_t *)st->fault) continue;
+    DeviceGuard dg(st->device);
+    if (check_fault(st) < 0) rc = THIP_EFAULT;
   }
   return rc;
 }
@@ -927,10 +956,9 @@ static hipError_t set_dynamic_lds(const void *kernel, int bytes, int which) {
 
 // Launch one chunk of <= THIP_MAX_BATCH streams.
 static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs, int n, hipStream_t s,
-                        int32_t *results) {
+                        int32_t *results, bool two_passes = false) {
   BatchK B;
   memset(&B, 0, sizeof(B));
-  B.fault = fault_word(states[0] ? states[0]->device : -1);
   int max_wg = 0, max_seam_wg = 0, any_lf = 0, nlive = 0;
   int any_skip = 0;
   int live_state[THIP_MAX_BATCH];
@@ -969,10 +997,24 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       continue;
     }
     if (results) results[i] = THIP_OK;
+    st->redo.valid = 0;
+    if (st->redo_owned) {   // (the descriptor points into the state's own buffers: the frame can be decoded again, recover_fault)
+      st->redo.d = d;
+      for (int k = 0; k < 3; k++) st->redo.ring[k] = st->ref_idx[k];
+      st->redo.lf_custom = st->lf_rows_custom;
+      for (int k = 0; k < 3; k++) {
+        st->redo.lf_y0[k] = st->lf_y0[k];
+        st->redo.lf_y1[k] = st->lf_y1[k];
+      }
+      st->redo.flush_flags = st->flush_flags;
+      st->redo.serial = st->frame_serial + 1;
+      st->redo.valid = 1;
+    }
     int bufi = 0;  // decode.c:2790-2794
     while (bufi == st->ref_idx[THIP_FRAME_GOLD] || bufi == st->ref_idx[THIP_FRAME_PREV]) bufi++;
     st->ref_idx[THIP_FRAME_SELF] = bufi;
     StreamK &K = B.s[nlive];
+    K.fault = st->fault;
     K.info = reinterpret_cast<const uint2 *>(d.frag_info);
     K.coeffs = reinterpret_cast<const int4 *>(d.coeffs);
     K.tile_slot0 = d.tile_slot0;
@@ -1079,7 +1121,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   // Default (option "fuse" = 3): k_recon_lf, reconstruction and the whole loop filter in one pass (thip_fused.h); 0: the two
   // passes k_recon + k_loopfilter.  Frames that leave static blocks in place (skip_ok) and frames without a loop filter
   // always take the two passes, whose first kernel knows how to skip whole tiles.
-  const int fuse = THIP_OPT("fuse");
+  const int fuse = two_passes ? 0 : THIP_OPT("fuse");
   if (fuse == 3 && any_lf && !any_skip && xcd_round_robin(states[live_state[0]]->device)) {
     // one wave per tile, reconstruction and every filter cell in one pass (thip_fused.h)
     int longest = 1;
@@ -1127,6 +1169,51 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     if (orc < 0) return orc;
   }
   return THIP_OK;
+}
+
+static int check_fault(thip_state *st) {
+  if (!st->fault) return THIP_OK;
+  const uint32_t w = *(volatile uint32_t *)st->fault;
+  if (!w) return THIP_OK;
+  // everything queued for this state has to be over before the frame is launched again
+  if (st->last_stream && is_library_stream(st->device, st->last_stream)) HIP_TRY(hipStreamSynchronize(st->last_stream));
+  else HIP_TRY(hipDeviceSynchronize());
+  *(volatile uint32_t *)st->fault = 0;
+  if ((w & 1u) && !(w & 2u) && st->redo.valid && st->redo.serial == st->frame_serial) {
+    fprintf(stderr, "theora_hip: a bounded wait of k_recon_lf for a neighbouring tile ran out (device %d); decoding the frame again with "
+                    "the two passes\n", st->device);
+    const thip_frame_desc d = st->redo.d;
+    for (int k = 0; k < 3; k++) st->ref_idx[k] = st->redo.ring[k];
+    st->lf_rows_custom = st->redo.lf_custom;
+    for (int k = 0; k < 3; k++) {
+      st->lf_y0[k] = st->redo.lf_y0[k];
+      st->lf_y1[k] = st->redo.lf_y1[k];
+    }
+    st->flush_flags = st->redo.flush_flags;
+    if (st->out_cur >= 0 && st->out_serial == st->frame_serial) st->out_cur ^= 1;   // the wrong picture's host image is the one to overwrite
+    hipStream_t s;
+    int rc = followup_stream(st, &s);
+    if (rc < 0) return rc;
+    thip_state *sp = st;
+    int32_t res = 0;
+    st->redo_owned = 1;
+    rc = launch_chunk(&sp, &d, 1, s, &res, true);
+    st->redo_owned = 0;
+    st->lf_rows_custom = 0;
+    st->flush_flags = 0;
+    if (rc < 0) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    if (!*(volatile uint32_t *)st->fault) {
+      static Option *const counter = find_option("faults_recovered");
+      if (counter) counter->value.fetch_add(1, std::memory_order_relaxed);
+      return 1;
+    }
+    *(volatile uint32_t *)st->fault = 0;
+  }
+  fprintf(stderr, "theora_hip: a kernel's bounded wait ran out on device %d (%s) and the frame could not be decoded again: the frames "
+                  "of this state since its last synchronisation are not to be trusted (option fuse = 0 takes the two-pass path)\n",
+          st->device, (w & 2u) ? "de-ringing" : "tile hand-over");
+  return THIP_EFAULT;
 }
 
 // What launch_chunk would refuse, checked for the whole call before anything is launched or any
@@ -1345,7 +1432,7 @@ int thip_state_postprocess(thip_state *st, int level, const uint8_t *dc_qis, con
       for (int pli = 0; pli < 3; pli++) K.done[pli] = st->pp_done + goff[pli];
       st->pp_run = st->pp_run == 0xFFFFFFFFu ? 1u : st->pp_run + 1u;
       K.serial = st->pp_run;
-      K.fault = fault_word(st->device);
+      K.fault = st->fault;
       hipLaunchKernelGGL(k_pp_dering, dim3((unsigned)gmax, 3, (unsigned)nd), dim3(64 * kPpGroup), 0, s, K);
     }
   }
@@ -1700,7 +1787,9 @@ int thip_frame_flush(thip_state *st) {
   }
   int32_t res = 0;
   thip_state *sp = st;
+  st->redo_owned = 1;   // (the descriptor points into this state's staging buffers, intact until the next thip_frame_begin)
   rc = thip_decode_frames(&sp, &d, 1, (void *)s, &res);
+  st->redo_owned = 0;
   st->lf_rows_custom = 0;
   st->flush_flags = 0;
   if (rc < 0) return rc;
@@ -1880,7 +1969,9 @@ int thip_state_token_lists_finish(thip_state *st, const int16_t *dc) {
   }
   int32_t res = 0;
   thip_state *sp = st;
+  st->redo_owned = 1;
   int rc = thip_decode_frames(&sp, &d, 1, (void *)s, &res);
+  st->redo_owned = 0;
   if (rc < 0) return rc;
   if (ncoded) {
     if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));

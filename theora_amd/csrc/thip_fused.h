@@ -117,11 +117,12 @@ __device__ __forceinline__ void tf_publish_units(const uint8_t *lds, uint8_t *re
 }
 
 // The consumer's side: every lane with a source loads its unit and looks again until its tag carries the launch's serial
-// number (bounded: see tf header; `fault` is the device's pinned host word).  Returns the unit.
-__device__ __forceinline__ uint4 tf_fetch_unit(const uint8_t *src, uint32_t ep, uint32_t *fault) {
+// number (bounded: see tf header; `fault` is the state's pinned host word: the host notices it at its next synchronising call
+// and decodes the frame again with the two passes, thip_decode.hip: recover_fault).  Returns the unit.
+__device__ __forceinline__ uint4 tf_fetch_unit(const uint8_t *src, uint32_t ep, uint32_t *fault, int max_spins) {
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
   bool ok = src == nullptr;
-  for (int spins = 0; spins < (1 << 20); spins++) {
+  for (int spins = 0; spins < max_spins; spins++) {
     if (!ok) {
       v = tf_load_unit(src);
       ok = (v.w >> 20) == ep;
@@ -226,10 +227,15 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   const int te0 = S.tile_end[0], te1 = S.tile_end[1];
   const int sqpx = S.qpx, sqpy = S.qpy;
   const int L2 = (S.debug & 256) ? 0 : S.flimit2;   // (ablation switch for profiling, option debug = 256: cells copy, no filtering)
+  // (test switch, option debug = 512: tile 1 of every stream tags its units with the WRONG serial number, so that its neighbours'
+  //  waits run out -- quickly -- and the host's recovery can be exercised: tests/test_gpu_frames.py::test_a_failed_hand_over_is_decoded_again)
+  const bool poison = (S.debug & 512) != 0;
+  const int max_spins = poison ? 256 : (1 << 20);
+  uint32_t *fault_p = S.fault;
   const uint32_t ep = S.epoch;
   const int bu0 = S.band_u0[band], bu1 = S.band_u0[band + 1];
   asm volatile("" ::"s"(info_p), "s"(coeffs_p), "s"(slot0_p), "s"(self), "s"(prev), "s"(gold), "s"(coded_map), "s"(dc_p), "s"(dq_p), "s"(edge_p),
-               "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2), "s"(ep), "s"(bu0), "s"(bu1));
+               "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2), "s"(ep), "s"(bu0), "s"(bu1), "s"(fault_p));
   const int u = bu0 + jb;
   if (u >= bu1) return;
   [[maybe_unused]] unsigned long long *tr = nullptr;   // tools/lf_trace.py: lane 0 stamps the phases of the wave's life (THIP_TRACE builds only)
@@ -363,8 +369,9 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
                              : (lane < 20 ? (lane - 16 + 1) * kTfFlagPitch + 16 : (lane >= 32 && lane < 48 ? kTfFlagPitch + (lane - 32) + 1 : 0));
     const bool fb = (lane < 20 || (lane >= 32 && lane < 48)) && lds[kTfFlagOff + fi] != 0;
     const uint64_t fm = __ballot(fb);
-    tf_publish_units(lds, myrec + kTfBot, myrec + kTfRight, 34, true, ep << 20 | (uint32_t)(fm & 0xFFFFFu), lane, xb_up);
-    if (xb_up) tf_publish_units(lds, myrec + kTfTop, nullptr, 4, false, ep << 20 | ((uint32_t)(fm >> 32) & 0xFFFFu), lane, true);
+    const uint32_t tag_ep = (poison && u == 1) ? 0u : ep;   // (serial numbers are never 0)
+    tf_publish_units(lds, myrec + kTfBot, myrec + kTfRight, 34, true, tag_ep << 20 | (uint32_t)(fm & 0xFFFFFu), lane, xb_up);
+    if (xb_up) tf_publish_units(lds, myrec + kTfTop, nullptr, 4, false, tag_ep << 20 | ((uint32_t)(fm >> 32) & 0xFFFFu), lane, true);
     THIP_TR(tr, 3);   // image in LDS, edges on their way
     THIP_TR(tr, 4);
   }
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     } else if (lane == kTfBotUnits + kTfRightUnits) {
       if (need_ul) src = rec_ul + kTfRight + 10 * kTfUnit;
     }
-    const uint4 un = tf_fetch_unit(src, ep, B.fault);
+    const uint4 un = tf_fetch_unit(src, ep, fault_p, max_spins);
     THIP_TR(tr, 5);   // the neighbours' units are there
     const uint32_t d[3] = {un.x, un.y, un.z};
     if (lane < kTfBotUnits) {
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
       const uint8_t *src = nullptr;
       if (lane < kTfBotUnits) src = rec_dn + kTfTop + lane * kTfUnit;
       else if (lane == kTfBotUnits && has_left) src = rec_dl + kTfRight;
-      const uint4 un = tf_fetch_unit(src, ep, B.fault);
+      const uint4 un = tf_fetch_unit(src, ep, fault_p, max_spins);
       const uint32_t d[3] = {un.x, un.y, un.z};
       if (lane < kTfBotUnits) {
 #pragma unroll

@@ -69,12 +69,12 @@ struct StreamK {
   uint8_t *edge;          // kTfRec bytes per tile: the tile's edges for its neighbours
   uint32_t epoch;         // serial number that marks the edge records of this launch
   int band_u0[9];         // first tile of each of the 8 XCD bands (whole tile rows), [8] = number of tiles
+  uint32_t *fault;        // pinned host word of the stream's state: set by a kernel whose bounded wait ran out (k_recon_lf's hand-over)
   PlaneK pl[3];
 };
 
 struct BatchK {
   StreamK s[THIP_MAX_BATCH];
-  uint32_t *fault;   // pinned host word of the device: set by a kernel whose bounded wait ran out (k_recon_lf's hand-over)
 };
 
 // ---------------------------------------------------------------------------------------

@@ -40,7 +40,7 @@ struct PpK {
   // de-ringing as ONE launch: a group of blocks waits for its left and upper neighbour groups (k_pp_dering)
   uint32_t *done[3];    // per plane, per group: the serial number of the launch that finished it
   uint32_t serial;      // of this launch (never 0)
-  uint32_t *fault;      // the device's pinned host word: set when a bounded wait runs out
+  uint32_t *fault;      // the state's pinned host word: set (bit 1) when a bounded wait runs out
 };
 
 __device__ __forceinline__ int pp_abs(int v) { return v < 0 ? -v : v; }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * kPpGroup) void k_pp_dering(const PpK K) {
       if (__all(ok)) break;
       __builtin_amdgcn_s_sleep(2);
     }
-    if (!ok && K.fault) __hip_atomic_store(K.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!ok && K.fault) __hip_atomic_store(K.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   // the region: rows Y0-1 .. Y0+64 clamped into the plane; the 64 pixels as dwords (plane widths are multiples of 8),
