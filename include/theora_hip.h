@@ -221,10 +221,15 @@ void thip_pack_dequant_table(uint16_t out[64], const uint16_t zz[64]);
    results[i] (optional, host) receives 0 or THIP_DUPFRAME per stream. */
 int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, int nstreams,
                        void *stream, int32_t *results);
-/* Wait for everything submitted on the library's own streams.  Returns THIP_EFAULT (once) if a kernel reported that one of
-   its bounded waits ran out since the last call -- k_recon_lf hands tile edges between concurrently running work groups
-   and relies on their being dispatched in order; a wait that gives up leaves a wrong picture, and this is how the caller
-   learns of it (thip_state_ycbcr_map / _out and thip_state_read_plane report it too).  It has never been observed. */
+/* Wait for everything submitted on the library's own streams.  k_recon_lf hands tile edges between concurrently running
+   work groups and relies on their being dispatched in order; every wait is bounded, and one that gives up sets a pinned word
+   of the state (it has never been observed outside the test that forces it).  The calls that synchronise with a state --
+   this one, thip_state_ycbcr_map / _out, thip_state_read_plane -- look at the word: the state's most recent frame is decoded
+   AGAIN with the two-pass kernels when its command stream lives in the state's own staging buffers (frames that came through
+   the enqueue slots or the token lists, i.e. every th_decode_* frame) and nothing has been decoded since; the call then
+   succeeds and option "faults_recovered" counts.  A frame given to thip_decode_frames by descriptor cannot be decoded again
+   (the descriptors are the caller's): the call returns THIP_EFAULT, once, and the state's pictures are wrong until its next
+   key frame. */
 int thip_synchronize(void);
 
 /* ------------------------------------------------------------------------------------
@@ -466,7 +471,9 @@ const char *thip_version_string(void);
  *   zerocopy     enqueue path: kernels read the pinned staging across PCIe (default 1)
  *   wait_spin    wait for a frame in hipEventSynchronize instead of polling with short sleeps (default 0)
  *   dc_global    DC un-prediction through memory even where the LDS kernel fits (default 0)
- *   debug        k_recon ablation switches (profiling)
+ *   debug        k_recon ablation switches (profiling); 256: k_recon_lf's cells copy without filtering; 512: tile 1 of every
+ *                stream mis-tags its edge units, so that a hand-over fails and the recovery below can be tested
+ *   faults_recovered   (counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf ran out
  *   fe_device_dc, fe_device_tokens   th_decode_*: front-end stages on the device (default 0; also TH_DECCTL_THIP_SET_DEVICE_*
  *                per context)
  *   fe_device_lists   th_decode_*: the token lists go to the device as the entropy decoder leaves them: 1 on, 0 off, -1 (default)
