@@ -310,8 +310,11 @@ def main_enc():
         v, dc = call()
         want_v, _ = theora_amd.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)
         assert torch.equal(v.reshape(-1), want_v)      # candidate-major = the order of the pair list above (checked against the oracle there)
+        # (the nine candidates of a block share its source block and all but a rim of the reference window: the traffic model is
+        #  the UNIQUE bytes -- both frames once, the results -- not 132 / 136 bytes a pair)
+        uniq = 2 * nblk * 64 + src_offs.size * (4 if op == "sad" else 8)
         results.append(dict(kernel="oc_enc_frag_%s, motion-search form (thip_enc_frag_metric_sites_batch)" % op, units=src_offs.size,
-                            unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=float("nan")))
+                            unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=float("nan"), unique_bytes=uniq))
     # --- ... and over several frames in one call (a single frame is one round of waves: its launch ramp, first loads and tail
     #     are a third of the call; an encoder with more than one stream to search hands them over together) -------------------
     for F in (2, 4):
@@ -331,15 +334,39 @@ def main_enc():
                                                 baseF[sel], 0)
                 assert np.array_equal(v.reshape(len(sites), -1)[si].cpu().numpy()[sel].view(np.uint32), wv)
             results.append(dict(kernel="oc_enc_frag_%s, motion-search form, %d frames per call" % (op, F), units=baseF.size * len(sites),
-                                unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=float("nan")))
+                                unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=float("nan"),
+                                unique_bytes=2 * baseF.size * 64 + baseF.size * len(sites) * (4 if op == "sad" else 8)))
+    # --- the per-macro-block cost maps of a whole frame (thip_enc_mb_cost_maps: oc_mb_intra_satd, oc_mb_activity, _fast) ---------
+    Wc, Hc = 1920, 1088
+    cplanes = [rng.integers(0, 256, (Hc, Wc)).astype(np.uint8) for _ in range(3)]
+    yy, xx = np.mgrid[0:Hc, 0:Wc]
+    cplanes[0] = np.where(((xx // 16 + yy // 16) % 3) == 0, 90, np.where(((xx // 16 + yy // 16) % 3) == 1, cplanes[0],
+                          np.where((xx + yy) % 16 < 8, 20, 230))).astype(np.uint8)       # flat / texture / edge macro blocks by turns
+    d_cpl = [torch.from_numpy(p).cuda() for p in cplanes]
+    call = lambda: theora_amd.enc_mb_cost_maps(d_cpl, Wc, Hc, 3)   # noqa: E731
+    t = timed(call)
+    got_maps = [g.cpu().numpy().view(np.uint32) for g in call()]
+    t0 = time.perf_counter()
+    want_maps = oracle.mb_cost_maps(cplanes, Wc, Hc, 3)
+    tc = time.perf_counter() - t0
+    assert all(np.array_equal(g, wv) for g, wv in zip(got_maps, want_maps))
+    nmb = (Wc // 16) * (Hc // 16)
+    results.append(dict(kernel="oc_mb_intra_satd + oc_mb_activity + oc_mb_activity_fast, whole frame (thip_enc_mb_cost_maps)", units=nmb,
+                        unit="macro blocks", seconds=t, bytes_per_unit=12 * 64 + 21 * 4, cpu_rate=nmb / tc,
+                        unique_bytes=3 * Wc * Hc + want_maps[0].shape[0] * 21 * 4 * 2))
     for r in results:
-        gbs = r["units"] * r["bytes_per_unit"] / r["seconds"] / 1e9
+        # bytes moved: the per-unit model of SURVEY section 8(d) for the pair lists (every pair fetches its own blocks); the
+        # unique bytes where units share their input (a frac above 1 against bytes that are not moved is not evidence)
+        nbytes = r.get("unique_bytes", r["units"] * r["bytes_per_unit"])
+        gbs = nbytes / r["seconds"] / 1e9
         print(json.dumps({
             "metric": r["kernel"] + " throughput", "value": round(r["units"] / r["seconds"] / 1e6, 1), "unit": "M%s/s" % r["unit"],
             "config": {"workload": "1920x1088 4:4:4%s, %d %s per call, 9-site square pattern" % (" x %s frames" % r["kernel"].split(", ")[-1].split()[0] if "frames per call" in r["kernel"] else "", r["units"], r["unit"])},
             "ms_per_call": round(1e3 * r["seconds"], 4), "dtype": "u8/i16", "data": "synthetic", "bit_exact_vs_oracle": True,
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 4), "alg_bytes_per_unit": r["bytes_per_unit"]},
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "alg_bytes_per_unit": r["bytes_per_unit"],
+                         "bytes_per_call": int(nbytes), "byte_model": "unique bytes (inputs once + results)" if "unique_bytes" in r
+                         else "per-unit bytes of SURVEY section 8(d)"},
             "cpu_baseline": ({"value": round(r["cpu_rate"] / 1e6, 3), "unit": "M%s/s" % r["unit"], "cores": 1, "kind": "port"}
                              if r["cpu_rate"] == r["cpu_rate"] else None)}))
 

@@ -373,6 +373,24 @@ int thip_enc_frag_metric_sites_batch(int op, uint32_t *out, int32_t *dc_out, con
                                      const uint8_t *ref_plane, int ystride, const int32_t *src_offs,
                                      const int32_t *ref_offs, const int8_t *site_dx, const int8_t *site_dy,
                                      int nsites, int64_t nblocks);
+/* The encoder's per-macro-block cost maps for a whole frame, computed up front in one launch: what
+   oc_mb_intra_satd (analyze.c:1360-1403), oc_mb_activity (analyze.c:1152-1237) and oc_mb_activity_fast (analyze.c:1239-1251)
+   return for every macro block -- the reference calls them macro block by macro block from its mode-decision loop
+   (analyze.c:1697-1718, 2372-2398), but they depend on the input picture alone.  planes: the frame to be encoded (device, unpadded,
+   bitstream row order like everything here; reads beyond a plane's edge are clamped, which is the replicated border of the
+   reference's input frame, encode.c:1735-1744); strides in bytes; frame size the coded size (multiples of 16).
+   Macro blocks are numbered as in the reference: mbi = luma super block << 2 | quadrant (state.c:300-330; thip_enc_mb_count of
+   them, those outside the frame are zero in every array).  Outputs (device, each may be NULL):
+     intra_satd[mbi*12 + k]   _frag_satd[k] of oc_mb_intra_satd: k = 0..3 the luma blocks in sb_maps order (state.c:134-139),
+                              then the macro block's Cb and Cr blocks in OC_MB_MAP_IDXS order (internal.c:67-76: 1+1, 2+2 or 4+4
+                              by pixel format), unused entries 0
+     luma[mbi]                its return value (the sum of the four luma blocks' pixels)
+     activity[mbi*4 + k]      _activity[k] of oc_mb_activity (edge classification and its 0.7 power included)
+     activity_fast[mbi*4 + k] _activity[k] of oc_mb_activity_fast
+   Stream and synchronisation as thip_set_batch_stream says. */
+int thip_enc_mb_count(int frame_width, int frame_height);
+int thip_enc_mb_cost_maps(const uint8_t *const planes[3], const int32_t strides[3], int frame_width, int frame_height, int pixel_fmt,
+                          uint32_t *intra_satd, uint32_t *luma, uint32_t *activity, uint32_t *activity_fast);
 /* oc_enc_frag_border_ssd (encfrag.c:352): per-block 64-bit pixel masks (state.h:285-292). */
 int thip_enc_frag_border_ssd_batch(uint32_t *out, const uint8_t *src_plane,
                                    const uint8_t *ref_plane, int ystride,

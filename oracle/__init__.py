@@ -80,6 +80,8 @@ def lib():
     L.orc_enc_metric_batch.argtypes = [C.c_int, P, P, P, P, C.c_int, P, P, P, C.c_uint, C.c_ssize_t]
     L.orc_mv_offsets.restype = C.c_int
     L.orc_mv_offsets.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_mb_cost_maps.restype = C.c_int
+    L.orc_mb_cost_maps.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, P, P, P]
     L.orc_frag_recon_intra.argtypes = [P, C.c_int, P]
     L.orc_frag_recon_inter.argtypes = [P, P, C.c_int, P]
     L.orc_frag_recon_inter2.argtypes = [P, P, P, C.c_int, P]
@@ -259,6 +261,23 @@ def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None,
     lib().orc_enc_metric_batch(METRIC_OPS[op], _p(out), _p(dc), _p(sp), _p(rp), ystride, _p(so), _p(ro),
                                _p(r2), thresh, so.size)
     return out, dc
+
+
+def mb_cost_maps(planes, frame_width, frame_height, pixel_fmt):
+    """oc_mb_intra_satd / oc_mb_activity / oc_mb_activity_fast over a whole frame (three unpadded planes, bitstream row order).
+    Returns (intra_satd [nmbs,12], luma [nmbs], activity [nmbs,4], activity_fast [nmbs,4]) in the reference's macro-block order."""
+    pl = [_c(p, np.uint8) for p in planes]
+    nsbw, nsbh = ((frame_width >> 3) + 3) >> 2, ((frame_height >> 3) + 3) >> 2
+    nmbs = 4 * nsbw * nsbh
+    ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in pl])
+    strides = (C.c_int * 3)(*[p.shape[1] for p in pl])
+    satd = np.zeros((nmbs, 12), np.uint32)
+    luma = np.zeros(nmbs, np.uint32)
+    act = np.zeros((nmbs, 4), np.uint32)
+    fast = np.zeros((nmbs, 4), np.uint32)
+    rc = lib().orc_mb_cost_maps(ptrs, strides, frame_width, frame_height, pixel_fmt, _p(satd), _p(luma), _p(act), _p(fast))
+    assert rc == 0
+    return satd, luma, act, fast
 
 
 def mv_offsets(ystride, qpx, qpy, dx, dy):

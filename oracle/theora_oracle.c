@@ -1201,3 +1201,152 @@ void orc_enc_metric_batch(int op, uint32_t *out, int32_t *dc_out, const uint8_t 
     if (dc_out) dc_out[i] = dc;
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* encoder analysis: per-macro-block cost maps     */
+/* ------------------------------------------------------------------------- */
+/* mathops.c:294-314 (oc_bexp32_q10, oc_blog32_q10) and mathops.h's OC_ILOGNZ_32 (the position of the top bit, one-based) */
+static uint32_t bexp32_q10(int z) {
+  unsigned n;
+  int ipart = z >> 10;
+  n = (unsigned)(z & ((1 << 10) - 1)) << 4;
+  n = (n * ((n * ((n * ((n * 3548 >> 15) + 6817) >> 15) + 15823) >> 15) + 22708) >> 15) + 16384;
+  return 14 - ipart > 0 ? (n + (1u << (13 - ipart))) >> (14 - ipart) : n << (ipart - 14);
+}
+static int blog32_q10(uint32_t w) {
+  int n, ipart, fpart;
+  if (w <= 0) return -1;
+  ipart = 32 - __builtin_clz(w);
+  n = (int)(ipart - 16 > 0 ? w >> (ipart - 16) : w << (16 - ipart)) - 32768 - 16384;
+  fpart = (n * ((n * ((n * ((n * -1402 >> 15) + 2546) >> 15) - 5216) >> 15) + 15745) >> 15) - 6793;
+  return (ipart << 10) + (fpart >> 4);
+}
+
+/* One plane of the encoder's input frame as the reference keeps it: replicated 16-pixel (luma) borders around it
+   (encode.c:1735-1744: oc_img_plane_copy_pad, oc_state_borders_fill_rows, _caps), so that the edge test of oc_mb_activity may
+   read one pixel beyond a block on every side.  Built here from the unpadded plane the caller hands over. */
+typedef struct {
+  uint8_t *buf, *origin;   /* origin = pixel (0, 0) */
+  int stride, w, h;
+} padded_plane;
+static int pad_plane(padded_plane *p, const uint8_t *src, int src_stride, int w, int h) {
+  const int B = 16;
+  int x, y;
+  p->stride = w + 2 * B;
+  p->w = w;
+  p->h = h;
+  p->buf = (uint8_t *)malloc((size_t)p->stride * (h + 2 * B));
+  if (!p->buf) return -1;
+  p->origin = p->buf + (size_t)B * p->stride + B;
+  for (y = -B; y < h + B; y++) {
+    const int yy = y < 0 ? 0 : y >= h ? h - 1 : y;
+    for (x = -B; x < w + B; x++) {
+      const int xx = x < 0 ? 0 : x >= w ? w - 1 : x;
+      p->origin[(ptrdiff_t)y * p->stride + x] = src[(ptrdiff_t)yy * src_stride + xx];
+    }
+  }
+  return 0;
+}
+
+/* oc_mb_activity's body for one luma block (analyze.c:1167-1234); returns the block's pixel sum through *x_out */
+static unsigned block_activity(const uint8_t *blk, int ystride, unsigned *x_out) {
+  const uint8_t *s = blk;
+  unsigned x = 0, x2 = 0, act;
+  int i, j;
+  for (i = 0; i < 8; i++, s += ystride)
+    for (j = 0; j < 8; j++) {
+      const unsigned c = s[j];
+      x += c;
+      x2 += c * c;
+    }
+  *x_out = x;
+  act = (x2 << 6) - x * x;
+  if (act < 8u << 12) return act < 5u << 12 ? act : 5u << 12;   /* the region is flat */
+  {
+    unsigned e1 = 0, e2 = 0, e3 = 0, e4 = 0, emax;
+    s = blk - 1;
+    for (i = 0; i < 8; i++, s += ystride)
+      for (j = 0; j < 8; j++) {
+        const uint8_t *u = s - ystride, *d = s + ystride;
+        e1 += (unsigned)abs(((s[j + 2] - s[j]) << 1) + u[j + 2] - u[j] + d[j + 2] - d[j]);
+        e2 += (unsigned)abs(((d[j + 1] - u[j + 1]) << 1) + d[j] - u[j] + d[j + 2] - u[j + 2]);
+        e3 += (unsigned)abs(((d[j + 2] - u[j]) << 1) + d[j + 1] - s[j] + s[j + 2] - u[j + 1]);
+        e4 += (unsigned)abs(((d[j] - u[j + 2]) << 1) + d[j + 1] - s[j + 2] + s[j] - u[j + 1]);
+      }
+    emax = e1 > e2 ? e1 : e2;
+    if (e3 > emax) emax = e3;
+    if (e4 > emax) emax = e4;
+    /* an edge block: act = act_th * (act / act_th)^0.7, 0x394A = oc_blog32_q10(5 << 12) */
+    if (5 * emax > 2 * (e1 + e2 + e3 + e4)) act = bexp32_q10(0x394A + (7 * (blog32_q10(act) - 0x394A + 5) / 10));
+  }
+  return act;
+}
+
+/* oc_mb_intra_satd (analyze.c:1360-1403), oc_mb_activity (:1152-1237) and oc_mb_activity_fast (:1239-1251) for EVERY macro block
+   of a frame, in the reference's macro-block numbering: mbi = super block << 2 | quadrant (state.c:300-330), luma blocks of a
+   macro block in the order of sb_maps (state.c:123-190), chroma blocks in the order of OC_MB_MAP_IDXS (internal.c:67-76).
+   planes: the input frame, unpadded, bitstream row order.  Macro blocks outside the frame: zeros. */
+int orc_mb_cost_maps(const uint8_t *const planes[3], const int strides[3], int frame_width, int frame_height, int pixel_fmt,
+                     uint32_t *intra_satd /* [nmbs][12] */, uint32_t *luma /* [nmbs] */, uint32_t *activity /* [nmbs][4] */,
+                     uint32_t *activity_fast /* [nmbs][4] */) {
+  static const int SB_MAP[4][4][2] = {{{0, 0}, {0, 1}, {3, 2}, {3, 3}}, {{0, 3}, {0, 2}, {3, 1}, {3, 0}},
+                                      {{1, 0}, {1, 3}, {2, 0}, {2, 3}}, {{1, 1}, {1, 2}, {2, 1}, {2, 2}}};   /* state.c:134-139 */
+  static const int MB_MAP[2][2] = {{0, 3}, {1, 2}};                                                          /* internal.c:63 */
+  static const int MAP_IDXS[4][12] = {{0, 1, 2, 3, 4, 8}, {0, 1, 2, 3, 4, 5, 8, 9}, {0, 1, 2, 3, 4, 6, 8, 10},
+                                      {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}};                               /* internal.c:67-72 */
+  static const int MAP_NIDXS[4] = {6, 8, 8, 12};
+  const int hdec = !(pixel_fmt & 1), vdec = !(pixel_fmt & 2);
+  const int nh = frame_width >> 3, nv = frame_height >> 3;
+  const int nsbw = (nh + 3) >> 2, nsbh = (nv + 3) >> 2;
+  const int nmbs = 4 * nsbw * nsbh;
+  padded_plane pp[3];
+  int pli, sby, sbx, ymb, xmb, rc = 0;
+  memset(intra_satd, 0, sizeof(uint32_t) * 12 * (size_t)nmbs);
+  memset(luma, 0, sizeof(uint32_t) * (size_t)nmbs);
+  memset(activity, 0, sizeof(uint32_t) * 4 * (size_t)nmbs);
+  memset(activity_fast, 0, sizeof(uint32_t) * 4 * (size_t)nmbs);
+  memset(pp, 0, sizeof(pp));
+  for (pli = 0; pli < 3; pli++)
+    rc |= pad_plane(pp + pli, planes[pli], strides[pli], pli ? frame_width >> hdec : frame_width, pli ? frame_height >> vdec : frame_height);
+  if (!rc)
+    for (sby = 0; sby < nsbh; sby++)
+      for (sbx = 0; sbx < nsbw; sbx++)
+        for (ymb = 0; ymb < 2; ymb++)
+          for (xmb = 0; xmb < 2; xmb++) {
+            const int quad = MB_MAP[ymb][xmb];
+            const unsigned mbi = (unsigned)(sby * nsbw + sbx) << 2 | (unsigned)quad;
+            const int mbx = sbx * 4 + xmb * 2, mby = sby * 4 + ymb * 2;   /* luma fragment coordinates of the macro block */
+            int i, j, mapii;
+            if (mbx >= nh || mby >= nv) continue;                        /* OC_MODE_INVALID, state.c:316-319 */
+            /* the four luma blocks in sb_maps order: block (row i, column j) of the super block is entry SB_MAP[i][j][1] of
+               quadrant SB_MAP[i][j][0] */
+            for (i = 0; i < 4; i++)
+              for (j = 0; j < 4; j++)
+                if (SB_MAP[i][j][0] == quad) {
+                  const int bi = SB_MAP[i][j][1], fx = sbx * 4 + j, fy = sby * 4 + i;
+                  const uint8_t *blk = pp[0].origin + (ptrdiff_t)(fy * 8) * pp[0].stride + fx * 8;
+                  int dc;
+                  unsigned x, satd;
+                  satd = orc_enc_frag_intra_satd(&dc, blk, pp[0].stride);
+                  intra_satd[mbi * 12 + bi] = satd;
+                  luma[mbi] += (uint32_t)dc;
+                  activity[mbi * 4 + bi] = block_activity(blk, pp[0].stride, &x);
+                  {
+                    uint32_t act = (11 * satd >> 8) * satd;                 /* analyze.c:1244 */
+                    if (act < 8u << 12 && act > 5u << 12) act = 5u << 12;
+                    activity_fast[mbi * 4 + bi] = act;
+                  }
+                }
+            /* the chroma blocks through mb_maps (state.c:200-290) */
+            for (mapii = 4; mapii < MAP_NIDXS[pixel_fmt]; mapii++) {
+              const int mapi = MAP_IDXS[pixel_fmt][mapii], p = mapi >> 2, bi = mapi & 3;
+              const int ci = bi >> 1, cj = bi & 1;                           /* mb_map[p][i << 1 | j] */
+              const int fx = (mbx >> hdec) + cj, fy = (mby >> vdec) + ci;
+              int dc;
+              intra_satd[mbi * 12 + mapii] =
+                  orc_enc_frag_intra_satd(&dc, pp[p].origin + (ptrdiff_t)(fy * 8) * pp[p].stride + fx * 8, pp[p].stride);
+            }
+          }
+  for (pli = 0; pli < 3; pli++) free(pp[pli].buf);
+  return rc;
+}

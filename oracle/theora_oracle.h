@@ -169,6 +169,11 @@ void orc_enc_metric_batch(int op, uint32_t *out, int32_t *dc_out, const uint8_t 
                           const int32_t *ref_offs, const int32_t *ref2_offs, unsigned thresh,
                           ptrdiff_t n);
 
+/* oc_mb_intra_satd / oc_mb_activity / oc_mb_activity_fast (analyze.c:1360-1403, 1152-1251) for every macro block of a frame,
+   in the reference's macro-block numbering; planes unpadded, bitstream row order.  Returns 0, or -1 when out of memory. */
+int orc_mb_cost_maps(const uint8_t *const planes[3], const int strides[3], int frame_width, int frame_height, int pixel_fmt,
+                     uint32_t *intra_satd, uint32_t *luma, uint32_t *activity, uint32_t *activity_fast);
+
 extern const uint8_t ORC_FZIG_ZAG[128];   /* internal.c:27 */
 
 #ifdef __cplusplus

@@ -283,3 +283,39 @@ def test_postprocessing_is_independent_of_the_mcu_chunking(w, h, fmt):
         got, var = st.postprocess(oracle.FRAME_PREV, 7, 1, dc_qis, frag_qi, dcs, shm)
         assert any(not np.array_equal(got[p], st.get_plane(oracle.FRAME_PREV, p)) for p in range(3))
         st.close()
+
+
+def test_mb_cost_maps_closed_forms():
+    """orc_mb_cost_maps against what analyze.c:1152-1251 gives in closed form: a flat picture (activity 0, SATD 0, luma = 64 x
+    4 x value), the macro-block numbering (a marked block lands in the entry sb_maps names), pure noise (texture: no edge
+    class), a hard straight edge (edge class: the 0.7 power shrinks the variance measure)."""
+    w, h = 64, 48
+    flat = [np.full((h, w), 77, np.uint8), np.full((h // 2, w // 2), 10, np.uint8), np.full((h // 2, w // 2), 200, np.uint8)]
+    satd, luma, act, fast = oracle.mb_cost_maps(flat, w, h, 0)
+    nsbw, nsbh = 2, 2
+    assert satd.shape == (4 * nsbw * nsbh, 12)
+    valid = luma > 0
+    assert valid.sum() == (w // 16) * (h // 16) and (luma[valid] == 77 * 256).all()
+    assert not satd.any() and not act.any() and not fast.any()
+    # block (row 1, column 2) of super block 0 is quadrant 3, entry 1 (state.c:134-139)
+    pic = [p.copy() for p in flat]
+    pic[0][8:16, 16:24] = np.arange(64, dtype=np.uint8).reshape(8, 8) * 3
+    satd2, _, act2, _ = oracle.mb_cost_maps(pic, w, h, 0)
+    changed = np.argwhere(satd2[:, :4] != 0)
+    assert (3, 1) in [tuple(c) for c in changed.tolist()]
+    # noise: large variance, no dominant direction -> the variance measure itself
+    rng = np.random.default_rng(5)
+    noise = [rng.integers(0, 256, (h, w)).astype(np.uint8), flat[1], flat[2]]
+    _, _, act3, _ = oracle.mb_cost_maps(noise, w, h, 0)
+    blk = noise[0][0:8, 0:8].astype(np.int64)
+    assert act3[0, 0] == 64 * (blk ** 2).sum() - blk.sum() ** 2
+    # a diagonal step edge: one direction carries more than 40 % of the edge energy -> classified as an edge, the 0.7 power
+    # shrinks the variance measure by an order of magnitude; an axis-aligned step sits at EXACTLY 40 % (4 : 3 : 3 : 0) and the
+    # reference's strict comparison (analyze.c:1226) leaves it alone
+    yy, xx = np.mgrid[0:h, 0:w]
+    for img, is_edge in ((np.where((xx + yy) % 16 < 8, 20, 230), True), (np.where(yy % 8 < 4, 20, 230), False)):
+        edge = [img.astype(np.uint8), flat[1], flat[2]]
+        _, _, act4, _ = oracle.mb_cost_maps(edge, w, h, 0)
+        b = edge[0][0:8, 0:8].astype(np.int64)
+        raw = 64 * (b ** 2).sum() - b.sum() ** 2
+        assert (0 < act4[0, 0] < raw // 4) if is_edge else (act4[0, 0] == raw)

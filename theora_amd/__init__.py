@@ -317,6 +317,24 @@ def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None,
     return out, dc
 
 
+def enc_mb_cost_maps(planes, frame_width, frame_height, pixel_fmt):
+    """thip_enc_mb_cost_maps over three device planes ([H, stride] uint8 tensors, bitstream row order).  Returns
+    (intra_satd [nmbs,12], luma [nmbs], activity [nmbs,4], activity_fast [nmbs,4]) as int32 device tensors."""
+    import torch
+    L = _lib.load()
+    nmbs = L.thip_enc_mb_count(frame_width, frame_height)
+    dev = planes[0].device
+    satd = torch.empty((nmbs, 12), dtype=torch.int32, device=dev)
+    luma = torch.empty(nmbs, dtype=torch.int32, device=dev)
+    act = torch.empty((nmbs, 4), dtype=torch.int32, device=dev)
+    fast = torch.empty((nmbs, 4), dtype=torch.int32, device=dev)
+    ptrs = (C.c_void_p * 3)(*[_ptr(p) for p in planes])
+    strides = (C.c_int32 * 3)(*[int(p.stride(0)) for p in planes])
+    _lib.check(L.thip_enc_mb_cost_maps(ptrs, strides, frame_width, frame_height, pixel_fmt, _ptr(satd), _ptr(luma), _ptr(act),
+                                       _ptr(fast)), "enc_mb_cost_maps")
+    return satd, luma, act, fast
+
+
 def enc_metric_sites_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs, sites):
     """thip_enc_frag_metric_sites_batch: every block against the candidate positions `sites` = [(dx, dy), ...] around its
     reference position.  Returns (values, dc), both [len(sites), nblocks] (candidate-major); dc is None for "sad"."""

@@ -14,6 +14,7 @@
 #include "../../include/theora_hip.h"
 #include "thip_device.h"
 #include "thip_enc.h"
+#include "thip_costmaps.h"
 
 using namespace thip;
 
@@ -464,6 +465,48 @@ int thip_frag_copy_list_batch(uint8_t *dst_frame, const uint8_t *src_frame, int 
   if (nfragis == 0) return THIP_OK;
   hipLaunchKernelGGL(k_frag_copy_list, grid_for(nfragis), dim3(256), 0, g_batch_stream, dst_frame, src_frame, ystride,
                      fragis, nfragis, frag_buf_offs);
+  HIP_TRY(hipGetLastError());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
+  return THIP_OK;
+}
+
+int thip_enc_mb_count(int frame_width, int frame_height) {
+  if (frame_width <= 0 || frame_height <= 0 || (frame_width & 15) || (frame_height & 15)) return THIP_EINVAL;
+  return 4 * (((frame_width >> 3) + 3) >> 2) * (((frame_height >> 3) + 3) >> 2);
+}
+
+int thip_enc_mb_cost_maps(const uint8_t *const planes[3], const int32_t strides[3], int frame_width, int frame_height, int pixel_fmt,
+                          uint32_t *intra_satd, uint32_t *luma, uint32_t *activity, uint32_t *activity_fast) {
+  if (!planes || !strides || !planes[0] || !planes[1] || !planes[2]) return THIP_EFAULT;
+  if (frame_width <= 0 || frame_height <= 0 || (frame_width & 15) || (frame_height & 15) || frame_width >= 0x8000 || frame_height >= 0x8000 ||
+      pixel_fmt < 0 || pixel_fmt > 3 || pixel_fmt == 1)
+    return THIP_EINVAL;
+  CostMapK K;
+  memset(&K, 0, sizeof(K));
+  K.fmt = pixel_fmt;
+  K.hdec = !(pixel_fmt & 1);
+  K.vdec = !(pixel_fmt & 2);
+  for (int p = 0; p < 3; p++) {
+    K.plane[p] = planes[p];
+    K.stride[p] = strides[p];
+    K.nh[p] = (frame_width >> 3) >> (p ? K.hdec : 0);
+    K.nv[p] = (frame_height >> 3) >> (p ? K.vdec : 0);
+    if (strides[p] < K.nh[p] * 8) return THIP_EINVAL;
+  }
+  K.nsbw = (K.nh[0] + 3) >> 2;
+  K.n_luma = K.nh[0] * K.nv[0];
+  K.n_all = K.n_luma + (intra_satd ? 2 * K.nh[1] * K.nv[1] : 0);
+  K.intra_satd = intra_satd;
+  K.luma = luma;
+  K.activity = activity;
+  K.activity_fast = activity_fast;
+  const size_t nmbs = (size_t)thip_enc_mb_count(frame_width, frame_height);
+  // macro blocks outside the frame stay zero, and the luma sums are added into
+  if (intra_satd) HIP_TRY(hipMemsetAsync(intra_satd, 0, nmbs * 12 * sizeof(uint32_t), g_batch_stream));
+  if (luma) HIP_TRY(hipMemsetAsync(luma, 0, nmbs * sizeof(uint32_t), g_batch_stream));
+  if (activity) HIP_TRY(hipMemsetAsync(activity, 0, nmbs * 4 * sizeof(uint32_t), g_batch_stream));
+  if (activity_fast) HIP_TRY(hipMemsetAsync(activity_fast, 0, nmbs * 4 * sizeof(uint32_t), g_batch_stream));
+  hipLaunchKernelGGL(k_enc_cost_maps, grid_for(K.n_all), dim3(256), 0, g_batch_stream, K);
   HIP_TRY(hipGetLastError());
   if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
