@@ -481,6 +481,9 @@ const char *thip_version_string(void);
  * a device is first used.  thip_option_name enumerates the table (NULL past its end) with a one-line
  * description of each entry:
  *   fuse         3 (default) k_recon_lf: reconstruction + loop filter in one pass; 0 the two passes
+ *   sb_tiles     launches of fewer tiles than this (all their streams together; default 600: a 720p frame has 345, a 1080p frame 782 and
+ *                gains nothing) take k_recon_lf_sb -- one
+ *                super block per wave, four lanes per block -- instead of k_recon_lf's one tile per wave (0: never)
  *   lanes        library-owned HIP streams per device for thip_decode_frames (default 2)
  *   ctx_lanes    HIP streams shared by the enqueue-fed states, i.e. th_decode_* contexts (default 8; 0 = the lanes)
  *   chunk        streams per kernel launch (default THIP_MAX_BATCH)

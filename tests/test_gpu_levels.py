@@ -119,3 +119,19 @@ def test_levels_form_argument_checks(hip):
     assert call(bad) == hip._lib.EINVAL
     assert gst.ref_idx(hip.FRAME_SELF) == -1          # nothing was decoded
     assert call(desc) == 0
+
+
+@pytest.mark.parametrize("sb_tiles", [0, 1 << 30])
+@pytest.mark.parametrize("form", ["levels", "dequant16"])
+@pytest.mark.parametrize("w,h,fmt,content", [(176, 144, PF_420, "mixed"), (80, 112, PF_422, "dense"), (336, 48, PF_444, "mixed"),
+                                             (16, 16, PF_420, "mixed"), (1280, 720, PF_420, "smooth"), (208, 272, PF_420, "dense")])
+def test_one_tile_per_wave_and_one_super_block_per_wave(hip, sb_tiles, form, w, h, fmt, content):
+    """k_recon_lf (a tile of 64 blocks per wave) and k_recon_lf_sb (a super block per wave, four lanes per block: the kernel of
+    launches that leave the chip empty, option sb_tiles) on the same sequences: ragged super blocks, every pixel format, both
+    coefficient forms, wide tiles, band boundaries in every plane."""
+    hip._lib.load().thip_set_option(b"sb_tiles", sb_tiles)
+    try:
+        rep = util.run_sequence(hip, w, h, fmt, nframes=7, content=content, seed=w + 3 * h + fmt, kf_interval=4, form=form)
+    finally:
+        hip._lib.load().thip_set_option(b"sb_tiles", 600)
+    assert not rep, rep[:3]

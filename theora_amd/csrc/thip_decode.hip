@@ -80,6 +80,7 @@ Option g_options[] = {
     {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
     {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
+    {"sb_tiles", 600, "k_recon_lf_sb (one super block per wave, four lanes per block) instead of k_recon_lf for launches of fewer tiles than this (0: never)"},
     {"faults_recovered", 0, "(counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf had run out"},
 };
 constexpr int kNumOptions = (int)(sizeof(g_options) / sizeof(g_options[0]));
@@ -132,6 +133,7 @@ extern "C" const char *thip_option_name(int index, const char **help) {
 
 #include "thip_kernels.h"
 #include "thip_fused.h"
+#include "thip_fused_sb.h"
 #include "thip_dc.h"
 #include "thip_postproc.h"
 #include "thip_tokens.h"
@@ -197,6 +199,8 @@ struct thip_state {
   int redo_owned;       // set by the callers whose descriptors point into the state's own buffers, around their thip_decode_frames call
   uint8_t *d_edge;      // device, k_recon_lf: kTfRec bytes per tile (the tiles' edges for their neighbours)
   uint32_t edge_epoch;  // serial number of the last k_recon_lf launch for this state (0 = never: the records are zero); 12 bits
+  uint8_t *d_edge_sb;   // ... and k_recon_lf_sb's: a record per super block (a buffer and a serial number of its own: a tag vouches for
+  uint32_t edge_epoch_sb;   //  the bytes in front of it only while every launch that uses the buffer rewrites every unit of it)
   int device_dc, enq_device_dc;
   int16_t *h_dc, *d_dc_in;   // enqueue path: token DC values staged per fragment (pinned) and their device copy
   uint8_t *h_flags, *d_flags;   // ... and the fragments' coded | refi << 1 in fragment-index order (the staged command
@@ -642,6 +646,7 @@ void thip_state_free(thip_state *st) {
   if (st->d_dc_rowhas) (void)hipFree(st->d_dc_rowhas);
   if (st->ev_order) (void)hipEventDestroy(st->ev_order);
   if (st->d_edge) (void)hipFree(st->d_edge);
+  if (st->d_edge_sb) (void)hipFree(st->d_edge_sb);
   if (st->h_tl) (void)hipHostFree(st->h_tl);
   if (st->d_tl) (void)hipFree(st->d_tl);
   if (st->d_tl_tmp) (void)hipFree(st->d_tl_tmp);
@@ -1123,13 +1128,27 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
   // always take the two passes, whose first kernel knows how to skip whole tiles.
   const int fuse = two_passes ? 0 : THIP_OPT("fuse");
   if (fuse == 3 && any_lf && !any_skip && xcd_round_robin(states[live_state[0]]->device)) {
-    // one wave per tile, reconstruction and every filter cell in one pass (thip_fused.h)
-    int longest = 1;
+    // one wave per tile, reconstruction and every filter cell in one pass (thip_fused.h) -- or, for a launch that would leave
+    // the chip empty, one wave per super block (thip_fused_sb.h)
+    int longest = 1, total_tiles = 0;
+    for (int j = 0; j < nlive; j++) total_tiles += B.s[j].tile_end[2];
+    const int sb_tiles = THIP_OPT("sb_tiles");
+    const bool small = sb_tiles > 0 && total_tiles < sb_tiles;
     for (int j = 0; j < nlive; j++) {
       thip_state *st = states[live_state[j]];
       StreamK &K = B.s[j];
       if (st->tiles.tiles_y[0] > 4096) return THIP_EIMPL;
       longest = std::max(longest, fill_bands(K, st));
+      if (small) {
+        if (!st->d_edge_sb) {
+          HIP_TRY(hipMalloc((void **)&st->d_edge_sb, (size_t)4 * K.tile_end[2] * Tf4::kRec));
+          HIP_TRY(hipMemsetAsync(st->d_edge_sb, 0, (size_t)4 * K.tile_end[2] * Tf4::kRec, s));
+        }
+        K.edge = st->d_edge_sb;
+        st->edge_epoch_sb = st->edge_epoch_sb % 4095u + 1u;
+        K.epoch = st->edge_epoch_sb;
+        continue;
+      }
       if (!st->d_edge) {
         HIP_TRY(hipMalloc((void **)&st->d_edge, (size_t)K.tile_end[2] * kTfRec));
         HIP_TRY(hipMemsetAsync(st->d_edge, 0, (size_t)K.tile_end[2] * kTfRec, s));
@@ -1139,7 +1158,10 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       K.epoch = st->edge_epoch;
     }
     ScopedTimer t(s, THIP_KERNEL_RECON);
-    if (levels) hipLaunchKernelGGL(k_recon_lf<true>, dim3(8 * longest, nlive), dim3(64), 0, s, B);
+    if (small) {
+      if (levels) hipLaunchKernelGGL(k_recon_lf_sb<true>, dim3(8 * longest, nlive), dim3(256), 0, s, B);
+      else hipLaunchKernelGGL(k_recon_lf_sb<false>, dim3(8 * longest, nlive), dim3(256), 0, s, B);
+    } else if (levels) hipLaunchKernelGGL(k_recon_lf<true>, dim3(8 * longest, nlive), dim3(64), 0, s, B);
     else hipLaunchKernelGGL(k_recon_lf<false>, dim3(8 * longest, nlive), dim3(64), 0, s, B);
   } else {
     {

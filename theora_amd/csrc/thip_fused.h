@@ -48,11 +48,26 @@
 #ifndef THIP_TF_PITCH
 #define THIP_TF_PITCH 144
 #endif
-constexpr int kTfPitch = THIP_TF_PITCH;                  // LDS image row: 8-byte left margin (4 used), 128 pixels, 8 spare
-constexpr int kTfX0 = 8;                       // byte offset of pixel column 0 in an image row
-constexpr int kTfImgRows = 40;                 // pixel rows -4 .. 35 (of the upper neighbour's rows only -2, -1 are filled, of the lower one's 32, 33)
-constexpr int kTfFlagOff = kTfImgRows * kTfPitch;   // coded flags: 6 rows (block rows -1..4) of kTfFlagPitch bytes
-constexpr int kTfFlagPitch = 20;               // [0] block column -1, [1..16] the tile, [17] column 16
+// The geometry of a tile's LDS image and of its edge record, for tiles of BW x 4 blocks: BW = 16 is k_recon_lf's tile (four
+// super blocks, one block per lane), BW = 4 k_recon_lf_sb's (one super block, four lanes per block: thip_fused_sb.h).
+template <int BW>
+struct TfGeom {
+  static constexpr int kBW = BW;
+  static constexpr int kPitch = BW == 16 ? THIP_TF_PITCH : 8 * BW + 16;   // LDS image row: 8-byte left margin (4 used), 8 BW pixels, 8 spare
+  static constexpr int kX0 = 8;                       // byte offset of pixel column 0 in an image row
+  static constexpr int kImgRows = 40;                 // pixel rows -4 .. 35 (of the upper neighbour's rows only -2, -1 are filled, of the lower one's 32, 33)
+  static constexpr int kFlagOff = kImgRows * kPitch;  // coded flags: 6 rows (block rows -1..4) of kFlagPitch bytes
+  static constexpr int kFlagPitch = BW + 4;           // [0] block column -1, [1..BW] the tile, [BW + 1] column BW
+  static constexpr int kRowDwords = 2 * BW;           // dwords of one pixel row of the tile
+  // a tile's record in StreamK::edge: units of 16 bytes = 3 dwords of pixels + tag
+  static constexpr int kBotUnits = (2 * kRowDwords + 2) / 3, kRightUnits = 11;   // two pixel rows; four pixel columns x 32 rows = 128 bytes
+  static constexpr int kBot = 0;                                  // pixel rows 30, 31 (row-major), tag flags: right4 << 16 | bottom BW
+  static constexpr int kRight = kBotUnits * 16;                   // pixel columns 8 BW - 4 .. 8 BW - 1 (32 rows x 4 bytes), same tag flags
+  static constexpr int kTop = (kBotUnits + kRightUnits) * 16;     // pixel rows 0, 1 (tiles that open a band only), tag flags: top BW
+  static constexpr int kRec = ((2 * kBotUnits + kRightUnits) * 16 + 127) & ~127;
+};
+typedef TfGeom<16> Tf16;
+constexpr int kTfPitch = Tf16::kPitch, kTfX0 = Tf16::kX0, kTfImgRows = Tf16::kImgRows, kTfFlagOff = Tf16::kFlagOff, kTfFlagPitch = Tf16::kFlagPitch;
 // The wave's LDS: 7 KB, not 8.  This chip hands LDS out in 1280-byte granules, so 8 KB costs 8960 bytes and a CU holds 18 such
 // waves; 7 KB costs 7680 and it holds the 20 the registers allow.  Seven of a tile's eight 1-KB int16 coefficient pieces are staged
 // here (LDS-DMA), the eighth stays in registers; in the levels form the four 1-KB pieces of int8 units (six of the eight of a
@@ -60,13 +75,10 @@ constexpr int kTfFlagPitch = 20;               // [0] block column -1, [1..16] t
 constexpr int kTfLds = 7168;
 static_assert(kTfFlagOff + 6 * kTfFlagPitch <= kTfLds, "the image lives in the wave's staging area");
 static_assert(kLdsTabOff + 768 <= kTfLds && kLdsTabOff >= 6 * 1024, "the tables sit behind six staged pieces");
-// a tile's record in StreamK::edge: units of 16 bytes = 3 dwords of pixels + tag
 constexpr int kTfUnit = 16;
-constexpr int kTfBotUnits = 22, kTfRightUnits = 11;      // 256 and 128 bytes of pixels
-constexpr int kTfBot = 0;                      // pixel rows 30, 31 (2 x 128 bytes, row-major), tag flags: right4 << 16 | bottom16
-constexpr int kTfRight = 352;                  // pixel columns 124..127 (32 rows x 4 bytes), same tag flags
-constexpr int kTfTop = 528;                    // pixel rows 0, 1 (tiles that open a band only), tag flags: top16
-constexpr int kTfRec = 896;
+constexpr int kTfBotUnits = Tf16::kBotUnits, kTfRightUnits = Tf16::kRightUnits;
+constexpr int kTfBot = Tf16::kBot, kTfRight = Tf16::kRight, kTfTop = Tf16::kTop, kTfRec = Tf16::kRec;
+static_assert(kTfBotUnits == 22 && kTfRight == 352 && kTfTop == 528 && kTfRec == 896, "the record layout of rounds 3 and 4");
 
 // A unit goes out with one 16-byte store (through to memory where the reader sits on another XCD) and comes in with one
 // 16-byte load that bypasses the CU's L1.  Inline assembly: there is no 16-byte atomic to ask the compiler for, and the
@@ -88,28 +100,31 @@ __device__ __forceinline__ uint4 tf_load_unit(const uint8_t *p) {
 
 // Where dword `idx` of a 4 x 128-byte row block / of a 32-row column lies in the LDS image (byte offsets), given the image
 // row of its first row.
-__device__ __forceinline__ int tf_rows_at(int idx, int ri0) { return (ri0 + (idx >> 5)) * kTfPitch + kTfX0 + (idx & 31) * 4; }
-__device__ __forceinline__ int tf_col_at(int idx, int ri0, int x) { return (ri0 + idx) * kTfPitch + kTfX0 + x; }
+template <class G>
+__device__ __forceinline__ int tf_rows_at(int idx, int ri0) { return (ri0 + idx / G::kRowDwords) * G::kPitch + G::kX0 + (idx % G::kRowDwords) * 4; }
+template <class G>
+__device__ __forceinline__ int tf_col_at(int idx, int ri0, int x) { return (ri0 + idx) * G::kPitch + G::kX0 + x; }
 
 // Lanes 0..21 assemble the units of the two pixel rows that start at image row ri0, lanes 22..32 (when `right`) the units of
-// the column at pixel x = 124; everything out of the LDS image.
+// the column at pixel x = 124 (tiles of 16 blocks across; 0..5, 6..16 and x = 28 for 4); everything out of the LDS image.
+template <class G>
 __device__ __forceinline__ void tf_publish_units(const uint8_t *lds, uint8_t *rec_rows, uint8_t *rec_right, int ri0, bool right, uint32_t tag,
                                                  int lane, bool through) {
   uint32_t d[3] = {0u, 0u, 0u};
   uint8_t *dst = nullptr;
-  if (lane < kTfBotUnits) {
+  if (lane < G::kBotUnits) {
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int idx = 3 * lane + j;
-      if (idx < 64) d[j] = *reinterpret_cast<const uint32_t *>(lds + tf_rows_at(idx, ri0));
+      if (idx < 2 * G::kRowDwords) d[j] = *reinterpret_cast<const uint32_t *>(lds + tf_rows_at<G>(idx, ri0));
     }
     dst = rec_rows + lane * kTfUnit;
-  } else if (right && lane < kTfBotUnits + kTfRightUnits) {
-    const int v = lane - kTfBotUnits;
+  } else if (right && lane < G::kBotUnits + G::kRightUnits) {
+    const int v = lane - G::kBotUnits;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int idx = 3 * v + j;
-      if (idx < 32) d[j] = *reinterpret_cast<const uint32_t *>(lds + tf_col_at(idx, 4, 124));
+      if (idx < 32) d[j] = *reinterpret_cast<const uint32_t *>(lds + tf_col_at<G>(idx, 4, 8 * G::kBW - 4));
     }
     dst = rec_right + v * kTfUnit;
   }
@@ -140,9 +155,11 @@ __device__ __forceinline__ uint4 tf_fetch_unit(const uint8_t *src, uint32_t ep, 
 // operations; `ext` cells (cell row 3) own the two rows below them as well, pixel rows 28 and 29 of the tile: nothing touches
 // those but the vertical edge of the cell's lower half (Vhi, one more row pair of the same operation), so they need not wait
 // for the tile below.
+template <class G>
 __device__ __forceinline__ void tf_cell(const uint8_t *lds, uint8_t *plane, int stride, int nh, int nv, int t, int sby, int kx, int m,
                                         bool active, int L2, int fy0, int fy1, int r_lo, int r_hi, uint32_t opmask, bool ext) {
-  const int k = 16 * t + kx, mm = 4 * sby + m;
+  constexpr int kTfPitch = G::kPitch, kTfX0 = G::kX0, kTfFlagOff = G::kFlagOff, kTfFlagPitch = G::kFlagPitch;
+  const int k = G::kBW * t + kx, mm = 4 * sby + m;
   active = active && k <= nh && mm <= nv;
   CellPix C;
   const uint8_t *img = lds + (8 * m) * kTfPitch + kTfX0 + 8 * kx - 4;   // image row index = pixel row + 4
@@ -370,8 +387,8 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     const bool fb = (lane < 20 || (lane >= 32 && lane < 48)) && lds[kTfFlagOff + fi] != 0;
     const uint64_t fm = __ballot(fb);
     const uint32_t tag_ep = (poison && u == 1) ? 0u : ep;   // (serial numbers are never 0)
-    tf_publish_units(lds, myrec + kTfBot, myrec + kTfRight, 34, true, tag_ep << 20 | (uint32_t)(fm & 0xFFFFFu), lane, xb_up);
-    if (xb_up) tf_publish_units(lds, myrec + kTfTop, nullptr, 4, false, tag_ep << 20 | ((uint32_t)(fm >> 32) & 0xFFFFu), lane, true);
+    tf_publish_units<Tf16>(lds, myrec + kTfBot, myrec + kTfRight, 34, true, tag_ep << 20 | (uint32_t)(fm & 0xFFFFFu), lane, xb_up);
+    if (xb_up) tf_publish_units<Tf16>(lds, myrec + kTfTop, nullptr, 4, false, tag_ep << 20 | ((uint32_t)(fm >> 32) & 0xFFFFu), lane, true);
     THIP_TR(tr, 3);   // image in LDS, edges on their way
     THIP_TR(tr, 4);
   }
@@ -394,17 +411,17 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const int idx = 3 * lane + j;
-        if (idx < 64) *reinterpret_cast<uint32_t *>(lds + tf_rows_at(idx, 2)) = d[j];
+        if (idx < 64) *reinterpret_cast<uint32_t *>(lds + tf_rows_at<Tf16>(idx, 2)) = d[j];
       }
     } else if (lane < kTfBotUnits + kTfRightUnits) {
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const int idx = 3 * (lane - kTfBotUnits) + j;
-        if (idx < 32) *reinterpret_cast<uint32_t *>(lds + tf_col_at(idx, 4, -4)) = d[j];
+        if (idx < 32) *reinterpret_cast<uint32_t *>(lds + tf_col_at<Tf16>(idx, 4, -4)) = d[j];
       }
     } else if (lane == kTfBotUnits + kTfRightUnits) {
 #pragma unroll
-      for (int j = 0; j < 2; j++) *reinterpret_cast<uint32_t *>(lds + tf_col_at(2 + j, 0, -4)) = d[j];   // dwords 30, 31
+      for (int j = 0; j < 2; j++) *reinterpret_cast<uint32_t *>(lds + tf_col_at<Tf16>(2 + j, 0, -4)) = d[j];   // dwords 30, 31
     }
     // their coded flags (the tags of the first unit of each record): block row -1 (columns 0..15), block column -1 (rows 0..3),
     // block (-1, -1)
@@ -428,7 +445,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   const uint32_t top_mask = xb_up ? 96u : 0xFFu;
   {
     const int m = lane >> 4;
-    tf_cell(lds, R.self, R.stride, nh, nv, t, sby, lane & 15, m, true, L2, fy0, fy1, m == 0 ? top_lo : 0, 8, m == 0 ? top_mask : 0xFFu, m == 3);
+    tf_cell<Tf16>(lds, R.self, R.stride, nh, nv, t, sby, lane & 15, m, true, L2, fy0, fy1, m == 0 ? top_lo : 0, 8, m == 0 ? top_mask : 0xFFu, m == 3);
   }
   THIP_TR(tr, 7);   // cells filtered, stores issued
 
@@ -450,11 +467,11 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
 #pragma unroll
         for (int j = 0; j < 3; j++) {
           const int idx = 3 * lane + j;
-          if (idx < 64) *reinterpret_cast<uint32_t *>(lds + tf_rows_at(idx, 36)) = d[j];
+          if (idx < 64) *reinterpret_cast<uint32_t *>(lds + tf_rows_at<Tf16>(idx, 36)) = d[j];
         }
       } else if (lane == kTfBotUnits) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) *reinterpret_cast<uint32_t *>(lds + tf_col_at(j, 36, -4)) = d[j];
+        for (int j = 0; j < 2; j++) *reinterpret_cast<uint32_t *>(lds + tf_col_at<Tf16>(j, 36, -4)) = d[j];
       }
       // block row 4: the lower tile's first block row (its top units' tags), the lower-left tile's block (15, 0)
       const uint32_t w_dn = (uint32_t)__builtin_amdgcn_readlane((int)un.w, 0);
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     const int kx = rowl ? lane : 16, m = rowl ? 4 : (lane - 32) & 3;
     const bool act = rowl ? (extra_row && (lane < 16 || extra_col)) : (coll && extra_col);
     // row cells: pixel rows 30, 31 and, of another band's tile below, its rows 0 and 1 (28 and 29 went out with cell row 3)
-    tf_cell(lds, R.self, R.stride, nh, nv, t, sby, kx, m, act, L2, fy0, fy1, rowl ? 2 : (m == 0 ? top_lo : 0), rowl ? (xb_dn ? 6 : 8) : 8,
+    tf_cell<Tf16>(lds, R.self, R.stride, nh, nv, t, sby, kx, m, act, L2, fy0, fy1, rowl ? 2 : (m == 0 ? top_lo : 0), rowl ? (xb_dn ? 6 : 8) : 8,
             (!rowl && m == 0) ? top_mask : 0xFFu, !rowl && m == 3);
   }
   THIP_TR(tr, 8);

@@ -468,10 +468,10 @@ __device__ __forceinline__ uint32_t table_of(uint32_t flags) {
 }
 // The plane's six tables into the wave's LDS (LDS-DMA, lanes 0..47 one 16-byte piece each).  Issued BEFORE the command words are
 // requested: loads come back in order, so whoever has its command word also has the tables.
-__device__ __forceinline__ void tables_to_lds(const uint4 *dequant, int pli, int lane, uint4 *lds_wave) {
+__device__ __forceinline__ void tables_to_lds(const uint4 *dequant, int pli, int lane, uint4 *lds_wave, int tab16 = kLdsTabOff / 16) {
   if (lane < 48)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dequant + pli * 48 + lane),
-                                     (__attribute__((address_space(3))) void *)(lds_wave + kLdsTabOff / 16), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)(lds_wave + tab16), 16, 0, 0);
 }
 
 // ---- k_recon in three parts, so that the residual can be computed by ALL lanes of the wave ------
@@ -648,9 +648,11 @@ __device__ __forceinline__ void residual_shared_load(const int4 *coeffs, const C
 
 // COMPACT: the results go where the exchange was (4 KB of LDS instead of 8 for LPB = 2): every lane
 // collects all its column pairs first, the wave's LDS traffic settles, then results are written.
-template <int LPB, bool COMPACT = false>
+// OUT = 32: the owner lane collects its whole block (Y[32]); OUT = 8 (k_recon_lf_sb, four lanes per block of the PICTURE too):
+// lane 4b + p collects rows 2p, 2p+1 of block b, whose owner rank is `prefix` (Y[8]).  tab16: where the tables are (levels form).
+template <int LPB, bool COMPACT = false, int OUT = 32>
 __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], const CoefForm &F, uint32_t *lds, uint32_t *meta, int lane,
-                                                const ReconLane &L, uint32_t prefix, uint32_t Y[32]) {
+                                                const ReconLane &L, uint32_t prefix, uint32_t *Y, int tab16 = kLdsTabOff / 16) {
   constexpr int NP = 4 / LPB;                        // row pairs (and column pairs) per lane
   const int last_zzi = (int)((L.flags >> THIP_INFO_LAST_ZZI_SHIFT) & 0x7Fu);
   if (L.has_coeff) {
@@ -663,7 +665,7 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], const 
   const int lz = (int)(mg & 0x7Fu);
   const uint32_t dcq_g = j == 0 ? mg >> 16 : 1u;    // the lane holding row pair 0 dequantises x[0][0]
   const bool c3 = lz <= 3, c10 = lz <= 10;
-  const uint4 *tab = reinterpret_cast<const uint4 *>(lds) + kLdsTabOff / 16 + ((mg >> 8) & 7u) * 8;   // (levels form)
+  const uint4 *tab = reinterpret_cast<const uint4 *>(lds) + tab16 + min((mg >> 8) & 7u, 5u) * 8;   // (levels form; surplus groups read garbage owner words)
   pk16 Rr[NP][8];
 #pragma unroll
   for (int n = 0; n < NP; n++) {
@@ -727,9 +729,9 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], const 
     for (int r = 0; r < 8; r++) res[g * 32 + r * 4 + cp] = as_u32(pk_descale(Qc[n][r]));   // Y[r*4+k] layout of the owner
   }
   if (L.has_coeff) {
-    const uint4 *y4 = reinterpret_cast<const uint4 *>(res + prefix * 32);
+    const uint4 *y4 = reinterpret_cast<const uint4 *>(res + prefix * 32) + (OUT == 8 ? 2 * (lane & 3) : 0);
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < OUT / 4; q++) {
       const uint4 w = y4[q];
       Y[q * 4 + 0] = w.x;
       Y[q * 4 + 1] = w.y;

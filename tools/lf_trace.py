@@ -57,7 +57,7 @@ def main():
         plans[0 if i == 0 else 1 + i % 3].submit(None)
     theora_amd.synchronize()
     L = _lib.load()
-    nrec = S * 8 * (geom.ntiles // 8 + 64)
+    nrec = 4 * S * 8 * (geom.ntiles // 8 + 64)      # (k_recon_lf_sb: four waves per work group)
     buf = torch.zeros((nrec, 12), dtype=torch.int64, device="cuda")
     L.thip_debug_trace_buffer.argtypes = [ctypes.c_void_p]
     L.thip_debug_trace_buffer(ctypes.c_void_p(buf.data_ptr()))
