@@ -290,6 +290,15 @@ def main_enc():
     tc = time.perf_counter() - t0
     assert np.array_equal(gq.cpu().numpy().reshape(-1, 64)[:ncpu], wq) and np.array_equal(gnz.cpu().numpy()[:ncpu], wnz)
     results.append(dict(kernel="oc_enc_quantize", units=nblk, unit="blocks", seconds=t, bytes_per_unit=260, cpu_rate=ncpu / tc))
+    # --- both in one pass (thip_enc_fdct_quantize_batch), one frame and four frames of residuals per call ------------------------
+    for F in (1, 4):
+        resF = np.tile(resid, (F, 1)) if F > 1 else resid
+        d_resF = torch.from_numpy(np.ascontiguousarray(resF)).cuda()
+        t = timed(lambda: theora_amd.enc_fdct_quantize_batch(d_resF, d_dq))
+        fq, fnz = theora_amd.enc_fdct_quantize_batch(d_resF, d_dq)
+        assert np.array_equal(fq.cpu().numpy().reshape(-1, 64)[:ncpu], wq) and np.array_equal(fnz.cpu().numpy()[:ncpu], wnz)
+        results.append(dict(kernel="oc_enc_fdct8x8 + oc_enc_quantize in one pass (thip_enc_fdct_quantize_batch)%s" % (", %d frames per call" % F if F > 1 else ""),
+                            units=nblk * F, unit="blocks", seconds=t, bytes_per_unit=260, cpu_rate=float("nan")))
     # --- SAD / SATD / SATD2 ---------------------------------------------------------------------
     for op, bpu in (("sad", 132), ("satd", 136), ("satd2", 136 + 64), ("intra_satd", 72)):
         call = lambda: theora_amd.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)   # noqa: E731

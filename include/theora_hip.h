@@ -433,6 +433,14 @@ void thip_enc_opt_data(size_t *enquant_table_size, int *enquant_table_alignment)
 int thip_enc_quantize_tab_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t *dequant,
                                 const void *enquant, int64_t n);
 
+/* oc_enc_fdct8x8 and oc_enc_quantize on the same blocks in one pass (what the encoder does with every residual block: fdct.c:128,
+   then enquant.c:219): x = n blocks of 64 natural-order int16 (the residual), qdct / nonzero as thip_enc_quantize_tab_batch
+   returns them for the transform of x; dct (may be NULL) additionally receives the unquantised zig-zag-ordered coefficients,
+   as thip_enc_fdct8x8_batch would; enquant NULL: the reciprocals are derived on the device as in thip_enc_quantize_batch.
+   The coefficients do not travel to memory and back between the two steps, and there is one launch instead of two. */
+int thip_enc_fdct_quantize_batch(int16_t *qdct, int32_t *nonzero, int16_t *dct, const int16_t *x, const uint16_t *dequant,
+                                 const void *enquant, int64_t n);
+
 /* ------------------------------------------------------------------------------------
  * The single-block slots of oc_enc_opt_vtable (encint.h:292-326) with the reference's signatures:
  * HOST pointers, one 8x8 block per call, each bound to a one-element batch of the kernels above.

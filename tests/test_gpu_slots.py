@@ -523,3 +523,36 @@ def test_dc_unpredict_plane_slot(hip, w, h, fmt):
     d = torch.zeros(8, dtype=torch.int16, device="cuda")
     f = torch.zeros(8, dtype=torch.uint8, device="cuda")
     assert L.thip_dc_unpredict_plane(d.data_ptr(), f.data_ptr(), 1, 1025) == _lib.EIMPL
+
+
+def test_enc_fdct_quantize_in_one_pass(hip):
+    """thip_enc_fdct_quantize_batch == oc_enc_fdct8x8 followed by oc_enc_quantize (fdct.c:128, enquant.c:219) on the oracle, for
+    the residual range, beyond it, the extreme step sizes, with and without the coefficients handed back, with the reciprocals
+    derived on the device and with a table of thip_enc_enquant_table_init."""
+    from theora_amd import _lib
+    import torch
+    L = _lib.load()
+    rng = np.random.default_rng(21)
+    n = 6001          # (not a multiple of a wave)
+    for trial in range(4):
+        x = rng.integers(-255, 256, (n, 64)).astype(np.int16)
+        if trial == 2:
+            x[:500] = rng.integers(-8160, 8161, (500, 64))
+        dq = rng.integers(8, 4097, 64).astype(np.uint16) if trial else np.full(64, 8, np.uint16)
+        if trial == 3:
+            dq[:] = 4096
+        want_dct = oracle.fdct8x8_batch(x)
+        want_q, want_nz = oracle.quantize_batch(want_dct, dq)
+        q, nz, dct = hip.enc_fdct_quantize_batch(dev(x), dev(dq), want_dct=True)
+        assert np.array_equal(dct.cpu().numpy().reshape(-1, 64), want_dct), trial
+        assert np.array_equal(q.cpu().numpy().reshape(-1, 64), want_q) and np.array_equal(nz.cpu().numpy(), want_nz), trial
+        q2, nz2 = hip.enc_fdct_quantize_batch(dev(x), dev(dq))
+        assert torch.equal(q2, q) and torch.equal(nz2, nz)
+        enq = np.zeros(128, np.int16)
+        L.thip_enc_enquant_table_init(enq.ctypes.data, dq.ctypes.data)
+        q3 = torch.empty((n, 64), dtype=torch.int16, device="cuda")
+        nz3 = torch.empty(n, dtype=torch.int32, device="cuda")
+        assert L.thip_enc_fdct_quantize_batch(q3.data_ptr(), nz3.data_ptr(), None, dev(x).data_ptr(), dev(dq).data_ptr(), dev(enq).data_ptr(), n) == 0
+        assert torch.equal(q3.reshape(-1), q.reshape(-1)) and torch.equal(nz3, nz)
+    assert L.thip_enc_fdct_quantize_batch(None, None, None, None, None, None, 0) == 0
+    assert L.thip_enc_fdct_quantize_batch(None, None, None, None, None, None, 5) == _lib.EFAULT

@@ -306,6 +306,18 @@ def enc_quantize_batch(dct_dev, dequant_dev):
     return q, nz
 
 
+def enc_fdct_quantize_batch(x_dev, dequant_dev, want_dct=False):
+    """thip_enc_fdct_quantize_batch over [n,64] natural-order int16 residual blocks; returns (qdct, nonzero[, dct])."""
+    import torch
+    n = x_dev.numel() // 64
+    q = torch.empty_like(x_dev)
+    nz = torch.empty(n, dtype=torch.int32, device=x_dev.device)
+    dct = torch.empty_like(x_dev) if want_dct else None
+    _lib.check(_lib.load().thip_enc_fdct_quantize_batch(_ptr(q), _ptr(nz), _ptr(dct), _ptr(x_dev), _ptr(dequant_dev), None, n),
+               "enc_fdct_quantize_batch")
+    return (q, nz, dct) if want_dct else (q, nz)
+
+
 def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None, ref2_offs=None, thresh=0):
     import torch
     n = src_offs.numel()

@@ -116,6 +116,7 @@ SYMBOLS = [
     ("thip_enc1_frag_recon_inter", None, [_P, _P, _I, _P]),
     ("thip_enc1_fdct8x8", None, [_P, _P]),
     ("thip_enc_quantize_batch", _I, [_P, _P, _P, _P, _I64]),
+    ("thip_enc_fdct_quantize_batch", _I, [_P, _P, _P, _P, _P, _P, _I64]),
     ("thip_profile_enable", _I, [_I]),
     ("thip_profile_read", _I, [C.POINTER(_I64), C.POINTER(C.c_double)]),
     ("thip_profile_reset", _I, []),

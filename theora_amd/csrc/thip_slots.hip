@@ -329,6 +329,64 @@ __global__ __launch_bounds__(256) void k_enc_quantize(int16_t *qdct, int32_t *no
   if (i < n) nonzero[i] = nz;
 }
 
+// oc_enc_fdct8x8 followed by oc_enc_quantize on the same block (what oc_enc_block_transform_quantize does with every residual,
+// tokenize.c / analyze.c: fdct.c:128 then enquant.c:219) in ONE pass: the coefficients never travel to memory and back, one
+// launch instead of two.  dct_out (may be null) still receives the unquantised coefficients for callers that want both.
+__global__ __launch_bounds__(256) void k_enc_fdct_quantize(int16_t *qdct, int32_t *nonzero, int16_t *dct_out, const int16_t *x,
+                                                          const uint16_t *dequant, const int16_t *enquant, int64_t n) {
+  __shared__ int s_d[64], s_m[64], s_l[64];
+  if (threadIdx.x < 64) {
+    s_d[threadIdx.x] = (int)dequant[threadIdx.x];
+    if (enquant) {
+      s_m[threadIdx.x] = (int)enquant[2 * threadIdx.x];
+      s_l[threadIdx.x] = (int)enquant[2 * threadIdx.x + 1];
+    } else {   // oc_iquant_init (enquant.c:183-191)
+      const uint32_t d = (uint32_t)dequant[threadIdx.x] << 1;
+      const int l = 31 - __builtin_clz(d);
+      const uint32_t t = 1u + ((1u << (16 + l)) / d);
+      s_m[threadIdx.x] = (int)(int16_t)(t - 0x10000u);
+      s_l[threadIdx.x] = l;
+    }
+  }
+  __shared__ int4 s_x[4 * 512];
+  int4 *lds = s_x + (threadIdx.x >> 6) * 512;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int w[64];
+  load_block16_wave(w, x, i, n, lds);
+#pragma unroll
+  for (int k = 0; k < 64; k++) w[k] = sx16(w[k] << 2);        // fdct.c:136
+  w[0] = sx16(w[0] + (w[0] != 0) + 1);                        // fdct.c:139-141
+  w[1] = sx16(w[1] + 1);
+  w[8] = sx16(w[8] - 1);
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    fdct8(w[0 * 8 + c], w[1 * 8 + c], w[2 * 8 + c], w[3 * 8 + c], w[4 * 8 + c], w[5 * 8 + c], w[6 * 8 + c], w[7 * 8 + c]);
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    fdct8(w[r * 8 + 0], w[r * 8 + 1], w[r * 8 + 2], w[r * 8 + 3], w[r * 8 + 4], w[r * 8 + 5], w[r * 8 + 6], w[r * 8 + 7]);
+  int o[64];
+#pragma unroll
+  for (int k = 0; k < 64; k++) o[k] = sx16((w[kFZigZag[k]] + 2) >> 2);   // fdct.c:149
+  if (dct_out) store_block16_wave(dct_out, i, n, o, lds);
+  __syncthreads();   // the tables; and every wave is done with its LDS area's first use
+  int nz = 0;
+#pragma unroll
+  for (int z = 0; z < 64; z++) {   // enquant.c:228-245
+    int val = o[z] << 1;
+    const int d = s_d[z];
+    int q = 0;
+    if (abs(val) >= d) {
+      const int sg = val >> 31;
+      val += (d + sg) ^ sg;
+      q = sx16(((((s_m[z] * val) >> 16) + val) >> s_l[z]) - sg);
+      nz = z;
+    }
+    o[z] = q;
+  }
+  store_block16_wave(qdct, i, n, o, lds);
+  if (i < n) nonzero[i] = nz;
+}
+
 // The same with the reciprocals handed in: `enquant` is the 64-entry {m, l} table
 // thip_enc_enquant_table_init built once (oc_enc_enquant_table_init, enquant.c:194), as the
 // reference's quantize slot receives it (encint.h:319-320), instead of being re-derived per launch.
@@ -413,6 +471,17 @@ void thip_enc_enquant_table_fixup(void *enquant[3][3][2], int nqis) {   // enqua
 void thip_enc_opt_data(size_t *enquant_table_size, int *enquant_table_alignment) {   // encint.h:331-338
   if (enquant_table_size) *enquant_table_size = THIP_ENQUANT_TABLE_SIZE;
   if (enquant_table_alignment) *enquant_table_alignment = 16;
+}
+
+int thip_enc_fdct_quantize_batch(int16_t *qdct, int32_t *nonzero, int16_t *dct, const int16_t *x, const uint16_t *dequant,
+                                 const void *enquant, int64_t n) {
+  if (n < 0) return THIP_EINVAL;
+  if (n == 0) return THIP_OK;
+  if (!qdct || !nonzero || !x || !dequant) return THIP_EFAULT;
+  hipLaunchKernelGGL(k_enc_fdct_quantize, grid_for(n), dim3(256), 0, g_batch_stream, qdct, nonzero, dct, x, dequant, (const int16_t *)enquant, n);
+  HIP_TRY(hipGetLastError());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
+  return THIP_OK;
 }
 
 int thip_enc_quantize_tab_batch(int16_t *qdct, int32_t *nonzero, const int16_t *dct, const uint16_t *dequant,
