@@ -267,6 +267,14 @@ int thip_frame_flush(thip_state *st);
    frame has received such a block through one entry point, the other refuses them with THIP_EINVAL and leaves
    the frame as it was; DC-only blocks (last_zzi < 2) own no slot and may arrive through either. */
 int thip_frame_dequant_table(thip_state *st, int sel, const uint16_t dequant[64]);
+/* Levels form of the oc_state_frag_recon slot: dct_coeffs[1..63] hold the QUANTISED levels as the tokens carry them (the caller
+   leaves out the multiplication of decode.c:1573-1574; natural order, dct_coeffs[0] the raw DC as ever, zeroed on return like the
+   other slot), qii = frags[fragi].qii (state.h:307).  The frame's tables go over with thip_frame_dequant_table (sel = (pli*3 + qii)*2
+   + qti) before the flush and `(ogg_int16_t)(coeff*ac_quant[zzi])` is done by the reconstruction kernel: 64 bytes of staging a
+   block instead of 128 (int16 units for the tiles in which a level does not fit eight bits).  One form per frame for the blocks
+   that own a slot, as above. */
+int thip_state_frag_recon_levels(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_coeffs[128], int last_zzi, uint16_t dc_quant,
+                                 int qii, int refi, int16_t mv);
 int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const uint32_t *toks, int ntoks,
                                  int16_t dc, int last_zzi, uint16_t dc_quant, int dqsel, int refi, int16_t mv);
 
@@ -508,6 +516,8 @@ const char *thip_version_string(void);
  *   fe_device_lists   th_decode_*: the token lists go to the device as the entropy decoder leaves them: 1 on, 0 off, -1 (default)
  *                on while at most four decoder contexts are alive in the process and neither of the two above is set (one to
  *                four streams decode a fifth faster that way, sixteen slower); TH_DECCTL_THIP_SET_DEVICE_LISTS per context
+ *   fe_levels    th_decode_*: 1: the host's own token walk feeds thip_state_frag_recon_levels; 0 (default): thip_state_frag_recon --
+ *                measured equal within 2 % end to end (the walk is bound by the tokens, not by the 64 bytes a block saved)
  *   fe_trace_backend, fe_prof   th_decode_*: record slot calls instead of running them (tests); per-stage host timing
  *   device       th_decode_alloc: -1 the calling thread's current device (default), n that device, -2 round robin
  * Returns THIP_EINVAL for a name the table does not have.

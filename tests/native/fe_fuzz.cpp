@@ -40,6 +40,7 @@ int thip_option(const char *name) {   // the library's option table is not linke
 }
 int thip_state_set_device_dc(thip_state *, int) { return -1; }
 int thip_frame_dequant_table(thip_state *, int, const uint16_t *) { return -1; }
+int thip_state_frag_recon_levels(thip_state *, ptrdiff_t, int, int16_t *, int, uint16_t, int, int, int16_t) { return -1; }
 int thip_state_frag_recon_tokens(thip_state *, ptrdiff_t, int, const uint32_t *, int, int16_t, int, uint16_t, int, int, int16_t) {
   return -1;
 }

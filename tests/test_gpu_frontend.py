@@ -61,6 +61,19 @@ def test_packets_decode_bit_exact_with_dc_unprediction_on_the_gpu(hip, w, h, fmt
     assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_dc=True) >= 3
 
 
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (336, 32, 0), (1280, 720, 0)])
+def test_packets_decode_bit_exact_with_levels_through_the_slot(hip, w, h, fmt):
+    """Option fe_levels: the host's own token walk hands thip_state_frag_recon_levels the quantised levels and the frame's
+    tables; the multiplication of decode.c:1573 is the reconstruction kernel's (streams with one to three qi per frame,
+    custom matrices, intra and inter tables)."""
+    L = hip._lib.load()
+    L.thip_set_option(b"fe_levels", 1)
+    try:
+        assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_lists=False) >= 3
+    finally:
+        L.thip_set_option(b"fe_levels", 0)
+
+
 @pytest.mark.parametrize("device_dc", [False, True])
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (1280, 720, 0)])
 def test_packets_decode_bit_exact_with_token_expansion_on_the_gpu(hip, w, h, fmt, device_dc):

@@ -135,3 +135,47 @@ def test_one_tile_per_wave_and_one_super_block_per_wave(hip, sb_tiles, form, w, 
     finally:
         hip._lib.load().thip_set_option(b"sb_tiles", 600)
     assert not rep, rep[:3]
+
+
+@pytest.mark.parametrize("w,h,fmt,content", [(176, 144, PF_420, "mixed"), (80, 112, PF_422, "dense"), (336, 48, PF_444, "mixed"), (256, 96, PF_420, "smooth")])
+@pytest.mark.parametrize("mode", ["levels", "levels_alternate"])
+def test_levels_through_the_enqueue_slot(hip, w, h, fmt, content, mode):
+    """thip_state_frag_recon_levels: the slot fed with quantised levels in the reference's MCU order -- narrow tiles, tiles that turn
+    wide after some of their blocks have been packed (class 'mixed': a level beyond eight bits now and then), frames by turns
+    with thip_decode_frames on the same state."""
+    rep = util.run_sequence(hip, w, h, fmt, nframes=8, content=content, seed=w * 5 + h, kf_interval=4, enqueue=mode)
+    assert not rep, rep[:3]
+
+
+def test_a_tile_turns_wide_with_its_last_block(hip):
+    """Every slot-owning block of every tile narrow except the LAST one that arrives: all units of the tile are rewritten."""
+    w, h = 256, 64
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(8)
+    ost, gst = oracle.State(w, h, PF_420), hip.State(w, h, PF_420)
+    for f in range(3):
+        fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "dense", flimit=2)
+        pos = geom.frag_pos[fr["coded_fragis"]]
+        tile = pos >> 6
+        last = np.r_[tile[1:] != tile[:-1], True]
+        fr["levels"][last, 5] = 300 * (1 if f % 2 else -1)
+        fr["coeffs"] = synth.dequantise(geom, fr)
+        util.oracle_apply(ost, fr)
+        util.enqueue_frame(hip, gst, geom, fr, levels=True)
+        assert not util.planes_equal(ost, gst), f
+
+
+def test_one_form_per_frame_for_slot_owning_blocks(hip):
+    w, h = 64, 48
+    geom = synth.Geometry(w, h)
+    gst = hip.State(w, h)
+    L = hip._lib.load()
+    gst.frame_begin(hip.INTRA_FRAME)
+    buf = np.zeros(128, np.int16)
+    buf[1] = 5
+    gst.frag_recon_levels(0, 0, buf, 3, 20, 0, hip.FRAME_SELF, 0)
+    buf[1] = 5
+    assert L.thip_state_frag_recon(gst.handle, 1, 0, buf.ctypes.data, 3, 20, hip.FRAME_SELF, 0) == hip._lib.EINVAL
+    assert buf[1] == 5                                   # a refused call leaves the block alone
+    assert L.thip_state_frag_recon(gst.handle, 1, 0, buf.ctypes.data, 1, 20, hip.FRAME_SELF, 0) == 0     # DC-only: no slot, either entry
+    assert L.thip_state_frag_recon_levels(gst.handle, 2, 0, buf.ctypes.data, 3, 20, 3, hip.FRAME_SELF, 0) == hip._lib.EINVAL   # qii 0..2

@@ -41,8 +41,8 @@ def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, e
         ftype = theora_amd.INTRA_FRAME if f % kf_interval == 0 else theora_amd.INTER_FRAME
         fr = synth.gen_frame(geom, rng, ftype, content)
         rc_o = oracle_apply(ost, fr)
-        if enqueue is True or (enqueue == "alternate" and f % 2 == 0):
-            rc_g = enqueue_frame(theora_amd, gst, geom, fr)
+        if enqueue is True or (enqueue == "alternate" and f % 2 == 0) or enqueue == "levels" or (enqueue == "levels_alternate" and f % 2 == 0):
+            rc_g = enqueue_frame(theora_amd, gst, geom, fr, levels=isinstance(enqueue, str) and enqueue.startswith("levels"))
         else:
             fm = ("levels", "dequant16")[f % 2] if form == "alternate" else form
             desc, ka = synth.upload_frame(synth.pack_frame(geom, fr, fm))
@@ -58,11 +58,17 @@ def run_sequence(theora_amd, w, h, fmt, nframes, content, seed, kf_interval=8, e
     return reports
 
 
-def enqueue_frame(theora_amd, gst, geom, fr):
+def enqueue_frame(theora_amd, gst, geom, fr, levels=False):
     """Drive the host-enqueue slots exactly as the reference's MCU loop would
     (decode.c:2858-2945): per MCU and plane, frag_recon for the coded fragments, one
-    frag_copy_list, then the loop filter with its one-row delays."""
+    frag_copy_list, then the loop filter with its one-row delays.  levels: through thip_state_frag_recon_levels (the quantised
+    levels, the frame's tables handed over with thip_frame_dequant_table) instead of the slot's dequantised coefficients."""
     gst.frame_begin(fr["frame_type"])
+    if levels:
+        for p_ in range(3):
+            for q_ in range(3):
+                for t_ in range(2):
+                    gst.frame_dequant_table((p_ * 3 + q_) * 2 + t_, fr["dequant"][p_, q_, t_])
     coded = np.zeros(geom.nfrags, bool)
     coded[fr["coded_fragis"]] = True
     base = np.cumsum([0] + fr["ncoded"])
@@ -82,11 +88,16 @@ def enqueue_frame(theora_amd, gst, geom, fr):
             for k in range(nc):
                 slot = base[pli] + done[pli] + k
                 fi = int(fr["coded_fragis"][slot])
-                buf[:64] = fr["coeffs"][slot]
                 mv = int((int(fr["mvx"][fi]) & 0xFF) | (int(fr["mvy"][fi]) << 8))
                 mv = (mv + 0x8000) % 0x10000 - 0x8000
-                gst.frag_recon(fi, pli, buf, int(fr["last_zzi"][slot]), int(fr["dc_quant"][slot]),
-                               int(fr["refi"][fi]), mv)
+                if levels:
+                    buf[:64] = fr["levels"][slot]
+                    gst.frag_recon_levels(fi, pli, buf, int(fr["last_zzi"][slot]), int(fr["dc_quant"][slot]), int(fr["qii"][slot]),
+                                          int(fr["refi"][fi]), mv)
+                else:
+                    buf[:64] = fr["coeffs"][slot]
+                    gst.frag_recon(fi, pli, buf, int(fr["last_zzi"][slot]), int(fr["dc_quant"][slot]),
+                                   int(fr["refi"][fi]), mv)
                 assert not buf[:64].any()
             done[pli] += nc
             unc = lo + np.nonzero(~coded[lo:hi])[0]

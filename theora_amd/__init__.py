@@ -211,6 +211,17 @@ class State:
         _lib.check(self._L.thip_state_frag_recon(self._h, fragi, pli, dct_coeffs.ctypes.data, last_zzi,
                                                  dc_quant, refi, mv), "state_frag_recon")
 
+    def frag_recon_levels(self, fragi, pli, levels, last_zzi, dc_quant, qii, refi, mv):
+        """thip_state_frag_recon_levels: `levels` is an int16[128] numpy array holding the quantised levels (zeroed on return)."""
+        assert levels.dtype == np.int16 and levels.size >= 128
+        _lib.check(self._L.thip_state_frag_recon_levels(self._h, fragi, pli, levels.ctypes.data, last_zzi, dc_quant, qii, refi, mv),
+                   "state_frag_recon_levels")
+
+    def frame_dequant_table(self, sel, table_zz):
+        t = np.ascontiguousarray(table_zz, np.uint16)
+        assert t.size == 64
+        _lib.check(self._L.thip_frame_dequant_table(self._h, sel, t.ctypes.data), "frame_dequant_table")
+
     def frag_copy_list(self, fragis):
         a = np.ascontiguousarray(fragis, np.int64)
         _lib.check(self._L.thip_frag_copy_list(self._h, a.ctypes.data, a.size), "frag_copy_list")

@@ -73,6 +73,7 @@ SYMBOLS = [
     ("thip_synchronize", _I, []),
     ("thip_frame_begin", _I, [_P, _I]),
     ("thip_state_frag_recon", _I, [_P, C.c_ssize_t, _I, _P, _I, C.c_uint16, _I, C.c_int16]),
+    ("thip_state_frag_recon_levels", _I, [_P, C.c_ssize_t, _I, _P, _I, C.c_uint16, _I, _I, C.c_int16]),
     ("thip_frag_copy_list", _I, [_P, _P, C.c_ssize_t]),
     ("thip_loop_filter_init", None, [_P, _I]),
     ("thip_state_loop_filter_frag_rows", _I, [_P, _I, _I, _I, _I, _I]),

@@ -77,6 +77,7 @@ Option g_options[] = {
     {"fe_device_dc", 0, "th_decode_*: DC un-prediction on the device"},
     {"fe_device_tokens", 0, "th_decode_*: token expansion + dequantisation on the device (host-delimited tokens)"},
     {"fe_device_lists", -1, "th_decode_*: the token lists themselves on the device (1 on, 0 off, -1 on while at most four decoder contexts are alive)"},
+    {"fe_levels", 0, "th_decode_*: 1: the host's own token walk hands the slots quantised levels (thip_state_frag_recon_levels: the kernel dequantises); 0 (default): dequantised coefficients"},
     {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
     {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
@@ -210,9 +211,13 @@ struct thip_state {
   uint32_t *h_tok, *d_tok;
   uint32_t *h_slot_tok, *d_slot_tok;
   uint16_t *h_dq, *d_dq;
+  uint16_t *h_dqp, *d_dqp;   // the same 18 tables in slot order (thip_pack_dequant_table): the levels form's thip_frame_desc.dequant
   size_t tok_cap;
   int tok_ready;             // all six token staging buffers exist
   int enq_ntok, enq_tok_slots, enq_dense_slots;
+  int enq_levels_hint;       // a DC-only block came through thip_state_frag_recon_levels: a frame without any unit is in the levels form too
+  int enq_level_slots;       // blocks that came through thip_state_frag_recon_levels (the frame is then in the levels form)
+  int enq_tile_blocks;       // ... of them in the tile being filled (enq_last_tile)
   // token lists expanded on the device (thip_state_decode_token_lists): pinned staging, its device copy, work arrays
   uint32_t *h_tl, *d_tl;
   size_t tl_cap;            // bytes of each
@@ -669,6 +674,8 @@ void thip_state_free(thip_state *st) {
   if (st->d_tok) (void)hipFree(st->d_tok);
   if (st->d_slot_tok) (void)hipFree(st->d_slot_tok);
   if (st->d_dq) (void)hipFree(st->d_dq);
+  if (st->h_dqp) (void)hipHostFree(st->h_dqp);
+  if (st->d_dqp) (void)hipFree(st->d_dqp);
   if (st->d_flags) (void)hipFree(st->d_flags);
   free(st->enq_last_lane);
   free(st->frag_pos);
@@ -1547,7 +1554,7 @@ int thip_frame_begin(thip_state *st, int frame_type) {
     st->enq_lf_y0[p] = 0x7FFFFFFF;
     st->enq_lf_y1[p] = -1;
   }
-  st->enq_ntok = st->enq_tok_slots = st->enq_dense_slots = 0;
+  st->enq_ntok = st->enq_tok_slots = st->enq_dense_slots = st->enq_level_slots = st->enq_tile_blocks = st->enq_levels_hint = 0;
   st->enq_device_dc = st->device_dc;
   if (st->enq_device_dc) {
     if (!st->h_dc) HIP_TRY(hipHostMalloc((void **)&st->h_dc, sizeof(int16_t) * (size_t)st->nfrags, hipHostMallocDefault));
@@ -1584,7 +1591,7 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
     // from the tile's first slot and a prefix count, so arrival must not jump backwards
     // inside a tile.
     const int tile = pos / THIP_TILE_FRAGS, lane = pos % THIP_TILE_FRAGS;
-    if (st->enq_tok_slots) return THIP_EINVAL;   // the frame's coefficient slots come from the token form (expanded on the device)
+    if (st->enq_tok_slots || st->enq_level_slots) return THIP_EINVAL;   // the frame's coefficient slots come in another form (tokens, levels)
     if (lane <= st->enq_last_lane[tile]) return THIP_EINVAL;
     if (st->enq_last_lane[tile] >= 0 && st->enq_last_tile != tile) return THIP_EINVAL;   // a tile's slots must be contiguous
     // (every refusal is above this line: a refused call leaves the tile bookkeeping as it was)
@@ -1618,6 +1625,21 @@ int thip_state_frag_recon(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_
   return THIP_OK;
 }
 
+// the frame's AC dequantisation tables (thip_frame_dequant_table): zig-zag order for k_expand_tokens, slot order for the levels form
+static int ensure_dq_staging(thip_state *st) {
+  if (!st->h_dq) {
+    HIP_TRY(hipHostMalloc((void **)&st->h_dq, 18 * 64 * 2, hipHostMallocDefault));
+    memset(st->h_dq, 0, 18 * 64 * 2);
+  }
+  if (!st->d_dq) HIP_TRY(hipMalloc((void **)&st->d_dq, 18 * 64 * 2));
+  if (!st->h_dqp) {
+    HIP_TRY(hipHostMalloc((void **)&st->h_dqp, 18 * 64 * 2, hipHostMallocDefault));
+    memset(st->h_dqp, 0, 18 * 64 * 2);
+  }
+  if (!st->d_dqp) HIP_TRY(hipMalloc((void **)&st->d_dqp, 18 * 64 * 2));
+  return THIP_OK;
+}
+
 static int ensure_token_staging(thip_state *st) {
   if (st->tok_ready) return THIP_OK;
   // A slot stages the raw DC plus up to 63 AC tokens: 64 words per block when every coefficient of every
@@ -1627,13 +1649,12 @@ static int ensure_token_staging(thip_state *st) {
   // each buffer on its own: a failed allocation leaves the others to a later call, and nothing is used before all exist
   if (!st->h_tok) HIP_TRY(hipHostMalloc((void **)&st->h_tok, st->tok_cap * 4 + 64 * 4, hipHostMallocDefault));
   if (!st->h_slot_tok) HIP_TRY(hipHostMalloc((void **)&st->h_slot_tok, ngroups * 64 * 8, hipHostMallocDefault));
-  if (!st->h_dq) {
-    HIP_TRY(hipHostMalloc((void **)&st->h_dq, 18 * 64 * 2, hipHostMallocDefault));
-    memset(st->h_dq, 0, 18 * 64 * 2);
+  {
+    const int rc = ensure_dq_staging(st);
+    if (rc) return rc;
   }
   if (!st->d_tok) HIP_TRY(hipMalloc((void **)&st->d_tok, st->tok_cap * 4 + 64 * 4));
   if (!st->d_slot_tok) HIP_TRY(hipMalloc((void **)&st->d_slot_tok, ngroups * 64 * 8));
-  if (!st->d_dq) HIP_TRY(hipMalloc((void **)&st->d_dq, 18 * 64 * 2));
   st->tok_ready = 1;
   return THIP_OK;
 }
@@ -1649,10 +1670,139 @@ void thip_pack_dequant_table(uint16_t out[64], const uint16_t zz[64]) {
 int thip_frame_dequant_table(thip_state *st, int sel, const uint16_t dequant[64]) {
   if (!st || !dequant) return THIP_EFAULT;
   if (!st->enq_active || sel < 0 || sel >= 18) return THIP_EINVAL;
-  DeviceGuard dg(st->device);
-  const int rc = ensure_token_staging(st);
-  if (rc) return rc;
+  if (!st->h_dq || !st->d_dq || !st->h_dqp || !st->d_dqp) {
+    DeviceGuard dg(st->device);
+    const int rc = ensure_dq_staging(st);
+    if (rc) return rc;
+  }
   memcpy(st->h_dq + sel * 64, dequant, 128);
+  thip_pack_dequant_table(st->h_dqp + sel * 64, dequant);
+  return THIP_OK;
+}
+
+// The levels form of the oc_state_frag_recon slot: dct_coeffs holds the quantised LEVELS as the tokens carry them (natural order,
+// [0] the raw DC as ever), qii = frags[fragi].qii; the frame's tables come through thip_frame_dequant_table and
+// `(ogg_int16_t)(coeff*ac_quant[zzi])` (decode.c:1573) happens in the reconstruction kernel.  64 bytes of staging per block
+// instead of 128 (the kernels read the staging across PCIe); a tile turns wide -- int16 units -- with its first level beyond
+// eight bits, and the units it has been given so far are rewritten in place (tiles arrive contiguously, so nothing lies behind them).
+static inline uint8_t *unit_piece_host(int16_t *base, uint32_t unit, int q) {
+  return reinterpret_cast<uint8_t *>(base) + (size_t)(unit >> 6) * THIP_UNIT_GROUP_BYTES + (size_t)q * 1024 + (size_t)(unit & 63) * 16;
+}
+static void pack_wide_block(int16_t *base, uint32_t unit, const int16_t lv[64]) {
+  typedef int16_t v8s __attribute__((vector_size(16)));
+  for (int j = 0; j < 4; j++) {
+    v8s a, b;
+    memcpy(&a, lv + (2 * j) * 8, 16);
+    memcpy(&b, lv + (2 * j + 1) * 8, 16);
+    const v8s lo = __builtin_shufflevector(a, b, 0, 8, 1, 9, 2, 10, 3, 11);
+    const v8s hi = __builtin_shufflevector(a, b, 4, 12, 5, 13, 6, 14, 7, 15);
+    memcpy(unit_piece_host(base, unit + (uint32_t)((2 * j) >> 2), (2 * j) & 3), &lo, 16);
+    memcpy(unit_piece_host(base, unit + (uint32_t)((2 * j + 1) >> 2), (2 * j + 1) & 3), &hi, 16);
+  }
+}
+static void pack_narrow_block(int16_t *base, uint32_t unit, const int16_t lv[64]) {
+  typedef int16_t v8s __attribute__((vector_size(16)));
+  typedef int8_t v16c __attribute__((vector_size(16)));
+  for (int j = 0; j < 4; j++) {
+    v8s a, b;
+    memcpy(&a, lv + (2 * j) * 8, 16);
+    memcpy(&b, lv + (2 * j + 1) * 8, 16);
+    const v16c ab = __builtin_convertvector(__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15), v16c);   // a0..a7 b0..b7 (the levels fit)
+    // dword d: a[2d], a[2d+1], b[2d], b[2d+1]
+    const v16c o = __builtin_shufflevector(ab, ab, 0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15);
+    memcpy(unit_piece_host(base, unit, j), &o, 16);
+  }
+}
+static void unpack_narrow_block(const int16_t *base, uint32_t unit, int16_t lv[64]) {
+  for (int j = 0; j < 4; j++) {
+    const int8_t *p = reinterpret_cast<const int8_t *>(unit_piece_host(const_cast<int16_t *>(base), unit, j));
+    for (int d = 0; d < 4; d++) {
+      lv[(2 * j) * 8 + 2 * d] = p[4 * d];
+      lv[(2 * j) * 8 + 2 * d + 1] = p[4 * d + 1];
+      lv[(2 * j + 1) * 8 + 2 * d] = p[4 * d + 2];
+      lv[(2 * j + 1) * 8 + 2 * d + 1] = p[4 * d + 3];
+    }
+  }
+}
+
+int thip_state_frag_recon_levels(thip_state *st, ptrdiff_t fragi, int pli, int16_t dct_coeffs[128], int last_zzi, uint16_t dc_quant,
+                                 int qii, int refi, int16_t mv) {
+  if (!st || !dct_coeffs) return THIP_EFAULT;
+  if (!st->enq_active || fragi < 0 || fragi >= st->nfrags || pli < 0 || pli > 2 || refi < 0 || refi > 2 || qii < 0 || qii > 2 ||
+      last_zzi < 0 || last_zzi > 64 || (int64_t)st->enq_ncoded + st->enq_nuncoded >= st->nfrags)
+    return THIP_EINVAL;
+  const int32_t pos = st->frag_pos[fragi];
+  if (st->h_info[2 * (size_t)pos] & THIP_INFO_CODED) return THIP_EINVAL;   // fragment enqueued twice
+  uint32_t flags = THIP_INFO_CODED | ((uint32_t)refi << THIP_INFO_REFI_SHIFT) | ((uint32_t)qii << THIP_INFO_QII_SHIFT) |
+                   ((uint32_t)last_zzi << THIP_INFO_LAST_ZZI_SHIFT) |
+                   ((uint32_t)(uint8_t)(mv & 0xFF) << THIP_INFO_MVX_SHIFT) |
+                   ((uint32_t)(uint8_t)((mv >> 8) & 0xFF) << THIP_INFO_MVY_SHIFT);
+  const uint32_t word1 = (uint32_t)dc_quant << 16 | (uint32_t)(uint16_t)dct_coeffs[0];   // the raw DC of every block rides here
+  if (last_zzi < 2) {
+    flags |= THIP_INFO_DC_ONLY;   // no unit
+    st->enq_levels_hint = 1;
+  } else {
+    if (st->enq_dense_slots || st->enq_tok_slots) return THIP_EINVAL;   // one form per frame for the blocks that own a slot
+    const int tile = pos / THIP_TILE_FRAGS, lane = pos % THIP_TILE_FRAGS;
+    if (lane <= st->enq_last_lane[tile]) return THIP_EINVAL;
+    if (st->enq_last_lane[tile] >= 0 && st->enq_last_tile != tile) return THIP_EINVAL;   // a tile's units must be contiguous
+    // (every refusal is above this line)
+    if (st->enq_last_lane[tile] < 0) {
+      st->h_slot0[tile] = (uint32_t)st->enq_nslots;
+      st->enq_tile_blocks = 0;
+    }
+    st->enq_last_lane[tile] = lane;
+    st->enq_last_tile = tile;
+    st->enq_level_slots++;
+    int16_t keep0 = dct_coeffs[0];
+    dct_coeffs[0] = 0;
+    bool big;
+    {
+      typedef int16_t v8s __attribute__((vector_size(16)));
+      typedef uint16_t v8u __attribute__((vector_size(16)));
+      v8u worst = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = 0; r < 8; r++) {
+        v8s a;
+        memcpy(&a, dct_coeffs + 8 * r, 16);
+        const v8u b = (v8u)(a + 127);          // 0..254 for the levels that fit eight bits
+        worst = worst > b ? worst : b;
+      }
+      uint16_t w8[8];
+      memcpy(w8, &worst, 16);
+      uint16_t m = 0;
+      for (int i = 0; i < 8; i++) m = m > w8[i] ? m : w8[i];
+      big = m > 254;
+    }
+    bool wide = (st->h_slot0[tile] & THIP_SLOT_WIDE) != 0;
+    const uint32_t u0 = st->h_slot0[tile] & ~THIP_SLOT_WIDE;
+    if (big && !wide) {   // the tile turns wide: its narrow units so far become pairs of int16 units, last block first
+      for (int i = st->enq_tile_blocks - 1; i >= 0; i--) {
+        int16_t lv[64];
+        unpack_narrow_block(st->h_coeffs, u0 + (uint32_t)i, lv);
+        pack_wide_block(st->h_coeffs, u0 + 2u * (uint32_t)i, lv);
+      }
+      st->h_slot0[tile] |= THIP_SLOT_WIDE;
+      st->enq_nslots = (int)(u0 + 2u * (uint32_t)st->enq_tile_blocks);
+      wide = true;
+    }
+    if (wide) {
+      pack_wide_block(st->h_coeffs, (uint32_t)st->enq_nslots, dct_coeffs);
+      st->enq_nslots += 2;
+    } else {
+      pack_narrow_block(st->h_coeffs, (uint32_t)st->enq_nslots, dct_coeffs);
+      st->enq_nslots += 1;
+    }
+    st->enq_tile_blocks++;
+    dct_coeffs[0] = keep0;
+  }
+  if (st->enq_device_dc) {
+    st->h_dc[fragi] = dct_coeffs[0];
+    st->h_flags[fragi] = (uint8_t)(1u | (uint32_t)refi << 1);
+  }
+  memset(dct_coeffs, 0, 64 * sizeof(int16_t));   // idct.c:245,276,295
+  st->h_info[2 * (size_t)pos] = flags;
+  st->h_info[2 * (size_t)pos + 1] = word1;
+  st->enq_ncoded++;
   return THIP_OK;
 }
 
@@ -1679,7 +1829,7 @@ int thip_state_frag_recon_tokens(thip_state *st, ptrdiff_t fragi, int pli, const
       const int rc = ensure_token_staging(st);
       if (rc) return rc;
     }
-    if (st->enq_dense_slots) return THIP_EINVAL;   // (see thip_state_frag_recon: one form per frame for the blocks that own a coefficient slot)
+    if (st->enq_dense_slots || st->enq_level_slots) return THIP_EINVAL;   // (see thip_state_frag_recon: one form per frame for the blocks that own a coefficient slot)
     if ((size_t)st->enq_ntok + (size_t)ntoks + 1 > st->tok_cap) return THIP_EINVAL;   // more tokens than the frame has coefficients
     const int tile = pos / THIP_TILE_FRAGS, lane = pos % THIP_TILE_FRAGS;
     if (lane <= st->enq_last_lane[tile]) return THIP_EINVAL;
@@ -1760,14 +1910,16 @@ int thip_frame_flush(thip_state *st) {
   if (rc) return rc;
   rc = order_behind_previous(st, s);   // before the first copy or kernel of this frame goes onto s
   if (rc) return rc;
-  const size_t ngroups = ((size_t)st->enq_nslots + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;
+  const bool levels_frame = st->enq_level_slots != 0 || (st->enq_ncoded && !st->enq_dense_slots && !st->enq_tok_slots && st->h_dqp && st->enq_levels_hint);
+  const size_t ngroups = ((size_t)st->enq_nslots + THIP_SLOT_GROUP - 1) / THIP_SLOT_GROUP;   // (groups of 64 slots, or of 64 units)
+  const size_t group_bytes = levels_frame ? THIP_UNIT_GROUP_BYTES : THIP_SLOT_GROUP_BYTES;
   const int zerocopy = THIP_OPT("zerocopy");
   if (st->enq_ncoded && !zerocopy) {
     HIP_TRY(hipMemcpyAsync(st->d_info, st->h_info, (size_t)st->tiles.ntiles * THIP_TILE_FRAGS * 8,
                            hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(st->d_slot0, st->h_slot0, (size_t)st->tiles.ntiles * 4, hipMemcpyHostToDevice, s));
     if (ngroups)
-      HIP_TRY(hipMemcpyAsync(st->d_coeffs, st->h_coeffs, ngroups * THIP_SLOT_GROUP_BYTES, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(st->d_coeffs, st->h_coeffs, ngroups * group_bytes, hipMemcpyHostToDevice, s));
   }
   thip_frame_desc d;
   memset(&d, 0, sizeof(d));
@@ -1780,6 +1932,11 @@ int thip_frame_flush(thip_state *st) {
   d.ncoded = st->enq_ncoded;
   d.frame_type = st->enq_frame_type;
   d.flimit = st->enq_lf_any ? st->enq_flimit : 0;
+  if (levels_frame) {   // the frame's tables to the device (2.3 KB; every wave of the kernel reads its plane's six)
+    HIP_TRY(hipMemcpyAsync(st->d_dqp, st->h_dqp, 18 * 64 * 2, hipMemcpyHostToDevice, s));
+    d.coeff_format = THIP_COEFFS_LEVELS;
+    d.dequant = st->d_dqp;
+  }
   if (st->enq_tok_slots) {
     // tokens -> device, expanded there into the coefficient slots k_recon reads (decode.c:1540-1581)
     HIP_TRY(hipMemcpyAsync(st->d_tok, st->h_tok, (size_t)st->enq_ntok * 4, hipMemcpyHostToDevice, s));

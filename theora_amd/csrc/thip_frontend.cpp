@@ -1582,7 +1582,12 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   const int flimit = d->setup.qp.lflims[d->qis[0]];
   d->tr_flimit = flimit;
   const bool use_tokens = d->device_tokens && !d->trace;
-  if (use_tokens) {   // the frame's AC dequantisation tables (decode.c:1358-1366): number = (plane * 3 + qii) * 2 + qti
+  // Option fe_levels = 1: the host's own walk hands the slot quantised LEVELS (thip_state_frag_recon_levels): the multiplication of
+  // decode.c:1573 is the reconstruction kernel's and the staging a block needs halves.  Off by default: end to end it measured
+  // the same within 2 % (720p and 1080p, 1 and 16 threads, tools/exp_fe_levels.sh) -- the walk is bound by the tokens.  The
+  // slot-trace mode of the tests always records the dequantised coefficients.
+  const bool use_levels = !use_tokens && !d->trace && thip_option("fe_levels") != 0;
+  if (use_tokens || use_levels) {   // the frame's AC dequantisation tables (decode.c:1358-1366): number = (plane * 3 + qii) * 2 + qti
     for (int p = 0; p < 3; p++)
       for (int qii = 0; qii < d->nqis; qii++)
         for (int qti = 0; qti < 2; qti++)
@@ -1647,7 +1652,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
           // half of block[], which nobody reads (the reference keeps such a dump slot too,
           // decint.h:96).
           const int at = z + t.skip;   // <= 63 + 63
-          block[kZigZagDump[at]] = (int16_t)(t.value * (int)acq[at & 63]);
+          block[kZigZagDump[at]] = use_levels ? (int16_t)t.value : (int16_t)(t.value * (int)acq[at & 63]);
           z += t.adv;
         }
         block[0] = d->dc[f];   // raw un-predicted DC; the slot dequantises it (state.c:967-979)
@@ -1663,7 +1668,8 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
           memset(block, 0, 64 * sizeof(block[0]));   // what the slot does (idct.c:245,276,295)
           continue;
         }
-        rc = thip_state_frag_recon(d->hip, f, p, block, last_zzi, dcq, d->refi[f], mv);
+        rc = use_levels ? thip_state_frag_recon_levels(d->hip, f, p, block, last_zzi, dcq, d->qii[f], d->refi[f], mv)
+                        : thip_state_frag_recon(d->hip, f, p, block, last_zzi, dcq, d->refi[f], mv);
         if (rc < 0) return TH_EFAULT;
       }
       const ptrdiff_t *const uncoded = d->ulist.data() + d->ul_start[p];
