@@ -111,16 +111,16 @@ __device__ __forceinline__ uint32_t sum2_u16(pk16 m, uint32_t acc) {   // acc + 
   const upk16 one = {(unsigned short)1, (unsigned short)1};
   return __builtin_amdgcn_udot2(__builtin_bit_cast(upk16, m), one, acc, false);
 }
-// D[r][j]: the c0 level of the difference block (row r, pixel pair j).  Returns sum |coefficient| without the DC term;
-// dc = the DC coefficient = the sum of all differences (encfrag.c:264-315).
-__device__ __forceinline__ uint32_t satd_sd(pk16 D[8][4], int &dc) {
-#pragma unroll
-  for (int r = 0; r < 8; r++) {   // c1, c2
-    bfly(D[r][0], D[r][1]);
-    bfly(D[r][2], D[r][3]);
-    bfly(D[r][0], D[r][2]);
-    bfly(D[r][1], D[r][3]);
-  }
+// The remaining horizontal levels (c1, c2) of one row whose c0 level is in R[0..3]
+__device__ __forceinline__ void row_h12(pk16 R[4]) {
+  bfly(R[0], R[1]);
+  bfly(R[2], R[3]);
+  bfly(R[0], R[2]);
+  bfly(R[1], R[3]);
+}
+// D[r][j]: the block with all three horizontal levels done.  The vertical levels r2, r1, the last level folded into a maximum;
+// returns sum |coefficient| without the DC term; dc = the DC coefficient = the sum of all differences (encfrag.c:264-315).
+__device__ __forceinline__ uint32_t satd_vert(pk16 D[8][4], int &dc) {
 #pragma unroll
   for (int j = 0; j < 4; j++) {   // r2, r1
 #pragma unroll
@@ -138,6 +138,12 @@ __device__ __forceinline__ uint32_t satd_sd(pk16 D[8][4], int &dc) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc = sum2_u16(__builtin_elementwise_max(pk_abs(D[r][j]), pk_abs(D[r + 1][j])), acc);
   return 2u * acc - (uint32_t)(dc < 0 ? -dc : dc);
+}
+// D[r][j]: the c0 level of the difference block (row r, pixel pair j): both remaining horizontal levels, then satd_vert.
+__device__ __forceinline__ uint32_t satd_sd(pk16 D[8][4], int &dc) {
+#pragma unroll
+  for (int r = 0; r < 8; r++) row_h12(D[r]);
+  return satd_vert(D, dc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -230,10 +236,18 @@ __global__ __launch_bounds__(256) void k_enc_sites(uint32_t *out, int32_t *dc_ou
     // of the 20 of the rows as bytes -- 104 with the source block's 32 and the difference block's 32, four waves per SIMD
     // instead of five -- for 168 instructions a lane less (10 row preparations instead of 24).
     pk16 S[8][4], E[10][4];
+    // (... and so are the two other HORIZONTAL levels: the transform is linear, the horizontal levels of the difference are the
+    //  difference of the rows' horizontal levels, whichever rows meet -- only the vertical levels depend on dy)
 #pragma unroll
-    for (int r = 0; r < 8; r++) row_sd(S[r], s[r]);
+    for (int r = 0; r < 8; r++) {
+      row_sd(S[r], s[r]);
+      row_h12(S[r]);
+    }
 #pragma unroll
-    for (int r = 0; r < 10; r++) row_sd(E[r], e[r]);
+    for (int r = 0; r < 10; r++) {
+      row_sd(E[r], e[r]);
+      row_h12(E[r]);
+    }
 #pragma unroll
     for (int dyi = 0; dyi < 3; dyi++) {
       if (c[dyi] < 0) continue;
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(256) void k_enc_sites(uint32_t *out, int32_t *dc_ou
 #pragma unroll
         for (int j = 0; j < 4; j++) D[r][j] = S[r][j] - E[r + dyi][j];
       int dc;
-      const uint32_t v = satd_sd(D, dc);
+      const uint32_t v = satd_vert(D, dc);
       out[(int64_t)c[dyi] * nblocks + i] = v;
       if (dc_out) dc_out[(int64_t)c[dyi] * nblocks + i] = dc;
     }
