@@ -127,11 +127,38 @@ def measure_pmc_traffic(args, kernels):
                 if row["Counter_Name"] == counter:
                     acc.setdefault(_kernel_base_name(row["Kernel_Name"]), []).append(float(row["Counter_Value"]))
             out[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+    # ... and, in a third pass, the vector ALU: instructions issued and the share of the kernel's time the VALUs were busy (the
+    # kernel is bound by them since round 4: DESIGN.md section 5.1)
+    valu = {}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
+        for group in (("VALUBusy",), ("SQ_INSTS_VALU", "SQ_WAVES")):
+            d = os.path.join(td, group[0])
+            cmd = [exe, "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "24", "--warmup", "4", "--repeats", "1", "--min-time", "0", "--no-cpu-baseline", "--no-parity",
+                   "--no-profile", "--no-pmc", "--no-1080p", "--second-content", "", "--content", args.content, "--size", args.size,
+                   "--streams-per-gpu", str(args.streams_per_gpu), "--pool", str(args.pool)]
+            try:
+                r = subprocess.run(cmd, env=dict(os.environ, THIP_LANES="1", TMPDIR=os.environ.get("TMPDIR", "/tmp")), cwd=td,
+                                   capture_output=True, text=True, timeout=240)
+                files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode == 0 and files:
+                    for row in csv.DictReader(open(files[0])):
+                        valu.setdefault((_kernel_base_name(row["Kernel_Name"]), row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+            except (OSError, subprocess.TimeoutExpired):
+                pass
     res = {}
     for k in kernels:
         if k and k in out["FETCH_SIZE"]:
             f, w = out["FETCH_SIZE"][k], out["WRITE_SIZE"].get(k, 0.0)
             res[k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "hbm_bytes_per_launch": int(round((2 * f + w) * 1024))}
+
+            def avg(c):
+                v = valu.get((k, c))
+                return sum(v) / len(v) if v else None
+            if avg("VALUBusy") is not None:
+                res[k]["valu_busy_pct_alone"] = round(avg("VALUBusy"), 1)      # of a launch that has the chip to itself (THIP_LANES=1)
+            if avg("SQ_INSTS_VALU") and avg("SQ_WAVES"):
+                res[k]["valu_insts_per_wave"] = round(avg("SQ_INSTS_VALU") / avg("SQ_WAVES"), 1)
     return res or None
 
 
@@ -874,6 +901,17 @@ def main():
                                "shape": "one launch per step carrying all %d streams, alone on the chip" % (S * G),
                                "measured": "HIP events around every launch, separate instrumented pass of %d steps on one "
                                            "stream (ms_per_step there: %.5f)" % (prof_steps, 1e3 * elapsed_b / prof_steps)}
+            td_ = (traffic or {}).get(KERNEL_NAMES[0]) or {}
+            if td_.get("valu_insts_per_wave"):
+                # the arithmetic floor of a step: waves x vector instructions per wave x 4.3 clocks an instruction (measured issue rate
+                # of the packed / permute / multiply instructions the kernel is made of, profiles/r04_valu_rate2.txt) / 1024 SIMDs
+                waves = geom.ntiles * S * G
+                floor_us = waves * td_["valu_insts_per_wave"] * 4.3 / 1024.0 / 2400.0
+                out["roofline"]["valu"] = {"insts_per_wave": td_["valu_insts_per_wave"], "busy_pct_of_a_lone_launch": td_.get("valu_busy_pct_alone"),
+                                           "issue_floor_us_per_step": round(floor_us, 2),
+                                           "step_us": round(1e6 * elapsed / args.steps, 2),
+                                           "note": "the kernel is bound by vector-ALU issue since round 4 (DESIGN.md section 5.1): the floor is "
+                                                   "waves x instructions x 4.3 clocks / 1024 SIMDs at 2.4 GHz"}
             if launches_t[0]:
                 # the timed shape: launches of the library's lanes overlap, so a launch is longer than its share of a step;
                 # sum of the durations / (steps x ms_per_step) = how many launches are in flight on average

@@ -147,3 +147,47 @@ def test_options_table():
     assert L.thip_set_option(b"no_such_option", 1) == _lib.EINVAL
     assert L.thip_get_option(b"no_such_option", C.byref(v)) == _lib.EINVAL
     assert L.thip_set_option(None, 1) == _lib.EINVAL
+
+
+def test_levels_form_host_helpers():
+    """The LEVELS form's host-side pieces, no GPU: thip_pack_dequant_table (C) == the numpy packer the tests use; pack_units puts
+    every level of a narrow and of a wide block where include/theora_hip.h says (piece j, dword d: x[2j][2d], x[2j][2d+1],
+    x[2j+1][2d], x[2j+1][2d+1]; wide: the int16 pieces of the other form over two consecutive units)."""
+    import numpy as np
+    import theora_amd
+    from theora_amd import _lib, synth
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    tabs = rng.integers(1, 65536, (3, 3, 2, 64)).astype(np.uint16)
+    want = theora_amd.pack_dequant_tables(tabs)
+    got = np.zeros((18, 64), np.uint16)
+    flat = np.ascontiguousarray(tabs).reshape(18, 64)
+    for t in range(18):
+        L.thip_pack_dequant_table(got[t].ctypes.data, flat[t].ctypes.data)
+    assert np.array_equal(got, want)
+    # entry (j*8 + c)*2 + p is the factor of natural position (2j + p, c)
+    nat = np.zeros(64, np.uint16)
+    nat[synth.FZIG_ZAG] = flat[5]
+    assert all(got[5][(j * 8 + c) * 2 + p] == nat[(2 * j + p) * 8 + c] for j in range(4) for c in range(8) for p in range(2))
+    lv = rng.integers(-127, 128, (70, 64)).astype(np.int16)
+    lv[40:] = rng.integers(-32768, 32768, (30, 64))
+    wide = np.arange(70) >= 40
+    first = np.concatenate([np.arange(40), 40 + 2 * np.arange(30)])
+    buf = theora_amd.pack_units(lv, wide, first, 100)
+    assert buf.size == 2 * 4096
+
+    def at(unit, piece):
+        o = (unit >> 6) * 4096 + piece * 1024 + (unit & 63) * 16
+        return buf[o:o + 16]
+    for b in (0, 17, 39):
+        x = lv[b].reshape(8, 8)
+        for j in range(4):
+            p = at(int(first[b]), j).view(np.int8)
+            for d in range(4):
+                assert list(p[4 * d:4 * d + 4]) == [x[2 * j, 2 * d], x[2 * j, 2 * d + 1], x[2 * j + 1, 2 * d], x[2 * j + 1, 2 * d + 1]]
+    for b in (40, 55, 69):
+        x = lv[b].reshape(8, 8)
+        for q in range(8):
+            j, h = q >> 1, q & 1
+            p = at(int(first[b]) + (q >> 2), q & 3).view(np.int16)
+            assert list(p) == [x[2 * j + k, 4 * h + cc] for cc in range(4) for k in range(2)]
