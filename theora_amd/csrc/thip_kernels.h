@@ -137,18 +137,26 @@ struct __attribute__((aligned(4))) Pix8 {
 // ---- the filter on the packed image: two pixels per register -------------------------------------
 // f = P2 - P5 + 3*(P4 - P3), R = (f+4)>>3, lflim(R), P3 += ., P4 -= . (state.c:1002-1031) in
 // 16-bit lanes: |f| <= 1020, every intermediate fits; the final clamp is v_sat_pk_u8_i16.
-// lflim without the detour over |R| and the sign: for R >= 0 it is max(min(R, 2L - R), 0) and the mirror image for R < 0, and
-// each of the two expressions is 0 on the other side, so lflim(R) = max(min(R, 2L - R), 0) + min(max(R, -2L - R), 0): seven
-// packed operations; 3 * (P4 - P3) + (P2 - P5) is one v_pk_mad_i16.
+// lflim without the detour over |R| and the sign: see pk_lf_delta (six packed operations); 3 * (P4 - P3) + (P2 - P5) is one v_pk_mad_i16.
 __device__ __forceinline__ pk16 pk_lf_delta(pk16 p2, pk16 p3, pk16 p4, pk16 p5, int L2) {
   const pk16 three = {(short)3, (short)3};
   const pk16 f = (p4 - p3) * three + (p2 - p5);
   const pk16 R = (f + (short)4) >> 3;
+#ifdef THIP_LFLIM7   // (A/B: the seven-operation form of rounds 2 and 3)
   const pk16 l2 = {(short)L2, (short)L2};
   const pk16 z = {0, 0};
   const pk16 pos = __builtin_elementwise_max(__builtin_elementwise_min(R, l2 - R), z);
   const pk16 neg = __builtin_elementwise_min(__builtin_elementwise_max(R, z - l2 - R), z);
   return pos + neg;
+#else
+  // six: with a = clamp(R, -L, L), lflim(R) = a - clamp(R - a, -L, L) (R inside the limit: a = R, nothing taken off; between L and 2L:
+  // a = +-L and the excess comes off; beyond: the excess is clamped to L as well and nothing is left) -- checked for every R and L
+  const short L = (short)(L2 >> 1);
+  const pk16 l = {L, L}, nl = {(short)-L, (short)-L};
+  const pk16 a = __builtin_elementwise_max(__builtin_elementwise_min(R, l), nl);
+  const pk16 b = __builtin_elementwise_max(__builtin_elementwise_min(R - a, l), nl);
+  return a - b;
+#endif
 }
 // horizontal edge y = 4 of the cell, columns 0..3 (half 0: the lo dwords) or 4..7 (half 1)
 __device__ __forceinline__ void lf_horz_pk(CellPix &C, int half, int L2) {
