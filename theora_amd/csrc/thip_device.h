@@ -209,17 +209,39 @@ __device__ __forceinline__ pk16 pk_q16(int c, pk16 x) {
   return as_pk(__builtin_amdgcn_perm((uint32_t)ph, (uint32_t)pl, 0x07060302u));
 }
 
+// {(ca*a >> 16) -+ (cb*b >> 16)} on both halves: the four 32-bit products stay where the multiplies leave them and the
+// subtraction (addition) reads their upper words and writes one half of the result each (SDWA): two instructions where
+// packing each product pair first (pk_q16) and a packed subtraction take three.  Exact: the same 16-bit differences mod 2^16.
+#ifndef THIP_NO_SDWA_ROT
+template <bool ADD>
+__device__ __forceinline__ pk16 pk_q16_rot(int ca, pk16 a, int cb, pk16 b) {
+  const int pla = ca * (int)a.x, pha = ca * (int)a.y, plb = cb * (int)b.x, phb = cb * (int)b.y;
+  uint32_t t;
+  if (ADD) {
+    asm("v_add_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(pla), "v"(plb));
+    asm("v_add_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t) : "v"(pha), "v"(phb));
+  } else {
+    asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(pla), "v"(plb));
+    asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t) : "v"(pha), "v"(phb));
+  }
+  return as_pk(t);
+}
+#else
+template <bool ADD>
+__device__ __forceinline__ pk16 pk_q16_rot(int ca, pk16 a, int cb, pk16 b) { return ADD ? pk_q16(ca, a) + pk_q16(cb, b) : pk_q16(ca, a) - pk_q16(cb, b); }
+#endif
+
 // 1-D inverse DCT on eight packed registers, in place -- lib/idct.c:30-81 on both halves.
 __device__ __forceinline__ void pk_idct8(pk16 &x0, pk16 &x1, pk16 &x2, pk16 &x3, pk16 &x4, pk16 &x5,
                                          pk16 &x6, pk16 &x7) {
   pk16 t0 = pk_q16(kC4, x0 + x4);
   pk16 t1 = pk_q16(kC4, x0 - x4);
-  pk16 t2 = pk_q16(kC6, x2) - pk_q16(kC2, x6);
-  pk16 t3 = pk_q16(kC2, x2) + pk_q16(kC6, x6);
-  pk16 t4 = pk_q16(kC7, x1) - pk_q16(kC1, x7);
-  pk16 t5 = pk_q16(kC3, x5) - pk_q16(kC5, x3);
-  pk16 t6 = pk_q16(kC5, x5) + pk_q16(kC3, x3);
-  pk16 t7 = pk_q16(kC1, x1) + pk_q16(kC7, x7);
+  pk16 t2 = pk_q16_rot<false>(kC6, x2, kC2, x6);
+  pk16 t3 = pk_q16_rot<true>(kC2, x2, kC6, x6);
+  pk16 t4 = pk_q16_rot<false>(kC7, x1, kC1, x7);
+  pk16 t5 = pk_q16_rot<false>(kC3, x5, kC5, x3);
+  pk16 t6 = pk_q16_rot<true>(kC5, x5, kC3, x3);
+  pk16 t7 = pk_q16_rot<true>(kC1, x1, kC7, x7);
   pk16 r;
   r = t4 + t5; t5 = pk_q16(kC4, t4 - t5); t4 = r;
   r = t7 + t6; t6 = pk_q16(kC4, t7 - t6); t7 = r;
