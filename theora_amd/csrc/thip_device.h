@@ -135,17 +135,13 @@ __device__ __forceinline__ Row12 load_row12(const uint8_t *p) {
   r.c = q[2];
   return r;
 }
-// bytes off..off+7 of the window, off in 0..4 (v_alignbyte_b32 funnel shifts)
-__device__ __forceinline__ uint2 extract8(Row12 w, int off) {
-  uint2 o;
-  o.x = __builtin_amdgcn_alignbyte(w.b, w.a, (uint32_t)off);
-  o.y = __builtin_amdgcn_alignbyte(w.c, w.b, (uint32_t)off);
-  if (off == 4) {   // alignbyte only looks at the low two bits of the shift
-    o.x = w.b;
-    o.y = w.c;
-  }
-  return o;
+// bytes off..off+7 of the window, off in 0..4: one v_perm_b32 per dword with the selector extract_sel(off) -- the lane's
+// selector is computed once for all its rows (v_alignbyte_b32 looks at two bits of the shift only: off = 4 cost two selects a row)
+__device__ __forceinline__ uint32_t extract_sel(int off) { return 0x03020100u + (uint32_t)off * 0x01010101u; }
+__device__ __forceinline__ uint2 extract8s(Row12 w, uint32_t sel) {
+  return make_uint2(__builtin_amdgcn_perm(w.b, w.a, sel), __builtin_amdgcn_perm(w.c, w.b, sel));
 }
+__device__ __forceinline__ uint2 extract8(Row12 w, int off) { return extract8s(w, extract_sel(off)); }
 
 // clamp255(res[k] + pred byte k) for the eight pixels of a row
 __device__ __forceinline__ uint2 recon_row(const int *res, uint2 pred) {
@@ -285,8 +281,18 @@ __device__ __forceinline__ void pk_idct8_first4(pk16 &x0, pk16 &x1, pk16 &x2, pk
   x7 = t0 - t7;
 }
 
-// (y+8)>>4 on int16 without the 16-bit overflow of y+8: ((y>>3)+1)>>1  (idct.c:243)
+// (y+8)>>4 (idct.c:243) for a residual that goes on to `clamp255(residual + predictor)` (fragment.c:34-80) and nowhere else: y + 8
+// with SIGNED SATURATION (v_pk_add_i16 clamp), then the shift -- two operations.  Where y + 8 fits 16 bits this is the reference's
+// value; for y in 32760..32767 it is 2047 where the reference has 2048, and with a predictor of 0..255 (or 128) both end as pixel
+// 255.  (The exact residual in three operations, for whoever needs the number itself: ((y >> 3) + 1) >> 1.)
+#ifndef THIP_DESCALE3
+__device__ __forceinline__ pk16 pk_descale(pk16 y) {
+  const pk16 eight = {(short)8, (short)8};
+  return __builtin_elementwise_add_sat(y, eight) >> 4;
+}
+#else
 __device__ __forceinline__ pk16 pk_descale(pk16 y) { return ((y >> 3) + (short)1) >> 1; }
+#endif
 
 // two predictor bytes (k, k+1 of a packed word) -> two int16
 __device__ __forceinline__ pk16 pk_bytes01(uint32_t w) { return as_pk(__builtin_amdgcn_perm(0u, w, 0x0c010c00u)); }
@@ -298,6 +304,18 @@ __device__ __forceinline__ uint32_t sat_pk_u8(pk16 v) {
   asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(as_u32(v)));
   return r;
 }
+// four bytes: clamp255 of lo's two values, then of hi's two.  The second conversion writes the upper half of the register the first
+// one filled (SDWA, the lower half preserved): two operations where shifting and merging the second result takes three.
+#ifndef THIP_NO_SDWA_SAT
+__device__ __forceinline__ uint32_t sat_pk_u8x4(pk16 lo, pk16 hi) {
+  uint32_t r;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(as_u32(lo)));
+  asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r) : "v"(as_u32(hi)));
+  return r;
+}
+#else
+__device__ __forceinline__ uint32_t sat_pk_u8x4(pk16 lo, pk16 hi) { return sat_pk_u8(lo) | (sat_pk_u8(hi) << 16); }
+#endif
 
 // One row of 8 pixels: OC_CLAMP255(residue + predictor), fragment.c:54,64,76.  The add
 // saturates at 16 bits so a residue near +32767 still clamps to 255 like the int sum.
@@ -307,8 +325,8 @@ __device__ __forceinline__ uint2 pk_recon_row(pk16 r01, pk16 r23, pk16 r45, pk16
   const pk16 s45 = __builtin_elementwise_add_sat(r45, pk_bytes01(pred.y));
   const pk16 s67 = __builtin_elementwise_add_sat(r67, pk_bytes23(pred.y));
   uint2 o;
-  o.x = sat_pk_u8(s01) | (sat_pk_u8(s23) << 16);
-  o.y = sat_pk_u8(s45) | (sat_pk_u8(s67) << 16);
+  o.x = sat_pk_u8x4(s01, s23);
+  o.y = sat_pk_u8x4(s45, s67);
   return o;
 }
 

@@ -163,8 +163,8 @@ __device__ __forceinline__ void lf_horz_pk(CellPix &C, int half, int L2) {
   uint32_t *w = half ? C.hi : C.lo;
   const pk16 d01 = pk_lf_delta(pk_bytes01(w[2]), pk_bytes01(w[3]), pk_bytes01(w[4]), pk_bytes01(w[5]), L2);
   const pk16 d23 = pk_lf_delta(pk_bytes23(w[2]), pk_bytes23(w[3]), pk_bytes23(w[4]), pk_bytes23(w[5]), L2);
-  const uint32_t n3 = sat_pk_u8(pk_bytes01(w[3]) + d01) | sat_pk_u8(pk_bytes23(w[3]) + d23) << 16;
-  const uint32_t n4 = sat_pk_u8(pk_bytes01(w[4]) - d01) | sat_pk_u8(pk_bytes23(w[4]) - d23) << 16;
+  const uint32_t n3 = sat_pk_u8x4(pk_bytes01(w[3]) + d01, pk_bytes23(w[3]) + d23);
+  const uint32_t n4 = sat_pk_u8x4(pk_bytes01(w[4]) - d01, pk_bytes23(w[4]) - d23);
   w[3] = n3;
   w[4] = n4;
 }
@@ -349,16 +349,22 @@ __device__ __forceinline__ void pred_finish(const PredWin &Q, int W, uint2 pred[
   const bool ra = Q.my2 < 0, rb = Q.my2 > 0;   // that sample starts one source row down
   const bool two = (Q.mx2 | Q.my2) != 0;
   if (!__any(Q.border)) {
+    // The two samples of a row are averaged, so which is called the first does not matter: T is the one whose rows are the window's
+    // rows 0..7, U the other -- in the same rows (my2 = 0) or one further down.  One byte selector per sample for all rows, and the
+    // choice of row is made on U's two extracted dwords (not on the three of the window, for both samples, as it used to be).
     const int offA = Q.sx - xw, offB = Q.sx + Q.mx2 - xw;   // 0..4
+    const uint32_t selT = extract_sel(ra ? offB : offA), selU = extract_sel(ra ? offA : offB);
+    const bool down = Q.my2 != 0;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const Row12 wa = ra ? Q.w[r + 1] : Q.w[r];
-      pred[r] = extract8(wa, offA);
-      if (two) {
-        const Row12 wb = rb ? Q.w[r + 1] : Q.w[r];
-        const uint2 b = extract8(wb, offB);
-        pred[r].x = avg4_trunc(pred[r].x, b.x);
-        pred[r].y = avg4_trunc(pred[r].y, b.y);
+    for (int r = 0; r < 8; r++) pred[r] = extract8s(Q.w[r], selT);
+    if (two) {
+      uint2 u = extract8s(Q.w[0], selU);
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const uint2 n = extract8s(Q.w[r + 1], selU);
+        pred[r].x = avg4_trunc(pred[r].x, down ? n.x : u.x);
+        pred[r].y = avg4_trunc(pred[r].y, down ? n.y : u.y);
+        u = n;
       }
     }
   } else {
