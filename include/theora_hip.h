@@ -321,6 +321,34 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl);
    _begin(st, tl) followed by _finish(st, tl->dc). */
 int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl);
 int thip_state_token_lists_finish(thip_state *st, const int16_t *dc);
+/* The lists in GROUPS of zig-zag indices, as the entropy decoder finishes them (decode.c:993-1139 reads index after index, all
+   three planes of one before the next): _open takes the frame's description without its tokens (tl->tokens, ntokens, list_off,
+   list_len, eob_carry, arrivals and dc are ignored) and prepares the device; every _append hands over the lists of the indices
+   [z0, z1) -- `tokens` holds just those, list_off[p][z] counts from its start, the four tables are read at columns z0..z1-1 only --
+   and the device walks them while the caller decodes the next indices; the groups come in order and without gaps (the first
+   z0 is 0, each z0 the z1 before it, THIP_EINVAL otherwise); after the group that ends at 64, _finish as above.  _abort gives up a
+   frame that was opened (a group failed its checks: the state is as it was before _open).  _begin(st, tl) is _open(st, tl)
+   followed by _append(st, 0, 64, tl->tokens, tl->ntokens, tl->list_off, ...).  All pointers are host memory, read before return;
+   one thread at a time per state (the calls of one frame may come from different threads, one after the other). */
+int thip_state_token_lists_open(thip_state *st, const thip_token_lists *tl);
+/* The pinned buffer the device reads a frame's arrays from, for a caller that writes them there itself: `coded`, `frag_meta`
+   (one entry per fragment of the frame at most), `dequant` ([18][64]) and `tokens` (token_capacity entries).  Pointers handed to
+   _open / _append that ARE these are not copied: tl->coded == coded, tl->frag_meta == frag_meta, tl->dequant == dequant, and the
+   tokens of a group written at tokens + n, n = the tokens handed over before it rounded up to a multiple of 4.  The call waits
+   until the device is done with the previous frame's contents; the pointers hold until the frame's _finish or _abort.
+   THIP_EIMPL where _open would return it for the frame size. */
+typedef struct thip_token_staging {
+  int32_t *coded;
+  uint32_t *frag_meta;
+  uint16_t *dequant;
+  uint32_t *tokens;
+  int64_t token_capacity;
+} thip_token_staging;
+int thip_state_token_lists_staging(thip_state *st, thip_token_staging *out);
+int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t *tokens, int64_t ntokens,
+                                  const uint32_t (*list_off)[64], const uint32_t (*list_len)[64],
+                                  const uint32_t (*eob_carry)[64], const uint32_t (*arrivals)[64]);
+int thip_state_token_lists_abort(thip_state *st);
 /* on != 0: the DC coefficient handed to thip_state_frag_recon (dct_coeffs[0]) is the value decoded from
    the tokens, NOT yet un-predicted: the caller skips its oc_dec_dc_unpredict_mcu_plane calls
    (decode.c:2869) and thip_frame_flush undoes the prediction on the device before reconstructing
@@ -516,6 +544,16 @@ const char *thip_version_string(void);
  *   fe_device_lists   th_decode_*: the token lists go to the device as the entropy decoder leaves them: 1 on, 0 off, -1 (default)
  *                on while at most four decoder contexts are alive in the process and neither of the two above is set (one to
  *                four streams decode a fifth faster that way, sixteen slower); TH_DECCTL_THIP_SET_DEVICE_LISTS per context
+ *   fe_groups    th_decode_*, token-list path: how many groups of zig-zag indices a frame's lists go to the device in WHILE the packet is
+ *                being decoded (thip_state_token_lists_open / _append; boundaries in thip_frontend.cpp, kFeGroupEnd*): 4 (default), 9, 5,
+ *                3, 2; 1: in one piece after the packet's last bit (thip_state_token_lists_begin).  More groups start the device
+ *                earlier and cost a pair of launches each
+ *   fe_worker    th_decode_*, token-list path: 1 (default): the context has a second thread that undoes the DC prediction (spec 7.8;
+ *                decode.c:1392-1500) while th_decode_packetin's caller decodes the tokens of indices 1..63; 0: the caller does it
+ *                behind the tokens.  With fe_groups = 4: +13..16 % for one stream (720p typical, 1080p, 4K), +29..37 % for four 1080p / 4K streams
+ *   fe_worker_pin   fe_worker on: 1 (default): that thread is kept (pthread_setaffinity_np) on the CPUs that share a last-level
+ *                cache with the thread that calls th_decode_packetin (the two hand each other a frame's flags, lists and DC values);
+ *                0: left to the scheduler (measured 5-10 % SLOWER than no second thread on a two-socket host)
  *   fe_levels    th_decode_*: 1: the host's own token walk feeds thip_state_frag_recon_levels; 0 (default): thip_state_frag_recon --
  *                measured equal within 2 % end to end (the walk is bound by the tokens, not by the 64 bytes a block saved)
  *   fe_trace_backend, fe_prof   th_decode_*: record slot calls instead of running them (tests); per-stage host timing

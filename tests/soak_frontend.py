@@ -15,6 +15,13 @@ while time.time() - t0 < limit:
     fmt = int(rng.choice([0, 2, 3]))
     trees = str(rng.choice(["random", "matched"]))
     seed = int(rng.integers(1 << 30))
-    T.run_stream(theora_amd, w, h, fmt, seed=seed, nframes=int(rng.integers(4, 10)), kf=int(rng.integers(2, 6)), trees=trees)
+    # the path behind the entropy decoder: the host's own walk, the token lists on the device (in one piece or in groups of indices,
+    # the DC chain on the caller's thread or on the context's second one), or the library's choice
+    lists = [False, True, True, None][int(rng.integers(4))]
+    L = theora_amd._lib.load()
+    L.thip_set_option(b"fe_groups", int(rng.choice([1, 2, 3, 4, 5, 9])))
+    L.thip_set_option(b"fe_worker", int(rng.integers(2)))
+    T.run_stream(theora_amd, w, h, fmt, seed=seed, nframes=int(rng.integers(4, 10)), kf=int(rng.integers(2, 6)), trees=trees,
+                 device_lists=lists)
     cases += 1
 print("front-end soak: %d streams bit-exact, %.0f s" % (cases, time.time() - t0))

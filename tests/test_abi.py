@@ -60,6 +60,10 @@ def test_argument_validation_without_gpu():
     assert L.thip_state_decode_token_lists(None, None) == _lib.EFAULT
     assert L.thip_state_token_lists_begin(None, None) == _lib.EFAULT
     assert L.thip_state_token_lists_finish(None, None) == _lib.EFAULT
+    assert L.thip_state_token_lists_open(None, None) == _lib.EFAULT
+    assert L.thip_state_token_lists_append(None, 0, 64, None, 0, None, None, None, None) == _lib.EFAULT
+    assert L.thip_state_token_lists_abort(None) == _lib.EFAULT
+    assert L.thip_state_token_lists_staging(None, None) == _lib.EFAULT
 
 
 def test_loop_filter_init_slot_matches_oracle_table():

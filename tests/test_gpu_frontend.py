@@ -97,6 +97,61 @@ def test_packets_decode_bit_exact_with_the_token_lists_on_the_gpu(hip, w, h, fmt
                       device_dc=device_dc) >= 3
 
 
+@pytest.mark.parametrize("groups,worker", [(1, 0), (1, 1), (4, 0), (9, 1), (2, 1)])
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (336, 32, 0), (1280, 720, 0), (1920, 1088, 0)])
+def test_packets_decode_bit_exact_with_the_token_lists_in_groups(hip, w, h, fmt, groups, worker):
+    """The token-list path's two options.  fe_groups: the lists go to the device in one piece after the packet's last bit
+    (1: thip_state_token_lists_begin) or in groups of zig-zag indices while the caller still decodes
+    (thip_state_token_lists_staging / _open / _append, k_tok_assign launched once per group, the fragments' positions kept
+    between the launches; the default of 4 is what the other tests run).  fe_worker: the DC prediction undone by the caller
+    behind the tokens (0) or by the context's second thread beside them."""
+    L = hip._lib.load()
+    L.thip_set_option(b"fe_groups", groups)
+    L.thip_set_option(b"fe_worker", worker)
+    try:
+        assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_lists=True) >= 3
+    finally:
+        L.thip_set_option(b"fe_groups", 4)
+        L.thip_set_option(b"fe_worker", 1)
+
+
+def test_token_list_groups_come_in_order(hip):
+    """thip_state_token_lists_append: the first group starts at index 0, each at the end of the one before, _finish wants
+    them all; _abort gives an opened frame up."""
+    import ctypes as C
+
+    class TL(C.Structure):
+        _fields_ = [("frame_type", C.c_int32), ("flimit", C.c_int32), ("tokens", C.c_void_p), ("ntokens", C.c_int64),
+                    ("list_off", C.c_uint32 * 64 * 3), ("list_len", C.c_uint32 * 64 * 3), ("eob_carry", C.c_uint32 * 64 * 3),
+                    ("arrivals", C.c_uint32 * 64 * 3), ("coded", C.c_void_p), ("frag_meta", C.c_void_p),
+                    ("ncoded", C.c_int32 * 3), ("dequant", C.c_void_p), ("dc_quant", C.c_uint16 * 2 * 3), ("dc", C.c_void_p)]
+
+    L = hip._lib.load()
+    st = hip.State(64, 48, 0)
+    tl = TL()
+    tl.frame_type = 1   # an inter frame with nothing coded
+    z = (C.c_uint32 * 64 * 3)()
+    EINVAL = hip._lib.EINVAL
+    assert L.thip_state_token_lists_abort(st.handle) == EINVAL                       # nothing opened
+    assert L.thip_state_token_lists_append(st.handle, 0, 64, None, 0, z, z, z, z) == EINVAL
+    assert L.thip_state_token_lists_open(st.handle, C.byref(tl)) == 0
+    assert L.thip_state_token_lists_open(st.handle, C.byref(tl)) == EINVAL           # one frame at a time
+    assert L.thip_state_token_lists_append(st.handle, 1, 2, None, 0, z, z, z, z) == EINVAL   # starts at 0
+    assert L.thip_state_token_lists_append(st.handle, 0, 0, None, 0, z, z, z, z) == EINVAL   # not empty
+    assert L.thip_state_token_lists_append(st.handle, 0, 5, None, 0, z, z, z, z) == 0
+    assert L.thip_state_token_lists_append(st.handle, 6, 64, None, 0, z, z, z, z) == EINVAL  # a gap
+    assert L.thip_state_token_lists_finish(st.handle, None) == EINVAL                # indices 5..63 still to come
+    assert L.thip_state_token_lists_append(st.handle, 5, 65, None, 0, z, z, z, z) == EINVAL
+    assert L.thip_state_token_lists_append(st.handle, 5, 64, None, 0, z, z, z, z) == 0
+    assert L.thip_state_token_lists_finish(st.handle, None) == hip._lib.DUPFRAME
+    assert L.thip_state_token_lists_open(st.handle, C.byref(tl)) == 0
+    assert L.thip_state_token_lists_abort(st.handle) == 0
+    assert L.thip_state_token_lists_open(st.handle, C.byref(tl)) == 0
+    assert L.thip_state_token_lists_append(st.handle, 0, 64, None, 0, z, z, z, z) == 0
+    assert L.thip_state_token_lists_finish(st.handle, None) == hip._lib.DUPFRAME
+    st.close()
+
+
 @pytest.mark.parametrize("lists", [False, None])
 def test_packets_decode_bit_exact_720p(hip, lists):
     """BASELINE.json's 720p size through the whole API (key frame + inter frames of three densities),

@@ -68,6 +68,10 @@ SYMBOLS = [
     ("thip_state_decode_token_lists", _I, [_P, _P]),
     ("thip_state_token_lists_begin", _I, [_P, _P]),
     ("thip_state_token_lists_finish", _I, [_P, _P]),
+    ("thip_state_token_lists_open", _I, [_P, _P]),
+    ("thip_state_token_lists_append", _I, [_P, _I, _I, _P, C.c_int64, _P, _P, _P, _P]),
+    ("thip_state_token_lists_abort", _I, [_P]),
+    ("thip_state_token_lists_staging", _I, [_P, _P]),
     ("thip_state_read_pp_plane", _I, [_P, _I, _P]),
     ("thip_decode_frames", _I, [C.POINTER(_P), C.POINTER(FrameDesc), _I, _P, C.POINTER(C.c_int32)]),
     ("thip_synchronize", _I, []),

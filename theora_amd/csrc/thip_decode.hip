@@ -77,6 +77,9 @@ Option g_options[] = {
     {"fe_device_dc", 0, "th_decode_*: DC un-prediction on the device"},
     {"fe_device_tokens", 0, "th_decode_*: token expansion + dequantisation on the device (host-delimited tokens)"},
     {"fe_device_lists", -1, "th_decode_*: the token lists themselves on the device (1 on, 0 off, -1 on while at most four decoder contexts are alive)"},
+    {"fe_groups", 4, "th_decode_*, token-list path: the groups of zig-zag indices a frame's lists are handed over in while the packet is still being decoded: 4 (default), 9, 5, 3, 2, or 1: in one piece after the packet's last bit"},
+    {"fe_worker", 1, "th_decode_*, token-list path: 1 (default): a second thread per context undoes the DC prediction while the caller decodes the tokens of indices 1..63; 0: the caller does it behind the tokens"},
+    {"fe_worker_pin", 1, "th_decode_*, fe_worker on: 1 (default): the second thread is kept on the CPUs that share a last-level cache with the caller's; 0: left to the scheduler"},
     {"fe_levels", 0, "th_decode_*: 1: the host's own token walk hands the slots quantised levels (thip_state_frag_recon_levels: the kernel dequantises); 0 (default): dequantised coefficients"},
     {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
@@ -232,6 +235,11 @@ struct thip_state {
   thip_frame_desc tl_desc;
   int64_t tl_ncoded;
   size_t tl_o_dcv;          // where the caller's DC values go in h_tl / d_tl (dwords)
+  size_t tl_o_tok;          // where the tokens start
+  int tl_z;                 // indices handed over so far (thip_state_token_lists_append)
+  int64_t tl_ntok;          // tokens staged so far
+  uint8_t *d_tl_pos;        // k_tok_assign's fragment positions between the launches of a frame
+  int tl_claimed;           // thip_state_token_lists_staging has handed the staging buffer out for the frame to come
   hipStream_t tl_stream;
   int32_t *d_frag_pos;      // [nfrags], uploaded once
   // out-of-loop post-processing (thip_state_postprocess): the post-processed picture, the per-fragment
@@ -658,6 +666,7 @@ void thip_state_free(thip_state *st) {
   if (st->d_tl_last) (void)hipFree(st->d_tl_last);
   if (st->d_tl_slot) (void)hipFree(st->d_tl_slot);
   if (st->d_tl_arr) (void)hipFree(st->d_tl_arr);
+  if (st->d_tl_pos) (void)hipFree(st->d_tl_pos);
   if (st->d_frag_pos) (void)hipFree(st->d_frag_pos);
   if (st->pp_frame) (void)hipFree(st->pp_frame);
   if (st->pp_var) (void)hipFree(st->pp_var);
@@ -1979,11 +1988,74 @@ int thip_frame_flush(thip_state *st) {
 }
 
 // ---- the frame's token lists, expanded on the device (thip_tokens.h) ---------------------------------------
-int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl) {
+// staging layout of the token-list path (dwords; 16-byte sections): header tables | coded list | fragment words | the caller's DC values |
+// dequantisation tables | tokens
+struct TlLayout {
+  size_t nf, o_cl, o_meta, o_dcv, o_dq, o_tok;
+  int pos_pitch;
+};
+static TlLayout tl_layout(const thip_state *st) {
+  TlLayout y;
+  y.nf = ((size_t)st->nfrags + 7) & ~(size_t)7;   // (whole 16-byte units of every element size used)
+  y.o_cl = THIP_TL_HDR;
+  y.o_meta = y.o_cl + y.nf;
+  y.o_dcv = y.o_meta + y.nf;
+  y.o_dq = y.o_dcv + y.nf / 2;
+  y.o_tok = y.o_dq + 18 * 64 / 2;
+  y.pos_pitch = (int)(((size_t)std::min<int64_t>(st->nfrags, kTlMaxFrags) + 31 + 15) & ~(size_t)15);
+  return y;
+}
+static int64_t tl_token_capacity(const thip_state *st) { return (int64_t)st->nfrags * 64 + 192 + 192; }   // (+ the groups' padding to 16-byte units)
+static int tl_ensure(thip_state *st) {
+  if (st->tl_ready) return THIP_OK;
+  const TlLayout y = tl_layout(st);
+  // (each buffer on its own: a failed allocation is retried by the next call, nothing is used before all exist)
+  st->tl_cap = (y.o_tok + (size_t)tl_token_capacity(st) + 8) * 4;
+  if (!st->h_tl) HIP_TRY(hipHostMalloc((void **)&st->h_tl, st->tl_cap, hipHostMallocDefault));
+  if (!st->d_tl) HIP_TRY(hipMalloc((void **)&st->d_tl, st->tl_cap));
+  if (!st->d_tl_tmp) HIP_TRY(hipMalloc((void **)&st->d_tl_tmp, (size_t)st->nfrags * 128));
+  if (!st->d_tl_last) HIP_TRY(hipMalloc((void **)&st->d_tl_last, y.nf));
+  if (!st->d_tl_slot) HIP_TRY(hipMalloc((void **)&st->d_tl_slot, y.nf * 4));
+  if (!st->d_tl_arr) HIP_TRY(hipMalloc((void **)&st->d_tl_arr, y.nf * 4));
+  if (!st->d_tl_pos) HIP_TRY(hipMalloc((void **)&st->d_tl_pos, (size_t)y.pos_pitch * 3));
+  if (!st->d_frag_pos) HIP_TRY(hipMalloc((void **)&st->d_frag_pos, y.nf * 4));
+  if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * y.nf));
+  HIP_TRY(hipMemcpy(st->d_frag_pos, st->frag_pos, (size_t)st->nfrags * 4, hipMemcpyHostToDevice));
+  st->tl_ready = 1;
+  return THIP_OK;
+}
+
+// The state's own staging buffer, for a caller that writes the frame's arrays where the device will read them instead of having
+// them copied there: valid from this call -- which waits until the device is done with the previous frame's contents -- to the
+// frame's _finish / _abort.
+int thip_state_token_lists_staging(thip_state *st, thip_token_staging *out) {
+  if (!st || !out) return THIP_EFAULT;
+  if (st->enq_active || st->tl_pending) return THIP_EINVAL;
+  for (int p = 0; p < 3; p++)
+    if (st->geom[p].nvfrags > kDcMaxRows) return THIP_EIMPL;
+  DeviceGuard dg(st->device);
+  int rc = tl_ensure(st);
+  if (rc) return rc;
+  if (wait_staging_free(st) < 0) return THIP_EFAULT;
+  const TlLayout y = tl_layout(st);
+  out->coded = reinterpret_cast<int32_t *>(st->h_tl + y.o_cl);
+  out->frag_meta = st->h_tl + y.o_meta;
+  out->dequant = reinterpret_cast<uint16_t *>(st->h_tl + y.o_dq);
+  out->tokens = st->h_tl + y.o_tok;
+  out->token_capacity = tl_token_capacity(st);
+  st->tl_claimed = 1;
+  return THIP_OK;
+}
+
+// _open: everything about the frame but its tokens -- checked, staged, the device's work arrays zeroed; _append: the lists of
+// the indices [z0, z1), which k_tok_assign walks at once; _finish: the DC values, the command words, the reconstruction.
+int thip_state_token_lists_open(thip_state *st, const thip_token_lists *tl) {
   if (!st || !tl) return THIP_EFAULT;
   if (st->enq_active || st->tl_pending) return THIP_EINVAL;   // a frame is being enqueued through the slots, or one is waiting for its finish
+  const int claimed = st->tl_claimed;   // (thip_state_token_lists_staging has waited for the buffer already; one frame's worth)
+  st->tl_claimed = 0;
   if (tl->frame_type != THIP_INTRA_FRAME && tl->frame_type != THIP_INTER_FRAME) return THIP_EINVAL;
-  if (tl->flimit < 0 || tl->flimit > 127 || tl->ntokens < 0) return THIP_EINVAL;
+  if (tl->flimit < 0 || tl->flimit > 127) return THIP_EINVAL;
   int64_t ncoded = 0;
   for (int p = 0; p < 3; p++) {
     const thip_plane_geom &g = st->geom[p];
@@ -1991,15 +2063,7 @@ int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl) {
     if (tl->ncoded[p] > kTlMaxFrags || g.nvfrags > kDcMaxRows) return THIP_EIMPL;
     ncoded += tl->ncoded[p];
   }
-  if (ncoded && (!tl->tokens || !tl->coded || !tl->frag_meta || !tl->dequant)) return THIP_EFAULT;
-  if (tl->ntokens > (int64_t)st->nfrags * 64 + 192) return THIP_EINVAL;
-  // the lists lie inside the token array; what they consume is the device's business (a list that asks for more
-  // than it has finds its fragments ended, a longer one has its surplus ignored)
-  for (int p = 0; p < 3; p++)
-    for (int z = 0; z < 64; z++) {
-      if ((int64_t)tl->list_off[p][z] + tl->list_len[p][z] > tl->ntokens) return THIP_EINVAL;
-      if (tl->arrivals[p][z] > (uint32_t)tl->ncoded[p] || tl->eob_carry[p][z] > tl->arrivals[p][z]) return THIP_EINVAL;
-    }
+  if (ncoded && (!tl->coded || !tl->frag_meta || !tl->dequant)) return THIP_EFAULT;
   {
     int64_t c = 0;
     for (int p = 0; p < 3; p++) {
@@ -2030,41 +2094,27 @@ int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl) {
   d.frame_type = tl->frame_type;
   d.flimit = tl->flimit;
   if (ncoded) {
-    // staging layout (16-byte sections): header tables | coded list | fragment words | the caller's DC values | dequantisation tables | tokens
-    const size_t nf = ((size_t)st->nfrags + 7) & ~(size_t)7;   // (whole 16-byte units of every element size used)
-    const size_t o_cl = THIP_TL_HDR, o_meta = o_cl + nf, o_dcv = o_meta + nf, o_dq = o_dcv + nf / 2, o_tok = o_dq + 18 * 64 / 2;
-    if (!st->tl_ready) {   // (each buffer on its own: a failed allocation is retried by the next call, nothing is used before all exist)
-      st->tl_cap = (o_tok + (size_t)st->nfrags * 64 + 192 + 4) * 4;
-      if (!st->h_tl) HIP_TRY(hipHostMalloc((void **)&st->h_tl, st->tl_cap, hipHostMallocDefault));
-      if (!st->d_tl) HIP_TRY(hipMalloc((void **)&st->d_tl, st->tl_cap));
-      if (!st->d_tl_tmp) HIP_TRY(hipMalloc((void **)&st->d_tl_tmp, (size_t)st->nfrags * 128));
-      if (!st->d_tl_last) HIP_TRY(hipMalloc((void **)&st->d_tl_last, nf));
-      if (!st->d_tl_slot) HIP_TRY(hipMalloc((void **)&st->d_tl_slot, nf * 4));
-      if (!st->d_tl_arr) HIP_TRY(hipMalloc((void **)&st->d_tl_arr, nf * 4));
-      if (!st->d_frag_pos) HIP_TRY(hipMalloc((void **)&st->d_frag_pos, nf * 4));
-      HIP_TRY(hipMemcpy(st->d_frag_pos, st->frag_pos, (size_t)st->nfrags * 4, hipMemcpyHostToDevice));
-      st->tl_ready = 1;
-    }
-    if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * nf));
-    // the previous frame's kernels must have read the staging buffer before it is reused
-    if (wait_staging_free(st) < 0) return THIP_EFAULT;
+    const TlLayout y = tl_layout(st);
+    const size_t nf = y.nf, o_cl = y.o_cl, o_meta = y.o_meta, o_dcv = y.o_dcv, o_dq = y.o_dq, o_tok = y.o_tok;
+    const int pos_pitch = y.pos_pitch;
+    rc = tl_ensure(st);
+    if (rc) return rc;
+    // the previous frame's kernels must have read the staging buffer before it is reused (thip_state_token_lists_staging has
+    // seen to that if the caller went through it)
+    if (!claimed && wait_staging_free(st) < 0) return THIP_EFAULT;
     uint32_t *h = st->h_tl;
-    memcpy(h + THIP_TL_OFF, tl->list_off, sizeof(tl->list_off));
-    memcpy(h + THIP_TL_LEN, tl->list_len, sizeof(tl->list_len));
-    memcpy(h + THIP_TL_CARRY, tl->eob_carry, sizeof(tl->eob_carry));
-    memcpy(h + THIP_TL_ARRIVE, tl->arrivals, sizeof(tl->arrivals));
+    memset(h, 0, THIP_TL_HDR * 4);
     for (int p = 0; p < 3; p++)
       for (int q = 0; q < 2; q++) h[THIP_TL_DCQ + p * 2 + q] = tl->dc_quant[p][q];
-    h[THIP_TL_DCQ + 6] = h[THIP_TL_DCQ + 7] = 0;
-    memcpy(h + o_cl, tl->coded, (size_t)ncoded * 4);
-    memcpy(h + o_meta, tl->frag_meta, (size_t)ncoded * 4);
-    memcpy(h + o_dq, tl->dequant, 18 * 64 * 2);
-    memcpy(h + o_tok, tl->tokens, (size_t)tl->ntokens * 4);
+    // (arrays the caller wrote into the staging buffer itself are where they belong)
+    if ((const void *)tl->coded != (const void *)(h + o_cl)) memcpy(h + o_cl, tl->coded, (size_t)ncoded * 4);
+    if ((const void *)tl->frag_meta != (const void *)(h + o_meta)) memcpy(h + o_meta, tl->frag_meta, (size_t)ncoded * 4);
+    if ((const void *)tl->dequant != (const void *)(h + o_dq)) memcpy(h + o_dq, tl->dequant, 18 * 64 * 2);
     const size_t npos = (size_t)st->tiles.ntiles * THIP_TILE_FRAGS;
     TlPrepK P;
     P.src = reinterpret_cast<const int4 *>(st->h_tl);
     P.dst = reinterpret_cast<int4 *>(st->d_tl);
-    P.ncopy = (o_tok + (size_t)tl->ntokens + 3) / 4;
+    P.ncopy = o_tok / 4;
     P.z[0] = reinterpret_cast<int4 *>(st->d_tl_tmp);
     P.nz[0] = (size_t)ncoded * 8;
     P.z[1] = reinterpret_cast<int4 *>(st->d_info);
@@ -2092,23 +2142,14 @@ int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl) {
     K.slot0 = st->d_slot0;
     K.coeffs = reinterpret_cast<int4 *>(st->d_coeffs);
     K.ncoded = (int)ncoded;
-    int c0 = 0, nmax = 0;
+    K.pos_save = st->d_tl_pos;
+    K.pos_pitch = pos_pitch;
+    int c0 = 0;
     for (int p = 0; p < 3; p++) {
       K.p[p].n = tl->ncoded[p];
       K.p[p].c0 = c0;
       c0 += tl->ncoded[p];
-      nmax = std::max(nmax, (int)tl->ncoded[p]);
     }
-    if (nmax <= kTlLdsFrags) {
-      const int lds = 2 * ((nmax + 31) & ~31) + 2 * nmax + 16;
-      HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<false>), 2 * ((kTlLdsFrags + 31) & ~31) + 2 * kTlLdsFrags + 16, 2));
-      hipLaunchKernelGGL(k_tok_assign<false>, dim3(3), dim3(tl_threads(nmax)), (size_t)lds, s, K);
-    } else {   // (4K luma: the rank -> fragment map in memory, the positions alone in LDS)
-      const int lds = ((nmax + 31) & ~31) + 16;
-      HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<true>), kTlMaxFrags + 32, 1));
-      hipLaunchKernelGGL(k_tok_assign<true>, dim3(3), dim3(tl_threads(nmax)), (size_t)lds, s, K);
-    }
-    hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
     HIP_TRY(hipGetLastError());
     d.frag_info = st->d_info;
     d.coeffs = st->d_coeffs;
@@ -2117,17 +2158,106 @@ int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl) {
     d.ncoded = (int)ncoded;
     st->tl_K = K;
     st->tl_o_dcv = o_dcv;
+    st->tl_o_tok = o_tok;
   }
   st->tl_desc = d;
   st->tl_ncoded = ncoded;
   st->tl_stream = s;
   st->tl_pending = 1;
+  st->tl_z = 0;
+  st->tl_ntok = 0;
   return THIP_OK;
+}
+
+int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t *tokens, int64_t ntokens, const uint32_t (*list_off)[64],
+                                  const uint32_t (*list_len)[64], const uint32_t (*eob_carry)[64], const uint32_t (*arrivals)[64]) {
+  if (!st) return THIP_EFAULT;
+  if (!st->tl_pending || z0 != st->tl_z || z1 <= z0 || z1 > 64 || ntokens < 0) return THIP_EINVAL;   // the groups come in order, without gaps
+  if (!list_off || !list_len || !eob_carry || !arrivals || (ntokens && !tokens)) return THIP_EFAULT;
+  const int64_t ncoded = st->tl_ncoded;
+  if (!ncoded) {
+    st->tl_z = z1;
+    return THIP_OK;
+  }
+  const TlK &K0 = st->tl_K;
+  // the lists lie inside the token array; what they consume is the device's business (a list that asks for more
+  // than it has finds its fragments ended, a longer one has its surplus ignored)
+  if ((((int64_t)st->tl_ntok + 3) & ~(int64_t)3) + ntokens > tl_token_capacity(st)) return THIP_EINVAL;
+  for (int p = 0; p < 3; p++)
+    for (int z = z0; z < z1; z++) {
+      if ((int64_t)list_off[p][z] + list_len[p][z] > ntokens) return THIP_EINVAL;
+      if (arrivals[p][z] > (uint32_t)K0.p[p].n || eob_carry[p][z] > arrivals[p][z]) return THIP_EINVAL;
+    }
+  DeviceGuard dg(st->device);
+  hipStream_t s = st->tl_stream;
+  uint32_t *h = st->h_tl;
+  const size_t at = ((size_t)st->tl_ntok + 3) & ~(size_t)3;   // the group starts on a 16-byte unit of the token area
+  for (int p = 0; p < 3; p++)
+    for (int z = z0; z < z1; z++) {
+      h[THIP_TL_OFF + p * 64 + z] = (uint32_t)at + list_off[p][z];
+      h[THIP_TL_LEN + p * 64 + z] = list_len[p][z];
+      h[THIP_TL_CARRY + p * 64 + z] = eob_carry[p][z];
+      h[THIP_TL_ARRIVE + p * 64 + z] = arrivals[p][z];
+    }
+  if (ntokens && tokens != h + st->tl_o_tok + at) memcpy(h + st->tl_o_tok + at, tokens, (size_t)ntokens * 4);   // (not if the caller wrote them there)
+  TlCopyK C;
+  C.src[0] = reinterpret_cast<const int4 *>(h);
+  C.dst[0] = reinterpret_cast<int4 *>(st->d_tl);
+  C.n[0] = THIP_TL_HDR / 4;
+  C.src[1] = reinterpret_cast<const int4 *>(h + st->tl_o_tok + at);
+  C.dst[1] = reinterpret_cast<int4 *>(st->d_tl + st->tl_o_tok + at);
+  C.n[1] = ((size_t)ntokens + 3) / 4;
+  const unsigned cgroups = (unsigned)std::min<size_t>(256, (C.n[1] + 255) / 256 + 1);
+  hipLaunchKernelGGL(k_tok_copy, dim3(cgroups), dim3(256), 0, s, C);
+  TlK K = K0;
+  K.z0 = z0;
+  K.z1 = z1;
+  int nmax = 0;
+  for (int p = 0; p < 3; p++) nmax = std::max(nmax, K.p[p].n);
+  if (nmax <= kTlLdsFrags) {
+    const int lds = 2 * ((nmax + 31) & ~31) + 2 * nmax + 16;
+    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<false>), 2 * ((kTlLdsFrags + 31) & ~31) + 2 * kTlLdsFrags + 16, 2));
+    hipLaunchKernelGGL(k_tok_assign<false>, dim3(3), dim3(tl_threads(nmax)), (size_t)lds, s, K);
+  } else {   // (4K luma: the rank -> fragment map in memory, the positions alone in LDS)
+    const int lds = ((nmax + 31) & ~31) + 16;
+    HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<true>), kTlMaxFrags + 32, 1));
+    hipLaunchKernelGGL(k_tok_assign<true>, dim3(3), dim3(tl_threads(nmax)), (size_t)lds, s, K);
+  }
+  if (z1 == 64) hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
+  HIP_TRY(hipGetLastError());
+  st->tl_z = z1;
+  st->tl_ntok = (int64_t)at + ntokens;
+  return THIP_OK;
+}
+
+// A frame opened and not to be finished (a later group failed its checks): the state is where it was before _open.
+int thip_state_token_lists_abort(thip_state *st) {
+  if (!st) return THIP_EFAULT;
+  if (!st->tl_pending) return THIP_EINVAL;
+  st->tl_pending = 0;
+  if (st->tl_ncoded) {   // the launches so far read the staging buffer
+    DeviceGuard dg(st->device);
+    (void)hipStreamSynchronize(st->tl_stream);
+  }
+  return THIP_OK;
+}
+
+int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl) {
+  if (!st || !tl) return THIP_EFAULT;
+  if (tl->ntokens < 0) return THIP_EINVAL;
+  int64_t ncoded = 0;
+  for (int p = 0; p < 3; p++) ncoded += tl->ncoded[p] > 0 ? tl->ncoded[p] : 0;
+  if (ncoded && !tl->tokens) return THIP_EFAULT;
+  int rc = thip_state_token_lists_open(st, tl);
+  if (rc < 0) return rc;
+  rc = thip_state_token_lists_append(st, 0, 64, tl->tokens, tl->ntokens, tl->list_off, tl->list_len, tl->eob_carry, tl->arrivals);
+  if (rc < 0) (void)thip_state_token_lists_abort(st);
+  return rc;
 }
 
 int thip_state_token_lists_finish(thip_state *st, const int16_t *dc) {
   if (!st) return THIP_EFAULT;
-  if (!st->tl_pending) return THIP_EINVAL;
+  if (!st->tl_pending || st->tl_z != 64) return THIP_EINVAL;   // (lists still to come: _append, or _abort)
   st->tl_pending = 0;
   DeviceGuard dg(st->device);
   hipStream_t s = st->tl_stream;

@@ -16,9 +16,14 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/theora_hip.h"
@@ -179,6 +184,42 @@ struct FeProf {
   }
 };
 
+// A frame that goes to the device in GROUPS of zig-zag indices (token-list path, option fe_groups > 1): th_decode_packetin's caller
+// runs the entropy decoder -- index after index, decode.c:993-1139 -- and writes each finished list, in the device's token format,
+// straight into the backend's pinned staging buffer (thip_state_token_lists_staging); whenever a group of indices is complete it is
+// handed over (thip_state_token_lists_append) and the device walks it under the rest of the packet instead of behind it.
+struct FeStream {
+  thip_token_lists tl;             // the frame without its tokens (pointers into the staging buffer)
+  thip_token_staging stg;
+  const int *ends;                 // where the groups end (kFeGroupEnd*)
+  int gi, z0;                      // the group being filled, its first index
+  size_t at, gstart;               // tokens written so far; where the group being filled starts (a multiple of 4)
+  bool overflow;
+  uint32_t list_off[3][64], list_len[3][64];
+  int grp_z0[16], grp_z1[16];
+  size_t grp_start[16];
+  int64_t grp_ntok[16];
+};
+// The context's second thread (option fe_worker): while the caller decodes the tokens of indices 1..63 it undoes the DC prediction
+// (fe_undo_dc: a chain through every plane in raster order that needs the lists of index 0 only) -- 0.15 ms of a 720p frame that
+// used to sit between the packet's last bit and the frame's hand-over.  The launches stay on the caller's thread, and so does
+// everything that touches the token lists: a first version that packed the tokens and built the fragment words on this thread made
+// the DECODER 40 % slower -- every line of the lists went to the other core and had to be fetched back for the next frame.
+struct FeWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool go = false, quit = false;   // a frame to work on / the context is going away (both under mu)
+  std::atomic<int> z0_ready{0};    // the three lists of index 0 are complete
+  std::atomic<int> done{0};        // the DC values of the frame are there
+  // Where it runs: on the CPUs that share a last-level cache with the caller's (option fe_worker_pin).  What the two threads hand each
+  // other -- the coded flags, reference indices and index-0 lists one way, the DC values the other -- crosses between their cores
+  // every frame; through a shared L3 that is tens of nanoseconds a line, across sockets several hundred (4K: the stages that
+  // write those arrays ran 2.7 x slower with the thread left to the scheduler of a two-socket host).
+  cpu_set_t domain;
+  bool placed = false;
+};
+
 struct th_dec_ctx {
   th_info info;
   FeProf prof;
@@ -223,6 +264,8 @@ struct th_dec_ctx {
   // default) on while few decoder contexts are alive: the device side of a frame is 0.3 ms of small dependent kernels -- a gain
   // of a fifth for one to four streams, a queue for sixteen.
   int device_lists;
+  FeWorker *worker;                  // (created with the first frame that takes the token-list path with option fe_worker on)
+  FeStream fs;
   uint32_t arrivals[3][64];          // fragments open at every (plane, index) of the current frame
   std::vector<uint32_t> tl_tokens, tl_meta;
   std::vector<int16_t> tl_dc;            // the un-predicted DC values in coded order (token-list path with the DC chain on the host)
@@ -798,6 +841,257 @@ void build_geometry(th_dec_ctx *d) {
 // ---------------------------------------------------------------------------------------
 // API
 // ---------------------------------------------------------------------------------------
+// ---- 7.8 undo DC prediction (the DC token values are the first coefficient of each block) -----------
+// Needs the lists of index 0 and the frame's coded flags and reference indices, nothing decoded after them: on the token-list path in
+// groups the context's second thread runs it while the caller decodes the other 63 indices (FeWorker).
+namespace {
+void fe_undo_dc(th_dec_ctx *d) {
+  // first pull the DC values out of the zzi == 0 lists: token by token over the coded blocks in order
+  {
+    for (int p = 0; p < 3; p++) {
+      const int *cl = d->clist.data() + d->cl_start[p];
+      const size_t nb = d->cl_start[p + 1] - d->cl_start[p];
+      size_t i = d->eob_carry[p][0] < nb ? d->eob_carry[p][0] : nb;   // blocks ended by a run from before
+      for (size_t j = 0; j < i; j++) d->dc[cl[j]] = 0;
+      const Tok *t = d->toks[p][0].data();
+      for (const Tok *const tend = t + d->ntoks[p][0]; t < tend && i < nb; t++) {
+        if (t->eob) {   // this block and the next eob - 1 have no coefficients at all
+          size_t e = nb - i < t->eob ? nb - i : t->eob;
+          while (e--) d->dc[cl[i++]] = 0;
+        } else d->dc[cl[i++]] = (int16_t)(t->skip == 0 ? t->value : 0);
+      }
+      while (i < nb) d->dc[cl[i++]] = 0;   // (cannot happen: the list covers every coded block)
+    }
+    // Which neighbours predict a block is a question of "coded, and from the same reference frame"
+    // (7.8.1, Table 7.47): one byte per block (reference index, 0xFF = not coded) in an array with a
+    // border of 0xFF all round answers it with four compares and no position tests.
+    // (With thip_state_set_device_dc the backend undoes the prediction itself -- k_dc_unpredict, a wavefront
+    //  per plane -- and the slots below are handed the token values.)
+    for (int p = 0; p < 3 && !d->device_dc; p++) {
+      const int nh = d->nh[p], nv = d->nv[p], W = nh + 2;
+      std::vector<uint8_t> &key = d->dc_key;
+      std::vector<int16_t> &val = d->dc_val;
+      key.assign((size_t)W * (nv + 1) + 1, 0xFF);
+      val.assign((size_t)W * (nv + 1) + 1, 0);
+      for (int y = 0; y < nv; y++) {
+        const int f0 = d->fro[p] + y * nh;
+        uint8_t *kr = &key[(size_t)(y + 1) * W + 1];
+        const uint8_t *__restrict cd = d->coded.data() + f0, *__restrict rf = d->refi.data() + f0;
+        for (int x = 0; x < nh; x++) kr[x] = (uint8_t)(rf[x] | (uint8_t)(cd[x] - 1));   // (coded is 0 or 1: 0xFF where it is 0)
+      }
+      // weights and divisors of Table 7.47, indexed by which neighbours are available (bit 0 left,
+      // 1 up-left, 2 up, 3 up-right); the divisors are powers of two, the division truncates
+      static const int8_t Wt[16][4] = {{0, 0, 0, 0},  {1, 0, 0, 0},   {0, 1, 0, 0},  {1, 0, 0, 0},
+                                       {0, 0, 1, 0},  {1, 0, 1, 0},   {0, 0, 1, 0},  {29, -26, 29, 0},
+                                       {0, 0, 0, 1},  {75, 0, 0, 53}, {0, 1, 0, 1},  {75, 0, 0, 53},
+                                       {0, 0, 1, 0},  {75, 0, 0, 53}, {0, 3, 10, 3}, {29, -26, 29, 0}};
+      static const uint8_t Dsh[16] = {0, 0, 0, 0, 0, 1, 0, 5, 0, 7, 1, 7, 0, 7, 4, 5};
+      int last[3] = {0, 0, 0};
+      for (int y = 0; y < nv; y++) {
+        const int f0 = d->fro[p] + y * nh;
+        const uint8_t *kr = &key[(size_t)(y + 1) * W + 1];
+        int16_t *vr = &val[(size_t)(y + 1) * W + 1];
+        // (the left neighbour's key and value travel in registers: the value is what the next block waits for, and through
+        //  memory it would wait for the store to come back as well)
+        const uint8_t *const ku = kr - W;
+        const int16_t *const vu = vr - W;
+        int lk = 0xFF, lv = 0;
+        for (int x = 0; x < nh; x++) {
+          const int r = kr[x];
+          if (r == 0xFF) {
+            lk = 0xFF;
+            continue;
+          }
+          const int mask = (lk == r) | (ku[x - 1] == r) << 1 | (ku[x] == r) << 2 | (ku[x + 1] == r) << 3;
+          int pred;
+          if ((mask & 7) == 7) {
+            // L, UL and U all present (every interior block of a key frame): (29 L - 26 UL + 29 U) / 32
+            // whether or not UR is, then the outlier clamp (7.8.1 step 5)
+            const int l = lv, ul = vu[x - 1], u = vu[x];
+            const int num = 29 * (l + u) - 26 * ul;
+            pred = (num + ((num >> 31) & 31)) >> 5;   // num / 32, towards zero
+            if (abs(pred - u) > 128) pred = u;
+            else if (abs(pred - l) > 128) pred = l;
+            else if (abs(pred - ul) > 128) pred = ul;
+          } else if (mask == 0) pred = last[r];
+          else {
+            const int l = lv, ul = vu[x - 1], u = vu[x], ur = vu[x + 1];
+            const int num = Wt[mask][0] * l + Wt[mask][1] * ul + Wt[mask][2] * u + Wt[mask][3] * ur;
+            const int sh = Dsh[mask];
+            pred = (num + ((num >> 31) & ((1 << sh) - 1))) >> sh;   // num / 2^sh, towards zero
+          }
+          const int16_t v = (int16_t)(d->dc[f0 + x] + pred);   // 16-bit wrap
+          d->dc[f0 + x] = v;
+          vr[x] = v;
+          last[r] = v;
+          lk = r;
+          lv = v;
+        }
+      }
+    }
+  }
+}
+}  // namespace
+
+// ---- a frame in groups of indices (see FeStream, FeWorker) --------------------------------------------------------------------
+namespace {
+// where a group of indices ends: the lists of low indices are the long ones (a group is worth a pair of launches once the device
+// has a few tens of microseconds of work in it), and the last group is what the device still has to walk when the packet's last bit
+// has been read
+constexpr int kFeGroupEnd9[] = {1, 3, 6, 10, 15, 21, 28, 40, 64};
+constexpr int kFeGroupEnd5[] = {1, 6, 15, 28, 64}, kFeGroupEnd4[] = {3, 10, 28, 64}, kFeGroupEnd3[] = {3, 15, 64}, kFeGroupEnd2[] = {6, 64};
+inline const int *fe_group_ends(int n) {
+  return n >= 9 ? kFeGroupEnd9 : n >= 5 ? kFeGroupEnd5 : n == 4 ? kFeGroupEnd4 : n == 3 ? kFeGroupEnd3 : kFeGroupEnd2;
+}
+
+// the frame's description and its fragment words, written into the staging buffer (caller's thread)
+int fe_stream_open_frame(th_dec_ctx *d, int ngroups) {
+  FeStream &fs = d->fs;
+  const int rc = thip_state_token_lists_staging(d->hip, &fs.stg);
+  if (rc < 0) return rc;
+  thip_token_lists &tl = fs.tl;
+  memset(&tl, 0, sizeof(tl));
+  tl.frame_type = d->frame_type;
+  tl.flimit = d->setup.qp.lflims[d->qis[0]];
+  for (int p = 0; p < 3; p++) {
+    tl.ncoded[p] = (int32_t)(d->cl_start[p + 1] - d->cl_start[p]);
+    for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
+      const int f = d->clist[ci];
+      const uint32_t qti = d->mbmode_of_frag[f] != MODE_INTRA;
+      fs.stg.coded[ci] = f;
+      fs.stg.frag_meta[ci] = (uint32_t)d->refi[f] | ((uint32_t)(p * 3 + d->qii[f]) * 2u + qti) << 2 |
+                             ((uint32_t)d->mvx[f] & 0xFFu) << 8 | ((uint32_t)d->mvy[f] & 0xFFu) << 16 | (uint32_t)p << 24;
+    }
+    for (int qti = 0; qti < 2; qti++) tl.dc_quant[p][qti] = d->dequant[(((size_t)d->qis[0] * 3 + p) * 2 + qti) * 64];
+  }
+  memset(fs.stg.dequant, 0, 18 * 64 * 2);
+  for (int p = 0; p < 3; p++)
+    for (int qii = 0; qii < d->nqis; qii++)
+      for (int qti = 0; qti < 2; qti++)
+        memcpy(fs.stg.dequant + ((p * 3 + qii) * 2 + qti) * 64, &d->dequant[(((size_t)d->qis[qii] * 3 + p) * 2 + qti) * 64], 128);
+  tl.coded = fs.stg.coded;
+  tl.frag_meta = fs.stg.frag_meta;
+  tl.dequant = fs.stg.dequant;
+  fs.ends = fe_group_ends(ngroups);
+  fs.gi = 0;
+  fs.z0 = 0;
+  fs.at = fs.gstart = 0;
+  fs.overflow = false;
+  return 0;
+}
+
+// The three lists of index z are complete: into the staging buffer in the device's token format (thip_tokens.h).  Returns true when
+// that completes a group (its description is in grp_*[gi - 1] then).
+bool fe_stream_pack_index(th_dec_ctx *d, int z) {
+  FeStream &fs = d->fs;
+  for (int p = 0; p < 3; p++) {
+    const size_t nk = d->ntoks[p][z];
+    fs.list_off[p][z] = (uint32_t)(fs.at - fs.gstart);
+    fs.list_len[p][z] = (uint32_t)nk;
+    if (fs.overflow || (int64_t)(fs.at + nk) > fs.stg.token_capacity) {   // (cannot happen: a token closes an open block of its list)
+      fs.overflow = true;
+      fs.list_len[p][z] = 0;
+      continue;
+    }
+    const Tok *__restrict t = d->toks[p][z].data();
+    uint32_t *__restrict w = fs.stg.tokens + fs.at;
+    for (size_t k = 0; k < nk; k++) {   // (branch-free, one list at a time: the compiler vectorises it)
+      const uint32_t e = t[k].eob;
+      const uint32_t run = e > 0xFFFFFFu ? 0xFFFFFFu : e;   // (more than any plane the backend takes has)
+      const uint32_t we = 0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24;
+      const uint32_t wv = (uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16;
+      w[k] = e ? we : wv;
+    }
+    fs.at += nk;
+  }
+  if (z + 1 != fs.ends[fs.gi]) return false;
+  fs.grp_z0[fs.gi] = fs.z0;
+  fs.grp_z1[fs.gi] = z + 1;
+  fs.grp_start[fs.gi] = fs.gstart;
+  fs.grp_ntok[fs.gi] = (int64_t)(fs.at - fs.gstart);
+  fs.gi++;
+  fs.z0 = z + 1;
+  fs.at = (fs.at + 3) & ~(size_t)3;   // the next group starts on a 16-byte unit
+  fs.gstart = fs.at;
+  return true;
+}
+int fe_stream_append(th_dec_ctx *d, int g) {
+  FeStream &fs = d->fs;
+  return thip_state_token_lists_append(d->hip, fs.grp_z0[g], fs.grp_z1[g], fs.stg.tokens + fs.grp_start[g], fs.grp_ntok[g], fs.list_off,
+                                       fs.list_len, d->eob_carry, d->arrivals);
+}
+
+// the CPUs that share the last-level cache of `cpu` (sysfs list format: "0-7,128-135"); false when the host does not say
+bool fe_llc_cpus(int cpu, cpu_set_t *set) {
+  char path[128], buf[512];
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  FILE *f = fopen(path, "r");
+  if (!f) return false;
+  const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+  fclose(f);
+  if (!got) return false;
+  CPU_ZERO(set);
+  int n = 0;
+  for (const char *c = buf; *c && *c != '\n';) {
+    char *e;
+    const long a = strtol(c, &e, 10);
+    if (e == c) return false;
+    long b = a;
+    c = e;
+    if (*c == '-') {
+      b = strtol(c + 1, &e, 10);
+      if (e == c + 1) return false;
+      c = e;
+    }
+    for (long k = a; k <= b && k < CPU_SETSIZE; k++) {
+      CPU_SET((int)k, set);
+      n++;
+    }
+    if (*c == ',') c++;
+  }
+  return n > 1;
+}
+// called by th_decode_packetin's thread before it wakes the worker: keep the worker next to it
+void fe_worker_place(FeWorker &w) {
+  const int cpu = sched_getcpu();
+  if (cpu < 0 || cpu >= CPU_SETSIZE) return;
+  if (w.placed && CPU_ISSET(cpu, &w.domain)) return;   // (the caller has not left the cache domain the worker is in)
+  cpu_set_t set;
+  if (!fe_llc_cpus(cpu, &set)) return;
+  if (pthread_setaffinity_np(w.th.native_handle(), sizeof(set), &set) != 0) return;   // (CPUs outside the process's set: left to the scheduler)
+  w.domain = set;
+  w.placed = true;
+}
+
+// the worker's side of a frame
+void fe_worker_frame(th_dec_ctx *d) {
+  FeWorker &w = *d->worker;
+  // (the lists of index 0 are a few tens of microseconds of the decoder's work away)
+  for (unsigned spins = 0; !w.z0_ready.load(std::memory_order_acquire); spins++) {
+    if (spins < 8192) __builtin_ia32_pause();
+    else std::this_thread::yield();
+  }
+  fe_undo_dc(d);
+  const size_t nc = d->cl_start[3];
+  d->tl_dc.resize(nc + 1);
+  for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
+}
+
+void fe_worker_main(th_dec_ctx *d) {
+  FeWorker &w = *d->worker;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(w.mu);
+      w.cv.wait(lk, [&] { return w.go || w.quit; });
+      if (w.quit) return;
+      w.go = false;
+    }
+    fe_worker_frame(d);
+    w.done.store(1, std::memory_order_release);
+  }
+}
+}  // namespace
+
 extern "C" {
 
 void th_info_init(th_info *info) {
@@ -1041,6 +1335,15 @@ void th_decode_free(th_dec_ctx *d) {
     for (int s = 0; s < FE_NSEC; s++)
       fprintf(stderr, "  %-28s %8.3f ms/frame %5.1f %%\n", kFeNames[s], 1e3 * d->prof.acc[s] / (double)d->prof.frames,
               100.0 * d->prof.acc[s] / tot);
+  }
+  if (d->worker) {
+    {
+      std::lock_guard<std::mutex> lk(d->worker->mu);
+      d->worker->quit = true;
+    }
+    d->worker->cv.notify_one();
+    if (d->worker->th.joinable()) d->worker->th.join();
+    delete d->worker;
   }
   if (d->hip) thip_state_free(d->hip);
   g_fe_contexts.fetch_sub(1, std::memory_order_relaxed);
@@ -1353,6 +1656,43 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     }
   }
   d->prof.lap(FE_QI);
+  // ---- everything behind the entropy decoder on the device, when asked for and possible (decided here: the worker starts now) ----
+  const bool lists_now = !d->trace && d->hip &&
+                         (d->device_lists > 0 || (d->device_lists < 0 && !d->device_dc && !d->device_tokens &&
+                                                  g_fe_contexts.load(std::memory_order_relaxed) <= kFeListsAutoContexts));
+  const int fe_groups = lists_now ? thip_option("fe_groups") : 0;
+  bool streaming = lists_now && fe_groups > 1;   // in groups of indices, as they are decoded (FeStream)
+  int stream_rc = 0;                             // (inline hand-over: the first failure)
+  if (streaming && fe_stream_open_frame(d, fe_groups) < 0) streaming = false;   // (the one-piece path below says why)
+  if (streaming) {
+    stream_rc = thip_state_token_lists_open(d->hip, &d->fs.tl);
+    if (stream_rc < 0) streaming = false;   // (THIP_EIMPL: the slots; anything else: reported by the one-piece path below)
+  }
+  bool with_worker = lists_now && !d->device_dc && thip_option("fe_worker") != 0;   // the DC chain on the second thread
+  if (with_worker && !d->worker) {
+    d->worker = new (std::nothrow) FeWorker();
+    if (d->worker) {
+      try {
+        d->worker->th = std::thread(fe_worker_main, d);
+      } catch (...) {   // (no thread to be had: the caller does it behind the tokens)
+        delete d->worker;
+        d->worker = nullptr;
+      }
+    }
+    if (!d->worker) with_worker = false;
+  }
+  if (with_worker) {
+    FeWorker &w = *d->worker;
+    if (thip_option("fe_worker_pin") != 0) fe_worker_place(w);
+    w.z0_ready.store(0, std::memory_order_relaxed);
+    w.done.store(0, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> lk(w.mu);
+      w.go = true;
+    }
+    w.cv.notify_one();
+  }
+  d->prof.lap(FE_LMETA);
   // ---- 7.7 DCT tokens, unpacked by counts per (plane, index) list -------------------------------------
   {
     size_t left[3][128];   // [64..127]: where advances past the last index land
@@ -1391,105 +1731,60 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         out->value = 0; out->skip = 0; out->adv = 0; out->eob = 0xFFFFFFFFu;
         d->prof.tokens += (long)d->ntoks[p][z];
       }
+      if (z == 0 && with_worker) d->worker->z0_ready.store(1, std::memory_order_release);   // the DC chain can start
+      // the three lists of index z are complete; with them maybe a group
+      if (streaming && fe_stream_pack_index(d, z) && stream_rc >= 0) stream_rc = fe_stream_append(d, d->fs.gi - 1);
     }
   }
   d->prof.lap(FE_TOKENS);
-  // ---- 7.8 undo DC prediction (the DC token values are the first coefficient of each block) -----------
-  // (a function of its own: the token-list path below wants the values before it hands the frame over)
+  // ---- 7.8 undo DC prediction: fe_undo_dc -------------------------------------------------------------
   bool dc_done = false;
   auto undo_dc = [&]() {
     dc_done = true;
-  // first pull the DC values out of the zzi == 0 lists: token by token over the coded blocks in order
-  {
-    for (int p = 0; p < 3; p++) {
-      const int *cl = d->clist.data() + d->cl_start[p];
-      const size_t nb = d->cl_start[p + 1] - d->cl_start[p];
-      size_t i = d->eob_carry[p][0] < nb ? d->eob_carry[p][0] : nb;   // blocks ended by a run from before
-      for (size_t j = 0; j < i; j++) d->dc[cl[j]] = 0;
-      const Tok *t = d->toks[p][0].data();
-      for (const Tok *const tend = t + d->ntoks[p][0]; t < tend && i < nb; t++) {
-        if (t->eob) {   // this block and the next eob - 1 have no coefficients at all
-          size_t e = nb - i < t->eob ? nb - i : t->eob;
-          while (e--) d->dc[cl[i++]] = 0;
-        } else d->dc[cl[i++]] = (int16_t)(t->skip == 0 ? t->value : 0);
-      }
-      while (i < nb) d->dc[cl[i++]] = 0;   // (cannot happen: the list covers every coded block)
+    fe_undo_dc(d);
+  };
+  // (with the second thread: it has been at it since the lists of index 0 were complete, and leaves the values in coded order in tl_dc too)
+  auto join_worker = [&]() {
+    if (!with_worker || dc_done) return;
+    FeWorker &w = *d->worker;
+    for (unsigned spins = 0; !w.done.load(std::memory_order_acquire); spins++) {
+      if (spins < 8192) __builtin_ia32_pause();
+      else std::this_thread::yield();
     }
-    // Which neighbours predict a block is a question of "coded, and from the same reference frame"
-    // (7.8.1, Table 7.47): one byte per block (reference index, 0xFF = not coded) in an array with a
-    // border of 0xFF all round answers it with four compares and no position tests.
-    // (With thip_state_set_device_dc the backend undoes the prediction itself -- k_dc_unpredict, a wavefront
-    //  per plane -- and the slots below are handed the token values.)
-    for (int p = 0; p < 3 && !d->device_dc; p++) {
-      const int nh = d->nh[p], nv = d->nv[p], W = nh + 2;
-      std::vector<uint8_t> &key = d->dc_key;
-      std::vector<int16_t> &val = d->dc_val;
-      key.assign((size_t)W * (nv + 1) + 1, 0xFF);
-      val.assign((size_t)W * (nv + 1) + 1, 0);
-      for (int y = 0; y < nv; y++) {
-        const int f0 = d->fro[p] + y * nh;
-        uint8_t *kr = &key[(size_t)(y + 1) * W + 1];
-        const uint8_t *__restrict cd = d->coded.data() + f0, *__restrict rf = d->refi.data() + f0;
-        for (int x = 0; x < nh; x++) kr[x] = (uint8_t)(rf[x] | (uint8_t)(cd[x] - 1));   // (coded is 0 or 1: 0xFF where it is 0)
-      }
-      // weights and divisors of Table 7.47, indexed by which neighbours are available (bit 0 left,
-      // 1 up-left, 2 up, 3 up-right); the divisors are powers of two, the division truncates
-      static const int8_t Wt[16][4] = {{0, 0, 0, 0},  {1, 0, 0, 0},   {0, 1, 0, 0},  {1, 0, 0, 0},
-                                       {0, 0, 1, 0},  {1, 0, 1, 0},   {0, 0, 1, 0},  {29, -26, 29, 0},
-                                       {0, 0, 0, 1},  {75, 0, 0, 53}, {0, 1, 0, 1},  {75, 0, 0, 53},
-                                       {0, 0, 1, 0},  {75, 0, 0, 53}, {0, 3, 10, 3}, {29, -26, 29, 0}};
-      static const uint8_t Dsh[16] = {0, 0, 0, 0, 0, 1, 0, 5, 0, 7, 1, 7, 0, 7, 4, 5};
-      int last[3] = {0, 0, 0};
-      for (int y = 0; y < nv; y++) {
-        const int f0 = d->fro[p] + y * nh;
-        const uint8_t *kr = &key[(size_t)(y + 1) * W + 1];
-        int16_t *vr = &val[(size_t)(y + 1) * W + 1];
-        // (the left neighbour's key and value travel in registers: the value is what the next block waits for, and through
-        //  memory it would wait for the store to come back as well)
-        const uint8_t *const ku = kr - W;
-        const int16_t *const vu = vr - W;
-        int lk = 0xFF, lv = 0;
-        for (int x = 0; x < nh; x++) {
-          const int r = kr[x];
-          if (r == 0xFF) {
-            lk = 0xFF;
-            continue;
-          }
-          const int mask = (lk == r) | (ku[x - 1] == r) << 1 | (ku[x] == r) << 2 | (ku[x + 1] == r) << 3;
-          int pred;
-          if ((mask & 7) == 7) {
-            // L, UL and U all present (every interior block of a key frame): (29 L - 26 UL + 29 U) / 32
-            // whether or not UR is, then the outlier clamp (7.8.1 step 5)
-            const int l = lv, ul = vu[x - 1], u = vu[x];
-            const int num = 29 * (l + u) - 26 * ul;
-            pred = (num + ((num >> 31) & 31)) >> 5;   // num / 32, towards zero
-            if (abs(pred - u) > 128) pred = u;
-            else if (abs(pred - l) > 128) pred = l;
-            else if (abs(pred - ul) > 128) pred = ul;
-          } else if (mask == 0) pred = last[r];
-          else {
-            const int l = lv, ul = vu[x - 1], u = vu[x], ur = vu[x + 1];
-            const int num = Wt[mask][0] * l + Wt[mask][1] * ul + Wt[mask][2] * u + Wt[mask][3] * ur;
-            const int sh = Dsh[mask];
-            pred = (num + ((num >> 31) & ((1 << sh) - 1))) >> sh;   // num / 2^sh, towards zero
-          }
-          const int16_t v = (int16_t)(d->dc[f0 + x] + pred);   // 16-bit wrap
-          d->dc[f0 + x] = v;
-          vr[x] = v;
-          last[r] = v;
-          lk = r;
-          lv = v;
-        }
-      }
-    }
-  }
+    dc_done = true;
   };
   // ---- everything from here to the pictures on the device, when asked for and possible ------------------
   bool lists_done = false;
-  const bool lists_now = !d->trace && d->hip &&
-                         (d->device_lists > 0 || (d->device_lists < 0 && !d->device_dc && !d->device_tokens &&
-                                                  g_fe_contexts.load(std::memory_order_relaxed) <= kFeListsAutoContexts));
-  if (lists_now) {
+  if (streaming) {
+    // The lists have been going over group by group; the device is a group or two behind.  The DC prediction is undone here
+    // meanwhile (the device needs the values last), then the frame is finished.
+    const size_t nc = d->cl_start[3];
+    const int16_t *dcv = nullptr;
+    if (with_worker) {
+      join_worker();
+      dcv = d->tl_dc.data();
+      d->prof.lap(FE_DC);
+    } else if (!d->device_dc) {
+      undo_dc();
+      d->tl_dc.resize(nc + 1);
+      for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
+      dcv = d->tl_dc.data();
+      d->prof.lap(FE_DC);
+    }
+    int lrc = stream_rc;
+    if (lrc < 0) (void)thip_state_token_lists_abort(d->hip);
+    if (lrc >= 0 && d->fs.overflow) {
+      (void)thip_state_token_lists_abort(d->hip);
+      lrc = THIP_EINVAL;
+    }
+    d->prof.lap(FE_LBEGIN);
+    if (lrc >= 0) {
+      lrc = thip_state_token_lists_finish(d->hip, dcv);
+      d->prof.lap(FE_LFINISH);
+    }
+    if (lrc >= 0) lists_done = true;
+    else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
+  } else if (lists_now) {
     thip_token_lists tl;
     memset(&tl, 0, sizeof(tl));
     tl.frame_type = d->frame_type;
@@ -1553,7 +1848,11 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     d->prof.lap(FE_LBEGIN);
     if (lrc >= 0) {
       const int16_t *dcv = nullptr;
-      if (!d->device_dc) {
+      if (with_worker) {
+        join_worker();
+        dcv = d->tl_dc.data();
+        d->prof.lap(FE_DC);
+      } else if (!d->device_dc) {
         undo_dc();
         d->tl_dc.resize(nc + 1);
         for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
@@ -1563,6 +1862,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
       lrc = thip_state_token_lists_finish(d->hip, dcv);
       d->prof.lap(FE_LFINISH);
     }
+    join_worker();   // (whatever happened: the second thread is done with the context's arrays)
     if (lrc >= 0) lists_done = true;
     else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
     d->prof.lap(FE_EXPAND);

@@ -54,6 +54,11 @@ struct TlK {
   int4 *coeffs;             // coefficient slots, tile layout
   int ncoded;
   TlPlaneK p[3];
+  // the indices this launch of k_tok_assign walks, [z0, z1): a frame's lists may arrive in groups of indices (the entropy decoder
+  // finishes index after index, thip_state_token_lists_append), and between two launches the fragments' next index waits in pos_save
+  int z0, z1;
+  uint8_t *pos_save;        // [3][pos_pitch]
+  int pos_pitch;            // bytes, a multiple of 16, >= the largest plane's coded fragments rounded up to 32
 };
 
 // exclusive prefix sum over the work group (blockDim.x a multiple of 64, at most 1024); scr: 16 dwords of LDS
@@ -184,9 +189,15 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
   const int G = n32 >> 5;                                // groups of 32 fragments
   const int Kg = (G + T - 1) >> lgT;                     // <= kTlGroups
   const int g0 = min(t * Kg, G), g1 = min(g0 + Kg, G);   // this thread's fragments: 32 g0 .. 32 g1 - 1
-  for (int i = t; i < n32 / 4; i += T) {
-    const int left = n - 4 * i;                          // fragments in this dword (the rest is padding that never matches)
-    posw[i] = left >= 4 ? 0u : (left <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8 * left)));
+  const int zend = K.z1;
+  uint32_t *const saved = reinterpret_cast<uint32_t *>(K.pos_save + (size_t)p * K.pos_pitch);
+  if (K.z0 == 0) {
+    for (int i = t; i < n32 / 4; i += T) {
+      const int left = n - 4 * i;                        // fragments in this dword (the rest is padding that never matches)
+      posw[i] = left >= 4 ? 0u : (left <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8 * left)));
+    }
+  } else {
+    for (int i = t; i < n32 / 4; i += T) posw[i] = saved[i];   // where the launch for the indices before z0 left the fragments
   }
   if (!BIG)
     for (int i = t; i < n; i += T) qsl[i] = (uint8_t)((K.meta[c0 + i] >> 2) & 31u);
@@ -253,12 +264,12 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
     }
     TLP(8)
   };
-  int z = 0;
-  while (z < 64 && s_hdr[3][z] == 0) z++;                // (uniform) the first index anybody arrives at
+  int z = K.z0;
+  while (z < zend && s_hdr[3][z] == 0) z++;              // (uniform) the first index anybody arrives at
   uint32_t off = 0, j0 = 0, j1 = 0, use = 0, cur[kTlPrefetch];
 #pragma unroll
   for (int q = 0; q < kTlPrefetch; q++) cur[q] = 0u;
-  if (z < 64) {
+  if (z < zend) {
     share(z, off, j0, j1);
 #pragma unroll
     for (int q = 0; q < kTlPrefetch; q++) cur[q] = j0 + (uint32_t)q < j1 ? K.tok[off + j0 + (uint32_t)q] : 0u;
@@ -270,15 +281,15 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
 #ifdef THIP_TL_PROF
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tq));
 #endif
-  while (z < 64) {
+  while (z < zend) {
     int zn = z + 1;
-    while (zn < 64 && s_hdr[3][zn] == 0) zn++;
+    while (zn < zend && s_hdr[3][zn] == 0) zn++;
     // ---- the next list's first tokens are asked for now; they are looked at before this round's first store goes out (this
     //      chip counts loads and stores in one in-order counter: a load behind a store waits for the store's acknowledgement) ----
     uint32_t offn = 0, j0n = 0, j1n = 0, nx[kTlPrefetch];
 #pragma unroll
     for (int q = 0; q < kTlPrefetch; q++) nx[q] = 0u;
-    if (zn < 64) {
+    if (zn < zend) {
       share(zn, offn, j0n, j1n);
 #pragma unroll
       for (int q = 0; q < kTlPrefetch; q++)
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
     TLP(2)
     // ---- the next list's share of the scan ------------------------------------------------------------------
     uint32_t usen = 0;
-    if (zn < 64) {
+    if (zn < zend) {
 #pragma unroll
       for (int q = 0; q < kTlPrefetch; q++) usen += j0n + (uint32_t)q < j1n ? tl_cost(nx[q]) : 0u;
       for (uint32_t j = j0n + kTlPrefetch; j < j1n; j++) usen += tl_cost(K.tok[offn + j]);
@@ -351,6 +362,10 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
     printf("k_tok_assign plane 0: n %d T %d rounds %d | count %llu scan %llu rank+barrier %llu nextuse %llu serve-rest %llu endbarrier %llu | serve: ranks %llu tables %llu stores %llu (10 ns ticks)\n", n, T, rounds,
            tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8]);
 #endif
+  if (zend < 64) {   // more indices to come: the next launch starts from here
+    for (int i = t; i < n32 / 4; i += T) saved[i] = posw[i];
+    return;
+  }
   // last_zzi (decode.c:1545: the index the fragment's last token -- or the run that ended it -- was met at)
   for (int i = t; i < n; i += T) K.last_zzi[c0 + i] = (uint8_t)(pos[i] < 64 ? pos[i] : pos[i] - 64);
 }
@@ -418,6 +433,18 @@ struct TlPrepK {
   int4 *z[4];
   size_t nz[4];   // 16-byte units
 };
+// A group of lists goes to the device: the header tables (they grow index by index) and the group's tokens.
+struct TlCopyK {
+  const int4 *src[2];
+  int4 *dst[2];
+  size_t n[2];   // 16-byte units
+};
+__global__ __launch_bounds__(256) void k_tok_copy(const TlCopyK C) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x, G = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+    for (size_t i = g; i < C.n[a]; i += G) C.dst[a][i] = C.src[a][i];
+}
 __global__ __launch_bounds__(256) void k_tok_prepare(const TlPrepK P) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x, G = (size_t)gridDim.x * blockDim.x;
   for (size_t i = g; i < P.ncopy; i += G) P.dst[i] = P.src[i];
