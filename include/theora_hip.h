@@ -321,7 +321,7 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl);
    _begin(st, tl) followed by _finish(st, tl->dc). */
 int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl);
 int thip_state_token_lists_finish(thip_state *st, const int16_t *dc);
-/* The lists in GROUPS of zig-zag indices, as the entropy decoder finishes them (decode.c:993-1139 reads index after index, all
+/* The lists in GROUPS of zig-zag indices, as the entropy decoder finishes them (decode.c:1164-1205 reads index after index, all
    three planes of one before the next): _open takes the frame's description without its tokens (tl->tokens, ntokens, list_off,
    list_len, eob_carry, arrivals and dc are ignored) and prepares the device; every _append hands over the lists of the indices
    [z0, z1) -- `tokens` holds just those, list_off[p][z] counts from its start, the four tables are read at columns z0..z1-1 only --
@@ -544,6 +544,9 @@ const char *thip_version_string(void);
  *   fe_device_lists   th_decode_*: the token lists go to the device as the entropy decoder leaves them: 1 on, 0 off, -1 (default)
  *                on while at most four decoder contexts are alive in the process and neither of the two above is set (one to
  *                four streams decode a fifth faster that way, sixteen slower); TH_DECCTL_THIP_SET_DEVICE_LISTS per context
+ *   tl_levels    thip_state_token_lists_* / thip_state_decode_token_lists: 1 (default): the device builds the coefficient slots in
+ *                the levels form (THIP_COEFFS_LEVELS: int8 units, wide tiles where a level needs more; the reconstruction kernel
+ *                dequantises); 0: dequantised int16 slots, as in round 3
  *   fe_groups    th_decode_*, token-list path: how many groups of zig-zag indices a frame's lists go to the device in WHILE the packet is
  *                being decoded (thip_state_token_lists_open / _append; boundaries in thip_frontend.cpp, kFeGroupEnd*): 4 (default), 9, 5,
  *                3, 2; 1: in one piece after the packet's last bit (thip_state_token_lists_begin).  More groups start the device

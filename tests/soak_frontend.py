@@ -21,6 +21,7 @@ while time.time() - t0 < limit:
     L = theora_amd._lib.load()
     L.thip_set_option(b"fe_groups", int(rng.choice([1, 2, 3, 4, 5, 9])))
     L.thip_set_option(b"fe_worker", int(rng.integers(2)))
+    L.thip_set_option(b"tl_levels", int(rng.integers(2)))
     T.run_stream(theora_amd, w, h, fmt, seed=seed, nframes=int(rng.integers(4, 10)), kf=int(rng.integers(2, 6)), trees=trees,
                  device_lists=lists)
     cases += 1

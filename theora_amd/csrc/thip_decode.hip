@@ -77,6 +77,7 @@ Option g_options[] = {
     {"fe_device_dc", 0, "th_decode_*: DC un-prediction on the device"},
     {"fe_device_tokens", 0, "th_decode_*: token expansion + dequantisation on the device (host-delimited tokens)"},
     {"fe_device_lists", -1, "th_decode_*: the token lists themselves on the device (1 on, 0 off, -1 on while at most four decoder contexts are alive)"},
+    {"tl_levels", 1, "token lists on the device (thip_state_token_lists_*): 1 (default): the device writes the coefficient slots in the levels form (int8 units, the reconstruction kernel dequantises); 0: dequantised int16 slots"},
     {"fe_groups", 4, "th_decode_*, token-list path: the groups of zig-zag indices a frame's lists are handed over in while the packet is still being decoded: 4 (default), 9, 5, 3, 2, or 1: in one piece after the packet's last bit"},
     {"fe_worker", 1, "th_decode_*, token-list path: 1 (default): a second thread per context undoes the DC prediction while the caller decodes the tokens of indices 1..63; 0: the caller does it behind the tokens"},
     {"fe_worker_pin", 1, "th_decode_*, fe_worker on: 1 (default): the second thread is kept on the CPUs that share a last-level cache with the caller's; 0: left to the scheduler"},
@@ -240,6 +241,7 @@ struct thip_state {
   int64_t tl_ntok;          // tokens staged so far
   uint8_t *d_tl_pos;        // k_tok_assign's fragment positions between the launches of a frame
   int tl_claimed;           // thip_state_token_lists_staging has handed the staging buffer out for the frame to come
+  uint32_t *d_tl_wide;      // [ntiles] levels form: the tiles whose levels do not all fit eight bits
   hipStream_t tl_stream;
   int32_t *d_frag_pos;      // [nfrags], uploaded once
   // out-of-loop post-processing (thip_state_postprocess): the post-processed picture, the per-fragment
@@ -667,6 +669,7 @@ void thip_state_free(thip_state *st) {
   if (st->d_tl_slot) (void)hipFree(st->d_tl_slot);
   if (st->d_tl_arr) (void)hipFree(st->d_tl_arr);
   if (st->d_tl_pos) (void)hipFree(st->d_tl_pos);
+  if (st->d_tl_wide) (void)hipFree(st->d_tl_wide);
   if (st->d_frag_pos) (void)hipFree(st->d_frag_pos);
   if (st->pp_frame) (void)hipFree(st->pp_frame);
   if (st->pp_var) (void)hipFree(st->pp_var);
@@ -2018,6 +2021,7 @@ static int tl_ensure(thip_state *st) {
   if (!st->d_tl_slot) HIP_TRY(hipMalloc((void **)&st->d_tl_slot, y.nf * 4));
   if (!st->d_tl_arr) HIP_TRY(hipMalloc((void **)&st->d_tl_arr, y.nf * 4));
   if (!st->d_tl_pos) HIP_TRY(hipMalloc((void **)&st->d_tl_pos, (size_t)y.pos_pitch * 3));
+  if (!st->d_tl_wide) HIP_TRY(hipMalloc((void **)&st->d_tl_wide, (((size_t)st->tiles.ntiles + 3) & ~(size_t)3) * 4));
   if (!st->d_frag_pos) HIP_TRY(hipMalloc((void **)&st->d_frag_pos, y.nf * 4));
   if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * y.nf));
   HIP_TRY(hipMemcpy(st->d_frag_pos, st->frag_pos, (size_t)st->nfrags * 4, hipMemcpyHostToDevice));
@@ -2109,7 +2113,15 @@ int thip_state_token_lists_open(thip_state *st, const thip_token_lists *tl) {
     // (arrays the caller wrote into the staging buffer itself are where they belong)
     if ((const void *)tl->coded != (const void *)(h + o_cl)) memcpy(h + o_cl, tl->coded, (size_t)ncoded * 4);
     if ((const void *)tl->frag_meta != (const void *)(h + o_meta)) memcpy(h + o_meta, tl->frag_meta, (size_t)ncoded * 4);
-    if ((const void *)tl->dequant != (const void *)(h + o_dq)) memcpy(h + o_dq, tl->dequant, 18 * 64 * 2);
+    const int levels = THIP_OPT("tl_levels") != 0;
+    if (levels) {   // the tables in the order the reconstruction kernel reads them (thip_pack_dequant_table), where the zig-zag ones would go
+      uint16_t zz[18 * 64];
+      memcpy(zz, tl->dequant, sizeof(zz));   // (the caller may have written them into the staging buffer itself)
+      uint16_t *hp = reinterpret_cast<uint16_t *>(h + o_dq);
+      for (int t = 0; t < 18; t++) thip_pack_dequant_table(hp + t * 64, zz + t * 64);
+    } else if ((const void *)tl->dequant != (const void *)(h + o_dq)) {
+      memcpy(h + o_dq, tl->dequant, 18 * 64 * 2);
+    }
     const size_t npos = (size_t)st->tiles.ntiles * THIP_TILE_FRAGS;
     TlPrepK P;
     P.src = reinterpret_cast<const int4 *>(st->h_tl);
@@ -2123,6 +2135,8 @@ int thip_state_token_lists_open(thip_state *st, const thip_token_lists *tl) {
     P.nz[2] = ((size_t)st->tiles.ntiles + 3) / 4;
     P.z[3] = reinterpret_cast<int4 *>(st->d_dc_in);
     P.nz[3] = nf / 8;
+    P.z[4] = reinterpret_cast<int4 *>(st->d_tl_wide);
+    P.nz[4] = ((size_t)st->tiles.ntiles + 3) / 4;
     hipLaunchKernelGGL(k_tok_prepare, dim3(256), dim3(256), 0, s, P);
     TlK K;
     memset(&K, 0, sizeof(K));
@@ -2144,6 +2158,8 @@ int thip_state_token_lists_open(thip_state *st, const thip_token_lists *tl) {
     K.ncoded = (int)ncoded;
     K.pos_save = st->d_tl_pos;
     K.pos_pitch = pos_pitch;
+    K.levels = levels;
+    K.wide = st->d_tl_wide;
     int c0 = 0;
     for (int p = 0; p < 3; p++) {
       K.p[p].n = tl->ncoded[p];
@@ -2154,8 +2170,12 @@ int thip_state_token_lists_open(thip_state *st, const thip_token_lists *tl) {
     d.frag_info = st->d_info;
     d.coeffs = st->d_coeffs;
     d.tile_slot0 = st->d_slot0;
-    d.nslots = (int)ncoded;      // (an upper bound: the device knows the number)
+    d.nslots = (int)ncoded * (levels ? 2 : 1);   // (an upper bound: the device knows the number)
     d.ncoded = (int)ncoded;
+    if (levels) {
+      d.coeff_format = THIP_COEFFS_LEVELS;
+      d.dequant = reinterpret_cast<const uint16_t *>(st->d_tl + o_dq);
+    }
     st->tl_K = K;
     st->tl_o_dcv = o_dcv;
     st->tl_o_tok = o_tok;
@@ -2223,7 +2243,10 @@ int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t
     HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<true>), kTlMaxFrags + 32, 1));
     hipLaunchKernelGGL(k_tok_assign<true>, dim3(3), dim3(tl_threads(nmax)), (size_t)lds, s, K);
   }
-  if (z1 == 64) hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
+  if (z1 == 64) {
+    if (K.levels) hipLaunchKernelGGL(k_tok_widths, dim3((unsigned)((ncoded + 255) / 256)), dim3(256), 0, s, K);
+    hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
+  }
   HIP_TRY(hipGetLastError());
   st->tl_z = z1;
   st->tl_ntok = (int64_t)at + ntokens;
@@ -2272,7 +2295,8 @@ int thip_state_token_lists_finish(thip_state *st, const int16_t *dc) {
     } else {
       K.dc_host = nullptr;
     }
-    hipLaunchKernelGGL(k_tok_write, dim3((unsigned)(((size_t)ncoded * 8 + 255) / 256)), dim3(256), 0, s, K);
+    if (K.levels) hipLaunchKernelGGL(k_tok_write_levels, dim3((unsigned)(((size_t)ncoded * 8 + 255) / 256)), dim3(256), 0, s, K);
+    else hipLaunchKernelGGL(k_tok_write, dim3((unsigned)(((size_t)ncoded * 8 + 255) / 256)), dim3(256), 0, s, K);
     HIP_TRY(hipGetLastError());
     d.dc_tokens = dc ? nullptr : st->d_dc_in;
   }

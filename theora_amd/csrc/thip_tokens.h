@@ -59,6 +59,11 @@ struct TlK {
   int z0, z1;
   uint8_t *pos_save;        // [3][pos_pitch]
   int pos_pitch;            // bytes, a multiple of 16, >= the largest plane's coded fragments rounded up to 32
+  // levels != 0: the coefficient slots are written in the LEVELS form (include/theora_hip.h: 64-byte units of int8, a tile whose
+  // levels do not all fit eight bits as int16 over two units) and the multiplication of decode.c:1573 is the reconstruction kernel's:
+  // tmp holds the levels as the tokens carry them, `wide` one word per tile, set by whoever meets a level beyond eight bits
+  int levels;
+  uint32_t *wide;           // [ntiles] (zeroed)
 };
 
 // exclusive prefix sum over the work group (blockDim.x a multiple of 64, at most 1024); scr: 16 dwords of LDS
@@ -183,13 +188,15 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
   uint32_t *garr = K.arr + c0;
   const int t = (int)threadIdx.x, T = (int)blockDim.x;
   const int lgT = 31 - __clz(T);                         // (the work group is 256, 512 or 1024 threads: shifts, not divisions)
-  for (int i = t; i < 18 * 64; i += T) s_dq[i] = K.dq[i];
+  if (!K.levels)
+    for (int i = t; i < 18 * 64; i += T) s_dq[i] = K.dq[i];
   if (t < 256) s_hdr[t >> 6][t & 63] = K.hdr[(t >> 6) * 192 + p * 64 + (t & 63)];   // THIP_TL_OFF / _LEN / _CARRY / _ARRIVE
   if (t < 64) s_nat[t] = (uint8_t)tl_nat(t);
   const int G = n32 >> 5;                                // groups of 32 fragments
   const int Kg = (G + T - 1) >> lgT;                     // <= kTlGroups
   const int g0 = min(t * Kg, G), g1 = min(g0 + Kg, G);   // this thread's fragments: 32 g0 .. 32 g1 - 1
   const int zend = K.z1;
+  const bool lv = K.levels != 0;
   uint32_t *const saved = reinterpret_cast<uint32_t *>(K.pos_save + (size_t)p * K.pos_pitch);
   if (K.z0 == 0) {
     for (int i = t; i < n32 / 4; i += T) {
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
   } else {
     for (int i = t; i < n32 / 4; i += T) posw[i] = saved[i];   // where the launch for the indices before z0 left the fragments
   }
-  if (!BIG)
+  if (!BIG && !K.levels)
     for (int i = t; i < n; i += T) qsl[i] = (uint8_t)((K.meta[c0 + i] >> 2) & 31u);
   __syncthreads();
   // this thread's share [j0, j1) of a list's tokens
@@ -242,13 +249,13 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
 #pragma unroll
     for (int q = 0; q < kTlPrefetch; q++) {
       at[q] = z + (int)((tk[q] >> 16) & 127u);
-      qs[q] = !live[q] ? 0u : (BIG ? (K.meta[c0 + fi[q]] >> 2) & 31u : (uint32_t)qsl[fi[q]]);
+      qs[q] = (!live[q] || lv) ? 0u : (BIG ? (K.meta[c0 + fi[q]] >> 2) & 31u : (uint32_t)qsl[fi[q]]);
       nat[q] = s_nat[at[q] & 63];
       cf[q] = (live[q] && at[q] == 0 && (tk[q] & 0xFFFFu)) ? K.clist[c0 + fi[q]] : 0;   // (DC tokens: the fragment's number)
     }
     int fac[kTlPrefetch];
 #pragma unroll
-    for (int q = 0; q < kTlPrefetch; q++) fac[q] = (int)s_dq[qs[q] * 64 + (uint32_t)(at[q] & 63)];
+    for (int q = 0; q < kTlPrefetch; q++) fac[q] = lv ? 1 : (int)s_dq[qs[q] * 64 + (uint32_t)(at[q] & 63)];
     asm volatile("" ::"v"(fac[0]), "v"(fac[1]), "v"(fac[2]), "v"(fac[3]), "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]));
     TLP(7)
 #pragma unroll
@@ -257,7 +264,10 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
       const int value = (int)(int16_t)(tk[q] & 0xFFFFu);
       if (value != 0) {
         if (at[q] == 0) K.dc_in[cf[q]] = (int16_t)value;   // the DC token value (un-predicted later, or the caller's is used)
-        else if (at[q] <= 63) K.tmp[(size_t)(c0 + fi[q]) * 64 + nat[q]] = (int16_t)(value * fac[q]);   // decode.c:1573
+        else if (at[q] <= 63) {
+          K.tmp[(size_t)(c0 + fi[q]) * 64 + nat[q]] = (int16_t)(value * fac[q]);   // decode.c:1573 (levels form: the level itself)
+          if (lv && (value > 127 || value < -128)) K.wide[K.frag_pos[K.clist[c0 + fi[q]]] >> 6] = 1u;   // (rare) the fragment's tile turns wide
+        }
       }
       const int np = at[q] + (value != 0 ? 1 : 0);
       pos[fi[q]] = (uint8_t)(np < 64 ? np : 64 + z);   // (np <= 63 + 64)
@@ -371,19 +381,32 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
 }
 #undef TLP
 
+// Levels form: which fragments lie in a wide tile -- bit 7 of their last_zzi byte (a thread per coded fragment: k_tok_slots, a single
+// work group that walks the fragments in a loop, would pay the two dependent look-ups fragment after fragment).
+__global__ __launch_bounds__(256) void k_tok_widths(const TlK K) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= K.ncoded) return;
+  if (K.wide[K.frag_pos[K.clist[i]] >> 6]) K.last_zzi[i] |= 0x80u;
+}
+
 // Slots are handed out in coded order to the fragments that need one (last_zzi >= 2, state.c:967).  One group.
 __global__ __launch_bounds__(1024) void k_tok_slots(const TlK K) {
   __shared__ uint32_t s_scr[16];
   const int t = (int)threadIdx.x, T = (int)blockDim.x, n = K.ncoded;
   const int Kf = (n + T - 1) / T;
   const int f0 = min(t * Kf, n), f1 = min(f0 + Kf, n);
+  // (levels form: a block of a wide tile takes two units -- bit 7 of its last_zzi byte, k_tok_widths)
+  auto need = [&](int i) -> uint32_t {
+    const uint32_t lz = K.last_zzi[i];
+    return (lz & 0x7Fu) < 2u ? 0u : 1u + (lz >> 7);
+  };
   uint32_t cnt = 0;
-  for (int i = f0; i < f1; i++) cnt += K.last_zzi[i] >= 2 ? 1u : 0u;
+  for (int i = f0; i < f1; i++) cnt += need(i);
   uint32_t total;
   uint32_t s = tl_exscan(cnt, s_scr, total);
   for (int i = f0; i < f1; i++) {
     K.slot[i] = s;
-    s += K.last_zzi[i] >= 2 ? 1u : 0u;
+    s += need(i);
   }
 }
 
@@ -424,14 +447,61 @@ __global__ __launch_bounds__(256) void k_tok_write(const TlK K) {
   }
 }
 
+// The same in the levels form.  Eight threads per coded fragment again: thread q = 2j + h holds columns 4h..4h+3 of rows 2j, 2j+1 -- half
+// of piece j of a narrow unit (eight int8: dwords 2h and 2h+1, bytes {x[2j][2d], x[2j][2d+1], x[2j+1][2d], x[2j+1][2d+1]}), or piece q of a
+// wide block (int16 pairs, piece q of the block that starts at unit u lies in unit u + (q >> 2), piece q & 3).  The command word carries
+// qii (the reconstruction kernel picks the table), word 1 the raw DC of EVERY block (coefficient 0 of a unit stays zero), the tile's
+// first unit bit 31 when the tile is wide.
+__global__ __launch_bounds__(256) void k_tok_write_levels(const TlK K) {
+  const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int i = g >> 3, q = g & 7;
+  if (i >= K.ncoded) return;
+  const int lzw = K.last_zzi[i], lz = lzw & 0x7F;
+  const uint32_t m = K.meta[i];
+  const int pos = K.frag_pos[K.clist[i]];
+  const uint32_t unit = K.slot[i];
+  const bool wide = (lzw & 0x80) != 0;
+  if (q == 0) {
+    const uint32_t pli = (m >> 24) & 3u, tab = (m >> 2) & 31u, qti = tab & 1u, qii = (tab >> 1) % 3u;
+    const uint32_t dcq = K.hdr[THIP_TL_DCQ + pli * 2 + qti];
+    uint32_t flags = THIP_INFO_CODED | (m & 3u) << THIP_INFO_REFI_SHIFT | qii << THIP_INFO_QII_SHIFT | (uint32_t)lz << THIP_INFO_LAST_ZZI_SHIFT |
+                     ((m >> 8) & 0xFFu) << THIP_INFO_MVX_SHIFT | ((m >> 16) & 0xFFu) << THIP_INFO_MVY_SHIFT;
+    if (lz < 2) flags |= THIP_INFO_DC_ONLY;
+    K.info[2 * (size_t)pos] = flags;
+    K.info[2 * (size_t)pos + 1] = dcq << 16 | (K.dc_host ? (uint32_t)(uint16_t)K.dc_host[i] : 0u);
+    // the first coded fragment of a tile: the units handed out before it are the tile's first unit number
+    if (i == 0 || (K.frag_pos[K.clist[i - 1]] >> 6) != (pos >> 6)) K.slot0[pos >> 6] = unit | (wide ? THIP_SLOT_WIDE : 0u);
+  }
+  if (lz >= 2) {
+    const int j = q >> 1, h = q & 1;
+    const uint2 a = *reinterpret_cast<const uint2 *>(K.tmp + (size_t)i * 64 + (2 * j) * 8 + 4 * h);       // x[2j][4h..4h+3]
+    const uint2 b = *reinterpret_cast<const uint2 *>(K.tmp + (size_t)i * 64 + (2 * j + 1) * 8 + 4 * h);   // x[2j+1][4h..4h+3]
+    uint8_t *const base = reinterpret_cast<uint8_t *>(K.coeffs);
+    if (wide) {
+      int4 o;
+      o.x = (int)__builtin_amdgcn_perm(b.x, a.x, 0x05040100u);   // {a0, b0}
+      o.y = (int)__builtin_amdgcn_perm(b.x, a.x, 0x07060302u);   // {a1, b1}
+      o.z = (int)__builtin_amdgcn_perm(b.y, a.y, 0x05040100u);
+      o.w = (int)__builtin_amdgcn_perm(b.y, a.y, 0x07060302u);
+      const uint32_t u = unit + (uint32_t)(q >> 2);
+      *reinterpret_cast<int4 *>(base + (size_t)(u >> 6) * THIP_UNIT_GROUP_BYTES + (size_t)(q & 3) * 1024 + (size_t)(u & 63) * 16) = o;
+    } else {
+      uint2 o;   // the low bytes of {a0, a1, b0, b1} and of {a2, a3, b2, b3}
+      o.x = __builtin_amdgcn_perm(b.x, a.x, 0x06040200u);
+      o.y = __builtin_amdgcn_perm(b.y, a.y, 0x06040200u);
+      *reinterpret_cast<uint2 *>(base + (size_t)(unit >> 6) * THIP_UNIT_GROUP_BYTES + (size_t)j * 1024 + (size_t)(unit & 63) * 16 + 8 * h) = o;
+    }
+  }
+}
+
 // Staging -> device and the zero fills, one launch: dst[0..ncopy) = src (16-byte units; src is pinned host memory the
 // kernel reads across PCIe), then the four areas that must be zero before the frame's kernels run.
 struct TlPrepK {
   const int4 *src;
   int4 *dst;
   size_t ncopy;
-  int4 *z[4];
-  size_t nz[4];   // 16-byte units
+  int4 *z[5];
+  size_t nz[5];   // 16-byte units
 };
 // A group of lists goes to the device: the header tables (they grow index by index) and the group's tokens.
 struct TlCopyK {
@@ -450,6 +520,6 @@ __global__ __launch_bounds__(256) void k_tok_prepare(const TlPrepK P) {
   for (size_t i = g; i < P.ncopy; i += G) P.dst[i] = P.src[i];
   const int4 zero = make_int4(0, 0, 0, 0);
 #pragma unroll
-  for (int a = 0; a < 4; a++)
+  for (int a = 0; a < 5; a++)
     for (size_t i = g; i < P.nz[a]; i += G) P.z[a][i] = zero;
 }

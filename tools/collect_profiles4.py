@@ -7,7 +7,7 @@ DST = "profiles"
 for name in ("bench_default.json", "bench_steps20.json", "bench_twopass.json", "bench_1080p_single.json", "bench_1080p_single_gop16.json",
              "bench_1080p_4streams.json", "bench_720p_single.json", "bench_720p_single_tilekernel.json", "lf_trace_dense.txt",
              "lf_trace_smooth.txt", "lf_trace_720p_single_sb.txt", "pmc_counters_dense_lanes2.txt", "pmc_counters_smooth_lanes2.txt",
-             "e2e_sizes.jsonl"):
+             "e2e_sizes.jsonl", "e2e_single_stream_one_piece.jsonl"):
     p = os.path.join(SRC, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(DST, "r04_" + name))

@@ -28,11 +28,17 @@ LANES=2 bash tools/pmc_r4.sh smooth > /dev/null 2>&1; cp gpurun_out/r04/pmc_smoo
 python tools/lf_trace.py --content dense 2>&1 | grep -v amdgpu.ids > $o/lf_trace_dense.txt
 python tools/lf_trace.py --content smooth 2>&1 | grep -v amdgpu.ids > $o/lf_trace_smooth.txt
 python tools/lf_trace.py --content dense --size 720p --streams 1 2>&1 | grep -v amdgpu.ids > $o/lf_trace_720p_single_sb.txt
+: > $o/e2e_sizes.jsonl
 for k in dense typical; do
-  for sz in 720p 1080p; do
+  for sz in 720p 1080p 4k; do
     for t in 1 4 16; do
-      timeout 600 python bench.py --mode e2e --e2e-size $sz --packets $k --threads $t --no-native 2>/dev/null | tail -1 >> $o/e2e_sizes.jsonl
+      timeout 600 python bench.py --mode e2e --e2e-size $sz --packets $k --threads $t --loops 4 --no-native 2>/dev/null | tail -1 >> $o/e2e_sizes.jsonl
     done
   done
+done
+# the same three single-stream cells with the round-3 shape of the token-list path (one piece after the packet, one thread)
+: > $o/e2e_single_stream_one_piece.jsonl
+for sz in 720p 1080p 4k; do
+  THIP_FE_GROUPS=1 THIP_FE_WORKER=0 timeout 600 python bench.py --mode e2e --e2e-size $sz --packets dense --threads 1 --loops 4 --no-native 2>/dev/null | tail -1 >> $o/e2e_single_stream_one_piece.jsonl
 done
 tail -c 600 $o/bench_default.json
