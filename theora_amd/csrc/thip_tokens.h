@@ -206,8 +206,12 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
   } else {
     for (int i = t; i < n32 / 4; i += T) posw[i] = saved[i];   // where the launch for the indices before z0 left the fragments
   }
-  if (!BIG && !K.levels)
-    for (int i = t; i < n; i += T) qsl[i] = (uint8_t)((K.meta[c0 + i] >> 2) & 31u);
+  if (!BIG) {   // products: the fragment's table; levels: "has a level beyond eight bits" (this launch)
+    if (!K.levels)
+      for (int i = t; i < n; i += T) qsl[i] = (uint8_t)((K.meta[c0 + i] >> 2) & 31u);
+    else
+      for (int i = t; i < n32 / 4; i += T) reinterpret_cast<uint32_t *>(qsl)[i] = 0u;
+  }
   __syncthreads();
   // this thread's share [j0, j1) of a list's tokens
   auto share = [&](int z, uint32_t &off, uint32_t &j0, uint32_t &j1) {
@@ -266,7 +270,10 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
         if (at[q] == 0) K.dc_in[cf[q]] = (int16_t)value;   // the DC token value (un-predicted later, or the caller's is used)
         else if (at[q] <= 63) {
           K.tmp[(size_t)(c0 + fi[q]) * 64 + nat[q]] = (int16_t)(value * fac[q]);   // decode.c:1573 (levels form: the level itself)
-          if (lv && (value > 127 || value < -128)) K.wide[K.frag_pos[K.clist[c0 + fi[q]]] >> 6] = 1u;   // (rare) the fragment's tile turns wide
+          if (lv && (value > 127 || value < -128)) {   // the fragment's tile turns wide
+            if (BIG) K.wide[K.frag_pos[K.clist[c0 + fi[q]]] >> 6] = 1u;
+            else qsl[fi[q]] = 1;   // (a byte of LDS now; the two look-ups that find the tile when the launch ends, for the marked fragments only)
+          }
         }
       }
       const int np = at[q] + (value != 0 ? 1 : 0);
@@ -372,6 +379,9 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
     printf("k_tok_assign plane 0: n %d T %d rounds %d | count %llu scan %llu rank+barrier %llu nextuse %llu serve-rest %llu endbarrier %llu | serve: ranks %llu tables %llu stores %llu (10 ns ticks)\n", n, T, rounds,
            tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8]);
 #endif
+  if (!BIG && lv)
+    for (int i = t; i < n; i += T)
+      if (qsl[i]) K.wide[K.frag_pos[K.clist[c0 + i]] >> 6] = 1u;
   if (zend < 64) {   // more indices to come: the next launch starts from here
     for (int i = t; i < n32 / 4; i += T) saved[i] = posw[i];
     return;
