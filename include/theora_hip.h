@@ -544,6 +544,10 @@ const char *thip_version_string(void);
  *   fe_device_lists   th_decode_*: the token lists go to the device as the entropy decoder leaves them: 1 on, 0 off, -1 (default)
  *                on while at most four decoder contexts are alive in the process and neither of the two above is set (one to
  *                four streams decode a fifth faster that way, sixteen slower); TH_DECCTL_THIP_SET_DEVICE_LISTS per context
+ *   tl_algo      thip_state_token_lists_*: which kernels pair tokens and fragments (thip_tokens.h): 1 k_tok_assign, 2 k_tok_rank +
+ *                k_tok_walk, 0 (default) the second for planes of more than 36 864 coded fragments (4K), the first otherwise -- equal
+ *                end to end at every size, the second 22 % less kernel time at 4K; tl_walk_threads: k_tok_walk's work-group size
+ *                (256, 512, 1024; 0 = by plane size)
  *   tl_levels    thip_state_token_lists_* / thip_state_decode_token_lists: 1 (default): the device builds the coefficient slots in
  *                the levels form (THIP_COEFFS_LEVELS: int8 units, wide tiles where a level needs more; the reconstruction kernel
  *                dequantises); 0: dequantised int16 slots, as in round 3

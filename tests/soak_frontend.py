@@ -22,6 +22,8 @@ while time.time() - t0 < limit:
     L.thip_set_option(b"fe_groups", int(rng.choice([1, 2, 3, 4, 5, 9])))
     L.thip_set_option(b"fe_worker", int(rng.integers(2)))
     L.thip_set_option(b"tl_levels", int(rng.integers(2)))
+    L.thip_set_option(b"tl_algo", int(rng.integers(0, 3)))
+    L.thip_set_option(b"tl_walk_threads", int(rng.choice([0, 256, 512, 1024])))
     T.run_stream(theora_amd, w, h, fmt, seed=seed, nframes=int(rng.integers(4, 10)), kf=int(rng.integers(2, 6)), trees=trees,
                  device_lists=lists)
     cases += 1

@@ -97,9 +97,9 @@ def test_packets_decode_bit_exact_with_the_token_lists_on_the_gpu(hip, w, h, fmt
                       device_dc=device_dc) >= 3
 
 
-@pytest.mark.parametrize("groups,worker,levels", [(1, 0, 1), (1, 1, 0), (4, 0, 0), (9, 1, 1), (2, 1, 1)])
+@pytest.mark.parametrize("groups,worker,levels,algo", [(1, 0, 1, 2), (1, 1, 0, 1), (4, 0, 0, 2), (9, 1, 1, 1), (2, 1, 1, 2), (4, 1, 1, 1)])
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (336, 32, 0), (1280, 720, 0), (1920, 1088, 0)])
-def test_packets_decode_bit_exact_with_the_token_lists_in_groups(hip, w, h, fmt, groups, worker, levels):
+def test_packets_decode_bit_exact_with_the_token_lists_in_groups(hip, w, h, fmt, groups, worker, levels, algo):
     """The token-list path's options.  tl_levels: the device writes the coefficient slots as dequantised int16 (0, round 3's
     form) or in the levels form (1, the default: int8 units, tiles with a level beyond eight bits as int16 over two units --
     the generator's streams have both kinds of tile --, k_recon_lf<LEVELS> dequantises).  fe_groups: the lists go to the device in one piece after the packet's last bit
@@ -111,12 +111,14 @@ def test_packets_decode_bit_exact_with_the_token_lists_in_groups(hip, w, h, fmt,
     L.thip_set_option(b"fe_groups", groups)
     L.thip_set_option(b"fe_worker", worker)
     L.thip_set_option(b"tl_levels", levels)
+    L.thip_set_option(b"tl_algo", algo)   # 1: k_tok_assign; 2: k_tok_rank + k_tok_walk (the default picks by plane size)
     try:
         assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_lists=True) >= 3
     finally:
         L.thip_set_option(b"fe_groups", 4)
         L.thip_set_option(b"fe_worker", 1)
         L.thip_set_option(b"tl_levels", 1)
+        L.thip_set_option(b"tl_algo", 0)
 
 
 def test_token_list_groups_come_in_order(hip):

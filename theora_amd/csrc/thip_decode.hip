@@ -77,6 +77,8 @@ Option g_options[] = {
     {"fe_device_dc", 0, "th_decode_*: DC un-prediction on the device"},
     {"fe_device_tokens", 0, "th_decode_*: token expansion + dequantisation on the device (host-delimited tokens)"},
     {"fe_device_lists", -1, "th_decode_*: the token lists themselves on the device (1 on, 0 off, -1 on while at most four decoder contexts are alive)"},
+    {"tl_algo", 0, "token lists on the device: 1: k_tok_assign (rank -> fragment map in LDS, or in memory for planes beyond 36 864 coded fragments); 2: k_tok_rank + k_tok_walk (every fragment looked after by one thread, one barrier per index, one byte of LDS per fragment); 0 (default): 2 where 1 would keep its map in memory (4K), 1 otherwise"},
+    {"tl_walk_threads", 0, "k_tok_walk: threads of the work group (256, 512, 1024); 0 (default): by plane size"},
     {"tl_levels", 1, "token lists on the device (thip_state_token_lists_*): 1 (default): the device writes the coefficient slots in the levels form (int8 units, the reconstruction kernel dequantises); 0: dequantised int16 slots"},
     {"fe_groups", 4, "th_decode_*, token-list path: the groups of zig-zag indices a frame's lists are handed over in while the packet is still being decoded: 4 (default), 9, 5, 3, 2, or 1: in one piece after the packet's last bit"},
     {"fe_worker", 1, "th_decode_*, token-list path: 1 (default): a second thread per context undoes the DC prediction while the caller decodes the tokens of indices 1..63; 0: the caller does it behind the tokens"},
@@ -242,6 +244,8 @@ struct thip_state {
   uint8_t *d_tl_pos;        // k_tok_assign's fragment positions between the launches of a frame
   int tl_claimed;           // thip_state_token_lists_staging has handed the staging buffer out for the frame to come
   uint32_t *d_tl_wide;      // [ntiles] levels form: the tiles whose levels do not all fit eight bits
+  uint32_t *d_tl_rank;      // [64 nfrags] k_tok_rank's output (option tl_algo = 2), allocated with its first use
+  int64_t tl_rank_at;       // entries of it handed out to the lists of the frame so far
   hipStream_t tl_stream;
   int32_t *d_frag_pos;      // [nfrags], uploaded once
   // out-of-loop post-processing (thip_state_postprocess): the post-processed picture, the per-fragment
@@ -670,6 +674,7 @@ void thip_state_free(thip_state *st) {
   if (st->d_tl_arr) (void)hipFree(st->d_tl_arr);
   if (st->d_tl_pos) (void)hipFree(st->d_tl_pos);
   if (st->d_tl_wide) (void)hipFree(st->d_tl_wide);
+  if (st->d_tl_rank) (void)hipFree(st->d_tl_rank);
   if (st->d_frag_pos) (void)hipFree(st->d_frag_pos);
   if (st->pp_frame) (void)hipFree(st->pp_frame);
   if (st->pp_var) (void)hipFree(st->pp_var);
@@ -967,7 +972,7 @@ int thip_profile_read(int64_t launches[THIP_NKERNELS], double ms[THIP_NKERNELS])
 // More than 64 KB of dynamic LDS has to be allowed per kernel and per device, once.
 static hipError_t set_dynamic_lds(const void *kernel, int bytes, int which) {
   static std::mutex mu;
-  static bool done[4][kMaxDevices];
+  static bool done[8][kMaxDevices];
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -2021,7 +2026,8 @@ static int tl_ensure(thip_state *st) {
   if (!st->d_tl_slot) HIP_TRY(hipMalloc((void **)&st->d_tl_slot, y.nf * 4));
   if (!st->d_tl_arr) HIP_TRY(hipMalloc((void **)&st->d_tl_arr, y.nf * 4));
   if (!st->d_tl_pos) HIP_TRY(hipMalloc((void **)&st->d_tl_pos, (size_t)y.pos_pitch * 3));
-  if (!st->d_tl_wide) HIP_TRY(hipMalloc((void **)&st->d_tl_wide, (((size_t)st->tiles.ntiles + 3) & ~(size_t)3) * 4));
+  if (!st->d_tl_wide)   // (+ k_tok_slots_count's sums, one per kTlSlotChunk fragments)
+    HIP_TRY(hipMalloc((void **)&st->d_tl_wide, ((((size_t)st->tiles.ntiles + 3) & ~(size_t)3) + (size_t)st->nfrags / kTlSlotChunk + 4) * 4));
   if (!st->d_frag_pos) HIP_TRY(hipMalloc((void **)&st->d_frag_pos, y.nf * 4));
   if (!st->d_dc_in) HIP_TRY(hipMalloc((void **)&st->d_dc_in, sizeof(int16_t) * y.nf));
   HIP_TRY(hipMemcpy(st->d_frag_pos, st->frag_pos, (size_t)st->nfrags * 4, hipMemcpyHostToDevice));
@@ -2186,6 +2192,7 @@ int thip_state_token_lists_open(thip_state *st, const thip_token_lists *tl) {
   st->tl_pending = 1;
   st->tl_z = 0;
   st->tl_ntok = 0;
+  st->tl_rank_at = 0;
   return THIP_OK;
 }
 
@@ -2212,6 +2219,20 @@ int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t
   hipStream_t s = st->tl_stream;
   uint32_t *h = st->h_tl;
   const size_t at = ((size_t)st->tl_ntok + 3) & ~(size_t)3;   // the group starts on a 16-byte unit of the token area
+  int algo = THIP_OPT("tl_algo");
+  if (algo != 1 && algo != 2) algo = std::max(std::max(K0.p[0].n, K0.p[1].n), K0.p[2].n) > kTlLdsFrags ? 2 : 1;
+  if (algo == 2) {
+    int64_t need = st->tl_rank_at;
+    for (int p = 0; p < 3; p++)
+      for (int z = z0; z < z1; z++) need += arrivals[p][z];
+    if (need > (int64_t)st->nfrags * 64) return THIP_EINVAL;   // (a fragment arrives at an index once)
+    if (!st->d_tl_rank) HIP_TRY(hipMalloc((void **)&st->d_tl_rank, (size_t)st->nfrags * 64 * 4));
+    for (int z = z0; z < z1; z++)
+      for (int p = 0; p < 3; p++) {
+        h[THIP_TL_ROFF + p * 64 + z] = (uint32_t)st->tl_rank_at;
+        st->tl_rank_at += arrivals[p][z];
+      }
+  }
   for (int p = 0; p < 3; p++)
     for (int z = z0; z < z1; z++) {
       h[THIP_TL_OFF + p * 64 + z] = (uint32_t)at + list_off[p][z];
@@ -2234,7 +2255,24 @@ int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t
   K.z1 = z1;
   int nmax = 0;
   for (int p = 0; p < 3; p++) nmax = std::max(nmax, K.p[p].n);
-  if (nmax <= kTlLdsFrags) {
+  if (algo == 2) {
+    K.rank = st->d_tl_rank;
+    hipLaunchKernelGGL(k_tok_rank, dim3(3 * (unsigned)(z1 - z0)), dim3(kTlRankThreads), 0, s, K);
+    int T = THIP_OPT("tl_walk_threads");
+    if (T != 256 && T != 512 && T != 1024) T = nmax <= 2048 ? 256 : (nmax <= 8192 ? 512 : 1024);   // (a round is one barrier: waves are cheap, arrivals per thread are not)
+    while (T < 1024 && ((((nmax + 31) & ~31) >> 5) + T - 1) / T > kTlGroups) T *= 2;   // (a thread looks after kTlGroups x 32 fragments at most)
+    const size_t lds = (size_t)((nmax + 31) & ~31) + 16;
+    if (T == 256) {
+      HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_walk<256>), kTlMaxFrags + 32, 4));
+      hipLaunchKernelGGL(k_tok_walk<256>, dim3(3), dim3(256), lds, s, K);
+    } else if (T == 512) {
+      HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_walk<512>), kTlMaxFrags + 32, 5));
+      hipLaunchKernelGGL(k_tok_walk<512>, dim3(3), dim3(512), lds, s, K);
+    } else {
+      HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_walk<1024>), kTlMaxFrags + 32, 6));
+      hipLaunchKernelGGL(k_tok_walk<1024>, dim3(3), dim3(1024), lds, s, K);
+    }
+  } else if (nmax <= kTlLdsFrags) {
     const int lds = 2 * ((nmax + 31) & ~31) + 2 * nmax + 16;
     HIP_TRY(set_dynamic_lds(reinterpret_cast<const void *>(k_tok_assign<false>), 2 * ((kTlLdsFrags + 31) & ~31) + 2 * kTlLdsFrags + 16, 2));
     hipLaunchKernelGGL(k_tok_assign<false>, dim3(3), dim3(tl_threads(nmax)), (size_t)lds, s, K);
@@ -2245,7 +2283,14 @@ int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t
   }
   if (z1 == 64) {
     if (K.levels) hipLaunchKernelGGL(k_tok_widths, dim3((unsigned)((ncoded + 255) / 256)), dim3(256), 0, s, K);
-    hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
+    if (ncoded <= 4 * kTlSlotChunk) {
+      hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
+    } else {   // (large frames: many groups, two launches)
+      const unsigned ng = (unsigned)((ncoded + kTlSlotChunk - 1) / kTlSlotChunk);
+      uint32_t *part = st->d_tl_wide + (((size_t)st->tiles.ntiles + 3) & ~(size_t)3);   // (behind the tiles' words)
+      hipLaunchKernelGGL(k_tok_slots_count, dim3(ng), dim3(1024), 0, s, K, part);
+      hipLaunchKernelGGL(k_tok_slots_assign, dim3(ng), dim3(1024), 0, s, K, (const uint32_t *)part);
+    }
   }
   HIP_TRY(hipGetLastError());
   st->tl_z = z1;

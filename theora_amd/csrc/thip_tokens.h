@@ -30,7 +30,8 @@
 #define THIP_TL_CARRY 384   // fragments ended at this index by an EOB run from an earlier list
 #define THIP_TL_ARRIVE 576  // fragments that reach this index at all
 #define THIP_TL_DCQ 768     // dc_quant[plane][qti], 6 dwords
-#define THIP_TL_HDR 776     // dwords
+#define THIP_TL_ROFF 776    // where the list's entries start in the rank-ordered token array (k_tok_rank / k_tok_walk)
+#define THIP_TL_HDR 968     // dwords
 
 struct TlPlaneK {
   int n;    // coded fragments of the plane
@@ -64,6 +65,7 @@ struct TlK {
   // tmp holds the levels as the tokens carry them, `wide` one word per tile, set by whoever meets a level beyond eight bits
   int levels;
   uint32_t *wide;           // [ntiles] (zeroed)
+  uint32_t *rank;           // k_tok_rank -> k_tok_walk: for every list, its arrivals' tokens in the order of the arrivals
 };
 
 // exclusive prefix sum over the work group (blockDim.x a multiple of 64, at most 1024); scr: 16 dwords of LDS
@@ -391,6 +393,170 @@ __global__ __launch_bounds__(1024) void k_tok_assign(const TlK K) {
 }
 #undef TLP
 
+// ---- the same walk with every fragment looked after by ONE thread (option tl_algo = 2) -----------------------------------------
+// k_tok_assign pairs tokens and fragments through a rank -> fragment map that all threads write and all threads read: two prefix sums, three
+// work-group barriers and two dependent LDS look-ups per token and round.  Which token an arrival gets depends on the arrival's RANK only --
+// the rank-th unit of what the list's entries consume --, and that half of the question has nothing to do with the fragments: k_tok_rank
+// answers it for a whole group of lists at once, one work group per list, into an array indexed by rank (EOB_MARK where the rank is
+// swallowed by the carry or by an EOB run, the token word where a token serves it).  What is left for the 64 dependent rounds of
+// k_tok_walk is: count my fragments' arrivals, ONE prefix sum over the work group, fetch my arrivals' entries (consecutive ranks:
+// consecutive addresses), move my fragments on.  `pos` belongs to its owner: one barrier a round (inside the prefix sum), one byte of
+// LDS per fragment for every plane size (no separate kernel for 4K), bit 7 of the byte = "has a level beyond eight bits".
+#define THIP_TOK_RANK_EOB 0xFFFFFFFFu   // (not a token: bit 23 with a zero run of 127 and value 0xFFFF never leaves the front end)
+constexpr int kTlRankThreads = 1024;
+constexpr int kTlWalkBatch = 8;       // arrivals of a thread whose entries are requested together
+__global__ __launch_bounds__(kTlRankThreads) void k_tok_rank(const TlK K) {
+  __shared__ uint32_t s_scr[16];
+  const int p = (int)blockIdx.x % 3, z = K.z0 + (int)blockIdx.x / 3;
+  const uint32_t narr = K.hdr[THIP_TL_ARRIVE + p * 64 + z];
+  if (narr == 0) return;
+  const uint32_t off = K.hdr[THIP_TL_OFF + p * 64 + z], m = K.hdr[THIP_TL_LEN + p * 64 + z];
+  uint32_t *const R = K.rank + K.hdr[THIP_TL_ROFF + p * 64 + z];
+  const int t = (int)threadIdx.x;
+  for (uint32_t i = (uint32_t)t; i < narr; i += kTlRankThreads) R[i] = THIP_TOK_RANK_EOB;
+  __syncthreads();
+  uint32_t S0 = K.hdr[THIP_TL_CARRY + p * 64 + z];   // what the entries before this chunk consume
+  for (uint32_t j0 = 0; j0 < m && S0 < narr; j0 += 4u * kTlRankThreads) {
+    const uint32_t j = j0 + 4u * (uint32_t)t;
+    uint32_t tk[4], c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      tk[q] = j + (uint32_t)q < m ? K.tok[off + j + (uint32_t)q] : 0u;
+      // (a run counts for no more than the list has arrivals -- beyond that it means "everything" anyway --, so that the sums of a
+      //  chunk stay far inside 32 bits whatever a malformed packet says: 4096 x 147 456 < 2^30)
+      c[q] = j + (uint32_t)q < m ? min(tl_cost(tk[q]), narr) : 0u;
+    }
+    uint32_t total;
+    uint32_t S = S0 + tl_exscan(c[0] + c[1] + c[2] + c[3], s_scr, total);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (j + (uint32_t)q < m && !(tk[q] & THIP_TOK_EOB) && S < narr) R[S] = tk[q];
+      S += c[q];
+    }
+    S0 += total;
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_tok_walk(const TlK K) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_tl[];
+  __shared__ uint16_t s_dq[18 * 64];
+  __shared__ uint32_t s_scr[2][16];
+  __shared__ uint32_t s_hdr[2][64];                      // arrivals, rank offset of every list of the plane
+  __shared__ uint8_t s_nat[64];
+  const int p = (int)blockIdx.x, n = K.p[p].n, c0 = K.p[p].c0;
+  if (n == 0) return;
+  const int n32 = (n + 31) & ~31;
+  uint8_t *pos = s_tl;
+  uint32_t *posw = reinterpret_cast<uint32_t *>(s_tl);
+  const int t = (int)threadIdx.x;
+  const bool lv = K.levels != 0;
+  if (!lv)
+    for (int i = t; i < 18 * 64; i += T) s_dq[i] = K.dq[i];
+  if (t < 64) {
+    s_hdr[0][t] = K.hdr[THIP_TL_ARRIVE + p * 64 + t];
+    s_hdr[1][t] = K.hdr[THIP_TL_ROFF + p * 64 + t];
+    s_nat[t] = (uint8_t)tl_nat(t);
+  }
+  constexpr int lgT = T == 256 ? 8 : T == 512 ? 9 : 10;
+  const int G = n32 >> 5;
+  const int Kg = (G + T - 1) >> lgT;                     // <= kTlGroups
+  const int g0 = min(t * Kg, G), g1 = min(g0 + Kg, G);   // this thread's fragments: 32 g0 .. 32 g1 - 1, nobody else's
+  uint32_t *const saved = reinterpret_cast<uint32_t *>(K.pos_save + (size_t)p * K.pos_pitch);
+  // (a thread initialises / restores what it owns: no barrier between that and its first look at it)
+  for (int i = 8 * g0; i < 8 * g1; i++) {
+    const int left = n - 4 * i;
+    posw[i] = K.z0 == 0 ? (left >= 4 ? 0u : (left <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8 * left)))) : saved[i];
+  }
+  __syncthreads();
+  const int zend = K.z1;
+  int buf = 0;
+  for (int z = K.z0; z < zend; z++) {
+    if (s_hdr[0][z] == 0) continue;                      // (uniform) nobody arrives at this index
+    const uint32_t zz = (uint32_t)z * 0x01010101u;
+    uint32_t cnt = 0, gm[kTlGroups];
+#pragma unroll
+    for (int k = 0; k < kTlGroups; k++) {
+      gm[k] = 0u;
+      if (g0 + k < g1) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(posw + 8 * (g0 + k)), b = *reinterpret_cast<const uint4 *>(posw + 8 * (g0 + k) + 4);
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) gm[k] |= ((((tl_eq_bytes(w[j] & 0x7F7F7F7Fu, zz) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * j);
+      }
+      cnt += (uint32_t)__popc(gm[k]);
+    }
+    // exclusive prefix sum of the arrival counts over the work group: the rank of this thread's first arrival
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t incl = tl_wave_scan(cnt);
+    if (lane == 63) s_scr[buf][wave] = incl;
+    tl_barrier_lds();
+    uint32_t wsum = lane < (T >> 6) ? s_scr[buf][lane & 15] : 0u;
+    wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x111, 0xF, 0xF, true);
+    wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x112, 0xF, 0xF, true);
+    wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x114, 0xF, 0xF, true);
+    wsum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wsum, 0x118, 0xF, 0xF, true);
+    const uint32_t upto = (uint32_t)__builtin_amdgcn_readlane((int)wsum, wave), mine = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t r = upto - mine + incl - cnt;
+    buf ^= 1;
+    const uint32_t *const R = K.rank + s_hdr[1][z];
+    const uint32_t narr = s_hdr[0][z];
+    // this thread's arrivals, kTlWalkBatch at a time: their entries (consecutive ranks: one round trip for the batch) first, then
+    // what they say
+#pragma unroll 1
+    for (int k = 0; k < kTlGroups; k++) {
+      uint32_t m = gm[k];
+      const uint32_t base = (uint32_t)(g0 + k) * 32u;
+      while (m) {
+        int fi[kTlWalkBatch];
+        uint32_t tk[kTlWalkBatch];
+        bool live[kTlWalkBatch];
+#pragma unroll
+        for (int q = 0; q < kTlWalkBatch; q++) {
+          live[q] = m != 0u;
+          fi[q] = (int)base + (live[q] ? __ffs((int)m) - 1 : 0);
+          m &= m - 1u;
+        }
+#pragma unroll
+        for (int q = 0; q < kTlWalkBatch; q++) tk[q] = live[q] && r + (uint32_t)q < narr ? R[r + (uint32_t)q] : THIP_TOK_RANK_EOB;
+#pragma unroll
+        for (int q = 0; q < kTlWalkBatch; q++) {
+          if (!live[q]) continue;
+          r++;
+          const uint8_t old = pos[fi[q]];
+          if (tk[q] == THIP_TOK_RANK_EOB) {             // ended at this index (the carry, an EOB run, or a list that ran out)
+            pos[fi[q]] = (uint8_t)((old & 0x80u) | (uint32_t)(64 + z));
+            continue;
+          }
+          const int at = z + (int)((tk[q] >> 16) & 127u);
+          const int value = (int)(int16_t)(tk[q] & 0xFFFFu);
+          uint32_t big = old & 0x80u;
+          if (value != 0) {
+            if (at == 0) K.dc_in[K.clist[c0 + fi[q]]] = (int16_t)value;   // the DC token value (un-predicted later, or the caller's is used)
+            else if (at <= 63) {
+              const int fac = lv ? 1 : (int)s_dq[((K.meta[c0 + fi[q]] >> 2) & 31u) * 64 + (uint32_t)at];
+              K.tmp[(size_t)(c0 + fi[q]) * 64 + s_nat[at]] = (int16_t)(value * fac);   // decode.c:1573 (levels form: the level itself)
+              if (lv && (value > 127 || value < -128)) big = 0x80u;
+            }
+          }
+          const int np = at + (value != 0 ? 1 : 0);
+          pos[fi[q]] = (uint8_t)(big | (uint32_t)(np < 64 ? np : 64 + z));
+        }
+      }
+    }
+  }
+  // (pos is its owner's: what follows needs no barrier either)
+  if (zend < 64) {
+    for (int i = 8 * g0; i < 8 * g1; i++) saved[i] = posw[i];
+    return;
+  }
+  for (int i = 32 * g0; i < min(32 * g1, n); i++) {
+    const uint32_t v = pos[i], q = v & 0x7Fu;
+    K.last_zzi[c0 + i] = (uint8_t)(q < 64u ? q : q - 64u);   // decode.c:1545
+    if (v & 0x80u) K.wide[K.frag_pos[K.clist[c0 + i]] >> 6] = 1u;
+  }
+}
+
 // Levels form: which fragments lie in a wide tile -- bit 7 of their last_zzi byte (a thread per coded fragment: k_tok_slots, a single
 // work group that walks the fragments in a loop, would pay the two dependent look-ups fragment after fragment).
 __global__ __launch_bounds__(256) void k_tok_widths(const TlK K) {
@@ -417,6 +583,45 @@ __global__ __launch_bounds__(1024) void k_tok_slots(const TlK K) {
   for (int i = f0; i < f1; i++) {
     K.slot[i] = s;
     s += need(i);
+  }
+}
+
+// The same for large frames, in two launches of many groups: a group of 1024 threads looks after kTlSlotChunk fragments -- counts what
+// they need (k_tok_slots_count -> part[group]), then adds up the groups before it and hands its own fragments their slots
+// (k_tok_slots_assign).  (One group walking 194 400 fragments of a 4K frame took 181 us at the end of every frame.)
+constexpr int kTlSlotChunk = 8192;
+__device__ __forceinline__ uint32_t tl_slot_need(const TlK &K, int i) {
+  const uint32_t lz = K.last_zzi[i];
+  return (lz & 0x7Fu) < 2u ? 0u : 1u + (lz >> 7);
+}
+__global__ __launch_bounds__(1024) void k_tok_slots_count(const TlK K, uint32_t *part) {
+  __shared__ uint32_t s_scr[16];
+  const int i0 = (int)blockIdx.x * kTlSlotChunk + (int)threadIdx.x * (kTlSlotChunk / 1024);
+  uint32_t cnt = 0;
+  for (int i = i0; i < min(i0 + kTlSlotChunk / 1024, K.ncoded); i++) cnt += tl_slot_need(K, i);
+  uint32_t total;
+  (void)tl_exscan(cnt, s_scr, total);
+  if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_tok_slots_assign(const TlK K, const uint32_t *part) {
+  __shared__ uint32_t s_scr[16];
+  __shared__ uint32_t s_before;
+  if (threadIdx.x < 64) {   // the groups before this one (a 4K frame has 24)
+    uint32_t v = 0;
+    for (int g = (int)threadIdx.x; g < (int)blockIdx.x; g += 64) v += part[g];
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (threadIdx.x == 0) s_before = v;
+  }
+  const int i0 = (int)blockIdx.x * kTlSlotChunk + (int)threadIdx.x * (kTlSlotChunk / 1024);
+  const int i1 = min(i0 + kTlSlotChunk / 1024, K.ncoded);
+  uint32_t cnt = 0;
+  for (int i = i0; i < i1; i++) cnt += tl_slot_need(K, i);
+  uint32_t total;
+  uint32_t sl = tl_exscan(cnt, s_scr, total);   // (its barriers publish s_before too)
+  sl += s_before;
+  for (int i = i0; i < i1; i++) {
+    K.slot[i] = sl;
+    sl += tl_slot_need(K, i);
   }
 }
 
