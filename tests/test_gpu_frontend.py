@@ -268,11 +268,27 @@ def test_contexts_on_concurrent_host_threads(hip):
                 assert all(np.array_equal(a, b) for a, b in zip(fa, fb)), i
 
 
-def test_mutated_packets_through_the_device_path(hip):
+@pytest.mark.parametrize("algo,groups", [(0, 4), (2, 4), (2, 1), (1, 9)])
+def test_mutated_packets_through_the_device_path(hip, algo, groups):
     """The same kind of damage tests/test_frontend_fuzz.py applies on the host, through the real
     backend: whatever th_decode_packetin accepts must reconstruct without a device fault (vectors
-    pointing anywhere are clamped reads; slots and tiles are assigned by the library itself) and
-    the context must stay usable -- a clean key frame afterwards decodes bit-exactly."""
+    pointing anywhere are clamped reads; slots and tiles are assigned by the library itself; EOB runs
+    of any length, lists longer or shorter than their arrivals -- with either of the device's two walks over
+    the token lists, in one piece or in groups) and the context must stay usable -- a clean key frame
+    afterwards decodes bit-exactly."""
+    from theora_amd.decoder import Decoder
+    from theora_amd._lib import TheoraHipError
+    L = hip._lib.load()
+    L.thip_set_option(b"tl_algo", algo)
+    L.thip_set_option(b"fe_groups", groups)
+    try:
+        _mutated_packets(hip)
+    finally:
+        L.thip_set_option(b"tl_algo", 0)
+        L.thip_set_option(b"fe_groups", 4)
+
+
+def _mutated_packets(hip):
     from theora_amd.decoder import Decoder
     from theora_amd._lib import TheoraHipError
     rng = np.random.default_rng(7)
