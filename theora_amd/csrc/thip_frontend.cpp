@@ -218,6 +218,7 @@ struct FeWorker {
   // write those arrays ran 2.7 x slower with the thread left to the scheduler of a two-socket host).
   cpu_set_t domain;
   bool placed = false;
+  bool solo = false;               // the caller's thread may run on ONE CPU only (taskset -c N): nothing to run beside it on
 };
 
 struct th_dec_ctx {
@@ -1056,8 +1057,18 @@ void fe_worker_place(FeWorker &w) {
   const int cpu = sched_getcpu();
   if (cpu < 0 || cpu >= CPU_SETSIZE) return;
   if (w.placed && CPU_ISSET(cpu, &w.domain)) return;   // (the caller has not left the cache domain the worker is in)
-  cpu_set_t set;
+  cpu_set_t set, allowed;
   if (!fe_llc_cpus(cpu, &set)) return;
+  // inside what the caller's own thread is allowed (a process pinned with taskset keeps its threads where it was put)
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+    w.solo = CPU_COUNT(&allowed) < 2;
+    CPU_AND(&set, &set, &allowed);
+    if (CPU_COUNT(&set) < 2) {   // (nothing to choose: asked again only when the caller turns up somewhere else)
+      w.domain = allowed;
+      w.placed = true;
+      return;
+    }
+  }
   if (pthread_setaffinity_np(w.th.native_handle(), sizeof(set), &set) != 0) return;   // (CPUs outside the process's set: left to the scheduler)
   w.domain = set;
   w.placed = true;
@@ -1684,6 +1695,10 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   if (with_worker) {
     FeWorker &w = *d->worker;
     if (thip_option("fe_worker_pin") != 0) fe_worker_place(w);
+    if (w.solo) with_worker = false;
+  }
+  if (with_worker) {
+    FeWorker &w = *d->worker;
     w.z0_ready.store(0, std::memory_order_relaxed);
     w.done.store(0, std::memory_order_relaxed);
     {
