@@ -561,6 +561,9 @@ const char *thip_version_string(void);
  *   fe_worker_pin   fe_worker on: 1 (default): that thread is kept (pthread_setaffinity_np) on the CPUs that share a last-level
  *                cache with the thread that calls th_decode_packetin (the two hand each other a frame's flags, lists and DC values);
  *                0: left to the scheduler (measured 5-10 % SLOWER than no second thread on a two-socket host)
+ *   fe_lookahead   th_decode_*: how many packets a caller may announce ahead of their th_decode_packetin
+ *                (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET, include/theoradec_hip.h): each is parsed -- entropy decoder and DC
+ *                chain -- by a thread of its own; 4 (default), up to 16; 0: announcements are not taken
  *   fe_levels    th_decode_*: 1: the host's own token walk feeds thip_state_frag_recon_levels; 0 (default): thip_state_frag_recon --
  *                measured equal within 2 % end to end (the walk is bound by the tokens, not by the 64 bytes a block saved)
  *   fe_trace_backend, fe_prof   th_decode_*: record slot calls instead of running them (tests); per-stage host timing

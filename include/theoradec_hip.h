@@ -151,6 +151,16 @@ typedef struct {
    fe_device_lists (THIP_FE_DEVICE_LISTS in the environment): 1 / 0, or -1, the default: this path while at most four
    decoder contexts are alive in the process. */
 #define TH_DECCTL_THIP_SET_DEVICE_LISTS (0x7104)
+/* Extension: buf = ogg_packet (a data packet the caller will hand to th_decode_packetin LATER, announced in decode order).
+   What th_decode_packetin reads out of a packet -- coded flags, modes, vectors, qi indices, DCT tokens, and the DC prediction it
+   undoes (decode.c:2790-2823 up to the MCU loop) -- depends on the headers and on nothing an earlier frame left behind: only the
+   pictures form a chain.  The packet is copied and parsed on a thread of its own (up to option fe_lookahead, default 4, at a
+   time); the th_decode_packetin that gets the same bytes adopts the result and does only the hand-over to the GPU, so one
+   stream is no longer bound by one host thread.  Returns 0: announced; 1: not taken (no slot free, an empty packet, a context with
+   TH_DECCTL_THIP_SET_DEVICE_DC / _DEVICE_TOKENS on, a process confined to one CPU) -- harmless, the packet is parsed in its
+   th_decode_packetin as ever.  A th_decode_packetin whose packet is not the oldest announced one drops everything announced and
+   parses the ordinary way: announcing is a hint, never a requirement, and the pictures are the same either way. */
+#define TH_DECCTL_THIP_PREFETCH_PACKET (0x7105)
 typedef struct thip_slot_trace {
   int64_t ncoded;           /* state_frag_recon calls, in call (= coded) order */
   const int32_t *fragi;     /* _fragi */

@@ -41,6 +41,8 @@ int thip_option(const char *name) {   // the library's option table is not linke
   if (name && !strcmp(name, "device")) return -1;
   if (name && !strcmp(name, "fe_trace_backend")) return 1;
   if (name && !strcmp(name, "fe_device_lists")) return 0;
+  if (name && !strcmp(name, "fe_lookahead")) return 4;
+  if (name && !strcmp(name, "fe_worker_pin")) return 1;
   return 0;
 }
 int thip_state_set_device_dc(thip_state *, int) { return -1; }
@@ -93,7 +95,7 @@ int main(int argc, char **argv) {
   fclose(f);
   const int iters = atoi(argv[2]);
   g_rng = (uint32_t)atoi(argv[3]);
-  long decoded = 0, rejected = 0, hdr_rejected = 0;
+  long decoded = 0, rejected = 0, hdr_rejected = 0, compared = 0;
   for (int it = 0; it < iters; it++) {
     const bool fuzz_headers = it % 4 == 3;
     th_info info;
@@ -109,38 +111,81 @@ int main(int argc, char **argv) {
       ok = th_decode_headerin(&info, &tc, &setup, &op) > 0;
     }
     th_dec_ctx *d = ok ? th_decode_alloc(&info, setup) : nullptr;
-    if (setup) th_setup_free(setup);
+    th_setup_info *setup_keep = setup;
     if (!d) {
+      if (setup) th_setup_free(setup);
       hdr_rejected++;
       th_comment_clear(&tc);
       th_info_clear(&info);
       continue;
     }
+    // the context's packets, mutated, up front: on every other iteration a second context decodes the same packets with a
+    // look-ahead (TH_DECCTL_THIP_PREFETCH_PACKET, now and then announcing something else than what comes) and must answer the same
+    std::vector<Pkt> seq;
     for (unsigned i = nh; i < nh + np; i++) {
       Pkt p = P[i];
       if (!fuzz_headers || rnd() % 2) mutate(p);
+      if (rnd() % 16 == 0) p.clear();   // a dropped frame
+      seq.push_back(p);
+    }
+    th_dec_ctx *d2 = (it & 1) ? th_decode_alloc(&info, setup_keep) : nullptr;
+    const unsigned ahead = 1 + rnd() % 5;
+    size_t announced = 0;
+    for (size_t i = 0; i < seq.size(); i++) {
+      Pkt &p = seq[i];
       ogg_packet op = as_packet(p, 0);
       int64_t gp = 0;
       const int rc = th_decode_packetin(d, &op, &gp);
+      unsigned long sum = 0;
       if (rc < 0) rejected++;
       else {
         decoded++;
         thip_slot_trace t;
         if (th_decode_ctl(d, TH_DECCTL_THIP_GET_SLOT_TRACE, &t, sizeof(t)) != 0) return 3;
         // touch what the trace points to (ASan checks the bounds)
-        long s = 0;
-        for (int64_t k = 0; k < t.ncoded; k++) s += t.fragi[k] + t.last_zzi[k] + t.coeffs[k * 64 + 63] + t.mv[k];
-        for (int64_t k = 0; k < t.nuncoded; k++) s += (long)t.uncoded[k];
-        if (s == 0x7fffffff) printf("!");
+        for (int64_t k = 0; k < t.ncoded; k++)
+          sum = sum * 31 + (unsigned long)(t.fragi[k] + t.last_zzi[k] * 3 + t.coeffs[k * 64 + 63] * 5 + t.coeffs[k * 64] * 7 + t.mv[k] * 11 + t.refi[k] * 13);
+        for (int64_t k = 0; k < t.nuncoded; k++) sum = sum * 31 + (unsigned long)t.uncoded[k];
+      }
+      if (d2) {
+        while (announced < seq.size() && announced < i + ahead) {
+          if (announced < i) announced = i;
+          Pkt q = seq[announced];
+          if (rnd() % 10 == 0) mutate(q);   // (an announcement that does not match: dropped, the packet parsed the ordinary way)
+          ogg_packet oq = as_packet(q, 0);
+          const int prc = th_decode_ctl(d2, TH_DECCTL_THIP_PREFETCH_PACKET, &oq, sizeof(oq));
+          if (prc < 0) return 5;
+          if (prc != 0 && !q.empty() && announced < i + 4) return 6;   // (four slots: refused only when they are full)
+          if (prc != 0 && !q.empty()) break;
+          announced++;
+        }
+        int64_t gp2 = 0;
+        const int rc2 = th_decode_packetin(d2, &op, &gp2);
+        unsigned long sum2 = 0;
+        if (rc2 >= 0) {
+          thip_slot_trace t;
+          if (th_decode_ctl(d2, TH_DECCTL_THIP_GET_SLOT_TRACE, &t, sizeof(t)) != 0) return 3;
+          for (int64_t k = 0; k < t.ncoded; k++)
+            sum2 = sum2 * 31 + (unsigned long)(t.fragi[k] + t.last_zzi[k] * 3 + t.coeffs[k * 64 + 63] * 5 + t.coeffs[k * 64] * 7 + t.mv[k] * 11 + t.refi[k] * 13);
+          for (int64_t k = 0; k < t.nuncoded; k++) sum2 = sum2 * 31 + (unsigned long)t.uncoded[k];
+        }
+        if (rc2 != rc || (rc >= 0 && (gp2 != gp || sum2 != sum))) {
+          printf("look-ahead differs: iteration %d packet %zu rc %d / %d granpos %ld / %ld\n", it, i, rc, rc2, (long)gp, (long)gp2);
+          return 4;
+        }
+        compared++;
       }
     }
+    if (d2) th_decode_free(d2);
     th_ycbcr_buffer yb;
     th_decode_ycbcr_out(d, yb);
     th_decode_free(d);
+    if (setup_keep) th_setup_free(setup_keep);
     th_comment_clear(&tc);
     th_info_clear(&info);
   }
   printf("fe_fuzz: %d iterations, %ld packets decoded, %ld rejected, %ld header sets rejected\n", iters, decoded, rejected,
          hdr_rejected);
+  printf("fe_fuzz: %ld packets compared with a look-ahead context\n", compared);
   return 0;
 }

@@ -174,3 +174,46 @@ def test_dropped_frame_before_any_frame_shows_grey(trace_env):
     for pl in dec.ycbcr_out():
         assert pl.size and np.all(pl == 0x80)
     dec.close()
+
+
+@pytest.mark.parametrize("ahead", [1, 3, 6])
+@pytest.mark.parametrize("w,h,fmt", [(176, 144, 0), (48, 64, 3), (80, 48, 2)])
+def test_announced_packets_give_the_same_slot_calls(trace_env, w, h, fmt, ahead):
+    """TH_DECCTL_THIP_PREFETCH_PACKET (include/theoradec_hip.h): packets announced ahead of their th_decode_packetin are parsed
+    on threads of their own and adopted; return codes, granule positions and every recorded slot call must equal those of a
+    context that was never told anything -- key frames, inter frames, dropped frames, several qi per frame, more announcements
+    than slots, an announcement that does not match what comes, and a context freed with announcements outstanding."""
+    from theora_amd.decoder import Decoder
+    st = streamgen.Stream(w, h, fmt, seed=w + 3 * h + fmt, trees="matched")
+    hdr = st.header_packets()
+    pk = []
+    for f in range(18):
+        if f in (7, 13):
+            pk.append(b"")                      # a dropped frame (decode.c:2746)
+        else:
+            pk.append(st.frame(0 if f % 6 == 0 else 1, density=[0.9, 0.5, 0.15][f % 3])[0])
+    plain, fast = Decoder(hdr), Decoder(hdr)
+    nxt, taken = 0, 0
+    for i, p in enumerate(pk):
+        while nxt < len(pk) and nxt < i + ahead:
+            if nxt < i:
+                nxt = i
+            q = pk[nxt]
+            if nxt == 10 and len(q) > 8:        # announce something else than what will come: dropped, parsed the ordinary way
+                q = bytes(q[:-4]) + b"\x55\xAA\x55\xAA"
+            if fast.prefetch(q):
+                taken += 1
+            elif len(q):
+                break                           # no slot free (option fe_lookahead: four)
+            nxt += 1
+        ra, rb = plain.packetin(p), fast.packetin(p)
+        assert ra == rb, (i, ra, rb)
+        if ra[0] == 0:
+            ta, tb = plain.slot_trace(), fast.slot_trace()
+            for k in ta:
+                assert np.array_equal(ta[k], tb[k]), (i, k)
+    assert taken >= 10
+    fast.prefetch(pk[0])
+    fast.prefetch(pk[1])
+    fast.close()                                # announcements outstanding: waited for, nothing leaks, nothing hangs
+    plain.close()

@@ -53,3 +53,7 @@ def test_mutated_packets_never_crash(fuzz_bin, tmp_path, w, h, fmt, seed):
     m = re.search(r"fe_fuzz: 300 iterations, (\d+) packets decoded, (\d+) rejected, (\d+) header sets rejected", r.stdout)
     assert m, r.stdout[-300:]
     assert int(m.group(1)) > 300 and int(m.group(3)) < 250, r.stdout[-300:]
+    # every other context had a twin that decoded the same mutated packets with a look-ahead (TH_DECCTL_THIP_PREFETCH_PACKET,
+    # announcements that match and announcements that do not): same return codes, granule positions and slot calls
+    m = re.search(r"fe_fuzz: (\d+) packets compared with a look-ahead context", r.stdout)
+    assert m and int(m.group(1)) > 300, r.stdout[-300:]

@@ -221,6 +221,12 @@ struct FeWorker {
   bool solo = false;               // the caller's thread may run on ONE CPU only (taskset -c N): nothing to run beside it on
 };
 
+struct FeLookahead;
+extern "C" {
+static void fe_lookahead_free(th_dec_ctx *d);
+static int fe_prefetch(th_dec_ctx *d, const ogg_packet *op);
+}
+
 struct th_dec_ctx {
   th_info info;
   FeProf prof;
@@ -266,8 +272,12 @@ struct th_dec_ctx {
   // of a fifth for one to four streams, a queue for sixteen.
   int device_lists;
   FeWorker *worker;                  // (created with the first frame that takes the token-list path with option fe_worker on)
+  FeLookahead *la;                   // packets announced ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), or null
+  bool parse_only;                   // a parser context of a look-ahead: no device state, no counters of its own, fe_front only
   FeStream fs;
   uint32_t arrivals[3][64];          // fragments open at every (plane, index) of the current frame
+  thip_token_lists tlp;              // the frame in the one-piece form of the token-list path (fe_pack_lists)
+  bool tl_packed;                    // tlp / tl_tokens / tl_meta / tl_coded hold the frame at hand (an adopted frame's parser did it)
   std::vector<uint32_t> tl_tokens, tl_meta;
   std::vector<int16_t> tl_dc;            // the un-predicted DC values in coded order (token-list path with the DC chain on the host)
   std::vector<int32_t> tl_coded;
@@ -1268,6 +1278,10 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   d->info = *info;
   d->setup = *setup;
   d->hip = nullptr;
+  d->worker = nullptr;
+  d->la = nullptr;
+  d->parse_only = false;
+  d->tl_packed = false;
   d->trace = thip_option("fe_trace_backend") != 0;
   d->tr_flimit = 0;
   if (!d->trace &&
@@ -1347,6 +1361,7 @@ void th_decode_free(th_dec_ctx *d) {
       fprintf(stderr, "  %-28s %8.3f ms/frame %5.1f %%\n", kFeNames[s], 1e3 * d->prof.acc[s] / (double)d->prof.frames,
               100.0 * d->prof.acc[s] / tot);
   }
+  fe_lookahead_free(d);
   if (d->worker) {
     {
       std::lock_guard<std::mutex> lk(d->worker->mu);
@@ -1417,6 +1432,10 @@ int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
       d->device_lists = *(int *)buf != 0 ? 1 : 0;
       return 0;
     }
+    case TH_DECCTL_THIP_PREFETCH_PACKET:
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(ogg_packet)) return TH_EINVAL;
+      return fe_prefetch(d, (const ogg_packet *)buf);
     case TH_DECCTL_THIP_GET_SLOT_TRACE: {
       if (!d || !buf) return TH_EFAULT;
       if (buf_sz != sizeof(thip_slot_trace)) return TH_EINVAL;
@@ -1455,10 +1474,27 @@ double th_granule_time(void *encdec, int64_t granpos) {
   return (double)(th_granule_frame(encdec, granpos) + 1) * ((double)d->info.fps_denominator / (double)d->info.fps_numerator);
 }
 
-// One data packet: spec 7.1 - 7.11, ending in the vtable slots of the HIP backend.
-int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
-  if (!d || !op) return TH_EFAULT;
+// One data packet: spec 7.1 - 7.11, ending in the vtable slots of the HIP backend.  In two halves: fe_front is the entropy decoder
+// (7.1 - 7.7: everything that reads the packet; on the token-list path in groups it hands the lists over as it goes), fe_back
+// what follows the packet's last bit (7.8 and the hand-over of the frame).  A frame's front half depends on nothing an earlier
+// frame left behind -- which is what the look-ahead of th_decode_ctl(TH_DECCTL_THIP_PREFETCH_PACKET) uses: the front halves of the
+// packets a caller has announced run on parser contexts of their own (FeLookahead), th_decode_packetin adopts the result.
+struct FeRun {
+  bool lists_now = false, streaming = false, with_worker = false, dc_done = false;
+  int stream_rc = 0;   // (inline hand-over: the first failure)
+};
+constexpr int kFeContinue = 0x7F00;   // fe_front: the frame goes on to fe_back (anything else is th_decode_packetin's return value)
+
+// is everything behind the entropy decoder the device's (the token-list path) for the frame at hand?
+static bool fe_lists_now(const th_dec_ctx *d) {
+  return !d->trace && d->hip &&
+         (d->device_lists > 0 || (d->device_lists < 0 && !d->device_dc && !d->device_tokens &&
+                                  g_fe_contexts.load(std::memory_order_relaxed) <= kFeListsAutoContexts));
+}
+
+static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun &r) {
   const int N = d->nfrags;
+  d->tl_packed = false;
   int ncoded_total = 0;
   // (a negative length reads as all-zero bits here and in the reference alike -- oc_pack_readinit with
   //  a stop pointer before the start -- i.e. as an intra frame header; only bytes == 0 is a drop)
@@ -1511,7 +1547,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     // Nothing decoded yet: the reference has just made its mid-grey dummy frame (decode.c:2757-2762,
     // oc_dec_init_dummy_frame) and th_decode_ycbcr_out shows that; the backend substitutes the same
     // grey when the first inter frame with coded blocks arrives (thip_decode_frames).
-    if (!d->have_frame)
+    if (!d->have_frame && !d->parse_only)   // (a look-ahead's parser has no pictures: its owner says TH_DUPFRAME itself)
       for (int p = 0; p < 3; p++) memset(d->mirror[p].data(), 0x80, d->mirror[p].size());
     d->curframe_num++;
     if (granpos) *granpos = d->granpos;
@@ -1668,18 +1704,18 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   }
   d->prof.lap(FE_QI);
   // ---- everything behind the entropy decoder on the device, when asked for and possible (decided here: the worker starts now) ----
-  const bool lists_now = !d->trace && d->hip &&
-                         (d->device_lists > 0 || (d->device_lists < 0 && !d->device_dc && !d->device_tokens &&
-                                                  g_fe_contexts.load(std::memory_order_relaxed) <= kFeListsAutoContexts));
+  const bool lists_now = r.lists_now = fe_lists_now(d);
   const int fe_groups = lists_now ? thip_option("fe_groups") : 0;
-  bool streaming = lists_now && fe_groups > 1;   // in groups of indices, as they are decoded (FeStream)
-  int stream_rc = 0;                             // (inline hand-over: the first failure)
+  bool &streaming = r.streaming;                 // in groups of indices, as they are decoded (FeStream)
+  streaming = lists_now && fe_groups > 1;
+  int &stream_rc = r.stream_rc;
   if (streaming && fe_stream_open_frame(d, fe_groups) < 0) streaming = false;   // (the one-piece path below says why)
   if (streaming) {
     stream_rc = thip_state_token_lists_open(d->hip, &d->fs.tl);
     if (stream_rc < 0) streaming = false;   // (THIP_EIMPL: the slots; anything else: reported by the one-piece path below)
   }
-  bool with_worker = lists_now && !d->device_dc && thip_option("fe_worker") != 0;   // the DC chain on the second thread
+  bool &with_worker = r.with_worker;
+  with_worker = lists_now && !d->device_dc && thip_option("fe_worker") != 0;   // the DC chain on the second thread
   if (with_worker && !d->worker) {
     d->worker = new (std::nothrow) FeWorker();
     if (d->worker) {
@@ -1752,8 +1788,65 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     }
   }
   d->prof.lap(FE_TOKENS);
+  return kFeContinue;
+}
+
+// The frame's token lists in the device's format (thip_tokens.h), its coded-fragment list and fragment words: d->tlp, tl_tokens,
+// tl_coded, tl_meta (the one-piece form of the token-list path; a look-ahead's parser does it for its owner).  The tables that
+// need the owner's dequantisation matrices are filled in by fe_back.
+static void fe_pack_lists(th_dec_ctx *d) {
+  thip_token_lists &tl = d->tlp;
+  memset(&tl, 0, sizeof(tl));
+  tl.frame_type = d->frame_type;
+  tl.flimit = d->setup.qp.lflims[d->qis[0]];
+  size_t nt = 0;
+  for (int p = 0; p < 3; p++)
+    for (int z = 0; z < 64; z++) nt += d->ntoks[p][z];
+  d->tl_tokens.resize(nt + 1);
+  uint32_t *o = d->tl_tokens.data();
+  size_t at = 0;
+  for (int p = 0; p < 3; p++)
+    for (int z = 0; z < 64; z++) {
+      tl.list_off[p][z] = (uint32_t)at;
+      tl.list_len[p][z] = (uint32_t)d->ntoks[p][z];
+      tl.eob_carry[p][z] = d->eob_carry[p][z];
+      tl.arrivals[p][z] = d->arrivals[p][z];
+      // (branch-free, one list at a time: the compiler vectorises it)
+      const Tok *__restrict t = d->toks[p][z].data();
+      uint32_t *__restrict w = o + at;
+      const size_t nk = d->ntoks[p][z];
+      for (size_t k = 0; k < nk; k++) {
+        const uint32_t e = t[k].eob;
+        const uint32_t run = e > 0xFFFFFFu ? 0xFFFFFFu : e;   // (more than any plane the backend takes has)
+        const uint32_t we = 0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24;
+        const uint32_t wv = (uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16;
+        w[k] = e ? we : wv;
+      }
+      at += nk;
+    }
+  tl.ntokens = (int64_t)nt;
+  d->prof.lap(FE_LPACK);
+  const size_t nc = d->cl_start[3];
+  d->tl_meta.resize(nc + 1);
+  d->tl_coded.resize(nc + 1);
+  for (int p = 0; p < 3; p++) {
+    tl.ncoded[p] = (int32_t)(d->cl_start[p + 1] - d->cl_start[p]);
+    for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
+      const int f = d->clist[ci];
+      const uint32_t qti = d->mbmode_of_frag[f] != MODE_INTRA;
+      d->tl_coded[ci] = f;
+      d->tl_meta[ci] = (uint32_t)d->refi[f] | ((uint32_t)(p * 3 + d->qii[f]) * 2u + qti) << 2 |
+                       ((uint32_t)d->mvx[f] & 0xFFu) << 8 | ((uint32_t)d->mvy[f] & 0xFFu) << 16 | (uint32_t)p << 24;
+    }
+  }
+}
+
+static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
+  const int N = d->nfrags;
+  const bool lists_now = r.lists_now, streaming = r.streaming, with_worker = r.with_worker;
+  const int stream_rc = r.stream_rc;
   // ---- 7.8 undo DC prediction: fe_undo_dc -------------------------------------------------------------
-  bool dc_done = false;
+  bool &dc_done = r.dc_done;
   auto undo_dc = [&]() {
     dc_done = true;
     fe_undo_dc(d);
@@ -1800,50 +1893,12 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     if (lrc >= 0) lists_done = true;
     else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
   } else if (lists_now) {
-    thip_token_lists tl;
-    memset(&tl, 0, sizeof(tl));
-    tl.frame_type = d->frame_type;
-    tl.flimit = d->setup.qp.lflims[d->qis[0]];
-    size_t nt = 0;
-    for (int p = 0; p < 3; p++)
-      for (int z = 0; z < 64; z++) nt += d->ntoks[p][z];
-    d->tl_tokens.resize(nt + 1);
-    uint32_t *o = d->tl_tokens.data();
-    size_t at = 0;
-    for (int p = 0; p < 3; p++)
-      for (int z = 0; z < 64; z++) {
-        tl.list_off[p][z] = (uint32_t)at;
-        tl.list_len[p][z] = (uint32_t)d->ntoks[p][z];
-        tl.eob_carry[p][z] = d->eob_carry[p][z];
-        tl.arrivals[p][z] = d->arrivals[p][z];
-        // (branch-free, one list at a time: the compiler vectorises it)
-        const Tok *__restrict t = d->toks[p][z].data();
-        uint32_t *__restrict w = o + at;
-        const size_t nk = d->ntoks[p][z];
-        for (size_t k = 0; k < nk; k++) {
-          const uint32_t e = t[k].eob;
-          const uint32_t run = e > 0xFFFFFFu ? 0xFFFFFFu : e;   // (more than any plane the backend takes has)
-          const uint32_t we = 0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24;
-          const uint32_t wv = (uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16;
-          w[k] = e ? we : wv;
-        }
-        at += nk;
-      }
-    d->prof.lap(FE_LPACK);
+    if (!d->tl_packed) fe_pack_lists(d);   // (an adopted frame may bring them packed)
+    d->tl_packed = false;
+    thip_token_lists &tl = d->tlp;
     const size_t nc = d->cl_start[3];
-    d->tl_meta.resize(nc + 1);
-    d->tl_coded.resize(nc + 1);
-    for (int p = 0; p < 3; p++) {
-      tl.ncoded[p] = (int32_t)(d->cl_start[p + 1] - d->cl_start[p]);
-      for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
-        const int f = d->clist[ci];
-        const uint32_t qti = d->mbmode_of_frag[f] != MODE_INTRA;
-        d->tl_coded[ci] = f;
-        d->tl_meta[ci] = (uint32_t)d->refi[f] | ((uint32_t)(p * 3 + d->qii[f]) * 2u + qti) << 2 |
-                         ((uint32_t)d->mvx[f] & 0xFFu) << 8 | ((uint32_t)d->mvy[f] & 0xFFu) << 16 | (uint32_t)p << 24;
-      }
+    for (int p = 0; p < 3; p++)
       for (int qti = 0; qti < 2; qti++) tl.dc_quant[p][qti] = d->dequant[(((size_t)d->qis[0] * 3 + p) * 2 + qti) * 64];
-    }
     uint16_t dq[18 * 64];
     memset(dq, 0, sizeof(dq));
     for (int p = 0; p < 3; p++)
@@ -1851,7 +1906,6 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         for (int qti = 0; qti < 2; qti++)
           memcpy(dq + ((p * 3 + qii) * 2 + qti) * 64, &d->dequant[(((size_t)d->qis[qii] * 3 + p) * 2 + qti) * 64], 128);
     tl.tokens = d->tl_tokens.data();
-    tl.ntokens = (int64_t)nt;
     tl.coded = d->tl_coded.data();
     tl.frag_meta = d->tl_meta.data();
     tl.dequant = dq;
@@ -1868,9 +1922,11 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
         dcv = d->tl_dc.data();
         d->prof.lap(FE_DC);
       } else if (!d->device_dc) {
-        undo_dc();
-        d->tl_dc.resize(nc + 1);
-        for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
+        if (!dc_done) {   // (an adopted frame brings the values along, in both orders)
+          undo_dc();
+          d->tl_dc.resize(nc + 1);
+          for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
+        }
         dcv = d->tl_dc.data();
         d->prof.lap(FE_DC);
       }
@@ -2048,6 +2104,318 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     d->stripe_cb.stripe_decoded(d->stripe_cb.ctx, yb, 0, d->nv[0]);
   }
   return 0;
+}
+
+// ---- look-ahead: the front halves of announced packets on parser contexts of their own ---------------------------------------
+// What th_decode_packetin reads out of a packet depends on the headers and on nothing an earlier frame left behind (the coded
+// flags, modes, vectors, qi indices and tokens of a frame are self-contained; DC prediction runs inside a frame; only the
+// PICTURES form a chain).  A caller that has packets in hand before their turn -- a demultiplexer's queue, a file -- announces them
+// in decode order with th_decode_ctl(TH_DECCTL_THIP_PREFETCH_PACKET): each is copied and parsed (fe_front, then the DC chain) by
+// a thread of its own on a parser context; the th_decode_packetin that later gets the same bytes adopts the result (vectors
+// swapped, not copied) and does only what the chain of pictures needs: the hand-over to the device.  One stream is no longer one
+// host thread.  A packet that was not announced, or does not match what was, is parsed the ordinary way (whatever was announced is
+// dropped first); nothing changes for a caller that never asks.
+constexpr int kFeLookaheadMax = 16;
+struct FeSlot {
+  th_dec_ctx *ctx = nullptr;        // the parser context (created with the slot's first packet)
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool go = false, quit = false;    // (under mu)
+  std::atomic<int> done{0};         // the packet is parsed, rc says how it went
+  bool busy = false;                // holds a packet (the caller's thread only)
+  int rc = 0;
+  bool want_lists = false;          // the owner takes the token-list path: the parser packs the lists too (fe_pack_lists)
+  std::vector<uint8_t> pkt;
+  long bytes = 0;
+};
+struct FeLookahead {
+  int nslots = 0, head = 0, count = 0;   // a ring in announcement order: the oldest packet is in slot `head`
+  FeSlot slots[kFeLookaheadMax];
+  th_dec_ctx *owner = nullptr;
+  cpu_set_t domain;
+  bool placed = false;
+  long adopted = 0, missed = 0;
+};
+
+static void fe_init_frame_arrays(th_dec_ctx *d) {
+  d->coded.assign(d->nfrags, 0);
+  d->refi.assign(d->nfrags, 0);
+  d->qii.assign(d->nfrags, 0);
+  d->qii_dirty = false;
+  d->mvx.assign(d->nfrags, 0);
+  d->mvy.assign(d->nfrags, 0);
+  d->dc.assign(d->nfrags, 0);
+  d->mbmode_of_frag.assign(d->nfrags, 0);
+  d->mbmodes.assign(d->mbs.size(), 0);
+}
+
+static th_dec_ctx *fe_new_parser(const th_dec_ctx *m) {
+  th_dec_ctx *s = new (std::nothrow) th_dec_ctx();
+  if (!s) return nullptr;
+  s->info = m->info;
+  s->setup = m->setup;   // (its own copy of the code tables: they are what the parser's core keeps in its cache)
+  s->hip = nullptr;
+  s->worker = nullptr;
+  s->la = nullptr;
+  s->parse_only = true;
+  s->tl_packed = false;
+  s->trace = false;
+  s->device_dc = s->device_tokens = false;
+  s->device_lists = 0;
+  s->pp_level = 0;
+  s->dc_qis_tracked = false;
+  s->granpos_bias = m->granpos_bias;
+  s->keyframe_num = s->curframe_num = 0;
+  s->granpos = 0;
+  s->have_frame = false;
+  s->stripe_cb.ctx = nullptr;
+  s->stripe_cb.stripe_decoded = nullptr;
+  memset(&s->prof, 0, sizeof(s->prof));
+  build_geometry(s);
+  fe_init_frame_arrays(s);
+  return s;
+}
+
+// one announced packet on a parser context: everything that reads the packet, then the DC chain (values in both orders)
+static void fe_parse_job(FeSlot &sl) {
+  th_dec_ctx *s = sl.ctx;
+  ogg_packet op;
+  memset(&op, 0, sizeof(op));
+  op.packet = sl.pkt.data();
+  op.bytes = sl.bytes;
+  FeRun r;
+  s->qii_dirty = true;   // (the coded blocks' entries are always written: the owner takes exactly those)
+  int rc = fe_front(s, &op, nullptr, r);
+  if (rc == kFeContinue) {
+    fe_undo_dc(s);
+    const size_t nc = s->cl_start[3];
+    s->tl_dc.resize(nc + 1);
+    for (size_t ci = 0; ci < nc; ci++) s->tl_dc[ci] = s->dc[s->clist[ci]];
+    s->tl_packed = false;
+    if (sl.want_lists) {
+      fe_pack_lists(s);
+      s->tl_packed = true;
+    }
+  }
+  sl.rc = rc;
+}
+
+static void fe_slot_main(FeSlot *sl) {
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(sl->mu);
+      sl->cv.wait(lk, [&] { return sl->go || sl->quit; });
+      if (sl->quit) return;
+      sl->go = false;
+    }
+    fe_parse_job(*sl);
+    sl->done.store(1, std::memory_order_release);
+  }
+}
+
+static void fe_slot_wait(FeSlot &sl) {
+  for (unsigned spins = 0; !sl.done.load(std::memory_order_acquire); spins++) {
+    if (spins < 8192) __builtin_ia32_pause();
+    else std::this_thread::yield();
+  }
+}
+
+// every announced packet dropped (their parsers are waited for: they write into the slots' contexts)
+static void fe_lookahead_drop(FeLookahead *la) {
+  for (int i = 0; i < la->count; i++) {
+    FeSlot &sl = la->slots[(la->head + i) % la->nslots];
+    fe_slot_wait(sl);
+    sl.busy = false;
+  }
+  la->missed += la->count;
+  la->head = la->count = 0;
+}
+
+static void fe_lookahead_free(th_dec_ctx *d) {
+  FeLookahead *la = d->la;
+  if (!la) return;
+  for (int i = 0; i < kFeLookaheadMax; i++) {
+    FeSlot &sl = la->slots[i];
+    if (sl.th.joinable()) {
+      {
+        std::lock_guard<std::mutex> lk(sl.mu);
+        sl.quit = true;
+      }
+      sl.cv.notify_one();
+      sl.th.join();
+    }
+    delete sl.ctx;   // (a parser context owns no device state, no threads and no count in g_fe_contexts)
+  }
+  if (d->prof.on) fprintf(stderr, "[thip front end] look-ahead: %ld packets adopted, %ld announced and not used\n", la->adopted, la->missed);
+  delete la;
+  d->la = nullptr;
+}
+
+// The parser threads next to the caller and never ON its CPU: on the CPUs that share its last-level cache, inside what the caller
+// itself may use (see fe_worker_place), without the one the caller is running on -- a thread woken on its waker's CPU runs FIRST
+// there, and the th_decode_ctl that announced a packet would return when the packet is parsed (measured: pthread_cond_signal
+// 0.46 ms with a 0.5 ms job on the same CPU, 0.012 ms next to it).  Asked again when the caller turns up on one of their CPUs.
+// false: the caller is confined to one CPU -- nothing would run beside it.
+static bool fe_lookahead_place(FeLookahead *la) {
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  const bool know = sched_getaffinity(0, sizeof(allowed), &allowed) == 0;
+  if (know && CPU_COUNT(&allowed) < 2) return false;
+  if (thip_option("fe_worker_pin") == 0 || !know) return true;
+  const int cpu = sched_getcpu();
+  if (cpu < 0 || cpu >= CPU_SETSIZE) return true;
+  if (la->placed && !CPU_ISSET(cpu, &la->domain)) return true;
+  cpu_set_t set;
+  if (fe_llc_cpus(cpu, &set)) CPU_AND(&set, &set, &allowed);
+  else set = allowed;
+  // (fewer CPUs in the cache domain than threads that want to run: the whole of what the caller may use)
+  if (CPU_COUNT(&set) < la->nslots + 1) set = allowed;
+  CPU_CLR(cpu, &set);
+  for (int i = 0; i < la->nslots; i++)
+    if (la->slots[i].th.joinable()) (void)pthread_setaffinity_np(la->slots[i].th.native_handle(), sizeof(set), &set);
+  la->domain = set;
+  la->placed = true;
+  return true;
+}
+
+// TH_DECCTL_THIP_PREFETCH_PACKET.  0: announced; 1: not taken (no slot free, an empty packet, a context that leaves the DC chain or
+// the token expansion to the device, a caller confined to one CPU) -- th_decode_packetin parses it itself then, as ever.
+static int fe_prefetch(th_dec_ctx *d, const ogg_packet *op) {
+  if (d->parse_only) return TH_EINVAL;
+  if (op->bytes <= 0 || !op->packet) return 1;   // (a dropped frame: nothing to parse)
+  if (d->device_dc || d->device_tokens) return 1;
+  int want = thip_option("fe_lookahead");
+  if (want <= 0) return 1;
+  if (want > kFeLookaheadMax) want = kFeLookaheadMax;
+  FeLookahead *la = d->la;
+  if (!la) {
+    la = d->la = new (std::nothrow) FeLookahead();
+    if (!la) return 1;
+    la->owner = d;
+    la->nslots = want;
+  }
+  if (la->count >= la->nslots) return 1;
+  FeSlot &sl = la->slots[(la->head + la->count) % la->nslots];
+  if (!sl.ctx) {
+    sl.ctx = fe_new_parser(d);
+    if (!sl.ctx) return 1;
+  }
+  if (!sl.th.joinable()) {
+    try {
+      sl.th = std::thread(fe_slot_main, &sl);
+    } catch (...) {
+      return 1;
+    }
+    la->placed = false;   // (a new thread: placed below with the others)
+  }
+  if (!fe_lookahead_place(la)) return 1;
+  sl.bytes = op->bytes;
+  sl.pkt.resize((size_t)op->bytes);
+  memcpy(sl.pkt.data(), op->packet, (size_t)op->bytes);
+  sl.want_lists = fe_lists_now(d);
+  sl.done.store(0, std::memory_order_relaxed);
+  sl.busy = true;
+  la->count++;
+  {
+    std::lock_guard<std::mutex> lk(sl.mu);
+    sl.go = true;
+  }
+  sl.cv.notify_one();
+  return 0;
+}
+
+// the oldest announced packet if it is `op`, parsed; null (and everything announced dropped) otherwise
+static FeSlot *fe_lookahead_take(th_dec_ctx *d, const ogg_packet *op) {
+  FeLookahead *la = d->la;
+  if (!la || !la->count) return nullptr;
+  FeSlot &sl = la->slots[la->head];
+  const bool same = op->bytes > 0 && op->bytes == sl.bytes && op->packet && !memcmp(op->packet, sl.pkt.data(), (size_t)sl.bytes) &&
+                    !d->device_dc && !d->device_tokens;
+  if (!same) {
+    fe_lookahead_drop(la);
+    return nullptr;
+  }
+  fe_slot_wait(sl);
+  la->head = (la->head + 1) % la->nslots;
+  la->count--;
+  sl.busy = false;
+  if (sl.rc != kFeContinue) {   // a frame without coded blocks, a packet the parser refused: the owner says so itself (cheap)
+    la->missed++;
+    return nullptr;
+  }
+  la->adopted++;
+  return &sl;
+}
+
+// the parsed frame of a parser context becomes the owner's: what fe_front would have left behind
+static void fe_adopt(th_dec_ctx *d, th_dec_ctx *s) {
+  d->coded.swap(s->coded);
+  d->refi.swap(s->refi);
+  d->mbmode_of_frag.swap(s->mbmode_of_frag);
+  d->mvx.swap(s->mvx);
+  d->mvy.swap(s->mvy);
+  d->dc.swap(s->dc);
+  d->clist.swap(s->clist);
+  d->ulist.swap(s->ulist);
+  d->tl_dc.swap(s->tl_dc);
+  d->tl_packed = s->tl_packed;
+  if (s->tl_packed) {
+    d->tl_tokens.swap(s->tl_tokens);
+    d->tl_meta.swap(s->tl_meta);
+    d->tl_coded.swap(s->tl_coded);
+    d->tlp = s->tlp;
+    s->tl_packed = false;
+  }
+  for (int p = 0; p < 3; p++)
+    for (int z = 0; z < 64; z++) d->toks[p][z].swap(s->toks[p][z]);
+  memcpy(d->cl_start, s->cl_start, sizeof(d->cl_start));
+  memcpy(d->ul_start, s->ul_start, sizeof(d->ul_start));
+  memcpy(d->ntoks, s->ntoks, sizeof(d->ntoks));
+  memcpy(d->eob_carry, s->eob_carry, sizeof(d->eob_carry));
+  memcpy(d->arrivals, s->arrivals, sizeof(d->arrivals));
+  memcpy(d->qis, s->qis, sizeof(d->qis));
+  d->nqis = s->nqis;
+  d->frame_type = s->frame_type;
+  // the qi index of a block outlives the frame (an uncoded block keeps the one it was last coded with, decode.c:913-917): the
+  // owner's array takes the coded blocks' entries, as the pass of 7.6 in fe_front would have written them
+  const size_t nc = d->cl_start[3];
+  const int *cl = d->clist.data();
+  if (d->nqis > 1 || d->qii_dirty) {
+    const uint8_t *sq = s->qii.data();
+    uint8_t *dq = d->qii.data();
+    for (size_t i = 0; i < nc; i++) dq[cl[i]] = sq[cl[i]];
+    if (d->frame_type == THIP_INTRA_FRAME) d->qii_dirty = false;
+  }
+  if (d->nqis > 1) d->qii_dirty = true;
+  // frame counters (fe_front, 7.1 and 7.4)
+  d->granpos = ((d->keyframe_num + d->granpos_bias) << d->info.keyframe_granule_shift) + (d->curframe_num - d->keyframe_num);
+  if (d->frame_type == THIP_INTRA_FRAME) {
+    d->keyframe_num = d->curframe_num;
+    d->granpos = ((d->keyframe_num + d->granpos_bias) << d->info.keyframe_granule_shift);
+  }
+  if (d->prof.on)
+    for (int p = 0; p < 3; p++)
+      for (int z = 0; z < 64; z++) d->prof.tokens += (long)d->ntoks[p][z];
+}
+
+int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
+  if (!d || !op) return TH_EFAULT;
+  if (d->parse_only) return TH_EINVAL;
+  FeRun r;
+  if (d->la && d->la->count) {
+    d->prof.start();
+    if (FeSlot *sl = fe_lookahead_take(d, op)) {
+      fe_adopt(d, sl->ctx);
+      r.lists_now = fe_lists_now(d);
+      r.dc_done = true;
+      d->prof.lap(FE_TOKENS);   // (the wait for the parser, if any, and the adoption)
+      return fe_back(d, granpos, r);
+    }
+  }
+  const int rc = fe_front(d, op, granpos, r);
+  if (rc != kFeContinue) return rc;
+  return fe_back(d, granpos, r);
 }
 
 int th_decode_ycbcr_out(th_dec_ctx *d, th_ycbcr_buffer ycbcr) {

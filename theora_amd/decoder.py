@@ -9,6 +9,7 @@ from ._lib import OggPacket, ThComment, ThImgPlane, ThInfo, TheoraHipError
 
 TH_DUPFRAME = 1
 TH_DECCTL_THIP_GET_SLOT_TRACE = 0x7101
+TH_DECCTL_THIP_PREFETCH_PACKET = 0x7105
 
 
 class SlotTrace(C.Structure):
@@ -57,6 +58,15 @@ class Decoder:
         if rc < 0:
             raise TheoraHipError("th_decode_packetin returned %d" % rc)
         return rc, gp.value
+
+    def prefetch(self, data):
+        """TH_DECCTL_THIP_PREFETCH_PACKET: announce a packet that a later packetin() will bring (decode order).  True when
+        it was taken; the pictures are the same either way."""
+        op, keep = _packet(data)
+        rc = self._L.th_decode_ctl(self._dec, TH_DECCTL_THIP_PREFETCH_PACKET, C.byref(op), C.sizeof(op))
+        if rc < 0:
+            raise TheoraHipError("TH_DECCTL_THIP_PREFETCH_PACKET returned %d" % rc)
+        return rc == 0
 
     def ycbcr_out(self):
         """Three numpy planes, display order (top row first), the full coded frame."""
