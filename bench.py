@@ -417,6 +417,9 @@ def main_e2e(main_args, argv):
     ap.add_argument("--e2e-size", default="", choices=["", "720p", "1080p", "4k", "cif", "qcif"], help="picture size of the generated packets")
     ap.add_argument("--no-native", action="store_true", help="skip the dump_video_hip / decode_bench legs")
     ap.add_argument("--trees", choices=["matched", "random"], default="matched")
+    ap.add_argument("--lookahead", type=int, default=0,
+                    help="announce every packet this many packets ahead of its th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET: "
+                         "parsed on the library's own threads, up to option fe_lookahead = 4 at a time); 0: the plain API loop")
     ap.add_argument("--packets", choices=["dense", "typical"], default="dense",
                     help="dense: 70 %% of the super blocks coded, 30 %% of the coded blocks with AC coefficients "
                          "(~80 KB per 720p frame); typical: 35 %% / 15 %% (closer to SURVEY section 6's statistics, ~30 KB)")
@@ -455,12 +458,18 @@ def main_e2e(main_args, argv):
 
     def worker(i):
         dec = decs[i]
-        for _ in range(args.loops):
-            for p in pkts:
-                dec.packetin(p)
-                if not args.no_output:
-                    dec.ycbcr_out()
-                counts[i] += 1
+        seq = pkts * args.loops
+        nxt = 0
+        for k, p in enumerate(seq):
+            while args.lookahead and nxt < len(seq) and nxt < k + args.lookahead:
+                nxt = max(nxt, k)
+                if not dec.prefetch(seq[nxt]) and len(seq[nxt]):
+                    break                    # no slot free
+                nxt += 1
+            dec.packetin(p)
+            if not args.no_output:
+                dec.ycbcr_out()
+            counts[i] += 1
         if args.no_output:
             dec.ycbcr_out()
 
@@ -477,9 +486,12 @@ def main_e2e(main_args, argv):
     n = sum(counts)
     print(json.dumps({"metric": "end-to-end decode frames/sec (%s 4:2:0, packets in host memory -> YUV in host memory)" % args.size,
                       "value": round(n / el, 2), "unit": "frames/s", "frames": n, "host_threads": T, "streams": T,
-                      "avg_packet_bytes": nbytes // len(pkts), "with_ycbcr_out": not args.no_output,
+                      "avg_packet_bytes": nbytes // len(pkts), "with_ycbcr_out": not args.no_output, "lookahead": args.lookahead,
                       "data": "synthetic packets (tests/streamgen.py), %s content, %s Huffman trees" % (args.packets, args.trees),
-                      "note": "host-bound: one entropy-decode thread per stream + PCIe; th_decode_* contexts are independent"}))
+                      "note": "host-bound: one entropy-decode thread per stream + PCIe; th_decode_* contexts are independent"
+                              if not args.lookahead else
+                              "packets announced ahead: the entropy decoder runs on the library's parser threads (up to 4 per stream), "
+                              "the caller's thread hands frames to the device"}))
     for dec in decs:
         dec.close()
     # the same packets in an Ogg file through the C program (examples/dump_video_hip.c): no Python between the calls
@@ -505,8 +517,9 @@ def main_e2e(main_args, argv):
             # many streams, one native host thread each (examples/decode_bench.c)
             nb = os.path.join(ROOT, "examples", "decode_bench")
             if os.path.exists(nb):
-                for nt in (1, 2, 4, 8, 16, 32, 64):
-                    r = subprocess.run([nb, ogv, str(nt), "2"], capture_output=True, text=True, timeout=900)
+                for nt, la in [(n, 0) for n in (1, 2, 4, 8, 16, 32, 64)] + [(1, 4), (2, 4), (4, 4)]:
+                    r = subprocess.run([nb, ogv, str(nt), "2"] + (["--lookahead", str(la)] if la else []),
+                                       capture_output=True, text=True, timeout=900)
                     line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "{}"
                     try:
                         d = json.loads(line)

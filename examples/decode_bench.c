@@ -3,7 +3,11 @@
  * batch configuration, end to end: packets in host memory -> frames in host memory).
  *
  *   cc -O2 -pthread -Iinclude examples/decode_bench.c -Ltheora_amd -ltheora_hip -o decode_bench
- *   decode_bench in.ogv <threads> <loops> [--no-output]
+ *   decode_bench in.ogv <threads> <loops> [--no-output] [--lookahead K]
+ *
+ * --lookahead K: every stream announces its packets K ahead (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET, what a player does
+ * with the packets its demultiplexer has queued): the library parses them on threads of its own and th_decode_packetin only
+ * hands the frame to the GPU -- one stream is no longer bound by one host thread.
  *
  * The contexts take the node's GPUs in turn (context i on device i mod thip_device_count()): a single
  * stream stays on one GPU, the batch is spread over all of them.
@@ -27,7 +31,7 @@ typedef struct {
 } packet;
 
 static packet *g_pkts;
-static int g_npkts, g_nhdr, g_loops, g_output;
+static int g_npkts, g_nhdr, g_loops, g_output, g_ahead;
 static pthread_barrier_t g_start;
 
 typedef struct {
@@ -39,11 +43,21 @@ typedef struct {
 static void *run(void *arg) {
   worker *w = (worker *)arg;
   int l, i;
+  const long ndata = g_npkts - g_nhdr, total = ndata * g_loops;
+  long cur = 0, nxt = 0;   /* packets decoded / announced so far */
   pthread_barrier_wait(&g_start);
   for (l = 0; l < g_loops && w->rc == 0; l++)
-    for (i = g_nhdr; i < g_npkts; i++) {
+    for (i = g_nhdr; i < g_npkts; i++, cur++) {
       ogg_packet op;
       int64_t gp;
+      while (g_ahead && nxt < total && nxt < cur + g_ahead) {
+        if (nxt < cur) nxt = cur;
+        memset(&op, 0, sizeof(op));
+        op.packet = g_pkts[g_nhdr + nxt % ndata].data;
+        op.bytes = g_pkts[g_nhdr + nxt % ndata].bytes;
+        if (th_decode_ctl(w->dec, TH_DECCTL_THIP_PREFETCH_PACKET, &op, sizeof(op)) != 0 && op.bytes > 0) break;   /* no slot free */
+        nxt++;
+      }
       memset(&op, 0, sizeof(op));
       op.packet = g_pkts[i].data;
       op.bytes = g_pkts[i].bytes;
@@ -59,12 +73,16 @@ static void *run(void *arg) {
 
 int main(int argc, char **argv) {
   if (argc < 4) {
-    fprintf(stderr, "usage: %s in.ogv <threads> <loops> [--no-output]\n", argv[0]);
+    fprintf(stderr, "usage: %s in.ogv <threads> <loops> [--no-output] [--lookahead K]\n", argv[0]);
     return 1;
   }
   const int nthreads = atoi(argv[2]);
   g_loops = atoi(argv[3]);
-  g_output = !(argc > 4 && !strcmp(argv[4], "--no-output"));
+  g_output = 1;
+  for (int a = 4; a < argc; a++) {
+    if (!strcmp(argv[a], "--no-output")) g_output = 0;
+    else if (!strcmp(argv[a], "--lookahead") && a + 1 < argc) g_ahead = atoi(argv[++a]);
+  }
   thip_ogg_reader *og = thip_ogg_open_file(argv[1]);
   if (!og || nthreads < 1 || g_loops < 1) return 1;
   /* all packets of the first logical stream */
@@ -130,10 +148,10 @@ int main(int argc, char **argv) {
   clock_gettime(CLOCK_MONOTONIC, &t1);
   const double el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
   printf("{\"streams\": %d, \"host_threads\": %d, \"frames\": %ld, \"seconds\": %.4f, \"frames_per_s\": %.1f, "
-         "\"size\": \"%ux%u\", \"gpus\": %d, \"with_ycbcr_out\": %s, \"ok\": %s}\n",
+         "\"size\": \"%ux%u\", \"gpus\": %d, \"with_ycbcr_out\": %s, \"lookahead\": %d, \"ok\": %s}\n",
          nthreads, nthreads, frames, el, el > 0 ? (double)frames / el : 0.0, (unsigned)ti.frame_width, (unsigned)ti.frame_height,
          ndev < nthreads ? ndev : nthreads,
-         g_output ? "true" : "false", bad ? "false" : "true");
+         g_output ? "true" : "false", g_ahead, bad ? "false" : "true");
   for (i = 0; i < nthreads; i++) th_decode_free(w[i].dec);
   th_comment_clear(&tc);
   th_info_clear(&ti);

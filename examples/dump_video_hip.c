@@ -3,7 +3,11 @@
  * container (the reference uses libogg), theoradec_hip.h for th_decode_*.
  *
  *   cc -Iinclude examples/dump_video_hip.c -Ltheora_amd -ltheora_hip -o dump_video_hip
- *   dump_video_hip [-o out.y4m] [-c|--crop] [-r|--raw] [-f|--fps-only] in.ogv
+ *   dump_video_hip [-o out.y4m] [-c|--crop] [-r|--raw] [-f|--fps-only] [--lookahead K] in.ogv
+ *
+ * The tool reads K (default 4, 0: none) data packets ahead of the one it decodes and announces each to the library as it
+ * comes off the demultiplexer (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET): their entropy decoding runs on the library's
+ * parser threads while th_decode_packetin / th_decode_ycbcr_out of the current frame run here.  The frames are the same.
  *
  * Same observable behaviour as the reference tool for one Theora stream: the first logical stream
  * whose first packet is a Theora identification header is decoded, other streams are skipped;
@@ -37,24 +41,74 @@ static void write_frame(FILE *out, const th_info *ti, th_ycbcr_buffer yb, int cr
   }
 }
 
+/* the data packets read ahead of the one being decoded (copies: the demultiplexer's buffer is its own) */
+#define QMAX 17
+typedef struct {
+  unsigned char *data;
+  long bytes, cap;
+} queued_packet;
+static queued_packet g_q[QMAX];
+static int g_qhead, g_qcount;
+
+static void queue_push(th_dec_ctx *td, const ogg_packet *op, int announce) {
+  queued_packet *q = &g_q[(g_qhead + g_qcount) % QMAX];
+  if (op->bytes > q->cap) {
+    q->cap = op->bytes + 4096;
+    q->data = (unsigned char *)realloc(q->data, (size_t)q->cap);
+    if (!q->data) exit(1);
+  }
+  q->bytes = op->bytes > 0 ? op->bytes : 0;
+  if (q->bytes) memcpy(q->data, op->packet, (size_t)q->bytes);
+  g_qcount++;
+  if (announce && q->bytes) {
+    ogg_packet a;
+    memset(&a, 0, sizeof(a));
+    a.packet = q->data;
+    a.bytes = q->bytes;
+    (void)th_decode_ctl(td, TH_DECCTL_THIP_PREFETCH_PACKET, &a, sizeof(a));   /* 1 = not taken: parsed in its turn, as ever */
+  }
+}
+
+/* the oldest queued packet through th_decode_packetin (+ th_decode_ycbcr_out and the output file) */
+static int decode_head(th_dec_ctx *td, FILE *out, const th_info *ti, int crop, int raw, long *frames) {
+  int64_t gp = -1;
+  ogg_packet cur;
+  memset(&cur, 0, sizeof(cur));
+  cur.packet = g_q[g_qhead].data;
+  cur.bytes = g_q[g_qhead].bytes;
+  g_qhead = (g_qhead + 1) % QMAX;
+  g_qcount--;
+  if (th_decode_packetin(td, &cur, &gp) < 0) return 0;   /* undecodable packet: no frame, like the reference */
+  ++*frames;
+  if (out) {
+    th_ycbcr_buffer yb;
+    if (th_decode_ycbcr_out(td, yb) < 0) return -1;
+    write_frame(out, ti, yb, crop, raw);
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const char *in = NULL, *outname = NULL;
-  int crop = 0, raw = 0, fps_only = 0, i;
+  int crop = 0, raw = 0, fps_only = 0, lookahead = 4, i;
   for (i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "-o") && i + 1 < argc) outname = argv[++i];
     else if (!strcmp(argv[i], "-c") || !strcmp(argv[i], "--crop")) crop = 1;
     else if (!strcmp(argv[i], "-r") || !strcmp(argv[i], "--raw")) raw = 1;
     else if (!strcmp(argv[i], "-f") || !strcmp(argv[i], "--fps-only")) fps_only = 1;
+    else if (!strcmp(argv[i], "--lookahead") && i + 1 < argc) lookahead = atoi(argv[++i]);
     else if (argv[i][0] != '-') in = argv[i];
     else {
-      fprintf(stderr, "usage: %s [-o out.y4m] [--crop] [--raw] [--fps-only] in.ogv\n", argv[0]);
+      fprintf(stderr, "usage: %s [-o out.y4m] [--crop] [--raw] [--fps-only] [--lookahead K] in.ogv\n", argv[0]);
       return 1;
     }
   }
   if (!in) {
-    fprintf(stderr, "usage: %s [-o out.y4m] [--crop] [--raw] [--fps-only] in.ogv\n", argv[0]);
+    fprintf(stderr, "usage: %s [-o out.y4m] [--crop] [--raw] [--fps-only] [--lookahead K] in.ogv\n", argv[0]);
     return 1;
   }
+  if (lookahead < 0) lookahead = 0;
+  if (lookahead > QMAX - 1) lookahead = QMAX - 1;
   thip_ogg_reader *og = thip_ogg_open_file(in);
   if (!og) {
     fprintf(stderr, "cannot read %s\n", in);
@@ -136,18 +190,12 @@ int main(int argc, char **argv) {
                 (int)ti.fps_denominator, 'p', (int)ti.aspect_numerator, (int)ti.aspect_denominator);
       }
     }
-    {
-      int64_t gp = -1;
-      const int rc = th_decode_packetin(td, &op, &gp);
-      if (rc < 0) continue;   /* undecodable packet: no frame, like the reference */
-      frames++;
-      if (out) {
-        th_ycbcr_buffer yb;
-        if (th_decode_ycbcr_out(td, yb) < 0) return 1;
-        write_frame(out, &ti, yb, crop, raw);
-      }
-    }
+    queue_push(td, &op, lookahead > 0);
+    /* (while fewer than `lookahead` packets wait behind the oldest, keep reading: they are being parsed meanwhile) */
+    if (g_qcount > lookahead && decode_head(td, out, &ti, crop, raw, &frames) < 0) return 1;
   }
+  while (td && g_qcount)   /* the file has ended: what was read ahead */
+    if (decode_head(td, out, &ti, crop, raw, &frames) < 0) return 1;
   clock_gettime(CLOCK_MONOTONIC, &t1);
   {
     int64_t bad = 0, gaps = 0;

@@ -12,7 +12,8 @@ from tests import streamgen, util
 pytestmark = pytest.mark.gpu
 
 
-def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=False, device_tokens=False, device_lists=False):
+def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=False, device_tokens=False, device_lists=False,
+               lookahead=0):
     import ctypes as C
     from theora_amd.decoder import Decoder
     st = streamgen.Stream(w, h, fmt, seed, trees=trees)
@@ -30,9 +31,23 @@ def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=Fa
     assert dec.comment.vendor == b"theora-hip streamgen"
     ost = oracle.State(w, h, fmt)
     nnew = 0
+    ahead = []   # lookahead > 0: the packets are made up front and announced that far ahead (TH_DECCTL_THIP_PREFETCH_PACKET)
+    if lookahead:
+        ahead = [st.frame(0 if f % kf == 0 else 1, density=[0.9, 0.5, 0.15][f % 3]) for f in range(nframes)]
+    announced = taken = 0
     for f in range(nframes):
         ftype = 0 if f % kf == 0 else 1
-        pkt, truth = st.frame(ftype, density=[0.9, 0.5, 0.15][f % 3])
+        if lookahead:
+            pkt, truth = ahead[f]
+            while announced < nframes and announced < f + lookahead:
+                announced = max(announced, f)
+                if dec.prefetch(ahead[announced][0]):
+                    taken += 1
+                elif len(ahead[announced][0]):
+                    break
+                announced += 1
+        else:
+            pkt, truth = st.frame(ftype, density=[0.9, 0.5, 0.15][f % 3])
         rc, gp = dec.packetin(pkt)
         if truth["dup"]:
             assert rc == 1, f
@@ -46,7 +61,21 @@ def run_stream(hip, w, h, fmt, seed, nframes, kf=5, trees="random", device_dc=Fa
             want = ost.get_plane(oracle.FRAME_PREV, pli)[::-1]
             assert np.array_equal(got[pli], want), (f, pli, int((got[pli] != want).sum()))
     dec.close()
+    if lookahead:
+        assert taken >= nnew - 1, (taken, nnew)   # (the announcements were taken: the test ran what it says)
     return nnew
+
+
+@pytest.mark.parametrize("lists", [True, False, None])
+@pytest.mark.parametrize("w,h,fmt,ahead", [(64, 48, 0, 1), (176, 144, 0, 3), (48, 64, 3, 2), (80, 48, 2, 4), (336, 32, 0, 6),
+                                           (1280, 720, 0, 3), (1920, 1088, 0, 2)])
+def test_packets_decode_bit_exact_with_a_look_ahead(hip, w, h, fmt, ahead, lists):
+    """TH_DECCTL_THIP_PREFETCH_PACKET: the packets announced `ahead` packets before their th_decode_packetin -- entropy decoder,
+    DC chain and the packing of the token lists on parser threads, th_decode_packetin adopts the frame and hands it to the device
+    (token lists in one piece, or the host's own token walk, or as the library chooses) -- give the oracle's pictures, frame by
+    frame, dropped frames and more announcements than slots included."""
+    assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=12 if w < 1000 else 5, device_lists=lists, lookahead=ahead,
+                      trees="matched" if w >= 1000 else "random") >= 4
 
 
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (336, 32, 0)])
@@ -166,14 +195,15 @@ def test_packets_decode_bit_exact_720p(hip, lists):
     assert run_stream(hip, 1280, 720, 0, seed=720, nframes=4, kf=3, trees="matched", device_lists=lists) >= 3
 
 
-@pytest.mark.parametrize("mode", ["host", "device_dc", "device_lists", "device_lists_dc"])
+@pytest.mark.parametrize("mode", ["host", "device_dc", "device_lists", "device_lists_dc", "device_lists_lookahead"])
 def test_packets_decode_bit_exact_4k(hip, mode):
     """BASELINE.json's 4K size (3840x2160 4:2:0, 194 400 fragments) through th_decode_*: a key frame and two inter frames with
     matched Huffman trees, by the host front end, with the DC un-prediction on the GPU (k_dc_wave: 480 x 270 luma fragments, the
     64 rows in flight in LDS), and with TH_DECCTL_THIP_SET_DEVICE_LISTS: the token lists themselves on the GPU, the key frame's luma
     plane (129 600 coded fragments) with k_tok_assign's rank -> fragment map in memory instead of LDS."""
     assert run_stream(hip, 3840, 2160, 0, seed=2160, nframes=3, kf=3, trees="matched", device_dc=mode in ("device_dc", "device_lists_dc"),
-                      device_lists=mode in ("device_lists", "device_lists_dc")) == 3
+                      device_lists=mode in ("device_lists", "device_lists_dc", "device_lists_lookahead"),
+                      lookahead=2 if mode == "device_lists_lookahead" else 0) == 3
 
 
 def test_empty_packet_is_dup_frame(hip):
@@ -374,6 +404,10 @@ def test_dump_video_example_on_an_ogg_file(hip, tmp_path):
         cr = np.frombuffer(rec, np.uint8, w * h // 4, 6 + w * h * 5 // 4).reshape(h // 2, w // 2)
         assert np.array_equal(y, planes[0]) and np.array_equal(cb, planes[1]) and np.array_equal(cr, planes[2]), f
     assert "9 frames" in r.stderr
+    # (that was the tool's default: four packets read ahead and announced to the library; the plain loop writes the same file)
+    out0 = tmp_path / "clip0.y4m"
+    r = subprocess.run([str(exe), "--lookahead", "0", "-o", str(out0), str(ogv)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and out0.read_bytes() == data
 
 
 def test_hip_decoder_agrees_with_ffmpeg_in_chromium(hip):
