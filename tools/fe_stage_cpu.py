@@ -1,6 +1,6 @@
 """Stage times of th_decode_packetin on the CPU alone: a context in slot-trace mode (option fe_trace_backend) parses the packets
 completely and records the slot calls instead of making them, so no device is needed; option fe_prof prints the wall time per
-stage when the context is freed.  The packets are bench.py --mode e2e's (tests/streamgen.py), cached under /tmp.
+stage when the context is freed.  The packets are bench.py --mode e2e's (tests/streamgen.py), cached under tools/_cache/.
   python tools/fe_stage_cpu.py [720p|1080p|4k] [dense|typical] [loops] [lookahead]
 With a look-ahead of K the packets are announced K ahead (TH_DECCTL_THIP_PREFETCH_PACKET) and parsed on K threads: the stage
 table is then the CALLER's thread -- the wait for the parser, the adoption and what follows the packet's last bit."""
@@ -10,11 +10,13 @@ import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-SIZES = {"qcif": (176, 144), "cif": (352, 288), "720p": (1280, 720), "1080p": (1920, 1080), "4k": (3840, 2160)}
+SIZES = {"qcif": (176, 144), "cif": (352, 288), "720p": (1280, 720), "1080p": (1920, 1088), "4k": (3840, 2160)}
 
 
 def packets(size, kind, frames):
-    path = "/tmp/fe_pkts_%s_%s_%d.pkl" % (size, kind, frames)
+    cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cache")   # (git-ignored; travels with gpurun)
+    os.makedirs(cache, exist_ok=True)
+    path = os.path.join(cache, "fe_pkts_%s_%s_%d.pkl" % (size, kind, frames))
     if os.path.exists(path):
         return pickle.load(open(path, "rb"))
     from tests import streamgen
