@@ -112,7 +112,7 @@ def measure_pmc_traffic(args, kernels):
             d = os.path.join(td, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "24", "--warmup", "4", "--repeats", "1", "--min-time", "0", "--no-cpu-baseline", "--no-parity",
-                   "--no-profile", "--no-pmc", "--no-1080p", "--second-content", "", "--content", args.content, "--size", args.size,
+                   "--no-profile", "--no-pmc", "--no-1080p", "--no-e2e", "--second-content", "", "--content", args.content, "--size", args.size,
                    "--streams-per-gpu", str(args.streams_per_gpu), "--pool", str(args.pool)]
             env = dict(os.environ, THIP_LANES="1", TMPDIR=os.environ.get("TMPDIR", "/tmp"))
             try:
@@ -135,7 +135,7 @@ def measure_pmc_traffic(args, kernels):
             d = os.path.join(td, group[0])
             cmd = [exe, "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "24", "--warmup", "4", "--repeats", "1", "--min-time", "0", "--no-cpu-baseline", "--no-parity",
-                   "--no-profile", "--no-pmc", "--no-1080p", "--second-content", "", "--content", args.content, "--size", args.size,
+                   "--no-profile", "--no-pmc", "--no-1080p", "--no-e2e", "--second-content", "", "--content", args.content, "--size", args.size,
                    "--streams-per-gpu", str(args.streams_per_gpu), "--pool", str(args.pool)]
             try:
                 r = subprocess.run(cmd, env=dict(os.environ, THIP_LANES="1", TMPDIR=os.environ.get("TMPDIR", "/tmp")), cwd=td,
@@ -225,6 +225,54 @@ def system_libtheora_baseline(size="720p", nframes=24):
         return {"kind": "system libtheora", "available": True, "library": name, "error": str(e)[:200]}
 
 
+def e2e_keyed_entry(size="720p", nframes=8, loops=6, ahead=4):
+    """The whole th_decode_* chain on the driver's clock, as a keyed entry of the default line: packets in host memory ->
+    th_decode_packetin -> th_decode_ycbcr_out -> pictures in host memory, ONE stream, the plain API loop and with the packets
+    announced `ahead` packets ahead (TH_DECCTL_THIP_PREFETCH_PACKET: the entropy decoder on the library's parser threads).  The two
+    legs must hand out the same pictures (CRC32 per frame); bit-exactness against the oracle is tests/test_gpu_frontend.py's.
+    Never fails the bench: an exception becomes the entry."""
+    try:
+        import zlib
+        from tests import streamgen
+        from theora_amd.decoder import Decoder
+        w, h = SIZES[size]
+        content = dict(density=0.7, p_dc_only=0.5, p_empty=0.2)
+        st = streamgen.Stream(w, h, 0, seed=99, trees="matched", probe_kwargs=content)
+        hdr = st.header_packets()
+        pkts = [st.frame(0 if f % 8 == 0 else 1, **content)[0] for f in range(nframes)]
+        seq = pkts * loops
+        res, crcs = {}, {}
+        for label, la in (("plain_loop", 0), ("lookahead_%d" % ahead, ahead)):
+            dec = Decoder(hdr)
+            for p in pkts:              # warm-up: device buffers, streams, parser threads
+                dec.packetin(p)
+                dec.ycbcr_out()
+            c, nxt = [], 0
+            t0 = time.perf_counter()
+            for k, p in enumerate(seq):
+                while la and nxt < len(seq) and nxt < k + la:
+                    nxt = max(nxt, k)
+                    if not dec.prefetch(seq[nxt]):
+                        break
+                    nxt += 1
+                dec.packetin(p)
+                planes = dec.ycbcr_out()
+                if k < len(pkts):
+                    c.append(zlib.crc32(b"".join(x.tobytes() for x in planes)))
+            dt = time.perf_counter() - t0
+            dec.close()
+            res[label] = round(len(seq) / dt, 1)
+            crcs[label] = c
+        same = len(set(tuple(v) for v in crcs.values())) == 1
+        return {"metric": "end-to-end decode frames/sec, one %s 4:2:0 stream (packets in host memory -> pictures in host memory)" % size,
+                "unit": "frames/s", **res, "same_pictures": same, "avg_packet_bytes": sum(map(len, pkts)) // len(pkts),
+                "data": "synthetic packets (tests/streamgen.py), dense content, matched Huffman trees",
+                "note": "host-bound (Python caller): the plain loop is one entropy-decode thread per stream; announced packets are "
+                        "parsed on up to four library threads and the device's token-list stage becomes the bound (DESIGN.md 5.1)"}
+    except Exception as e:
+        return {"error": str(e)[:300]}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="decode", choices=["decode", "enc", "e2e"])
@@ -248,6 +296,7 @@ def parse_args():
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-process-per-core leg of the CPU baseline")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-1080p", action="store_true", help="skip the 1080p keyed entries (single stream, four streams)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the keyed entry e2e_720p (th_decode_* end to end, one stream, with and without the look-ahead)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-execute under rocprofv3 --pmc for roofline.traffic (N = 1 only)")
     return ap.parse_known_args()
 
@@ -943,6 +992,8 @@ def main():
             out["second_content"] = second
         if other_size:
             out["size_1080p"] = other_size
+        if world == 1 and G == 1 and not args.no_e2e and args.size == "4k":
+            out["e2e_720p"] = e2e_keyed_entry()
         if cpu_baseline:
             cpu_baseline["system_libtheora"] = system_libtheora_baseline()
             out["cpu_baseline"] = cpu_baseline
