@@ -321,6 +321,18 @@ int thip_state_decode_token_lists(thip_state *st, const thip_token_lists *tl);
    _begin(st, tl) followed by _finish(st, tl->dc). */
 int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl);
 int thip_state_token_lists_finish(thip_state *st, const int16_t *dc);
+/* _begin for a caller that has done the walk of decode.c:1540-1581 itself -- which token belongs to which fragment is 64 dependent
+   rounds per plane, one compute unit's work on the device (k_tok_assign) and nothing at all on a host thread that is not on
+   anybody's critical path (th_decode_*'s look-ahead parses announced packets on threads of their own).  `assign`: one word per
+   entry of tl->tokens: bits 0-17 the index, in the order of tl->coded, of the fragment the token belongs to, bits 18-24 the
+   zig-zag position its value lands at (the list's index + the zeros before the value; positions beyond 63 are dropped like the
+   reference's dump slot, decint.h:96), 0xFFFFFFFF for a token no fragment consumes (EOB tokens' words are not read);
+   `last_zzi`: for every fragment of tl->coded the index at which it met its end (decode.c:1545).  The device pairs nothing: one
+   thread per token stores the (dequantised) value (k_tok_scatter), the rest is _begin's.  tl->list_off / list_len / eob_carry /
+   arrivals are not read.  Returns what _begin returns, or THIP_EIMPL when the two arrays do not fit behind the tokens in the
+   state's staging buffer (a frame of nearly 32 tokens a fragment) or the frame has more than 262143 coded fragments: call
+   _begin then -- the state is untouched.  Followed by _finish, as _begin is. */
+int thip_state_token_lists_begin_assigned(thip_state *st, const thip_token_lists *tl, const uint32_t *assign, const uint8_t *last_zzi);
 /* The lists in GROUPS of zig-zag indices, as the entropy decoder finishes them (decode.c:1164-1205 reads index after index, all
    three planes of one before the next): _open takes the frame's description without its tokens (tl->tokens, ntokens, list_off,
    list_len, eob_carry, arrivals and dc are ignored) and prepares the device; every _append hands over the lists of the indices
@@ -564,6 +576,9 @@ const char *thip_version_string(void);
  *   fe_lookahead   th_decode_*: how many packets a caller may announce ahead of their th_decode_packetin
  *                (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET, include/theoradec_hip.h): each is parsed -- entropy decoder and DC
  *                chain -- by a thread of its own; 4 (default), up to 16; 0: announcements are not taken
+ *   fe_assign    th_decode_*, announced packets on the token-list path: 1 (default): the parser thread also walks the lists
+ *                (which token belongs to which fragment) and the frame goes to thip_state_token_lists_begin_assigned -- the
+ *                device pairs nothing; 0: thip_state_token_lists_begin, the device walks (k_tok_assign / k_tok_walk)
  *   fe_levels    th_decode_*: 1: the host's own token walk feeds thip_state_frag_recon_levels; 0 (default): thip_state_frag_recon --
  *                measured equal within 2 % end to end (the walk is bound by the tokens, not by the 64 bytes a block saved)
  *   fe_trace_backend, fe_prof   th_decode_*: record slot calls instead of running them (tests); per-stage host timing

@@ -30,6 +30,7 @@ int thip_state_create_on(thip_state **, int, int, int, int) { return -1; }
 int thip_state_postprocess(thip_state *, int, const uint8_t *, const uint8_t *, const int32_t *, const int32_t *) { return -1; }
 int thip_state_decode_token_lists(thip_state *, const thip_token_lists *) { return -1; }
 int thip_state_token_lists_begin(thip_state *, const thip_token_lists *) { return -1; }
+int thip_state_token_lists_begin_assigned(thip_state *, const thip_token_lists *, const uint32_t *, const uint8_t *) { return -1; }
 int thip_state_token_lists_finish(thip_state *, const int16_t *) { return -1; }
 int thip_state_token_lists_open(thip_state *, const thip_token_lists *) { return -1; }
 int thip_state_token_lists_append(thip_state *, int, int, const uint32_t *, int64_t, const uint32_t (*)[64], const uint32_t (*)[64],
@@ -43,6 +44,7 @@ int thip_option(const char *name) {   // the library's option table is not linke
   if (name && !strcmp(name, "fe_device_lists")) return 0;
   if (name && !strcmp(name, "fe_lookahead")) return 4;
   if (name && !strcmp(name, "fe_worker_pin")) return 1;
+  if (name && !strcmp(name, "fe_assign")) return 1;
   return 0;
 }
 int thip_state_set_device_dc(thip_state *, int) { return -1; }

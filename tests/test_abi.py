@@ -59,6 +59,7 @@ def test_argument_validation_without_gpu():
     assert L.thip_state_ref_idx(None, 0) == _lib.EINVAL
     assert L.thip_state_decode_token_lists(None, None) == _lib.EFAULT
     assert L.thip_state_token_lists_begin(None, None) == _lib.EFAULT
+    assert L.thip_state_token_lists_begin_assigned(None, None, None, None) == _lib.EFAULT
     assert L.thip_state_token_lists_finish(None, None) == _lib.EFAULT
     assert L.thip_state_token_lists_open(None, None) == _lib.EFAULT
     assert L.thip_state_token_lists_append(None, 0, 64, None, 0, None, None, None, None) == _lib.EFAULT

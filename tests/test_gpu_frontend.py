@@ -78,6 +78,24 @@ def test_packets_decode_bit_exact_with_a_look_ahead(hip, w, h, fmt, ahead, lists
                       trees="matched" if w >= 1000 else "random") >= 4
 
 
+@pytest.mark.parametrize("levels", [1, 0])
+@pytest.mark.parametrize("w,h,fmt,ahead", [(176, 144, 0, 3), (48, 64, 3, 2), (336, 32, 0, 4), (1280, 720, 0, 3)])
+def test_look_ahead_with_the_walk_left_to_the_device(hip, w, h, fmt, ahead, levels):
+    """Option fe_assign = 0: an announced packet's parser packs the lists and leaves the walk (which token belongs to which
+    fragment) to the device (thip_state_token_lists_begin: k_tok_assign / k_tok_walk) instead of doing it itself
+    (thip_state_token_lists_begin_assigned: k_tok_scatter, the default, what the other look-ahead tests run); and both forms of
+    the coefficient slots (tl_levels) behind the host's walk."""
+    L = hip._lib.load()
+    L.thip_set_option(b"fe_assign", 0 if levels else 1)
+    L.thip_set_option(b"tl_levels", levels)
+    try:
+        assert run_stream(hip, w, h, fmt, seed=w + 5 * h + fmt, nframes=10 if w < 1000 else 5, device_lists=True, lookahead=ahead,
+                          trees="matched" if w >= 1000 else "random") >= 4
+    finally:
+        L.thip_set_option(b"fe_assign", 1)
+        L.thip_set_option(b"tl_levels", 1)
+
+
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (336, 32, 0)])
 def test_packets_decode_bit_exact(hip, w, h, fmt):
     assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9) >= 6

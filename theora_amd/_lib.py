@@ -67,6 +67,7 @@ SYMBOLS = [
     ("thip_state_postprocess", _I, [_P, _I, _P, _P, _P, _P]),
     ("thip_state_decode_token_lists", _I, [_P, _P]),
     ("thip_state_token_lists_begin", _I, [_P, _P]),
+    ("thip_state_token_lists_begin_assigned", _I, [_P, _P, _P, _P]),
     ("thip_state_token_lists_finish", _I, [_P, _P]),
     ("thip_state_token_lists_open", _I, [_P, _P]),
     ("thip_state_token_lists_append", _I, [_P, _I, _I, _P, C.c_int64, _P, _P, _P, _P]),

@@ -84,6 +84,7 @@ Option g_options[] = {
     {"fe_worker", 1, "th_decode_*, token-list path: 1 (default): a second thread per context undoes the DC prediction while the caller decodes the tokens of indices 1..63; 0: the caller does it behind the tokens"},
     {"fe_worker_pin", 1, "th_decode_*, fe_worker on: 1 (default): the second thread is kept on the CPUs that share a last-level cache with the caller's; 0: left to the scheduler"},
     {"fe_lookahead", 4, "th_decode_*: packets a caller may announce ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), each parsed by a thread of its own on a parser context: 4 (default), up to 16; 0: announcements are not taken"},
+    {"fe_assign", 1, "th_decode_*, announced packets on the token-list path: 1 (default): the parser thread walks the lists too and the frame goes to thip_state_token_lists_begin_assigned (k_tok_scatter: the device pairs nothing); 0: the device walks them (thip_state_token_lists_begin)"},
     {"fe_levels", 0, "th_decode_*: 1: the host's own token walk hands the slots quantised levels (thip_state_frag_recon_levels: the kernel dequantises); 0 (default): dequantised coefficients"},
     {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
@@ -2322,6 +2323,62 @@ int thip_state_token_lists_begin(thip_state *st, const thip_token_lists *tl) {
   rc = thip_state_token_lists_append(st, 0, 64, tl->tokens, tl->ntokens, tl->list_off, tl->list_len, tl->eob_carry, tl->arrivals);
   if (rc < 0) (void)thip_state_token_lists_abort(st);
   return rc;
+}
+
+// _begin for a caller that has walked the lists itself (k_tok_scatter, thip_tokens.h): `assign` one word per token, `last_zzi` one byte
+// per coded fragment.  THIP_EIMPL when the two do not fit behind the tokens in the staging buffer (more than half its token area
+// used: frames of nearly 32 tokens a fragment) -- _begin takes the frame then; the state is as it was.
+int thip_state_token_lists_begin_assigned(thip_state *st, const thip_token_lists *tl, const uint32_t *assign, const uint8_t *last_zzi) {
+  if (!st || !tl) return THIP_EFAULT;
+  if (tl->ntokens < 0) return THIP_EINVAL;
+  int64_t ncoded = 0;
+  for (int p = 0; p < 3; p++) ncoded += tl->ncoded[p] > 0 ? tl->ncoded[p] : 0;
+  if (ncoded && (!tl->tokens || !assign || !last_zzi)) return THIP_EFAULT;
+  if (ncoded > 0x3FFFF) return THIP_EIMPL;   // (eighteen bits of fragment index)
+  const int64_t ntok = tl->ntokens;
+  const int64_t a_asg = (ntok + 3) & ~(int64_t)3, a_lz = (a_asg + ntok + 3) & ~(int64_t)3, a_end = a_lz + ((ncoded + 15) / 16) * 4;
+  if (a_end > tl_token_capacity(st)) return THIP_EIMPL;
+  int rc = thip_state_token_lists_open(st, tl);
+  if (rc < 0) return rc;
+  if (!ncoded) {
+    st->tl_z = 64;
+    return THIP_OK;
+  }
+  DeviceGuard dg(st->device);
+  hipStream_t s = st->tl_stream;
+  uint32_t *h = st->h_tl + st->tl_o_tok;
+  if (ntok && tl->tokens != h) memcpy(h, tl->tokens, (size_t)ntok * 4);
+  if (ntok) memcpy(h + a_asg, assign, (size_t)ntok * 4);
+  memcpy(h + a_lz, last_zzi, (size_t)ncoded);
+  TlCopyK C;
+  C.src[0] = reinterpret_cast<const int4 *>(st->h_tl);
+  C.dst[0] = reinterpret_cast<int4 *>(st->d_tl);
+  C.n[0] = THIP_TL_HDR / 4;
+  C.src[1] = reinterpret_cast<const int4 *>(h);
+  C.dst[1] = reinterpret_cast<int4 *>(st->d_tl + st->tl_o_tok);
+  C.n[1] = (size_t)a_end / 4;
+  const unsigned cgroups = (unsigned)std::min<size_t>(256, (C.n[1] + 255) / 256 + 1);
+  hipLaunchKernelGGL(k_tok_copy, dim3(cgroups), dim3(256), 0, s, C);
+  TlK K = st->tl_K;
+  K.z0 = 0;
+  K.z1 = 64;
+  const uint32_t *d_tok = st->d_tl + st->tl_o_tok;
+  const int64_t nthreads = std::max<int64_t>(ntok, ncoded);
+  hipLaunchKernelGGL(k_tok_scatter, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, K, d_tok + a_asg,
+                     reinterpret_cast<const uint8_t *>(d_tok + a_lz), (int)ntok);
+  if (K.levels) hipLaunchKernelGGL(k_tok_widths, dim3((unsigned)((ncoded + 255) / 256)), dim3(256), 0, s, K);
+  if (ncoded <= 4 * kTlSlotChunk) {
+    hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
+  } else {   // (large frames: many groups, two launches)
+    const unsigned ng = (unsigned)((ncoded + kTlSlotChunk - 1) / kTlSlotChunk);
+    uint32_t *part = st->d_tl_wide + (((size_t)st->tiles.ntiles + 3) & ~(size_t)3);   // (behind the tiles' words)
+    hipLaunchKernelGGL(k_tok_slots_count, dim3(ng), dim3(1024), 0, s, K, part);
+    hipLaunchKernelGGL(k_tok_slots_assign, dim3(ng), dim3(1024), 0, s, K, (const uint32_t *)part);
+  }
+  HIP_TRY(hipGetLastError());
+  st->tl_z = 64;
+  st->tl_ntok = a_end;
+  return THIP_OK;
 }
 
 int thip_state_token_lists_finish(thip_state *st, const int16_t *dc) {

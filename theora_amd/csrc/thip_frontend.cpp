@@ -277,6 +277,12 @@ struct th_dec_ctx {
   FeStream fs;
   uint32_t arrivals[3][64];          // fragments open at every (plane, index) of the current frame
   thip_token_lists tlp;              // the frame in the one-piece form of the token-list path (fe_pack_lists)
+  // the walk of decode.c:1540-1581 done on the host for the device (fe_assign_tokens): for every entry of tl_tokens the fragment it
+  // belongs to and the position its value lands at, for every coded fragment its last index (thip_state_token_lists_begin_assigned)
+  std::vector<uint32_t> tl_assign;
+  std::vector<uint8_t> tl_lastz;
+  bool tl_assigned;
+  long assign_checked;               // (slot-trace mode: adopted frames whose walk was checked against the host's own)
   bool tl_packed;                    // tlp / tl_tokens / tl_meta / tl_coded hold the frame at hand (an adopted frame's parser did it)
   std::vector<uint32_t> tl_tokens, tl_meta;
   std::vector<int16_t> tl_dc;            // the un-predicted DC values in coded order (token-list path with the DC chain on the host)
@@ -1281,7 +1287,7 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   d->worker = nullptr;
   d->la = nullptr;
   d->parse_only = false;
-  d->tl_packed = false;
+  d->tl_packed = d->tl_assigned = false;
   d->trace = thip_option("fe_trace_backend") != 0;
   d->tr_flimit = 0;
   if (!d->trace &&
@@ -1494,7 +1500,7 @@ static bool fe_lists_now(const th_dec_ctx *d) {
 
 static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun &r) {
   const int N = d->nfrags;
-  d->tl_packed = false;
+  d->tl_packed = d->tl_assigned = false;
   int ncoded_total = 0;
   // (a negative length reads as all-zero bits here and in the reference alike -- oc_pack_readinit with
   //  a stop pointer before the start -- i.e. as an intra frame header; only bytes == 0 is a drop)
@@ -1841,6 +1847,77 @@ static void fe_pack_lists(th_dec_ctx *d) {
   }
 }
 
+// Which token belongs to which fragment (decode.c:1540-1581), without expanding anything: the fragments of a plane in coded order,
+// each taking the next token of the list of the index it stands at until an EOB ends it -- the walk the device's k_tok_assign does in
+// 64 dependent rounds on one compute unit per plane.  Here it is a look-ahead parser's, beside the frames before and after it.  Needs
+// fe_pack_lists (the lists' places in tl_tokens).  The packed tokens and these two arrays are all the device needs (k_tok_scatter).
+static void fe_assign_tokens(th_dec_ctx *d) {
+  const thip_token_lists &tl = d->tlp;
+  const size_t nc = d->cl_start[3];
+  d->tl_assign.assign((size_t)tl.ntokens + 1, 0xFFFFFFFFu);   // (a token nobody takes: the surplus of a malformed list)
+  d->tl_lastz.resize(nc + 1);
+  uint32_t *const asg = d->tl_assign.data();
+  for (int p = 0; p < 3; p++) {
+    const Tok *tp[64];   // next token of every index list (each list ends in an endless EOB run)
+    const Tok *base[64];
+    uint32_t run[64];
+    for (int z = 0; z < 64; z++) {
+      tp[z] = base[z] = d->toks[p][z].data();
+      run[z] = d->eob_carry[p][z];
+    }
+    for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
+      int z = 0, last_zzi = 0;
+      while (z < 64) {
+        last_zzi = z;
+        if (run[z]) {
+          run[z]--;
+          break;
+        }
+        const Tok *const t = tp[z]++;
+        if (t->eob) {   // (the sentinel behind a list is one: nothing behind a list's last token is ever written to)
+          run[z] = t->eob - 1;
+          break;
+        }
+        asg[tl.list_off[p][z] + (uint32_t)(t - base[z])] = (uint32_t)ci | (uint32_t)(z + t->skip) << 18;   // (position <= 63 + 63)
+        z += t->adv;
+      }
+      d->tl_lastz[ci] = (uint8_t)last_zzi;
+    }
+  }
+  d->tl_assigned = true;
+}
+
+// Slot-trace mode: what k_tok_scatter would make of an adopted frame's assignment -- every token on its own, as the device has
+// them -- against the coefficients the host's own walk has just recorded (fe_back).  False: they differ.
+static bool fe_check_assignment(const th_dec_ctx *d) {
+  const thip_token_lists &tl = d->tlp;
+  const size_t nc = d->cl_start[3];
+  if (d->tr_fragi.size() != nc || d->tl_assign.size() < (size_t)tl.ntokens || d->tl_lastz.size() < nc) return false;
+  std::vector<int16_t> c(nc * 64, 0);
+  for (int64_t j = 0; j < tl.ntokens; j++) {
+    const uint32_t tk = d->tl_tokens[(size_t)j];
+    if (tk & 0x00800000u) continue;
+    const uint32_t w = d->tl_assign[(size_t)j];
+    const uint32_t ci = w & 0x3FFFFu;
+    const int at = (int)((w >> 18) & 127u);
+    if (w == 0xFFFFFFFFu || ci >= nc) continue;
+    const int value = (int16_t)(tk & 0xFFFFu);
+    if (!value || at == 0 || at > 63) continue;
+    const int f = d->clist[ci];
+    int p = 0;
+    while (p < 2 && ci >= d->cl_start[p + 1]) p++;
+    const int qti = d->mbmode_of_frag[f] != MODE_INTRA;
+    const uint16_t *acq = &d->dequant[(((size_t)d->qis[d->qii[f]] * 3 + p) * 2 + qti) * 64];
+    c[ci * 64 + kZigZag[at]] = (int16_t)(value * (int)acq[at]);
+  }
+  for (size_t ci = 0; ci < nc; ci++) {
+    if (d->tl_lastz[ci] != d->tr_last_zzi[ci]) return false;
+    for (int k = 1; k < 64; k++)
+      if (c[ci * 64 + k] != d->tr_coeffs[ci * 64 + k]) return false;
+  }
+  return true;
+}
+
 static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
   const int N = d->nfrags;
   const bool lists_now = r.lists_now, streaming = r.streaming, with_worker = r.with_worker;
@@ -1893,7 +1970,10 @@ static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
     if (lrc >= 0) lists_done = true;
     else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
   } else if (lists_now) {
-    if (!d->tl_packed) fe_pack_lists(d);   // (an adopted frame may bring them packed)
+    if (!d->tl_packed) {   // (an adopted frame may bring them packed, and walked)
+      fe_pack_lists(d);
+      d->tl_assigned = false;
+    }
     d->tl_packed = false;
     thip_token_lists &tl = d->tlp;
     const size_t nc = d->cl_start[3];
@@ -1913,7 +1993,10 @@ static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
     // too (option fe_device_dc) -- a chain through the plane in raster order, a few nanoseconds a fragment here, a dependent
     // step of a wave there -- and the values follow with the second call: the device needs them last.
     d->prof.lap(FE_LMETA);
-    int lrc = thip_state_token_lists_begin(d->hip, &tl);
+    int lrc = THIP_EIMPL;
+    if (d->tl_assigned) lrc = thip_state_token_lists_begin_assigned(d->hip, &tl, d->tl_assign.data(), d->tl_lastz.data());
+    d->tl_assigned = false;
+    if (lrc == THIP_EIMPL) lrc = thip_state_token_lists_begin(d->hip, &tl);   // (not walked, or no room for the walk's arrays)
     d->prof.lap(FE_LBEGIN);
     if (lrc >= 0) {
       const int16_t *dcv = nullptr;
@@ -2058,6 +2141,12 @@ static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
   if (!d->trace) {
     rc = thip_frame_flush(d->hip);
     if (rc < 0) return TH_EFAULT;
+  } else if (d->tl_assigned) {
+    // an adopted frame whose parser walked the lists for the device: every token applied on its own, as k_tok_scatter applies
+    // them, must give the coefficients recorded above
+    d->tl_assigned = false;
+    if (!fe_check_assignment(d)) return TH_EFAULT;
+    d->assign_checked++;
   }
   }   // (!lists_done)
   // ---- out-of-loop post-processing (decode.c:1203-1325, :2893-2911), on the backend -----------------------
@@ -2126,6 +2215,7 @@ struct FeSlot {
   bool busy = false;                // holds a packet (the caller's thread only)
   int rc = 0;
   bool want_lists = false;          // the owner takes the token-list path: the parser packs the lists too (fe_pack_lists)
+  bool want_assign = false;         // ... and walks them (fe_assign_tokens, option fe_assign)
   std::vector<uint8_t> pkt;
   long bytes = 0;
 };
@@ -2159,7 +2249,7 @@ static th_dec_ctx *fe_new_parser(const th_dec_ctx *m) {
   s->worker = nullptr;
   s->la = nullptr;
   s->parse_only = true;
-  s->tl_packed = false;
+  s->tl_packed = s->tl_assigned = false;
   s->trace = false;
   s->device_dc = s->device_tokens = false;
   s->device_lists = 0;
@@ -2192,10 +2282,11 @@ static void fe_parse_job(FeSlot &sl) {
     const size_t nc = s->cl_start[3];
     s->tl_dc.resize(nc + 1);
     for (size_t ci = 0; ci < nc; ci++) s->tl_dc[ci] = s->dc[s->clist[ci]];
-    s->tl_packed = false;
+    s->tl_packed = s->tl_assigned = false;
     if (sl.want_lists) {
       fe_pack_lists(s);
       s->tl_packed = true;
+      if (sl.want_assign) fe_assign_tokens(s);
     }
   }
   sl.rc = rc;
@@ -2247,7 +2338,9 @@ static void fe_lookahead_free(th_dec_ctx *d) {
     }
     delete sl.ctx;   // (a parser context owns no device state, no threads and no count in g_fe_contexts)
   }
-  if (d->prof.on) fprintf(stderr, "[thip front end] look-ahead: %ld packets adopted, %ld announced and not used\n", la->adopted, la->missed);
+  if (d->prof.on)
+    fprintf(stderr, "[thip front end] look-ahead: %ld packets adopted, %ld announced and not used, %ld walks checked (slot-trace mode)\n", la->adopted,
+            la->missed, d->assign_checked);
   delete la;
   d->la = nullptr;
 }
@@ -2313,7 +2406,8 @@ static int fe_prefetch(th_dec_ctx *d, const ogg_packet *op) {
   sl.bytes = op->bytes;
   sl.pkt.resize((size_t)op->bytes);
   memcpy(sl.pkt.data(), op->packet, (size_t)op->bytes);
-  sl.want_lists = fe_lists_now(d);
+  sl.want_lists = fe_lists_now(d) || d->trace;   // (slot-trace mode: packed and walked too, and checked against the host's own walk)
+  sl.want_assign = sl.want_lists && thip_option("fe_assign") != 0;
   sl.done.store(0, std::memory_order_relaxed);
   sl.busy = true;
   la->count++;
@@ -2359,6 +2453,7 @@ static void fe_adopt(th_dec_ctx *d, th_dec_ctx *s) {
   d->clist.swap(s->clist);
   d->ulist.swap(s->ulist);
   d->tl_dc.swap(s->tl_dc);
+  d->tl_assigned = false;
   d->tl_packed = s->tl_packed;
   if (s->tl_packed) {
     d->tl_tokens.swap(s->tl_tokens);
@@ -2366,6 +2461,12 @@ static void fe_adopt(th_dec_ctx *d, th_dec_ctx *s) {
     d->tl_coded.swap(s->tl_coded);
     d->tlp = s->tlp;
     s->tl_packed = false;
+    d->tl_assigned = s->tl_assigned;
+    if (s->tl_assigned) {
+      d->tl_assign.swap(s->tl_assign);
+      d->tl_lastz.swap(s->tl_lastz);
+      s->tl_assigned = false;
+    }
   }
   for (int p = 0; p < 3; p++)
     for (int z = 0; z < 64; z++) d->toks[p][z].swap(s->toks[p][z]);

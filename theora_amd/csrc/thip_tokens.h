@@ -719,6 +719,34 @@ struct TlPrepK {
   size_t nz[5];   // 16-byte units
 };
 // A group of lists goes to the device: the header tables (they grow index by index) and the group's tokens.
+// ---- the walk done by the caller: every token comes with the fragment it belongs to ---------------------------------------------
+// thip_state_token_lists_begin_assigned: a caller that has walked the lists itself (th_decode_*'s look-ahead does it on its parser
+// threads, where a frame's 64 dependent rounds cost nothing on anybody's critical path) hands over, beside the tokens, one word
+// per token -- bits 0-17 the fragment's index in coded order, bits 18-24 the zig-zag position the value lands at (list index +
+// zeros before it), all ones for a token nobody consumes -- and the last index of every fragment.  What is left for the device is
+// what k_tok_assign does AFTER it knows the pairing, and that is independent per token: one thread a token, the whole chip.
+__global__ __launch_bounds__(256) void k_tok_scatter(const TlK K, const uint32_t *__restrict__ asg, const uint8_t *__restrict__ lz, int ntok) {
+  const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (j < K.ncoded) K.last_zzi[j] = (uint8_t)(lz[j] & 63u);   // decode.c:1545
+  if (j >= ntok) return;
+  const uint32_t tk = K.tok[j];
+  if (tk & THIP_TOK_EOB) return;
+  const uint32_t w = asg[j];
+  const uint32_t ci = w & 0x3FFFFu;
+  const int at = (int)((w >> 18) & 127u);
+  if (w == 0xFFFFFFFFu || ci >= (uint32_t)K.ncoded) return;   // (a token no fragment consumed: the surplus of a malformed list)
+  const int value = (int)(int16_t)(tk & 0xFFFFu);
+  if (value == 0) return;                                      // a pure zero run
+  if (at == 0) {
+    K.dc_in[K.clist[ci]] = (int16_t)value;                     // the DC token value (un-predicted later, or the caller's is used)
+  } else if (at <= 63) {
+    const uint32_t qs = (K.meta[ci] >> 2) & 31u;
+    const int fac = K.levels ? 1 : (int)K.dq[qs * 64 + (uint32_t)at];
+    K.tmp[(size_t)ci * 64 + tl_nat(at)] = (int16_t)(value * fac);   // decode.c:1573 (levels form: the level itself)
+    if (K.levels && (value > 127 || value < -128)) K.wide[K.frag_pos[K.clist[ci]] >> 6] = 1u;   // the fragment's tile turns wide
+  }
+}
+
 struct TlCopyK {
   const int4 *src[2];
   int4 *dst[2];
