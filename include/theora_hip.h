@@ -575,10 +575,11 @@ const char *thip_version_string(void);
  *                0: left to the scheduler (measured 5-10 % SLOWER than no second thread on a two-socket host)
  *   fe_lookahead   th_decode_*: how many packets a caller may announce ahead of their th_decode_packetin
  *                (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET, include/theoradec_hip.h): each is parsed -- entropy decoder and DC
- *                chain -- by a thread of its own; 4 (default), up to 16; 0: announcements are not taken
- *   fe_assign    th_decode_*, announced packets on the token-list path: 1 (default): the parser thread also walks the lists
- *                (which token belongs to which fragment) and the frame goes to thip_state_token_lists_begin_assigned -- the
- *                device pairs nothing; 0: thip_state_token_lists_begin, the device walks (k_tok_assign / k_tok_walk)
+ *                chain -- by a thread of its own; 8 (default), up to 16; 0: announcements are not taken
+ *   fe_assign    th_decode_*, announced packets on the token-list path: 1 (default): the parser pairs tokens and fragments
+ *                (which token belongs to which fragment, decode.c:1540-1581) as it decodes the tokens and the frame goes to
+ *                thip_state_token_lists_begin_assigned -- the device pairs nothing; 0: thip_state_token_lists_begin, the
+ *                device walks the lists (k_tok_assign / k_tok_walk)
  *   fe_levels    th_decode_*: 1: the host's own token walk feeds thip_state_frag_recon_levels; 0 (default): thip_state_frag_recon --
  *                measured equal within 2 % end to end (the walk is bound by the tokens, not by the 64 bytes a block saved)
  *   fe_trace_backend, fe_prof   th_decode_*: record slot calls instead of running them (tests); per-stage host timing

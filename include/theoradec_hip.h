@@ -154,7 +154,7 @@ typedef struct {
 /* Extension: buf = ogg_packet (a data packet the caller will hand to th_decode_packetin LATER, announced in decode order).
    What th_decode_packetin reads out of a packet -- coded flags, modes, vectors, qi indices, DCT tokens, and the DC prediction it
    undoes (decode.c:2790-2823 up to the MCU loop) -- depends on the headers and on nothing an earlier frame left behind: only the
-   pictures form a chain.  The packet is copied and parsed on a thread of its own (up to option fe_lookahead, default 4, at a
+   pictures form a chain.  The packet is copied and parsed on a thread of its own (up to option fe_lookahead, default 8, at a
    time); the th_decode_packetin that gets the same bytes adopts the result and does only the hand-over to the GPU, so one
    stream is no longer bound by one host thread.  Returns 0: announced; 1: not taken (no slot free, an empty packet, a context with
    TH_DECCTL_THIP_SET_DEVICE_DC / _DEVICE_TOKENS on, a process confined to one CPU) -- harmless, the packet is parsed in its

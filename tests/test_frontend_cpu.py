@@ -204,7 +204,7 @@ def test_announced_packets_give_the_same_slot_calls(trace_env, w, h, fmt, ahead)
             if fast.prefetch(q):
                 taken += 1
             elif len(q):
-                break                           # no slot free (option fe_lookahead: four)
+                break                           # no slot free (option fe_lookahead: eight)
             nxt += 1
         ra, rb = plain.packetin(p), fast.packetin(p)
         assert ra == rb, (i, ra, rb)

@@ -28,6 +28,9 @@
 
 #include "../../include/theora_hip.h"
 #include "../../include/theoradec_hip.h"
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace {
 
@@ -277,11 +280,15 @@ struct th_dec_ctx {
   FeStream fs;
   uint32_t arrivals[3][64];          // fragments open at every (plane, index) of the current frame
   thip_token_lists tlp;              // the frame in the one-piece form of the token-list path (fe_pack_lists)
-  // the walk of decode.c:1540-1581 done on the host for the device (fe_assign_tokens): for every entry of tl_tokens the fragment it
-  // belongs to and the position its value lands at, for every coded fragment its last index (thip_state_token_lists_begin_assigned)
+  // the pairing of decode.c:1540-1581 done on the host for the device (decode_token_list<true>): for every entry of tl_tokens the fragment
+  // it belongs to and the position its value lands at, for every coded fragment its last index (thip_state_token_lists_begin_assigned)
   std::vector<uint32_t> tl_assign;
   std::vector<uint8_t> tl_lastz;
   bool tl_assigned;
+  bool pair_on;                      // fe_front pairs tokens and fragments as it decodes the tokens (decode_token_list<true>)
+  std::vector<uint32_t> tokw[3][64]; // ... the words of every list, beside toks
+  std::vector<uint8_t> pair_pos[3];  // ... the index every coded fragment of a plane arrives at next
+  std::vector<uint32_t> pair_arr;    // ... the arrivals of the list at hand
   long assign_checked;               // (slot-trace mode: adopted frames whose walk was checked against the host's own)
   bool tl_packed;                    // tlp / tl_tokens / tl_meta / tl_coded hold the frame at hand (an adopted frame's parser did it)
   std::vector<uint32_t> tl_tokens, tl_meta;
@@ -714,8 +721,40 @@ const TokTable kTokTab;
 // that move on to index z + adv in left[p][z + adv], leaves in *eobs what is left of an EOB run that
 // reaches past this list, and returns the end of the written tokens.  A function of its own (not
 // inlined) so that the bit window and the counters get registers instead of stack slots.
+// PAIR: the pairing of tokens and fragments (decode.c:1540-1581: which fragment a token belongs to) done HERE, as the tokens are
+// decoded, for the device (k_tok_scatter; fe_front's token stage has the story).  The lists are decoded index after index, so when
+// list (p, z) is read every fragment that arrives at z is known: `arr` holds them in coded order (the ones a carried EOB run ends
+// already skipped), token after token takes the next -- an EOB token as many as it ends --, the fragment's next index goes into
+// its byte of `pos` (z + adv; for an EOB token that is z itself: nothing changes) and the token's word (fragment, position of the
+// value) into `words`.  Two loads and two stores a token in a loop that waits for its bit window most of the time.
+// positions of the set bits of a byte, in order (the rest of an entry is zero), and how many there are
+struct BitIndexTable {
+  alignas(8) uint8_t idx[256][8];
+  uint8_t count[256];
+  BitIndexTable() {
+    for (int m = 0; m < 256; m++) {
+      int n = 0;
+      for (int b = 0; b < 8; b++) idx[m][b] = 0;
+      for (int b = 0; b < 8; b++)
+        if (m >> b & 1) idx[m][n++] = (uint8_t)b;
+      count[m] = (uint8_t)n;
+    }
+  }
+};
+const BitIndexTable kBitIndex;
+struct PairArgs {
+  const uint32_t *arr;   // arrivals of this list, coded order: index of the fragment in the plane's coded list
+  uint32_t *words;       // one per token of the list (room for n + 1)
+  uint8_t *pos;          // the plane's fragments: the index each arrives at next
+  uint32_t c0;           // the plane's first fragment in the frame's coded order
+};
+template <bool PAIR>
 __attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &tree, size_t n, Tok *out,
-                                                 size_t (*left)[128], int p, int z, uint32_t *eobs) {
+                                                 size_t (*left)[128], int p, int z, uint32_t *eobs, const PairArgs *pa) {
+  const uint32_t *arr = PAIR ? pa->arr : nullptr;
+  uint32_t *words = PAIR ? pa->words : nullptr;
+  uint8_t *const ppos = PAIR ? pa->pos : nullptr;
+  const uint32_t pc0 = PAIR ? pa->c0 : 0u;
   // the reader's state as plain locals: br itself is only touched on the slow paths, so nothing
   // here has its address taken
   uint64_t win = br.win;
@@ -787,6 +826,12 @@ __attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &
     const size_t take = want < n ? want : n;
     run_left = (uint32_t)(want - take);
     left_next[k.adv]++;   // z + adv <= 127
+    if (PAIR) {
+      const uint32_t f = *arr;   // (n > 0: there is one)
+      arr += take;
+      ppos[f] = (uint8_t)(z + k.adv);   // (>= 64: done; an EOB token leaves z, which no later list looks for)
+      *words++ = (pc0 + f) | (uint32_t)(z + k.skip) << 18;
+    }
     n -= take;
     // (A truncated packet is not special: past the end the reader supplies zero bits, as
     //  oc_pack_read does, and tokens go on being decoded from them -- every token closes or
@@ -1287,6 +1332,7 @@ th_dec_ctx *th_decode_alloc_on(const th_info *info, const th_setup_info *setup, 
   d->worker = nullptr;
   d->la = nullptr;
   d->parse_only = false;
+  d->pair_on = false;
   d->tl_packed = d->tl_assigned = false;
   d->trace = thip_option("fe_trace_backend") != 0;
   d->tr_flimit = 0;
@@ -1759,6 +1805,19 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
     memset(d->eob_carry, 0, sizeof(d->eob_carry));
     uint32_t eobs = 0;
     int htil = 0, htic = 0;
+    // Pairing tokens and fragments while the tokens are decoded (a look-ahead's parser, option fe_assign): see decode_token_list.
+    const bool pair = d->pair_on;
+    if (pair) {
+      size_t nmax = 0;
+      for (int p = 0; p < 3; p++) {
+        const size_t np = d->cl_start[p + 1] - d->cl_start[p], np16 = (np + 15) & ~(size_t)15;
+        d->pair_pos[p].assign(np16 + 16, 0xFF);   // 0xFF: not a fragment
+        if (np) memset(d->pair_pos[p].data(), 0, np);   // every coded fragment arrives at index 0
+        nmax = np16 > nmax ? np16 : nmax;
+      }
+      d->pair_arr.resize(nmax + 32);                   // (+ the eight entries a block's last store may reach past its arrivals)
+      d->tl_lastz.assign(d->cl_start[3] + 1 + 16, 0);   // (+ 16: the last block of a plane is written whole)
+    }
     for (int z = 0; z < 64; z++) {
       if (z < 2) {
         htil = (int)br.read(4);
@@ -1781,7 +1840,52 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
         // is their length.
         std::vector<Tok> &list = d->toks[p][z];
         if (list.size() < n + 2) list.resize(n + 2);
-        Tok *const out = decode_token_list(br, tree, n, list.data(), left, p, z, &eobs);
+        Tok *out;
+        if (pair) {
+          // the fragments that arrive at index z of this plane, in coded order: the bytes of `pos` equal to z.  Every one of them
+          // has its last index set to z here (decode.c:1545; whoever arrives again later overwrites it).
+          std::vector<uint32_t> &words = d->tokw[p][z];
+          if (words.size() < n + 2) words.resize(n + 2);
+          const size_t c0 = d->cl_start[p], np = d->cl_start[p + 1] - c0, np16 = (np + 15) & ~(size_t)15;
+          uint8_t *const pos = d->pair_pos[p].data();
+          uint32_t *const arr = d->pair_arr.data();
+          uint8_t *const lastz = d->tl_lastz.data() + c0;
+          size_t na = 0;
+          if (d->arrivals[p][z]) {
+#if defined(__SSE2__)
+            // sixteen fragments at a time, nothing per arrival: the last indices are blended in as a vector, the arrivals' numbers
+            // come out of a table indexed by eight bits of the comparison's mask (how many bits a block has set is close to
+            // random for the middle indices: a loop over them costs a mispredicted branch per block, more than everything else)
+            const __m128i zz = _mm_set1_epi8((char)z), zero = _mm_setzero_si128();
+            for (size_t i = 0; i < np16; i += 16) {
+              const __m128i eq = _mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(pos + i)), zz);
+              const unsigned m = (unsigned)_mm_movemask_epi8(eq);
+              if (!m) continue;   // (nobody of these sixteen: the rule at high indices)
+              __m128i *const lzp = reinterpret_cast<__m128i *>(lastz + i);   // (tl_lastz has room for whole blocks)
+              _mm_storeu_si128(lzp, _mm_or_si128(_mm_andnot_si128(eq, _mm_loadu_si128(lzp)), _mm_and_si128(eq, zz)));
+              for (int half = 0; half < 2; half++) {
+                const unsigned m8 = (m >> (8 * half)) & 0xFFu;
+                const __m128i b = _mm_unpacklo_epi8(_mm_loadl_epi64(reinterpret_cast<const __m128i *>(kBitIndex.idx[m8])), zero);
+                const __m128i base = _mm_set1_epi32((int)(i + 8 * (size_t)half));
+                _mm_storeu_si128(reinterpret_cast<__m128i *>(arr + na), _mm_add_epi32(_mm_unpacklo_epi16(b, zero), base));
+                _mm_storeu_si128(reinterpret_cast<__m128i *>(arr + na + 4), _mm_add_epi32(_mm_unpackhi_epi16(b, zero), base));
+                na += kBitIndex.count[m8];
+              }
+            }
+#else
+            for (size_t k = 0; k < np; k++)
+              if (pos[k] == z) {
+                arr[na++] = (uint32_t)k;
+                lastz[k] = (uint8_t)z;
+              }
+#endif
+          }
+          // (na == the list's arrivals by construction; a carried run has ended the first eob_carry of them)
+          PairArgs pa = {arr + d->eob_carry[p][z], words.data(), pos, (uint32_t)c0};
+          out = decode_token_list<true>(br, tree, n, list.data(), left, p, z, &eobs, &pa);
+        } else {
+          out = decode_token_list<false>(br, tree, n, list.data(), left, p, z, &eobs, nullptr);
+        }
         d->ntoks[p][z] = (size_t)(out - list.data());
         // behind the list: an EOB run without end, so that the expansion needs no end-of-list test
         // (a malformed stream that asks for more tokens than the list has finds its blocks ended)
@@ -1831,6 +1935,16 @@ static void fe_pack_lists(th_dec_ctx *d) {
       at += nk;
     }
   tl.ntokens = (int64_t)nt;
+  d->tl_assigned = false;
+  if (d->pair_on) {   // the words fe_front made beside the tokens (decode_token_list<true>), in the same places
+    d->tl_assign.resize(nt + 1);
+    uint32_t *const a = d->tl_assign.data();
+    for (int p = 0; p < 3; p++)
+      for (int z = 0; z < 64; z++)
+        if (d->ntoks[p][z]) memcpy(a + tl.list_off[p][z], d->tokw[p][z].data(), d->ntoks[p][z] * 4);
+    a[nt] = 0xFFFFFFFFu;
+    d->tl_assigned = true;   // (tl_lastz is fe_front's too)
+  }
   d->prof.lap(FE_LPACK);
   const size_t nc = d->cl_start[3];
   d->tl_meta.resize(nc + 1);
@@ -1845,46 +1959,6 @@ static void fe_pack_lists(th_dec_ctx *d) {
                        ((uint32_t)d->mvx[f] & 0xFFu) << 8 | ((uint32_t)d->mvy[f] & 0xFFu) << 16 | (uint32_t)p << 24;
     }
   }
-}
-
-// Which token belongs to which fragment (decode.c:1540-1581), without expanding anything: the fragments of a plane in coded order,
-// each taking the next token of the list of the index it stands at until an EOB ends it -- the walk the device's k_tok_assign does in
-// 64 dependent rounds on one compute unit per plane.  Here it is a look-ahead parser's, beside the frames before and after it.  Needs
-// fe_pack_lists (the lists' places in tl_tokens).  The packed tokens and these two arrays are all the device needs (k_tok_scatter).
-static void fe_assign_tokens(th_dec_ctx *d) {
-  const thip_token_lists &tl = d->tlp;
-  const size_t nc = d->cl_start[3];
-  d->tl_assign.assign((size_t)tl.ntokens + 1, 0xFFFFFFFFu);   // (a token nobody takes: the surplus of a malformed list)
-  d->tl_lastz.resize(nc + 1);
-  uint32_t *const asg = d->tl_assign.data();
-  for (int p = 0; p < 3; p++) {
-    const Tok *tp[64];   // next token of every index list (each list ends in an endless EOB run)
-    const Tok *base[64];
-    uint32_t run[64];
-    for (int z = 0; z < 64; z++) {
-      tp[z] = base[z] = d->toks[p][z].data();
-      run[z] = d->eob_carry[p][z];
-    }
-    for (size_t ci = d->cl_start[p]; ci < d->cl_start[p + 1]; ci++) {
-      int z = 0, last_zzi = 0;
-      while (z < 64) {
-        last_zzi = z;
-        if (run[z]) {
-          run[z]--;
-          break;
-        }
-        const Tok *const t = tp[z]++;
-        if (t->eob) {   // (the sentinel behind a list is one: nothing behind a list's last token is ever written to)
-          run[z] = t->eob - 1;
-          break;
-        }
-        asg[tl.list_off[p][z] + (uint32_t)(t - base[z])] = (uint32_t)ci | (uint32_t)(z + t->skip) << 18;   // (position <= 63 + 63)
-        z += t->adv;
-      }
-      d->tl_lastz[ci] = (uint8_t)last_zzi;
-    }
-  }
-  d->tl_assigned = true;
 }
 
 // Slot-trace mode: what k_tok_scatter would make of an adopted frame's assignment -- every token on its own, as the device has
@@ -2215,7 +2289,10 @@ struct FeSlot {
   bool busy = false;                // holds a packet (the caller's thread only)
   int rc = 0;
   bool want_lists = false;          // the owner takes the token-list path: the parser packs the lists too (fe_pack_lists)
-  bool want_assign = false;         // ... and walks them (fe_assign_tokens, option fe_assign)
+  bool want_assign = false;         // ... and pairs tokens and fragments as it decodes them (decode_token_list<true>, option fe_assign)
+  bool timed = false;               // option fe_prof: the parser's stages (its own thread's clock)
+  double acc[4] = {0, 0, 0, 0};     // entropy decoder, DC chain, lists packed, (unused)
+  long jobs = 0;
   std::vector<uint8_t> pkt;
   long bytes = 0;
 };
@@ -2249,6 +2326,7 @@ static th_dec_ctx *fe_new_parser(const th_dec_ctx *m) {
   s->worker = nullptr;
   s->la = nullptr;
   s->parse_only = true;
+  s->pair_on = false;
   s->tl_packed = s->tl_assigned = false;
   s->trace = false;
   s->device_dc = s->device_tokens = false;
@@ -2276,17 +2354,26 @@ static void fe_parse_job(FeSlot &sl) {
   op.bytes = sl.bytes;
   FeRun r;
   s->qii_dirty = true;   // (the coded blocks' entries are always written: the owner takes exactly those)
+  double t[5] = {0, 0, 0, 0, 0};
+  if (sl.timed) t[0] = fe_now();
+  s->pair_on = sl.want_assign;
   int rc = fe_front(s, &op, nullptr, r);
+  if (sl.timed) t[1] = fe_now();
   if (rc == kFeContinue) {
     fe_undo_dc(s);
     const size_t nc = s->cl_start[3];
     s->tl_dc.resize(nc + 1);
     for (size_t ci = 0; ci < nc; ci++) s->tl_dc[ci] = s->dc[s->clist[ci]];
-    s->tl_packed = s->tl_assigned = false;
+    if (sl.timed) t[2] = fe_now();
+    s->tl_packed = false;
     if (sl.want_lists) {
       fe_pack_lists(s);
       s->tl_packed = true;
-      if (sl.want_assign) fe_assign_tokens(s);
+      if (sl.timed) t[3] = t[4] = fe_now();
+    }
+    if (sl.timed && t[4] > 0) {
+      for (int k = 0; k < 4; k++) sl.acc[k] += t[k + 1] - t[k];
+      sl.jobs++;
     }
   }
   sl.rc = rc;
@@ -2337,6 +2424,17 @@ static void fe_lookahead_free(th_dec_ctx *d) {
       sl.th.join();
     }
     delete sl.ctx;   // (a parser context owns no device state, no threads and no count in g_fe_contexts)
+  }
+  if (d->prof.on) {
+    double a[4] = {0, 0, 0, 0};
+    long jobs = 0;
+    for (int i = 0; i < kFeLookaheadMax; i++) {
+      for (int k = 0; k < 4; k++) a[k] += la->slots[i].acc[k];
+      jobs += la->slots[i].jobs;
+    }
+    if (jobs)
+      fprintf(stderr, "[thip front end] look-ahead: a parser's frame: entropy decoder%s %.3f, DC chain %.3f, lists packed %.3f ms (%ld frames, %d parsers)\n",
+              thip_option("fe_assign") ? " (pairing tokens and fragments)" : "", 1e3 * a[0] / jobs, 1e3 * a[1] / jobs, 1e3 * (a[2] + a[3]) / jobs, jobs, la->nslots);
   }
   if (d->prof.on)
     fprintf(stderr, "[thip front end] look-ahead: %ld packets adopted, %ld announced and not used, %ld walks checked (slot-trace mode)\n", la->adopted,
@@ -2408,6 +2506,7 @@ static int fe_prefetch(th_dec_ctx *d, const ogg_packet *op) {
   memcpy(sl.pkt.data(), op->packet, (size_t)op->bytes);
   sl.want_lists = fe_lists_now(d) || d->trace;   // (slot-trace mode: packed and walked too, and checked against the host's own walk)
   sl.want_assign = sl.want_lists && thip_option("fe_assign") != 0;
+  sl.timed = d->prof.on;
   sl.done.store(0, std::memory_order_relaxed);
   sl.busy = true;
   la->count++;
