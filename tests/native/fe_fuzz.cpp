@@ -44,7 +44,7 @@ int thip_option(const char *name) {   // the library's option table is not linke
   if (name && !strcmp(name, "fe_device_lists")) return 0;
   if (name && !strcmp(name, "fe_lookahead")) return 4;
   if (name && !strcmp(name, "fe_worker_pin")) return 1;
-  if (name && !strcmp(name, "fe_assign")) return 1;
+  if (name && !strcmp(name, "fe_assign")) return 2;
   return 0;
 }
 int thip_state_set_device_dc(thip_state *, int) { return -1; }

@@ -84,7 +84,7 @@ Option g_options[] = {
     {"fe_worker", 1, "th_decode_*, token-list path: 1 (default): a second thread per context undoes the DC prediction while the caller decodes the tokens of indices 1..63; 0: the caller does it behind the tokens"},
     {"fe_worker_pin", 1, "th_decode_*, fe_worker on: 1 (default): the second thread is kept on the CPUs that share a last-level cache with the caller's; 0: left to the scheduler"},
     {"fe_lookahead", 8, "th_decode_*: packets a caller may announce ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), each parsed by a thread of its own on a parser context: 8 (default), up to 16; 0: announcements are not taken"},
-    {"fe_assign", 1, "th_decode_*, announced packets on the token-list path: 1 (default): the parser pairs tokens and fragments while it decodes the tokens and the frame goes to thip_state_token_lists_begin_assigned (k_tok_scatter: the device pairs nothing); 0: the device walks the lists (thip_state_token_lists_begin)"},
+    {"fe_assign", 2, "th_decode_*, announced packets on the token-list path: 1: the parser pairs tokens and fragments while it decodes the tokens and the frame goes to thip_state_token_lists_begin_assigned (k_tok_scatter: the device pairs nothing); 0: the device walks the lists (thip_state_token_lists_begin); 2 (default): whichever measures faster for this stream (24 frames each way, the better for 1024, and again)"},
     {"fe_levels", 0, "th_decode_*: 1: the host's own token walk hands the slots quantised levels (thip_state_frag_recon_levels: the kernel dequantises); 0 (default): dequantised coefficients"},
     {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},

@@ -2303,7 +2303,24 @@ struct FeLookahead {
   cpu_set_t domain;
   bool placed = false;
   long adopted = 0, missed = 0;
+  // Who pairs tokens and fragments -- the parser, as it decodes (k_tok_scatter on the device: nothing to walk), or the device
+  // (k_tok_assign: a frame's 64 dependent rounds on one compute unit per plane) -- moves work between the two sides of the
+  // pipeline: pairing costs a parser 3.5-4.3 ns a token (720p dense 1.1 ms a frame instead of 0.75), the device's walk 0.2 / 0.25 /
+  // 1.0 ms of a 720p / 1080p / 4K frame behind the packet.  Which side has room depends on the frame size and on how many packets
+  // the caller announces (4K, four ahead: the parsers are the bound and the device's walk is free, 184 against 136 frames/s;
+  // eight ahead: 334 against 295), so option fe_assign = 2 (the default) MEASURES: the time from one adopted frame's
+  // th_decode_packetin to the next, 24 frames with the parsers pairing, 24 without (the frames parsed under the other rule
+  // skipped), then the better of the two for 1024 frames, and again.  A caller that paces itself sees no difference and keeps
+  // the parsers pairing (less device time).
+  int pair_mode = 1;       // what the next announced packet's parser is told
+  int pair_phase = 0;      // 0: timing pair_mode 1; 1: timing pair_mode 0; 2: settled
+  int pair_frames = 0;     // adopted frames in this phase
+  double pair_sum[2] = {0, 0};
+  int pair_cnt[2] = {0, 0};
+  double pair_last = 0;    // when the previous adopted frame's th_decode_packetin began (0: the previous packet was not adopted)
+  long pair_settled[2] = {0, 0};   // (statistics: how often each rule won)
 };
+constexpr int kFePairSample = 24, kFePairSettled = 1024;
 
 static void fe_init_frame_arrays(th_dec_ctx *d) {
   d->coded.assign(d->nfrags, 0);
@@ -2437,8 +2454,9 @@ static void fe_lookahead_free(th_dec_ctx *d) {
               thip_option("fe_assign") ? " (pairing tokens and fragments)" : "", 1e3 * a[0] / jobs, 1e3 * a[1] / jobs, 1e3 * (a[2] + a[3]) / jobs, jobs, la->nslots);
   }
   if (d->prof.on)
-    fprintf(stderr, "[thip front end] look-ahead: %ld packets adopted, %ld announced and not used, %ld walks checked (slot-trace mode)\n", la->adopted,
-            la->missed, d->assign_checked);
+    fprintf(stderr, "[thip front end] look-ahead: %ld packets adopted, %ld announced and not used, %ld walks checked (slot-trace mode); fe_assign = %d"
+            " (measured: the parsers pairing won %ld times, the device's walk %ld)\n", la->adopted, la->missed, d->assign_checked, thip_option("fe_assign"),
+            la->pair_settled[1], la->pair_settled[0]);
   delete la;
   d->la = nullptr;
 }
@@ -2505,7 +2523,8 @@ static int fe_prefetch(th_dec_ctx *d, const ogg_packet *op) {
   sl.pkt.resize((size_t)op->bytes);
   memcpy(sl.pkt.data(), op->packet, (size_t)op->bytes);
   sl.want_lists = fe_lists_now(d) || d->trace;   // (slot-trace mode: packed and walked too, and checked against the host's own walk)
-  sl.want_assign = sl.want_lists && thip_option("fe_assign") != 0;
+  const int asg = thip_option("fe_assign");
+  sl.want_assign = sl.want_lists && (asg == 1 || (asg >= 2 && la->pair_mode));
   sl.timed = d->prof.on;
   sl.done.store(0, std::memory_order_relaxed);
   sl.busy = true;
@@ -2599,13 +2618,50 @@ static void fe_adopt(th_dec_ctx *d, th_dec_ctx *s) {
       for (int z = 0; z < 64; z++) d->prof.tokens += (long)d->ntoks[p][z];
 }
 
+// option fe_assign = 2: which of the two rules is faster here (see FeLookahead); called with the time a th_decode_packetin began and
+// whether it found its packet parsed
+static void fe_pair_rule(FeLookahead *la, double now, bool adopted) {
+  if (!adopted) {
+    la->pair_last = 0;   // (the next interval would not be one between two adopted frames)
+    return;
+  }
+  if (la->pair_last > 0 && la->pair_phase < 2) {
+    la->pair_frames++;
+    if (la->pair_frames > la->nslots + 2) {   // (the packets announced before the rule changed have gone through)
+      la->pair_sum[la->pair_phase] += now - la->pair_last;
+      if (++la->pair_cnt[la->pair_phase] >= kFePairSample) {
+        if (la->pair_phase == 0) {
+          la->pair_mode = 0;
+        } else {
+          const double with = la->pair_sum[0] / la->pair_cnt[0], without = la->pair_sum[1] / la->pair_cnt[1];
+          la->pair_mode = with <= 1.03 * without ? 1 : 0;
+          la->pair_settled[la->pair_mode]++;
+        }
+        la->pair_phase++;
+        la->pair_frames = 0;
+      }
+    }
+  } else if (la->pair_phase == 2 && ++la->pair_frames >= kFePairSettled) {
+    la->pair_phase = 0;
+    la->pair_frames = 0;
+    la->pair_mode = 1;
+    la->pair_sum[0] = la->pair_sum[1] = 0;
+    la->pair_cnt[0] = la->pair_cnt[1] = 0;
+  }
+  la->pair_last = now;
+}
+
 int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   if (!d || !op) return TH_EFAULT;
   if (d->parse_only) return TH_EINVAL;
   FeRun r;
+  if (d->la && !d->la->count) d->la->pair_last = 0;
   if (d->la && d->la->count) {
     d->prof.start();
-    if (FeSlot *sl = fe_lookahead_take(d, op)) {
+    const double now = fe_now();
+    FeSlot *const sl = fe_lookahead_take(d, op);
+    fe_pair_rule(d->la, now, sl != nullptr);
+    if (sl) {
       fe_adopt(d, sl->ctx);
       r.lists_now = fe_lists_now(d);
       r.dc_done = true;

@@ -22,7 +22,7 @@ def main():
     for size in sizes:
         for kind in kinds:
             hdr, pk = packets(size, kind, {"4k": 4, "1080p": 8}.get(size, 12))
-            loops = {"4k": 6, "1080p": 6}.get(size, 8)
+            loops = {"4k": 6, "1080p": 6}.get(size, 8) * int(os.environ.get("E2E_LOOPS", "1"))   # (option fe_assign = 2 takes ~70 frames to settle)
             for T in threads:
                 for la in aheads:
                     decs = [Decoder(hdr) for _ in range(T)]
