@@ -225,7 +225,7 @@ def system_libtheora_baseline(size="720p", nframes=24):
         return {"kind": "system libtheora", "available": True, "library": name, "error": str(e)[:200]}
 
 
-def e2e_keyed_entry(size="720p", nframes=8, loops=6, ahead=4):
+def e2e_keyed_entry(size="720p", nframes=8, loops=30, ahead=8):
     """The whole th_decode_* chain on the driver's clock, as a keyed entry of the default line: packets in host memory ->
     th_decode_packetin -> th_decode_ycbcr_out -> pictures in host memory, ONE stream, the plain API loop and with the packets
     announced `ahead` packets ahead (TH_DECCTL_THIP_PREFETCH_PACKET: the entropy decoder on the library's parser threads).  The two
@@ -268,7 +268,7 @@ def e2e_keyed_entry(size="720p", nframes=8, loops=6, ahead=4):
                 "unit": "frames/s", **res, "same_pictures": same, "avg_packet_bytes": sum(map(len, pkts)) // len(pkts),
                 "data": "synthetic packets (tests/streamgen.py), dense content, matched Huffman trees",
                 "note": "host-bound (Python caller): the plain loop is one entropy-decode thread per stream; announced packets are "
-                        "parsed on up to four library threads and the device's token-list stage becomes the bound (DESIGN.md 5.1)"}
+                        "parsed on up to eight library threads, which also pair tokens and fragments for the device (DESIGN.md 5.1)"}
     except Exception as e:
         return {"error": str(e)[:300]}
 

@@ -2625,6 +2625,10 @@ static void fe_pair_rule(FeLookahead *la, double now, bool adopted) {
     la->pair_last = 0;   // (the next interval would not be one between two adopted frames)
     return;
   }
+  if (la->adopted < 4 * la->nslots + 8) {   // (a stream's first frames: parser contexts and threads come into being, their arrays grow)
+    la->pair_last = now;
+    return;
+  }
   if (la->pair_last > 0 && la->pair_phase < 2) {
     la->pair_frames++;
     if (la->pair_frames > la->nslots + 2) {   // (the packets announced before the rule changed have gone through)

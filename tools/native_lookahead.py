@@ -24,7 +24,7 @@ def main():
                 ls = oggmux.LogicalStream(0x7E0)
                 for k, hp in enumerate(hdr):
                     ls.add_packet(hp, granulepos=0, flush=(k == 0 or k == len(hdr) - 1))
-                reps = {"4k": 4, "1080p": 6}.get(size, 8)
+                reps = {"4k": 8, "1080p": 16}.get(size, 24)
                 for rep in range(reps):
                     for k, p in enumerate(pk):
                         ls.add_packet(p, granulepos=rep * len(pk) + k + 1)
