@@ -566,7 +566,7 @@ def main_e2e(main_args, argv):
             # many streams, one native host thread each (examples/decode_bench.c)
             nb = os.path.join(ROOT, "examples", "decode_bench")
             if os.path.exists(nb):
-                for nt, la in [(n, 0) for n in (1, 2, 4, 8, 16, 32, 64)] + [(1, 4), (2, 4), (4, 4)]:
+                for nt, la in [(n, 0) for n in (1, 2, 4, 8, 16, 32, 64)] + [(1, 4), (1, 8), (4, 4), (4, 8)]:
                     r = subprocess.run([nb, ogv, str(nt), "2"] + (["--lookahead", str(la)] if la else []),
                                        capture_output=True, text=True, timeout=900)
                     line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "{}"

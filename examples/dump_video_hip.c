@@ -5,7 +5,7 @@
  *   cc -Iinclude examples/dump_video_hip.c -Ltheora_amd -ltheora_hip -o dump_video_hip
  *   dump_video_hip [-o out.y4m] [-c|--crop] [-r|--raw] [-f|--fps-only] [--lookahead K] in.ogv
  *
- * The tool reads K (default 4, 0: none) data packets ahead of the one it decodes and announces each to the library as it
+ * The tool reads K (default 8, 0: none) data packets ahead of the one it decodes and announces each to the library as it
  * comes off the demultiplexer (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET): their entropy decoding runs on the library's
  * parser threads while th_decode_packetin / th_decode_ycbcr_out of the current frame run here.  The frames are the same.
  *
@@ -90,7 +90,7 @@ static int decode_head(th_dec_ctx *td, FILE *out, const th_info *ti, int crop, i
 
 int main(int argc, char **argv) {
   const char *in = NULL, *outname = NULL;
-  int crop = 0, raw = 0, fps_only = 0, lookahead = 4, i;
+  int crop = 0, raw = 0, fps_only = 0, lookahead = 8, i;
   for (i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "-o") && i + 1 < argc) outname = argv[++i];
     else if (!strcmp(argv[i], "-c") || !strcmp(argv[i], "--crop")) crop = 1;

@@ -24,7 +24,10 @@ while time.time() - t0 < limit:
     L.thip_set_option(b"tl_levels", int(rng.integers(2)))
     L.thip_set_option(b"tl_algo", int(rng.integers(0, 3)))
     L.thip_set_option(b"tl_walk_threads", int(rng.choice([0, 256, 512, 1024])))
-    T.run_stream(theora_amd, w, h, fmt, seed=seed, nframes=int(rng.integers(4, 10)), kf=int(rng.integers(2, 6)), trees=trees,
-                 device_lists=lists)
+    # ... and the packets announced ahead or not (TH_DECCTL_THIP_PREFETCH_PACKET), their parsers pairing tokens and fragments (1), the
+    # device walking the lists (0), or the measured rule (2)
+    L.thip_set_option(b"fe_assign", int(rng.integers(3)))
+    T.run_stream(theora_amd, w, h, fmt, seed=seed, nframes=int(rng.integers(4, 14)), kf=int(rng.integers(2, 6)), trees=trees,
+                 device_lists=lists, lookahead=int(rng.choice([0, 0, 1, 3, 8])))
     cases += 1
 print("front-end soak: %d streams bit-exact, %.0f s" % (cases, time.time() - t0))

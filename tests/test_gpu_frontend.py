@@ -422,7 +422,7 @@ def test_dump_video_example_on_an_ogg_file(hip, tmp_path):
         cr = np.frombuffer(rec, np.uint8, w * h // 4, 6 + w * h * 5 // 4).reshape(h // 2, w // 2)
         assert np.array_equal(y, planes[0]) and np.array_equal(cb, planes[1]) and np.array_equal(cr, planes[2]), f
     assert "9 frames" in r.stderr
-    # (that was the tool's default: four packets read ahead and announced to the library; the plain loop writes the same file)
+    # (that was the tool's default: eight packets read ahead and announced to the library; the plain loop writes the same file)
     out0 = tmp_path / "clip0.y4m"
     r = subprocess.run([str(exe), "--lookahead", "0", "-o", str(out0), str(ogv)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and out0.read_bytes() == data
