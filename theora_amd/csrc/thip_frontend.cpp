@@ -2286,7 +2286,6 @@ struct FeSlot {
   std::condition_variable cv;
   bool go = false, quit = false;    // (under mu)
   std::atomic<int> done{0};         // the packet is parsed, rc says how it went
-  bool busy = false;                // holds a packet (the caller's thread only)
   int rc = 0;
   bool want_lists = false;          // the owner takes the token-list path: the parser packs the lists too (fe_pack_lists)
   bool want_assign = false;         // ... and pairs tokens and fragments as it decodes them (decode_token_list<true>, option fe_assign)
@@ -2299,7 +2298,6 @@ struct FeSlot {
 struct FeLookahead {
   int nslots = 0, head = 0, count = 0;   // a ring in announcement order: the oldest packet is in slot `head`
   FeSlot slots[kFeLookaheadMax];
-  th_dec_ctx *owner = nullptr;
   cpu_set_t domain;
   bool placed = false;
   long adopted = 0, missed = 0;
@@ -2421,7 +2419,6 @@ static void fe_lookahead_drop(FeLookahead *la) {
   for (int i = 0; i < la->count; i++) {
     FeSlot &sl = la->slots[(la->head + i) % la->nslots];
     fe_slot_wait(sl);
-    sl.busy = false;
   }
   la->missed += la->count;
   la->head = la->count = 0;
@@ -2501,7 +2498,6 @@ static int fe_prefetch(th_dec_ctx *d, const ogg_packet *op) {
   if (!la) {
     la = d->la = new (std::nothrow) FeLookahead();
     if (!la) return 1;
-    la->owner = d;
     la->nslots = want;
   }
   if (la->count >= la->nslots) return 1;
@@ -2527,7 +2523,6 @@ static int fe_prefetch(th_dec_ctx *d, const ogg_packet *op) {
   sl.want_assign = sl.want_lists && (asg == 1 || (asg >= 2 && la->pair_mode));
   sl.timed = d->prof.on;
   sl.done.store(0, std::memory_order_relaxed);
-  sl.busy = true;
   la->count++;
   {
     std::lock_guard<std::mutex> lk(sl.mu);
@@ -2551,7 +2546,6 @@ static FeSlot *fe_lookahead_take(th_dec_ctx *d, const ogg_packet *op) {
   fe_slot_wait(sl);
   la->head = (la->head + 1) % la->nslots;
   la->count--;
-  sl.busy = false;
   if (sl.rc != kFeContinue) {   // a frame without coded blocks, a packet the parser refused: the owner says so itself (cheap)
     la->missed++;
     return nullptr;
