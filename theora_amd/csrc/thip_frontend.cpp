@@ -286,7 +286,7 @@ struct th_dec_ctx {
   std::vector<uint8_t> tl_lastz;
   bool tl_assigned;
   bool pair_on;                      // fe_front pairs tokens and fragments as it decodes the tokens (decode_token_list<true>)
-  std::vector<uint32_t> tokw[3][64]; // ... the words of every list, beside toks
+  uint32_t pair_off[3][64];          // ... where every list's tokens and words start in tl_tokens / tl_assign
   std::vector<uint8_t> pair_pos[3];  // ... the index every coded fragment of a plane arrives at next
   std::vector<uint32_t> pair_arr;    // ... the arrivals of the list at hand
   long assign_checked;               // (slot-trace mode: adopted frames whose walk was checked against the host's own)
@@ -745,6 +745,7 @@ const BitIndexTable kBitIndex;
 struct PairArgs {
   const uint32_t *arr;   // arrivals of this list, coded order: index of the fragment in the plane's coded list
   uint32_t *words;       // one per token of the list (room for n + 1)
+  uint32_t *tokd;        // the list's tokens in the device's format (thip_tokens.h), beside the words
   uint8_t *pos;          // the plane's fragments: the index each arrives at next
   uint32_t c0;           // the plane's first fragment in the frame's coded order
 };
@@ -753,6 +754,7 @@ __attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &
                                                  size_t (*left)[128], int p, int z, uint32_t *eobs, const PairArgs *pa) {
   const uint32_t *arr = PAIR ? pa->arr : nullptr;
   uint32_t *words = PAIR ? pa->words : nullptr;
+  uint32_t *tokd = PAIR ? pa->tokd : nullptr;
   uint8_t *const ppos = PAIR ? pa->pos : nullptr;
   const uint32_t pc0 = PAIR ? pa->c0 : 0u;
   // the reader's state as plain locals: br itself is only touched on the slow paths, so nothing
@@ -831,6 +833,11 @@ __attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &
       arr += take;
       ppos[f] = (uint8_t)(z + k.adv);   // (>= 64: done; an EOB token leaves z, which no later list looks for)
       *words++ = (pc0 + f) | (uint32_t)(z + k.skip) << 18;
+      // (and the token as the device reads it: what fe_pack_lists makes of a list afterwards, made here while the token is in registers)
+      const uint32_t e = k.eob, run = e > 0xFFFFFFu ? 0xFFFFFFu : e;
+      const uint32_t we = 0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24;
+      const uint32_t wv = (uint32_t)(uint16_t)k.value | (uint32_t)k.skip << 16;
+      *tokd++ = e ? we : wv;
     }
     n -= take;
     // (A truncated packet is not special: past the end the reader supplies zero bits, as
@@ -1807,6 +1814,7 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
     int htil = 0, htic = 0;
     // Pairing tokens and fragments while the tokens are decoded (a look-ahead's parser, option fe_assign): see decode_token_list.
     const bool pair = d->pair_on;
+    size_t pair_at = 0;   // tokens written so far
     if (pair) {
       size_t nmax = 0;
       for (int p = 0; p < 3; p++) {
@@ -1844,8 +1852,11 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
         if (pair) {
           // the fragments that arrive at index z of this plane, in coded order: the bytes of `pos` equal to z.  Every one of them
           // has its last index set to z here (decode.c:1545; whoever arrives again later overwrites it).
-          std::vector<uint32_t> &words = d->tokw[p][z];
-          if (words.size() < n + 2) words.resize(n + 2);
+          // tokens (device format) and words go straight to where the device's copy is made from, list after list in the order
+          // they are decoded (the lists' places are a table of the hand-over: any order will do)
+          if (d->tl_tokens.size() < pair_at + n + 2) d->tl_tokens.resize((pair_at + n + 2) * 2);
+          if (d->tl_assign.size() < pair_at + n + 2) d->tl_assign.resize((pair_at + n + 2) * 2);
+          d->pair_off[p][z] = (uint32_t)pair_at;
           const size_t c0 = d->cl_start[p], np = d->cl_start[p + 1] - c0, np16 = (np + 15) & ~(size_t)15;
           uint8_t *const pos = d->pair_pos[p].data();
           uint32_t *const arr = d->pair_arr.data();
@@ -1881,8 +1892,9 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
 #endif
           }
           // (na == the list's arrivals by construction; a carried run has ended the first eob_carry of them)
-          PairArgs pa = {arr + d->eob_carry[p][z], words.data(), pos, (uint32_t)c0};
+          PairArgs pa = {arr + d->eob_carry[p][z], d->tl_assign.data() + pair_at, d->tl_tokens.data() + pair_at, pos, (uint32_t)c0};
           out = decode_token_list<true>(br, tree, n, list.data(), left, p, z, &eobs, &pa);
+          pair_at += (size_t)(out - list.data());
         } else {
           out = decode_token_list<false>(br, tree, n, list.data(), left, p, z, &eobs, nullptr);
         }
@@ -1912,39 +1924,42 @@ static void fe_pack_lists(th_dec_ctx *d) {
   size_t nt = 0;
   for (int p = 0; p < 3; p++)
     for (int z = 0; z < 64; z++) nt += d->ntoks[p][z];
-  d->tl_tokens.resize(nt + 1);
-  uint32_t *o = d->tl_tokens.data();
-  size_t at = 0;
-  for (int p = 0; p < 3; p++)
-    for (int z = 0; z < 64; z++) {
-      tl.list_off[p][z] = (uint32_t)at;
-      tl.list_len[p][z] = (uint32_t)d->ntoks[p][z];
-      tl.eob_carry[p][z] = d->eob_carry[p][z];
-      tl.arrivals[p][z] = d->arrivals[p][z];
-      // (branch-free, one list at a time: the compiler vectorises it)
-      const Tok *__restrict t = d->toks[p][z].data();
-      uint32_t *__restrict w = o + at;
-      const size_t nk = d->ntoks[p][z];
-      for (size_t k = 0; k < nk; k++) {
-        const uint32_t e = t[k].eob;
-        const uint32_t run = e > 0xFFFFFFu ? 0xFFFFFFu : e;   // (more than any plane the backend takes has)
-        const uint32_t we = 0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24;
-        const uint32_t wv = (uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16;
-        w[k] = e ? we : wv;
-      }
-      at += nk;
-    }
-  tl.ntokens = (int64_t)nt;
-  d->tl_assigned = false;
-  if (d->pair_on) {   // the words fe_front made beside the tokens (decode_token_list<true>), in the same places
-    d->tl_assign.resize(nt + 1);
-    uint32_t *const a = d->tl_assign.data();
+  if (d->pair_on) {   // fe_front has written the tokens and their words where they belong (decode_token_list<true>): the tables only
     for (int p = 0; p < 3; p++)
-      for (int z = 0; z < 64; z++)
-        if (d->ntoks[p][z]) memcpy(a + tl.list_off[p][z], d->tokw[p][z].data(), d->ntoks[p][z] * 4);
-    a[nt] = 0xFFFFFFFFu;
-    d->tl_assigned = true;   // (tl_lastz is fe_front's too)
+      for (int z = 0; z < 64; z++) {
+        tl.list_off[p][z] = d->pair_off[p][z];
+        tl.list_len[p][z] = (uint32_t)d->ntoks[p][z];
+        tl.eob_carry[p][z] = d->eob_carry[p][z];
+        tl.arrivals[p][z] = d->arrivals[p][z];
+      }
+    if (d->tl_assign.size() < nt + 1) d->tl_assign.resize(nt + 1);
+    d->tl_assign[nt] = 0xFFFFFFFFu;
+  } else {
+    d->tl_tokens.resize(nt + 1);
+    uint32_t *o = d->tl_tokens.data();
+    size_t at = 0;
+    for (int p = 0; p < 3; p++)
+      for (int z = 0; z < 64; z++) {
+        tl.list_off[p][z] = (uint32_t)at;
+        tl.list_len[p][z] = (uint32_t)d->ntoks[p][z];
+        tl.eob_carry[p][z] = d->eob_carry[p][z];
+        tl.arrivals[p][z] = d->arrivals[p][z];
+        // (branch-free, one list at a time: the compiler vectorises it)
+        const Tok *__restrict t = d->toks[p][z].data();
+        uint32_t *__restrict w = o + at;
+        const size_t nk = d->ntoks[p][z];
+        for (size_t k = 0; k < nk; k++) {
+          const uint32_t e = t[k].eob;
+          const uint32_t run = e > 0xFFFFFFu ? 0xFFFFFFu : e;   // (more than any plane the backend takes has)
+          const uint32_t we = 0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24;
+          const uint32_t wv = (uint32_t)(uint16_t)t[k].value | (uint32_t)t[k].skip << 16;
+          w[k] = e ? we : wv;
+        }
+        at += nk;
+      }
   }
+  tl.ntokens = (int64_t)nt;
+  d->tl_assigned = d->pair_on;   // (tl_assign and tl_lastz are fe_front's too)
   d->prof.lap(FE_LPACK);
   const size_t nc = d->cl_start[3];
   d->tl_meta.resize(nc + 1);
