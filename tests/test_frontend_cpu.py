@@ -176,14 +176,20 @@ def test_dropped_frame_before_any_frame_shows_grey(trace_env):
     dec.close()
 
 
-@pytest.mark.parametrize("ahead", [1, 3, 6])
+@pytest.mark.parametrize("ahead,assign", [(1, 2), (3, 1), (6, 2), (4, 0)])
 @pytest.mark.parametrize("w,h,fmt", [(176, 144, 0), (48, 64, 3), (80, 48, 2)])
-def test_announced_packets_give_the_same_slot_calls(trace_env, w, h, fmt, ahead):
+def test_announced_packets_give_the_same_slot_calls(trace_env, w, h, fmt, ahead, assign):
     """TH_DECCTL_THIP_PREFETCH_PACKET (include/theoradec_hip.h): packets announced ahead of their th_decode_packetin are parsed
     on threads of their own and adopted; return codes, granule positions and every recorded slot call must equal those of a
     context that was never told anything -- key frames, inter frames, dropped frames, several qi per frame, more announcements
-    than slots, an announcement that does not match what comes, and a context freed with announcements outstanding."""
+    than slots, an announcement that does not match what comes, and a context freed with announcements outstanding.  With
+    option fe_assign at 1 or 2 the parsers also pair tokens and fragments for the device while they decode (decode_token_list<true>);
+    in slot-trace mode every adopted frame's pairing is applied token by token, as k_tok_scatter applies it, and compared with the
+    coefficients of the host's own fragment-order walk -- a mismatch makes th_decode_packetin fail."""
+    from theora_amd import _lib
     from theora_amd.decoder import Decoder
+    L = _lib.load()
+    L.thip_set_option(b"fe_assign", assign)
     st = streamgen.Stream(w, h, fmt, seed=w + 3 * h + fmt, trees="matched")
     hdr = st.header_packets()
     pk = []
@@ -217,3 +223,4 @@ def test_announced_packets_give_the_same_slot_calls(trace_env, w, h, fmt, ahead)
     fast.prefetch(pk[1])
     fast.close()                                # announcements outstanding: waited for, nothing leaks, nothing hangs
     plain.close()
+    L.thip_set_option(b"fe_assign", 2)
