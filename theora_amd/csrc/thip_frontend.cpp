@@ -2298,9 +2298,9 @@ struct FeSlot {
   th_dec_ctx *ctx = nullptr;        // the parser context (created with the slot's first packet)
   std::thread th;
   std::mutex mu;
-  std::condition_variable cv;
+  std::condition_variable cv, cv_done;
   bool go = false, quit = false;    // (under mu)
-  std::atomic<int> done{0};         // the packet is parsed, rc says how it went
+  std::atomic<int> done{0};         // the packet is parsed, rc says how it went (set under mu, read without)
   int rc = 0;
   bool want_lists = false;          // the owner takes the token-list path: the parser packs the lists too (fe_pack_lists)
   bool want_assign = false;         // ... and pairs tokens and fragments as it decodes them (decode_token_list<true>, option fe_assign)
@@ -2418,15 +2418,23 @@ static void fe_slot_main(FeSlot *sl) {
       sl->go = false;
     }
     fe_parse_job(*sl);
-    sl->done.store(1, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(sl->mu);   // (a waiter that has given up spinning sleeps on cv_done under mu)
+      sl->done.store(1, std::memory_order_release);
+    }
+    sl->cv_done.notify_one();
   }
 }
 
+// the packet in this slot is parsed: a short spin (the usual case: the parsers are ahead, or nearly), then asleep -- a caller whose
+// parsers are the bound would otherwise burn a core, and with it a share of a CPU quota, doing nothing
 static void fe_slot_wait(FeSlot &sl) {
-  for (unsigned spins = 0; !sl.done.load(std::memory_order_acquire); spins++) {
-    if (spins < 8192) __builtin_ia32_pause();
-    else std::this_thread::yield();
+  for (unsigned spins = 0; spins < 4096; spins++) {
+    if (sl.done.load(std::memory_order_acquire)) return;
+    __builtin_ia32_pause();
   }
+  std::unique_lock<std::mutex> lk(sl.mu);
+  sl.cv_done.wait(lk, [&] { return sl.done.load(std::memory_order_acquire) != 0; });
 }
 
 // every announced packet dropped (their parsers are waited for: they write into the slots' contexts)
