@@ -2059,7 +2059,7 @@ static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
     if (lrc >= 0) lists_done = true;
     else if (lrc != THIP_EIMPL) return TH_EFAULT;   // (THIP_EIMPL: a plane too large for that path -- the slots below)
   } else if (lists_now) {
-    if (!d->tl_packed) {   // (an adopted frame may bring them packed, and walked)
+    if (!d->tl_packed) {   // (an adopted frame may bring them packed, and its tokens paired with their fragments)
       fe_pack_lists(d);
       d->tl_assigned = false;
     }
@@ -2085,7 +2085,7 @@ static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
     int lrc = THIP_EIMPL;
     if (d->tl_assigned) lrc = thip_state_token_lists_begin_assigned(d->hip, &tl, d->tl_assign.data(), d->tl_lastz.data());
     d->tl_assigned = false;
-    if (lrc == THIP_EIMPL) lrc = thip_state_token_lists_begin(d->hip, &tl);   // (not walked, or no room for the walk's arrays)
+    if (lrc == THIP_EIMPL) lrc = thip_state_token_lists_begin(d->hip, &tl);   // (not paired, or no room for the pairing's arrays)
     d->prof.lap(FE_LBEGIN);
     if (lrc >= 0) {
       const int16_t *dcv = nullptr;
@@ -2231,7 +2231,7 @@ static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
     rc = thip_frame_flush(d->hip);
     if (rc < 0) return TH_EFAULT;
   } else if (d->tl_assigned) {
-    // an adopted frame whose parser walked the lists for the device: every token applied on its own, as k_tok_scatter applies
+    // an adopted frame whose parser paired tokens and fragments for the device: every token applied on its own, as k_tok_scatter applies
     // them, must give the coefficients recorded above
     d->tl_assigned = false;
     if (!fe_check_assignment(d)) return TH_EFAULT;
@@ -2541,7 +2541,7 @@ static int fe_prefetch(th_dec_ctx *d, const ogg_packet *op) {
   sl.bytes = op->bytes;
   sl.pkt.resize((size_t)op->bytes);
   memcpy(sl.pkt.data(), op->packet, (size_t)op->bytes);
-  sl.want_lists = fe_lists_now(d) || d->trace;   // (slot-trace mode: packed and walked too, and checked against the host's own walk)
+  sl.want_lists = fe_lists_now(d) || d->trace;   // (slot-trace mode: packed and paired too, and checked against the host's own walk)
   const int asg = thip_option("fe_assign");
   sl.want_assign = sl.want_lists && (asg == 1 || (asg >= 2 && la->pair_mode));
   sl.timed = d->prof.on;
