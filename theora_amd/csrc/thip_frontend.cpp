@@ -562,24 +562,44 @@ void read_short_run_bits(BitReader &br, size_t nbits, std::vector<uint8_t> &out)
 // ---------------------------------------------------------------------------------------
 // motion vectors (spec 7.5.1)
 // ---------------------------------------------------------------------------------------
-int read_mv_component(BitReader &br, int mvmode) {
-  if (mvmode) {
-    int v = (int)br.read(5);
-    return br.bit() ? -v : v;
+// Table 7.23 is a 3-bit prefix + magnitude bits + sign, eight bits at most: tabulated by the next eight bits (value, length)
+struct MvTable {
+  int8_t value[256];
+  uint8_t len[256];
+  MvTable() {
+    for (int w = 0; w < 256; w++) {
+      const int p = w >> 5;
+      int mag = 0, nb = 3, v;
+      switch (p) {
+        case 0: v = 0; break;
+        case 1: v = 1; break;
+        case 2: v = -1; break;
+        case 3: mag = 2; nb = 3; v = 2; break;
+        case 4: mag = 3; nb = 3; v = 2; break;
+        case 5: nb = 5; mag = 4 + ((w >> 3) & 3); v = 2; break;
+        case 6: nb = 6; mag = 8 + ((w >> 2) & 7); v = 2; break;
+        default: nb = 7; mag = 16 + ((w >> 1) & 15); v = 2; break;
+      }
+      if (p >= 3) {   // the sign follows the magnitude bits
+        const int sign = (w >> (7 - nb)) & 1;
+        v = sign ? -mag : mag;
+        nb++;
+      }
+      value[w] = (int8_t)v;
+      len[w] = (uint8_t)nb;
+    }
   }
-  const uint32_t p = br.read(3);   // Table 7.23 is a 3-bit prefix + magnitude bits + sign
-  int mag;
-  switch (p) {
-    case 0: return 0;
-    case 1: return 1;
-    case 2: return -1;
-    case 3: mag = 2; break;
-    case 4: mag = 3; break;
-    case 5: mag = 4 + (int)br.read(2); break;
-    case 6: mag = 8 + (int)br.read(3); break;
-    default: mag = 16 + (int)br.read(4); break;
+};
+const MvTable kMvTab;
+inline int read_mv_component(BitReader &br, int mvmode) {
+  if (mvmode) {   // five bits of magnitude, one of sign
+    const uint32_t v = br.read(6);
+    const int mag = (int)(v >> 1);
+    return (v & 1u) ? -mag : mag;
   }
-  return br.bit() ? -mag : mag;
+  const uint32_t w = br.peek(8);   // (bits past the packet's end read as zeros)
+  br.skip(kMvTab.len[w]);
+  return kMvTab.value[w];
 }
 
 inline int round_div(int v, int shift) {   // round(v / 2^shift), ties away from zero (spec 7.5.2)
@@ -1655,8 +1675,11 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
       int mode = MODE_INTER_NOMV;
       if (any) {
         if (mscheme != 7) {
-          int mi = 0;
-          while (mi < 7 && br.bit()) mi++;
+          // Table 7.19's codes are unary: up to seven ones, closed by a zero unless there are seven.  One look at seven bits instead
+          // of a read per bit (bits past the packet's end read as zeros either way).
+          int mi = __builtin_clz(~(br.peek(7) << 25));
+          if (mi > 7) mi = 7;
+          br.skip(mi < 7 ? mi + 1 : 7);
           mode = alphabet[mi];
         } else {
           mode = (int)br.read(3);
