@@ -575,7 +575,8 @@ const char *thip_version_string(void);
  *                0: left to the scheduler (measured 5-10 % SLOWER than no second thread on a two-socket host)
  *   fe_lookahead   th_decode_*: how many packets a caller may announce ahead of their th_decode_packetin
  *                (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET, include/theoradec_hip.h): each is parsed -- entropy decoder and DC
- *                chain -- by a thread of its own; 8 (default), up to 16; 0: announcements are not taken
+ *                chain -- by a thread of its own; 8 (default), up to 16; 0: announcements are not taken (read when a context's
+ *                first packet is announced)
  *   fe_assign    th_decode_*, announced packets on the token-list path: 1: the parser pairs tokens and fragments
  *                (which token belongs to which fragment, decode.c:1540-1581) as it decodes the tokens and the frame goes to
  *                thip_state_token_lists_begin_assigned -- the device pairs nothing; 0: thip_state_token_lists_begin, the

@@ -224,3 +224,39 @@ def test_announced_packets_give_the_same_slot_calls(trace_env, w, h, fmt, ahead,
     fast.close()                                # announcements outstanding: waited for, nothing leaks, nothing hangs
     plain.close()
     L.thip_set_option(b"fe_assign", 2)
+
+
+def test_prefetch_request_arguments_and_refusals(trace_env):
+    """TH_DECCTL_THIP_PREFETCH_PACKET: TH_EFAULT without a context or a buffer, TH_EINVAL for a buffer that is not an ogg_packet;
+    1 ("not taken", harmless) for an empty packet, with option fe_lookahead at 0, and once the slots are full -- and the
+    packets decode the same whatever was refused."""
+    import ctypes as C
+    from theora_amd import _lib
+    from theora_amd.decoder import Decoder, TH_DECCTL_THIP_PREFETCH_PACKET, _packet
+    L = _lib.load()
+    st = streamgen.Stream(64, 48, 0, seed=3)
+    hdr = st.header_packets()
+    pk = [st.frame(0 if f == 0 else 1, density=0.6)[0] for f in range(12)]
+    dec, ref = Decoder(hdr), Decoder(hdr)
+    op, keep = _packet(pk[0])
+    assert L.th_decode_ctl(None, TH_DECCTL_THIP_PREFETCH_PACKET, C.byref(op), C.sizeof(op)) == _lib.EFAULT
+    assert L.th_decode_ctl(dec._dec, TH_DECCTL_THIP_PREFETCH_PACKET, None, C.sizeof(op)) == _lib.EFAULT
+    assert L.th_decode_ctl(dec._dec, TH_DECCTL_THIP_PREFETCH_PACKET, C.byref(op), 4) == _lib.EINVAL
+    assert dec.prefetch(b"") is False                       # a dropped frame: nothing to parse
+    old = L.thip_option(b"fe_lookahead")
+    L.thip_set_option(b"fe_lookahead", 0)
+    assert dec.prefetch(pk[0]) is False                     # announcements are not taken
+    L.thip_set_option(b"fe_lookahead", 3)
+    try:
+        taken = [dec.prefetch(p) for p in pk[:5]]
+        assert taken == [True, True, True, False, False]    # three slots
+        for i, p in enumerate(pk):
+            ra, rb = ref.packetin(p), dec.packetin(p)
+            assert ra == rb
+            ta, tb = ref.slot_trace(), dec.slot_trace()
+            for k in ta:
+                assert np.array_equal(ta[k], tb[k]), (i, k)
+    finally:
+        L.thip_set_option(b"fe_lookahead", old)
+    dec.close()
+    ref.close()
