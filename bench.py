@@ -747,20 +747,31 @@ def main():
     step0 += args.warmup
     sync()
     elapsed_blocks = []
+    submit_times = []
     total_t = 0.0
     while len(elapsed_blocks) < args.repeats or (total_t < args.min_time and len(elapsed_blocks) < 4096):
         sync()
         barrier()
         t0 = time.perf_counter()
         run(args.steps, first=step0)
+        t_sub = time.perf_counter() - t0   # (diagnostic: the host's part, all K steps submitted)
         sync()
         dt = time.perf_counter() - t0      # this rank's K steps, start aligned by the barrier; the MAX over ranks is taken below
+        submit_times.append(t_sub)
         barrier()                          # (outside the clock: a trailing collective would add its own latency to every 0.8 ms block)
         elapsed_blocks.append(dt)
         total_t += dt
         step0 += args.steps
         if dist.is_initialized():   # every rank must run the same number of blocks
             total_t = shard.reduce_max([total_t], torch.device("cuda", local_rank))[0]
+    # (diagnostic: what the bracket itself costs -- sync() on an idle device, part of every block's time)
+    idle_sync = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        sync()
+        idle_sync.append(time.perf_counter() - t0)
+    idle_sync_us = 1e6 * sorted(idle_sync)[len(idle_sync) // 2]
+    submit_us = 1e6 * sorted(submit_times)[len(submit_times) // 2]
     # Pass B: steps with every kernel bracketed by HIP events on the stream it runs on -> per-kernel durations for the
     # roofline.  Kept out of pass A because four event records per step cost ~15 % of the step.  Two shapes:
     #   (1) ONE stream, one launch per step carrying all S streams: the kernel has the chip to itself -- the roofline of the
@@ -940,7 +951,8 @@ def main():
             "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "statistic": "median block",
                        "ms_per_step_min": round(1e3 * min(blocks) / args.steps, 5),
                        "ms_per_step_max": round(1e3 * max(blocks) / args.steps, 5),
-                       "ms_per_step_first_block": round(1e3 * blocks[0] / args.steps, 5)},
+                       "ms_per_step_first_block": round(1e3 * blocks[0] / args.steps, 5),
+                       "host_submit_us_per_block": round(submit_us, 1), "idle_sync_us": round(idle_sync_us, 1)},
         }
         # HBM bytes per launch from the PMC counters of THIS workload: two more passes of this script under rocprofv3
         traffic, traffic_bytes = None, None

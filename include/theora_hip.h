@@ -224,12 +224,15 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
 /* Wait for everything submitted on the library's own streams.  k_recon_lf hands tile edges between concurrently running
    work groups and relies on their being dispatched in order; every wait is bounded, and one that gives up sets a pinned word
    of the state (it has never been observed outside the test that forces it).  The calls that synchronise with a state --
-   this one, thip_state_ycbcr_map / _out, thip_state_read_plane -- look at the word: the state's most recent frame is decoded
+   thip_state_ycbcr_map / _out, thip_state_read_plane -- look at the word: the state's most recent frame is decoded
    AGAIN with the two-pass kernels when its command stream lives in the state's own staging buffers (frames that came through
    the enqueue slots or the token lists, i.e. every th_decode_* frame) and nothing has been decoded since; the call then
-   succeeds and option "faults_recovered" counts.  A frame given to thip_decode_frames by descriptor cannot be decoded again
-   (the descriptors are the caller's): the call returns THIP_EFAULT, once, and the state's pictures are wrong until its next
-   key frame. */
+   succeeds and option "faults_recovered" counts.  A frame given to thip_decode_frames by descriptor can be decoded again only
+   if the caller has promised (option "redo_descs" = 1) that the buffers its descriptors point to stay as they are until the
+   state's next synchronising call; otherwise, and whenever a frame was decoded on top of the failed one before anything looked
+   (the kernels record WHICH launch gave up), the call returns THIP_EFAULT, once, and the state's pictures are wrong until its
+   next key frame.  thip_synchronize itself only reports (THIP_EFAULT while some state's words are set): a state belongs to
+   one thread at a time, so decoding again is left to the state's own synchronising calls. */
 int thip_synchronize(void);
 
 /* ------------------------------------------------------------------------------------
@@ -551,6 +554,9 @@ const char *thip_version_string(void);
  *   debug        k_recon ablation switches (profiling); 256: k_recon_lf's cells copy without filtering; 512: tile 1 of every
  *                stream mis-tags its edge units, so that a hand-over fails and the recovery below can be tested
  *   faults_recovered   (counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf ran out
+ *   redo_descs   thip_decode_frames on the caller's descriptors: 1 = the caller promises that the buffers a descriptor points to stay
+ *                as they are until the state's next synchronising call, so a frame whose hand-over failed is decoded again (default 0:
+ *                THIP_EFAULT, see thip_synchronize)
  *   fe_device_dc, fe_device_tokens   th_decode_*: front-end stages on the device (default 0; also TH_DECCTL_THIP_SET_DEVICE_*
  *                per context)
  *   fe_device_lists   th_decode_*: the token lists go to the device as the entropy decoder leaves them: 1 on, 0 off, -1 (default)

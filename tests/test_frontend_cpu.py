@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle
-from tests import streamgen
+from tests import streamgen, util
 
 
 @pytest.fixture()
@@ -189,41 +189,40 @@ def test_announced_packets_give_the_same_slot_calls(trace_env, w, h, fmt, ahead,
     from theora_amd import _lib
     from theora_amd.decoder import Decoder
     L = _lib.load()
-    L.thip_set_option(b"fe_assign", assign)
-    st = streamgen.Stream(w, h, fmt, seed=w + 3 * h + fmt, trees="matched")
-    hdr = st.header_packets()
-    pk = []
-    for f in range(18):
-        if f in (7, 13):
-            pk.append(b"")                      # a dropped frame (decode.c:2746)
-        else:
-            pk.append(st.frame(0 if f % 6 == 0 else 1, density=[0.9, 0.5, 0.15][f % 3])[0])
-    plain, fast = Decoder(hdr), Decoder(hdr)
-    nxt, taken = 0, 0
-    for i, p in enumerate(pk):
-        while nxt < len(pk) and nxt < i + ahead:
-            if nxt < i:
-                nxt = i
-            q = pk[nxt]
-            if nxt == 10 and len(q) > 8:        # announce something else than what will come: dropped, parsed the ordinary way
-                q = bytes(q[:-4]) + b"\x55\xAA\x55\xAA"
-            if fast.prefetch(q):
-                taken += 1
-            elif len(q):
-                break                           # no slot free (option fe_lookahead: eight)
-            nxt += 1
-        ra, rb = plain.packetin(p), fast.packetin(p)
-        assert ra == rb, (i, ra, rb)
-        if ra[0] == 0:
-            ta, tb = plain.slot_trace(), fast.slot_trace()
-            for k in ta:
-                assert np.array_equal(ta[k], tb[k]), (i, k)
-    assert taken >= 10
-    fast.prefetch(pk[0])
-    fast.prefetch(pk[1])
-    fast.close()                                # announcements outstanding: waited for, nothing leaks, nothing hangs
-    plain.close()
-    L.thip_set_option(b"fe_assign", 2)
+    with util.options(L, fe_assign=assign):
+        st = streamgen.Stream(w, h, fmt, seed=w + 3 * h + fmt, trees="matched")
+        hdr = st.header_packets()
+        pk = []
+        for f in range(18):
+            if f in (7, 13):
+                pk.append(b"")                      # a dropped frame (decode.c:2746)
+            else:
+                pk.append(st.frame(0 if f % 6 == 0 else 1, density=[0.9, 0.5, 0.15][f % 3])[0])
+        plain, fast = Decoder(hdr), Decoder(hdr)
+        nxt, taken = 0, 0
+        for i, p in enumerate(pk):
+            while nxt < len(pk) and nxt < i + ahead:
+                if nxt < i:
+                    nxt = i
+                q = pk[nxt]
+                if nxt == 10 and len(q) > 8:        # announce something else than what will come: dropped, parsed the ordinary way
+                    q = bytes(q[:-4]) + b"\x55\xAA\x55\xAA"
+                if fast.prefetch(q):
+                    taken += 1
+                elif len(q):
+                    break                           # no slot free (option fe_lookahead: eight)
+                nxt += 1
+            ra, rb = plain.packetin(p), fast.packetin(p)
+            assert ra == rb, (i, ra, rb)
+            if ra[0] == 0:
+                ta, tb = plain.slot_trace(), fast.slot_trace()
+                for k in ta:
+                    assert np.array_equal(ta[k], tb[k]), (i, k)
+        assert taken >= 10
+        fast.prefetch(pk[0])
+        fast.prefetch(pk[1])
+        fast.close()                                # announcements outstanding: waited for, nothing leaks, nothing hangs
+        plain.close()
 
 
 def test_prefetch_request_arguments_and_refusals(trace_env):

@@ -694,3 +694,97 @@ def test_a_failed_hand_over_is_decoded_again(hip, capfd):
             assert not util.planes_equal(ost2, gst), f
     finally:
         L.thip_set_option(b"debug", 0)
+
+
+def test_a_frame_decoded_on_top_of_a_failed_one_is_reported_not_repeated(hip, capfd):
+    """The kernels record WHICH launch's wait ran out.  A caller that enqueues frame N (whose hand-over fails) and frame N + 1 before
+    any synchronising call has decoded N + 1 against a wrong reference: repeating N + 1 -- the only frame the state can still
+    repeat -- would not make it right, so the next synchronising call says THIP_EFAULT (once) instead of counting a recovery, and
+    the state is good again from its next key frame."""
+    L = hip._lib.load()
+    import ctypes as C
+    w, h = 512, 256
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(654)
+    ost = oracle.State(w, h, PF_420)
+    gst = hip.State(w, h, PF_420)
+    n0 = C.c_int()
+    L.thip_get_option(b"faults_recovered", C.byref(n0))
+    try:
+        for f in range(3):
+            fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "dense", flimit=3)
+            util.oracle_apply(ost, fr)
+            L.thip_set_option(b"debug", 512 if f == 1 else 0)
+            util.enqueue_frame(hip, gst, geom, fr)      # (no synchronising call between frame 1 and frame 2)
+        L.thip_set_option(b"debug", 0)
+        with pytest.raises(hip.TheoraHipError):
+            gst.read_plane(gst.ref_idx(hip.FRAME_PREV), 0)
+        gst.read_plane(gst.ref_idx(hip.FRAME_PREV), 0)            # reported once
+        n1 = C.c_int()
+        L.thip_get_option(b"faults_recovered", C.byref(n1))
+        assert n1.value == n0.value
+        assert "could not be decoded again" in capfd.readouterr().err
+        ost2 = oracle.State(w, h, PF_420)
+        for f in range(2):
+            fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "mixed", flimit=3)
+            util.oracle_apply(ost2, fr)
+            util.enqueue_frame(hip, gst, geom, fr)
+            assert not util.planes_equal(ost2, gst), f
+    finally:
+        L.thip_set_option(b"debug", 0)
+
+
+def test_a_failed_hand_over_on_the_callers_descriptors(hip, capfd):
+    """thip_decode_frames on descriptors that are the caller's (the multi-stream server's and bench.py's path), two states in one
+    call.  By default the library cannot repeat such a frame: each state's next synchronising call returns THIP_EFAULT once.  With
+    option redo_descs = 1 -- the caller's promise that the buffers behind a descriptor stay as they are until the state's next
+    synchronising call -- the frame is decoded again with the two passes and both pictures are the oracle's."""
+    L = hip._lib.load()
+    import ctypes as C
+    w, h = 512, 256
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(987)
+    osts = [oracle.State(w, h, PF_420) for _ in range(2)]
+    gsts = [hip.State(w, h, PF_420) for _ in range(2)]
+    keep = []
+    n0 = C.c_int()
+    L.thip_get_option(b"faults_recovered", C.byref(n0))
+    try:
+        L.thip_set_option(b"redo_descs", 1)
+        for f in range(3):
+            descs = []
+            for i in range(2):
+                fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "dense", flimit=3)
+                util.oracle_apply(osts[i], fr)
+                desc, ka = synth.upload_frame(synth.pack_frame(geom, fr, form="dequant16" if f & 1 else None))
+                keep.append(ka)
+                descs.append(desc)
+            L.thip_set_option(b"debug", 512 if f >= 1 else 0)
+            hip.decode_frames(gsts, descs)
+            L.thip_set_option(b"debug", 0)
+            for i in range(2):
+                assert not util.planes_equal(osts[i], gsts[i]), (f, i)
+        n1 = C.c_int()
+        L.thip_get_option(b"faults_recovered", C.byref(n1))
+        assert n1.value - n0.value == 4
+        assert "decoding the frame again" in capfd.readouterr().err
+        # without the promise: THIP_EFAULT once per state, pictures wrong until the next key frame
+        L.thip_set_option(b"redo_descs", 0)
+        descs = []
+        for i in range(2):
+            fr = synth.gen_frame(geom, rng, hip.INTER_FRAME, "dense", flimit=3)
+            desc, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+            keep.append(ka)
+            descs.append(desc)
+        L.thip_set_option(b"debug", 512)
+        hip.decode_frames(gsts, descs)
+        L.thip_set_option(b"debug", 0)
+        assert L.thip_synchronize() == -1   # THIP_EFAULT: reports, repairs nothing
+        for i in range(2):
+            with pytest.raises(hip.TheoraHipError):
+                gsts[i].read_plane(gsts[i].ref_idx(hip.FRAME_PREV), 0)
+            gsts[i].read_plane(gsts[i].ref_idx(hip.FRAME_PREV), 0)
+        assert L.thip_synchronize() == 0
+    finally:
+        L.thip_set_option(b"debug", 0)
+        L.thip_set_option(b"redo_descs", 0)

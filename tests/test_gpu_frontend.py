@@ -86,14 +86,9 @@ def test_look_ahead_with_the_walk_left_to_the_device(hip, w, h, fmt, ahead, leve
     (thip_state_token_lists_begin_assigned: k_tok_scatter, the default, what the other look-ahead tests run); and both forms of
     the coefficient slots (tl_levels) behind the host's walk."""
     L = hip._lib.load()
-    L.thip_set_option(b"fe_assign", 0 if levels else 1)
-    L.thip_set_option(b"tl_levels", levels)
-    try:
+    with util.options(L, fe_assign=0 if levels else 1, tl_levels=levels):
         assert run_stream(hip, w, h, fmt, seed=w + 5 * h + fmt, nframes=10 if w < 1000 else 5, device_lists=True, lookahead=ahead,
                           trees="matched" if w >= 1000 else "random") >= 4
-    finally:
-        L.thip_set_option(b"fe_assign", 1)
-        L.thip_set_option(b"tl_levels", 1)
 
 
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (80, 48, 2), (16, 16, 0), (336, 32, 0)])

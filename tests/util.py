@@ -108,3 +108,42 @@ def enqueue_frame(theora_amd, gst, geom, fr, levels=False):
         notstart = 1
         stripe += mcu
     return gst.frame_flush()
+
+
+import contextlib
+
+
+def options_snapshot(L):
+    """Every run-time option of the library (thip_option_name enumerates the table) except the counters."""
+    import ctypes as C
+    L.thip_option_name.restype = C.c_char_p
+    L.thip_option_name.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    out, i = {}, 0
+    while True:
+        help_ = C.c_char_p()
+        name = L.thip_option_name(i, C.byref(help_))
+        if name is None:
+            return out
+        i += 1
+        if (help_.value or b"").startswith(b"(counter)"):
+            continue
+        v = C.c_int()
+        assert L.thip_get_option(name, C.byref(v)) == 0
+        out[name] = v.value
+
+
+@contextlib.contextmanager
+def options(L, **kw):
+    """Set options for the body and put back WHAT THEY WERE (not what the test believes the default is)."""
+    import ctypes as C
+    old = {}
+    for k, v in kw.items():
+        c = C.c_int()
+        assert L.thip_get_option(k.encode(), C.byref(c)) == 0, k
+        old[k] = c.value
+        assert L.thip_set_option(k.encode(), int(v)) == 0, k
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            L.thip_set_option(k.encode(), v)

@@ -90,6 +90,7 @@ Option g_options[] = {
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
     {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
     {"sb_tiles", 600, "k_recon_lf_sb (one super block per wave, four lanes per block) instead of k_recon_lf for launches of fewer tiles than this (0: never)"},
+    {"redo_descs", 0, "thip_decode_frames on the caller's descriptors: 1: the caller promises that the buffers a descriptor points to stay as they are until the state's next synchronising call, so a frame whose hand-over failed can be decoded again like a th_decode_* frame; 0 (default): such a frame gets THIP_EFAULT"},
     {"faults_recovered", 0, "(counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf had run out"},
 };
 constexpr int kNumOptions = (int)(sizeof(g_options) / sizeof(g_options[0]));
@@ -194,7 +195,8 @@ struct thip_state {
   int16_t *d_dc;        // device, nfrags: un-predicted DC values of the frame being decoded
   uint4 *d_dc_ent;      // device, nfrags: k_dc_prepare's per-fragment entries
   uint8_t *d_dc_rowhas; // device, one byte per fragment row of every plane
-  uint32_t *fault;      // pinned host word: bit 0 set by k_recon_lf, bit 1 by k_pp_dering, when a bounded wait ran out
+  uint32_t *fault;      // pinned host words (16): [0] set to 1 by k_recon_lf / k_recon_lf_sb when a bounded wait ran out, [1 + id % 8] = the
+                        // id of the launch that did (its edge serial number, | 0x1000 for the super-block kernel), [9] set to 2 by k_pp_dering
   // the state's most recent frame, kept so that it can be decoded again with the two passes if its hand-over failed
   // (recover_fault); only frames whose command stream lives in the state's own staging buffers (enqueue slots, token lists)
   struct {
@@ -204,6 +206,7 @@ struct thip_state {
     int lf_custom, lf_y0[3], lf_y1[3];
     int flush_flags;
     int64_t serial;         // frame_serial after the frame
+    uint32_t launch_id;     // what its fused launch writes behind the fault flag (0: the frame took the two passes)
   } redo;
   int redo_owned;       // set by the callers whose descriptors point into the state's own buffers, around their thip_decode_frames call
   uint8_t *d_edge;      // device, k_recon_lf: kTfRec bytes per tile (the tiles' edges for their neighbours)
@@ -286,6 +289,9 @@ int g_next_lane[kMaxDevices];
 constexpr int kCtxLanes = 16;
 hipStream_t g_ctx_lanes[kMaxDevices][kCtxLanes];
 int g_ctx_ready[kMaxDevices], g_next_ctx[kMaxDevices];
+// thip_synchronize waits for the streams that got work since it last did: ten hipStreamSynchronize calls on idle streams are
+// tens of microseconds of host time, which a caller that brackets 0.8 ms of work with it (bench.py's blocks) would book as GPU time.
+std::atomic<uint8_t> g_lane_dirty[kMaxDevices][kMaxLanes], g_ctx_dirty[kMaxDevices][kCtxLanes];
 
 // Makes `device` current for the calling host thread for the lifetime of the object (HIP's current
 // device is per thread) and puts the previous one back: a state may live on any GPU of the node
@@ -363,6 +369,7 @@ struct ScopedTimer {
 int context_stream(thip_state *st, hipStream_t *out) {
   if (st->ctx_stream_cached) {   // (a context keeps its stream: no locks on the per-frame path)
     *out = st->ctx_stream_cached;
+    if (st->ctx_lane >= 0) g_ctx_dirty[st->device][st->ctx_lane].store(1, std::memory_order_relaxed);
     return THIP_OK;
   }
   static const int nctx = [] {   // (streams are created once: read at first use)
@@ -375,6 +382,7 @@ int context_stream(thip_state *st, hipStream_t *out) {
   if (nctx == 0) {
     if (st->lane < 0) st->lane = g_next_lane[st->device]++ % g_nlanes;
     *out = g_lanes[st->device][st->lane];
+    g_lane_dirty[st->device][st->lane].store(1, std::memory_order_relaxed);
     return THIP_OK;
   }
   if (!g_ctx_ready[st->device]) {
@@ -384,6 +392,7 @@ int context_stream(thip_state *st, hipStream_t *out) {
   if (st->ctx_lane < 0) st->ctx_lane = g_next_ctx[st->device]++ % nctx;
   *out = g_ctx_lanes[st->device][st->ctx_lane];
   st->ctx_stream_cached = *out;
+  g_ctx_dirty[st->device][st->ctx_lane].store(1, std::memory_order_relaxed);
   return THIP_OK;
 }
 
@@ -412,9 +421,17 @@ int order_behind_previous(thip_state *st, hipStream_t s) {
 int followup_stream(thip_state *st, hipStream_t *out);
 
 // ... and behind a frame's launch on `s`: a caller-owned stream gets its event now (a library stream lives as long as the library).
+static void mark_dirty(int device, hipStream_t s) {   // (thip_synchronize waits for the library streams that got work)
+  if (!s || device < 0 || device >= kMaxDevices) return;
+  for (int i = 0; i < kMaxLanes; i++)
+    if (g_lanes[device][i] == s) g_lane_dirty[device][i].store(1, std::memory_order_relaxed);
+  for (int i = 0; i < kCtxLanes; i++)
+    if (g_ctx_lanes[device][i] == s) g_ctx_dirty[device][i].store(1, std::memory_order_relaxed);
+}
 int order_mark(thip_state *st, hipStream_t s) {
   st->last_stream = s;
   st->order_recorded = 0;
+  mark_dirty(st->device, s);
   if (!is_library_stream(st->device, s)) {
     if (!st->ev_order) HIP_TRY(hipEventCreateWithFlags(&st->ev_order, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(st->ev_order, s));
@@ -426,6 +443,7 @@ int order_mark(thip_state *st, hipStream_t s) {
 int followup_stream(thip_state *st, hipStream_t *out) {
   if (st->last_stream && is_library_stream(st->device, st->last_stream)) {
     *out = st->last_stream;
+    mark_dirty(st->device, st->last_stream);
     return THIP_OK;
   }
   hipStream_t s;
@@ -610,7 +628,7 @@ int thip_state_create_on(thip_state **out, int device, int frame_width, int fram
   if (err == hipSuccess) err = hipMalloc((void **)&st->coded_map, 2 * (size_t)st->nfrags);
   if (err == hipSuccess) err = hipMemset(st->coded_map, 0, 2 * (size_t)st->nfrags);
   if (err == hipSuccess) err = hipHostMalloc((void **)&st->fault, 64, hipHostMallocMapped);
-  if (err == hipSuccess) *st->fault = 0;
+  if (err == hipSuccess) memset(st->fault, 0, 64);
   if (err != hipSuccess) {
     fprintf(stderr, "theora_hip: thip_state_create: device allocation failed: %s\n", hipGetErrorString(err));
     thip_state_free(st);
@@ -913,20 +931,21 @@ int thip_synchronize(void) {
   for (int d = 0; d < kMaxDevices; d++) {
     if (!g_lanes_ready[d] && !g_ctx_ready[d]) continue;
     DeviceGuard dg(d);
-    for (int i = 0; i < g_nlanes && g_lanes_ready[d]; i++) HIP_TRY(hipStreamSynchronize(g_lanes[d][i]));
+    for (int i = 0; i < g_nlanes && g_lanes_ready[d]; i++)
+      if (g_lane_dirty[d][i].exchange(0, std::memory_order_relaxed)) HIP_TRY(hipStreamSynchronize(g_lanes[d][i]));
     for (int i = 0; i < kCtxLanes; i++)
-      if (g_ctx_ready[d] && g_ctx_lanes[d][i]) HIP_TRY(hipStreamSynchronize(g_ctx_lanes[d][i]));
+      if (g_ctx_ready[d] && g_ctx_lanes[d][i] && g_ctx_dirty[d][i].exchange(0, std::memory_order_relaxed)) HIP_TRY(hipStreamSynchronize(g_ctx_lanes[d][i]));
   }
-  // every state's fault word, whichever stream its frames went down (a caller-owned stream is the caller's to synchronise)
-  std::vector<thip_state *> all;
+  // Every state's fault words, whichever stream its frames went down (a caller-owned stream is the caller's to synchronise).  This
+  // call only REPORTS: a state belongs to one thread at a time (include/theora_hip.h) and this may not be that thread, so the
+  // words stay set and the state's own next synchronising call (thip_state_ycbcr_map / _out, thip_state_read_plane) decodes the
+  // frame again or returns THIP_EFAULT itself.  The list is read under the lock thip_state_free takes before a state goes away.
   {
     std::lock_guard<std::mutex> lk(g_states_mu);
-    all = g_states;
-  }
-  for (thip_state *st : all) {
-    if (!st->fault || !*(volatile uint32_t *)st->fault) continue;
-    DeviceGuard dg(st->device);
-    if (check_fault(st) < 0) rc = THIP_EFAULT;
+    for (thip_state *st : g_states) {
+      volatile uint32_t *const fw = st->fault;
+      if (fw && (fw[0] | fw[9])) rc = THIP_EFAULT;
+    }
   }
   return rc;
 }
@@ -1029,7 +1048,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     }
     if (results) results[i] = THIP_OK;
     st->redo.valid = 0;
-    if (st->redo_owned) {   // (the descriptor points into the state's own buffers: the frame can be decoded again, recover_fault)
+    if (st->redo_owned || THIP_OPT("redo_descs")) {   // (the descriptor points into the state's own buffers, or into buffers the caller keeps still: the frame can be decoded again, check_fault)
       st->redo.d = d;
       for (int k = 0; k < 3; k++) st->redo.ring[k] = st->ref_idx[k];
       st->redo.lf_custom = st->lf_rows_custom;
@@ -1039,6 +1058,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       }
       st->redo.flush_flags = st->flush_flags;
       st->redo.serial = st->frame_serial + 1;
+      st->redo.launch_id = 0;
       st->redo.valid = 1;
     }
     int bufi = 0;  // decode.c:2790-2794
@@ -1173,6 +1193,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
         K.edge = st->d_edge_sb;
         st->edge_epoch_sb = st->edge_epoch_sb % 4095u + 1u;
         K.epoch = st->edge_epoch_sb;
+        st->redo.launch_id = K.epoch | 0x1000u;
         continue;
       }
       if (!st->d_edge) {
@@ -1182,6 +1203,7 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
       K.edge = st->d_edge;
       st->edge_epoch = st->edge_epoch % 4095u + 1u;   // 12 bits in a record's flag word, never 0
       K.epoch = st->edge_epoch;
+      st->redo.launch_id = K.epoch;
     }
     ScopedTimer t(s, THIP_KERNEL_RECON);
     if (small) {
@@ -1221,13 +1243,23 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
 
 static int check_fault(thip_state *st) {
   if (!st->fault) return THIP_OK;
-  const uint32_t w = *(volatile uint32_t *)st->fault;
-  if (!w) return THIP_OK;
+  volatile uint32_t *const fw = st->fault;
+  if (!(fw[0] | fw[9])) return THIP_OK;
   // everything queued for this state has to be over before the frame is launched again
   if (st->last_stream && is_library_stream(st->device, st->last_stream)) HIP_TRY(hipStreamSynchronize(st->last_stream));
   else HIP_TRY(hipDeviceSynchronize());
-  *(volatile uint32_t *)st->fault = 0;
-  if ((w & 1u) && !(w & 2u) && st->redo.valid && st->redo.serial == st->frame_serial) {
+  const uint32_t w = fw[0] | fw[9];
+  // Which launches reported a failed wait (tf_fetch_unit).  The frame that can be repeated is the state's most recent one; if an
+  // EARLIER launch failed as well -- the caller decoded on without a synchronising call in between -- repeating the last frame
+  // would put a right picture on top of a wrong reference and call it recovered.
+  bool only_last = st->redo.valid && st->redo.launch_id != 0;
+  for (int k = 1; k <= 8; k++) {
+    if (fw[k] && fw[k] != st->redo.launch_id) only_last = false;
+    fw[k] = 0;
+  }
+  fw[0] = 0;
+  fw[9] = 0;
+  if ((w & 1u) && !(w & 2u) && only_last && st->redo.serial == st->frame_serial) {
     fprintf(stderr, "theora_hip: a bounded wait of k_recon_lf for a neighbouring tile ran out (device %d); decoding the frame again with "
                     "the two passes\n", st->device);
     const thip_frame_desc d = st->redo.d;
@@ -1251,12 +1283,12 @@ static int check_fault(thip_state *st) {
     st->flush_flags = 0;
     if (rc < 0) return rc;
     HIP_TRY(hipStreamSynchronize(s));
-    if (!*(volatile uint32_t *)st->fault) {
+    if (!(fw[0] | fw[9])) {
       static Option *const counter = find_option("faults_recovered");
       if (counter) counter->value.fetch_add(1, std::memory_order_relaxed);
       return 1;
     }
-    *(volatile uint32_t *)st->fault = 0;
+    for (int k = 0; k <= 9; k++) fw[k] = 0;
   }
   fprintf(stderr, "theora_hip: a kernel's bounded wait ran out on device %d (%s) and the frame could not be decoded again: the frames "
                   "of this state since its last synchronisation are not to be trusted (option fuse = 0 takes the two-pass path)\n",
@@ -1345,6 +1377,7 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
           n++;
         }
         if (n == chunk_max || (i == nstreams && n > 0)) {
+          g_lane_dirty[dev][lane].store(1, std::memory_order_relaxed);
           rc = launch_chunk(ls, ld, n, g_lanes[dev][lane], lr);
           if (rc < 0) return rc;
           if (results)

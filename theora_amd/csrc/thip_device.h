@@ -254,6 +254,65 @@ __device__ __forceinline__ void pk_idct8(pk16 &x0, pk16 &x1, pk16 &x2, pk16 &x3,
   x7 = t0 - t7;
 }
 
+// The column pass straight off the row pass's registers, without the 2x2 transposes between them.  The row pass leaves
+// A[j] = { r[2j][c], r[2j+1][c] } and B[j] = the same for column c'; the column pass wants x_r = { r[r][c], r[r][c'] }.  Its
+// multiplications read ONE 16-bit half each (v_mul_i32_i24 with an SDWA word select), so they can take r[r][c] from wherever it
+// lies -- half r & 1 of A[r >> 1] -- and the SDWA additions behind them write each product pair's sum into the half of the
+// result it belongs to; only x0 +- x4 need a packed addition first, done per column on { r[0], r[1] } +- { r[4], r[5] } (the upper
+// halves compute something nobody reads; THIP_COLS_ADD4) or two of the old transposes (the default: fewer registers in flight).  24 v_perm_b32 fewer per block; the same values in the same
+// 16-bit arithmetic as pk_idct8 (lib/idct.c:30-81 on both halves).
+#ifndef THIP_NO_SDWA_ROT
+template <bool ADD>
+__device__ __forceinline__ pk16 q16_rot4(int ca, int a0, int a1, int cb, int b0, int b1) {
+  const int pla = ca * a0, pha = ca * a1, plb = cb * b0, phb = cb * b1;
+  uint32_t t;
+  if (ADD) {
+    asm("v_add_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(pla), "v"(plb));
+    asm("v_add_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t) : "v"(pha), "v"(phb));
+  } else {
+    asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(pla), "v"(plb));
+    asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t) : "v"(pha), "v"(phb));
+  }
+  return as_pk(t);
+}
+__device__ __forceinline__ pk16 q16_pair(int c, int a0, int a1) {
+  return as_pk(__builtin_amdgcn_perm((uint32_t)(c * a1), (uint32_t)(c * a0), 0x07060302u));
+}
+__device__ __forceinline__ void pk_idct8_cols(const pk16 A[4], const pk16 B[4], pk16 &x0, pk16 &x1, pk16 &x2, pk16 &x3, pk16 &x4,
+                                              pk16 &x5, pk16 &x6, pk16 &x7) {
+#ifdef THIP_COLS_ADD4
+  const pk16 sa = A[0] + A[2], sb = B[0] + B[2], da = A[0] - A[2], db = B[0] - B[2];   // .x: x0 +- x4 of column c / c'
+  pk16 t0 = q16_pair(kC4, (int)sa.x, (int)sb.x);
+  pk16 t1 = q16_pair(kC4, (int)da.x, (int)db.x);
+#else
+  const pk16 q0 = as_pk(__builtin_amdgcn_perm(as_u32(B[0]), as_u32(A[0]), 0x05040100u)), q4 = as_pk(__builtin_amdgcn_perm(as_u32(B[2]), as_u32(A[2]), 0x05040100u));
+  pk16 t0 = pk_q16(kC4, q0 + q4);
+  pk16 t1 = pk_q16(kC4, q0 - q4);
+#endif
+  pk16 t2 = q16_rot4<false>(kC6, (int)A[1].x, (int)B[1].x, kC2, (int)A[3].x, (int)B[3].x);   // x2, x6
+  pk16 t3 = q16_rot4<true>(kC2, (int)A[1].x, (int)B[1].x, kC6, (int)A[3].x, (int)B[3].x);
+  pk16 t4 = q16_rot4<false>(kC7, (int)A[0].y, (int)B[0].y, kC1, (int)A[3].y, (int)B[3].y);   // x1, x7
+  pk16 t5 = q16_rot4<false>(kC3, (int)A[2].y, (int)B[2].y, kC5, (int)A[1].y, (int)B[1].y);   // x5, x3
+  pk16 t6 = q16_rot4<true>(kC5, (int)A[2].y, (int)B[2].y, kC3, (int)A[1].y, (int)B[1].y);
+  pk16 t7 = q16_rot4<true>(kC1, (int)A[0].y, (int)B[0].y, kC7, (int)A[3].y, (int)B[3].y);
+  pk16 r;
+  r = t4 + t5; t5 = pk_q16(kC4, t4 - t5); t4 = r;
+  r = t7 + t6; t6 = pk_q16(kC4, t7 - t6); t7 = r;
+  r = t0 + t3; t3 = t0 - t3; t0 = r;
+  r = t1 + t2; t2 = t1 - t2; t1 = r;
+  r = t6 + t5; t5 = t6 - t5; t6 = r;
+  x0 = t0 + t7;
+  x1 = t1 + t6;
+  x2 = t2 + t5;
+  x3 = t3 + t4;
+  x4 = t3 - t4;
+  x5 = t2 - t5;
+  x6 = t1 - t6;
+  x7 = t0 - t7;
+}
+#define THIP_HAVE_IDCT8_COLS 1
+#endif
+
 // Same transform when inputs 4..7 are zero (lib/idct.c:92-130 on both halves).
 __device__ __forceinline__ void pk_idct8_first4(pk16 &x0, pk16 &x1, pk16 &x2, pk16 &x3, pk16 &x4,
                                                 pk16 &x5, pk16 &x6, pk16 &x7) {
@@ -360,8 +419,24 @@ __device__ __forceinline__ void pk_idct8x8(const uint32_t P[32], uint32_t Y[32],
     pk_idct8(R[16], R[17], R[18], R[19], R[20], R[21], R[22], R[23]);
     pk_idct8(R[24], R[25], R[26], R[27], R[28], R[29], R[30], R[31]);
   }
-  // 2x2 transposes: row pairs -> column pairs.  Q[r*4+k] = {R[r][2k], R[r][2k+1]}
   pk16 Q[32];
+#if defined(THIP_HAVE_IDCT8_COLS) && !defined(THIP_NO_FUSED_TRANSPOSE)
+  if (!rows4) {   // (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const pk16 A[4] = {R[0 * 8 + 2 * k], R[1 * 8 + 2 * k], R[2 * 8 + 2 * k], R[3 * 8 + 2 * k]};
+      const pk16 B[4] = {R[0 * 8 + 2 * k + 1], R[1 * 8 + 2 * k + 1], R[2 * 8 + 2 * k + 1], R[3 * 8 + 2 * k + 1]};
+      pk_idct8_cols(A, B, Q[0 * 4 + k], Q[1 * 4 + k], Q[2 * 4 + k], Q[3 * 4 + k], Q[4 * 4 + k], Q[5 * 4 + k], Q[6 * 4 + k], Q[7 * 4 + k]);
+#ifdef THIP_COLS_FENCE
+      __builtin_amdgcn_sched_barrier(0);   // one column pair after the other: interleaved they need registers the wave does not have
+#endif
+    }
+#pragma unroll
+    for (int i = 0; i < 32; i++) Y[i] = as_u32(pk_descale(Q[i]));
+    return;
+  }
+#endif
+  // 2x2 transposes: row pairs -> column pairs.  Q[r*4+k] = {R[r][2k], R[r][2k+1]}
 #pragma unroll
   for (int j = 0; j < 4; j++)
 #pragma unroll

@@ -134,7 +134,7 @@ __device__ __forceinline__ void tf_publish_units(const uint8_t *lds, uint8_t *re
 // The consumer's side: every lane with a source loads its unit and looks again until its tag carries the launch's serial
 // number (bounded: see tf header; `fault` is the state's pinned host word: the host notices it at its next synchronising call
 // and decodes the frame again with the two passes, thip_decode.hip: recover_fault).  Returns the unit.
-__device__ __forceinline__ uint4 tf_fetch_unit(const uint8_t *src, uint32_t ep, uint32_t *fault, int max_spins) {
+__device__ __forceinline__ uint4 tf_fetch_unit(const uint8_t *src, uint32_t ep, uint32_t *fault, int max_spins, uint32_t fault_id) {
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
   bool ok = src == nullptr;
   for (int spins = 0; spins < max_spins; spins++) {
@@ -145,7 +145,13 @@ __device__ __forceinline__ uint4 tf_fetch_unit(const uint8_t *src, uint32_t ep, 
     if (__all(ok)) break;
     __builtin_amdgcn_s_sleep(1);
   }
-  if (!ok && fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // WHICH launch it was goes into one of eight words behind the flag (fault_id = the launch's serial number, 0x1000 added by
+  // k_recon_lf_sb, whose buffer counts on its own): the host decodes a frame again only if every launch that reports a failed
+  // wait is the frame it can still repeat -- a frame launched on top of a failed one is not made right by repeating it.
+  if (!ok && fault) {
+    __hip_atomic_store(fault + 1 + (fault_id & 7u), fault_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   return v;
 }
 
@@ -222,6 +228,71 @@ __device__ __forceinline__ void tf_cell(const uint8_t *lds, uint8_t *plane, int 
   }
 }
 
+// The same cell when the whole wave knows the answer to every question tf_cell asks (k_recon_lf decides, wave-uniformly): the tile
+// touches no border of its plane and no band boundary above it, every block of the tile and of the neighbours' edges is coded, the
+// filter is on and the whole tile lies inside the fragment-row range.  Then every cell applies T3, T5, T7, T8 of lf_cell_ops'
+// list -- the vertical edge of its upper half, the horizontal edge's left half, the vertical edge of its lower half, the horizontal
+// edge's right half, in that order (state.c:1083-1104 with all four blocks coded) -- and stores both halves of its rows: no flag
+// bytes, no per-lane operation word, no exec masks but the two that follow from the cell row (m = 0: rows 2..7; m = 3: rows 8, 9 too).
+template <class G>
+__device__ __forceinline__ void tf_cell_all_coded(const uint8_t *lds, uint8_t *plane, int stride, int t, int sby, int kx, int m, int L2) {
+  constexpr int kTfPitch = G::kPitch, kTfX0 = G::kX0;
+  const int k = G::kBW * t + kx, mm = 4 * sby + m;
+  CellPix C;
+  const uint8_t *img = lds + (8 * m) * kTfPitch + kTfX0 + 8 * kx - 4;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(img + r * kTfPitch);
+    C.lo[r] = q[0];
+    C.hi[r] = q[1];
+  }
+  uint32_t xlo[2], xhi[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(img + (8 + r) * kTfPitch);
+    xlo[r] = q[0];
+    xhi[r] = q[1];
+  }
+  lf_vert_pk(C, 0, L2);
+  lf_horz_pk(C, 0, L2);
+  lf_vert_pk(C, 4, L2);
+  lf_horz_pk(C, 1, L2);
+  lf_vert_pair(xlo[0], xlo[1], xhi[0], xhi[1], L2);   // (rows 28, 29 of the tile: stored by cell row 3 only)
+  uint8_t *base = plane + (ptrdiff_t)(8 * mm - 4) * stride + (8 * k - 4);
+  if (m != 0) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      Pix8 o;
+      o.x = C.lo[r];
+      o.y = C.hi[r];
+      *reinterpret_cast<Pix8 *>(base + (ptrdiff_t)r * stride) = o;
+    }
+  }
+#pragma unroll
+  for (int r = 2; r < 8; r++) {
+    Pix8 o;
+    o.x = C.lo[r];
+    o.y = C.hi[r];
+    *reinterpret_cast<Pix8 *>(base + (ptrdiff_t)r * stride) = o;
+  }
+  if (m == 3) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      Pix8 o;
+      o.x = xlo[r];
+      o.y = xhi[r];
+      *reinterpret_cast<Pix8 *>(base + (ptrdiff_t)(8 + r) * stride) = o;
+    }
+  }
+}
+
+// Experiment hooks: the wave's issue priority by phase (0 start, 1 loads out, 2 pixels done, 3 cells).  THIP_PRIO_SEQ is four digits,
+// e.g. 0x3003: priority 3 until the loads are out, 0 through the transforms and the hand-over, 3 for the cells.  Not defined: nothing.
+#ifdef THIP_PRIO_SEQ
+#define THIP_PRIO_AT(i) __builtin_amdgcn_s_setprio((THIP_PRIO_SEQ >> (12 - 4 * (i))) & 3)
+#else
+#define THIP_PRIO_AT(i) do { } while (0)
+#endif
 #ifndef THIP_TF_WAVES_PER_EU
 #define THIP_TF_WAVES_PER_EU 5    // 96 VGPRs; with 8 KB of LDS per wave that is 20 waves per CU
 #endif
@@ -266,6 +337,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   }
 #endif
   THIP_TR(tr, 0);
+  THIP_PRIO_AT(0);
   const int pli = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
   constexpr bool levels = LEVELS;   // (one kernel per coefficient form: each is straight-line code for its own)
   if (levels) tables_to_lds(dq_p, pli, lane, s_tf);   // (first: whoever has its command word has the tables)
@@ -307,6 +379,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   L.has_coeff = L.coded && !L.dc_only;
   L.x0 = bx * 8;
   L.y0 = by * 8;
+  const bool own_all_coded = __all(valid && L.coded);   // (cells' fast path, step 5)
   ReconPlane R;
   R.self = self + G.off;
   R.prev = prev + G.off;
@@ -335,20 +408,24 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   uint32_t Y[32];
   if (nown == 0) {
     if (valid) recon_issue(R, L, Q, inter, ref);
+    THIP_PRIO_AT(1);
   } else if (nown <= 16) {
     int4 Wc[1][2];
     residual_shared_load<4>(coeffs_p, F, nown, lane, Wc);
     if (valid) recon_issue(R, L, Q, inter, ref);
+    THIP_PRIO_AT(1);
     residual_shared<4>(Wc, F, lds_dw, meta, lane, L, prefix, Y);
   } else if (nown <= 32) {
     int4 Wc[2][2];
     residual_shared_load<2>(coeffs_p, F, nown, lane, Wc);
     if (valid) recon_issue(R, L, Q, inter, ref);
+    THIP_PRIO_AT(1);
     residual_shared<2, true>(Wc, F, lds_dw, meta, lane, L, prefix, Y);
   } else {
     int4 w7;
     dense_issue<7>(coeffs_p, F, L.has_coeff, prefix, s_tf, w7);
     if (valid) recon_issue(R, L, Q, inter, ref);
+    THIP_PRIO_AT(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)
     dense_finish<7>(coeffs_p, F, L.has_coeff, prefix, s_tf, lane, L, w7, Y);
   }
@@ -361,12 +438,13 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   THIP_TR(tr, 11);  // residual there (coefficients had arrived, transform done); the predictor windows may still be on their way
 #endif
   uint2 rows[8];
-  recon_rows(R, Q, inter, Y, rows);
+  recon_rows(R, Q, inter, Y, rows, L.coded ? L.flags : 0u, L.x0);
 #ifdef THIP_TRACE
   asm volatile("" : "+v"(rows[0].x), "+v"(rows[7].y));
   THIP_TR(tr, 2);   // pixels done (coefficients and predictor windows had arrived)
 #endif
 
+  THIP_PRIO_AT(2);
   // ---- 3. the tile image into LDS, its edges out as units ---------------------------------------------------------
   uint8_t *const myrec = edge_p + (size_t)u * kTfRec;
   const uint8_t *const rec_up = myrec - (ptrdiff_t)tiles_x * kTfRec, *const rec_left = myrec - kTfRec;
@@ -393,6 +471,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     THIP_TR(tr, 4);
   }
 
+  bool nb_all_coded = false;   // every block on the upper, left and upper-left neighbours' edges is coded (their tags)
   // ---- 4. the neighbours' edges into the image margins: lanes 0..21 the upper tile's rows 30, 31, 22..32 the left tile's
   //         columns 124..127, 33 the upper-left tile's corner (dwords 30, 31 of its column: unit 10) ------------------------
   {
@@ -404,7 +483,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     } else if (lane == kTfBotUnits + kTfRightUnits) {
       if (need_ul) src = rec_ul + kTfRight + 10 * kTfUnit;
     }
-    const uint4 un = tf_fetch_unit(src, ep, fault_p, max_spins);
+    const uint4 un = tf_fetch_unit(src, ep, fault_p, max_spins, ep);
     THIP_TR(tr, 5);   // the neighbours' units are there
     const uint32_t d[3] = {un.x, un.y, un.z};
     if (lane < kTfBotUnits) {
@@ -428,6 +507,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     const uint32_t w_up = (uint32_t)__builtin_amdgcn_readlane((int)un.w, 0);
     const uint32_t w_left = (uint32_t)__builtin_amdgcn_readlane((int)un.w, kTfBotUnits);
     const uint32_t w_ul = (uint32_t)__builtin_amdgcn_readlane((int)un.w, kTfBotUnits + kTfRightUnits);
+    nb_all_coded = (w_up & 0xFFFFu) == 0xFFFFu && (w_left & 0xF0000u) == 0xF0000u && (w_ul & 0x80000u) != 0;
     if (lane < 16)
       lds[kTfFlagOff + lane + 1] = (uint8_t)((w_up >> lane) & 1u);
     else if (lane < 20)
@@ -438,6 +518,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     THIP_TR(tr, 6);   // ... and in the margins
   }
 
+  THIP_PRIO_AT(3);
   // ---- 5. the cells: lane (kx, m) on corner (16t + kx, 4 sby + m) ---------------------------------------------
   // (cell row 0 below a tile of this band: rows 2..7, the two above them are the upper tile's; below another band's tile: only
   //  the lower half's vertical edge, rows 6 and 7 -- the upper tile closes the rest as its 17th..20th pixel rows, see 6.)
@@ -445,7 +526,15 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
   const uint32_t top_mask = xb_up ? 96u : 0xFFu;
   {
     const int m = lane >> 4;
-    tf_cell<Tf16>(lds, R.self, R.stride, nh, nv, t, sby, lane & 15, m, true, L2, fy0, fy1, m == 0 ? top_lo : 0, 8, m == 0 ? top_mask : 0xFFu, m == 3);
+#ifndef THIP_NO_CELL_FAST
+    // (wave-uniform, scalar: see tf_cell_all_coded)
+    const bool plain = own_all_coded && nb_all_coded && L2 != 0 && has_left && !row_end && up_in && 4 * sby + 3 <= nv - 1 &&
+                       fy0 <= 4 * sby - 1 && fy1 >= 4 * sby + 4;
+    if (plain)
+      tf_cell_all_coded<Tf16>(lds, R.self, R.stride, t, sby, lane & 15, m, L2);
+    else
+#endif
+      tf_cell<Tf16>(lds, R.self, R.stride, nh, nv, t, sby, lane & 15, m, true, L2, fy0, fy1, m == 0 ? top_lo : 0, 8, m == 0 ? top_mask : 0xFFu, m == 3);
   }
   THIP_TR(tr, 7);   // cells filtered, stores issued
 
@@ -461,7 +550,7 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
       const uint8_t *src = nullptr;
       if (lane < kTfBotUnits) src = rec_dn + kTfTop + lane * kTfUnit;
       else if (lane == kTfBotUnits && has_left) src = rec_dl + kTfRight;
-      const uint4 un = tf_fetch_unit(src, ep, fault_p, max_spins);
+      const uint4 un = tf_fetch_unit(src, ep, fault_p, max_spins, ep);
       const uint32_t d[3] = {un.x, un.y, un.z};
       if (lane < kTfBotUnits) {
 #pragma unroll

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_recon_lf_sb(const BatchK B) {
     } else if (lane == kB + kR) {
       if (need_ul) usrc = rec_ul + Tf4::kRight + 10 * kTfUnit;
     }
-    const uint4 un = tf_fetch_unit(usrc, ep, fault_p, max_spins);
+    const uint4 un = tf_fetch_unit(usrc, ep, fault_p, max_spins, ep | 0x1000u);
     THIP_TR(tr, 5);
     const uint32_t d[3] = {un.x, un.y, un.z};
     if (lane < kB) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_recon_lf_sb(const BatchK B) {
       const uint8_t *s2 = nullptr;
       if (lane < kB) s2 = rec_dn + Tf4::kTop + lane * kTfUnit;
       else if (lane == kB && has_left) s2 = rec_dl + Tf4::kRight;
-      const uint4 u2 = tf_fetch_unit(s2, ep, fault_p, max_spins);
+      const uint4 u2 = tf_fetch_unit(s2, ep, fault_p, max_spins, ep | 0x1000u);
       const uint32_t e[3] = {u2.x, u2.y, u2.z};
       if (lane < kB) {
 #pragma unroll

@@ -344,7 +344,25 @@ __device__ __forceinline__ uint32_t pred_pick(const Row12 &w, uint32_t sel, bool
   return __builtin_amdgcn_perm(k ? w.c : w.b, k ? w.b : w.a, sel);
 }
 
-__device__ __forceinline__ void pred_finish(const PredWin &Q, int W, uint2 pred[8]) {
+// (What pred_issue worked out of the command word is worked out again here -- a dozen instructions -- instead of
+//  being carried in three registers through the inverse transform, which has none to spare.)
+__device__ __forceinline__ void pred_finish(const PredWin &Qin, int W, uint2 pred[8], uint32_t flags, int x0, bool qpx, bool qpy) {
+#ifndef THIP_NO_PRED_REMAT
+  PredWin Q;
+  {
+    asm volatile("" : "+v"(flags), "+v"(x0));
+    const int dx = (int)(int8_t)(flags >> THIP_INFO_MVX_SHIFT), dy = (int)(int8_t)(flags >> THIP_INFO_MVY_SHIFT);
+    int mx, my;
+    mv_axis(dx, qpx, mx, Q.mx2);
+    mv_axis(dy, qpy, my, Q.my2);
+    Q.sx = x0 + mx;
+    Q.border = Qin.border;
+#pragma unroll
+    for (int r = 0; r < 9; r++) Q.w[r] = Qin.w[r];
+  }
+#else
+  const PredWin &Q = Qin;
+#endif
   const int xw = pred_xw(Q.sx + min(Q.mx2, 0), W);
   const bool ra = Q.my2 < 0, rb = Q.my2 > 0;   // that sample starts one source row down
   const bool two = (Q.mx2 | Q.my2) != 0;
@@ -475,6 +493,24 @@ __device__ __forceinline__ void unpack_levels(uint32_t w, uint32_t &even, uint32
   odd = as_u32(v >> 8);            // bytes 1 and 3, sign-extended (v_pk_ashrrev_i16)
   even = as_u32((v << 8) >> 8);    // bytes 0 and 2
 }
+// Unpacking and multiplying in one go: `(ogg_int16_t)(level * ac_quant)` for the four int8 levels of a dword, the byte picked and
+// sign-extended by the multiplier's SDWA source select, each product written to its half of the result: four operations where
+// unpack_levels + two packed multiplies take five.
+#ifndef THIP_NO_SDWA_DEQ
+__device__ __forceinline__ void dequant_levels(uint32_t w, uint32_t t_even, uint32_t t_odd, uint32_t &even, uint32_t &odd) {
+  asm("v_mul_lo_u16_sdwa %0, sext(%1), %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:WORD_0" : "=v"(even) : "v"(w), "v"(t_even));
+  asm("v_mul_lo_u16_sdwa %0, sext(%1), %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:WORD_1" : "+v"(even) : "v"(w), "v"(t_even));
+  asm("v_mul_lo_u16_sdwa %0, sext(%1), %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:WORD_0" : "=v"(odd) : "v"(w), "v"(t_odd));
+  asm("v_mul_lo_u16_sdwa %0, sext(%1), %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:WORD_1" : "+v"(odd) : "v"(w), "v"(t_odd));
+}
+#else
+__device__ __forceinline__ void dequant_levels(uint32_t w, uint32_t t_even, uint32_t t_odd, uint32_t &even, uint32_t &odd) {
+  uint32_t e, o;
+  unpack_levels(w, e, o);
+  even = as_u32(as_pk(e) * as_pk(t_even));
+  odd = as_u32(as_pk(o) * as_pk(t_odd));
+}
+#endif
 __device__ __forceinline__ uint32_t pk_mul_lo(uint32_t a, uint32_t b) { return as_u32(as_pk(a) * as_pk(b)); }   // low 16 bits of each product: the (ogg_int16_t) cast
 // the dequantisation table of a block inside its plane's six: qii * 2 + qti (decode.c:1537-1538)
 __device__ __forceinline__ uint32_t table_of(uint32_t flags) {
@@ -502,11 +538,11 @@ __device__ __forceinline__ void recon_issue(const ReconPlane &R, const ReconLane
 // The eight reconstructed rows of this lane's block: predictor (fragment.c:49-80: 128, one block, or the
 // average of two) + residual, clamped.
 __device__ __forceinline__ void recon_rows(const ReconPlane &R, const PredWin &Q, bool inter, const uint32_t Y[32],
-                                           uint2 rows[8]) {
+                                           uint2 rows[8], uint32_t Lflags, int Lx0) {
   uint2 pred[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) pred[r] = make_uint2(0x80808080u, 0x80808080u);
-  if (inter) pred_finish(Q, R.nh * 8, pred);
+  if (inter) pred_finish(Q, R.nh * 8, pred, Lflags, Lx0, R.qpx, R.qpy);
 #pragma unroll
   for (int r = 0; r < 8; r++)
     rows[r] = pk_recon_row(as_pk(Y[r * 4 + 0]), as_pk(Y[r * 4 + 1]), as_pk(Y[r * 4 + 2]), as_pk(Y[r * 4 + 3]), pred[r]);
@@ -516,7 +552,7 @@ __device__ __forceinline__ void recon_finish(const ReconPlane &R, const ReconLan
                                              const uint32_t Y[32]) {
   uint8_t *dst = R.self + (ptrdiff_t)L.y0 * R.stride + L.x0;
   uint2 rows[8];
-  recon_rows(R, Q, inter, Y, rows);
+  recon_rows(R, Q, inter, Y, rows, L.coded ? L.flags : 0u, L.x0);
   if (!(R.debug & 4)) {
 #pragma unroll
     for (int r = 0; r < 8; r++) store_row8(dst + (ptrdiff_t)r * R.stride, rows[r]);
@@ -572,19 +608,10 @@ __device__ __forceinline__ void dense_finish(const int4 *coeffs_p, const CoefFor
     for (int j = 0; j < 4; j++) {
       const uint4 w = lds_coef[j * 64];
       const uint4 t0 = tab[2 * j], t1 = tab[2 * j + 1];
-      uint32_t e, o;
-      unpack_levels(w.x, e, o);
-      P[j * 8 + 0] = pk_mul_lo(e, t0.x);
-      P[j * 8 + 1] = pk_mul_lo(o, t0.y);
-      unpack_levels(w.y, e, o);
-      P[j * 8 + 2] = pk_mul_lo(e, t0.z);
-      P[j * 8 + 3] = pk_mul_lo(o, t0.w);
-      unpack_levels(w.z, e, o);
-      P[j * 8 + 4] = pk_mul_lo(e, t1.x);
-      P[j * 8 + 5] = pk_mul_lo(o, t1.y);
-      unpack_levels(w.w, e, o);
-      P[j * 8 + 6] = pk_mul_lo(e, t1.z);
-      P[j * 8 + 7] = pk_mul_lo(o, t1.w);
+      dequant_levels(w.x, t0.x, t0.y, P[j * 8 + 0], P[j * 8 + 1]);
+      dequant_levels(w.y, t0.z, t0.w, P[j * 8 + 2], P[j * 8 + 3]);
+      dequant_levels(w.z, t1.x, t1.y, P[j * 8 + 4], P[j * 8 + 5]);
+      dequant_levels(w.w, t1.z, t1.w, P[j * 8 + 6], P[j * 8 + 7]);
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -687,14 +714,14 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], const 
     const int4 w0 = W[n][0], w1 = W[n][1];
     uint32_t X[8] = {(uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w,
                      (uint32_t)w1.x, (uint32_t)w1.y, (uint32_t)w1.z, (uint32_t)w1.w};   // {x[2rp][c], x[2rp+1][c]}, c = 0..7
-    if (F.levels) {
-      if (!F.wide) {
-        unpack_levels((uint32_t)w0.x, X[0], X[1]);
-        unpack_levels((uint32_t)w0.y, X[2], X[3]);
-        unpack_levels((uint32_t)w0.z, X[4], X[5]);
-        unpack_levels((uint32_t)w0.w, X[6], X[7]);
-      }
+    if (F.levels && !F.wide) {
       const uint4 t0 = tab[2 * rp], t1 = tab[2 * rp + 1];   // decode.c:1573
+      dequant_levels((uint32_t)w0.x, t0.x, t0.y, X[0], X[1]);
+      dequant_levels((uint32_t)w0.y, t0.z, t0.w, X[2], X[3]);
+      dequant_levels((uint32_t)w0.z, t1.x, t1.y, X[4], X[5]);
+      dequant_levels((uint32_t)w0.w, t1.z, t1.w, X[6], X[7]);
+    } else if (F.levels) {
+      const uint4 t0 = tab[2 * rp], t1 = tab[2 * rp + 1];
       X[0] = pk_mul_lo(X[0], t0.x);
       X[1] = pk_mul_lo(X[1], t0.y);
       X[2] = pk_mul_lo(X[2], t0.z);
@@ -724,21 +751,38 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], const 
     x4[1] = make_uint4(as_u32(Rr[n][4]), as_u32(Rr[n][5]), as_u32(Rr[n][6]), as_u32(Rr[n][7]));
   }
   pk16 Qc[NP][8];
+#if defined(THIP_HAVE_IDCT8_COLS) && !defined(THIP_NO_FUSED_TRANSPOSE)
+  constexpr bool kFusedCols = true;    // the column pass reads the row pass's pairs as they are (pk_idct8_cols)
+#else
+  constexpr bool kFusedCols = false;
+#endif
 #pragma unroll
   for (int n = 0; n < NP; n++) {
     const int cp = j * NP + n;                       // column pair: columns 2cp, 2cp+1
 #pragma unroll
     for (int rp = 0; rp < 4; rp++) {                 // row pair rp lives at slot (g*LPB*NP + rp) = g*4 + rp
       const uint2 ab = *reinterpret_cast<const uint2 *>(xch + (g * 4 + rp) * 8 + 2 * cp);
-      Qc[n][2 * rp] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x05040100u));
-      Qc[n][2 * rp + 1] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x07060302u));
+      if (kFusedCols) {
+        Qc[n][rp] = as_pk(ab.x);                     // { r[2rp][2cp], r[2rp+1][2cp] }
+        Qc[n][4 + rp] = as_pk(ab.y);                 // the same of column 2cp + 1
+      } else {
+        Qc[n][2 * rp] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x05040100u));
+        Qc[n][2 * rp + 1] = as_pk(__builtin_amdgcn_perm(ab.y, ab.x, 0x07060302u));
+      }
     }
   }
   if (COMPACT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all of the exchange is read before results overwrite it
 #pragma unroll
   for (int n = 0; n < NP; n++) {
     const int cp = j * NP + n;
+#if defined(THIP_HAVE_IDCT8_COLS) && !defined(THIP_NO_FUSED_TRANSPOSE)
+    {
+      const pk16 A[4] = {Qc[n][0], Qc[n][1], Qc[n][2], Qc[n][3]}, B[4] = {Qc[n][4], Qc[n][5], Qc[n][6], Qc[n][7]};
+      pk_idct8_cols(A, B, Qc[n][0], Qc[n][1], Qc[n][2], Qc[n][3], Qc[n][4], Qc[n][5], Qc[n][6], Qc[n][7]);
+    }
+#else
     pk_idct8(Qc[n][0], Qc[n][1], Qc[n][2], Qc[n][3], Qc[n][4], Qc[n][5], Qc[n][6], Qc[n][7]);
+#endif
 #pragma unroll
     for (int r = 0; r < 8; r++) res[g * 32 + r * 4 + cp] = as_u32(pk_descale(Qc[n][r]));   // Y[r*4+k] layout of the owner
   }

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * kPpGroup) void k_pp_dering(const PpK K) {
       if (__all(ok)) break;
       __builtin_amdgcn_s_sleep(2);
     }
-    if (!ok && K.fault) __hip_atomic_store(K.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!ok && K.fault) __hip_atomic_store(K.fault + 9, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (a word of its own: thip_decode.hip, check_fault)
   }
   __syncthreads();
   // the region: rows Y0-1 .. Y0+64 clamped into the plane; the 64 pixels as dwords (plane widths are multiples of 8),
