@@ -229,7 +229,7 @@ def e2e_keyed_entry(size="720p", nframes=8, loops=30, ahead=8):
     """The whole th_decode_* chain on the driver's clock, as a keyed entry of the default line: packets in host memory ->
     th_decode_packetin -> th_decode_ycbcr_out -> pictures in host memory, ONE stream, the plain API loop and with the packets
     announced `ahead` packets ahead (TH_DECCTL_THIP_PREFETCH_PACKET: the entropy decoder on the library's parser threads).  The two
-    legs must hand out the same pictures (CRC32 per frame); bit-exactness against the oracle is tests/test_gpu_frontend.py's.
+    legs must hand out the ORACLE's pictures: every frame of a second, untimed pass of each leg over the same packets (CRC32 per frame).
     Never fails the bench: an exception becomes the entry."""
     try:
         import zlib
@@ -239,9 +239,20 @@ def e2e_keyed_entry(size="720p", nframes=8, loops=30, ahead=8):
         content = dict(density=0.7, p_dc_only=0.5, p_empty=0.2)
         st = streamgen.Stream(w, h, 0, seed=99, trees="matched", probe_kwargs=content)
         hdr = st.header_packets()
-        pkts = [st.frame(0 if f % 8 == 0 else 1, **content)[0] for f in range(nframes)]
+        made = [st.frame(0 if f % 8 == 0 else 1, **content) for f in range(nframes)]
+        pkts = [m[0] for m in made]
+        # the oracle's pictures of these packets (packet 0 is a key frame, so every loop over the packets gives the same pictures):
+        # EVERY frame of both legs is compared with them, the look-ahead's changes of sides (option fe_assign = 2) included
+        import oracle
+        ost = oracle.State(w, h, 0)
+        want = []
+        for pkt, truth in made:
+            if not truth["dup"]:
+                assert ost.decode_frame(**st.oracle_inputs(truth, ost)) == 0
+            want.append(zlib.crc32(b"".join(np.ascontiguousarray(ost.get_plane(oracle.FRAME_PREV, pli)[::-1]).tobytes() for pli in range(3))))
+        ost.close()
         seq = pkts * loops
-        res, crcs = {}, {}
+        res, crcs, bad = {}, {}, {}
         for label, la in (("plain_loop", 0), ("lookahead_%d" % ahead, ahead)):
             dec = Decoder(hdr)
             for p in pkts:              # warm-up: device buffers, streams, parser threads
@@ -260,12 +271,29 @@ def e2e_keyed_entry(size="720p", nframes=8, loops=30, ahead=8):
                 if k < len(pkts):
                     c.append(zlib.crc32(b"".join(x.tobytes() for x in planes)))
             dt = time.perf_counter() - t0
-            dec.close()
             res[label] = round(len(seq) / dt, 1)
             crcs[label] = c
+            # ... and once more with the clock off and EVERY frame's checksum taken (half a millisecond a frame in this caller:
+            # inside the clock it would be the figure): the same context goes on, so this pass starts where the look-ahead's
+            # measured rule stands after the timed one
+            nxt, nb = 0, 0
+            for k, p in enumerate(seq):
+                while la and nxt < len(seq) and nxt < k + la:
+                    nxt = max(nxt, k)
+                    if not dec.prefetch(seq[nxt]):
+                        break
+                    nxt += 1
+                dec.packetin(p)
+                planes = dec.ycbcr_out()
+                nb += zlib.crc32(b"".join(x.tobytes() for x in planes)) != want[k % len(pkts)]
+            bad[label] = nb + sum(1 for k, v in enumerate(c) if v != want[k])
+            dec.close()
         same = len(set(tuple(v) for v in crcs.values())) == 1
+        if any(bad.values()):
+            return {"error": "pictures differ from the oracle's: %r frames of %d" % (bad, len(seq))}
         return {"metric": "end-to-end decode frames/sec, one %s 4:2:0 stream (packets in host memory -> pictures in host memory)" % size,
-                "unit": "frames/s", **res, "same_pictures": same, "avg_packet_bytes": sum(map(len, pkts)) // len(pkts),
+                "unit": "frames/s", **res, "same_pictures": same, "frames_equal_to_the_oracle": "all %d of each leg's second, untimed pass (and the first %d of the timed one)" % (len(seq), len(pkts)),
+                "avg_packet_bytes": sum(map(len, pkts)) // len(pkts),
                 "data": "synthetic packets (tests/streamgen.py), dense content, matched Huffman trees",
                 "note": "host-bound (Python caller): the plain loop is one entropy-decode thread per stream; announced packets are "
                         "parsed on up to eight library threads, which also pair tokens and fragments for the device (DESIGN.md 5.1)"}
@@ -293,15 +321,22 @@ def parse_args():
     ap.add_argument("--min-time", type=float, default=0.3, help="keep timing blocks until this many seconds have been measured")
     ap.add_argument("--second-content", default="smooth", help="content class of the second keyed entry ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-late", action="store_true", help="time the CPU baseline behind the GPU's timed region (always so at N > 1)")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-process-per-core leg of the CPU baseline")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-1080p", action="store_true", help="skip the 1080p keyed entries (single stream, four streams)")
+    ap.add_argument("--no-wide", action="store_true", help="skip the keyed entry wide_tiles (the dense batch with 1 %% / 10 %% of the tiles wide)")
+    ap.add_argument("--no-enc", action="store_true", help="skip the keyed entry enc_1080p_444 (BASELINE.json config 5: the encoder's block kernels)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the keyed entry e2e_720p (th_decode_* end to end, one stream, with and without the look-ahead)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-execute under rocprofv3 --pmc for roofline.traffic (N = 1 only)")
     return ap.parse_known_args()
 
 
-def main_enc():
+def main_enc(emit=True, subset=False):
+    """BASELINE.json config 5: the encoder's block kernels on one 1920x1088 4:4:4 frame.  emit: print one JSON line per kernel
+    (--mode enc); else return the entries (the keyed entry enc_1080p_444 of the default line, subset = the kernels VERDICT r04
+    asks for: fDCT, quantiser, both in one pass for one and four frames, the motion-search forms of SAD / SATD incl. the half-pel
+    refinement, the cost maps).  Every kernel's output is compared with the oracle before its time counts."""
     import torch
     import theora_amd
     import oracle
@@ -354,6 +389,7 @@ def main_enc():
     want = oracle.fdct8x8_batch(resid[:ncpu])
     tc = time.perf_counter() - t0
     assert np.array_equal(got[:ncpu], want)
+    tc_fdct = tc
     results.append(dict(kernel="oc_enc_fdct8x8", units=nblk, unit="blocks", seconds=t, bytes_per_unit=256, cpu_rate=ncpu / tc))
     # --- quantiser (enquant.c:219) on the fDCT output ------------------------------------------
     d_dct = theora_amd.fdct8x8_batch(d_res)
@@ -365,6 +401,7 @@ def main_enc():
     wq, wnz = oracle.quantize_batch(got[:ncpu], dq)
     tc = time.perf_counter() - t0
     assert np.array_equal(gq.cpu().numpy().reshape(-1, 64)[:ncpu], wq) and np.array_equal(gnz.cpu().numpy()[:ncpu], wnz)
+    tc_quant = tc
     results.append(dict(kernel="oc_enc_quantize", units=nblk, unit="blocks", seconds=t, bytes_per_unit=260, cpu_rate=ncpu / tc))
     # --- both in one pass (thip_enc_fdct_quantize_batch), one frame and four frames of residuals per call ------------------------
     for F in (1, 4):
@@ -374,9 +411,9 @@ def main_enc():
         fq, fnz = theora_amd.enc_fdct_quantize_batch(d_resF, d_dq)
         assert np.array_equal(fq.cpu().numpy().reshape(-1, 64)[:ncpu], wq) and np.array_equal(fnz.cpu().numpy()[:ncpu], wnz)
         results.append(dict(kernel="oc_enc_fdct8x8 + oc_enc_quantize in one pass (thip_enc_fdct_quantize_batch)%s" % (", %d frames per call" % F if F > 1 else ""),
-                            units=nblk * F, unit="blocks", seconds=t, bytes_per_unit=260, cpu_rate=float("nan")))
+                            units=nblk * F, unit="blocks", seconds=t, bytes_per_unit=260, cpu_rate=ncpu / (tc_fdct + tc_quant)))   # (the oracle's two calls)
     # --- SAD / SATD / SATD2 ---------------------------------------------------------------------
-    for op, bpu in (("sad", 132), ("satd", 136), ("satd2", 136 + 64), ("intra_satd", 72)):
+    for op, bpu in (() if subset else (("sad", 132), ("satd", 136), ("satd2", 136 + 64), ("intra_satd", 72))):
         call = lambda: theora_amd.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)   # noqa: E731
         t = timed(call)
         v, dc = call()
@@ -394,15 +431,20 @@ def main_enc():
         t = timed(call)
         v, dc = call()
         want_v, _ = theora_amd.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)
-        assert torch.equal(v.reshape(-1), want_v)      # candidate-major = the order of the pair list above (checked against the oracle there)
+        assert torch.equal(v.reshape(-1), want_v)      # candidate-major = the order of the pair list (checked against the oracle above, or here:)
+        ncpu = 30000
+        t0 = time.perf_counter()
+        wv, _ = oracle.enc_metric_batch(op, cur, prev, stride, src_offs[:ncpu], ref_offs[:ncpu], ref2_offs[:ncpu], 0)
+        tc_pairs = time.perf_counter() - t0
+        assert np.array_equal(want_v.cpu().numpy()[:ncpu].view(np.uint32), wv)
         # (the nine candidates of a block share its source block and all but a rim of the reference window: the traffic model is
         #  the UNIQUE bytes -- both frames once, the results -- not 132 / 136 bytes a pair)
         uniq = 2 * nblk * 64 + src_offs.size * (4 if op == "sad" else 8)
         results.append(dict(kernel="oc_enc_frag_%s, motion-search form (thip_enc_frag_metric_sites_batch)" % op, units=src_offs.size,
-                            unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=float("nan"), unique_bytes=uniq))
+                            unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=ncpu / tc_pairs, unique_bytes=uniq))
     # --- ... and over several frames in one call (a single frame is one round of waves: its launch ramp, first loads and tail
     #     are a third of the call; an encoder with more than one stream to search hands them over together) -------------------
-    for F in (2, 4):
+    for F in ((4,) if subset else (2, 4)):
         prevF = rng.integers(0, 256, (H * planes * F + 16, W + 16)).astype(np.uint8)
         curF = np.clip(np.roll(prevF, (1, 3), (0, 1)).astype(np.int32) + rng.integers(-6, 7, prevF.shape), 0, 255).astype(np.uint8)
         byF, bxF = np.mgrid[0:H * planes * F // 8, 0:W // 8]
@@ -414,12 +456,15 @@ def main_enc():
             v, dc = call()
             ncpu = 20000
             sel = rng.integers(0, baseF.size, ncpu)
+            tc_pairs = 0.0
             for si, (dx, dy) in enumerate(sites[:3]):
+                t0 = time.perf_counter()
                 wv, _ = oracle.enc_metric_batch(op, curF, prevF, stride, baseF[sel], (baseF[sel] + dy * stride + dx).astype(np.int32),
                                                 baseF[sel], 0)
+                tc_pairs += time.perf_counter() - t0
                 assert np.array_equal(v.reshape(len(sites), -1)[si].cpu().numpy()[sel].view(np.uint32), wv)
             results.append(dict(kernel="oc_enc_frag_%s, motion-search form, %d frames per call" % (op, F), units=baseF.size * len(sites),
-                                unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=float("nan"),
+                                unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=3 * ncpu / tc_pairs,
                                 unique_bytes=2 * baseF.size * 64 + baseF.size * len(sites) * (4 if op == "sad" else 8)))
     # --- the per-macro-block cost maps of a whole frame (thip_enc_mb_cost_maps: oc_mb_intra_satd, oc_mb_activity, _fast) ---------
     Wc, Hc = 1920, 1088
@@ -439,12 +484,13 @@ def main_enc():
     results.append(dict(kernel="oc_mb_intra_satd + oc_mb_activity + oc_mb_activity_fast, whole frame (thip_enc_mb_cost_maps)", units=nmb,
                         unit="macro blocks", seconds=t, bytes_per_unit=12 * 64 + 21 * 4, cpu_rate=nmb / tc,
                         unique_bytes=3 * Wc * Hc + want_maps[0].shape[0] * 21 * 4 * 2))
+    lines = []
     for r in results:
         # bytes moved: the per-unit model of SURVEY section 8(d) for the pair lists (every pair fetches its own blocks); the
         # unique bytes where units share their input (a frac above 1 against bytes that are not moved is not evidence)
         nbytes = r.get("unique_bytes", r["units"] * r["bytes_per_unit"])
         gbs = nbytes / r["seconds"] / 1e9
-        print(json.dumps({
+        lines.append(({
             "metric": r["kernel"] + " throughput", "value": round(r["units"] / r["seconds"] / 1e6, 1), "unit": "M%s/s" % r["unit"],
             "config": {"workload": "1920x1088 4:4:4%s, %d %s per call, 9-site square pattern" % (" x %s frames" % r["kernel"].split(", ")[-1].split()[0] if "frames per call" in r["kernel"] else "", r["units"], r["unit"])},
             "ms_per_call": round(1e3 * r["seconds"], 4), "dtype": "u8/i16", "data": "synthetic", "bit_exact_vs_oracle": True,
@@ -454,6 +500,10 @@ def main_enc():
                          else "per-unit bytes of SURVEY section 8(d)"},
             "cpu_baseline": ({"value": round(r["cpu_rate"] / 1e6, 3), "unit": "M%s/s" % r["unit"], "cores": 1, "kind": "port"}
                              if r["cpu_rate"] == r["cpu_rate"] else None)}))
+    if emit:
+        for ln in lines:
+            print(json.dumps(ln))
+    return lines
 
 
 
@@ -678,6 +728,9 @@ def main():
     # frames (every rank checks its own streams; a stream's content depends on its global id only, so
     # streams [0, S) are the same pictures at every world size).  No number is printed on a mismatch.
     cpu_baseline, parity = None, None
+    # At N > 1 rank 0's CPU baseline (tens of seconds, up to 64 processes) runs BEHIND the timed region, so that no rank's clock
+    # starts after a long wait in a collective (--cpu-baseline-late forces the same order at N = 1)
+    cpu_late = world > 1 or args.cpu_baseline_late
     nparity = 0 if args.no_parity else max(1, args.parity_frames)
     if nparity:
         import oracle
@@ -688,7 +741,7 @@ def main():
         for q, (s_local, gid, g) in enumerate((sl, gi, gg) for sl, gi in enumerate(shard.stream_ids(rank, world, S)) for gg in range(G)):
             ost = oracle.State(w, h)
             # stream 0 of rank 0 goes on to `cpu_frames` frames for the CPU baseline; the comparison is at frame nparity-1
-            nf = max(nparity, args.cpu_frames) if (rank == 0 and q == 0 and not args.no_cpu_baseline) else nparity
+            nf = max(nparity, args.cpu_frames) if (rank == 0 and q == 0 and not args.no_cpu_baseline and not cpu_late) else nparity
             for i in range(nf):
                 fr = host_frames[s_local][frame_of_state(g, i)]
                 ost.refi[:] = fr["refi"]
@@ -717,13 +770,7 @@ def main():
                   "checked": "the timed batch itself: all %d streams of every rank%s, decoded %d frames deep by the timed "
                              "states in the timed launch shape (one thip_decode_frames call per step), every plane of "
                              "every stream against the oracle" % (S, " (x %d key-frame intervals side by side)" % G if G > 1 else "", nparity)}
-        if rank == 0 and not args.no_cpu_baseline:
-            cpu_baseline = {"value": round(n_cpu / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                            "sample": "%d frames of one %s %s stream through oracle/theora_oracle.c "
-                                      "(scalar C restatement of the reference's C path, gcc -O2)" % (n_cpu, args.size, args.content),
-                            "note": "a scalar-C port, not libtheora's x86 SIMD path (which cannot be built here: no libogg); "
-                                    "SURVEY section 6 measured the reference's SIMD build at about 2.4x its C build on this "
-                                    "kind of content, so the reference on one of these cores would be roughly 2.4x this figure"}
+        def cpu_all_cores(cb):
             # the same decoder on every core the box gives us, one process per core (the reference is
             # single-threaded per stream; many streams are many processes)
             ncores = min(_usable_cores(), 64)
@@ -732,8 +779,16 @@ def main():
                 per = max(16, args.cpu_frames // 4)
                 with mp.get_context("spawn").Pool(ncores) as pool_:
                     times = pool_.map(_cpu_worker, [(args.size, args.content, args.pool, per)] * ncores)
-                cpu_baseline["all_cores"] = {"value": round(ncores * per / max(times), 2), "unit": "frames/s", "cores": ncores,
-                                             "sample": "%d processes x %d frames, decode time of the slowest" % (ncores, per)}
+                cb["all_cores"] = {"value": round(ncores * per / max(times), 2), "unit": "frames/s", "cores": ncores,
+                                   "sample": "%d processes x %d frames, decode time of the slowest" % (ncores, per)}
+        if rank == 0 and not args.no_cpu_baseline and not cpu_late:
+            cpu_baseline = {"value": round(n_cpu / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                            "sample": "%d frames of one %s %s stream through oracle/theora_oracle.c "
+                                      "(scalar C restatement of the reference's C path, gcc -O2)" % (n_cpu, args.size, args.content),
+                            "note": "a scalar-C port, not libtheora's x86 SIMD path (which cannot be built here: no libogg); "
+                                    "SURVEY section 6 measured the reference's SIMD build at about 2.4x its C build on this "
+                                    "kind of content, so the reference on one of these cores would be roughly 2.4x this figure"}
+            cpu_all_cores(cpu_baseline)
 
     # ---- timed region ---------------------------------------------------------------------
     # Pass A: blocks of exactly K steps, each bracketed by synchronize + barrier on both sides, no
@@ -810,6 +865,9 @@ def main():
         crcs.append(c)
     dev = torch.device("cuda", local_rank)
     blocks = shard.reduce_max(elapsed_blocks, dev)          # per block: the slowest rank
+    per_rank_ms = [round(1e3 * v / args.steps, 5) for v in shard.gather_floats(float(np.median(elapsed_blocks)), dev)]   # every rank's own median
+    pg = {"initialized": bool(dist.is_initialized()), "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+          "backend": dist.get_backend() if dist.is_initialized() else None}
     _, crcs = shard.reduce_results(0.0, crcs, dev)
     if nparity:
         _, parity_crcs = shard.reduce_results(0.0, parity_crcs, dev)
@@ -912,9 +970,167 @@ def main():
             for st3 in states3:
                 st3.close()
             del keep3, descs3
+        # ---- config 3's roofline form: ONE 1080p stream whose key-frame intervals are decoded side by side (a key frame resets
+        #      both references, decode.c:2947-2955, so intervals are independent): 16 states, state g takes intervals g, g + 16, ... ----
+        try:
+            G3 = 16
+            rng = np.random.default_rng(shard.stream_seed(777, shard.stream_ids(rank, world, 1)[0]))
+            frames3 = [synth.gen_frame(geom2, rng, theora_amd.INTRA_FRAME, args.content, flimit=2)]
+            for _ in range(args.pool):
+                frames3.append(synth.gen_frame(geom2, rng, theora_amd.INTER_FRAME, args.content, flimit=2))
+            keep3, descs3 = [], []
+            for f in frames3:
+                d, ka = synth.upload_frame(synth.pack_frame(geom2, f))
+                keep3.append(ka)
+                descs3.append(d)
+            balg3 = [synth.algorithmic_bytes(geom2, f) for f in frames3]
+            states3 = [theora_amd.State(w2, h2) for _ in range(G3)]
+
+            def fos3(g, i):
+                return frame_in_interval(i % KF_INTERVAL, g + G3 * (i // KF_INTERVAL))
+            cache3 = {}
+
+            def plan3(i):
+                key = tuple(fos3(g, i) for g in range(G3))
+                if key not in cache3:
+                    cache3[key] = theora_amd.BatchPlan(states3, [descs3[k] for k in key])
+                return cache3[key]
+            # parity of this shape before its clock: the first six steps, states 0 and 15 against the oracle
+            NP3 = 6
+            for i in range(NP3):
+                plan3(i).submit(None)
+            sync()
+            if nparity:
+                for g in (0, G3 - 1):
+                    ost = oracle.State(w2, h2)
+                    for i in range(NP3):
+                        fr = frames3[fos3(g, i)]
+                        ost.refi[:] = fr["refi"]
+                        ost.mvs[:] = ((fr["mvx"] & 0xFF) | (fr["mvy"] << 8)).astype(np.int16)
+                        ost.decode_frame(fr["frame_type"], fr["coded_fragis"], fr["ncoded"], fr["coeffs"], fr["last_zzi"],
+                                         fr["dc_quant"], fr["uncoded_fragis"], fr["flimit"])
+                    for pli in range(3):
+                        if not np.array_equal(ost.get_plane(oracle.FRAME_PREV, pli), states3[g].read_plane(states3[g].ref_idx(theora_amd.FRAME_PREV), pli)):
+                            raise SystemExit("bench: single_gop16 differs from the oracle (state %d, plane %d)" % (g, pli))
+                    ost.close()
+            K3 = max(args.steps, 64)
+            for i in range(NP3, KF_INTERVAL):
+                plan3(i).submit(None)
+            sync()
+            b3 = []
+            for rep in range(max(5, min(args.repeats, 15))):
+                sync()
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(KF_INTERVAL + rep * K3, KF_INTERVAL + (rep + 1) * K3):
+                    plan3(i).submit(None)
+                sync()
+                b3.append(time.perf_counter() - t0)
+                barrier()
+            b3 = shard.reduce_max(b3, dev)
+            e3 = float(np.median(b3))
+            read3 = sum(balg3[fos3(g, KF_INTERVAL + i)][1] for i in range(K3) for g in range(G3))
+            other_size["single_gop16"] = {"value": round(K3 * G3 * world / e3, 2), "unit": "frames/s", "streams_per_gpu": 1,
+                                          "key_frame_intervals_side_by_side": G3, "steps": K3, "ms_per_step": round(1e3 * e3 / K3, 5),
+                                          "pipeline_read_roofline_frac": round(read3 / e3 / 1e9 / HBM_PEAK_GBS, 4),
+                                          "bit_exact": bool(nparity),
+                                          "note": "BASELINE.json config 3 in the form that fills the chip: the caller decodes 16 key-frame "
+                                                  "intervals of the one stream side by side (16 states in one thip_decode_frames call per step)"}
+            for st3 in states3:
+                st3.close()
+            del keep3, descs3
+        except SystemExit:
+            raise
+        except Exception as e:   # (never fails the bench)
+            other_size["single_gop16"] = {"error": str(e)[:300]}
         other_size["note"] = ("1080p (1920x1088 coded) 4:2:0, kf %d, content class '%s', frames decoded one after the other through "
                               "thip_decode_frames; parity of these shapes: tests/test_gpu_frames.py::test_config3_as_written, "
                               "::test_full_size_sequences" % (KF_INTERVAL, args.content))
+
+    # ---- rank 0's CPU baseline behind the timed region (N > 1, or --cpu-baseline-late): the other ranks go on to the final gather ----
+    if nparity and rank == 0 and not args.no_cpu_baseline and cpu_late:
+        t1 = _cpu_worker((args.size, args.content, args.pool, args.cpu_frames))
+        cpu_baseline = {"value": round(args.cpu_frames / t1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                        "sample": "%d frames of one %s %s stream through oracle/theora_oracle.c (scalar C restatement of the reference's "
+                                  "C path, gcc -O2), timed behind the GPU's timed region" % (args.cpu_frames, args.size, args.content)}
+        cpu_all_cores(cpu_baseline)
+
+    # ---- wide tiles: the same dense step with 1 % and 10 % of the tiles holding a level beyond eight bits (the levels form's
+    #      escape, include/theora_hip.h THIP_SLOT_WIDE: such a tile's blocks own two units of int16 levels) ---------------------------
+    wide_tiles = None
+    if args.size == "4k" and args.content == "dense" and G == 1 and not args.no_wide and world == 1:
+        wide_tiles = {}
+        try:
+            for label, frac in (("1pct", 0.01), ("10pct", 0.10)):
+                descs4, keep4, balg4, frames4 = [], [], [], []
+                wrng = np.random.default_rng(4242)
+                nwide, ntl = 0, 0
+                for s_ in range(S):
+                    row, rowf = [], []
+                    for f in host_frames[s_][:3]:      # the key frame and two inter frames of the timed pool, some tiles widened
+                        fw, nw = synth.widen_tiles(geom, f, frac, wrng)
+                        nwide += nw
+                        ntl += geom.ntiles
+                        d, ka = synth.upload_frame(synth.pack_frame(geom, fw))
+                        keep4.append(ka)
+                        row.append(d)
+                        rowf.append(fw)
+                    descs4.append(row)
+                    frames4.append(rowf)
+                    balg4.append([synth.algorithmic_bytes(geom, f) for f in rowf])
+                plans4 = [theora_amd.BatchPlan(states, [descs4[s_][j] for s_ in range(S)]) for j in range(3)]
+
+                def f4(i):
+                    return 0 if i % KF_INTERVAL == 0 else 1 + (i % 2)
+                for i in range(3):
+                    plans4[f4(i)].submit(None)
+                sync()
+                if nparity:        # stream 0 against the oracle, three frames deep
+                    ost = oracle.State(w, h)
+                    for i in range(3):
+                        fr = frames4[0][f4(i)]
+                        ost.refi[:] = fr["refi"]
+                        ost.mvs[:] = ((fr["mvx"] & 0xFF) | (fr["mvy"] << 8)).astype(np.int16)
+                        ost.decode_frame(fr["frame_type"], fr["coded_fragis"], fr["ncoded"], fr["coeffs"], fr["last_zzi"],
+                                         fr["dc_quant"], fr["uncoded_fragis"], fr["flimit"])
+                    for pli in range(3):
+                        if not np.array_equal(ost.get_plane(oracle.FRAME_PREV, pli), states[0].read_plane(states[0].ref_idx(theora_amd.FRAME_PREV), pli)):
+                            raise SystemExit("bench: the wide-tile batch differs from the oracle (plane %d)" % pli)
+                    ost.close()
+                K4 = max(args.steps, 64)
+                for i in range(3, KF_INTERVAL):
+                    plans4[f4(i)].submit(None)
+                sync()
+                b4 = []
+                for rep in range(max(5, min(args.repeats, 15))):
+                    sync()
+                    t0 = time.perf_counter()
+                    for i in range(KF_INTERVAL + rep * K4, KF_INTERVAL + (rep + 1) * K4):
+                        plans4[f4(i)].submit(None)
+                    sync()
+                    b4.append(time.perf_counter() - t0)
+                e4 = float(np.median(b4))
+                read4 = sum(balg4[s_][f4(KF_INTERVAL + i)][1] for i in range(K4) for s_ in range(S))
+                wide_tiles[label] = {"value": round(K4 * S / e4, 2), "unit": "frames/s", "steps": K4, "ms_per_step": round(1e3 * e4 / K4, 5),
+                                     "pipeline_read_roofline_frac": round(read4 / e4 / 1e9 / HBM_PEAK_GBS, 4),
+                                     "wide_tiles": nwide, "tiles": ntl, "bit_exact": bool(nparity)}
+                del keep4, descs4, plans4
+            wide_tiles["note"] = ("the timed dense batch with one level of 300 planted in that share of the tiles (every block of such a tile "
+                                  "then travels as two units of int16 levels instead of one of int8); the headline's content has no wide tile")
+        except SystemExit:
+            raise
+        except Exception as e:
+            wide_tiles["error"] = str(e)[:300]
+
+    # ---- BASELINE.json config 5: the encoder's block kernels on one 1920x1088 4:4:4 frame (each checked against the oracle first) ----
+    enc_entry = None
+    if rank == 0 and world == 1 and args.size == "4k" and G == 1 and not args.no_enc:
+        try:
+            enc_entry = {"entries": main_enc(emit=False, subset=True),
+                         "note": "BASELINE.json config 5 (1920x1088 4:4:4): rooflines of the motion-search and cost-map entries are on UNIQUE "
+                                 "bytes (their candidates share their input); cpu_baseline = the oracle's scalar C on one core, same run"}
+        except Exception as e:
+            enc_entry = {"error": str(e)[:300]}
 
     if rank == 0:
         first_timed = nparity + args.warmup
@@ -952,7 +1168,9 @@ def main():
                        "ms_per_step_min": round(1e3 * min(blocks) / args.steps, 5),
                        "ms_per_step_max": round(1e3 * max(blocks) / args.steps, 5),
                        "ms_per_step_first_block": round(1e3 * blocks[0] / args.steps, 5),
-                       "host_submit_us_per_block": round(submit_us, 1), "idle_sync_us": round(idle_sync_us, 1)},
+                       "host_submit_us_per_block": round(submit_us, 1), "idle_sync_us": round(idle_sync_us, 1),
+                       "ms_per_step_by_rank": per_rank_ms},
+            "process_group": pg,
         }
         # HBM bytes per launch from the PMC counters of THIS workload: two more passes of this script under rocprofv3
         traffic, traffic_bytes = None, None
@@ -1004,6 +1222,10 @@ def main():
             out["second_content"] = second
         if other_size:
             out["size_1080p"] = other_size
+        if wide_tiles:
+            out["wide_tiles"] = wide_tiles
+        if enc_entry:
+            out["enc_1080p_444"] = enc_entry
         if world == 1 and G == 1 and not args.no_e2e and args.size == "4k":
             out["e2e_720p"] = e2e_keyed_entry()
         if cpu_baseline:

@@ -3,7 +3,7 @@
  * batch configuration, end to end: packets in host memory -> frames in host memory).
  *
  *   cc -O2 -pthread -Iinclude examples/decode_bench.c -Ltheora_amd -ltheora_hip -o decode_bench
- *   decode_bench in.ogv <threads> <loops> [--no-output] [--lookahead K]
+ *   decode_bench in.ogv <threads> <loops> [--no-output] [--lookahead K] [--devices]
  *
  * --lookahead K: every stream announces its packets K ahead (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET, what a player does
  * with the packets its demultiplexer has queued): the library parses them on threads of its own and th_decode_packetin only
@@ -73,15 +73,17 @@ static void *run(void *arg) {
 
 int main(int argc, char **argv) {
   if (argc < 4) {
-    fprintf(stderr, "usage: %s in.ogv <threads> <loops> [--no-output] [--lookahead K]\n", argv[0]);
+    fprintf(stderr, "usage: %s in.ogv <threads> <loops> [--no-output] [--lookahead K] [--devices]\n", argv[0]);
     return 1;
   }
   const int nthreads = atoi(argv[2]);
+  int check_devices = 0;   /* --devices: every context must sit on the GPU its turn gives it (context i on device i mod the node's GPUs) */
   g_loops = atoi(argv[3]);
   g_output = 1;
   for (int a = 4; a < argc; a++) {
     if (!strcmp(argv[a], "--no-output")) g_output = 0;
     else if (!strcmp(argv[a], "--lookahead") && a + 1 < argc) g_ahead = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--devices")) check_devices = 1;
   }
   thip_ogg_reader *og = thip_ogg_open_file(argv[1]);
   if (!og || nthreads < 1 || g_loops < 1) return 1;
@@ -125,6 +127,14 @@ int main(int argc, char **argv) {
     if (!w[i].dec) {
       fprintf(stderr, "th_decode_alloc failed for stream %d\n", i);
       return 1;
+    }
+    if (check_devices) {
+      int dev = -1;
+      if (th_decode_ctl(w[i].dec, TH_DECCTL_THIP_GET_DEVICE, &dev, sizeof(dev)) != 0 || dev != (ndev > 0 ? i % ndev : dev)) {
+        fprintf(stderr, "--devices: context %d sits on device %d, its turn is device %d of %d\n", i, dev, ndev > 0 ? i % ndev : -1, ndev);
+        return 2;
+      }
+      fprintf(stderr, "context %d -> device %d\n", i, dev);
     }
     /* one untimed frame per context: device buffers, streams and staging come into being here */
     memset(&op, 0, sizeof(op));

@@ -424,6 +424,19 @@ int thip_enc_frag_metric_sites_batch(int op, uint32_t *out, int32_t *dc_out, con
                                      const uint8_t *ref_plane, int ystride, const int32_t *src_offs,
                                      const int32_t *ref_offs, const int8_t *site_dx, const int8_t *site_dy,
                                      int nsites, int64_t nblocks);
+/* The half-pel refinement's form of oc_enc_frag_satd2 (encfrag.c:323-328) / oc_enc_frag_sad2_thresh (encfrag.c:62-86, without a
+   threshold: every row is added): every block i against nsites of the eight half-pel vectors 2 * vec[i] + (site_dx[c],
+   site_dy[c]) around its whole-pel vector vec[i] (vecs[i] = x & 0xFF | y << 8, the reference's oc_mv, state.h:232-240), as
+   oc_mcenc_ysatd_halfpel_mbrefine / oc_mcenc_ysad_halfpel_mbrefine do it (mcenc.c:551-657): the source block against the
+   truncating average of the two whole-pel blocks ref_plane + ref_offs[i] + mvoffset0 / mvoffset1 of mcenc.c:633-636 (ref_offs[i]
+   is the block at the whole-pel vector, the reference's frag_offs + mvoffset_base).  One launch instead of nsites calls per
+   block: the ten rows around the whole-pel position are fetched once per column, and the two vertical sites share their nine
+   averaged rows' horizontal Hadamard levels.  (0, 0) is not a half-pel site (THIP_EINVAL).  Results site-major: out[c*nblocks
+   + i] (and dc_out, SATD2 only, may be null).  op: THIP_ENC_SATD2 or THIP_ENC_SAD2_THRESH. */
+int thip_enc_frag_metric_halfpel_batch(int op, uint32_t *out, int32_t *dc_out, const uint8_t *src_plane,
+                                       const uint8_t *ref_plane, int ystride, const int32_t *src_offs,
+                                       const int32_t *ref_offs, const int16_t *vecs, const int8_t *site_dx,
+                                       const int8_t *site_dy, int nsites, int64_t nblocks);
 /* The encoder's per-macro-block cost maps for a whole frame, computed up front in one launch: what
    oc_mb_intra_satd (analyze.c:1360-1403), oc_mb_activity (analyze.c:1152-1237) and oc_mb_activity_fast (analyze.c:1239-1251)
    return for every macro block -- the reference calls them macro block by macro block from its mode-decision loop
@@ -554,6 +567,8 @@ const char *thip_version_string(void);
  *   debug        k_recon ablation switches (profiling); 256: k_recon_lf's cells copy without filtering; 512: tile 1 of every
  *                stream mis-tags its edge units, so that a hand-over fails and the recovery below can be tested
  *   faults_recovered   (counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf ran out
+ *   stagger      thip_decode_frames: when a call finds every lane of the device idle, lane i's launch is held back i x stagger
+ *                microseconds by a sleeping wave, so that launches of equal length on different lanes do not run in step (0 = off)
  *   redo_descs   thip_decode_frames on the caller's descriptors: 1 = the caller promises that the buffers a descriptor points to stay
  *                as they are until the state's next synchronising call, so a frame whose hand-over failed is decoded again (default 0:
  *                THIP_EFAULT, see thip_synchronize)
@@ -589,6 +604,12 @@ const char *thip_version_string(void);
  *                device walks the lists (k_tok_assign / k_tok_walk); 2 (default): measured per stream -- the time between
  *                adopted frames, 24 frames each way, the better rule for the next 1024 (pairing moves 3.5-4.3 ns a token
  *                from the device's critical path to the parser threads: right when they have room, wrong when they are the bound)
+ *   fe_lookahead_adopted, fe_lookahead_missed   (counters) announced packets taken over by their th_decode_packetin / parsed for
+ *                nothing (a different packet came -- every announcement outstanding is then dropped -- or the parser refused it; a
+ *                zero-byte packet, i.e. a dropped frame, leaves the announcements where they are)
+ *   fe_assign_settle   fe_assign = 2: adopted frames a stream keeps the rule that measured faster before it measures again (default 1024)
+ *   fe_assign_to_device, fe_assign_to_parsers   (counters) fe_assign = 2: how often a stream's rule changed from the parsers pairing to
+ *                the device walking (every measurement begins with one such change) and back
  *   fe_levels    th_decode_*: 1: the host's own token walk feeds thip_state_frag_recon_levels; 0 (default): thip_state_frag_recon --
  *                measured equal within 2 % end to end (the walk is bound by the tokens, not by the 64 bytes a block saved)
  *   fe_trace_backend, fe_prof   th_decode_*: record slot calls instead of running them (tests); per-stage host timing
@@ -600,6 +621,8 @@ int thip_get_option(const char *name, int *value);
 const char *thip_option_name(int index, const char **help);
 /* (internal shorthand of thip_get_option for the library's own translation units: 0 for an unknown name) */
 int thip_option(const char *name);
+/* (internal: adds to a counter of the table) */
+void thip_option_add(const char *name, int delta);
 
 #ifdef __cplusplus
 }

@@ -161,6 +161,9 @@ typedef struct {
    th_decode_packetin as ever.  A th_decode_packetin whose packet is not the oldest announced one drops everything announced and
    parses the ordinary way: announcing is a hint, never a requirement, and the pictures are the same either way. */
 #define TH_DECCTL_THIP_PREFETCH_PACKET (0x7105)
+/* Which GPU the context's device state lives on (th_decode_alloc_on, option "device" / THIP_DEVICE): buf = int, receives the
+   device index (thip_state_device); TH_EINVAL for a context without device state (slot-trace mode). */
+#define TH_DECCTL_THIP_GET_DEVICE (0x7106)
 typedef struct thip_slot_trace {
   int64_t ncoded;           /* state_frag_recon calls, in call (= coded) order */
   const int32_t *fragi;     /* _fragi */

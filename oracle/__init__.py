@@ -263,6 +263,38 @@ def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None,
     return out, dc
 
 
+def halfpel_mvoffsets(vx, vy, dx, dy, ystride):
+    """The two block offsets the half-pel refinement hands to oc_enc_frag_satd2 / oc_enc_frag_sad2_thresh for the half-pel vector
+    2 * (vx, vy) + (dx, dy), relative to the block at the whole-pel vector (the reference's mvoffset_base):
+    oc_mcenc_ysatd_halfpel_mbrefine, mcenc.c:620-636 (offset_y[site] = dy * ystride, :621-623; xmask / ymask = OC_SIGNMASK(((vec <<
+    1) + d) ^ d), :633-634; mvoffset0 = (dx & xmask) + (offset_y & ymask), mvoffset1 = (dx & ~xmask) + (offset_y & ~ymask), :635-636).
+    vx, vy: integer arrays; returns (mvoffset0, mvoffset1) as int64 arrays."""
+    vx, vy = np.asarray(vx, np.int64), np.asarray(vy, np.int64)
+    xmask = np.where((((vx << 1) + dx) ^ dx) < 0, -1, 0).astype(np.int64)
+    ymask = np.where((((vy << 1) + dy) ^ dy) < 0, -1, 0).astype(np.int64)
+    oy = dy * ystride
+    return (dx & xmask) + (oy & ymask), (dx & ~xmask) + (oy & ~ymask)
+
+
+def enc_halfpel_sites(op, src_plane, ref_plane, ystride, src_offs, ref_offs, vecs, sites):
+    """What the refinement computes for every block and every half-pel site of `sites` = [(dx, dy), ...] (mcenc.c:551-657): the
+    reference's own slot (orc_enc_metric_batch: oc_enc_frag_satd2_c, encfrag.c:323-328, or oc_enc_frag_sad2_thresh_c with a
+    threshold nothing reaches, encfrag.c:62-86) on the two blocks of halfpel_mvoffsets.  vecs: int16, x & 0xFF | y << 8
+    (state.h:232-240).  Returns (values, dc) as [len(sites), nblocks] arrays."""
+    v = np.asarray(vecs).astype(np.int16)
+    vx = (v & 0xFF).astype(np.int8).astype(np.int64)
+    vy = (v >> 8).astype(np.int8).astype(np.int64)
+    ro = np.asarray(ref_offs, np.int64)
+    vals, dcs = [], []
+    for dx, dy in sites:
+        o0, o1 = halfpel_mvoffsets(vx, vy, dx, dy, ystride)
+        a, d = enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, (ro + o0).astype(np.int32), (ro + o1).astype(np.int32),
+                                0xFFFFFFFF if op == "sad2_thresh" else 0)
+        vals.append(a)
+        dcs.append(d)
+    return np.stack(vals), np.stack(dcs)
+
+
 def mb_cost_maps(planes, frame_width, frame_height, pixel_fmt):
     """oc_mb_intra_satd / oc_mb_activity / oc_mb_activity_fast over a whole frame (three unpadded planes, bitstream row order).
     Returns (intra_satd [nmbs,12], luma [nmbs], activity [nmbs,4], activity_fast [nmbs,4]) in the reference's macro-block order."""

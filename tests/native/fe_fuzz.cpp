@@ -45,8 +45,11 @@ int thip_option(const char *name) {   // the library's option table is not linke
   if (name && !strcmp(name, "fe_lookahead")) return 4;
   if (name && !strcmp(name, "fe_worker_pin")) return 1;
   if (name && !strcmp(name, "fe_assign")) return 2;
+  if (name && !strcmp(name, "fe_assign_settle")) return 16;   // (short, so that the fuzzed streams cross the rule's switch points)
   return 0;
 }
+void thip_option_add(const char *, int) {}   // (the counters live in the table that is not linked)
+int thip_state_device(const thip_state *) { return -1; }
 int thip_state_set_device_dc(thip_state *, int) { return -1; }
 int thip_frame_dequant_table(thip_state *, int, const uint16_t *) { return -1; }
 int thip_state_frag_recon_levels(thip_state *, ptrdiff_t, int, int16_t *, int, uint16_t, int, int, int16_t) { return -1; }

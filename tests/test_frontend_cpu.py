@@ -259,3 +259,44 @@ def test_prefetch_request_arguments_and_refusals(trace_env):
         L.thip_set_option(b"fe_lookahead", old)
     dec.close()
     ref.close()
+
+
+def test_the_measured_rule_changes_sides_in_a_long_stream(trace_env):
+    """Option fe_assign = 2 across its switch points (thip_frontend.cpp, fe_pair_rule) on the CPU, slot-trace mode: 170 frames,
+    eight announced ahead, the settled phase shortened to six frames so that a second measurement begins inside the stream.  Every
+    adopted frame's pairing is checked against the host's own walk (a mismatch fails th_decode_packetin), every slot call equals
+    the plain loop's, dropped frames leave the announcements in place, and the counters show both changes of sides."""
+    import ctypes as C
+    from theora_amd import _lib
+    from theora_amd.decoder import Decoder
+    L = _lib.load()
+
+    def counter(name):
+        v = C.c_int()
+        assert L.thip_get_option(name, C.byref(v)) == 0
+        return v.value
+    before = [counter(n) for n in (b"fe_assign_to_device", b"fe_assign_to_parsers", b"fe_lookahead_adopted")]
+    st = streamgen.Stream(64, 48, 0, seed=99, trees="matched")
+    hdr = st.header_packets()
+    pk = [st.frame(0 if f % 17 == 0 else 1, density=[0.9, 0.5, 0.15][f % 3])[0] for f in range(170)]
+    with util.options(L, fe_assign=2, fe_assign_settle=6, fe_lookahead=8):
+        plain, fast = Decoder(hdr), Decoder(hdr)
+        nxt = 0
+        for i, p in enumerate(pk):
+            while nxt < len(pk) and nxt < i + 8:
+                nxt = max(nxt, i)
+                if not fast.prefetch(pk[nxt]) and len(pk[nxt]):
+                    break
+                nxt += 1
+            ra, rb = plain.packetin(p), fast.packetin(p)
+            assert ra == rb, (i, ra, rb)
+            if ra[0] == 0:
+                ta, tb = plain.slot_trace(), fast.slot_trace()
+                for k in ta:
+                    assert np.array_equal(ta[k], tb[k]), (i, k)
+        fast.close()
+        plain.close()
+    after = [counter(n) for n in (b"fe_assign_to_device", b"fe_assign_to_parsers", b"fe_lookahead_adopted")]
+    nonempty = sum(1 for p in pk if len(p))
+    assert after[2] - before[2] >= nonempty - 12, (before, after, nonempty)     # (all but the first few and the frames without coded blocks)
+    assert after[0] > before[0] and after[1] > before[1], (before, after)

@@ -78,6 +78,31 @@ def test_packets_decode_bit_exact_with_a_look_ahead(hip, w, h, fmt, ahead, lists
                       trees="matched" if w >= 1000 else "random") >= 4
 
 
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0)])
+def test_look_ahead_rule_changes_sides_against_the_oracle(hip, w, h, fmt):
+    """Option fe_assign = 2 (the default) measures per stream who pairs tokens and fragments -- the announced packets' parsers
+    (k_tok_scatter on the device) or the device's walk (k_tok_assign) -- and changes sides while the stream runs: after
+    4 * 8 + 8 adopted frames 24 frames are timed each way (the frames announced under the other rule let through first), the
+    faster rule is kept for fe_assign_settle frames (shortened here: 1024 by default) and the measurement begins again.  Long
+    enough to cross every one of those points, eight packets announced ahead, EVERY frame compared with the oracle: the frames
+    around a change of sides were parsed under one rule and handed over under the other's successor.  The counters say that both
+    changes happened."""
+    import ctypes as C
+    L = hip._lib.load()
+    to_dev0, to_par0, to_dev1, to_par1 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ad0, ad1 = C.c_int(), C.c_int()
+    L.thip_get_option(b"fe_assign_to_device", C.byref(to_dev0))
+    L.thip_get_option(b"fe_assign_to_parsers", C.byref(to_par0))
+    L.thip_get_option(b"fe_lookahead_adopted", C.byref(ad0))
+    with util.options(L, fe_assign=2, fe_assign_settle=6, fe_lookahead=8):
+        assert run_stream(hip, w, h, fmt, seed=7 * w + h + fmt, nframes=170, kf=17, device_lists=True, lookahead=8, trees="matched") >= 120
+    L.thip_get_option(b"fe_assign_to_device", C.byref(to_dev1))
+    L.thip_get_option(b"fe_assign_to_parsers", C.byref(to_par1))
+    L.thip_get_option(b"fe_lookahead_adopted", C.byref(ad1))
+    assert ad1.value - ad0.value >= 120, (ad0.value, ad1.value)     # (dropped frames leave the announcements in place)
+    assert to_dev1.value > to_dev0.value and to_par1.value > to_par0.value, (to_dev0.value, to_dev1.value, to_par0.value, to_par1.value)
+
+
 @pytest.mark.parametrize("levels", [1, 0])
 @pytest.mark.parametrize("w,h,fmt,ahead", [(176, 144, 0, 3), (48, 64, 3, 2), (336, 32, 0, 4), (1280, 720, 0, 3)])
 def test_look_ahead_with_the_walk_left_to_the_device(hip, w, h, fmt, ahead, levels):

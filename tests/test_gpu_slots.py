@@ -218,6 +218,68 @@ def test_enc_metric_sites(hip, op):
     assert call(_lib.ENC_OPS["ssd"], [0], [0]) == _lib.EINVAL
 
 
+@pytest.mark.parametrize("op", ["satd2", "sad2_thresh"])
+def test_enc_metric_halfpel_sites(hip, op):
+    """The half-pel refinement's form (thip_enc_frag_metric_halfpel_batch): every block against the half-pel vectors around its
+    whole-pel vector -- against the oracle's restatement of the reference's call pattern (oc_mcenc_ysatd_halfpel_mbrefine,
+    mcenc.c:606-657: mvoffset0 / mvoffset1 from the signs of the vector, then oc_enc_frag_satd2 / oc_enc_frag_sad2_thresh on the
+    two blocks).  Whole-pel vectors of both signs and zero on both axes (which of the two blocks gets the step, and whether a
+    diagonal site pairs {(0,0),(dx,dy)} or {(dx,0),(0,dy)}, follows from them); all eight sites in the reference's order, subsets
+    in other orders, single sites; reference positions of every byte alignment; saturated and checkerboard pictures."""
+    from theora_amd import _lib
+    rng = np.random.default_rng(23 + len(op))
+    stride, H = 272, 136
+    src = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    ref = np.clip(src.astype(np.int32) + rng.integers(-20, 21, (H, stride)), 0, 255).astype(np.uint8)
+    ref[:40] = rng.integers(0, 256, (40, stride))
+    src[40:56] = 255
+    ref[40:56] = 0
+    src[56:72] = (np.indices((16, stride)).sum(0) & 1) * 255
+    ref[56:72] = 255 - src[56:72]
+    ref[72:88] = (np.indices((16, stride))[1] & 1) * 255          # columns alternate: every horizontal average is 127
+    n = 6000
+    so = (rng.integers(0, H - 8, n) * stride + rng.integers(0, stride - 8, n)).astype(np.int32)
+    ro = (rng.integers(1, H - 9, n) * stride + rng.integers(1, stride - 9, n)).astype(np.int32)
+    vx = rng.integers(-3, 4, n)
+    vy = rng.integers(-3, 4, n)
+    vx[:500] = 0
+    vy[250:750] = 0
+    vecs = ((vx & 0xFF) | (vy << 8)).astype(np.int16)
+    full = [(-1, -1), (0, -1), (1, -1), (-1, 0), (1, 0), (-1, 1), (0, 1), (1, 1)]     # OC_SQUARE_SITES[0], mcenc.c:50-56
+    for sites in (full, [(1, 1), (-1, 0), (0, -1), (0, 1)], [(-1, 1)], [(0, 1)], [(1, 0), (1, -1)]):
+        got, got_dc = hip.enc_metric_halfpel_batch(op, dev(src), dev(ref), stride, dev(so), dev(ro), dev(vecs), sites)
+        want, want_dc = oracle.enc_halfpel_sites(op, src, ref, stride, so, ro, vecs, sites)
+        assert np.array_equal(want, got.cpu().numpy().view(np.uint32)), (op, sites, np.argwhere(want != got.cpu().numpy().view(np.uint32))[:4])
+        if op == "satd2":
+            assert np.array_equal(want_dc, got_dc.cpu().numpy()), (op, sites)
+    # the full-size call of BASELINE.json config 5: every block of a 1920x1088 4:4:4 frame, all eight sites
+    W5, H5 = 1920 + 16, 3 * 1088 + 16
+    prev = rng.integers(0, 256, (H5, W5)).astype(np.uint8)
+    cur = np.clip(np.roll(prev, (1, 3), (0, 1)).astype(np.int32) + rng.integers(-6, 7, prev.shape), 0, 255).astype(np.uint8)
+    by, bx = np.mgrid[0:3 * 1088 // 8, 0:1920 // 8]
+    base = ((by * 8 + 8) * W5 + bx * 8 + 8).reshape(-1).astype(np.int32)
+    v5 = ((rng.integers(-2, 3, base.size) & 0xFF) | (rng.integers(-2, 3, base.size) << 8)).astype(np.int16)
+    got, got_dc = hip.enc_metric_halfpel_batch(op, dev(cur), dev(prev), W5, dev(base), dev(base), dev(v5), full)
+    sel = rng.integers(0, base.size, 30000)
+    want, want_dc = oracle.enc_halfpel_sites(op, cur, prev, W5, base[sel], base[sel], v5[sel], full)
+    assert np.array_equal(want, got.cpu().numpy().view(np.uint32)[:, sel]), op
+    if op == "satd2":
+        assert np.array_equal(want_dc, got_dc.cpu().numpy()[:, sel]), op
+    # argument errors: the centre is not a half-pel site, a site twice, nine sites, an operation without this form
+    L = _lib.load()
+    o = dev(np.zeros(8 * n, np.int32))
+
+    def call(opc, dx, dy):
+        dx, dy = np.array(dx, np.int8), np.array(dy, np.int8)
+        return L.thip_enc_frag_metric_halfpel_batch(opc, o.data_ptr(), None, dev(src).data_ptr(), dev(ref).data_ptr(), stride, dev(so).data_ptr(),
+                                                    dev(ro).data_ptr(), dev(vecs).data_ptr(), dx.ctypes.data, dy.ctypes.data, len(dx), n)
+    assert call(_lib.ENC_OPS[op], [0], [0]) == _lib.EINVAL
+    assert call(_lib.ENC_OPS[op], [1, 1], [1, 1]) == _lib.EINVAL
+    assert call(_lib.ENC_OPS[op], [1] * 9, [0] * 9) == _lib.EINVAL
+    assert call(_lib.ENC_OPS["satd"], [1], [0]) == _lib.EINVAL
+    assert call(_lib.ENC_OPS[op], [1], [0]) == 0
+
+
 def test_enc_fdct(hip):
     rng = np.random.default_rng(8)
     n = 20000

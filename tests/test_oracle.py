@@ -319,3 +319,19 @@ def test_mb_cost_maps_closed_forms():
         b = edge[0][0:8, 0:8].astype(np.int64)
         raw = 64 * (b ** 2).sum() - b.sum() ** 2
         assert (0 < act4[0, 0] < raw // 4) if is_edge else (act4[0, 0] == raw)
+
+
+def test_halfpel_refinement_offsets_are_the_decoders():
+    """mcenc.c:626-631 says its mask arithmetic 'SHOULD be equivalent to oc_state_get_mv_offsets' for the vector 2 * vec + (dx, dy)
+    on the luma plane: the oracle's restatement of the one (halfpel_mvoffsets, mcenc.c:620-636) against its restatement of the
+    other (mv_offsets, state.c:846-957) for every whole-pel vector and site -- the same two blocks in the same order."""
+    for vx in range(-15, 16):
+        for vy in (-15, -2, -1, 0, 1, 7, 15):
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    if dx == 0 and dy == 0:
+                        continue
+                    o0, o1 = oracle.halfpel_mvoffsets([vx], [vy], dx, dy, 416)
+                    n, a0, a1 = oracle.mv_offsets(416, 0, 0, 2 * vx + dx, 2 * vy + dy)
+                    base = vx + vy * 416
+                    assert n == 2 and (base + int(o0[0]), base + int(o1[0])) == (a0, a1), (vx, vy, dx, dy)

@@ -358,6 +358,24 @@ def enc_mb_cost_maps(planes, frame_width, frame_height, pixel_fmt):
     return satd, luma, act, fast
 
 
+def enc_metric_halfpel_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs, vecs, sites):
+    """thip_enc_frag_metric_halfpel_batch: every block against the half-pel vectors 2 * vec + (dx, dy), `sites` = [(dx, dy), ...]
+    without (0, 0), around its whole-pel vector (vecs: int16 tensor, x & 0xFF | y << 8; ref_offs: the block at that vector).
+    op "satd2" or "sad2_thresh".  Returns (values, dc), both [len(sites), nblocks]; dc is None for "sad2_thresh"."""
+    import numpy as np
+    import torch
+    n = src_offs.numel()
+    ns = len(sites)
+    out = torch.empty((ns, n), dtype=torch.int32, device=src_offs.device)
+    dc = torch.empty((ns, n), dtype=torch.int32, device=src_offs.device) if op == "satd2" else None
+    dx = np.array([s[0] for s in sites], np.int8)
+    dy = np.array([s[1] for s in sites], np.int8)
+    _lib.check(_lib.load().thip_enc_frag_metric_halfpel_batch(
+        _lib.ENC_OPS[op], _ptr(out), _ptr(dc), _ptr(src_plane), _ptr(ref_plane), ystride, _ptr(src_offs), _ptr(ref_offs), _ptr(vecs),
+        dx.ctypes.data, dy.ctypes.data, ns, n), "enc_frag_metric_halfpel_batch")
+    return out, dc
+
+
 def enc_metric_sites_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs, sites):
     """thip_enc_frag_metric_sites_batch: every block against the candidate positions `sites` = [(dx, dy), ...] around its
     reference position.  Returns (values, dc), both [len(sites), nblocks] (candidate-major); dc is None for "sad"."""

@@ -94,6 +94,7 @@ SYMBOLS = [
     ("thip_state_frag_recon_tokens", _I, [_P, C.c_ssize_t, _I, _P, _I, C.c_int16, _I, C.c_uint16, _I, _I, C.c_int16]),
     ("thip_enc_frag_metric_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _U32, _I64]),
     ("thip_enc_frag_metric_sites_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I64]),
+    ("thip_enc_frag_metric_halfpel_batch", _I, [_I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I64]),
     ("thip_enc_mb_count", _I, [_I, _I]),
     ("thip_enc_mb_cost_maps", _I, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P, _P]),
     ("thip_enc_frag_border_ssd_batch", _I, [_P, _P, _P, _I, _P, _P, _P, _I64]),
@@ -131,6 +132,7 @@ SYMBOLS = [
     ("thip_get_option", _I, [C.c_char_p, C.POINTER(_I)]),
     ("thip_option_name", C.c_char_p, [_I, C.POINTER(C.c_char_p)]),
     ("thip_option", _I, [C.c_char_p]),
+    ("thip_option_add", None, [C.c_char_p, _I]),
 ]
 
 # ---- th_decode_* API (include/theoradec_hip.h) ----------------------------------------------

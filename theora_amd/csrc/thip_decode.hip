@@ -85,11 +85,17 @@ Option g_options[] = {
     {"fe_worker_pin", 1, "th_decode_*, fe_worker on: 1 (default): the second thread is kept on the CPUs that share a last-level cache with the caller's; 0: left to the scheduler"},
     {"fe_lookahead", 8, "th_decode_*: packets a caller may announce ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), each parsed by a thread of its own on a parser context: 8 (default), up to 16; 0: announcements are not taken"},
     {"fe_assign", 2, "th_decode_*, announced packets on the token-list path: 1: the parser pairs tokens and fragments while it decodes the tokens and the frame goes to thip_state_token_lists_begin_assigned (k_tok_scatter: the device pairs nothing); 0: the device walks the lists (thip_state_token_lists_begin); 2 (default): whichever measures faster for this stream (24 frames each way, the better for 1024, and again)"},
+    {"fe_lookahead_adopted", 0, "(counter) announced packets whose th_decode_packetin found them parsed and took the frame over"},
+    {"fe_lookahead_missed", 0, "(counter) announced packets that were parsed for nothing: another packet came instead (everything announced is then dropped), or the parser refused the packet"},
+    {"fe_assign_settle", 1024, "th_decode_*, fe_assign = 2: adopted frames a stream keeps the rule that measured faster before it measures again (default 1024; tests shorten it)"},
+    {"fe_assign_to_device", 0, "(counter) fe_assign = 2: times a stream's rule went from the parsers pairing to the device walking (every measurement begins with one)"},
+    {"fe_assign_to_parsers", 0, "(counter) fe_assign = 2: times it went back to the parsers pairing (they measured faster, or a new measurement began)"},
     {"fe_levels", 0, "th_decode_*: 1: the host's own token walk hands the slots quantised levels (thip_state_frag_recon_levels: the kernel dequantises); 0 (default): dequantised coefficients"},
     {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
     {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
     {"sb_tiles", 600, "k_recon_lf_sb (one super block per wave, four lanes per block) instead of k_recon_lf for launches of fewer tiles than this (0: never)"},
+    {"stagger", 0, "thip_decode_frames: microseconds by which lane i's first launch is held back (i x stagger) when the call finds every lane of the device idle, so that the lanes' launches do not run in step (0: off)"},
     {"redo_descs", 0, "thip_decode_frames on the caller's descriptors: 1: the caller promises that the buffers a descriptor points to stay as they are until the state's next synchronising call, so a frame whose hand-over failed can be decoded again like a th_decode_* frame; 0 (default): such a frame gets THIP_EFAULT"},
     {"faults_recovered", 0, "(counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf had run out"},
 };
@@ -123,6 +129,11 @@ extern "C" int thip_option(const char *name) {
 }
 // ... and for this translation unit's per-frame reads: the entry is looked up once per call site, a read is one relaxed load
 #define THIP_OPT(name) ([]() -> int { static const Option *const o_ = find_option(name); return o_ ? o_->value.load(std::memory_order_relaxed) : 0; }())
+// (internal, for the counters thip_frontend.cpp keeps in the table)
+extern "C" void thip_option_add(const char *name, int delta) {
+  Option *o = find_option(name);
+  if (o) o->value.fetch_add(delta, std::memory_order_relaxed);
+}
 extern "C" int thip_set_option(const char *name, int value) {
   Option *o = find_option(name);
   if (!o) return THIP_EINVAL;
@@ -292,6 +303,7 @@ int g_ctx_ready[kMaxDevices], g_next_ctx[kMaxDevices];
 // thip_synchronize waits for the streams that got work since it last did: ten hipStreamSynchronize calls on idle streams are
 // tens of microseconds of host time, which a caller that brackets 0.8 ms of work with it (bench.py's blocks) would book as GPU time.
 std::atomic<uint8_t> g_lane_dirty[kMaxDevices][kMaxLanes], g_ctx_dirty[kMaxDevices][kCtxLanes];
+std::atomic<uint8_t> g_cold[kMaxDevices];   // set by thip_synchronize: the device's lanes are idle (option "stagger")
 
 // Makes `device` current for the calling host thread for the lifetime of the object (HIP's current
 // device is per thread) and puts the previous one back: a state may live on any GPU of the node
@@ -462,6 +474,18 @@ __global__ void k_xcc_probe(uint32_t *out) {
   uint32_t xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   if (threadIdx.x == 0) out[blockIdx.x] = xcc & 15u;
+}
+// Lanes that start together stay together: two launches of equal length that begin at the same moment have their ramps, their
+// arithmetic and their tails at the same moments, and the second lane is there to put one launch's tail under the other's body.
+// So in the first call after a thip_synchronize (every lane of the device is idle), lane i
+// first runs a wave that sleeps i * stagger microseconds (option "stagger", 0 = off).
+__global__ void k_stagger(uint32_t ticks) {   // ticks of s_memrealtime (100 MHz)
+  unsigned long long t0, t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  do {
+    __builtin_amdgcn_s_sleep(32);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  } while (t - t0 < ticks);
 }
 bool xcd_round_robin(int device) {   // the device must be current
   static std::mutex mu;
@@ -933,6 +957,7 @@ int thip_synchronize(void) {
     DeviceGuard dg(d);
     for (int i = 0; i < g_nlanes && g_lanes_ready[d]; i++)
       if (g_lane_dirty[d][i].exchange(0, std::memory_order_relaxed)) HIP_TRY(hipStreamSynchronize(g_lanes[d][i]));
+    g_cold[d].store(1, std::memory_order_relaxed);
     for (int i = 0; i < kCtxLanes; i++)
       if (g_ctx_ready[d] && g_ctx_lanes[d][i] && g_ctx_dirty[d][i].exchange(0, std::memory_order_relaxed)) HIP_TRY(hipStreamSynchronize(g_ctx_lanes[d][i]));
   }
@@ -1362,6 +1387,10 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
         std::lock_guard<std::mutex> lk(g_mu);
         states[i]->lane = g_next_lane[dev]++ % g_nlanes;
       }
+    const int stagger_us = THIP_OPT("stagger");
+    // (cold = the first call after a thip_synchronize: asking the streams -- hipStreamQuery -- puts markers into their queues,
+    //  which cost the lanes their overlap: measured 10 % of a step)
+    const bool cold = g_cold[dev].exchange(0, std::memory_order_relaxed) != 0 && stagger_us > 0 && g_nlanes > 1;
     for (int lane = 0; lane < g_nlanes; lane++)
      for (int form = 0; form < 2; form++) {   // (a chunk holds one coefficient form)
       thip_state *ls[THIP_MAX_BATCH];
@@ -1378,6 +1407,8 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
         }
         if (n == chunk_max || (i == nstreams && n > 0)) {
           g_lane_dirty[dev][lane].store(1, std::memory_order_relaxed);
+          if (cold && lane > 0 && form == (descs[li[0]].coeff_format == THIP_COEFFS_LEVELS ? 1 : 0))
+            hipLaunchKernelGGL(k_stagger, dim3(1), dim3(64), 0, g_lanes[dev][lane], (uint32_t)(lane * stagger_us * 100));
           rc = launch_chunk(ls, ld, n, g_lanes[dev][lane], lr);
           if (rc < 0) return rc;
           if (results)

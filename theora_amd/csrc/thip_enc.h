@@ -264,4 +264,121 @@ __global__ __launch_bounds__(256) void k_enc_sites(uint32_t *out, int32_t *dc_ou
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// half-pel refinement: every block against the half-pel positions around ONE whole-pel vector (mcenc.c:596-657)
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's refinement (oc_mcenc_ysatd_halfpel_mbrefine, mcenc.c:606-657; the SAD form :551-594) tries the eight half-pel
+// vectors 2 * vec + (dx, dy), (dx, dy) in {-1, 0, 1}^2 without the centre, each as oc_enc_frag_satd2 / oc_enc_frag_sad2_thresh
+// (encfrag.c:62-86, 323-328) of the source block against the truncating average of TWO whole-pel blocks: per axis the pair is
+// {0, d} and WHICH of the two blocks gets the step follows from the signs (mcenc.c:633-636: the block towards zero comes first,
+// as oc_state_get_mv_offsets has it); the average does not care which is first, so all that matters is whether the x step and the
+// y step of a diagonal site land on the same block -- the pair {(0, 0), (dx, dy)} -- or on different ones -- {(dx, 0), (0, dy)}.
+// One lane = one block and one dx (the grid's y: a wave has one dx, its branches are scalar): the ten rows around the whole-pel
+// position are loaded once per column (0 and dx) and serve the lane's two or three sites.  dx = 0: both sites average vertically
+// neighbouring rows, nine averaged rows prepared once (all three horizontal Hadamard levels) serve both.  Results site-major.
+__device__ __forceinline__ bool halfpel_first_gets_step(int v, int d) { return (((2 * v + d) ^ d) < 0); }   // OC_SIGNMASK(((vec<<1)+d)^d), mcenc.c:633-634
+template <int OP>
+__global__ __launch_bounds__(256) void k_enc_halfpel(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
+                                                    int ystride, const int32_t *src_offs, const int32_t *ref_offs, const int16_t *vecs,
+                                                    const SitesK K, int64_t nblocks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nblocks) return;
+  const int dxi = (int)blockIdx.y, dx = dxi - 1;
+  int c[3];
+#pragma unroll
+  for (int dyi = 0; dyi < 3; dyi++) c[dyi] = K.site_of[dyi * 3 + dxi];
+  if ((c[0] & c[1] & c[2]) < 0) return;
+  const int vv = vecs[i];
+  const int vx = (int)(int8_t)(vv & 0xFF), vy = (int)(int8_t)(vv >> 8);   // OC_MV_X / OC_MV_Y, state.h:232-240
+  uint2 s[8], e0[10], e1[10];
+  load_rows8(s, src_plane + src_offs[i], ystride);
+  const uint8_t *rp = ref_plane + ref_offs[i] - ystride;
+#pragma unroll
+  for (int r = 0; r < 10; r++) e0[r] = load_row8(rp + (ptrdiff_t)r * ystride);
+  if (dx != 0) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) e1[r] = load_row8(rp + (ptrdiff_t)r * ystride + dx);
+  }
+  constexpr bool kSad = OP == THIP_ENC_SAD2_THRESH;
+  pk16 S[8][4];
+  if (!kSad) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      row_sd(S[r], s[r]);
+      row_h12(S[r]);
+    }
+  }
+  if (dx == 0) {
+    // rows r, r + 1 averaged for r = 0..8 (pixel rows -1..7): the site above takes the first eight, the site below the last eight
+    uint2 a[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) a[r] = avg_row(e0[r], e0[r + 1]);
+    if (kSad) {
+#pragma unroll
+      for (int dyi = 0; dyi < 3; dyi += 2) {
+        if (c[dyi] < 0) continue;
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) v = sad_row(s[r], a[r + dyi / 2], v);
+        out[(int64_t)c[dyi] * nblocks + i] = v;
+      }
+    } else {
+      pk16 E[9][4];
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
+        row_sd(E[r], a[r]);
+        row_h12(E[r]);
+      }
+#pragma unroll
+      for (int dyi = 0; dyi < 3; dyi += 2) {
+        if (c[dyi] < 0) continue;
+        pk16 D[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) D[r][j] = S[r][j] - E[r + dyi / 2][j];
+        int dc;
+        const uint32_t v = satd_vert(D, dc);
+        out[(int64_t)c[dyi] * nblocks + i] = v;
+        if (dc_out) dc_out[(int64_t)c[dyi] * nblocks + i] = dc;
+      }
+    }
+    return;
+  }
+  const bool xfirst = halfpel_first_gets_step(vx, dx);
+#pragma unroll
+  for (int dyi = 0; dyi < 3; dyi++) {
+    if (c[dyi] < 0) continue;
+    const int dy = dyi - 1;
+    // the two blocks: {(0, 0), (dx, dy)} when both steps go to the same one, {(dx, 0), (0, dy)} otherwise (dy = 0: {(0, 0), (dx, 0)})
+    const bool same = dy == 0 || xfirst == halfpel_first_gets_step(vy, dy);
+    uint2 a[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const uint2 p0 = e0[r + 1], p1 = e1[r + 1], q0 = e0[r + 1 + dy], q1 = e1[r + 1 + dy];
+      a[r] = avg_row(same ? p0 : p1, same ? q1 : q0);
+    }
+    if (kSad) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int r = 0; r < 8; r++) v = sad_row(s[r], a[r], v);
+      out[(int64_t)c[dyi] * nblocks + i] = v;
+    } else {
+      pk16 D[8][4];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        pk16 B[4];
+        row_sd(B, a[r]);
+        row_h12(B);
+#pragma unroll
+        for (int j = 0; j < 4; j++) D[r][j] = S[r][j] - B[j];
+      }
+      int dc;
+      const uint32_t v = satd_vert(D, dc);
+      out[(int64_t)c[dyi] * nblocks + i] = v;
+      if (dc_out) dc_out[(int64_t)c[dyi] * nblocks + i] = dc;
+    }
+  }
+}
+
 }  // namespace thip

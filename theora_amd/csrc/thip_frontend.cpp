@@ -1511,6 +1511,13 @@ int th_decode_ctl(th_dec_ctx *d, int req, void *buf, size_t buf_sz) {
       d->device_lists = *(int *)buf != 0 ? 1 : 0;
       return 0;
     }
+    case TH_DECCTL_THIP_GET_DEVICE: {
+      if (!d || !buf) return TH_EFAULT;
+      if (buf_sz != sizeof(int)) return TH_EINVAL;
+      if (!d->hip) return TH_EINVAL;
+      *(int *)buf = thip_state_device(d->hip);
+      return 0;
+    }
     case TH_DECCTL_THIP_PREFETCH_PACKET:
       if (!d || !buf) return TH_EFAULT;
       if (buf_sz != sizeof(ogg_packet)) return TH_EINVAL;
@@ -2356,7 +2363,7 @@ struct FeLookahead {
   double pair_last = 0;    // when the previous adopted frame's th_decode_packetin began (0: the previous packet was not adopted)
   long pair_settled[2] = {0, 0};   // (statistics: how often each rule won)
 };
-constexpr int kFePairSample = 24, kFePairSettled = 1024;
+constexpr int kFePairSample = 24;   // (how long a measured rule is kept: option fe_assign_settle, 1024 frames)
 
 static void fe_init_frame_arrays(th_dec_ctx *d) {
   d->coded.assign(d->nfrags, 0);
@@ -2467,6 +2474,7 @@ static void fe_lookahead_drop(FeLookahead *la) {
     fe_slot_wait(sl);
   }
   la->missed += la->count;
+  thip_option_add("fe_lookahead_missed", la->count);
   la->head = la->count = 0;
 }
 
@@ -2582,6 +2590,9 @@ static int fe_prefetch(th_dec_ctx *d, const ogg_packet *op) {
 static FeSlot *fe_lookahead_take(th_dec_ctx *d, const ogg_packet *op) {
   FeLookahead *la = d->la;
   if (!la || !la->count) return nullptr;
+  // A dropped frame (a zero-byte packet, decode.c:2746) is never announced -- there is nothing to parse --, so it says nothing
+  // about the announcements around it: they stay where they are.
+  if (op->bytes <= 0) return nullptr;
   FeSlot &sl = la->slots[la->head];
   const bool same = op->bytes > 0 && op->bytes == sl.bytes && op->packet && !memcmp(op->packet, sl.pkt.data(), (size_t)sl.bytes) &&
                     !d->device_dc && !d->device_tokens;
@@ -2594,9 +2605,11 @@ static FeSlot *fe_lookahead_take(th_dec_ctx *d, const ogg_packet *op) {
   la->count--;
   if (sl.rc != kFeContinue) {   // a frame without coded blocks, a packet the parser refused: the owner says so itself (cheap)
     la->missed++;
+    thip_option_add("fe_lookahead_missed", 1);
     return nullptr;
   }
   la->adopted++;
+  thip_option_add("fe_lookahead_adopted", 1);
   return &sl;
 }
 
@@ -2676,18 +2689,21 @@ static void fe_pair_rule(FeLookahead *la, double now, bool adopted) {
       if (++la->pair_cnt[la->pair_phase] >= kFePairSample) {
         if (la->pair_phase == 0) {
           la->pair_mode = 0;
+          thip_option_add("fe_assign_to_device", 1);
         } else {
           const double with = la->pair_sum[0] / la->pair_cnt[0], without = la->pair_sum[1] / la->pair_cnt[1];
           la->pair_mode = with <= 1.03 * without ? 1 : 0;
           la->pair_settled[la->pair_mode]++;
+          if (la->pair_mode) thip_option_add("fe_assign_to_parsers", 1);
         }
         la->pair_phase++;
         la->pair_frames = 0;
       }
     }
-  } else if (la->pair_phase == 2 && ++la->pair_frames >= kFePairSettled) {
+  } else if (la->pair_phase == 2 && ++la->pair_frames >= std::max(1, thip_option("fe_assign_settle"))) {
     la->pair_phase = 0;
     la->pair_frames = 0;
+    if (!la->pair_mode) thip_option_add("fe_assign_to_parsers", 1);
     la->pair_mode = 1;
     la->pair_sum[0] = la->pair_sum[1] = 0;
     la->pair_cnt[0] = la->pair_cnt[1] = 0;

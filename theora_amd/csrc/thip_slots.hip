@@ -638,6 +638,33 @@ int thip_enc_frag_metric_sites_batch(int op, uint32_t *out, int32_t *dc_out, con
   return THIP_OK;
 }
 
+int thip_enc_frag_metric_halfpel_batch(int op, uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
+                                       int ystride, const int32_t *src_offs, const int32_t *ref_offs, const int16_t *vecs,
+                                       const int8_t *site_dx, const int8_t *site_dy, int nsites, int64_t nblocks) {
+  if (!out || !src_plane || !ref_plane || !src_offs || !ref_offs || !vecs || !site_dx || !site_dy) return THIP_EFAULT;
+  if ((op != THIP_ENC_SAD2_THRESH && op != THIP_ENC_SATD2) || nsites < 1 || nsites > 8 || nblocks < 0) return THIP_EINVAL;
+  SitesK K;
+  for (int k = 0; k < 9; k++) K.site_of[k] = -1;
+  K.nsites = nsites;
+  for (int c = 0; c < nsites; c++) {
+    if (site_dx[c] < -1 || site_dx[c] > 1 || site_dy[c] < -1 || site_dy[c] > 1 || (site_dx[c] == 0 && site_dy[c] == 0)) return THIP_EINVAL;
+    int8_t &slot = K.site_of[(site_dy[c] + 1) * 3 + (site_dx[c] + 1)];
+    if (slot >= 0) return THIP_EINVAL;   // a position asked for twice
+    slot = (int8_t)c;
+  }
+  if (nblocks == 0) return THIP_OK;
+  const dim3 grid((unsigned)((nblocks + 255) / 256), 3);
+  if (op == THIP_ENC_SAD2_THRESH)
+    hipLaunchKernelGGL(k_enc_halfpel<THIP_ENC_SAD2_THRESH>, grid, dim3(256), 0, g_batch_stream, out, dc_out, src_plane, ref_plane, ystride,
+                       src_offs, ref_offs, vecs, K, nblocks);
+  else
+    hipLaunchKernelGGL(k_enc_halfpel<THIP_ENC_SATD2>, grid, dim3(256), 0, g_batch_stream, out, dc_out, src_plane, ref_plane, ystride,
+                       src_offs, ref_offs, vecs, K, nblocks);
+  HIP_TRY(hipGetLastError());
+  if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
+  return THIP_OK;
+}
+
 int thip_enc_frag_border_ssd_batch(uint32_t *out, const uint8_t *src_plane, const uint8_t *ref_plane,
                                    int ystride, const int32_t *src_offs, const int32_t *ref_offs,
                                    const int64_t *masks, int64_t n) {

@@ -57,3 +57,15 @@ def reduce_min(value, device):
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return int(t.item())
+
+
+def gather_floats(value, device):
+    """One float of every rank, in rank order (e.g. every rank's own median step time: whether "RCCL saw N ranks" and how far
+    the ranks are apart can then be read off the line rank 0 prints)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    world = dist.get_world_size()
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return [float(p.item()) for p in parts]

@@ -224,6 +224,27 @@ def gen_frame(geom, rng, frame_type, content="mixed", flimit=None, global_mv=Non
                 levels=levels, qii=qii.astype(np.uint8), dequant=dequant)
 
 
+def widen_tiles(geom, frame, frac, rng):
+    """A copy of `frame` in which a share `frac` of the tiles that hold a block with coefficients got ONE level beyond eight bits
+    (300 at zig-zag index 1 of one of their blocks): in the levels form such a tile is wide (include/theora_hip.h THIP_SLOT_WIDE).
+    Returns (frame, number of tiles widened)."""
+    out = dict(frame)
+    cf = frame["coded_fragis"]
+    has = np.nonzero(frame["last_zzi"] >= 2)[0]            # coded blocks that carry AC coefficients
+    if has.size == 0:
+        return out, 0
+    tile = geom.frag_pos[cf[has]] // 64
+    tiles, first = np.unique(tile, return_index=True)
+    pick = rng.random(tiles.size) < frac
+    blocks = has[first[pick]]
+    levels = np.array(frame["levels"], np.int16, copy=True)
+    levels[blocks, FZIG_ZAG[1]] = 300
+    out["levels"] = levels
+    co = dequantise(geom, out)
+    out["coeffs"] = co
+    return out, int(pick.sum())
+
+
 def nothing_coded(geom, frame, frame_type=None):
     """The frame with no coded fragment at all (decode.c:2764-2772: a duplicate of the previous frame)."""
     out = dict(frame)
