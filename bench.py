@@ -62,7 +62,8 @@ def _usable_cores():
 def _cpu_worker(job):
     """One process of the all-cores CPU baseline: the oracle decoding `nframes` frames of stream 0
     (regenerated here from its seed: nothing but numbers crosses the process boundary)."""
-    size, content, pool, nframes = job
+    size, content, pool, nframes = job[:4]
+    simd = len(job) > 4 and bool(job[4])
     import oracle
     import theora_amd
     from theora_amd import shard, synth
@@ -72,7 +73,7 @@ def _cpu_worker(job):
     frames = [synth.gen_frame(geom, rng, theora_amd.INTRA_FRAME, content, flimit=2)]
     for _ in range(pool):
         frames.append(synth.gen_frame(geom, rng, theora_amd.INTER_FRAME, content, flimit=2))
-    ost = oracle.State(w, h)
+    ost = oracle.State(w, h, simd=simd)
     t = 0.0
     for i in range(nframes):
         fr = frames[0 if i % KF_INTERVAL == 0 else 1 + (i % pool)]
@@ -442,6 +443,26 @@ def main_enc(emit=True, subset=False):
         uniq = 2 * nblk * 64 + src_offs.size * (4 if op == "sad" else 8)
         results.append(dict(kernel="oc_enc_frag_%s, motion-search form (thip_enc_frag_metric_sites_batch)" % op, units=src_offs.size,
                             unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=ncpu / tc_pairs, unique_bytes=uniq))
+    # --- the half-pel refinement around each block's whole-pel vector: eight sites (thip_enc_frag_metric_halfpel_batch; what the
+    #     reference does with eight oc_enc_frag_satd2 / oc_enc_frag_sad2_thresh calls per block, mcenc.c:551-657) -----------------------
+    hp_sites = [(-1, -1), (0, -1), (1, -1), (-1, 0), (1, 0), (-1, 1), (0, 1), (1, 1)]
+    vecs = ((rng.integers(-2, 3, nblk) & 0xFF) | (rng.integers(-2, 3, nblk) << 8)).astype(np.int16)
+    d_vecs = torch.from_numpy(vecs).cuda()
+    for op, bpu in (("satd2", 136 + 64), ("sad2_thresh", 132 + 64)):
+        call = lambda: theora_amd.enc_metric_halfpel_batch(op, d_cur, d_prev, stride, d_base, d_base, d_vecs, hp_sites)   # noqa: E731
+        t = timed(call)
+        v, dc = call()
+        ncpu = 6000
+        sel = rng.integers(0, nblk, ncpu)
+        t0 = time.perf_counter()
+        wv, wdc = oracle.enc_halfpel_sites(op, cur, prev, stride, base[sel], base[sel], vecs[sel], hp_sites)
+        tc_pairs = time.perf_counter() - t0
+        assert np.array_equal(wv, v.cpu().numpy().view(np.uint32)[:, sel])
+        if dc is not None:
+            assert np.array_equal(wdc, dc.cpu().numpy()[:, sel])
+        results.append(dict(kernel="oc_enc_frag_%s, half-pel refinement form (thip_enc_frag_metric_halfpel_batch)" % op, units=nblk * len(hp_sites),
+                            unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=ncpu * len(hp_sites) / tc_pairs,
+                            unique_bytes=2 * nblk * 64 + nblk * 2 + nblk * len(hp_sites) * (4 if op != "satd2" else 8)))
     # --- ... and over several frames in one call (a single frame is one round of waves: its launch ramp, first loads and tail
     #     are a third of the call; an encoder with more than one stream to search hands them over together) -------------------
     for F in ((4,) if subset else (2, 4)):
@@ -771,6 +792,14 @@ def main():
                              "states in the timed launch shape (one thip_decode_frames call per step), every plane of "
                              "every stream against the oracle" % (S, " (x %d key-frame intervals side by side)" % G if G > 1 else "", nparity)}
         def cpu_all_cores(cb):
+            # the vectorised build of the same decoder (oracle/Makefile -DORC_SIMD: inverse transform, reconstruction and loop-filter
+            # edges as SSE2 intrinsics, equal to the scalar build value for value, tests/test_oracle.py), one core
+            nsimd = max(16, args.cpu_frames // 2)
+            ts = _cpu_worker((args.size, args.content, args.pool, nsimd, True))
+            cb["simd"] = {"value": round(nsimd / ts, 3), "unit": "frames/s", "cores": 1, "kind": "port, simd",
+                          "sample": "%d frames of the same stream through oracle/_build/libtheora_oracle_simd.so" % nsimd,
+                          "note": "own SSE2 code for the three hot loops, the rest scalar; the reference's x86 path (which cannot be built "
+                                  "here: no libogg) also vectorises its loop filter's row order and runs MMX/SSE2 assembly throughout"}
             # the same decoder on every core the box gives us, one process per core (the reference is
             # single-threaded per stream; many streams are many processes)
             ncores = min(_usable_cores(), 64)
@@ -779,15 +808,16 @@ def main():
                 per = max(16, args.cpu_frames // 4)
                 with mp.get_context("spawn").Pool(ncores) as pool_:
                     times = pool_.map(_cpu_worker, [(args.size, args.content, args.pool, per)] * ncores)
+                    times_simd = pool_.map(_cpu_worker, [(args.size, args.content, args.pool, per, True)] * ncores)
                 cb["all_cores"] = {"value": round(ncores * per / max(times), 2), "unit": "frames/s", "cores": ncores,
-                                   "sample": "%d processes x %d frames, decode time of the slowest" % (ncores, per)}
+                                   "sample": "%d processes x %d frames, decode time of the slowest" % (ncores, per),
+                                   "simd": round(ncores * per / max(times_simd), 2)}
         if rank == 0 and not args.no_cpu_baseline and not cpu_late:
             cpu_baseline = {"value": round(n_cpu / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                             "sample": "%d frames of one %s %s stream through oracle/theora_oracle.c "
                                       "(scalar C restatement of the reference's C path, gcc -O2)" % (n_cpu, args.size, args.content),
-                            "note": "a scalar-C port, not libtheora's x86 SIMD path (which cannot be built here: no libogg); "
-                                    "SURVEY section 6 measured the reference's SIMD build at about 2.4x its C build on this "
-                                    "kind of content, so the reference on one of these cores would be roughly 2.4x this figure"}
+                            "note": "a scalar-C port, not libtheora's x86 SIMD path (which cannot be built here: no libogg); the "
+                                    "vectorised build of the same port is timed beside it (simd)"}
             cpu_all_cores(cpu_baseline)
 
     # ---- timed region ---------------------------------------------------------------------

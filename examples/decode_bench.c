@@ -3,7 +3,7 @@
  * batch configuration, end to end: packets in host memory -> frames in host memory).
  *
  *   cc -O2 -pthread -Iinclude examples/decode_bench.c -Ltheora_amd -ltheora_hip -o decode_bench
- *   decode_bench in.ogv <threads> <loops> [--no-output] [--lookahead K] [--devices]
+ *   decode_bench in.ogv <threads> <loops> [--no-output] [--lookahead K] [--pipeline] [--devices]
  *
  * --lookahead K: every stream announces its packets K ahead (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET, what a player does
  * with the packets its demultiplexer has queued): the library parses them on threads of its own and th_decode_packetin only
@@ -73,10 +73,11 @@ static void *run(void *arg) {
 
 int main(int argc, char **argv) {
   if (argc < 4) {
-    fprintf(stderr, "usage: %s in.ogv <threads> <loops> [--no-output] [--lookahead K] [--devices]\n", argv[0]);
+    fprintf(stderr, "usage: %s in.ogv <threads> <loops> [--no-output] [--lookahead K] [--pipeline] [--devices]\n", argv[0]);
     return 1;
   }
   const int nthreads = atoi(argv[2]);
+  int pipeline = 0;
   int check_devices = 0;   /* --devices: every context must sit on the GPU its turn gives it (context i on device i mod the node's GPUs) */
   g_loops = atoi(argv[3]);
   g_output = 1;
@@ -84,7 +85,9 @@ int main(int argc, char **argv) {
     if (!strcmp(argv[a], "--no-output")) g_output = 0;
     else if (!strcmp(argv[a], "--lookahead") && a + 1 < argc) g_ahead = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--devices")) check_devices = 1;
+    else if (!strcmp(argv[a], "--pipeline")) pipeline = 1;   /* option fe_pipeline: the next announced frame goes to the device inside th_decode_ycbcr_out */
   }
+  if (pipeline) thip_set_option("fe_pipeline", 1);
   thip_ogg_reader *og = thip_ogg_open_file(argv[1]);
   if (!og || nthreads < 1 || g_loops < 1) return 1;
   /* all packets of the first logical stream */
@@ -158,10 +161,10 @@ int main(int argc, char **argv) {
   clock_gettime(CLOCK_MONOTONIC, &t1);
   const double el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
   printf("{\"streams\": %d, \"host_threads\": %d, \"frames\": %ld, \"seconds\": %.4f, \"frames_per_s\": %.1f, "
-         "\"size\": \"%ux%u\", \"gpus\": %d, \"with_ycbcr_out\": %s, \"lookahead\": %d, \"ok\": %s}\n",
+         "\"size\": \"%ux%u\", \"gpus\": %d, \"with_ycbcr_out\": %s, \"lookahead\": %d, \"pipeline\": %d, \"ok\": %s}\n",
          nthreads, nthreads, frames, el, el > 0 ? (double)frames / el : 0.0, (unsigned)ti.frame_width, (unsigned)ti.frame_height,
          ndev < nthreads ? ndev : nthreads,
-         g_output ? "true" : "false", g_ahead, bad ? "false" : "true");
+         g_output ? "true" : "false", g_ahead, pipeline, bad ? "false" : "true");
   for (i = 0; i < nthreads; i++) th_decode_free(w[i].dec);
   th_comment_clear(&tc);
   th_info_clear(&ti);

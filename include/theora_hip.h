@@ -92,6 +92,12 @@ int thip_state_ycbcr_out(thip_state *st, uint8_t *const dst[3], const int32_t ds
    (theoradec.h:283-299) they belong to the decoder and must not be written; they stay intact until
    the SECOND following frame has been decoded (two images alternate). */
 int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strides[3]);
+/* The same in two halves: _begin names the picture of the frame decoded last (launching its copy to the host if need be), the
+   caller may then hand the NEXT frame over -- it goes to the other of the state's two host images -- and _end waits for the named
+   picture and hands it out (what th_decode_ycbcr_out does with option fe_pipeline).  THIP_EINVAL without a _begin; THIP_EFAULT
+   from _end if the named frame's hand-over failed: with the next frame on the device it cannot be repeated any more. */
+int thip_state_ycbcr_map_begin(thip_state *st);
+int thip_state_ycbcr_map_end(thip_state *st, const uint8_t *planes[3], int32_t strides[3]);
 /* on != 0: every decoded frame of this state is sent to its pinned host image by the launch that
    decodes it (a kernel behind the loop filter writes it across PCIe), so that
    thip_state_ycbcr_map / _out only wait.  Off by default: a caller that keeps frames on the
@@ -567,8 +573,7 @@ const char *thip_version_string(void);
  *   debug        k_recon ablation switches (profiling); 256: k_recon_lf's cells copy without filtering; 512: tile 1 of every
  *                stream mis-tags its edge units, so that a hand-over fails and the recovery below can be tested
  *   faults_recovered   (counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf ran out
- *   stagger      thip_decode_frames: when a call finds every lane of the device idle, lane i's launch is held back i x stagger
- *                microseconds by a sleeping wave, so that launches of equal length on different lanes do not run in step (0 = off)
+ *   enc_fq_lanes   thip_enc_fdct_quantize_batch: 4 (default) four lanes per block, 1 one block per lane
  *   redo_descs   thip_decode_frames on the caller's descriptors: 1 = the caller promises that the buffers a descriptor points to stay
  *                as they are until the state's next synchronising call, so a frame whose hand-over failed is decoded again (default 0:
  *                THIP_EFAULT, see thip_synchronize)
@@ -604,6 +609,15 @@ const char *thip_version_string(void);
  *                device walks the lists (k_tok_assign / k_tok_walk); 2 (default): measured per stream -- the time between
  *                adopted frames, 24 frames each way, the better rule for the next 1024 (pairing moves 3.5-4.3 ns a token
  *                from the device's critical path to the parser threads: right when they have room, wrong when they are the bound)
+ *   fe_pipeline  th_decode_*, with packets announced ahead: 1: th_decode_ycbcr_out(N) hands frame N + 1 -- the oldest announced packet,
+ *                if its parser is done -- to the device BEFORE it waits for picture N, so that the device never waits for the caller's
+ *                thread (one 720p stream, eight ahead: +60 %).  The announcement becomes a promise: the next th_decode_packetin
+ *                must bring that packet (TH_EINVAL otherwise; zero-byte packets in between are fine), and a failed tile hand-over
+ *                of frame N is THIP_EFAULT instead of a frame decoded again.  0 (default): off.  fe_pipelined: (counter) such frames
+ *   fe_lists_rule   th_decode_*, fe_device_lists = -1: 1 (default): lists on the device or the host's own walk, measured per context
+ *                (the time between its th_decode_packetin calls, 16 inter frames each way, the faster for fe_assign_settle frames, and
+ *                again); 0: the count of contexts alive decides (rounds 3 and 4).  fe_lists_to_device, fe_lists_to_host: (counters) how
+ *                often a context changed sides
  *   fe_lookahead_adopted, fe_lookahead_missed   (counters) announced packets taken over by their th_decode_packetin / parsed for
  *                nothing (a different packet came -- every announcement outstanding is then dropped -- or the parser refused it; a
  *                zero-byte packet, i.e. a dropped frame, leaves the announcements where they are)

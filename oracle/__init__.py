@@ -21,8 +21,9 @@ def build(force=False):
     """Compile the C restatement with gcc (seconds)."""
     src = os.path.join(_HERE, "theora_oracle.c")
     hdr = os.path.join(_HERE, "theora_oracle.h")
-    if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    newest = max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(os.path.join(_HERE, "Makefile")))
+    if (not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= newest
+            and os.path.exists(_SO_SIMD) and os.path.getmtime(_SO_SIMD) >= newest):
         return _SO
     subprocess.check_call(["make", "-s", "-B", "-C", _HERE])
     return _SO
@@ -48,15 +49,31 @@ class _State(C.Structure):
                 ("plane_off", C.c_ssize_t * 3)]
 
 
+_SO_SIMD = os.path.join(_HERE, "_build", "libtheora_oracle_simd.so")
 _lib = None
+_lib_simd = None
 
 
-def lib():
-    global _lib
+def lib(simd=False):
+    """The oracle library; simd=True: the build whose inverse transform, reconstruction loops and loop-filter edges are SSE2
+    intrinsics (oracle/Makefile, -DORC_SIMD) -- bench.py's vectorised CPU baseline, equal to the scalar one value for value
+    (tests/test_oracle.py)."""
+    global _lib, _lib_simd
+    if simd:
+        if _lib_simd is None:
+            build()
+            if not os.path.exists(_SO_SIMD):
+                subprocess.check_call(["make", "-s", "-B", "-C", _HERE])
+            _lib_simd = _bind(C.CDLL(_SO_SIMD))
+        return _lib_simd
     if _lib is not None:
         return _lib
     build()
-    L = C.CDLL(_SO)
+    _lib = _bind(C.CDLL(_SO))
+    return _lib
+
+
+def _bind(L):
     P = C.c_void_p
     L.orc_state_new.restype = C.POINTER(_State)
     L.orc_state_new.argtypes = [C.c_int] * 3
@@ -104,7 +121,6 @@ def lib():
         f = getattr(L, name)
         f.restype = res
         f.argtypes = args
-    _lib = L
     return L
 
 
@@ -119,8 +135,8 @@ def _c(a, dt):
 class State:
     """The oracle's restatement of the path-relevant part of oc_theora_state."""
 
-    def __init__(self, frame_width, frame_height, pixel_fmt=PF_420):
-        self._L = lib()
+    def __init__(self, frame_width, frame_height, pixel_fmt=PF_420, simd=False):
+        self._L = lib(simd)
         self._st = self._L.orc_state_new(frame_width, frame_height, pixel_fmt)
         if not self._st:
             raise ValueError("invalid frame geometry")

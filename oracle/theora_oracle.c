@@ -156,6 +156,85 @@ static void idct8x8_zz10(int16_t y[64], int16_t x[64]) {
   x[0] = x[1] = x[2] = x[3] = x[8] = x[9] = x[10] = x[16] = x[17] = x[24] = 0;
 }
 
+#ifdef ORC_SIMD
+/* ------------------------------------------------------------------------------------------------------------------
+   The SSE2 legs of this file (built only into _build/libtheora_oracle_simd.so, -DORC_SIMD): own intrinsics code for the three
+   hot loops -- the full 8x8 inverse transform, the three reconstruction loops and the loop filter's two edge filters -- so
+   that bench.py's cpu_baseline has a figure from a VECTORISED CPU path measured on the box, beside the scalar one (BASELINE.md
+   section 4.2; the reference's own x86 path cannot be built here).  tests/test_oracle.py proves them equal to the scalar
+   functions above and below, value for value; nothing else differs between the two libraries.
+   ------------------------------------------------------------------------------------------------------------------ */
+#include <emmintrin.h>
+static void idct8_all(int16_t *y, const int16_t x[8]);
+static void (*const orc_scalar_idct8_all)(int16_t *, const int16_t *) __attribute__((unused)) = idct8_all;   /* (the scalar pass stays compiled) */
+/* (c * v) >> 16 on eight int16: pmulhw is signed x signed, so a constant beyond 32767 goes in as c - 65536 and v is added back
+   (floor(c v / 65536) = floor((c - 65536) v / 65536) + v, v being an integer) */
+static inline __m128i q16v(int c, __m128i v) {
+  if (c >= 32768) return _mm_add_epi16(_mm_mulhi_epi16(v, _mm_set1_epi16((short)(c - 65536))), v);
+  return _mm_mulhi_epi16(v, _mm_set1_epi16((short)c));
+}
+static inline void transpose8x8_epi16(__m128i r[8]) {
+  __m128i a0 = _mm_unpacklo_epi16(r[0], r[1]), a1 = _mm_unpackhi_epi16(r[0], r[1]);
+  __m128i a2 = _mm_unpacklo_epi16(r[2], r[3]), a3 = _mm_unpackhi_epi16(r[2], r[3]);
+  __m128i a4 = _mm_unpacklo_epi16(r[4], r[5]), a5 = _mm_unpackhi_epi16(r[4], r[5]);
+  __m128i a6 = _mm_unpacklo_epi16(r[6], r[7]), a7 = _mm_unpackhi_epi16(r[6], r[7]);
+  __m128i b0 = _mm_unpacklo_epi32(a0, a2), b1 = _mm_unpackhi_epi32(a0, a2);
+  __m128i b2 = _mm_unpacklo_epi32(a1, a3), b3 = _mm_unpackhi_epi32(a1, a3);
+  __m128i b4 = _mm_unpacklo_epi32(a4, a6), b5 = _mm_unpackhi_epi32(a4, a6);
+  __m128i b6 = _mm_unpacklo_epi32(a5, a7), b7 = _mm_unpackhi_epi32(a5, a7);
+  r[0] = _mm_unpacklo_epi64(b0, b4); r[1] = _mm_unpackhi_epi64(b0, b4);
+  r[2] = _mm_unpacklo_epi64(b1, b5); r[3] = _mm_unpackhi_epi64(b1, b5);
+  r[4] = _mm_unpacklo_epi64(b2, b6); r[5] = _mm_unpackhi_epi64(b2, b6);
+  r[6] = _mm_unpacklo_epi64(b3, b7); r[7] = _mm_unpackhi_epi64(b3, b7);
+}
+/* idct8_all (idct.c:30-81) on eight vectors at once: v[k] holds input k of eight independent 1-D transforms; on return v[k] is
+   output k.  Additions wrap at 16 bits, which is what the scalar code's (ogg_int16_t) casts make of its int32 sums: between two
+   casts it only adds and subtracts. */
+static inline void idct8_all_v(__m128i v[8]) {
+  __m128i t0 = q16v(C4, _mm_add_epi16(v[0], v[4]));
+  __m128i t1 = q16v(C4, _mm_sub_epi16(v[0], v[4]));
+  __m128i t2 = _mm_sub_epi16(q16v(C6, v[2]), q16v(C2, v[6]));
+  __m128i t3 = _mm_add_epi16(q16v(C2, v[2]), q16v(C6, v[6]));
+  __m128i t4 = _mm_sub_epi16(q16v(C7, v[1]), q16v(C1, v[7]));
+  __m128i t5 = _mm_sub_epi16(q16v(C3, v[5]), q16v(C5, v[3]));
+  __m128i t6 = _mm_add_epi16(q16v(C5, v[5]), q16v(C3, v[3]));
+  __m128i t7 = _mm_add_epi16(q16v(C1, v[1]), q16v(C7, v[7]));
+  __m128i r;
+  r = _mm_add_epi16(t4, t5); t5 = q16v(C4, _mm_sub_epi16(t4, t5)); t4 = r;
+  r = _mm_add_epi16(t7, t6); t6 = q16v(C4, _mm_sub_epi16(t7, t6)); t7 = r;
+  r = _mm_add_epi16(t0, t3); t3 = _mm_sub_epi16(t0, t3); t0 = r;
+  r = _mm_add_epi16(t1, t2); t2 = _mm_sub_epi16(t1, t2); t1 = r;
+  r = _mm_add_epi16(t6, t5); t5 = _mm_sub_epi16(t6, t5); t6 = r;
+  v[0] = _mm_add_epi16(t0, t7);
+  v[1] = _mm_add_epi16(t1, t6);
+  v[2] = _mm_add_epi16(t2, t5);
+  v[3] = _mm_add_epi16(t3, t4);
+  v[4] = _mm_sub_epi16(t3, t4);
+  v[5] = _mm_sub_epi16(t2, t5);
+  v[6] = _mm_sub_epi16(t1, t6);
+  v[7] = _mm_sub_epi16(t0, t7);
+}
+/* idct.c:286-296: every 1-D pass reads rows and writes columns, i.e. transposes; with input k of eight transforms in v[k] the
+   pass itself needs the rows transposed first and leaves output k of all eight rows in v[k] = row k of the transposed result */
+void orc_idct8x8_full(int16_t y[64], int16_t x[64]) {
+  __m128i v[8];
+  const __m128i eight = _mm_set1_epi16(8);
+  int i;
+  for (i = 0; i < 8; i++) v[i] = _mm_loadu_si128((const __m128i *)(x + i * 8));
+  transpose8x8_epi16(v);
+  idct8_all_v(v);
+  transpose8x8_epi16(v);
+  idct8_all_v(v);
+  /* (y + 8) >> 4 as the scalar code has it: the sum in int32, the result cast -- y + 8 can pass 32767, so the vector form
+     shifts first: ((y >> 3) + 1) >> 1 is the same number for every int16 y */
+  (void)eight;
+  for (i = 0; i < 8; i++) {
+    const __m128i h = _mm_add_epi16(_mm_srai_epi16(v[i], 3), _mm_set1_epi16(1));
+    _mm_storeu_si128((__m128i *)(y + i * 8), _mm_srai_epi16(h, 1));
+  }
+  memset(x, 0, 64 * sizeof(*x));
+}
+#else
 /* idct.c:286-296 */
 void orc_idct8x8_full(int16_t y[64], int16_t x[64]) {
   int16_t w[64];
@@ -165,6 +244,7 @@ void orc_idct8x8_full(int16_t y[64], int16_t x[64]) {
   idct_descale(y);
   memset(x, 0, 64 * sizeof(*x));
 }
+#endif
 
 /* idct.c:301-330 */
 void orc_idct8x8(int16_t y[64], int16_t x[64], int last_zzi) {
@@ -201,6 +281,35 @@ void orc_frag_copy_list(uint8_t *dst_frame, const uint8_t *src_frame, int ystrid
   }
 }
 
+#ifdef ORC_SIMD
+/* clamp255(residue + predictor) for a row of eight: the sum saturates at 16 bits (a residue near 32767 still ends as 255, as the
+   int sum does), packuswb clamps to 0..255 */
+static inline void recon_row_v(uint8_t *dst, const int16_t *res, __m128i pred16) {
+  const __m128i sum = _mm_adds_epi16(_mm_loadu_si128((const __m128i *)res), pred16);
+  _mm_storel_epi64((__m128i *)dst, _mm_packus_epi16(sum, sum));
+}
+void orc_frag_recon_intra(uint8_t *dst, int ystride, const int16_t residue[64]) { /* fragment.c:49-57 */
+  const __m128i p = _mm_set1_epi16(128);
+  int i;
+  for (i = 0; i < 8; i++, dst += ystride) recon_row_v(dst, residue + i * 8, p);
+}
+void orc_frag_recon_inter(uint8_t *dst, const uint8_t *src, int ystride, const int16_t residue[64]) { /* fragment.c:59-68 */
+  const __m128i z = _mm_setzero_si128();
+  int i;
+  for (i = 0; i < 8; i++, dst += ystride, src += ystride)
+    recon_row_v(dst, residue + i * 8, _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i *)src), z));
+}
+void orc_frag_recon_inter2(uint8_t *dst, const uint8_t *src1, const uint8_t *src2, int ystride,
+                           const int16_t residue[64]) {                   /* fragment.c:70-80 */
+  const __m128i z = _mm_setzero_si128();
+  int i;
+  for (i = 0; i < 8; i++, dst += ystride, src1 += ystride, src2 += ystride) {
+    const __m128i a = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i *)src1), z);
+    const __m128i b = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i *)src2), z);
+    recon_row_v(dst, residue + i * 8, _mm_srli_epi16(_mm_add_epi16(a, b), 1));   /* (a + b) >> 1, truncating */
+  }
+}
+#else
 void orc_frag_recon_intra(uint8_t *dst, int ystride, const int16_t residue[64]) { /* fragment.c:49-57 */
   int i, j;
   for (i = 0; i < 8; i++, dst += ystride)
@@ -220,6 +329,7 @@ void orc_frag_recon_inter2(uint8_t *dst, const uint8_t *src1, const uint8_t *src
   for (i = 0; i < 8; i++, dst += ystride, src1 += ystride, src2 += ystride)
     for (j = 0; j < 8; j++) dst[j] = clamp255(residue[i * 8 + j] + ((src1[j] + src2[j]) >> 1));
 }
+#endif
 
 /* ------------------------------------------------------------------------- */
 /* motion vector -> buffer offsets, state.c:846-957                           */
@@ -443,6 +553,73 @@ void orc_loop_filter_init(int8_t bv[256], int flimit) {                   /* sta
   }
 }
 
+#ifdef ORC_SIMD
+/* The table of oc_loop_filter_init tabulates lflim(R) = sign(R) * min(|R|, max(2L - |R|, 0)) for R = (f + 4) >> 3 (state.c:1036-1045,
+   spec 7.10); on vectors the function itself: with a = clamp(R, -L, L), lflim(R) = a - clamp(R - a, -L, L).  L is read back
+   from the table (its largest entry: lflim(L) = L).  p2..p5: the four pixels across the edge as int16; returns the new p3, p4. */
+static inline int lf_limit_of(const int8_t *bv127) {
+  /* lflim(R) = R for 0 <= R <= L and falls from there: the first index whose entry is not its own number ends the ramp */
+  int L = 0;
+  while (L < 127 && bv127[L + 1] == L + 1) L++;
+  return L;
+}
+static inline void lf_filter_v(__m128i p2, __m128i *p3, __m128i *p4, __m128i p5, int L) {
+  const __m128i l = _mm_set1_epi16((short)L), nl = _mm_set1_epi16((short)-L);
+  const __m128i d = _mm_sub_epi16(*p4, *p3);
+  const __m128i f = _mm_add_epi16(_mm_sub_epi16(p2, p5), _mm_add_epi16(d, _mm_add_epi16(d, d)));
+  const __m128i R = _mm_srai_epi16(_mm_add_epi16(f, _mm_set1_epi16(4)), 3);
+  const __m128i a = _mm_max_epi16(_mm_min_epi16(R, l), nl);
+  const __m128i b = _mm_max_epi16(_mm_min_epi16(_mm_sub_epi16(R, a), l), nl);
+  const __m128i lf = _mm_sub_epi16(a, b);
+  *p3 = _mm_add_epi16(*p3, lf);       /* clamped to 0..255 by the caller's packuswb */
+  *p4 = _mm_sub_epi16(*p4, lf);
+}
+/* state.c:1002-1016: eight rows, four pixels each around the edge -- transposed into four vectors of eight, filtered, the two
+   changed columns written back */
+static void lf_across_vertical_edge(uint8_t *pix, int ystride, const int8_t *bv127) {
+  const __m128i z = _mm_setzero_si128();
+  const int L = lf_limit_of(bv127);
+  __m128i r[8], p2, p3, p4, p5, o;
+  uint8_t q3[16], q4[16];
+  int y;
+  for (y = 0; y < 8; y++) {
+    int32_t w;
+    memcpy(&w, pix + (ptrdiff_t)y * ystride - 2, 4);
+    r[y] = _mm_unpacklo_epi8(_mm_cvtsi32_si128(w), z);      /* four int16: p2 p3 p4 p5 of row y */
+  }
+  {
+    /* 8 rows x 4 columns of int16 -> 4 vectors of 8 */
+    const __m128i a0 = _mm_unpacklo_epi16(r[0], r[1]), a1 = _mm_unpacklo_epi16(r[2], r[3]);
+    const __m128i a2 = _mm_unpacklo_epi16(r[4], r[5]), a3 = _mm_unpacklo_epi16(r[6], r[7]);
+    const __m128i b0 = _mm_unpacklo_epi32(a0, a1), b1 = _mm_unpackhi_epi32(a0, a1);
+    const __m128i b2 = _mm_unpacklo_epi32(a2, a3), b3 = _mm_unpackhi_epi32(a2, a3);
+    p2 = _mm_unpacklo_epi64(b0, b2);
+    p3 = _mm_unpackhi_epi64(b0, b2);
+    p4 = _mm_unpacklo_epi64(b1, b3);
+    p5 = _mm_unpackhi_epi64(b1, b3);
+  }
+  lf_filter_v(p2, &p3, &p4, p5, L);
+  o = _mm_packus_epi16(p3, p4);
+  _mm_storeu_si128((__m128i *)q3, o);
+  memcpy(q4, q3 + 8, 8);
+  for (y = 0; y < 8; y++) {
+    pix[(ptrdiff_t)y * ystride - 1] = q3[y];
+    pix[(ptrdiff_t)y * ystride] = q4[y];
+  }
+}
+/* state.c:1018-1031: eight columns at once, the four rows across the edge as they lie in memory */
+static void lf_across_horizontal_edge(uint8_t *pix, int ystride, const int8_t *bv127) {
+  const __m128i z = _mm_setzero_si128();
+  const int L = lf_limit_of(bv127);
+  const __m128i p2 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i *)(pix - 2 * (ptrdiff_t)ystride)), z);
+  __m128i p3 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i *)(pix - (ptrdiff_t)ystride)), z);
+  __m128i p4 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i *)pix), z);
+  const __m128i p5 = _mm_unpacklo_epi8(_mm_loadl_epi64((const __m128i *)(pix + ystride)), z);
+  lf_filter_v(p2, &p3, &p4, p5, L);
+  _mm_storel_epi64((__m128i *)(pix - (ptrdiff_t)ystride), _mm_packus_epi16(p3, p3));
+  _mm_storel_epi64((__m128i *)pix, _mm_packus_epi16(p4, p4));
+}
+#else
 /* filter across a vertical edge: pix points at the first column right of it, state.c:1002-1016 */
 static void lf_across_vertical_edge(uint8_t *pix, int ystride, const int8_t *bv127) {
   int y;
@@ -465,6 +642,7 @@ static void lf_across_horizontal_edge(uint8_t *pix, int ystride, const int8_t *b
     p[0] = clamp255(p[0] - f);
   }
 }
+#endif
 
 void orc_state_loop_filter_frag_rows(orc_state *st, int8_t bvarray[256], int slot, int pli,
                                      int fragy0, int fragy_end) {          /* state.c:1055-1105 */

@@ -25,6 +25,8 @@ int thip_state_loop_filter_frag_rows(thip_state *, int, int, int, int, int) { re
 int thip_frame_flush(thip_state *) { return -1; }
 int thip_state_ycbcr_out(thip_state *, uint8_t *const *, const int32_t *) { return -1; }
 int thip_state_ycbcr_map(thip_state *, const uint8_t **, int32_t *) { return -1; }
+int thip_state_ycbcr_map_begin(thip_state *) { return -1; }
+int thip_state_ycbcr_map_end(thip_state *, const uint8_t **, int32_t *) { return -1; }
 int thip_state_set_eager_output(thip_state *, int) { return -1; }
 int thip_state_create_on(thip_state **, int, int, int, int) { return -1; }
 int thip_state_postprocess(thip_state *, int, const uint8_t *, const uint8_t *, const int32_t *, const int32_t *) { return -1; }

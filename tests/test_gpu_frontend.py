@@ -103,6 +103,81 @@ def test_look_ahead_rule_changes_sides_against_the_oracle(hip, w, h, fmt):
     assert to_dev1.value > to_dev0.value and to_par1.value > to_par0.value, (to_dev0.value, to_dev1.value, to_par0.value, to_par1.value)
 
 
+@pytest.mark.parametrize("lists", [True, False])
+@pytest.mark.parametrize("w,h,fmt,ahead,n", [(64, 48, 0, 4, 60), (176, 144, 0, 8, 40), (16, 16, 0, 3, 60), (48, 64, 3, 2, 30), (1280, 720, 0, 4, 8)])
+def test_next_frame_on_the_device_before_this_picture_is_waited_for(hip, w, h, fmt, ahead, n, lists):
+    """Option fe_pipeline: th_decode_ycbcr_out(N) hands the next announced packet's frame to the device before it waits for picture
+    N (thip_state_ycbcr_map_begin / _end: the two pictures live in the state's two host images) and th_decode_packetin(N + 1) finds
+    the work done.  Every picture against the oracle -- the one handed out while the next frame is already being decoded included --,
+    return codes and dropped frames (zero-byte packets between announced ones: the 16 x 16 stream has them) as ever; the counter
+    says that frames did go ahead."""
+    import ctypes as C
+    L = hip._lib.load()
+    c0, c1 = C.c_int(), C.c_int()
+    L.thip_get_option(b"fe_pipelined", C.byref(c0))
+    with util.options(L, fe_pipeline=1):
+        assert run_stream(hip, w, h, fmt, seed=5 * w + h + fmt, nframes=n, kf=7, device_lists=lists, lookahead=ahead,
+                          trees="matched" if w >= 1000 else "random") >= n // 3
+    L.thip_get_option(b"fe_pipelined", C.byref(c1))
+    assert c1.value - c0.value >= n // 3, (c0.value, c1.value)
+
+
+def test_a_pipelined_announcement_is_a_promise(hip):
+    """fe_pipeline's contract: once th_decode_ycbcr_out has handed the announced packet's frame to the device, another packet
+    gets TH_EINVAL (the frame cannot be taken back), the context stays usable and is right again from the next key frame."""
+    from theora_amd.decoder import Decoder
+    L = hip._lib.load()
+    st = streamgen.Stream(64, 48, 0, seed=77, trees="random")
+    dec = Decoder(st.header_packets())
+    ost = oracle.State(64, 48, 0)
+    made = [st.frame(0 if f % 4 == 0 else 1, density=0.9, p_empty=0.0) for f in range(12)]
+    with util.options(L, fe_pipeline=1):
+        def step(i, check=True):
+            pkt, truth = made[i]
+            rc, _ = dec.packetin(pkt)
+            assert rc == 0, (i, rc)
+            assert ost.decode_frame(**st.oracle_inputs(truth, ost)) == 0
+            got = dec.ycbcr_out()
+            if check:
+                for pli in range(3):
+                    assert np.array_equal(got[pli], ost.get_plane(oracle.FRAME_PREV, pli)[::-1]), (i, pli)
+        step(0)
+        assert dec.prefetch(made[1][0])
+        import time
+        time.sleep(0.05)                       # (the parser is done: the next th_decode_ycbcr_out takes the frame ahead)
+        dec.ycbcr_out()
+        from theora_amd._lib import TheoraHipError
+        with pytest.raises(TheoraHipError, match="-10"):     # TH_EINVAL
+            dec.packetin(made[2][0])           # not the packet that was announced
+        # from the next key frame on everything is right again (frame 4 is one)
+        ost.close()
+        ost = oracle.State(64, 48, 0)
+        for i in range(4, 12):
+            step(i)
+    dec.close()
+    ost.close()
+
+
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 2)])
+def test_lists_or_host_walk_is_measured_per_context_against_the_oracle(hip, w, h, fmt):
+    """The plain th_decode_* loop with the library left to choose (TH_DECCTL_THIP_SET_DEVICE_LISTS not called, option fe_device_lists
+    = -1): since round 5 a context MEASURES whether its token lists go to the device or the host walks them -- 16 inter frames
+    each way, the faster kept for fe_assign_settle frames (shortened here), and again -- so a stream changes sides while it runs.
+    Every frame against the oracle; the counters say that it went both ways."""
+    import ctypes as C
+    L = hip._lib.load()
+
+    def counter(name):
+        v = C.c_int()
+        assert L.thip_get_option(name, C.byref(v)) == 0
+        return v.value
+    before = (counter(b"fe_lists_to_device"), counter(b"fe_lists_to_host"))
+    with util.options(L, fe_device_lists=-1, fe_lists_rule=1, fe_assign_settle=5):
+        assert run_stream(hip, w, h, fmt, seed=11 * w + h + fmt, nframes=150, kf=30, device_lists=None, trees="matched") >= 110
+    after = (counter(b"fe_lists_to_device"), counter(b"fe_lists_to_host"))
+    assert after[0] > before[0] and after[1] > before[1], (before, after)
+
+
 @pytest.mark.parametrize("levels", [1, 0])
 @pytest.mark.parametrize("w,h,fmt,ahead", [(176, 144, 0, 3), (48, 64, 3, 2), (336, 32, 0, 4), (1280, 720, 0, 3)])
 def test_look_ahead_with_the_walk_left_to_the_device(hip, w, h, fmt, ahead, levels):

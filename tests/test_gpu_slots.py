@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import oracle
+from tests import util
 
 pytestmark = pytest.mark.gpu
 
@@ -587,8 +588,10 @@ def test_dc_unpredict_plane_slot(hip, w, h, fmt):
     assert L.thip_dc_unpredict_plane(d.data_ptr(), f.data_ptr(), 1, 1025) == _lib.EIMPL
 
 
-def test_enc_fdct_quantize_in_one_pass(hip):
-    """thip_enc_fdct_quantize_batch == oc_enc_fdct8x8 followed by oc_enc_quantize (fdct.c:128, enquant.c:219) on the oracle, for
+@pytest.mark.parametrize("lanes", [4, 1])
+def test_enc_fdct_quantize_in_one_pass(hip, lanes):
+    """(Both kernels: four lanes per block, the default, and one block per lane -- option enc_fq_lanes.)
+    thip_enc_fdct_quantize_batch == oc_enc_fdct8x8 followed by oc_enc_quantize (fdct.c:128, enquant.c:219) on the oracle, for
     the residual range, beyond it, the extreme step sizes, with and without the coefficients handed back, with the reciprocals
     derived on the device and with a table of thip_enc_enquant_table_init."""
     from theora_amd import _lib
@@ -596,6 +599,14 @@ def test_enc_fdct_quantize_in_one_pass(hip):
     L = _lib.load()
     rng = np.random.default_rng(21)
     n = 6001          # (not a multiple of a wave)
+    with util.options(L, enc_fq_lanes=lanes):
+        _fdct_quantize_trials(hip, L, rng, n)
+    assert L.thip_enc_fdct_quantize_batch(None, None, None, None, None, None, 0) == 0
+    assert L.thip_enc_fdct_quantize_batch(None, None, None, None, None, None, 5) == _lib.EFAULT
+
+
+def _fdct_quantize_trials(hip, L, rng, n):
+    import torch
     for trial in range(4):
         x = rng.integers(-255, 256, (n, 64)).astype(np.int16)
         if trial == 2:
@@ -616,5 +627,3 @@ def test_enc_fdct_quantize_in_one_pass(hip):
         nz3 = torch.empty(n, dtype=torch.int32, device="cuda")
         assert L.thip_enc_fdct_quantize_batch(q3.data_ptr(), nz3.data_ptr(), None, dev(x).data_ptr(), dev(dq).data_ptr(), dev(enq).data_ptr(), n) == 0
         assert torch.equal(q3.reshape(-1), q.reshape(-1)) and torch.equal(nz3, nz)
-    assert L.thip_enc_fdct_quantize_batch(None, None, None, None, None, None, 0) == 0
-    assert L.thip_enc_fdct_quantize_batch(None, None, None, None, None, None, 5) == _lib.EFAULT

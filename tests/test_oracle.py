@@ -8,6 +8,7 @@ import pytest
 
 import oracle
 from theora_amd import synth
+from tests import util
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -335,3 +336,48 @@ def test_halfpel_refinement_offsets_are_the_decoders():
                     n, a0, a1 = oracle.mv_offsets(416, 0, 0, 2 * vx + dx, 2 * vy + dy)
                     base = vx + vy * 416
                     assert n == 2 and (base + int(o0[0]), base + int(o1[0])) == (a0, a1), (vx, vy, dx, dy)
+
+
+def test_simd_legs_equal_the_scalar_oracle():
+    """oracle/_build/libtheora_oracle_simd.so (-DORC_SIMD: the full inverse transform, the three reconstruction loops and the loop
+    filter's edge filters as SSE2 intrinsics -- bench.py's vectorised CPU baseline) against the scalar build, value for value: the
+    transform over the whole int16 range, reconstruction with residues that overflow a 16-bit sum, and whole sequences -- every
+    coding mode, vectors out of the frame, three pixel formats, loop-filter limits 0..63, extreme coefficients."""
+    from theora_amd import synth
+    Ls, Lv = oracle.lib(), oracle.lib(simd=True)
+    rng = np.random.default_rng(77)
+    x = rng.integers(-32768, 32768, (30000, 64)).astype(np.int16)
+    x[:10000] = rng.integers(-700, 700, (10000, 64))
+    x[10000:10100] = 32767
+    x[10100:10200] = -32768
+    ys, yv = np.zeros_like(x), np.zeros_like(x)
+    Ls.orc_idct8x8_batch(ys.ctypes.data, x.ctypes.data, None, x.shape[0])
+    Lv.orc_idct8x8_batch(yv.ctypes.data, x.ctypes.data, None, x.shape[0])
+    assert np.array_equal(ys, yv)
+    # reconstruction: residues of any size against any predictor
+    res = rng.integers(-32768, 32768, (2000, 64)).astype(np.int16)
+    res[:500] = rng.integers(-300, 300, (500, 64))
+    src = rng.integers(0, 256, (2000, 2, 8, 16)).astype(np.uint8)
+    for k in range(res.shape[0]):
+        outs = []
+        for L in (Ls, Lv):
+            d = np.zeros((3, 8, 16), np.uint8)
+            L.orc_frag_recon_intra(d[0].ctypes.data, 16, res[k].ctypes.data)
+            L.orc_frag_recon_inter(d[1].ctypes.data, src[k, 0].ctypes.data, 16, res[k].ctypes.data)
+            L.orc_frag_recon_inter2(d[2].ctypes.data, src[k, 0].ctypes.data, src[k, 1].ctypes.data, 16, res[k].ctypes.data)
+            outs.append(d)
+        assert np.array_equal(outs[0], outs[1]), k
+    # whole sequences through orc_decode_frame (the loop filter in the reference's order, MCU by MCU)
+    for (w, h, fmt, content, seed) in ((176, 144, oracle.PF_420, "mixed", 1), (80, 112, oracle.PF_422, "mixed", 2),
+                                       (64, 48, oracle.PF_444, "dense", 3), (336, 48, oracle.PF_420, "smooth", 4)):
+        geom = synth.Geometry(w, h, fmt)
+        r = np.random.default_rng(seed)
+        a, b = oracle.State(w, h, fmt), oracle.State(w, h, fmt, simd=True)
+        for f in range(10):
+            fr = synth.gen_frame(geom, r, 0 if f % 5 == 0 else 1, content, flimit=[0, 1, 2, 4, 15, 31, 63, 3, 7, 30][f])
+            util.oracle_apply(a, fr)
+            util.oracle_apply(b, fr)
+            for pli in range(3):
+                assert np.array_equal(a.get_plane(oracle.FRAME_PREV, pli), b.get_plane(oracle.FRAME_PREV, pli)), (w, h, f, pli)
+        a.close()
+        b.close()

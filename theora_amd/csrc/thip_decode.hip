@@ -85,6 +85,11 @@ Option g_options[] = {
     {"fe_worker_pin", 1, "th_decode_*, fe_worker on: 1 (default): the second thread is kept on the CPUs that share a last-level cache with the caller's; 0: left to the scheduler"},
     {"fe_lookahead", 8, "th_decode_*: packets a caller may announce ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), each parsed by a thread of its own on a parser context: 8 (default), up to 16; 0: announcements are not taken"},
     {"fe_assign", 2, "th_decode_*, announced packets on the token-list path: 1: the parser pairs tokens and fragments while it decodes the tokens and the frame goes to thip_state_token_lists_begin_assigned (k_tok_scatter: the device pairs nothing); 0: the device walks the lists (thip_state_token_lists_begin); 2 (default): whichever measures faster for this stream (24 frames each way, the better for 1024, and again)"},
+    {"fe_pipeline", 0, "th_decode_*: 1: th_decode_ycbcr_out hands the next ANNOUNCED packet's frame to the device before it waits for its own picture (the announced packet must then be the next one: TH_EINVAL otherwise; a failed tile hand-over is THIP_EFAULT instead of a frame decoded again); 0 (default): off"},
+    {"fe_pipelined", 0, "(counter) frames handed to the device ahead of their th_decode_packetin (fe_pipeline)"},
+    {"fe_lists_rule", 1, "th_decode_*, fe_device_lists = -1: 1 (default): whether a context's token lists go to the device or the host walks them is measured per context (the time between its th_decode_packetin calls, 16 inter frames each way, the faster for fe_assign_settle frames); 0: by the count of contexts alive (at most four: the device)"},
+    {"fe_lists_to_device", 0, "(counter) fe_lists_rule: times a context went from the host's walk to the lists on the device"},
+    {"fe_lists_to_host", 0, "(counter) fe_lists_rule: times a context went from the lists on the device to the host's walk"},
     {"fe_lookahead_adopted", 0, "(counter) announced packets whose th_decode_packetin found them parsed and took the frame over"},
     {"fe_lookahead_missed", 0, "(counter) announced packets that were parsed for nothing: another packet came instead (everything announced is then dropped), or the parser refused the packet"},
     {"fe_assign_settle", 1024, "th_decode_*, fe_assign = 2: adopted frames a stream keeps the rule that measured faster before it measures again (default 1024; tests shorten it)"},
@@ -95,7 +100,7 @@ Option g_options[] = {
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
     {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
     {"sb_tiles", 600, "k_recon_lf_sb (one super block per wave, four lanes per block) instead of k_recon_lf for launches of fewer tiles than this (0: never)"},
-    {"stagger", 0, "thip_decode_frames: microseconds by which lane i's first launch is held back (i x stagger) when the call finds every lane of the device idle, so that the lanes' launches do not run in step (0: off)"},
+    {"enc_fq_lanes", 4, "thip_enc_fdct_quantize_batch: 4 (default): four lanes per block (k_enc_fdct_quantize4); 1: one block per lane (round 4's kernel)"},
     {"redo_descs", 0, "thip_decode_frames on the caller's descriptors: 1: the caller promises that the buffers a descriptor points to stay as they are until the state's next synchronising call, so a frame whose hand-over failed can be decoded again like a th_decode_* frame; 0 (default): such a frame gets THIP_EFAULT"},
     {"faults_recovered", 0, "(counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf had run out"},
 };
@@ -197,7 +202,8 @@ struct thip_state {
   uint8_t *h_out[2];
   int out_cur, eager_out;
   int64_t frame_serial, out_serial;
-  hipEvent_t ev_out;         // recorded behind k_frame_out
+  hipEvent_t ev_out2[2];     // recorded behind k_frame_out, one per host image
+  int held_img;              // thip_state_ycbcr_map_begin: the image (and its event) thip_state_ycbcr_map_end hands out, -1 none
   int32_t *enq_last_lane;   // per tile: last lane that received a slot (arrival-order check)
   int enq_ncoded, enq_nuncoded, enq_nslots, enq_frame_type, enq_flimit, enq_active, enq_last_tile;
   int enq_lf_y0[3], enq_lf_y1[3], enq_lf_any;
@@ -303,7 +309,6 @@ int g_ctx_ready[kMaxDevices], g_next_ctx[kMaxDevices];
 // thip_synchronize waits for the streams that got work since it last did: ten hipStreamSynchronize calls on idle streams are
 // tens of microseconds of host time, which a caller that brackets 0.8 ms of work with it (bench.py's blocks) would book as GPU time.
 std::atomic<uint8_t> g_lane_dirty[kMaxDevices][kMaxLanes], g_ctx_dirty[kMaxDevices][kCtxLanes];
-std::atomic<uint8_t> g_cold[kMaxDevices];   // set by thip_synchronize: the device's lanes are idle (option "stagger")
 
 // Makes `device` current for the calling host thread for the lifetime of the object (HIP's current
 // device is per thread) and puts the previous one back: a state may live on any GPU of the node
@@ -474,18 +479,6 @@ __global__ void k_xcc_probe(uint32_t *out) {
   uint32_t xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   if (threadIdx.x == 0) out[blockIdx.x] = xcc & 15u;
-}
-// Lanes that start together stay together: two launches of equal length that begin at the same moment have their ramps, their
-// arithmetic and their tails at the same moments, and the second lane is there to put one launch's tail under the other's body.
-// So in the first call after a thip_synchronize (every lane of the device is idle), lane i
-// first runs a wave that sleeps i * stagger microseconds (option "stagger", 0 = off).
-__global__ void k_stagger(uint32_t ticks) {   // ticks of s_memrealtime (100 MHz)
-  unsigned long long t0, t;
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-  do {
-    __builtin_amdgcn_s_sleep(32);
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  } while (t - t0 < ticks);
 }
 bool xcd_round_robin(int device) {   // the device must be current
   static std::mutex mu;
@@ -663,6 +656,7 @@ int thip_state_create_on(thip_state **out, int device, int frame_width, int fram
   st->lane = -1;
   st->ctx_lane = -1;
   st->out_cur = -1;
+  st->held_img = -1;
   st->out_serial = -1;
   st->buf_serial[0] = st->buf_serial[1] = st->buf_serial[2] = -1;
   st->map_serial[0] = st->map_serial[1] = -1;
@@ -699,7 +693,8 @@ void thip_state_free(thip_state *st) {
   if (st->h_slot0) (void)hipHostFree(st->h_slot0);
   for (int b = 0; b < 2; b++)
     if (st->h_out[b]) (void)hipHostFree(st->h_out[b]);
-  if (st->ev_out) (void)hipEventDestroy(st->ev_out);
+  for (int k = 0; k < 2; k++)
+    if (st->ev_out2[k]) (void)hipEventDestroy(st->ev_out2[k]);
   if (st->ev_staging) (void)hipEventDestroy(st->ev_staging);
   if (st->d_info) (void)hipFree(st->d_info);
   if (st->d_coeffs) (void)hipFree(st->d_coeffs);
@@ -871,7 +866,7 @@ static int wait_event(hipEvent_t ev) {
 static int launch_frame_out(thip_state *st, hipStream_t s) {
   const int nb = st->out_cur < 0 ? 0 : st->out_cur ^ 1;   // the other image: the previous one stays intact
   if (!st->h_out[nb]) HIP_TRY(hipHostMalloc((void **)&st->h_out[nb], st->frame_bytes, hipHostMallocDefault));
-  if (!st->ev_out) HIP_TRY(hipEventCreateWithFlags(&st->ev_out, hipEventDisableTiming));
+  if (!st->ev_out2[nb]) HIP_TRY(hipEventCreateWithFlags(&st->ev_out2[nb], hipEventDisableTiming));
   OutK K;
   const bool pp = st->pp_serial == st->frame_serial;
   for (int p = 0; p < 3; p++) K.src[p] = pp && st->pp_active[p] ? st->pp_frame : st->frames[st->last_decoded];
@@ -890,7 +885,7 @@ static int launch_frame_out(thip_state *st, hipStream_t s) {
   }
   hipLaunchKernelGGL(k_frame_out, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, K);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(st->ev_out, s));
+  HIP_TRY(hipEventRecord(st->ev_out2[nb], s));
   st->out_cur = nb;
   st->out_serial = st->frame_serial;
   return THIP_OK;
@@ -902,23 +897,30 @@ int thip_state_set_eager_output(thip_state *st, int on) {
   return THIP_OK;
 }
 
+static int ensure_frame_out(thip_state *st) {
+  if (st->out_serial != st->frame_serial) {   // not copied yet (no eager output, or the frame came from write_plane)
+    hipStream_t fs;
+    int rc = followup_stream(st, &fs);
+    if (rc < 0) return rc;
+    rc = launch_frame_out(st, fs);
+    if (rc < 0) return rc;
+    if (fs != st->last_stream) {
+      rc = order_mark(st, fs);
+      if (rc < 0) return rc;
+    }
+  }
+  return THIP_OK;
+}
+
 int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strides[3]) {
   if (!st || !planes || !strides) return THIP_EFAULT;
   if (st->last_decoded < 0) return THIP_EINVAL;
   DeviceGuard dg(st->device);
+  st->held_img = -1;
   for (int attempt = 0; attempt < 2; attempt++) {
-    if (st->out_serial != st->frame_serial) {   // not copied yet (no eager output, or the frame came from write_plane)
-      hipStream_t fs;
-      int rc = followup_stream(st, &fs);
-      if (rc < 0) return rc;
-      rc = launch_frame_out(st, fs);
-      if (rc < 0) return rc;
-      if (fs != st->last_stream) {
-        rc = order_mark(st, fs);
-        if (rc < 0) return rc;
-      }
-    }
-    if (wait_event(st->ev_out) < 0) return THIP_EFAULT;
+    const int rc = ensure_frame_out(st);
+    if (rc < 0) return rc;
+    if (wait_event(st->ev_out2[st->out_cur]) < 0) return THIP_EFAULT;
     st->out_done_serial = st->out_serial;
     const int frc = check_fault(st);
     if (frc < 0) return frc;
@@ -928,6 +930,37 @@ int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strid
   int off = 0;
   for (int p = 0; p < 3; p++) {
     planes[p] = st->h_out[st->out_cur] + off;
+    strides[p] = st->geom[p].width;
+    off += st->geom[p].width * st->geom[p].height;
+  }
+  return THIP_OK;
+}
+
+// The same in two halves, for a caller that wants the NEXT frame on the device before it waits for this one's picture (the
+// th_decode_* front end with option fe_pipeline): _begin names the picture (the frame decoded last; its copy to the host is
+// launched if it was not), the caller hands the next frame over -- which goes to the OTHER host image -- and _end waits for the
+// named picture and hands it out.  A hand-over of the named frame that failed cannot be repaired any more once the next frame is
+// on the device (the kernels record which launch gave up: check_fault): _end then returns THIP_EFAULT.
+int thip_state_ycbcr_map_begin(thip_state *st) {
+  if (!st) return THIP_EFAULT;
+  if (st->last_decoded < 0) return THIP_EINVAL;
+  DeviceGuard dg(st->device);
+  const int rc = ensure_frame_out(st);
+  if (rc < 0) return rc;
+  st->held_img = st->out_cur;
+  return THIP_OK;
+}
+int thip_state_ycbcr_map_end(thip_state *st, const uint8_t *planes[3], int32_t strides[3]) {
+  if (!st || !planes || !strides) return THIP_EFAULT;
+  if (st->held_img < 0) return THIP_EINVAL;
+  DeviceGuard dg(st->device);
+  if (wait_event(st->ev_out2[st->held_img]) < 0) return THIP_EFAULT;
+  const int frc = check_fault(st);
+  if (frc < 0) return frc;
+  if (frc > 0 && st->held_img == st->out_cur) return THIP_EFAULT;   // (cannot be: a repeated frame is the newest one, and that is not the held one)
+  int off = 0;
+  for (int p = 0; p < 3; p++) {
+    planes[p] = st->h_out[st->held_img] + off;
     strides[p] = st->geom[p].width;
     off += st->geom[p].width * st->geom[p].height;
   }
@@ -957,7 +990,6 @@ int thip_synchronize(void) {
     DeviceGuard dg(d);
     for (int i = 0; i < g_nlanes && g_lanes_ready[d]; i++)
       if (g_lane_dirty[d][i].exchange(0, std::memory_order_relaxed)) HIP_TRY(hipStreamSynchronize(g_lanes[d][i]));
-    g_cold[d].store(1, std::memory_order_relaxed);
     for (int i = 0; i < kCtxLanes; i++)
       if (g_ctx_ready[d] && g_ctx_lanes[d][i] && g_ctx_dirty[d][i].exchange(0, std::memory_order_relaxed)) HIP_TRY(hipStreamSynchronize(g_ctx_lanes[d][i]));
   }
@@ -1387,10 +1419,6 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
         std::lock_guard<std::mutex> lk(g_mu);
         states[i]->lane = g_next_lane[dev]++ % g_nlanes;
       }
-    const int stagger_us = THIP_OPT("stagger");
-    // (cold = the first call after a thip_synchronize: asking the streams -- hipStreamQuery -- puts markers into their queues,
-    //  which cost the lanes their overlap: measured 10 % of a step)
-    const bool cold = g_cold[dev].exchange(0, std::memory_order_relaxed) != 0 && stagger_us > 0 && g_nlanes > 1;
     for (int lane = 0; lane < g_nlanes; lane++)
      for (int form = 0; form < 2; form++) {   // (a chunk holds one coefficient form)
       thip_state *ls[THIP_MAX_BATCH];
@@ -1407,8 +1435,6 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
         }
         if (n == chunk_max || (i == nstreams && n > 0)) {
           g_lane_dirty[dev][lane].store(1, std::memory_order_relaxed);
-          if (cold && lane > 0 && form == (descs[li[0]].coeff_format == THIP_COEFFS_LEVELS ? 1 : 0))
-            hipLaunchKernelGGL(k_stagger, dim3(1), dim3(64), 0, g_lanes[dev][lane], (uint32_t)(lane * stagger_us * 100));
           rc = launch_chunk(ls, ld, n, g_lanes[dev][lane], lr);
           if (rc < 0) return rc;
           if (results)

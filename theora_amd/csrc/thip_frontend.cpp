@@ -274,6 +274,25 @@ struct th_dec_ctx {
   // default) on while few decoder contexts are alive: the device side of a frame is 0.3 ms of small dependent kernels -- a gain
   // of a fifth for one to four streams, a queue for sixteen.
   int device_lists;
+  // -1 (the default): MEASURED per context (fe_lists_rule): the time from one plain th_decode_packetin to the next, 16 inter frames
+  // with the lists on the device and 16 with the host's own walk, the faster for option fe_assign_settle frames, and again.  The
+  // count of contexts alive (the rule of rounds 3 and 4: lists while at most four) is only where a context starts.
+  struct {
+    int mode = -1;          // 1: the token lists go to the device; 0: the host walks them; -1: not started
+    int phase = 0;          // 0: timing `mode`; 1: timing the other one; 2: settled
+    int frames = 0, cnt[2] = {0, 0};
+    double sum[2] = {0, 0}, last = 0;   // last: when the previous plain inter frame's th_decode_packetin began (0: none)
+    int first = 1;          // the mode the measurement began with (ties go to it)
+  } lists_rule;
+  // option fe_pipeline: the next announced packet's frame handed to the device INSIDE th_decode_ycbcr_out, before that call waits
+  // for its own picture (th_decode_ycbcr_out has the story); what its th_decode_packetin will find:
+  struct {
+    bool valid = false;
+    int rc = 0;
+    int64_t granpos = 0;
+    int64_t key0 = 0, cur0 = 0;        // the frame counters before it (a dropped frame may still come in between)
+    std::vector<uint8_t> pkt;          // the packet it was made from
+  } early;
   FeWorker *worker;                  // (created with the first frame that takes the token-list path with option fe_worker on)
   FeLookahead *la;                   // packets announced ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), or null
   bool parse_only;                   // a parser context of a look-ahead: no device state, no counters of its own, fe_front only
@@ -1573,9 +1592,52 @@ constexpr int kFeContinue = 0x7F00;   // fe_front: the frame goes on to fe_back 
 
 // is everything behind the entropy decoder the device's (the token-list path) for the frame at hand?
 static bool fe_lists_now(const th_dec_ctx *d) {
-  return !d->trace && d->hip &&
-         (d->device_lists > 0 || (d->device_lists < 0 && !d->device_dc && !d->device_tokens &&
-                                  g_fe_contexts.load(std::memory_order_relaxed) <= kFeListsAutoContexts));
+  if (d->trace || !d->hip) return false;
+  if (d->device_lists >= 0) return d->device_lists > 0;
+  if (d->device_dc || d->device_tokens) return false;
+  if (thip_option("fe_lists_rule") == 0 || d->lists_rule.mode < 0)   // (the count of contexts: option fe_lists_rule = 0, and where a context starts)
+    return g_fe_contexts.load(std::memory_order_relaxed) <= kFeListsAutoContexts;
+  return d->lists_rule.mode != 0;
+}
+constexpr int kFeListsSample = 16, kFeListsWarm = 8;
+// option fe_device_lists = -1, fe_lists_rule = 1: which of the two is faster for THIS context (see th_dec_ctx::lists_rule); called
+// when a th_decode_packetin begins, with whether the packet takes the plain path (not adopted from the look-ahead, not empty)
+static void fe_lists_rule(th_dec_ctx *d, double now, bool plain) {
+  auto &R = d->lists_rule;
+  if (d->trace || !d->hip || d->device_lists >= 0 || d->device_dc || d->device_tokens || thip_option("fe_lists_rule") == 0) return;
+  if (R.mode < 0) {
+    R.mode = R.first = g_fe_contexts.load(std::memory_order_relaxed) <= kFeListsAutoContexts ? 1 : 0;
+    R.frames = -kFeListsWarm;   // (a stream's first frames: buffers, streams and threads come into being)
+  }
+  // the interval that ends now is the frame before this one: counted if it was a plain inter frame (a key frame costs several
+  // inter frames, and whether one falls into a sample is chance)
+  const bool counted = R.last > 0 && plain;
+  const double dt = now - R.last;
+  R.last = plain ? now : 0;
+  if (!counted || d->frame_type == THIP_INTRA_FRAME) return;
+  if (R.phase < 2) {
+    if (++R.frames <= 2) return;   // (the first two frames behind a change of sides still carry the other side's work)
+    const int which = R.phase;
+    R.sum[which] += dt;
+    if (++R.cnt[which] >= kFeListsSample) {
+      const int before = R.mode;
+      if (R.phase == 0) {
+        R.mode ^= 1;
+      } else {
+        const double first = R.sum[0] / R.cnt[0], other = R.sum[1] / R.cnt[1];
+        R.mode = first <= 1.03 * other ? R.first : R.first ^ 1;
+      }
+      if (R.mode != before) thip_option_add(R.mode ? "fe_lists_to_device" : "fe_lists_to_host", 1);
+      R.phase++;
+      R.frames = 0;
+    }
+  } else if (++R.frames >= std::max(1, thip_option("fe_assign_settle"))) {
+    R.phase = 0;
+    R.frames = 0;
+    R.first = R.mode;
+    R.sum[0] = R.sum[1] = 0;
+    R.cnt[0] = R.cnt[1] = 0;
+  }
 }
 
 static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun &r) {
@@ -2714,6 +2776,34 @@ static void fe_pair_rule(FeLookahead *la, double now, bool adopted) {
 int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
   if (!d || !op) return TH_EFAULT;
   if (d->parse_only) return TH_EINVAL;
+  if (d->early.valid) {
+    // th_decode_ycbcr_out has decoded the next announced packet ahead (option fe_pipeline)
+    auto G = [&](int64_t key, int64_t cur) { return ((key + d->granpos_bias) << d->info.keyframe_granule_shift) + (cur - key); };
+    if (op->bytes == 0) {
+      // a dropped frame in between (decode.c:2746; such a packet cannot be announced): it changes no picture, so the frame decoded
+      // ahead is still right; only the counters move -- this packet takes the number the other one had
+      const int64_t k0 = d->early.key0, c0 = d->early.cur0;
+      if (granpos) *granpos = G(k0, c0);
+      if (d->frame_type == THIP_INTRA_FRAME) {
+        d->keyframe_num = c0 + 1;
+        d->early.granpos = G(c0 + 1, c0 + 1);
+      } else {
+        d->early.granpos = G(k0, c0 + 1);
+      }
+      d->granpos = d->early.granpos;
+      d->early.cur0 = c0 + 1;
+      d->curframe_num = c0 + 2;
+      return TH_DUPFRAME;
+    }
+    d->early.valid = false;
+    if ((size_t)op->bytes == d->early.pkt.size() && op->packet && !memcmp(op->packet, d->early.pkt.data(), d->early.pkt.size())) {
+      if (granpos) *granpos = d->early.granpos;
+      return d->early.rc;
+    }
+    // The contract of fe_pipeline: once th_decode_ycbcr_out has been called, the oldest announced packet IS the next one.  The
+    // frame decoded ahead cannot be taken back; the stream is good again from its next key frame.
+    return TH_EINVAL;
+  }
   FeRun r;
   if (d->la && !d->la->count) d->la->pair_last = 0;
   if (d->la && d->la->count) {
@@ -2722,6 +2812,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
     FeSlot *const sl = fe_lookahead_take(d, op);
     fe_pair_rule(d->la, now, sl != nullptr);
     if (sl) {
+      fe_lists_rule(d, now, false);
       fe_adopt(d, sl->ctx);
       r.lists_now = fe_lists_now(d);
       r.dc_done = true;
@@ -2729,6 +2820,7 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
       return fe_back(d, granpos, r);
     }
   }
+  if (d->device_lists < 0) fe_lists_rule(d, fe_now(), op->bytes > 0);
   const int rc = fe_front(d, op, granpos, r);
   if (rc != kFeContinue) return rc;
   return fe_back(d, granpos, r);
@@ -2742,7 +2834,45 @@ int th_decode_ycbcr_out(th_dec_ctx *d, th_ycbcr_buffer ycbcr) {
   const uint8_t *src[3] = {d->mirror[0].data(), d->mirror[1].data(), d->mirror[2].data()};
   int32_t strides[3] = {d->nh[0] * 8, d->nh[1] * 8, d->nh[2] * 8};
   d->prof.start();
-  if (d->have_frame && !d->trace && thip_state_ycbcr_map(d->hip, src, strides) < 0) return TH_EFAULT;
+  if (d->have_frame && !d->trace) {
+    // Option fe_pipeline (off by default: it turns an announcement into a promise).  The caller's loop is th_decode_packetin(N),
+    // th_decode_ycbcr_out(N), th_decode_packetin(N + 1), ...: the device works on frame N while this thread waits here, and sits idle
+    // while this thread hands frame N + 1 over -- adoption, copies and a dozen launches, as long as the device's own share at 720p.
+    // With the packets announced ahead the next frame is usually parsed by now, so it is handed over HERE, before the wait: the
+    // picture of frame N is named first (thip_state_ycbcr_map_begin), frame N + 1 goes to the state's other host image behind
+    // frame N's kernels, and its th_decode_packetin finds the work done.  What it costs: the announced packet MUST then come next
+    // (another one gets TH_EINVAL -- the frame cannot be taken back; a dropped frame in between is fine), and a failed tile
+    // hand-over of frame N can no longer be repaired by decoding it again (THIP_EFAULT instead; never observed outside its test).
+    bool held = d->early.valid;   // (a second th_decode_ycbcr_out for the same frame: the picture named the first time)
+    FeLookahead *const la = d->la;
+    if (!held && la && la->count && d->pp_level <= 0 && !d->stripe_cb.stripe_decoded && !d->device_dc && !d->device_tokens &&
+        thip_option("fe_pipeline") != 0) {
+      FeSlot &sl = la->slots[la->head];
+      if (sl.done.load(std::memory_order_acquire) && sl.rc == kFeContinue && sl.bytes > 0) {   // (parsed already: nobody is waited for here)
+        if (thip_state_ycbcr_map_begin(d->hip) < 0) return TH_EFAULT;
+        held = true;
+        la->head = (la->head + 1) % la->nslots;
+        la->count--;
+        la->adopted++;
+        thip_option_add("fe_lookahead_adopted", 1);
+        thip_option_add("fe_pipelined", 1);
+        const double now = fe_now();
+        fe_pair_rule(la, now, true);
+        fe_lists_rule(d, now, false);
+        d->early.pkt.assign(sl.pkt.begin(), sl.pkt.begin() + sl.bytes);
+        d->early.key0 = d->keyframe_num;
+        d->early.cur0 = d->curframe_num;
+        fe_adopt(d, sl.ctx);
+        FeRun r;
+        r.lists_now = fe_lists_now(d);
+        r.dc_done = true;
+        d->early.granpos = 0;
+        d->early.rc = fe_back(d, &d->early.granpos, r);
+        d->early.valid = true;
+      }
+    }
+    if ((held ? thip_state_ycbcr_map_end(d->hip, src, strides) : thip_state_ycbcr_map(d->hip, src, strides)) < 0) return TH_EFAULT;
+  }
   d->prof.lap(FE_OUT);
   for (int p = 0; p < 3; p++) {
     ycbcr[p].width = d->nh[p] * 8;

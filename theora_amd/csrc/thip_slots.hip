@@ -387,6 +387,120 @@ __global__ __launch_bounds__(256) void k_enc_fdct_quantize(int16_t *qdct, int32_
   if (i < n) nonzero[i] = nz;
 }
 
+// The same pass with FOUR lanes per block (the default of thip_enc_fdct_quantize_batch).  One block per lane is 1 500 dependent
+// vector instructions a wave, and a 1080p 4:4:4 frame is 1 530 such waves -- one and a half per SIMD, issuing at the single-wave
+// rate (8.3 clocks an instruction, profiles/r04_valu_rate2.txt) behind one exposed round trip: 17.3 us, slower per block than
+// either half alone.  Here lane 4b + j takes columns 2j, 2j + 1 of block b for the first pass (fdct.c:143), the block is
+// transposed through the wave's 2 KB of LDS as int16 pairs, the lane takes rows 2j, 2j + 1 for the second (fdct.c:145), and it
+// quantises its sixteen coefficients with the tables kept by NATURAL position; the zig-zag order (fdct.c:149) happens on the way
+// out, through the same 2 KB, so that the stores are whole 16-byte pieces.  Four times the waves, a quarter of the chain each.
+__global__ __launch_bounds__(256) void k_enc_fdct_quantize4(int16_t *qdct, int32_t *nonzero, int16_t *dct_out, const int16_t *x,
+                                                           const uint16_t *dequant, const int16_t *enquant, int64_t n) {
+  __shared__ int s_d[64], s_m[64], s_l[64], s_z[64];   // by natural position: step, reciprocal {m, l}, zig-zag index
+  if (threadIdx.x < 64) {
+    const int z = (int)threadIdx.x, pos = kFZigZag[z];
+    s_d[pos] = (int)dequant[z];
+    s_z[pos] = z;
+    if (enquant) {
+      s_m[pos] = (int)enquant[2 * z];
+      s_l[pos] = (int)enquant[2 * z + 1];
+    } else {   // oc_iquant_init (enquant.c:183-191)
+      const uint32_t d = (uint32_t)dequant[z] << 1;
+      const int l = 31 - __builtin_clz(d);
+      const uint32_t t = 1u + ((1u << (16 + l)) / d);
+      s_m[pos] = (int)(int16_t)(t - 0x10000u);
+      s_l[pos] = l;
+    }
+  }
+  __shared__ int4 s_x[4 * 128];                          // 2 KB a wave: 16 blocks of eight 16-byte pieces (piece r = row r)
+  int4 *lds = s_x + (threadIdx.x >> 6) * 128;
+  const int lane = (int)threadIdx.x & 63, b = lane >> 2, j = lane & 3;
+  const int64_t b0 = ((int64_t)blockIdx.x * 256 + (threadIdx.x & ~63u)) >> 2;   // the wave's first block
+  const int64_t i = b0 + b;
+  // piece pc of block bb lives at lds[bb * 8 + ((pc + bb) & 7)]: rotated, so that sixteen blocks' equal rows spread over the banks
+  {
+    const int4 *g = reinterpret_cast<const int4 *>(x) + b0 * 8;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int idx = q * 64 + lane, bb = idx >> 3, pc = idx & 7;
+      if (b0 + bb < n) lds[bb * 8 + ((pc + bb) & 7)] = g[idx];
+    }
+  }
+  __syncthreads();   // (the tables too)
+  const int *ldw = reinterpret_cast<const int *>(lds);
+  int c0[8], c1[8];   // columns 2j and 2j + 1
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int w = ldw[(b * 8 + ((r + b) & 7)) * 4 + j];
+    c0[r] = sx16(sx16(w) << 2);                          // fdct.c:136
+    c1[r] = sx16((w >> 16) << 2);
+  }
+  if (j == 0) {                                          // fdct.c:139-141: positions 0, 1 and 8
+    c0[0] = sx16(c0[0] + (c0[0] != 0) + 1);
+    c1[0] = sx16(c1[0] + 1);
+    c0[1] = sx16(c0[1] - 1);
+  }
+  fdct8(c0[0], c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7]);
+  fdct8(c1[0], c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every lane of the wave has read the input
+  int *ldww = reinterpret_cast<int *>(lds);
+#pragma unroll
+  for (int k = 0; k < 8; k++) ldww[(b * 8 + ((k + b) & 7)) * 4 + j] = (c0[k] & 0xFFFF) | (c1[k] << 16);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int o[16];           // rows 2j and 2j + 1, natural position (2j + h) * 8 + c at o[h * 8 + c]
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int r = 2 * j + h;
+    const int4 w = lds[b * 8 + ((r + b) & 7)];
+    int v[8] = {sx16(w.x), w.x >> 16, sx16(w.y), w.y >> 16, sx16(w.z), w.z >> 16, sx16(w.w), w.w >> 16};
+    fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+    for (int c = 0; c < 8; c++) o[h * 8 + c] = sx16((v[c] + 2) >> 2);   // fdct.c:149
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int16_t *lds16 = reinterpret_cast<int16_t *>(lds);
+  // where zig-zag index z of block b lies in the wave's area (the same rotation of 16-byte pieces)
+  auto at = [&](int z) { return (b * 8 + (((z >> 3) + b) & 7)) * 8 + (z & 7); };
+  if (dct_out) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds16[at(s_z[(2 * j + (k >> 3)) * 8 + (k & 7)])] = (int16_t)o[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int4 *g = reinterpret_cast<int4 *>(dct_out) + b0 * 8;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int idx = q * 64 + lane, bb = idx >> 3, pc = idx & 7;
+      if (b0 + bb < n) g[idx] = lds[bb * 8 + ((pc + bb) & 7)];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  int nz = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {   // enquant.c:228-245
+    const int pos = (2 * j + (k >> 3)) * 8 + (k & 7);
+    const int z = s_z[pos], d = s_d[pos];
+    int val = o[k] << 1, q = 0;
+    if (abs(val) >= d) {
+      const int sg = val >> 31;
+      val += (d + sg) ^ sg;
+      q = sx16(((((s_m[pos] * val) >> 16) + val) >> s_l[pos]) - sg);
+      nz = max(nz, z);            // (the reference's loop runs up the zig-zag order: the last index that passes is the largest)
+    }
+    lds16[at(z)] = (int16_t)q;
+  }
+  nz = max(nz, __shfl_xor(nz, 1));
+  nz = max(nz, __shfl_xor(nz, 2));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    int4 *g = reinterpret_cast<int4 *>(qdct) + b0 * 8;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int idx = q * 64 + lane, bb = idx >> 3, pc = idx & 7;
+      if (b0 + bb < n) g[idx] = lds[bb * 8 + ((pc + bb) & 7)];
+    }
+  }
+  if (j == 0 && i < n) nonzero[i] = nz;
+}
+
 // The same with the reciprocals handed in: `enquant` is the 64-entry {m, l} table
 // thip_enc_enquant_table_init built once (oc_enc_enquant_table_init, enquant.c:194), as the
 // reference's quantize slot receives it (encint.h:319-320), instead of being re-derived per launch.
@@ -478,7 +592,12 @@ int thip_enc_fdct_quantize_batch(int16_t *qdct, int32_t *nonzero, int16_t *dct, 
   if (n < 0) return THIP_EINVAL;
   if (n == 0) return THIP_OK;
   if (!qdct || !nonzero || !x || !dequant) return THIP_EFAULT;
-  hipLaunchKernelGGL(k_enc_fdct_quantize, grid_for(n), dim3(256), 0, g_batch_stream, qdct, nonzero, dct, x, dequant, (const int16_t *)enquant, n);
+  // four lanes per block (option "enc_fq_lanes" = 1: the round-4 kernel, one block per lane)
+  const bool lanes1 = thip_option("enc_fq_lanes") == 1;
+  if (lanes1)
+    hipLaunchKernelGGL(k_enc_fdct_quantize, grid_for(n), dim3(256), 0, g_batch_stream, qdct, nonzero, dct, x, dequant, (const int16_t *)enquant, n);
+  else
+    hipLaunchKernelGGL(k_enc_fdct_quantize4, grid_for(4 * n), dim3(256), 0, g_batch_stream, qdct, nonzero, dct, x, dequant, (const int16_t *)enquant, n);
   HIP_TRY(hipGetLastError());
   if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;

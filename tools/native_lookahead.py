@@ -1,5 +1,5 @@
 """examples/decode_bench (no Python between the calls) on the cached e2e packets, with and without --lookahead: writes the packets
-into an Ogg file (tests/oggmux.py) and runs the C program.  python tools/native_lookahead.py [sizes] [kinds] [threads] [lookaheads]"""
+into an Ogg file (tests/oggmux.py) and runs the C program.  python tools/native_lookahead.py [sizes] [kinds] [threads] [lookaheads] [pipeline: 0,1]"""
 import json
 import os
 import subprocess
@@ -16,6 +16,7 @@ def main():
     arg = lambda i, d: (sys.argv[i] if len(sys.argv) > i else d).split(",")
     sizes, kinds = arg(1, "720p,1080p,4k"), arg(2, "dense")
     threads, aheads = [int(x) for x in arg(3, "1,4")], [int(x) for x in arg(4, "0,4")]
+    pipes = [int(x) for x in arg(5, "0")]      # 1: decode_bench --pipeline (option fe_pipeline)
     exe = os.path.join(ROOT, "examples", "decode_bench")
     with tempfile.TemporaryDirectory() as td:
         for size in sizes:
@@ -32,8 +33,9 @@ def main():
                 with open(ogv, "wb") as f:
                     f.write(b"".join(ls.finish()))
                 for T in threads:
-                    for la in aheads:
-                        r = subprocess.run([exe, ogv, str(T), "2"] + (["--lookahead", str(la)] if la else []), capture_output=True, text=True, timeout=300)
+                    for la, pipe in [(a_, p_) for a_ in aheads for p_ in pipes if a_ or not p_]:
+                        r = subprocess.run([exe, ogv, str(T), "2"] + (["--lookahead", str(la)] if la else []) + (["--pipeline"] if pipe else []),
+                                           capture_output=True, text=True, timeout=300)
                         line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "{}"
                         try:
                             d = json.loads(line)
