@@ -88,6 +88,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--pipeline")) pipeline = 1;   /* option fe_pipeline: the next announced frame goes to the device inside th_decode_ycbcr_out */
   }
   if (pipeline) thip_set_option("fe_pipeline", 1);
+  if (g_ahead > 8) thip_set_option("fe_lookahead", g_ahead > 16 ? 16 : g_ahead);   /* (the default takes eight announcements at a time) */
   thip_ogg_reader *og = thip_ogg_open_file(argv[1]);
   if (!og || nthreads < 1 || g_loops < 1) return 1;
   /* all packets of the first logical stream */

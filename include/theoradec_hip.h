@@ -159,7 +159,9 @@ typedef struct {
    stream is no longer bound by one host thread.  Returns 0: announced; 1: not taken (no slot free, an empty packet, a context with
    TH_DECCTL_THIP_SET_DEVICE_DC / _DEVICE_TOKENS on, a process confined to one CPU) -- harmless, the packet is parsed in its
    th_decode_packetin as ever.  A th_decode_packetin whose packet is not the oldest announced one drops everything announced and
-   parses the ordinary way: announcing is a hint, never a requirement, and the pictures are the same either way. */
+   parses the ordinary way: announcing is a hint, never a requirement, and the pictures are the same either way.
+   (Except under option fe_pipeline = 1, include/theora_hip.h: there th_decode_ycbcr_out hands the oldest announced packet's frame to
+   the device before it waits for its own picture, and the next th_decode_packetin MUST bring that packet -- TH_EINVAL otherwise.) */
 #define TH_DECCTL_THIP_PREFETCH_PACKET (0x7105)
 /* Which GPU the context's device state lives on (th_decode_alloc_on, option "device" / THIP_DEVICE): buf = int, receives the
    device index (thip_state_device); TH_EINVAL for a context without device state (slot-trace mode). */

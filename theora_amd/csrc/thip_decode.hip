@@ -247,7 +247,13 @@ struct thip_state {
   int enq_level_slots;       // blocks that came through thip_state_frag_recon_levels (the frame is then in the levels form)
   int enq_tile_blocks;       // ... of them in the tile being filled (enq_last_tile)
   // token lists expanded on the device (thip_state_decode_token_lists): pinned staging, its device copy, work arrays
-  uint32_t *h_tl, *d_tl;
+  uint32_t *h_tl, *d_tl;     // (h_tl: the staging buffer of the frame being handed over, one of h_tl_buf)
+  // Two pinned staging buffers by turns: the host may write frame N + 1's lists while frame N's kernels still read theirs (the
+  // th_decode_* front end with option fe_pipeline hands frame N + 1 over before it has waited for frame N).  The device copy d_tl
+  // and the work arrays exist once: what uses them runs on one stream, in order.
+  uint32_t *h_tl_buf[2];
+  int tl_buf;                // which of the two h_tl is
+  int64_t tl_buf_serial[2];  // frame_serial of the frame that last used each (its kernels have read it once that frame is done)
   size_t tl_cap;            // bytes of each
   int tl_ready;             // all of the buffers below exist and d_frag_pos is filled
   int16_t *d_tl_tmp;        // [nfrags][64]
@@ -705,7 +711,8 @@ void thip_state_free(thip_state *st) {
   if (st->ev_order) (void)hipEventDestroy(st->ev_order);
   if (st->d_edge) (void)hipFree(st->d_edge);
   if (st->d_edge_sb) (void)hipFree(st->d_edge_sb);
-  if (st->h_tl) (void)hipHostFree(st->h_tl);
+  for (int k = 0; k < 2; k++)
+    if (st->h_tl_buf[k]) (void)hipHostFree(st->h_tl_buf[k]);
   if (st->d_tl) (void)hipFree(st->d_tl);
   if (st->d_tl_tmp) (void)hipFree(st->d_tl_tmp);
   if (st->d_tl_last) (void)hipFree(st->d_tl_last);
@@ -1640,6 +1647,15 @@ static int wait_staging_free(thip_state *st) {
   if (st->out_done_serial >= st->staging_serial) return THIP_OK;
   return wait_event(st->ev_staging);
 }
+// ... for the token lists: the OTHER of the two buffers is taken, which the frame before the previous one used -- a caller that
+// looks at its pictures has waited for that frame long ago, so nothing is asked even with the previous frame still on the device.
+static int tl_take_staging(thip_state *st) {
+  const int nb = st->tl_buf ^ 1;
+  if (st->ev_staging && st->out_done_serial < st->tl_buf_serial[nb] && wait_event(st->ev_staging) < 0) return THIP_EFAULT;
+  st->tl_buf = nb;
+  st->h_tl = st->h_tl_buf[nb];
+  return THIP_OK;
+}
 
 int thip_frame_begin(thip_state *st, int frame_type) {
   if (!st) return THIP_EFAULT;
@@ -2111,7 +2127,9 @@ static int tl_ensure(thip_state *st) {
   const TlLayout y = tl_layout(st);
   // (each buffer on its own: a failed allocation is retried by the next call, nothing is used before all exist)
   st->tl_cap = (y.o_tok + (size_t)tl_token_capacity(st) + 8) * 4;
-  if (!st->h_tl) HIP_TRY(hipHostMalloc((void **)&st->h_tl, st->tl_cap, hipHostMallocDefault));
+  for (int k = 0; k < 2; k++)
+    if (!st->h_tl_buf[k]) HIP_TRY(hipHostMalloc((void **)&st->h_tl_buf[k], st->tl_cap, hipHostMallocDefault));
+  st->h_tl = st->h_tl_buf[st->tl_buf];
   if (!st->d_tl) HIP_TRY(hipMalloc((void **)&st->d_tl, st->tl_cap));
   if (!st->d_tl_tmp) HIP_TRY(hipMalloc((void **)&st->d_tl_tmp, (size_t)st->nfrags * 128));
   if (!st->d_tl_last) HIP_TRY(hipMalloc((void **)&st->d_tl_last, y.nf));
@@ -2138,7 +2156,7 @@ int thip_state_token_lists_staging(thip_state *st, thip_token_staging *out) {
   DeviceGuard dg(st->device);
   int rc = tl_ensure(st);
   if (rc) return rc;
-  if (wait_staging_free(st) < 0) return THIP_EFAULT;
+  if (tl_take_staging(st) < 0) return THIP_EFAULT;
   const TlLayout y = tl_layout(st);
   out->coded = reinterpret_cast<int32_t *>(st->h_tl + y.o_cl);
   out->frag_meta = st->h_tl + y.o_meta;
@@ -2203,7 +2221,7 @@ int thip_state_token_lists_open(thip_state *st, const thip_token_lists *tl) {
     if (rc) return rc;
     // the previous frame's kernels must have read the staging buffer before it is reused (thip_state_token_lists_staging has
     // seen to that if the caller went through it)
-    if (!claimed && wait_staging_free(st) < 0) return THIP_EFAULT;
+    if (!claimed && tl_take_staging(st) < 0) return THIP_EFAULT;
     uint32_t *h = st->h_tl;
     memset(h, 0, THIP_TL_HDR * 4);
     for (int p = 0; p < 3; p++)
@@ -2503,6 +2521,7 @@ int thip_state_token_lists_finish(thip_state *st, const int16_t *dc) {
     if (!st->ev_staging) HIP_TRY(hipEventCreateWithFlags(&st->ev_staging, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(st->ev_staging, s));
     st->staging_serial = st->frame_serial;
+    st->tl_buf_serial[st->tl_buf] = st->frame_serial;
   }
   return res;
 }

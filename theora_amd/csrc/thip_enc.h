@@ -293,11 +293,22 @@ __global__ __launch_bounds__(256) void k_enc_halfpel(uint32_t *out, int32_t *dc_
   uint2 s[8], e0[10], e1[10];
   load_rows8(s, src_plane + src_offs[i], ystride);
   const uint8_t *rp = ref_plane + ref_offs[i] - ystride;
+  if (dx == 0) {
 #pragma unroll
-  for (int r = 0; r < 10; r++) e0[r] = load_row8(rp + (ptrdiff_t)r * ystride);
-  if (dx != 0) {
+    for (int r = 0; r < 10; r++) e0[r] = load_row8(rp + (ptrdiff_t)r * ystride);
+  } else {
+    // columns 0 and dx of a row are nine consecutive bytes: ONE 12-byte load a row (the kernel waits for its loads more than it
+    // computes), the second column shifted out of it (dx is the grid's y: no selects)
+    const uint8_t *rq = rp + (dx < 0 ? -1 : 0);
 #pragma unroll
-    for (int r = 0; r < 10; r++) e1[r] = load_row8(rp + (ptrdiff_t)r * ystride + dx);
+    for (int r = 0; r < 10; r++) {
+      Row12 w;
+      __builtin_memcpy(&w, rq + (ptrdiff_t)r * ystride, 12);
+      const uint2 lo = make_uint2(w.a, w.b);
+      const uint2 hi = make_uint2(__builtin_amdgcn_alignbyte(w.b, w.a, 1), __builtin_amdgcn_alignbyte(w.c, w.b, 1));
+      e0[r] = dx < 0 ? hi : lo;
+      e1[r] = dx < 0 ? lo : hi;
+    }
   }
   constexpr bool kSad = OP == THIP_ENC_SAD2_THRESH;
   pk16 S[8][4];
