@@ -57,6 +57,16 @@ using namespace thip;
 // ---------------------------------------------------------------------------------------
 // run-time options: one table, one parser (include/theora_hip.h: thip_set_option)
 // ---------------------------------------------------------------------------------------
+// a spinning thread's pause: the x86 hint where there is one (the unguarded builtin kept other hosts from compiling)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::this_thread::yield();
+#endif
+}
 namespace {
 struct Option {
   const char *name;
@@ -863,7 +873,7 @@ static int wait_event(hipEvent_t ev) {
         timespec ts = {0, 20000};
         nanosleep(&ts, nullptr);
       } else {
-        __builtin_ia32_pause();
+        cpu_relax();
       }
     }
   }
@@ -2351,6 +2361,11 @@ int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t
       h[THIP_TL_ARRIVE + p * 64 + z] = arrivals[p][z];
     }
   if (ntokens && tokens != h + st->tl_o_tok + at) memcpy(h + st->tl_o_tok + at, tokens, (size_t)ntokens * 4);   // (not if the caller wrote them there)
+  // INVARIANT: the whole header travels with every group, and the host goes on to write the NEXT group's columns
+  // [z1, ...) of the same pinned header while this copy may still be reading it.  That is harmless only because (a) a group's kernels
+  // read nothing but their own columns [z0, z1) of the tables OFF / LEN / CARRY / ARRIVE / ROFF and the frame-constant words, which
+  // are final when this launch is issued, and (b) the next group's copy brings the header again, its own columns final by then.
+  // A kernel that reads another group's column must not be added without copying columns per group (or a second header).
   TlCopyK C;
   C.src[0] = reinterpret_cast<const int4 *>(h);
   C.dst[0] = reinterpret_cast<int4 *>(st->d_tl);

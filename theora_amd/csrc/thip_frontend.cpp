@@ -166,6 +166,15 @@ static const char *const kFeNames[FE_NSEC] = {"header+coded flags", "modes+MVs",
                                               "expand+dequant+stage", "flush (H2D, launch, sync)", "ycbcr_out (D2H)",
                                               "lists: tokens packed", "lists: fragment words", "lists: begin (stage, launch)",
                                               "lists: finish (launch)"};
+static inline void cpu_relax() {   // a spinning thread's pause (the x86 hint where there is one)
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::this_thread::yield();
+#endif
+}
 static inline double fe_now() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1186,7 +1195,7 @@ void fe_worker_frame(th_dec_ctx *d) {
   FeWorker &w = *d->worker;
   // (the lists of index 0 are a few tens of microseconds of the decoder's work away)
   for (unsigned spins = 0; !w.z0_ready.load(std::memory_order_acquire); spins++) {
-    if (spins < 8192) __builtin_ia32_pause();
+    if (spins < 8192) cpu_relax();
     else std::this_thread::yield();
   }
   fe_undo_dc(d);
@@ -2114,7 +2123,7 @@ static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
     if (!with_worker || dc_done) return;
     FeWorker &w = *d->worker;
     for (unsigned spins = 0; !w.done.load(std::memory_order_acquire); spins++) {
-      if (spins < 8192) __builtin_ia32_pause();
+      if (spins < 8192) cpu_relax();
       else std::this_thread::yield();
     }
     dc_done = true;
@@ -2523,7 +2532,7 @@ static void fe_slot_main(FeSlot *sl) {
 static void fe_slot_wait(FeSlot &sl) {
   for (unsigned spins = 0; spins < 4096; spins++) {
     if (sl.done.load(std::memory_order_acquire)) return;
-    __builtin_ia32_pause();
+    cpu_relax();
   }
   std::unique_lock<std::mutex> lk(sl.mu);
   sl.cv_done.wait(lk, [&] { return sl.done.load(std::memory_order_acquire) != 0; });
