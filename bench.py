@@ -254,7 +254,10 @@ def e2e_keyed_entry(size="720p", nframes=8, loops=30, ahead=8):
         ost.close()
         seq = pkts * loops
         res, crcs, bad = {}, {}, {}
-        for label, la in (("plain_loop", 0), ("lookahead_%d" % ahead, ahead)):
+        from theora_amd import _lib as _l
+        for label, la, pipe in (("plain_loop", 0, 0), ("lookahead_%d" % ahead, ahead, 0), ("lookahead_%d_pipelined" % ahead, ahead, 1)):
+            # (the third leg: option fe_pipeline -- th_decode_ycbcr_out hands the next announced frame to the device before it waits)
+            _l.load().thip_set_option(b"fe_pipeline", pipe)
             dec = Decoder(hdr)
             for p in pkts:              # warm-up: device buffers, streams, parser threads
                 dec.packetin(p)
@@ -289,6 +292,7 @@ def e2e_keyed_entry(size="720p", nframes=8, loops=30, ahead=8):
                 nb += zlib.crc32(b"".join(x.tobytes() for x in planes)) != want[k % len(pkts)]
             bad[label] = nb + sum(1 for k, v in enumerate(c) if v != want[k])
             dec.close()
+        _l.load().thip_set_option(b"fe_pipeline", 0)
         same = len(set(tuple(v) for v in crcs.values())) == 1
         if any(bad.values()):
             return {"error": "pictures differ from the oracle's: %r frames of %d" % (bad, len(seq))}
@@ -299,6 +303,11 @@ def e2e_keyed_entry(size="720p", nframes=8, loops=30, ahead=8):
                 "note": "host-bound (Python caller): the plain loop is one entropy-decode thread per stream; announced packets are "
                         "parsed on up to eight library threads, which also pair tokens and fragments for the device (DESIGN.md 5.1)"}
     except Exception as e:
+        try:
+            from theora_amd import _lib as _l2
+            _l2.load().thip_set_option(b"fe_pipeline", 0)
+        except Exception:
+            pass
         return {"error": str(e)[:300]}
 
 
