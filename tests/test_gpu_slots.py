@@ -219,16 +219,23 @@ def test_enc_metric_sites(hip, op):
     assert call(_lib.ENC_OPS["ssd"], [0], [0]) == _lib.EINVAL
 
 
+@pytest.mark.parametrize("lanes", [2, 3])
 @pytest.mark.parametrize("op", ["satd2", "sad2_thresh"])
-def test_enc_metric_halfpel_sites(hip, op):
+def test_enc_metric_halfpel_sites(hip, op, lanes):
     """The half-pel refinement's form (thip_enc_frag_metric_halfpel_batch): every block against the half-pel vectors around its
     whole-pel vector -- against the oracle's restatement of the reference's call pattern (oc_mcenc_ysatd_halfpel_mbrefine,
     mcenc.c:606-657: mvoffset0 / mvoffset1 from the signs of the vector, then oc_enc_frag_satd2 / oc_enc_frag_sad2_thresh on the
     two blocks).  Whole-pel vectors of both signs and zero on both axes (which of the two blocks gets the step, and whether a
     diagonal site pairs {(0,0),(dx,dy)} or {(dx,0),(0,dy)}, follows from them); all eight sites in the reference's order, subsets
     in other orders, single sites; reference positions of every byte alignment; saturated and checkerboard pictures."""
-    from theora_amd import _lib
     rng = np.random.default_rng(23 + len(op))
+    from theora_amd import _lib
+    with util.options(_lib.load(), enc_halfpel_lanes=lanes):     # 2: a lane per side, four sites each (default); 3: a lane per dx
+        _halfpel_sites_body(hip, op, rng)
+
+
+def _halfpel_sites_body(hip, op, rng):
+    from theora_amd import _lib
     stride, H = 272, 136
     src = rng.integers(0, 256, (H, stride)).astype(np.uint8)
     ref = np.clip(src.astype(np.int32) + rng.integers(-20, 21, (H, stride)), 0, 255).astype(np.uint8)

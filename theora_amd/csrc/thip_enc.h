@@ -273,42 +273,34 @@ __global__ __launch_bounds__(256) void k_enc_sites(uint32_t *out, int32_t *dc_ou
 // {0, d} and WHICH of the two blocks gets the step follows from the signs (mcenc.c:633-636: the block towards zero comes first,
 // as oc_state_get_mv_offsets has it); the average does not care which is first, so all that matters is whether the x step and the
 // y step of a diagonal site land on the same block -- the pair {(0, 0), (dx, dy)} -- or on different ones -- {(dx, 0), (0, dy)}.
-// One lane = one block and one dx (the grid's y: a wave has one dx, its branches are scalar): the ten rows around the whole-pel
-// position are loaded once per column (0 and dx) and serve the lane's two or three sites.  dx = 0: both sites average vertically
-// neighbouring rows, nine averaged rows prepared once (all three horizontal Hadamard levels) serve both.  Results site-major.
+// One lane = one block and one side (the grid's y: dx = -1 or +1, so a wave's branches are scalar): the ten rows around the whole-pel
+// position are loaded once (one 12-byte window a row holds columns 0 and dx) and serve the lane's four sites -- the three with its dx
+// and the vertical site on its side, (0, dx).  Results site-major.
 __device__ __forceinline__ bool halfpel_first_gets_step(int v, int d) { return (((2 * v + d) ^ d) < 0); }   // OC_SIGNMASK(((vec<<1)+d)^d), mcenc.c:633-634
-template <int OP>
-__global__ __launch_bounds__(256) void k_enc_halfpel(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
-                                                    int ystride, const int32_t *src_offs, const int32_t *ref_offs, const int16_t *vecs,
-                                                    const SitesK K, int64_t nblocks) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nblocks) return;
-  const int dxi = (int)blockIdx.y, dx = dxi - 1;
-  int c[3];
+// the three sites with one dx (DX = -1 / +1), and with VERT the vertical site of the same side, (0, DX)
+template <int OP, int DX, bool VERT>
+__device__ __forceinline__ void halfpel_side(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
+                                             int ystride, const int32_t *src_offs, const int32_t *ref_offs, const int16_t *vecs,
+                                             const SitesK &K, int64_t nblocks, int64_t i) {
+  int c[4];
 #pragma unroll
-  for (int dyi = 0; dyi < 3; dyi++) c[dyi] = K.site_of[dyi * 3 + dxi];
-  if ((c[0] & c[1] & c[2]) < 0) return;
+  for (int dyi = 0; dyi < 3; dyi++) c[dyi] = K.site_of[dyi * 3 + DX + 1];
+  c[3] = VERT ? K.site_of[(DX + 1) * 3 + 1] : -1;
+  if ((c[0] & c[1] & c[2] & c[3]) < 0) return;
   const int vv = vecs[i];
   const int vx = (int)(int8_t)(vv & 0xFF), vy = (int)(int8_t)(vv >> 8);   // OC_MV_X / OC_MV_Y, state.h:232-240
   uint2 s[8], e0[10], e1[10];
   load_rows8(s, src_plane + src_offs[i], ystride);
-  const uint8_t *rp = ref_plane + ref_offs[i] - ystride;
-  if (dx == 0) {
+  // columns 0 and DX of a row are nine consecutive bytes: one 12-byte load a row, the second column shifted out of it
+  const uint8_t *rq = ref_plane + ref_offs[i] - ystride + (DX < 0 ? -1 : 0);
 #pragma unroll
-    for (int r = 0; r < 10; r++) e0[r] = load_row8(rp + (ptrdiff_t)r * ystride);
-  } else {
-    // columns 0 and dx of a row are nine consecutive bytes: ONE 12-byte load a row (the kernel waits for its loads more than it
-    // computes), the second column shifted out of it (dx is the grid's y: no selects)
-    const uint8_t *rq = rp + (dx < 0 ? -1 : 0);
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-      Row12 w;
-      __builtin_memcpy(&w, rq + (ptrdiff_t)r * ystride, 12);
-      const uint2 lo = make_uint2(w.a, w.b);
-      const uint2 hi = make_uint2(__builtin_amdgcn_alignbyte(w.b, w.a, 1), __builtin_amdgcn_alignbyte(w.c, w.b, 1));
-      e0[r] = dx < 0 ? hi : lo;
-      e1[r] = dx < 0 ? lo : hi;
-    }
+  for (int r = 0; r < 10; r++) {
+    Row12 w;
+    __builtin_memcpy(&w, rq + (ptrdiff_t)r * ystride, 12);
+    const uint2 lo = make_uint2(w.a, w.b);
+    const uint2 hi = make_uint2(__builtin_amdgcn_alignbyte(w.b, w.a, 1), __builtin_amdgcn_alignbyte(w.c, w.b, 1));
+    e0[r] = DX < 0 ? hi : lo;
+    e1[r] = DX < 0 ? lo : hi;
   }
   constexpr bool kSad = OP == THIP_ENC_SAD2_THRESH;
   pk16 S[8][4];
@@ -319,61 +311,29 @@ __global__ __launch_bounds__(256) void k_enc_halfpel(uint32_t *out, int32_t *dc_
       row_h12(S[r]);
     }
   }
-  if (dx == 0) {
-    // rows r, r + 1 averaged for r = 0..8 (pixel rows -1..7): the site above takes the first eight, the site below the last eight
-    uint2 a[9];
+  const bool xfirst = halfpel_first_gets_step(vx, DX);
 #pragma unroll
-    for (int r = 0; r < 9; r++) a[r] = avg_row(e0[r], e0[r + 1]);
-    if (kSad) {
-#pragma unroll
-      for (int dyi = 0; dyi < 3; dyi += 2) {
-        if (c[dyi] < 0) continue;
-        uint32_t v = 0;
-#pragma unroll
-        for (int r = 0; r < 8; r++) v = sad_row(s[r], a[r + dyi / 2], v);
-        out[(int64_t)c[dyi] * nblocks + i] = v;
-      }
-    } else {
-      pk16 E[9][4];
-#pragma unroll
-      for (int r = 0; r < 9; r++) {
-        row_sd(E[r], a[r]);
-        row_h12(E[r]);
-      }
-#pragma unroll
-      for (int dyi = 0; dyi < 3; dyi += 2) {
-        if (c[dyi] < 0) continue;
-        pk16 D[8][4];
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) D[r][j] = S[r][j] - E[r + dyi / 2][j];
-        int dc;
-        const uint32_t v = satd_vert(D, dc);
-        out[(int64_t)c[dyi] * nblocks + i] = v;
-        if (dc_out) dc_out[(int64_t)c[dyi] * nblocks + i] = dc;
-      }
-    }
-    return;
-  }
-  const bool xfirst = halfpel_first_gets_step(vx, dx);
-#pragma unroll
-  for (int dyi = 0; dyi < 3; dyi++) {
-    if (c[dyi] < 0) continue;
-    const int dy = dyi - 1;
-    // the two blocks: {(0, 0), (dx, dy)} when both steps go to the same one, {(dx, 0), (0, dy)} otherwise (dy = 0: {(0, 0), (dx, 0)})
+  for (int k = 0; k < (VERT ? 4 : 3); k++) {
+    if (c[k] < 0) continue;
+    const int dy = k < 3 ? k - 1 : DX;
+    // the two blocks: {(0, 0), (dx, dy)} when both steps go to the same one, {(dx, 0), (0, dy)} otherwise (dy = 0: {(0, 0), (dx, 0)};
+    // the vertical site: {(0, 0), (0, dy)})
     const bool same = dy == 0 || xfirst == halfpel_first_gets_step(vy, dy);
     uint2 a[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const uint2 p0 = e0[r + 1], p1 = e1[r + 1], q0 = e0[r + 1 + dy], q1 = e1[r + 1 + dy];
-      a[r] = avg_row(same ? p0 : p1, same ? q1 : q0);
+      if (k == 3) {
+        a[r] = avg_row(e0[r + 1], e0[r + 1 + dy]);
+      } else {
+        const uint2 p0 = e0[r + 1], p1 = e1[r + 1], q0 = e0[r + 1 + dy], q1 = e1[r + 1 + dy];
+        a[r] = avg_row(same ? p0 : p1, same ? q1 : q0);
+      }
     }
     if (kSad) {
       uint32_t v = 0;
 #pragma unroll
       for (int r = 0; r < 8; r++) v = sad_row(s[r], a[r], v);
-      out[(int64_t)c[dyi] * nblocks + i] = v;
+      out[(int64_t)c[k] * nblocks + i] = v;
     } else {
       pk16 D[8][4];
 #pragma unroll
@@ -386,9 +346,77 @@ __global__ __launch_bounds__(256) void k_enc_halfpel(uint32_t *out, int32_t *dc_
       }
       int dc;
       const uint32_t v = satd_vert(D, dc);
-      out[(int64_t)c[dyi] * nblocks + i] = v;
-      if (dc_out) dc_out[(int64_t)c[dyi] * nblocks + i] = dc;
+      out[(int64_t)c[k] * nblocks + i] = v;
+      if (dc_out) dc_out[(int64_t)c[k] * nblocks + i] = dc;
     }
+  }
+}
+// the two vertical sites, (0, -1) and (0, +1): rows r, r + 1 averaged for r = 0..8 (pixel rows -1..7), prepared once -- the site above
+// takes the first eight, the site below the last eight
+template <int OP>
+__device__ __forceinline__ void halfpel_vertical(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
+                                                 int ystride, const int32_t *src_offs, const int32_t *ref_offs, const SitesK &K,
+                                                 int64_t nblocks, int64_t i) {
+  const int c[2] = {K.site_of[1], K.site_of[7]};
+  if ((c[0] & c[1]) < 0) return;
+  uint2 s[8], e0[10], a[9];
+  load_rows8(s, src_plane + src_offs[i], ystride);
+  const uint8_t *rp = ref_plane + ref_offs[i] - ystride;
+#pragma unroll
+  for (int r = 0; r < 10; r++) e0[r] = load_row8(rp + (ptrdiff_t)r * ystride);
+#pragma unroll
+  for (int r = 0; r < 9; r++) a[r] = avg_row(e0[r], e0[r + 1]);
+  if (OP == THIP_ENC_SAD2_THRESH) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      if (c[k] < 0) continue;
+      uint32_t v = 0;
+#pragma unroll
+      for (int r = 0; r < 8; r++) v = sad_row(s[r], a[r + k], v);
+      out[(int64_t)c[k] * nblocks + i] = v;
+    }
+  } else {
+    pk16 S[8][4], E[9][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      row_sd(S[r], s[r]);
+      row_h12(S[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+      row_sd(E[r], a[r]);
+      row_h12(E[r]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      if (c[k] < 0) continue;
+      pk16 D[8][4];
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) D[r][j] = S[r][j] - E[r + k][j];
+      int dc;
+      const uint32_t v = satd_vert(D, dc);
+      out[(int64_t)c[k] * nblocks + i] = v;
+      if (dc_out) dc_out[(int64_t)c[k] * nblocks + i] = dc;
+    }
+  }
+}
+// LANES = 3: the grid's y is dx + 1 (two or three sites a lane); LANES = 2: y is the side, four sites a lane
+template <int OP, int LANES>
+__global__ __launch_bounds__(256) void k_enc_halfpel(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,
+                                                    int ystride, const int32_t *src_offs, const int32_t *ref_offs, const int16_t *vecs,
+                                                    const SitesK K, int64_t nblocks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nblocks) return;
+  const int y = (int)blockIdx.y;
+  if (LANES == 2) {
+    if (y == 0) halfpel_side<OP, -1, true>(out, dc_out, src_plane, ref_plane, ystride, src_offs, ref_offs, vecs, K, nblocks, i);
+    else halfpel_side<OP, 1, true>(out, dc_out, src_plane, ref_plane, ystride, src_offs, ref_offs, vecs, K, nblocks, i);
+  } else {
+    if (y == 0) halfpel_side<OP, -1, false>(out, dc_out, src_plane, ref_plane, ystride, src_offs, ref_offs, vecs, K, nblocks, i);
+    else if (y == 1) halfpel_vertical<OP>(out, dc_out, src_plane, ref_plane, ystride, src_offs, ref_offs, K, nblocks, i);
+    else halfpel_side<OP, 1, false>(out, dc_out, src_plane, ref_plane, ystride, src_offs, ref_offs, vecs, K, nblocks, i);
   }
 }
 
