@@ -525,6 +525,24 @@ def main_enc(emit=True, subset=False):
             results.append(dict(kernel="oc_enc_frag_%s, motion-search form, %d frames per call" % (op, F), units=baseF.size * len(sites),
                                 unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=3 * ncpu / tc_pairs,
                                 unique_bytes=2 * baseF.size * 64 + baseF.size * len(sites) * (4 if op == "sad" else 8)))
+        if F == 4:
+            vecsF = ((rng.integers(-2, 3, baseF.size) & 0xFF) | (rng.integers(-2, 3, baseF.size) << 8)).astype(np.int16)
+            d_vecsF = torch.from_numpy(vecsF).cuda()
+            for op, bpu in (("satd2", 136 + 64), ("sad2_thresh", 132 + 64)):
+                call = lambda: theora_amd.enc_metric_halfpel_batch(op, d_curF, d_prevF, stride, d_baseF, d_baseF, d_vecsF, hp_sites)   # noqa: E731
+                t = timed(call)
+                v, dc = call()
+                ncpu = 6000
+                sel = rng.integers(0, baseF.size, ncpu)
+                t0 = time.perf_counter()
+                wv, wdc = oracle.enc_halfpel_sites(op, curF, prevF, stride, baseF[sel], baseF[sel], vecsF[sel], hp_sites)
+                tc_pairs = time.perf_counter() - t0
+                assert np.array_equal(wv, v.cpu().numpy().view(np.uint32)[:, sel])
+                if dc is not None:
+                    assert np.array_equal(wdc, dc.cpu().numpy()[:, sel])
+                results.append(dict(kernel="oc_enc_frag_%s, half-pel refinement form, %d frames per call" % (op, F), units=baseF.size * len(hp_sites),
+                                    unit="(block,candidate)", seconds=t, bytes_per_unit=bpu, cpu_rate=ncpu * len(hp_sites) / tc_pairs,
+                                    unique_bytes=2 * baseF.size * 64 + baseF.size * 2 + baseF.size * len(hp_sites) * (4 if op != "satd2" else 8)))
     # --- the per-macro-block cost maps of a whole frame (thip_enc_mb_cost_maps: oc_mb_intra_satd, oc_mb_activity, _fast) ---------
     Wc, Hc = 1920, 1088
     cplanes = [rng.integers(0, 256, (Hc, Wc)).astype(np.uint8) for _ in range(3)]

@@ -85,11 +85,14 @@ __device__ __forceinline__ uint32_t ssd_rows(const uint2 a[8], const uint2 b[8])
 
 // ---- SATD -------------------------------------------------------------------------------------------------------
 // one row of pixels -> four registers {x[2j] + x[2j+1], x[2j] - x[2j+1]}, j = 0..3 (the c0 level)
+// (one perm spreads the two bytes over the halves; the butterfly INSIDE the register is one packed multiply-add whose operand
+//  selects read the upper half twice and the lower half twice -- {hi, hi} * {1, -1} + {lo, lo}: the compiler folds the two
+//  broadcasts into op_sel / op_sel_hi, no second perm)
 __device__ __forceinline__ pk16 pair_sd(uint32_t w, bool upper) {
-  const pk16 e = as_pk(__builtin_amdgcn_perm(0u, w, upper ? 0x0c020c02u : 0x0c000c00u));   // {even, even}
-  const pk16 o = as_pk(__builtin_amdgcn_perm(0u, w, upper ? 0x0c030c03u : 0x0c010c01u));   // {odd, odd}
+  const pk16 x = as_pk(__builtin_amdgcn_perm(0u, w, upper ? 0x0c030c02u : 0x0c010c00u));   // {even, odd}
+  const pk16 xh = {x.y, x.y}, xl = {x.x, x.x};
   const pk16 k = {(short)1, (short)-1};
-  return o * k + e;
+  return xh * k + xl;
 }
 __device__ __forceinline__ void row_sd(pk16 out[4], uint2 row) {
   out[0] = pair_sd(row.x, false);
@@ -136,7 +139,11 @@ __device__ __forceinline__ uint32_t satd_vert(pk16 D[8][4], int &dc) {
 #pragma unroll
   for (int r = 0; r < 8; r += 2)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc = sum2_u16(__builtin_elementwise_max(pk_abs(D[r][j]), pk_abs(D[r + 1][j])), acc);
+    for (int j = 0; j < 4; j++) {
+      // max(|p|, |q|) = max(max(p, q), -min(p, q)): four packed operations instead of the five of two absolute values and a maximum
+      const pk16 p = D[r][j], q = D[r + 1][j], z = {0, 0};
+      acc = sum2_u16(__builtin_elementwise_max(__builtin_elementwise_max(p, q), z - __builtin_elementwise_min(p, q)), acc);
+    }
   return 2u * acc - (uint32_t)(dc < 0 ? -dc : dc);
 }
 // D[r][j]: the c0 level of the difference block (row r, pixel pair j): both remaining horizontal levels, then satd_vert.
