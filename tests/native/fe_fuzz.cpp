@@ -47,6 +47,7 @@ int thip_option(const char *name) {   // the library's option table is not linke
   if (name && !strcmp(name, "fe_lookahead")) return 4;
   if (name && !strcmp(name, "fe_worker_pin")) return 1;
   if (name && !strcmp(name, "fe_assign")) return 2;
+  if (name && !strcmp(name, "fe_prof")) return getenv("THIP_FE_PROF") ? 1 : 0;   // (the stage table, for tools/fe_tokbench.cpp)
   if (name && !strcmp(name, "fe_assign_settle")) return 16;   // (short, so that the fuzzed streams cross the rule's switch points)
   return 0;
 }

@@ -435,13 +435,15 @@ int parse_huff_tree(BitReader &br, HuffTree &t, int depth, int *nleaves) {   // 
 const uint8_t kTokExtraBits[32] = {0, 0, 0, 2, 3, 4, 12, 3, 6, 0, 0, 0, 0, 1, 1, 1,
                                    1, 2, 3, 4, 5, 6, 10, 1, 1, 1, 1, 1, 3, 4, 2, 3};
 constexpr uint32_t kLutMore = 0x80000000u;
-// lut entry: token | code length << 8 | (code length + extra bits) << 16, so that how far the bit
-// window moves is known one load after the window (the token loop's dependency chain), or
+// lut entry: (code length + extra bits) | code length << 8 | token << 16, so that how far the bit
+// window moves is known one load after the window -- in the entry's LOW byte, which is what a variable shift reads its count
+// from: no instruction between the load and the shift on the token loop's dependency chain --, or
 // kLutMore | node when the code is longer than the table covers.
+inline uint32_t huff_lut_entry(int token, int len) { return (uint32_t)(len + kTokExtraBits[token]) | ((uint32_t)len << 8) | ((uint32_t)token << 16); }
 void build_huff_lut(HuffTree &t) {
   for (int v = 0; v < (1 << kHuffLutBits); v++) {
     uint32_t e = 0;
-    if (t.root_leaf) e = (uint32_t)(t.root_leaf - 1) | ((uint32_t)kTokExtraBits[t.root_leaf - 1] << 16);   // zero-length code
+    if (t.root_leaf) e = huff_lut_entry(t.root_leaf - 1, 0);   // zero-length code
     else {
       int node = 0, len = 0;
       e = kLutMore;
@@ -449,8 +451,7 @@ void build_huff_lut(HuffTree &t) {
         const int c = t.child[node][(v >> (kHuffLutBits - 1 - len)) & 1];
         len++;
         if (c < 0) {
-          const int token = -c - 1;
-          e = (uint32_t)token | ((uint32_t)len << 8) | ((uint32_t)(len + kTokExtraBits[token]) << 16);
+          e = huff_lut_entry(-c - 1, len);
           break;
         }
         node = c;
@@ -653,7 +654,7 @@ inline int read_token(BitReader &br, const HuffTree &t) {
   const uint32_t e = t.lut[w >> (32 - kHuffLutBits)];
   if (!(e & kLutMore)) {
     br.skip((e >> 8) & 0xFF);
-    return e & 0xFF;
+    return (e >> 16) & 0xFF;
   }
   // longer than the table covers: finish the walk on the peeked word, one skip at the end
   int node = (int)(e & 0x7FFFu), len = kHuffLutBits;
@@ -806,26 +807,49 @@ __attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &
   uint8_t *const ppos = PAIR ? pa->pos : nullptr;
   const uint32_t pc0 = PAIR ? pa->c0 : 0u;
   // the reader's state as plain locals: br itself is only touched on the slow paths, so nothing
-  // here has its address taken
+  // here has its address taken.  The bit position is not carried along: pos == 8 * bytepos - have wherever the reader stands
+  // (every refill adds the same bits to both, every skip takes them from `have` and adds them to pos), so it is put back
+  // from the two when somebody else reads on.
   uint64_t win = br.win;
   int have = br.have;
-  size_t pos = br.pos, bytepos = br.bytepos;
-  const size_t nbits = br.nbits, nbytes = br.nbytes;
+  size_t bytepos = br.bytepos;
   const uint8_t *const data = br.data;
   size_t *const left_next = &left[p][z];
-  const bool lut_ok = !tree.root_leaf;
   const uint32_t *const lut = tree.lut;
+  // Fast path: eight bytes can be loaded at the read position -- then the next 64 bits are all inside the packet too (the
+  // longest code and the most extra bits together are 44) -- and the tree is not a single leaf: ONE comparison a token,
+  // bytepos against fast_last (-1: never).
+  const ptrdiff_t fast_last = !tree.root_leaf && br.nbytes >= 8 ? (ptrdiff_t)(br.nbytes - 8) : (ptrdiff_t)-1;
+  // what the fast path wants of the window when it starts on a token: fewer than 64 counted bits (a window that is full to the
+  // last bit -- possible only right after a refill nobody consumed from -- cannot be shifted by `have`: a byte is un-counted, its
+  // bits stay where they are and are OR-ed in again, unchanged) and the code's first kHuffLutBits bits (after a token of the fast
+  // path itself there are 12 or more: a topped-up window has 56+ and a token takes at most 44; other readers may leave fewer)
+  auto ready = [&]() {
+    if (have >= 64) {
+      have -= 8;
+      bytepos -= 1;
+    }
+    if (have < kHuffLutBits && (ptrdiff_t)bytepos <= fast_last) {
+      uint64_t v0;
+      memcpy(&v0, data + bytepos, 8);
+      win |= __builtin_bswap64(v0) >> have;
+      bytepos += (size_t)((63 - have) >> 3);
+      have |= 56;
+    }
+  };
+  ready();
   uint32_t run_left = *eobs;   // what the last token's EOB run has left for later lists
   while (n > 0) {
     Tok &k = *out++;
-    bool fast = false;
-    // Fast path: the next 64 bits are all inside the packet (the longest code and the most extra
-    // bits together are 44) and eight bytes can be loaded at the read position.  Nothing on it
-    // depends on the data except through arithmetic: which token comes next and whether the window
+    // Nothing on the fast path depends on the data except through arithmetic: which token comes next and whether the window
     // needs topping up are both close to random, and a mispredicted branch costs more than all the
-    // arithmetic of a token.  (have < 64: a window that is full to the last bit -- possible only
-    // right after a refill nobody consumed from -- cannot be shifted by `have`.)
-    if (lut_ok && have < 64 && pos + 64 <= nbits && bytepos + 8 <= nbytes) {
+    // arithmetic of a token.
+    if (__builtin_expect((ptrdiff_t)bytepos <= fast_last, 1)) {
+      // The table is asked BEFORE the window is topped up: the code's first kHuffLutBits bits are in the window already, so the
+      // look-up -- the load the next token's shift waits for -- starts from the shift of the last token alone, and the top-up
+      // (a load whose address follows from the last token's length, then a swap, a shift and an OR) runs beside it instead of
+      // in front of it.
+      uint32_t e = lut[win >> (64 - kHuffLutBits)];
       // top the window up to 56..63 bits: bits that are loaded but not yet counted in `have` are the
       // stream's own and are OR-ed in again, unchanged, next time
       uint64_t v;
@@ -834,34 +858,30 @@ __attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &
       bytepos += (size_t)((63 - have) >> 3);
       have |= 56;
       const uint64_t w = win;
-      uint32_t e = lut[w >> (64 - kHuffLutBits)];
-      if (e & kLutMore) {
+      if (__builtin_expect((e & kLutMore) != 0, 0)) {
         // a code longer than the table covers (at most 32 bits): finish the walk on the window
         int node = (int)(e & 0x7FFFu), len = kHuffLutBits;
         for (;;) {
           const int c = tree.child[node][(w >> (63 - len)) & 1u];
           len++;
           if (c < 0) {
-            const int token = -c - 1;
-            e = (uint32_t)token | ((uint32_t)len << 8) | ((uint32_t)(len + kTokExtraBits[token]) << 16);
+            e = huff_lut_entry(-c - 1, len);
             break;
           }
           node = c;
         }
       }
-      const int len = (int)((e >> 8) & 0xFF), total = (int)(e >> 16);   // total <= 32 + 12 <= have
+      const int len = (int)((e >> 8) & 0xFF), total = (int)(e & 0xFF);   // total <= 32 + 12 <= have
       win <<= total;   // the only thing the next token waits for
       have -= total;
-      pos += (size_t)total;
       const uint32_t x = (uint32_t)(((w << len) >> 1) >> (63 - (total - len)));   // the extra bits (none: 0)
-      k = kTokTab.tab[kTokTab.base[e & 0xFF] + x];
-      fast = true;
-    }
-    if (!fast) {   // single-leaf tree or the last bytes of the packet
-      br.win = win; br.have = have; br.pos = pos; br.bytepos = bytepos;
+      k = kTokTab.tab[kTokTab.base[(e >> 16) & 0xFF] + x];
+    } else {   // single-leaf tree or the last bytes of the packet
+      br.win = win; br.have = have; br.pos = 8 * bytepos - (size_t)have; br.bytepos = bytepos;
       const TokFast &t = kTokFast.t[read_token(br, tree)];
       expand_token(t, br.read(t.ebits), k);
-      win = br.win; have = br.have; pos = br.pos; bytepos = br.bytepos;
+      win = br.win; have = br.have; bytepos = br.bytepos;
+      ready();
     }
     if (k.eob == 0xFFFFFFFFu) {   // every block still open anywhere ends (7.7.1)
       size_t all = n;
@@ -893,7 +913,7 @@ __attribute__((noinline)) Tok *decode_token_list(BitReader &br, const HuffTree &
     //  advances at least one block, so the list still ends -- which is what libtheora outputs.)
   }
   *eobs = run_left;
-  br.win = win; br.have = have; br.pos = pos; br.bytepos = bytepos;
+  br.win = win; br.have = have; br.pos = 8 * bytepos - (size_t)have; br.bytepos = bytepos;
   return out;
 }
 
