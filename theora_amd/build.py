@@ -21,17 +21,33 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def compile_library(out, extra_flags=(), verbose=False):
+    """hipcc for gfx950 -> `out`.  The .hip files are device + host code; the .cpp files are host code only (the th_decode_* front
+    end, the Ogg demuxer): compiled as plain C++ first -- no device pass over them, and host-only builtins (the front end asks the
+    CPU for BMI2) are legal --, the objects linked in with the .hip files' compilation."""
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("THIP_EXTRA_CFLAGS", "").split() + list(extra_flags)
+    with tempfile.TemporaryDirectory(prefix="thip_build_") as td:
+        objs = []
+        for s in SOURCES:
+            if s.endswith(".hip"):
+                continue
+            o = os.path.join(td, os.path.splitext(s)[0] + ".o")
+            subprocess.check_call([hipcc, "-x", "c++", "-c"] + flags + ["-o", o, os.path.join(CSRC, s)])
+            objs.append(o)
+        # (objects first: hipcc's "-x hip" for the .hip files sticks to what follows them)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared"] + flags + ["-o", out] + objs + [os.path.join(CSRC, s) for s in SOURCES if s.endswith(".hip")]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not _stale():
         return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function"] + os.environ.get("THIP_EXTRA_CFLAGS", "").split() + [
-           "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
-    return OUT
+    return compile_library(OUT, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -23,10 +23,9 @@ def build_trace_lib(extra):
     out = os.path.join(ROOT, "tools", "_build", "libtheora_hip_trace.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     csrc = os.path.join(ROOT, "theora_amd", "csrc")
-    srcs = [os.path.join(csrc, s) for s in ("thip_decode.hip", "thip_slots.hip", "thip_frontend.cpp", "thip_ogg.cpp")]
     if not os.path.exists(out) or any(os.path.getmtime(os.path.join(csrc, f)) > os.path.getmtime(out) for f in os.listdir(csrc)):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-DTHIP_TRACE", "-I" + os.path.join(ROOT, "include"), "-o", out] + extra + srcs)
+        from theora_amd import build as thip_build
+        thip_build.compile_library(out, ["-DTHIP_TRACE", "-I" + os.path.join(ROOT, "include")] + extra)
     return out
 
 
