@@ -294,10 +294,12 @@ def e2e_keyed_entry(size="720p", nframes=8, loops=30, ahead=8):
             dec.close()
         _l.load().thip_set_option(b"fe_pipeline", 0)
         same = len(set(tuple(v) for v in crcs.values())) == 1
+        native = _e2e_native_legs(hdr, pkts, loops, ahead)
         if any(bad.values()):
             return {"error": "pictures differ from the oracle's: %r frames of %d" % (bad, len(seq))}
         return {"metric": "end-to-end decode frames/sec, one %s 4:2:0 stream (packets in host memory -> pictures in host memory)" % size,
                 "unit": "frames/s", **res, "same_pictures": same, "frames_equal_to_the_oracle": "all %d of each leg's second, untimed pass (and the first %d of the timed one)" % (len(seq), len(pkts)),
+                "c_caller": native,
                 "avg_packet_bytes": sum(map(len, pkts)) // len(pkts),
                 "data": "synthetic packets (tests/streamgen.py), dense content, matched Huffman trees",
                 "note": "host-bound (Python caller): the plain loop is one entropy-decode thread per stream; announced packets are "
@@ -308,6 +310,51 @@ def e2e_keyed_entry(size="720p", nframes=8, loops=30, ahead=8):
             _l2.load().thip_set_option(b"fe_pipeline", 0)
         except Exception:
             pass
+        return {"error": str(e)[:300]}
+
+
+def _e2e_native_legs(hdr, pkts, loops, ahead):
+    """The same packets through examples/decode_bench.c -- the same th_decode_* calls from C, nothing of Python between them: what a
+    player or a server pays.  The packets go into an Ogg file (tests/oggmux.py, the library's own demultiplexer reads it back); the
+    program is compiled here with the host compiler when it is not there.  The pictures of these legs are the library's, which the
+    Python legs above have just compared with the oracle frame by frame; the program itself checks that every call succeeds."""
+    import subprocess
+    import tempfile
+    try:
+        from tests import oggmux
+        root = os.path.dirname(os.path.abspath(__file__))
+        with tempfile.TemporaryDirectory(prefix="thip_e2e_") as td:
+            exe = os.path.join(td, "decode_bench")
+            cc = subprocess.run(["gcc", "-O2", "-pthread", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "decode_bench.c"),
+                                 "-L" + os.path.join(root, "theora_amd"), "-ltheora_hip", "-Wl,-rpath," + os.path.join(root, "theora_amd"), "-o", exe],
+                                capture_output=True, text=True)
+            if cc.returncode != 0:
+                return {"error": "decode_bench.c does not compile: " + cc.stderr[-200:]}
+            ls = oggmux.LogicalStream(0x7E0)
+            for k, hp in enumerate(hdr):
+                ls.add_packet(hp, granulepos=0, flush=(k == 0 or k == len(hdr) - 1))
+            reps = 3
+            for rep in range(reps):
+                for k, p in enumerate(pkts):
+                    ls.add_packet(p, granulepos=rep * len(pkts) + k + 1)
+            ogv = os.path.join(td, "clip.ogv")
+            with open(ogv, "wb") as f:
+                f.write(b"".join(ls.finish()))
+            out = {}
+            for label, extra in (("plain_loop", []), ("lookahead_%d" % ahead, ["--lookahead", str(ahead)]),
+                                 ("lookahead_%d_pipelined" % ahead, ["--lookahead", str(ahead), "--pipeline"])):
+                best = None
+                for _ in range(2):      # (host-bound and short: the better of two runs)
+                    r = subprocess.run([exe, ogv, "1", str(max(2, loops // reps))] + extra, capture_output=True, text=True, timeout=300)
+                    line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "{}"
+                    d = json.loads(line)
+                    if r.returncode != 0 or not d.get("ok"):
+                        return {"error": "decode_bench %s: rc %d %s" % (label, r.returncode, (r.stderr or line)[-200:])}
+                    best = d["frames_per_s"] if best is None else max(best, d["frames_per_s"])
+                out[label] = round(best, 1)
+            out["program"] = "examples/decode_bench.c, one stream, %d frames a run, better of two runs" % (len(pkts) * reps * max(2, loops // reps))
+            return out
+    except Exception as e:   # noqa: BLE001
         return {"error": str(e)[:300]}
 
 
