@@ -41,13 +41,20 @@ int thip_state_token_lists_abort(thip_state *) { return -1; }
 int thip_state_token_lists_staging(thip_state *, thip_token_staging *) { return -1; }
 int thip_device_count(void) { return 0; }
 int thip_option(const char *name) {   // the library's option table is not linked: trace mode on, everything else at its default
+  if (name) {   // (THIP_<NAME> in the environment first, as the library's own table has it: tools/fe_tokbench.cpp sets options that way)
+    char env[64] = "THIP_";
+    size_t k = 5;
+    for (const char *c = name; *c && k + 1 < sizeof(env); c++) env[k++] = (char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+    env[k] = 0;
+    const char *v = getenv(env);
+    if (v && *v) return atoi(v);
+  }
   if (name && !strcmp(name, "device")) return -1;
   if (name && !strcmp(name, "fe_trace_backend")) return 1;
   if (name && !strcmp(name, "fe_device_lists")) return 0;
   if (name && !strcmp(name, "fe_lookahead")) return 4;
   if (name && !strcmp(name, "fe_worker_pin")) return 1;
   if (name && !strcmp(name, "fe_assign")) return 2;
-  if (name && !strcmp(name, "fe_prof")) return getenv("THIP_FE_PROF") ? 1 : 0;   // (the stage table, for tools/fe_tokbench.cpp)
   if (name && !strcmp(name, "fe_assign_settle")) return 16;   // (short, so that the fuzzed streams cross the rule's switch points)
   return 0;
 }

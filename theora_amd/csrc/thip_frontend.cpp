@@ -759,14 +759,26 @@ inline void expand_token(const TokFast &t, uint32_t x, Tok &k) {
 
 // ... and tabulated: every (token, extra bits) pair there is -- 5405 of them, of which the few dozen
 // that real streams use stay in L1 -- so the token loop copies eight bytes instead of computing them.
+// a token as the device reads it (thip_tokens.h): an EOB run (flag, 24 bits of length) or a value with the zeros before it
+inline uint32_t tok_device_word(const Tok &k) {
+  const uint32_t e = k.eob, run = e > 0xFFFFFFu ? 0xFFFFFFu : e;
+  const uint32_t we = 0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24;
+  const uint32_t wv = (uint32_t)(uint16_t)k.value | (uint32_t)k.skip << 16;
+  return e ? we : wv;
+}
 struct TokTable {
   uint16_t base[32];
   Tok tab[5405];
+  uint32_t dev[5405];   // tok_device_word(tab[i])
   TokTable() {
     int n = 0;
     for (int i = 0; i < 32; i++) {
       base[i] = (uint16_t)n;
-      for (uint32_t x = 0; x < (1u << kTokExtraBits[i]); x++) expand_token(kTokFast.t[i], x, tab[n++]);
+      for (uint32_t x = 0; x < (1u << kTokExtraBits[i]); x++) {
+        expand_token(kTokFast.t[i], x, tab[n]);
+        dev[n] = tok_device_word(tab[n]);
+        n++;
+      }
     }
     if (n != 5405) abort();
   }
@@ -809,11 +821,17 @@ struct PairArgs {
 template <bool PAIR>
 static inline __attribute__((always_inline)) Tok *decode_token_list_body(BitReader &br, const HuffTree &tree, size_t n, Tok *out,
                                                                          size_t (*left)[128], int p, int z, uint32_t *eobs, const PairArgs *pa) {
+  // (ONE counter for the three arrays a token is written to -- the list, the words, the device's tokens: the loop carries the bit
+  //  window, its count, the byte position, the open blocks and the arrivals' pointer besides, and what does not fit sixteen
+  //  registers goes through memory on the loop's dependency chain)
+  Tok *const out0 = out;
+  size_t ti = 0;
   const uint32_t *arr = PAIR ? pa->arr : nullptr;
-  uint32_t *words = PAIR ? pa->words : nullptr;
-  uint32_t *tokd = PAIR ? pa->tokd : nullptr;
+  uint32_t *const words0 = PAIR ? pa->words : nullptr;
+  uint32_t *const tokd0 = PAIR ? pa->tokd : nullptr;
   uint8_t *const ppos = PAIR ? pa->pos : nullptr;
   const uint32_t pc0 = PAIR ? pa->c0 : 0u;
+  const uint32_t zword = (uint32_t)z << 18;
   // the reader's state as plain locals: br itself is only touched on the slow paths, so nothing
   // here has its address taken.  The bit position is not carried along: pos == 8 * bytepos - have wherever the reader stands
   // (every refill adds the same bits to both, every skip takes them from `have` and adds them to pos), so it is put back
@@ -851,7 +869,8 @@ static inline __attribute__((always_inline)) Tok *decode_token_list_body(BitRead
   THIP_FE_READY();
   uint32_t run_left = *eobs;   // what the last token's EOB run has left for later lists
   while (n > 0) {
-    Tok &k = *out++;
+    Tok &k = out0[ti];
+    uint32_t dw = 0;   // (PAIR) the token as the device reads it
     // Nothing on the fast path depends on the data except through arithmetic: which token comes next and whether the window
     // needs topping up are both close to random, and a mispredicted branch costs more than all the
     // arithmetic of a token.
@@ -888,12 +907,14 @@ static inline __attribute__((always_inline)) Tok *decode_token_list_body(BitRead
       // the extra bits: the last (e >> 8 & 0xFF) of the `total` bits the token takes (none: 0)
       const uint32_t x = (uint32_t)((w >> ((64 - total) & 63)) & ((1ull << ((e >> 8) & 0xFF)) - 1));
       k = kTokTab.tab[(uint32_t)(e >> 32) + x];
+      if (PAIR) dw = kTokTab.dev[(uint32_t)(e >> 32) + x];
     } else {   // single-leaf tree or the last bytes of the packet
       br.win = win; br.have = have; br.pos = 8 * bytepos - (size_t)have; br.bytepos = bytepos;
       const TokFast &t = kTokFast.t[read_token(br, tree)];
       expand_token(t, br.read(t.ebits), k);
       win = br.win; have = br.have; bytepos = br.bytepos;
       THIP_FE_READY();
+      if (PAIR) dw = tok_device_word(k);
     }
     if (k.eob == 0xFFFFFFFFu) {   // every block still open anywhere ends (7.7.1)
       size_t all = n;
@@ -901,6 +922,7 @@ static inline __attribute__((always_inline)) Tok *decode_token_list_body(BitRead
       for (int zz = z + 1; zz < 64; zz++)
         for (int pp = 0; pp < 3; pp++) all += left[pp][zz];
       k.eob = (uint32_t)all;
+      if (PAIR) dw = tok_device_word(k);
     }
     // an EOB token ends up to k.eob of the open blocks, any other token advances one of them
     // (for an EOB token adv is 0 and the count lands in this list's own, no longer needed, entry)
@@ -912,13 +934,10 @@ static inline __attribute__((always_inline)) Tok *decode_token_list_body(BitRead
       const uint32_t f = *arr;   // (n > 0: there is one)
       arr += take;
       ppos[f] = (uint8_t)(z + k.adv);   // (>= 64: done; an EOB token leaves z, which no later list looks for)
-      *words++ = (pc0 + f) | (uint32_t)(z + k.skip) << 18;
-      // (and the token as the device reads it: what fe_pack_lists makes of a list afterwards, made here while the token is in registers)
-      const uint32_t e = k.eob, run = e > 0xFFFFFFu ? 0xFFFFFFu : e;
-      const uint32_t we = 0x00800000u | (run & 0xFFFFu) | (run >> 16) << 24;
-      const uint32_t wv = (uint32_t)(uint16_t)k.value | (uint32_t)k.skip << 16;
-      *tokd++ = e ? we : wv;
+      words0[ti] = (pc0 + f) | (zword + ((uint32_t)k.skip << 18));
+      tokd0[ti] = dw;   // (the token as the device reads it: what fe_pack_lists makes of a list afterwards)
     }
+    ti++;
     n -= take;
     // (A truncated packet is not special: past the end the reader supplies zero bits, as
     //  oc_pack_read does, and tokens go on being decoded from them -- every token closes or
@@ -926,7 +945,7 @@ static inline __attribute__((always_inline)) Tok *decode_token_list_body(BitRead
   }
   *eobs = run_left;
   br.win = win; br.have = have; br.pos = 8 * bytepos - (size_t)have; br.bytepos = bytepos;
-  return out;
+  return out0 + ti;
 }
 #undef THIP_FE_READY
 // The loop is bound by its instruction count (about 53 a token, five or six a cycle), and a fifth of them only move shift counts

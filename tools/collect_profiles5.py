@@ -20,6 +20,9 @@ for d in ("stats_lanes1", "stats_default"):
     f = glob.glob(os.path.join(F, d, "**", "*kernel_stats.csv"), recursive=True)
     if f:
         cp(max(f, key=os.path.getmtime), "4k_dense_%s_kernel_stats.csv" % d.split("_")[1])
+f = glob.glob(os.path.join(F, "stats_enc", "**", "*kernel_stats.csv"), recursive=True)
+if f:
+    cp(max(f, key=os.path.getmtime), "enc_kernel_stats.csv")
 for sec, names in (("ab", ("ab256.txt", "ab20.txt")), ("ends", ("block_ends.txt",)), ("trace", ("block_timeline_dense.csv", "block_timeline_smooth.csv")),
                    ("e2e", ("native_1stream.jsonl", "native_4streams.jsonl", "stage_tables.txt"))):
     for n in names:

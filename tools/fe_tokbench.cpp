@@ -2,7 +2,7 @@
 // packet file written by tools/fe_tokbench.py, the same packets decoded `loops` times; THIP_FE_PROF=1 prints the front end's own
 // stage table (ms per frame and tokens per frame of the token stage) at th_decode_free.
 //   g++ -O2 -std=c++17 -Iinclude tools/fe_tokbench.cpp theora_amd/csrc/thip_frontend.cpp -lpthread -o tools/_build/tok/bench
-//   THIP_FE_PROF=1 tools/_build/tok/bench pkts.bin 20
+//   THIP_FE_PROF=1 tools/_build/tok/bench pkts.bin 20 [packets announced ahead; THIP_FE_LOOKAHEAD=8 THIP_FE_ASSIGN=1: eight parsers that pair]
 #define main fe_fuzz_main
 #include "../tests/native/fe_fuzz.cpp"
 #undef main
@@ -23,6 +23,7 @@ int main(int argc, char **argv) {
   }
   fclose(f);
   const int loops = atoi(argv[2]);
+  const int ahead = argc > 3 ? atoi(argv[3]) : 0;   // packets announced ahead (TH_DECCTL_THIP_PREFETCH_PACKET; THIP_FE_LOOKAHEAD parsers)
   th_info info;
   th_comment tc;
   th_setup_info *setup = nullptr;
@@ -37,8 +38,16 @@ int main(int argc, char **argv) {
   unsigned long sum = 0;
   long frames = 0;
   const auto t0 = std::chrono::steady_clock::now();
+  const long total = (long)loops * np;
+  long announced = 0;
   for (int l = 0; l < loops; l++)
     for (unsigned i = nh; i < nh + np; i++) {
+      while (ahead && announced < total && announced < frames + ahead) {
+        if (announced < frames) announced = frames;
+        ogg_packet oq = as_packet(P[nh + announced % np], 0);
+        if (th_decode_ctl(d, TH_DECCTL_THIP_PREFETCH_PACKET, &oq, sizeof(oq)) != 0) break;
+        announced++;
+      }
       ogg_packet op = as_packet(P[i], 0);
       int64_t gp = 0;
       const int rc = th_decode_packetin(d, &op, &gp);

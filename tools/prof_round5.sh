@@ -60,6 +60,7 @@ final)
   python bench.py --steps 20 > $o/bench_steps20.json 2>/dev/null
   THIP_FUSE=0 python bench.py --no-cpu-baseline --no-1080p --no-e2e --no-wide --no-enc > $o/bench_twopass.json 2>/dev/null
   python bench.py --mode enc > $o/bench_enc.jsonl 2>/dev/null
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_enc -- python bench.py --mode enc > $o/bench_enc_under_rocprof.jsonl 2>$o/stats_enc.log
   THIP_LANES=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_lanes1 -- python bench.py --steps 64 --repeats 2 --min-time 0 --no-cpu-baseline --no-parity --no-profile --no-pmc --no-1080p --no-e2e --no-wide --no-enc --second-content "" > $o/stats_lanes1.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_default -- python bench.py --steps 64 --repeats 2 --min-time 0 --no-cpu-baseline --no-parity --no-profile --no-pmc --no-1080p --no-e2e --no-wide --no-enc --second-content "" > $o/stats_default.log 2>&1
   LANES=2 bash tools/pmc_r4.sh dense > /dev/null 2>&1; cp gpurun_out/r04/pmc_dense.txt $o/pmc_counters_dense_lanes2.txt 2>/dev/null
