@@ -594,9 +594,11 @@ const char *thip_version_string(void);
  *                being decoded (thip_state_token_lists_open / _append; boundaries in thip_frontend.cpp, kFeGroupEnd*): 4 (default), 9, 5,
  *                3, 2; 1: in one piece after the packet's last bit (thip_state_token_lists_begin).  More groups start the device
  *                earlier and cost a pair of launches each
- *   fe_worker    th_decode_*, token-list path: 1 (default): the context has a second thread that undoes the DC prediction (spec 7.8;
+ *   fe_worker    th_decode_*, token-list path: 1: the context has a second thread that undoes the DC prediction (spec 7.8;
  *                decode.c:1392-1500) while th_decode_packetin's caller decodes the tokens of indices 1..63; 0: the caller does it
- *                behind the tokens.  With fe_groups = 4: +13..16 % for one stream (720p typical, 1080p, 4K), +29..37 % for four 1080p / 4K streams
+ *                behind the tokens, while the device still walks the last group of indices (it needs the values last); 2 (default):
+ *                1 for frames of more than 32 768 fragments, 0 otherwise.  Round 5, one stream, plain loop: 1080p + 11..13 % with
+ *                the thread, 720p 0 (dense) .. - 7 % (typical content) with it -- up to 720p the chain fits under the device's walk
  *   fe_worker_pin   fe_worker on: 1 (default): that thread is kept (pthread_setaffinity_np) on the CPUs that share a last-level
  *                cache with the thread that calls th_decode_packetin (the two hand each other a frame's flags, lists and DC values);
  *                0: left to the scheduler (measured 5-10 % SLOWER than no second thread on a two-socket host)

@@ -258,7 +258,7 @@ def test_packets_decode_bit_exact_with_the_token_lists_in_groups(hip, w, h, fmt,
         assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_lists=True) >= 3
     finally:
         L.thip_set_option(b"fe_groups", 4)
-        L.thip_set_option(b"fe_worker", 1)
+        L.thip_set_option(b"fe_worker", 2)
         L.thip_set_option(b"tl_levels", 1)
         L.thip_set_option(b"tl_algo", 0)
 

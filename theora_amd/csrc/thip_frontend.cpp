@@ -1956,7 +1956,12 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
     if (stream_rc < 0) streaming = false;   // (THIP_EIMPL: the slots; anything else: reported by the one-piece path below)
   }
   bool &with_worker = r.with_worker;
-  with_worker = lists_now && !d->device_dc && thip_option("fe_worker") != 0;   // the DC chain on the second thread
+  // the DC chain on the second thread -- where it is worth a thread: the device needs the values LAST (thip_state_token_lists_finish),
+  // behind its walk of the last group of indices (3 us an index: 110-160 us), so up to 720p the caller undoes the prediction itself
+  // while that walk runs (0.16 ms at 720p) and a second thread only adds its hand-overs (measured: + 5 % without it at 720p, - 10 %
+  // at 1080p, where the chain is 0.36 ms); fe_worker = 2 (default) draws the line at 32 768 fragments, 1 / 0: always / never
+  const int fe_worker = thip_option("fe_worker");
+  with_worker = lists_now && !d->device_dc && (fe_worker == 1 || (fe_worker == 2 && d->nfrags > 32768));
   if (with_worker && !d->worker) {
     d->worker = new (std::nothrow) FeWorker();
     if (d->worker) {
