@@ -396,21 +396,23 @@ __global__ __launch_bounds__(256) void k_enc_fdct_quantize(int16_t *qdct, int32_
 // out, through the same 2 KB, so that the stores are whole 16-byte pieces.  Four times the waves, a quarter of the chain each.
 __global__ __launch_bounds__(256) void k_enc_fdct_quantize4(int16_t *qdct, int32_t *nonzero, int16_t *dct_out, const int16_t *x,
                                                            const uint16_t *dequant, const int16_t *enquant, int64_t n) {
-  __shared__ int s_d[64], s_m[64], s_l[64], s_z[64];   // by natural position: step, reciprocal {m, l}, zig-zag index
+  // by natural position, ONE 8-byte entry: step | reciprocal m << 16, shift l | zig-zag index << 8 -- a lane's sixteen positions are
+  // two runs of eight entries, eight 16-byte LDS reads instead of the 64 four-byte ones of four separate tables (the LDS pipe is
+  // one per compute unit: with four lanes a block it is as busy as the vector units)
+  __shared__ __attribute__((aligned(16))) uint2 s_t[64];
   if (threadIdx.x < 64) {
     const int z = (int)threadIdx.x, pos = kFZigZag[z];
-    s_d[pos] = (int)dequant[z];
-    s_z[pos] = z;
+    int m, l;
     if (enquant) {
-      s_m[pos] = (int)enquant[2 * z];
-      s_l[pos] = (int)enquant[2 * z + 1];
+      m = (int)enquant[2 * z];
+      l = (int)enquant[2 * z + 1];
     } else {   // oc_iquant_init (enquant.c:183-191)
       const uint32_t d = (uint32_t)dequant[z] << 1;
-      const int l = 31 - __builtin_clz(d);
+      l = 31 - __builtin_clz(d);
       const uint32_t t = 1u + ((1u << (16 + l)) / d);
-      s_m[pos] = (int)(int16_t)(t - 0x10000u);
-      s_l[pos] = l;
+      m = (int)(int16_t)(t - 0x10000u);
     }
+    s_t[pos] = make_uint2((uint32_t)dequant[z] | (uint32_t)(uint16_t)m << 16, (uint32_t)(l & 0xFF) | (uint32_t)z << 8);
   }
   __shared__ int4 s_x[4 * 128];                          // 2 KB a wave: 16 blocks of eight 16-byte pieces (piece r = row r)
   int4 *lds = s_x + (threadIdx.x >> 6) * 128;
@@ -461,9 +463,15 @@ __global__ __launch_bounds__(256) void k_enc_fdct_quantize4(int16_t *qdct, int32
   int16_t *lds16 = reinterpret_cast<int16_t *>(lds);
   // where zig-zag index z of block b lies in the wave's area (the same rotation of 16-byte pieces)
   auto at = [&](int z) { return (b * 8 + (((z >> 3) + b) & 7)) * 8 + (z & 7); };
+  // (the table entries of positions k, k + 1: one 16-byte read)
+  auto entries = [&](int k) { return *reinterpret_cast<const uint4 *>(&s_t[(2 * j + (k >> 3)) * 8 + (k & 7)]); };
   if (dct_out) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) lds16[at(s_z[(2 * j + (k >> 3)) * 8 + (k & 7)])] = (int16_t)o[k];
+    for (int k = 0; k < 16; k += 2) {
+      const uint4 e = entries(k);
+      lds16[at((int)(e.y >> 8))] = (int16_t)o[k];
+      lds16[at((int)(e.w >> 8))] = (int16_t)o[k + 1];
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int4 *g = reinterpret_cast<int4 *>(dct_out) + b0 * 8;
 #pragma unroll
@@ -475,17 +483,21 @@ __global__ __launch_bounds__(256) void k_enc_fdct_quantize4(int16_t *qdct, int32
   }
   int nz = 0;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {   // enquant.c:228-245
-    const int pos = (2 * j + (k >> 3)) * 8 + (k & 7);
-    const int z = s_z[pos], d = s_d[pos];
-    int val = o[k] << 1, q = 0;
-    if (abs(val) >= d) {
-      const int sg = val >> 31;
-      val += (d + sg) ^ sg;
-      q = sx16(((((s_m[pos] * val) >> 16) + val) >> s_l[pos]) - sg);
-      nz = max(nz, z);            // (the reference's loop runs up the zig-zag order: the last index that passes is the largest)
+  for (int k = 0; k < 16; k += 2) {   // enquant.c:228-245
+    const uint4 e = entries(k);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+      const uint32_t ex = h2 ? e.z : e.x, ey = h2 ? e.w : e.y;
+      const int z = (int)(ey >> 8), d = (int)(ex & 0xFFFFu), m = (int)ex >> 16, l = (int)(ey & 0xFFu);
+      int val = o[k + h2] << 1, q = 0;
+      if (abs(val) >= d) {
+        const int sg = val >> 31;
+        val += (d + sg) ^ sg;
+        q = sx16(((((m * val) >> 16) + val) >> l) - sg);
+        nz = max(nz, z);            // (the reference's loop runs up the zig-zag order: the last index that passes is the largest)
+      }
+      lds16[at(z)] = (int16_t)q;
     }
-    lds16[at(z)] = (int16_t)q;
   }
   nz = max(nz, __shfl_xor(nz, 1));
   nz = max(nz, __shfl_xor(nz, 2));
