@@ -87,6 +87,7 @@ Option g_options[] = {
     {"fe_device_dc", 0, "th_decode_*: DC un-prediction on the device"},
     {"fe_device_tokens", 0, "th_decode_*: token expansion + dequantisation on the device (host-delimited tokens)"},
     {"fe_device_lists", -1, "th_decode_*: the token lists themselves on the device (1 on, 0 off, -1 on while at most four decoder contexts are alive)"},
+    {"tl_dc_copy", 0, "token lists on the device, thip_state_token_lists_finish: 0 (default): a kernel copies the caller's DC values out of the pinned staging buffer (k_tok_copy); 1: a copy engine does (rounds 3-4)"},
     {"tl_algo", 0, "token lists on the device: 1: k_tok_assign (rank -> fragment map in LDS, or in memory for planes beyond 36 864 coded fragments); 2: k_tok_rank + k_tok_walk (every fragment looked after by one thread, one barrier per index, one byte of LDS per fragment); 0 (default): 2 where 1 would keep its map in memory (4K), 1 otherwise"},
     {"tl_walk_threads", 0, "k_tok_walk: threads of the work group (256, 512, 1024); 0 (default): by plane size"},
     {"tl_levels", 1, "token lists on the device (thip_state_token_lists_*): 1 (default): the device writes the coefficient slots in the levels form (int8 units, the reconstruction kernel dequantises); 0: dequantised int16 slots"},
@@ -2517,7 +2518,21 @@ int thip_state_token_lists_finish(thip_state *st, const int16_t *dc) {
     TlK K = st->tl_K;
     if (dc) {   // the caller's un-predicted values: behind k_tok_prepare's copy of the staging buffer, into the same place
       memcpy(st->h_tl + st->tl_o_dcv, dc, (size_t)ncoded * 2);
-      HIP_TRY(hipMemcpyAsync(st->d_tl + st->tl_o_dcv, st->h_tl + st->tl_o_dcv, (((size_t)ncoded * 2) + 15) & ~(size_t)15, hipMemcpyHostToDevice, s));
+      if (THIP_OPT("tl_dc_copy") == 1) {
+        HIP_TRY(hipMemcpyAsync(st->d_tl + st->tl_o_dcv, st->h_tl + st->tl_o_dcv, (((size_t)ncoded * 2) + 15) & ~(size_t)15, hipMemcpyHostToDevice, s));
+      } else {
+        // a kernel brings them over, as it brings the tokens: a copy engine's transfer between two kernels of one stream costs 6 us
+        // of copy and 18 us of waiting either side of it for 28 KB (profiles/r05_plain_loop_timeline_720p.txt) -- and having the
+        // kernel that writes the command words read the pinned buffer itself was slower still (one 2-byte read per eight lanes)
+        TlCopyK C;
+        C.src[0] = reinterpret_cast<const int4 *>(st->h_tl + st->tl_o_dcv);
+        C.dst[0] = reinterpret_cast<int4 *>(st->d_tl + st->tl_o_dcv);
+        C.n[0] = ((size_t)ncoded * 2 + 15) / 16;
+        C.src[1] = nullptr;
+        C.dst[1] = nullptr;
+        C.n[1] = 0;
+        hipLaunchKernelGGL(k_tok_copy, dim3((unsigned)std::min<size_t>(64, (C.n[0] + 255) / 256)), dim3(256), 0, s, C);
+      }
       K.dc_host = reinterpret_cast<const int16_t *>(st->d_tl + st->tl_o_dcv);
     } else {
       K.dc_host = nullptr;
