@@ -300,3 +300,17 @@ def test_the_measured_rule_changes_sides_in_a_long_stream(trace_env):
     nonempty = sum(1 for p in pk if len(p))
     assert after[2] - before[2] >= nonempty - 12, (before, after, nonempty)     # (all but the first few and the frames without coded blocks)
     assert after[0] > before[0] and after[1] > before[1], (before, after)
+
+
+def test_the_plain_clone_of_the_token_loop():
+    """decode_token_list has two clones of one body, chosen when the library is loaded: compiled for BMI2 where the CPU has it (every
+    box these tests run on), plain otherwise.  THIP_FE_NO_BMI2=1 selects the plain one: the ground-truth test above once more, in a
+    process of its own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, THIP_FE_NO_BMI2="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_frontend_cpu.py"),
+                        "-k", "test_slot_calls_match_ground_truth and matched"], capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    assert "5 passed" in r.stdout, r.stdout[-500:]
