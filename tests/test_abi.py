@@ -196,3 +196,19 @@ def test_levels_form_host_helpers():
             j, h = q >> 1, q & 1
             p = at(int(first[b]) + (q >> 2), q & 3).view(np.int16)
             assert list(p) == [x[2 * j + k, 4 * h + cc] for cc in range(4) for k in range(2)]
+
+
+def test_no_kernel_owns_scratch():
+    """k_recon_lf<false> picked up 16 bytes of scratch a lane unnoticed.  Every build records the compiler's
+    resource remarks (theora_amd/build.py -> libtheora_hip.so.resources.json); no kernel of the product may own scratch, and the
+    reconstruction kernels keep the occupancy their LDS budget is sized for."""
+    from theora_amd import build
+    rows = build.resources()
+    by = {r["name"]: r for r in rows if r.get("name")}
+    assert len(by) >= 55, "the resource table of the build is incomplete: %d kernels" % len(by)
+    bad = {n: r["ScratchSize"] for n, r in by.items() if r.get("ScratchSize", 0) != 0}
+    assert not bad, "kernels with scratch: %r" % bad
+    for n in ("k_recon_lf<true>", "k_recon_lf<false>"):
+        assert by[n]["VGPRs"] <= 96 and by[n]["Occupancy"] >= 5 and by[n]["LDS"] <= 7168, (n, by[n])
+    for n in ("k_recon_lf_sb<true>", "k_recon_lf_sb<false>"):
+        assert by[n]["Occupancy"] >= 8, (n, by[n])

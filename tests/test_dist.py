@@ -75,14 +75,43 @@ def test_stream_partition():
 
 
 def test_bench_argument_plumbing():
-    """bench.py's N > 1 control flow that needs no GPU: the CPU baseline is timed behind the timed region whenever more than one
-    rank runs (no rank's clock waits for rank 0's tens of seconds of CPU work), and the flags that select it parse."""
+    """bench.py's control flow that needs no GPU: the CPU baseline is timed behind every timed region at every world size (no
+    rank's clock waits for rank 0's tens of seconds of CPU work), the flags parse, and the worker-side functions -- generation,
+    packing in both coefficient forms, the oracle's pictures, the CPU-baseline job -- do what the parent expects of them."""
     import subprocess
     import sys
+    import tempfile
+    import numpy as np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "bench.py")).read()
-    assert "cpu_late = world > 1 or args.cpu_baseline_late" in src
-    assert src.index("cpu_late = world > 1") < src.index("# ---- timed region") < src.index("if nparity and rank == 0 and not args.no_cpu_baseline and cpu_late")
+    assert "cpu_late = True" in src
+    assert src.index("# ---- timed region") < src.index("# ---- CPU baseline, behind everything the GPU did")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "--cpu-baseline-late" in out.stdout and "--no-wide" in out.stdout and "--no-enc" in out.stdout
+    assert "--form" in out.stdout and "--no-form16" in out.stdout and "--detail" in out.stdout
     assert shard.gather_floats(3.5, None) == [3.5]      # no process group: this rank's value
+    sys.path.insert(0, root)
+    import bench
+    # the sequence of a stream: a key frame at the head of every interval, inter frames from the pool, shifted by the interval
+    assert [bench.seq_frame(i, 0, 1, 6) for i in (0, 1, 2, 64, 65)] == [0, 2, 3, 0, 5]
+    assert bench.seq_frame(64, 3, 16, 6) == 0 and bench.seq_frame(1, 3, 16, 6) == 1 + (1 + 9) % 6
+    with tempfile.TemporaryDirectory() as td:
+        r = bench._gen_job(dict(tag="s", dir=td, pool=2, forms=("levels", "dequant16"), size="qcif", content="dense", seed=5,
+                                parity={"frames": 5}, host=True))
+        assert len(r["files"]["levels"]) == 3 and len(r["files"]["dequant16"]) == 3 and len(r["balg"]) == 3
+        assert r["desc_bytes"]["dequant16"] > r["desc_bytes"]["levels"] > 0
+        lv = bench._npz_load(r["files"]["levels"][1])
+        assert "dequant" in lv and isinstance(lv["nslots"], int)
+        planes = bench._npz_load(r["oracle_planes"])
+        assert planes["p0"].shape == (144, 176) and planes["p1"].shape == (72, 88)
+        # ... and those planes are what the oracle decodes from the host frames the job wrote (the CPU-baseline job's input)
+        import oracle
+        ost = oracle.State(176, 144)
+        frames = [bench._npz_load(p) for p in r["host"]]
+        for i in range(5):
+            bench._oracle_decode(ost, frames[bench.seq_frame(i, 0, 1, 2)])
+        assert all(np.array_equal(ost.get_plane(oracle.FRAME_PREV, pli), planes["p%d" % pli]) for pli in range(3))
+        ost.close()
+        assert bench._cpu_job((r["host"], "qcif", 2, 4, False)) > 0 and bench._cpu_job((r["host"], "qcif", 2, 4, True)) > 0
+        w = bench._gen_job(dict(tag="w", dir=td, pool=2, forms=("levels",), size="qcif", content="dense", seed=5, widen=(0.5, 1)))
+        assert 0 < w["wide_tiles"] <= w["tiles"] and w["desc_bytes"]["levels"] > r["desc_bytes"]["levels"]

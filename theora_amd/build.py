@@ -1,5 +1,6 @@
 """Builds libtheora_hip.so (the C-ABI product library) for gfx950 with hipcc, in-tree."""
 import os
+import re
 import subprocess
 import sys
 
@@ -37,11 +38,54 @@ def compile_library(out, extra_flags=(), verbose=False):
             subprocess.check_call([hipcc, "-x", "c++", "-c"] + flags + ["-o", o, os.path.join(CSRC, s)])
             objs.append(o)
         # (objects first: hipcc's "-x hip" for the .hip files sticks to what follows them)
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared"] + flags + ["-o", out] + objs + [os.path.join(CSRC, s) for s in SOURCES if s.endswith(".hip")]
-        if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        subprocess.check_call(cmd)
+        # the resource remark costs nothing and is the build's own check: every kernel's registers / LDS / scratch go into
+        # <out>.resources.json, and tests/test_abi.py fails on any kernel that owns scratch (k_recon_lf<false>
+        # picked up 16 bytes a lane unnoticed)
+        cmd = [hipcc, "-Rpass-analysis=kernel-resource-usage", "--offload-arch=gfx950", "-shared"] + flags + ["-o", out] + objs + \
+              [os.path.join(CSRC, s) for s in SOURCES if s.endswith(".hip")]
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        rows = parse_resource_remarks(r.stderr)
+        other = [l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not re.match(r"^\s*(\d+ \||\| )", l)]
+        if r.returncode or verbose:
+            sys.stderr.write(r.stderr if verbose else "\n".join(other) + "\n")
+        elif any("warning" in l or "error" in l for l in other):
+            sys.stderr.write("\n".join(other) + "\n")
+        if r.returncode:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        import json
+        with open(out + ".resources.json", "w") as f:
+            json.dump(rows, f, indent=0)
     return out
+
+
+def parse_resource_remarks(text):
+    """hipcc -Rpass-analysis=kernel-resource-usage -> [{name, VGPRs, AGPRs, TotalSGPRs, ScratchSize, Occupancy, LDS}] (demangled)."""
+    cur, rows = None, []
+    for line in text.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = {"mangled": m.group(1)}
+            rows.append(cur)
+            continue
+        m = re.search(r"\s(VGPRs|AGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    if rows:
+        try:
+            names = subprocess.run(["c++filt"], input="\n".join(c["mangled"] for c in rows), capture_output=True, text=True).stdout.splitlines()
+        except OSError:
+            names = [c["mangled"] for c in rows]
+        for c, n in zip(rows, names):
+            c["name"] = n.split("(")[0].replace("void ", "")
+    return rows
+
+
+def resources():
+    """The table written by the last build of the in-tree library (built now if there is none)."""
+    import json
+    if not os.path.exists(OUT + ".resources.json"):
+        build(force=True)
+    return json.load(open(OUT + ".resources.json"))
 
 
 def build(force=False, verbose=False):

@@ -88,6 +88,7 @@ Option g_options[] = {
     {"fe_device_tokens", 0, "th_decode_*: token expansion + dequantisation on the device (host-delimited tokens)"},
     {"fe_device_lists", -1, "th_decode_*: the token lists themselves on the device (1 on, 0 off, -1 on while at most four decoder contexts are alive)"},
     {"tl_dc_copy", 0, "token lists on the device, thip_state_token_lists_finish: 0 (default): a kernel copies the caller's DC values out of the pinned staging buffer (k_tok_copy); 1: a copy engine does (rounds 3-4)"},
+    {"spec_coeffs", 1, "k_recon_lf, levels form: 1 (default): for a frame with a coefficient unit for every block (nslots == its fragments) the waves ask for their tile's units when they start, at the address that follows from the tile's number, and check it against the first-slot word; 0: always after the command words"},
     {"tl_algo", 0, "token lists on the device: 1: k_tok_assign (rank -> fragment map in LDS, or in memory for planes beyond 36 864 coded fragments); 2: k_tok_rank + k_tok_walk (every fragment looked after by one thread, one barrier per index, one byte of LDS per fragment); 0 (default): 2 where 1 would keep its map in memory (4K), 1 otherwise"},
     {"tl_walk_threads", 0, "k_tok_walk: threads of the work group (256, 512, 1024); 0 (default): by plane size"},
     {"tl_levels", 1, "token lists on the device (thip_state_token_lists_*): 1 (default): the device writes the coefficient slots in the levels form (int8 units, the reconstruction kernel dequantises); 0: dequantised int16 slots"},
@@ -216,6 +217,7 @@ struct thip_state {
   int64_t frame_serial, out_serial;
   hipEvent_t ev_out2[2];     // recorded behind k_frame_out, one per host image
   int held_img;              // thip_state_ycbcr_map_begin: the image (and its event) thip_state_ycbcr_map_end hands out, -1 none
+  int64_t held_serial;       // ... and the frame_serial of the frame that image holds (its output copy done = that frame is done)
   int32_t *enq_last_lane;   // per tile: last lane that received a slot (arrival-order check)
   int enq_ncoded, enq_nuncoded, enq_nslots, enq_frame_type, enq_flimit, enq_active, enq_last_tile;
   int enq_lf_y0[3], enq_lf_y1[3], enq_lf_any;
@@ -967,6 +969,7 @@ int thip_state_ycbcr_map_begin(thip_state *st) {
   const int rc = ensure_frame_out(st);
   if (rc < 0) return rc;
   st->held_img = st->out_cur;
+  st->held_serial = st->out_serial;
   return THIP_OK;
 }
 int thip_state_ycbcr_map_end(thip_state *st, const uint8_t *planes[3], int32_t strides[3]) {
@@ -974,6 +977,9 @@ int thip_state_ycbcr_map_end(thip_state *st, const uint8_t *planes[3], int32_t s
   if (st->held_img < 0) return THIP_EINVAL;
   DeviceGuard dg(st->device);
   if (wait_event(st->ev_out2[st->held_img]) < 0) return THIP_EFAULT;
+  // the held frame's copy is behind all of its kernels: whatever staging buffer that frame read is free (without this
+  // tl_take_staging waited for ev_staging -- recorded behind the NEXT frame -- from the second pipelined frame on)
+  if (st->held_serial > st->out_done_serial) st->out_done_serial = st->held_serial;
   const int frc = check_fault(st);
   if (frc < 0) return frc;
   if (frc > 0 && st->held_img == st->out_cur) return THIP_EFAULT;   // (cannot be: a repeated frame is the newest one, and that is not the held one)
@@ -1169,6 +1175,19 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     st->buf_serial[bufi] = serial;
     K.flimit2 = 2 * d.flimit;
     K.debug = THIP_OPT("debug");
+    // a unit for every block of the frame, every plane a whole number of tiles wide: the first unit of a tile in the whole tile
+    // rows of a plane is the plane's first + 64 * the tile's number in the plane (StreamK::spec_*)
+    K.spec_on = 0;
+    if (d.coeff_format == THIP_COEFFS_LEVELS && d.nslots == st->nfrags && d.ncoded == st->nfrags && THIP_OPT("spec_coeffs") != 0 &&
+        st->geom[0].nhfrags % 16 == 0 && st->geom[1].nhfrags % 16 == 0 && st->geom[2].nhfrags % 16 == 0) {
+      K.spec_on = 1;
+      uint32_t base = 0;
+      for (int pli = 0; pli < 3; pli++) {
+        K.spec_base[pli] = base;
+        K.spec_full[pli] = (st->geom[pli].nhfrags / 16) * (st->geom[pli].nvfrags / 4);
+        base += (uint32_t)st->geom[pli].nhfrags * (uint32_t)st->geom[pli].nvfrags;
+      }
+    }
     // flags-first loop filter when at least a tenth of the frame is uncoded (THIP_LF_SPARSE=0/1 forces)
     const int lf_sparse_env = THIP_OPT("lf_sparse");
     K.lf_sparse = lf_sparse_env >= 0 ? lf_sparse_env : (int64_t)d.ncoded * 10 < (int64_t)st->nfrags * 9;

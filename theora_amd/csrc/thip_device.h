@@ -409,6 +409,7 @@ __device__ __forceinline__ void pk_mask_by_last_zzi(uint32_t P[32], int last_zzi
 // Full 2-D transform.  In: P[j*8+c] = {x[2j][c], x[2j+1][c]}.  Out: Y[r*4+k] =
 // {y[r][2k], y[r][2k+1]} (residue pairs along a row), descaled.  rows4: rows 4..7 of the
 // input are known to be zero for every lane of the wave.
+template <bool FUSED_COLS = true>
 __device__ __forceinline__ void pk_idct8x8(const uint32_t P[32], uint32_t Y[32], bool rows4) {
   pk16 R[32];
 #pragma unroll
@@ -421,7 +422,7 @@ __device__ __forceinline__ void pk_idct8x8(const uint32_t P[32], uint32_t Y[32],
   }
   pk16 Q[32];
 #if defined(THIP_HAVE_IDCT8_COLS) && !defined(THIP_NO_FUSED_TRANSPOSE)
-  if (!rows4) {   // (wave-uniform)
+  if (FUSED_COLS && !rows4) {   // (wave-uniform)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const pk16 A[4] = {R[0 * 8 + 2 * k], R[1 * 8 + 2 * k], R[2 * 8 + 2 * k], R[3 * 8 + 2 * k]};

@@ -326,6 +326,25 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
                "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2), "s"(ep), "s"(bu0), "s"(bu1), "s"(fault_p));
   const int u = bu0 + jb;
   if (u >= bu1) return;
+  // ---- 0. (levels form, a frame with a unit for every block) the coefficients asked for NOW: the tile's first unit follows from
+  //      its number where every tile before it is whole, and what comes back is checked against the first-slot word when that
+  //      arrives -- a wave's second round trip, 3 of its 15 us, is gone for every tile the guess is right for; a wrong guess costs
+  //      its 4 KB and nothing else (the real loads land behind it, in order, in the same place)
+  bool spec = false;
+  uint32_t spec_slot0 = 0;
+  if (LEVELS && S.spec_on) {
+    const int pl0 = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
+    const int rel0 = u - (pl0 == 0 ? 0 : (pl0 == 1 ? te0 : te1));
+    if (rel0 < S.spec_full[pl0]) {
+      spec = true;
+      spec_slot0 = S.spec_base[pl0] + 64u * (uint32_t)rel0;
+      const uint32_t unit = spec_slot0 + (uint32_t)lane;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)unit_piece(coeffs_p, unit, q),
+                                         (__attribute__((address_space(3))) void *)(s_tf + q * 64), 16, 0, THIP_COEF_CPOL);
+    }
+  }
   [[maybe_unused]] unsigned long long *tr = nullptr;   // tools/lf_trace.py: lane 0 stamps the phases of the wave's life (THIP_TRACE builds only)
 #ifdef THIP_TRACE
   if (g_trace_buf && lane == 0) {
@@ -422,8 +441,10 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     THIP_PRIO_AT(1);
     residual_shared<2, true>(Wc, F, lds_dw, meta, lane, L, prefix, Y);
   } else {
-    int4 w7;
-    dense_issue<7>(coeffs_p, F, L.has_coeff, prefix, s_tf, w7);
+    int4 w7 = make_int4(0, 0, 0, 0);
+    // (the units asked for in step 0 are this tile's: all 64 blocks own one, in lane order from the guessed first unit)
+    const bool spec_hit = spec && nown == 64 && !F.wide && F.slot0 == spec_slot0;
+    if (!spec_hit) dense_issue<7>(coeffs_p, F, L.has_coeff, prefix, s_tf, w7);
     if (valid) recon_issue(R, L, Q, inter, ref);
     THIP_PRIO_AT(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)

@@ -70,6 +70,13 @@ struct StreamK {
   uint32_t epoch;         // serial number that marks the edge records of this launch
   int band_u0[9];         // first tile of each of the 8 XCD bands (whole tile rows), [8] = number of tiles
   uint32_t *fault;        // pinned host word of the stream's state: set by a kernel whose bounded wait ran out (k_recon_lf's hand-over)
+  // k_recon_lf, levels form: the frame has one coefficient unit for every block (nslots == the frame's fragments: the dense class, an
+  // intra frame at a high bit rate), so a tile's first unit is known without its first-slot word wherever the tile rows before it
+  // are whole -- spec_base[plane] + 64 * (tile within the plane), for the plane's first spec_full[plane] tiles -- and the wave asks
+  // for its coefficients when it starts, beside the command words, instead of a round trip later
+  int spec_on;
+  uint32_t spec_base[3];
+  int spec_full[3];
   PlaneK pl[3];
 };
 
@@ -650,7 +657,15 @@ __device__ __forceinline__ void dense_finish(const int4 *coeffs_p, const CoefFor
   // the masks are all ones for last_zzi > 10: ~100 instructions skipped when no owner needs them
   if (__any(L.has_coeff && last_zzi <= 10)) pk_mask_by_last_zzi(P, last_zzi);
   const bool all_zz10 = !__any(L.has_coeff && last_zzi > 10);
+  // The int16 form keeps the 2 x 2 transposes between the passes: with the column pass straight off the row pass's registers
+  // (pk_idct8_cols) k_recon_lf<false> spills a predictor window row -- 16 bytes of scratch a lane, VERDICT r05 -- because its 32
+  // coefficient registers all arrive at once (the levels form's come row pair by row pair out of the dequantisation).
+#ifndef THIP_INT16_FUSED_COLS
+  if (F.levels || NLDS == 8) pk_idct8x8<true>(P, Y, all_zz10);    // (NLDS == 8: k_recon, which has the registers)
+  else pk_idct8x8<false>(P, Y, all_zz10);
+#else
   pk_idct8x8(P, Y, all_zz10);
+#endif
 }
 
 // ---- at most 64/LPB lanes of the wave own coefficients (the usual case

@@ -5,8 +5,14 @@ and never exchange data: a stream's three reference frames stay on its GPU.  The
 collectives are control-plane: a barrier around the timed region, MAX of the elapsed time
 and an all-gather of per-stream checksums/counters (RCCL on GPUs, gloo in the CPU tests).
 """
-import torch
-import torch.distributed as dist
+
+
+def _torch():
+    """torch and torch.distributed, imported on first use: stream_ids / stream_seed are plain arithmetic, and bench.py asks its
+    worker processes for every stream's content before it pays for the import (1-2 minutes on a fresh box)."""
+    import torch
+    import torch.distributed as dist
+    return torch, dist
 
 
 def stream_ids(rank, world, streams_per_gpu):
@@ -25,12 +31,14 @@ def stream_seed(base_seed, stream_id):
 def barrier(world):
     """Barrier over the ranks; a process group of one rank (torchrun --nproc-per-node 1) still goes
     through the backend, so that the collective path is exercised on a single-GPU box too."""
+    torch, dist = _torch()
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
 
 
 def reduce_results(elapsed, per_stream_values, device):
     """(max elapsed over ranks, values of all streams in global stream order)."""
+    torch, dist = _torch()
     if not dist.is_initialized():
         return float(elapsed), [int(v) for v in per_stream_values]
     world = dist.get_world_size()
@@ -43,6 +51,7 @@ def reduce_results(elapsed, per_stream_values, device):
 
 
 def reduce_max(values, device):
+    torch, dist = _torch()
     if not dist.is_initialized():
         return [float(v) for v in values]
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
@@ -52,6 +61,7 @@ def reduce_max(values, device):
 
 def reduce_min(value, device):
     """Minimum of an integer over ranks (e.g. "every rank's parity check passed")."""
+    torch, dist = _torch()
     if not dist.is_initialized():
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
@@ -62,6 +72,7 @@ def reduce_min(value, device):
 def gather_floats(value, device):
     """One float of every rank, in rank order (e.g. every rank's own median step time: whether "RCCL saw N ranks" and how far
     the ranks are apart can then be read off the line rank 0 prints)."""
+    torch, dist = _torch()
     if not dist.is_initialized():
         return [float(value)]
     world = dist.get_world_size()

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round 6 on the GPU box, one script with sections (run from the repository root, e.g. through gpurun):
+#   bash tools/prof_round6.sh ab1      parity of the kernel changes, the new bench line, A/B of spec_coeffs by shape, the int16 form
+#   bash tools/prof_round6.sh final    the numbers kept under profiles/r06_* (then here: python tools/collect_profiles6.py)
+export TMPDIR=/tmp
+what=${1:-final}
+o=gpurun_out/r06_$what; mkdir -p $o
+Q="--second-content '' --no-cpu-baseline --parity-frames 4 --no-1080p --no-e2e --no-pmc --no-wide --no-enc --no-form16"
+show() { python -c "
+import sys,json
+try:
+    d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-34s' % '$1', d['value'], d['ms_per_step'], d['pipeline']['read_roofline_frac'], 'lone_us', (d.get('roofline') or {}).get('avg_launch_us'))
+except Exception as e:
+    print('%-34s' % '$1', 'FAILED', e)"; }
+case $what in
+ab1)
+  timeout 1500 python -m pytest tests/test_gpu_frames.py tests/test_gpu_levels.py tests/test_gpu_zz_launch_variants.py -m gpu -q -x > $o/pytest_kernels.txt 2>&1; tail -3 $o/pytest_kernels.txt
+  python bench.py --detail $o/bench_detail.json > $o/bench_default.json 2> $o/bench_default.err; tail -c 600 $o/bench_default.err; wc -c $o/bench_default.json
+  for round in 1 2; do
+    for spec in 0 1; do
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --size 1080p --streams-per-gpu 1 --steps 256 $Q" 2>/dev/null | show "1080p_1stream spec=$spec"
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --size 1080p --streams-per-gpu 4 --steps 256 $Q" 2>/dev/null | show "1080p_4streams spec=$spec"
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --size 720p --streams-per-gpu 1 --steps 256 $Q" 2>/dev/null | show "720p_1stream spec=$spec"
+      THIP_SPEC_COEFFS=$spec THIP_SB_TILES=0 bash -c "python bench.py --size 720p --streams-per-gpu 1 --steps 256 $Q" 2>/dev/null | show "720p_1stream tilekernel spec=$spec"
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --steps 256 $Q" 2>/dev/null | show "4k_dense spec=$spec"
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --steps 20 $Q" 2>/dev/null | show "4k_dense steps20 spec=$spec"
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --steps 256 --content smooth $Q" 2>/dev/null | show "4k_smooth spec=$spec"
+    done
+    bash -c "python bench.py --form dequant16 --steps 256 $Q" 2>/dev/null | show "4k_dense int16 (no scratch)"
+    THIP_LIB=tools/_build/ab/int16fused.so bash -c "python bench.py --form dequant16 --steps 256 $Q" 2>/dev/null | show "4k_dense int16 fused cols (scratch)"
+    bash -c "python bench.py --form dequant16 --steps 256 --content smooth $Q" 2>/dev/null | show "4k_smooth int16 (no scratch)"
+    THIP_LIB=tools/_build/ab/int16fused.so bash -c "python bench.py --form dequant16 --steps 256 --content smooth $Q" 2>/dev/null | show "4k_smooth int16 fused cols (scratch)"
+  done 2>&1 | tee $o/ab_spec_int16.txt ;;
+esac
