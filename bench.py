@@ -550,6 +550,7 @@ def parse_args():
     ap.add_argument("--no-e2e", action="store_true", help="skip the keyed entry e2e_720p (th_decode_* end to end, one stream, with and without the look-ahead)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-execute under rocprofv3 --pmc for roofline.traffic (N = 1 only)")
     ap.add_argument("--detail", default="", help="where the detail file goes (default: gpurun_out/bench_detail.json if gpurun_out/ exists, else ./bench_detail.json)")
+    ap.add_argument("--all-entries", action="store_true", help="the keyed entries at any --size (they belong to the 4K default line; tests/test_bench_flow.py)")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
     return ap.parse_known_args()
 
@@ -1018,7 +1019,7 @@ def main():
 
     S = args.streams_per_gpu
     nparity = 0 if args.no_parity else max(1, args.parity_frames)
-    main_4k = args.size == "4k"
+    main_4k = args.size == "4k" or args.all_entries
     do_second = bool(args.second_content) and args.second_content != args.content
     do_1080p = main_4k and not args.no_1080p
     do_form16 = main_4k and args.form == "levels" and not args.no_form16
@@ -1041,7 +1042,7 @@ def main():
     jobs = {}
 
     def ask(tag, **kw):
-        job = dict(tag=tag, dir=tmp.name, pool=args.pool, forms=("levels",), **kw)
+        job = dict(dict(tag=tag, dir=tmp.name, pool=args.pool, forms=("levels",)), **kw)
         jobs[tag] = workers.apply_async(_gen_job, (job,))
 
     for s, gid in enumerate(gids):

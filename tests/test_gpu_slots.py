@@ -288,17 +288,28 @@ def _halfpel_sites_body(hip, op, rng):
     assert call(_lib.ENC_OPS[op], [1], [0]) == 0
 
 
-def test_enc_fdct(hip):
+@pytest.mark.parametrize("lanes", [4, 1])
+def test_enc_fdct(hip, lanes):
+    """oc_enc_fdct8x8 (fdct.c:128-150) in both layouts: four lanes per block (k_enc_fdct4, the default since round 6) and one block per
+    lane; block counts that end inside a wave's sixteen blocks and inside a work group."""
+    from theora_amd import _lib
     rng = np.random.default_rng(8)
-    n = 20000
+    n = 20000 + 7
     x = rng.integers(-255, 256, (n, 64)).astype(np.int16)
     x[:100] = 0
     x[100:200] = 255
     x[200:300] = -255
     x[300:1000] = rng.integers(-8160, 8161, (700, 64))    # beyond the residual range, still defined
     want = oracle.fdct8x8_batch(x)
-    got = hip.fdct8x8_batch(dev(x)).cpu().numpy().reshape(-1, 64)
-    assert np.array_equal(want, got)
+    _lib.load().thip_set_option(b"enc_fdct_lanes", lanes)
+    try:
+        got = hip.fdct8x8_batch(dev(x)).cpu().numpy().reshape(-1, 64)
+        assert np.array_equal(want, got)
+        for m in (1, 15, 17, 63, 65):
+            got = hip.fdct8x8_batch(dev(x[:m])).cpu().numpy().reshape(-1, 64)
+            assert np.array_equal(want[:m], got)
+    finally:
+        _lib.load().thip_set_option(b"enc_fdct_lanes", 4)
 
 
 def test_enc_sub_copy2_border_ssd(hip):

@@ -26,9 +26,10 @@ struct CostMapK {
   int nh[3], nv[3];        // blocks across / down
   int nsbw;                // luma super blocks across
   int hdec, vdec, fmt;
-  int n_luma, n_all;       // lanes: [0, n_luma) luma blocks (raster), [n_luma, n_all) Cb then Cr blocks
+  int n_luma, n_all;       // lanes: [0, n_luma) luma blocks (macro block by macro block, four lanes each), [n_luma, n_all) Cb then Cr blocks
+  int n_pad;               // ... [n_all, n_all + n_pad): one lane per macro-block SLOT, zeroing the slots outside the frame (0: there are none)
   uint32_t *intra_satd;    // [nmbs][12], may be null
-  uint32_t *luma;          // [nmbs] (zeroed by the caller: four lanes add into an entry), may be null
+  uint32_t *luma;          // [nmbs], may be null
   uint32_t *activity;      // [nmbs][4], may be null
   uint32_t *activity_fast; // [nmbs][4], may be null
 };
@@ -106,9 +107,32 @@ __device__ __forceinline__ void cm_luma_slot(int bx, int by, int nsbw, uint32_t 
   bi = hidx & 3;
 }
 
+// ONE launch writes every entry of the four maps (round 6; the call used to be four hipMemsetAsync + the kernel, 14.8 us for a 7.9 us
+// kernel): the four luma blocks of a macro block sit in four neighbouring lanes, which add their DC terms among themselves (no
+// atomics into a zeroed array) and whose first lane zeroes the chroma entries its pixel format leaves unused; the macro-block slots
+// a frame does not fill (widths or heights that are not a multiple of 32: the maps are indexed by super block) are zeroed by lanes
+// of their own.
 __global__ __launch_bounds__(256) void k_enc_cost_maps(const CostMapK K) {
   const int u = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (u >= K.n_all) return;
+  if (u >= K.n_all + K.n_pad) return;
+  if (u >= K.n_all) {
+    // ---- a macro-block slot: zero it when its macro block lies outside the frame (OC_MB_MAP, internal.c:63: quadrant -> place) ----
+    const int slot = u - K.n_all, sb = slot >> 2, quad = slot & 3;
+    const int sby = sb / K.nsbw, sbx = sb - sby * K.nsbw;
+    const int mx = quad >> 1, my = (quad == 1 || quad == 2) ? 1 : 0;      // 0: (0,0)  1: (0,1)  2: (1,1)  3: (1,0)   (x, y)
+    if (sbx * 4 + mx * 2 < K.nh[0] && sby * 4 + my * 2 < K.nv[0]) return;
+    if (K.intra_satd) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) K.intra_satd[(size_t)slot * 12 + k] = 0u;
+    }
+    if (K.luma) K.luma[slot] = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (K.activity) K.activity[(size_t)slot * 4 + k] = 0u;
+      if (K.activity_fast) K.activity_fast[(size_t)slot * 4 + k] = 0u;
+    }
+    return;
+  }
   if (u >= K.n_luma) {
     // ---- a chroma block: its intra SATD into the macro block's entry (analyze.c:1393-1400) ---------------------------------
     int v = u - K.n_luma;
@@ -137,7 +161,9 @@ __global__ __launch_bounds__(256) void k_enc_cost_maps(const CostMapK K) {
   }
   // ---- a luma block ---------------------------------------------------------------------------------------------------------
   const int nh = K.nh[0], nv = K.nv[0];
-  const int by = u / nh, bx = u - by * nh;
+  // lane 4 m + q: block q (raster inside the macro block) of macro block m (raster); nh and nv are even
+  const int mbw = nh >> 1, mb_r = u >> 2, mb_y = mb_r / mbw, mb_x = mb_r - mb_y * mbw;
+  const int by = 2 * mb_y + ((u >> 1) & 1), bx = 2 * mb_x + (u & 1);
   const int W = nh * 8, H = nv * 8, x0 = bx * 8, y0 = by * 8;
   const int edge = x0 == 0 ? 1 : (x0 + 8 == W ? 2 : 0);
   const int xw = edge == 1 ? 0 : (edge == 2 ? W - 16 : x0 - 4);
@@ -214,7 +240,16 @@ __global__ __launch_bounds__(256) void k_enc_cost_maps(const CostMapK K) {
   int bi;
   cm_luma_slot(bx, by, K.nsbw, mbi, bi);
   if (K.intra_satd) K.intra_satd[(size_t)mbi * 12 + bi] = satd;
-  if (K.luma) atomicAdd(K.luma + mbi, (uint32_t)dc);
+  // the macro block's luma sum: its four lanes are neighbours (and all here: n_luma is a multiple of four)
+  int dcs = dc + __shfl_xor(dc, 1);
+  dcs += __shfl_xor(dcs, 2);
+  if ((u & 3) == 0) {
+    if (K.luma) K.luma[mbi] = (uint32_t)dcs;
+    if (K.intra_satd) {   // OC_MB_MAP_IDXS (internal.c:67-72): 4:2:0 fills entries 4, 5; 4:2:2 4..7; 4:4:4 4..11
+      const int used = K.fmt == 3 ? 12 : (K.fmt == 2 ? 8 : 6);
+      for (int k = used; k < 12; k++) K.intra_satd[(size_t)mbi * 12 + k] = 0u;
+    }
+  }
   if (K.activity) K.activity[(size_t)mbi * 4 + bi] = act;
   if (K.activity_fast) {
     uint32_t fa = (11u * satd >> 8) * satd;   // analyze.c:1244

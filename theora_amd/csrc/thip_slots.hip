@@ -292,6 +292,81 @@ __global__ __launch_bounds__(256) void k_enc_fdct(int16_t *y, const int16_t *x, 
   store_block16_wave(y, i, n, o, lds);
 }
 
+// oc_enc_fdct8x8 with FOUR lanes per block (round 6; the layout of k_enc_fdct_quantize4 below, without its second half): one block per
+// lane is 700 dependent instructions a wave on 1.5 waves per SIMD behind one exposed round trip, 105 registers and 32 KB of LDS a
+// work group -- 10.4 us for the 25 MB of a 1080p 4:4:4 frame.  Lane 4b + j takes columns 2j, 2j + 1 of block b for the first pass
+// (fdct.c:143), the block is transposed through the wave's 2 KB of LDS as int16 pairs, the lane takes rows 2j, 2j + 1 for the
+// second (fdct.c:145); the zig-zag order (fdct.c:149) happens on the way out through the same 2 KB, so that loads and stores are
+// whole 16-byte pieces.
+__global__ __launch_bounds__(256) void k_enc_fdct4(int16_t *y, const int16_t *x, int64_t n) {
+  __shared__ __attribute__((aligned(8))) uint8_t s_zz[64];   // zig-zag index of a natural position
+  if (threadIdx.x < 64) s_zz[kFZigZag[threadIdx.x]] = (uint8_t)threadIdx.x;
+  __shared__ int4 s_x[4 * 128];                          // 2 KB a wave: 16 blocks of eight 16-byte pieces (piece r = row r)
+  int4 *lds = s_x + (threadIdx.x >> 6) * 128;
+  const int lane = (int)threadIdx.x & 63, b = lane >> 2, j = lane & 3;
+  const int64_t b0 = ((int64_t)blockIdx.x * 256 + (threadIdx.x & ~63u)) >> 2;   // the wave's first block
+  // piece pc of block bb lives at lds[bb * 8 + ((pc + bb) & 7)]: rotated, so that sixteen blocks' equal rows spread over the banks
+  {
+    const int4 *g = reinterpret_cast<const int4 *>(x) + b0 * 8;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int idx = q * 64 + lane, bb = idx >> 3, pc = idx & 7;
+      if (b0 + bb < n) lds[bb * 8 + ((pc + bb) & 7)] = g[idx];
+    }
+  }
+  __syncthreads();   // (the table too)
+  const int *ldw = reinterpret_cast<const int *>(lds);
+  int c0[8], c1[8];   // columns 2j and 2j + 1
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int w = ldw[(b * 8 + ((r + b) & 7)) * 4 + j];
+    c0[r] = sx16(sx16(w) << 2);                          // fdct.c:136
+    c1[r] = sx16((w >> 16) << 2);
+  }
+  if (j == 0) {                                          // fdct.c:139-141: positions 0, 1 and 8
+    c0[0] = sx16(c0[0] + (c0[0] != 0) + 1);
+    c1[0] = sx16(c1[0] + 1);
+    c0[1] = sx16(c0[1] - 1);
+  }
+  fdct8(c0[0], c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7]);
+  fdct8(c1[0], c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every lane of the wave has read the input
+  int *ldww = reinterpret_cast<int *>(lds);
+#pragma unroll
+  for (int k = 0; k < 8; k++) ldww[(b * 8 + ((k + b) & 7)) * 4 + j] = (c0[k] & 0xFFFF) | (c1[k] << 16);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int o[16];           // rows 2j and 2j + 1, natural position (2j + h) * 8 + c at o[h * 8 + c]
+  uint2 zz[2];         // ... and their zig-zag indices, a byte each
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int r = 2 * j + h;
+    const int4 w = lds[b * 8 + ((r + b) & 7)];
+    zz[h] = *reinterpret_cast<const uint2 *>(s_zz + r * 8);
+    int v[8] = {sx16(w.x), w.x >> 16, sx16(w.y), w.y >> 16, sx16(w.z), w.z >> 16, sx16(w.w), w.w >> 16};
+    fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+    for (int c = 0; c < 8; c++) o[h * 8 + c] = sx16((v[c] + 2) >> 2);   // fdct.c:149
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int16_t *lds16 = reinterpret_cast<int16_t *>(lds);
+  // where zig-zag index z of block b lies in the wave's area (the same rotation of 16-byte pieces)
+  auto at = [&](int z) { return (b * 8 + (((z >> 3) + b) & 7)) * 8 + (z & 7); };
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const uint32_t word = c < 4 ? zz[h].x : zz[h].y;
+      lds16[at((int)((word >> (8 * (c & 3))) & 0xFFu))] = (int16_t)o[h * 8 + c];
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int4 *g = reinterpret_cast<int4 *>(y) + b0 * 8;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int idx = q * 64 + lane, bb = idx >> 3, pc = idx & 7;
+    if (b0 + bb < n) g[idx] = lds[bb * 8 + ((pc + bb) & 7)];
+  }
+}
+
 // oc_enc_quantize_c (enquant.c:219-248); the {m,l} reciprocal of each step is derived in
 // place exactly as oc_iquant_init does (enquant.c:183-191).
 __global__ __launch_bounds__(256) void k_enc_quantize(int16_t *qdct, int32_t *nonzero, const int16_t *dct,
@@ -700,13 +775,9 @@ int thip_enc_mb_cost_maps(const uint8_t *const planes[3], const int32_t strides[
   K.luma = luma;
   K.activity = activity;
   K.activity_fast = activity_fast;
-  const size_t nmbs = (size_t)thip_enc_mb_count(frame_width, frame_height);
-  // macro blocks outside the frame stay zero, and the luma sums are added into
-  if (intra_satd) HIP_TRY(hipMemsetAsync(intra_satd, 0, nmbs * 12 * sizeof(uint32_t), g_batch_stream));
-  if (luma) HIP_TRY(hipMemsetAsync(luma, 0, nmbs * sizeof(uint32_t), g_batch_stream));
-  if (activity) HIP_TRY(hipMemsetAsync(activity, 0, nmbs * 4 * sizeof(uint32_t), g_batch_stream));
-  if (activity_fast) HIP_TRY(hipMemsetAsync(activity_fast, 0, nmbs * 4 * sizeof(uint32_t), g_batch_stream));
-  hipLaunchKernelGGL(k_enc_cost_maps, grid_for(K.n_all), dim3(256), 0, g_batch_stream, K);
+  // macro-block slots outside the frame are zeroed by lanes of their own (one launch, nothing to memset: thip_costmaps.h)
+  K.n_pad = ((K.nh[0] & 3) || (K.nv[0] & 3)) ? thip_enc_mb_count(frame_width, frame_height) : 0;
+  hipLaunchKernelGGL(k_enc_cost_maps, grid_for(K.n_all + K.n_pad), dim3(256), 0, g_batch_stream, K);
   HIP_TRY(hipGetLastError());
   if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;
@@ -846,7 +917,11 @@ int thip_enc_fdct8x8_batch(int16_t *y, const int16_t *x, int64_t n) {
   if (!y || !x) return THIP_EFAULT;
   if (n < 0) return THIP_EINVAL;
   if (n == 0) return THIP_OK;
-  hipLaunchKernelGGL(k_enc_fdct, grid_for(n), dim3(256), 0, g_batch_stream, y, x, n);
+  // four lanes per block (option "enc_fdct_lanes" = 1: one block per lane, the kernel of rounds 1-5)
+  if (thip_option("enc_fdct_lanes") == 1)
+    hipLaunchKernelGGL(k_enc_fdct, grid_for(n), dim3(256), 0, g_batch_stream, y, x, n);
+  else
+    hipLaunchKernelGGL(k_enc_fdct4, grid_for(4 * n), dim3(256), 0, g_batch_stream, y, x, n);
   HIP_TRY(hipGetLastError());
   if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;

@@ -14,7 +14,7 @@ except Exception as e:
     print('%-34s' % '$1', 'FAILED', e)"; }
 case $what in
 ab1)
-  timeout 1500 python -m pytest tests/test_gpu_frames.py tests/test_gpu_levels.py tests/test_gpu_zz_launch_variants.py -m gpu -q -x > $o/pytest_kernels.txt 2>&1; tail -3 $o/pytest_kernels.txt
+  timeout 1500 python -m pytest tests/test_gpu_slots.py tests/test_gpu_costmaps.py -m gpu -q > $o/pytest_kernels.txt 2>&1; tail -3 $o/pytest_kernels.txt
   python bench.py --detail $o/bench_detail.json > $o/bench_default.json 2> $o/bench_default.err; tail -c 600 $o/bench_default.err; wc -c $o/bench_default.json
   for round in 1 2; do
     for spec in 0 1; do
