@@ -3,7 +3,7 @@
  * batch configuration, end to end: packets in host memory -> frames in host memory).
  *
  *   cc -O2 -pthread -Iinclude examples/decode_bench.c -Ltheora_amd -ltheora_hip -o decode_bench
- *   decode_bench in.ogv <threads> <loops> [--no-output] [--lookahead K] [--pipeline] [--devices]
+ *   decode_bench in.ogv <threads> <loops> [--no-output] [--lookahead K] [--pipeline|--no-pipeline] [--devices]
  *
  * --lookahead K: every stream announces its packets K ahead (th_decode_ctl TH_DECCTL_THIP_PREFETCH_PACKET, what a player does
  * with the packets its demultiplexer has queued): the library parses them on threads of its own and th_decode_packetin only
@@ -73,11 +73,11 @@ static void *run(void *arg) {
 
 int main(int argc, char **argv) {
   if (argc < 4) {
-    fprintf(stderr, "usage: %s in.ogv <threads> <loops> [--no-output] [--lookahead K] [--pipeline] [--devices]\n", argv[0]);
+    fprintf(stderr, "usage: %s in.ogv <threads> <loops> [--no-output] [--lookahead K] [--pipeline|--no-pipeline] [--devices]\n", argv[0]);
     return 1;
   }
   const int nthreads = atoi(argv[2]);
-  int pipeline = 0;
+  int pipeline = -1;       /* -1: the library's default (on since round 6) */
   int check_devices = 0;   /* --devices: every context must sit on the GPU its turn gives it (context i on device i mod the node's GPUs) */
   g_loops = atoi(argv[3]);
   g_output = 1;
@@ -86,8 +86,9 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--lookahead") && a + 1 < argc) g_ahead = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--devices")) check_devices = 1;
     else if (!strcmp(argv[a], "--pipeline")) pipeline = 1;   /* option fe_pipeline: the next announced frame goes to the device inside th_decode_ycbcr_out */
+    else if (!strcmp(argv[a], "--no-pipeline")) pipeline = 0;
   }
-  if (pipeline) thip_set_option("fe_pipeline", 1);
+  if (pipeline >= 0) thip_set_option("fe_pipeline", pipeline);
   if (g_ahead > 8) thip_set_option("fe_lookahead", g_ahead > 16 ? 16 : g_ahead);   /* (the default takes eight announcements at a time) */
   thip_ogg_reader *og = thip_ogg_open_file(argv[1]);
   if (!og || nthreads < 1 || g_loops < 1) return 1;

@@ -98,6 +98,16 @@ int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strid
    from _end if the named frame's hand-over failed: with the next frame on the device it cannot be repeated any more. */
 int thip_state_ycbcr_map_begin(thip_state *st);
 int thip_state_ycbcr_map_end(thip_state *st, const uint8_t *planes[3], int32_t strides[3]);
+/* A frame decoded AHEAD of its turn can be taken back: _mark notes the reference ring (which buffer is GOLD / PREV / the frame
+   decoded last: oc_theora_state.ref_frame_idx, state.h:404) before such a frame is handed over, _rewind puts the ring back --
+   the frames decoded since the mark never happened as far as references and pictures go: the next frame is decoded against the
+   marked references, thip_state_ycbcr_map shows the marked frame again (the picture a _map_begin named before the mark stays
+   valid).  What the discarded frame left in its buffer, its half of the coded map and the host image it went to is treated as
+   unknown (the next frame takes no static-block shortcut).  Work already queued is not cancelled: it runs, in order, ahead of
+   whatever is queued next.  th_decode_packetin uses this when, with option fe_pipeline, another packet arrives than the one
+   th_decode_ycbcr_out decoded ahead.  mark: eight words owned by the caller. */
+int thip_state_ring_mark(thip_state *st, int64_t mark[8]);
+int thip_state_ring_rewind(thip_state *st, const int64_t mark[8]);
 /* on != 0: every decoded frame of this state is sent to its pinned host image by the launch that
    decodes it (a kernel behind the loop filter writes it across PCIe), so that
    thip_state_ycbcr_map / _out only wait.  Off by default: a caller that keeps frames on the
@@ -615,11 +625,14 @@ const char *thip_version_string(void);
  *                device walks the lists (k_tok_assign / k_tok_walk); 2 (default): measured per stream -- the time between
  *                adopted frames, 24 frames each way, the better rule for the next 1024 (pairing moves 3.5-4.3 ns a token
  *                from the device's critical path to the parser threads: right when they have room, wrong when they are the bound)
- *   fe_pipeline  th_decode_*, with packets announced ahead: 1: th_decode_ycbcr_out(N) hands frame N + 1 -- the oldest announced packet,
- *                if its parser is done -- to the device BEFORE it waits for picture N, so that the device never waits for the caller's
- *                thread (one 720p stream, eight ahead: +60 %).  The announcement becomes a promise: the next th_decode_packetin
- *                must bring that packet (TH_EINVAL otherwise; zero-byte packets in between are fine), and a failed tile hand-over
- *                of frame N is THIP_EFAULT instead of a frame decoded again.  0 (default): off.  fe_pipelined: (counter) such frames
+ *   fe_pipeline  th_decode_*, with packets announced ahead: 1 (default since round 6): th_decode_ycbcr_out(N) hands frame N + 1 -- the
+ *                oldest announced packet, if its parser is done -- to the device BEFORE it waits for picture N, so that the device never
+ *                waits for the caller's thread.  An announcement stays a hint: if the next th_decode_packetin brings another packet the
+ *                frame decoded ahead is taken back (thip_state_ring_rewind: reference ring, counters, qi indices as they were; zero-byte
+ *                packets in between are fine) and the packet is decoded the ordinary way -- the pictures are the same either way.  What
+ *                is left of the price: a failed tile hand-over of frame N, noticed when frame N + 1 is already on the device, is
+ *                THIP_EFAULT instead of a frame decoded again.  0: off.  fe_pipelined: (counter) frames handed over ahead;
+ *                fe_pipeline_taken_back: (counter) those of them that were taken back
  *   fe_lists_rule   th_decode_*, fe_device_lists = -1: 1 (default): lists on the device or the host's own walk, measured per context
  *                (the time between its th_decode_packetin calls, 16 inter frames each way, the faster for fe_assign_settle frames, and
  *                again); 0: the count of contexts alive decides (rounds 3 and 4).  fe_lists_to_device, fe_lists_to_host: (counters) how

@@ -160,8 +160,8 @@ typedef struct {
    TH_DECCTL_THIP_SET_DEVICE_DC / _DEVICE_TOKENS on, a process confined to one CPU) -- harmless, the packet is parsed in its
    th_decode_packetin as ever.  A th_decode_packetin whose packet is not the oldest announced one drops everything announced and
    parses the ordinary way: announcing is a hint, never a requirement, and the pictures are the same either way.
-   (Except under option fe_pipeline = 1, include/theora_hip.h: there th_decode_ycbcr_out hands the oldest announced packet's frame to
-   the device before it waits for its own picture, and the next th_decode_packetin MUST bring that packet -- TH_EINVAL otherwise.) */
+   (That holds under option fe_pipeline too, include/theora_hip.h -- there th_decode_ycbcr_out hands the oldest announced packet's
+   frame to the device before it waits for its own picture: a th_decode_packetin that brings another packet takes that frame back.) */
 #define TH_DECCTL_THIP_PREFETCH_PACKET (0x7105)
 /* Which GPU the context's device state lives on (th_decode_alloc_on, option "device" / THIP_DEVICE): buf = int, receives the
    device index (thip_state_device); TH_EINVAL for a context without device state (slot-trace mode). */

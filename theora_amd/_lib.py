@@ -65,6 +65,8 @@ SYMBOLS = [
     ("thip_state_ycbcr_map", _I, [_P, C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("thip_state_ycbcr_map_begin", _I, [_P]),
     ("thip_state_ycbcr_map_end", _I, [_P, C.POINTER(_P), C.POINTER(C.c_int32)]),
+    ("thip_state_ring_mark", _I, [_P, C.POINTER(_I64)]),
+    ("thip_state_ring_rewind", _I, [_P, C.POINTER(_I64)]),
     ("thip_state_set_eager_output", _I, [_P, _I]),
     ("thip_state_postprocess", _I, [_P, _I, _P, _P, _P, _P]),
     ("thip_state_decode_token_lists", _I, [_P, _P]),

@@ -97,8 +97,9 @@ Option g_options[] = {
     {"fe_worker_pin", 1, "th_decode_*, fe_worker on: 1 (default): the second thread is kept on the CPUs that share a last-level cache with the caller's; 0: left to the scheduler"},
     {"fe_lookahead", 8, "th_decode_*: packets a caller may announce ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), each parsed by a thread of its own on a parser context: 8 (default), up to 16; 0: announcements are not taken"},
     {"fe_assign", 2, "th_decode_*, announced packets on the token-list path: 1: the parser pairs tokens and fragments while it decodes the tokens and the frame goes to thip_state_token_lists_begin_assigned (k_tok_scatter: the device pairs nothing); 0: the device walks the lists (thip_state_token_lists_begin); 2 (default): whichever measures faster for this stream (24 frames each way, the better for 1024, and again)"},
-    {"fe_pipeline", 0, "th_decode_*: 1: th_decode_ycbcr_out hands the next ANNOUNCED packet's frame to the device before it waits for its own picture (the announced packet must then be the next one: TH_EINVAL otherwise; a failed tile hand-over is THIP_EFAULT instead of a frame decoded again); 0 (default): off"},
+    {"fe_pipeline", 1, "th_decode_*: 1 (default since round 6): th_decode_ycbcr_out hands the next ANNOUNCED packet's frame to the device before it waits for its own picture; if another packet than the announced one comes next, the frame decoded ahead is taken back (reference ring and counters restored, fe_pipeline_taken_back counts it); a failed tile hand-over of a frame behind which the next one is already on the device is THIP_EFAULT instead of a frame decoded again; 0: off"},
     {"fe_pipelined", 0, "(counter) frames handed to the device ahead of their th_decode_packetin (fe_pipeline)"},
+    {"fe_pipeline_taken_back", 0, "(counter) frames decoded ahead that were taken back because another packet came (fe_pipeline)"},
     {"fe_lists_rule", 1, "th_decode_*, fe_device_lists = -1: 1 (default): whether a context's token lists go to the device or the host walks them is measured per context (the time between its th_decode_packetin calls, 16 inter frames each way, the faster for fe_assign_settle frames); 0: by the count of contexts alive (at most four: the device)"},
     {"fe_lists_to_device", 0, "(counter) fe_lists_rule: times a context went from the host's walk to the lists on the device"},
     {"fe_lists_to_host", 0, "(counter) fe_lists_rule: times a context went from the lists on the device to the host's walk"},
@@ -990,6 +991,43 @@ int thip_state_ycbcr_map_end(thip_state *st, const uint8_t *planes[3], int32_t s
     strides[p] = st->geom[p].width;
     off += st->geom[p].width * st->geom[p].height;
   }
+  return THIP_OK;
+}
+
+// The reference ring noted and put back (include/theora_hip.h): what a frame decoded ahead of its turn changed on the HOST side of
+// the state.  frame_serial stays where it is -- it only ever grows, the events and staging buffers that are labelled with it keep
+// their order -- so the discarded frame has used a number up, and whatever it wrote is labelled "unknown".
+int thip_state_ring_mark(thip_state *st, int64_t mark[8]) {
+  if (!st || !mark) return THIP_EFAULT;
+  mark[0] = st->ref_idx[0];
+  mark[1] = st->ref_idx[1];
+  mark[2] = st->ref_idx[2];
+  mark[3] = st->last_decoded;
+  mark[4] = st->frame_serial;
+  mark[5] = mark[6] = 0;
+  mark[7] = 0x7468697052696e67ll;   // (a mark is a mark)
+  return THIP_OK;
+}
+int thip_state_ring_rewind(thip_state *st, const int64_t mark[8]) {
+  if (!st || !mark) return THIP_EFAULT;
+  if (mark[7] != 0x7468697052696e67ll || mark[4] > st->frame_serial) return THIP_EINVAL;
+  for (int k = 0; k < 3; k++)
+    if (mark[k] < -1 || mark[k] > 2) return THIP_EINVAL;
+  if (mark[3] < -1 || mark[3] > 2) return THIP_EINVAL;
+  if (mark[4] == st->frame_serial) return THIP_OK;   // nothing was decoded since
+  for (int k = 0; k < 3; k++) st->ref_idx[k] = (int)mark[k];
+  st->last_decoded = (int)mark[3];
+  // every buffer that is not one of the marked references may have been written by a discarded frame; so may either half of the
+  // coded map (a half keeps its label only if it is older than the mark)
+  for (int b = 0; b < 3; b++)
+    if (b != st->ref_idx[THIP_FRAME_GOLD] && b != st->ref_idx[THIP_FRAME_PREV]) st->buf_serial[b] = -1;
+  for (int h = 0; h < 2; h++)
+    if (st->map_serial[h] > mark[4]) st->map_serial[h] = -1;
+  // the references' labels are serial numbers of the past: "the previous frame is the PREV reference" (launch_chunk's static-block
+  // test) compares them with frame_serial, which has moved on -- no shortcut for the next frame, as promised
+  st->out_serial = -1;      // the host images: the newest one holds a discarded picture (thip_state_ycbcr_map copies the marked frame again)
+  st->pp_serial = -1;
+  st->redo.valid = 0;       // the frame that could be decoded again is not the state's newest any more
   return THIP_OK;
 }
 

@@ -301,6 +301,13 @@ struct th_dec_ctx {
     int64_t granpos = 0;
     int64_t key0 = 0, cur0 = 0;        // the frame counters before it (a dropped frame may still come in between)
     std::vector<uint8_t> pkt;          // the packet it was made from
+    // what taking it back needs (round 6: another packet than the announced one may come after all -- theoradec.h:279-302 promises
+    // nothing about the order of packets --, and the frame decoded ahead is then undone): the backend's reference ring
+    // (thip_state_ring_mark), and what of this context outlives a frame
+    int64_t mark[8] = {0};
+    int frame_type0 = 0, nqis0 = 0, qis0[3] = {0, 0, 0};
+    bool qii_dirty0 = false, qii_saved = false;
+    std::vector<uint8_t> qii0;         // the blocks' qi indices (they outlive a frame, decode.c:913-917), when the frame ahead writes them
   } early;
   FeWorker *worker;                  // (created with the first frame that takes the token-list path with option fe_worker on)
   FeLookahead *la;                   // packets announced ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), or null
@@ -2895,9 +2902,23 @@ int th_decode_packetin(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos) {
       if (granpos) *granpos = d->early.granpos;
       return d->early.rc;
     }
-    // The contract of fe_pipeline: once th_decode_ycbcr_out has been called, the oldest announced packet IS the next one.  The
-    // frame decoded ahead cannot be taken back; the stream is good again from its next key frame.
-    return TH_EINVAL;
+    // Another packet than the one th_decode_ycbcr_out decoded ahead (a seek, a caller that changed its mind): the frame is TAKEN
+    // BACK.  The backend's reference ring goes back to where it stood (thip_state_ring_rewind: the discarded frame's kernels still
+    // run, ahead of whatever comes next on the state's stream; what they wrote counts as unknown), the context's counters and the
+    // blocks' qi indices likewise, and this packet is decoded as if nothing had happened (it may itself be the next
+    // announced one).  (Round 5 returned TH_EINVAL here -- an announcement was a promise.)
+    if (thip_state_ring_rewind(d->hip, d->early.mark) < 0) return TH_EFAULT;
+    d->keyframe_num = d->early.key0;
+    d->curframe_num = d->early.cur0;
+    d->granpos = G(d->early.key0, d->early.cur0 - 1);
+    d->frame_type = d->early.frame_type0;
+    d->nqis = d->early.nqis0;
+    memcpy(d->qis, d->early.qis0, sizeof(d->qis));
+    d->qii_dirty = d->early.qii_dirty0;
+    if (d->early.qii_saved && d->early.qii0.size() == d->qii.size()) d->qii.swap(d->early.qii0);
+    d->early.qii_saved = false;
+    thip_option_add("fe_pipeline_taken_back", 1);
+    // (what else was announced is looked at below like any announcement: adopted if this packet is the oldest of them, dropped if not)
   }
   FeRun r;
   if (d->la && !d->la->count) d->la->pair_last = 0;
@@ -2930,14 +2951,15 @@ int th_decode_ycbcr_out(th_dec_ctx *d, th_ycbcr_buffer ycbcr) {
   int32_t strides[3] = {d->nh[0] * 8, d->nh[1] * 8, d->nh[2] * 8};
   d->prof.start();
   if (d->have_frame && !d->trace) {
-    // Option fe_pipeline (off by default: it turns an announcement into a promise).  The caller's loop is th_decode_packetin(N),
+    // Option fe_pipeline (on by default since round 6: an announcement is no promise any more).  The caller's loop is th_decode_packetin(N),
     // th_decode_ycbcr_out(N), th_decode_packetin(N + 1), ...: the device works on frame N while this thread waits here, and sits idle
     // while this thread hands frame N + 1 over -- adoption, copies and a dozen launches, as long as the device's own share at 720p.
     // With the packets announced ahead the next frame is usually parsed by now, so it is handed over HERE, before the wait: the
     // picture of frame N is named first (thip_state_ycbcr_map_begin), frame N + 1 goes to the state's other host image behind
-    // frame N's kernels, and its th_decode_packetin finds the work done.  What it costs: the announced packet MUST then come next
-    // (another one gets TH_EINVAL -- the frame cannot be taken back; a dropped frame in between is fine), and a failed tile
-    // hand-over of frame N can no longer be repaired by decoding it again (THIP_EFAULT instead; never observed outside its test).
+    // frame N's kernels, and its th_decode_packetin finds the work done.  What it costs: if ANOTHER packet comes next the frame is
+    // taken back (th_decode_packetin: reference ring and counters put back, the work thrown away; a dropped frame in between is
+    // fine), and a failed tile hand-over of frame N can no longer be repaired by decoding it again (THIP_EFAULT instead; never
+    // observed outside its test).  On by default since round 6.
     bool held = d->early.valid;   // (a second th_decode_ycbcr_out for the same frame: the picture named the first time)
     FeLookahead *const la = d->la;
     if (!held && la && la->count && d->pp_level <= 0 && !d->stripe_cb.stripe_decoded && !d->device_dc && !d->device_tokens &&
@@ -2957,6 +2979,14 @@ int th_decode_ycbcr_out(th_dec_ctx *d, th_ycbcr_buffer ycbcr) {
         d->early.pkt.assign(sl.pkt.begin(), sl.pkt.begin() + sl.bytes);
         d->early.key0 = d->keyframe_num;
         d->early.cur0 = d->curframe_num;
+        // (what th_decode_packetin needs to take this frame back, should another packet come)
+        if (thip_state_ring_mark(d->hip, d->early.mark) < 0) return TH_EFAULT;
+        d->early.frame_type0 = d->frame_type;
+        d->early.nqis0 = d->nqis;
+        memcpy(d->early.qis0, d->qis, sizeof(d->qis));
+        d->early.qii_dirty0 = d->qii_dirty;
+        d->early.qii_saved = sl.ctx->nqis > 1 || d->qii_dirty;   // (fe_adopt writes the coded blocks' entries then)
+        if (d->early.qii_saved) d->early.qii0.assign(d->qii.begin(), d->qii.end());
         fe_adopt(d, sl.ctx);
         FeRun r;
         r.lists_now = fe_lists_now(d);

@@ -7,7 +7,7 @@ for round in $(seq 1 ${AB_ROUNDS:-2}); do
   for kv in "$@"; do
     name=${kv%%=*}; lib=${kv#*=}
     for c in ${AB_CONTENTS:-dense smooth}; do
-      THIP_LIB=$lib timeout 300 python bench.py --steps ${AB_STEPS:-256} --content $c --second-content '' --no-cpu-baseline --parity-frames 4 --no-1080p --no-e2e --no-pmc ${AB_ARGS} 2>/dev/null | python -c "
+      THIP_LIB=$lib timeout 300 python bench.py --steps ${AB_STEPS:-256} --content $c --second-content '' --no-cpu-baseline --parity-frames 4 --no-1080p --no-e2e --no-pmc --no-form16 --no-wide --no-enc ${AB_ARGS} 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('round $round %-14s %-6s' % ('$name','$c'), d['value'], d['ms_per_step'], d['pipeline']['read_roofline_frac'], (d.get('roofline') or {}).get('avg_launch_us'))"
     done
   done

@@ -34,7 +34,7 @@ def main():
                     f.write(b"".join(ls.finish()))
                 for T in threads:
                     for la, pipe in [(a_, p_) for a_ in aheads for p_ in pipes if a_ or not p_]:
-                        r = subprocess.run([exe, ogv, str(T), os.environ.get("E2E_LOOPS", "2")] + (["--lookahead", str(la)] if la else []) + (["--pipeline"] if pipe else []),
+                        r = subprocess.run([exe, ogv, str(T), os.environ.get("E2E_LOOPS", "2")] + (["--lookahead", str(la)] if la else []) + (["--pipeline"] if pipe else ["--no-pipeline"]),
                                            capture_output=True, text=True, timeout=300)
                         line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "{}"
                         try:

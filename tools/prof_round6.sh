@@ -31,4 +31,12 @@ ab1)
     bash -c "python bench.py --form dequant16 --steps 256 --content smooth $Q" 2>/dev/null | show "4k_smooth int16 (no scratch)"
     THIP_LIB=tools/_build/ab/int16fused.so bash -c "python bench.py --form dequant16 --steps 256 --content smooth $Q" 2>/dev/null | show "4k_smooth int16 fused cols (scratch)"
   done 2>&1 | tee $o/ab_spec_int16.txt ;;
+ab2)
+  timeout 1500 python -m pytest tests/test_gpu_frontend.py -m gpu -q -x > $o/pytest_frontend.txt 2>&1; tail -3 $o/pytest_frontend.txt
+  python bench.py --mode enc > $o/bench_enc.jsonl 2> $o/bench_enc.err; tail -5 $o/bench_enc.err; cut -c1-200 $o/bench_enc.jsonl
+  python bench.py --detail $o/bench_detail.json > $o/bench_default.json 2> $o/bench_default.err; tail -c 1500 $o/bench_default.err; wc -c $o/bench_default.json
+  python bench.py --steps 20 --detail $o/bench_detail20.json > $o/bench_steps20.json 2> /dev/null; wc -c $o/bench_steps20.json
+  AB_ROUNDS=2 bash tools/ab.sh base=tools/_build/ab/base.so pitch152=tools/_build/ab/pitch152.so 2>&1 | tee $o/ab_pitch.txt
+  AB_ROUNDS=2 AB_STEPS=20 bash tools/ab.sh base=tools/_build/ab/base.so pitch152=tools/_build/ab/pitch152.so 2>&1 | tee $o/ab_pitch20.txt
+  E2E_LOOPS=6 python tools/native_lookahead.py 720p,1080p dense 1 0,8 0,1 > $o/native_1stream.jsonl 2>$o/native.err; cut -c1-250 $o/native_1stream.jsonl ;;
 esac
