@@ -693,8 +693,8 @@ def main_enc(emit=True, subset=False, calls_only=False, pmc=None):
         def call_pairs(op=op):
             return theora_amd.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)
 
-        def chk_pairs(op=op):
-            v, dc = call_pairs()
+        def chk_pairs(op=op, call=call_pairs):
+            v, dc = call()
             ncpu = 30000
             t0 = time.perf_counter()
             wv, wdc = oracle.enc_metric_batch(op, cur, prev, stride, src_offs[:ncpu], ref_offs[:ncpu], ref2_offs[:ncpu], 0)
@@ -711,8 +711,8 @@ def main_enc(emit=True, subset=False, calls_only=False, pmc=None):
         def call_sites(op=op):
             return theora_amd.enc_metric_sites_batch(op, d_cur, d_prev, stride, d_base, d_base, sites)
 
-        def chk_sites(op=op):
-            v, dc = call_sites()
+        def chk_sites(op=op, call=call_sites):
+            v, dc = call()
             want_v, _ = theora_amd.enc_metric_batch(op, d_cur, d_prev, stride, d_so, d_ro, d_r2, 0)
             assert torch.equal(v.reshape(-1), want_v)      # candidate-major = the order of the pair list, which is compared with the oracle:
             ncpu = 30000
@@ -732,8 +732,8 @@ def main_enc(emit=True, subset=False, calls_only=False, pmc=None):
         def call_hp(op=op):
             return theora_amd.enc_metric_halfpel_batch(op, d_cur, d_prev, stride, d_base, d_base, d_vecs, hp_sites)
 
-        def chk_hp(op=op):
-            v, dc = call_hp()
+        def chk_hp(op=op, call=call_hp):
+            v, dc = call()
             ncpu = 6000
             sel = np.random.default_rng(11).integers(0, nblk, ncpu)
             t0 = time.perf_counter()

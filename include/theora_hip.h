@@ -248,8 +248,12 @@ int thip_decode_frames(thip_state *const *states, const thip_frame_desc *descs, 
    state's next synchronising call; otherwise, and whenever a frame was decoded on top of the failed one before anything looked
    (the kernels record WHICH launch gave up), the call returns THIP_EFAULT, once, and the state's pictures are wrong until its
    next key frame.  thip_synchronize itself only reports (THIP_EFAULT while some state's words are set): a state belongs to
-   one thread at a time, so decoding again is left to the state's own synchronising calls. */
+   one thread at a time, so decoding again is left to the state's own synchronising calls -- or to thip_state_check_fault,
+   for a caller that keeps its frames on the device and brackets its work with thip_synchronize only: it waits for the state's
+   stream and does what those calls do about a set word.  0: nothing was wrong; 1: the newest frame was decoded again and is
+   right; THIP_EFAULT: see above (reported once -- the words are cleared). */
 int thip_synchronize(void);
+int thip_state_check_fault(thip_state *st);
 
 /* ------------------------------------------------------------------------------------
  * Host-enqueue form of the same path: the vtable slots as the reference calls them, one
@@ -379,6 +383,15 @@ int thip_state_token_lists_staging(thip_state *st, thip_token_staging *out);
 int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t *tokens, int64_t ntokens,
                                   const uint32_t (*list_off)[64], const uint32_t (*list_len)[64],
                                   const uint32_t (*eob_carry)[64], const uint32_t (*arrivals)[64]);
+/* The LAST group of an opened frame, [z0, 64), for a caller that has walked these lists itself (round 6: th_decode_*'s plain loop
+   pairs the high indices on its second thread while the packet is still being decoded, so that the device's walk of the last
+   group -- 3 us an index, 110-160 us at 720p, all of it behind the packet's last bit -- is replaced by one launch over the
+   tokens): `tokens` as for _append (the group's tokens, device format), `assign` one word per token and `last_zzi` one byte per
+   coded fragment of the FRAME, both as for thip_state_token_lists_begin_assigned (the last index of a fragment that ended in an
+   earlier group is what the device found itself).  THIP_EIMPL when tokens, words and bytes do not fit the staging buffer's token
+   area behind what the frame has used (the caller hands the group to _append then); the other checks are _append's. */
+int thip_state_token_lists_append_assigned(thip_state *st, int z0, const uint32_t *tokens, const uint32_t *assign, int64_t ntokens,
+                                           const uint8_t *last_zzi);
 int thip_state_token_lists_abort(thip_state *st);
 /* on != 0: the DC coefficient handed to thip_state_frag_recon (dct_coeffs[0]) is the value decoded from
    the tokens, NOT yet un-predicted: the caller skips its oc_dec_dc_unpredict_mcu_plane calls
@@ -444,11 +457,15 @@ int thip_enc_frag_metric_sites_batch(int op, uint32_t *out, int32_t *dc_out, con
    threshold: every row is added): every block i against nsites of the eight half-pel vectors 2 * vec[i] + (site_dx[c],
    site_dy[c]) around its whole-pel vector vec[i] (vecs[i] = x & 0xFF | y << 8, the reference's oc_mv, state.h:232-240), as
    oc_mcenc_ysatd_halfpel_mbrefine / oc_mcenc_ysad_halfpel_mbrefine do it (mcenc.c:551-657): the source block against the
-   truncating average of the two whole-pel blocks ref_plane + ref_offs[i] + mvoffset0 / mvoffset1 of mcenc.c:633-636 (ref_offs[i]
+   truncating average of the two whole-pel blocks ref_plane + ref_offs[i] + mvoffset0 / mvoffset1 of mcenc.c:644-647 (ref_offs[i]
    is the block at the whole-pel vector, the reference's frag_offs + mvoffset_base).  One launch instead of nsites calls per
    block: the ten rows around the whole-pel position are fetched once per column, and the two vertical sites share their nine
    averaged rows' horizontal Hadamard levels.  (0, 0) is not a half-pel site (THIP_EINVAL).  Results site-major: out[c*nblocks
-   + i] (and dc_out, SATD2 only, may be null).  op: THIP_ENC_SATD2 or THIP_ENC_SAD2_THRESH. */
+   + i] (and dc_out, SATD2 only, may be null).  op: THIP_ENC_SATD2 or THIP_ENC_SAD2_THRESH.
+   Footprint: a row is fetched as one 12-byte window that starts at column -1 or 0 of the whole-pel block, ten rows from the row
+   above it -- up to three bytes beyond the 9 x 10 samples the refinement can need.  ref_plane must be readable that far: one
+   pixel of margin around every whole-pel block (what the refinement itself needs) plus FOUR more bytes behind the last row's
+   last needed sample.  The reference's frames have a 16-pixel border (state.c:545-671), which covers it. */
 int thip_enc_frag_metric_halfpel_batch(int op, uint32_t *out, int32_t *dc_out, const uint8_t *src_plane,
                                        const uint8_t *ref_plane, int ystride, const int32_t *src_offs,
                                        const int32_t *ref_offs, const int16_t *vecs, const int8_t *site_dx,

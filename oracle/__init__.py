@@ -282,8 +282,8 @@ def enc_metric_batch(op, src_plane, ref_plane, ystride, src_offs, ref_offs=None,
 def halfpel_mvoffsets(vx, vy, dx, dy, ystride):
     """The two block offsets the half-pel refinement hands to oc_enc_frag_satd2 / oc_enc_frag_sad2_thresh for the half-pel vector
     2 * (vx, vy) + (dx, dy), relative to the block at the whole-pel vector (the reference's mvoffset_base):
-    oc_mcenc_ysatd_halfpel_mbrefine, mcenc.c:620-636 (offset_y[site] = dy * ystride, :621-623; xmask / ymask = OC_SIGNMASK(((vec <<
-    1) + d) ^ d), :633-634; mvoffset0 = (dx & xmask) + (offset_y & ymask), mvoffset1 = (dx & ~xmask) + (offset_y & ~ymask), :635-636).
+    oc_mcenc_ysatd_halfpel_mbrefine, mcenc.c:606-657 (offset_y[site] = dy * ystride, :624-626; xmask / ymask = OC_SIGNMASK(((vec <<
+    1) + d) ^ d), :644-645; mvoffset0 = (dx & xmask) + (offset_y & ymask), mvoffset1 = (dx & ~xmask) + (offset_y & ~ymask), :646-647).
     vx, vy: integer arrays; returns (mvoffset0, mvoffset1) as int64 arrays."""
     vx, vy = np.asarray(vx, np.int64), np.asarray(vy, np.int64)
     xmask = np.where((((vx << 1) + dx) ^ dx) < 0, -1, 0).astype(np.int64)

@@ -323,8 +323,8 @@ def test_mb_cost_maps_closed_forms():
 
 
 def test_halfpel_refinement_offsets_are_the_decoders():
-    """mcenc.c:626-631 says its mask arithmetic 'SHOULD be equivalent to oc_state_get_mv_offsets' for the vector 2 * vec + (dx, dy)
-    on the luma plane: the oracle's restatement of the one (halfpel_mvoffsets, mcenc.c:620-636) against its restatement of the
+    """mcenc.c:639-643 says its mask arithmetic 'SHOULD be equivalent to oc_state_get_mv_offsets' for the vector 2 * vec + (dx, dy)
+    on the luma plane: the oracle's restatement of the one (halfpel_mvoffsets, mcenc.c:644-647) against its restatement of the
     other (mv_offsets, state.c:846-957) for every whole-pel vector and site -- the same two blocks in the same order."""
     for vx in range(-15, 16):
         for vy in (-15, -2, -1, 0, 1, 7, 15):

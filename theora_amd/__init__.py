@@ -163,6 +163,11 @@ class State:
     def ref_idx(self, which):
         return self._L.thip_state_ref_idx(self._h, which)
 
+    def check_fault(self):
+        """thip_state_check_fault: waits for the state's stream; 0 nothing wrong, 1 the newest frame was decoded again (a tile
+        hand-over had failed), raises on THIP_EFAULT.  For callers that only bracket their work with synchronize()."""
+        return _lib.check(self._L.thip_state_check_fault(self._h), "thip_state_check_fault")
+
     def set_ref_idx(self, gold, prev, self_):
         _lib.check(self._L.thip_state_set_ref_idx(self._h, gold, prev, self_), "set_ref_idx")
 
@@ -264,6 +269,8 @@ class BatchPlan:
 
 
 def synchronize():
+    """thip_synchronize: waits for the library's streams; raises while some state's fault word is set (it only reports: the state's
+    own State.check_fault() / ycbcr_out / read_plane repair or clear it)."""
     _lib.check(_lib.load().thip_synchronize(), "thip_synchronize")
 
 

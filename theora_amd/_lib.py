@@ -65,6 +65,7 @@ SYMBOLS = [
     ("thip_state_ycbcr_map", _I, [_P, C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("thip_state_ycbcr_map_begin", _I, [_P]),
     ("thip_state_ycbcr_map_end", _I, [_P, C.POINTER(_P), C.POINTER(C.c_int32)]),
+    ("thip_state_check_fault", _I, [_P]),
     ("thip_state_ring_mark", _I, [_P, C.POINTER(_I64)]),
     ("thip_state_ring_rewind", _I, [_P, C.POINTER(_I64)]),
     ("thip_state_set_eager_output", _I, [_P, _I]),
@@ -75,6 +76,7 @@ SYMBOLS = [
     ("thip_state_token_lists_finish", _I, [_P, _P]),
     ("thip_state_token_lists_open", _I, [_P, _P]),
     ("thip_state_token_lists_append", _I, [_P, _I, _I, _P, C.c_int64, _P, _P, _P, _P]),
+    ("thip_state_token_lists_append_assigned", _I, [_P, _I, _P, _P, C.c_int64, _P]),
     ("thip_state_token_lists_abort", _I, [_P]),
     ("thip_state_token_lists_staging", _I, [_P, _P]),
     ("thip_state_read_pp_plane", _I, [_P, _I, _P]),

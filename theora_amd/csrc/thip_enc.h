@@ -277,13 +277,13 @@ __global__ __launch_bounds__(256) void k_enc_sites(uint32_t *out, int32_t *dc_ou
 // The reference's refinement (oc_mcenc_ysatd_halfpel_mbrefine, mcenc.c:606-657; the SAD form :551-594) tries the eight half-pel
 // vectors 2 * vec + (dx, dy), (dx, dy) in {-1, 0, 1}^2 without the centre, each as oc_enc_frag_satd2 / oc_enc_frag_sad2_thresh
 // (encfrag.c:62-86, 323-328) of the source block against the truncating average of TWO whole-pel blocks: per axis the pair is
-// {0, d} and WHICH of the two blocks gets the step follows from the signs (mcenc.c:633-636: the block towards zero comes first,
+// {0, d} and WHICH of the two blocks gets the step follows from the signs (mcenc.c:644-647: the block towards zero comes first,
 // as oc_state_get_mv_offsets has it); the average does not care which is first, so all that matters is whether the x step and the
 // y step of a diagonal site land on the same block -- the pair {(0, 0), (dx, dy)} -- or on different ones -- {(dx, 0), (0, dy)}.
 // One lane = one block and one side (the grid's y: dx = -1 or +1, so a wave's branches are scalar): the ten rows around the whole-pel
 // position are loaded once (one 12-byte window a row holds columns 0 and dx) and serve the lane's four sites -- the three with its dx
 // and the vertical site on its side, (0, dx).  Results site-major.
-__device__ __forceinline__ bool halfpel_first_gets_step(int v, int d) { return (((2 * v + d) ^ d) < 0); }   // OC_SIGNMASK(((vec<<1)+d)^d), mcenc.c:633-634
+__device__ __forceinline__ bool halfpel_first_gets_step(int v, int d) { return (((2 * v + d) ^ d) < 0); }   // OC_SIGNMASK(((vec<<1)+d)^d), mcenc.c:644-645
 // the three sites with one dx (DX = -1 / +1), and with VERT the vertical site of the same side, (0, DX)
 template <int OP, int DX, bool VERT>
 __device__ __forceinline__ void halfpel_side(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane, const uint8_t *ref_plane,

@@ -1145,8 +1145,11 @@ namespace {
 // has been read
 constexpr int kFeGroupEnd9[] = {1, 3, 6, 10, 15, 21, 28, 40, 64};
 constexpr int kFeGroupEnd5[] = {1, 6, 15, 28, 64}, kFeGroupEnd4[] = {3, 10, 28, 64}, kFeGroupEnd3[] = {3, 15, 64}, kFeGroupEnd2[] = {6, 64};
+// (round 6: the same low groups with a SHORTER last one -- what the device walks behind the packet's last bit is 3 us an index --
+//  at the price of one or two more pairs of launches on the caller's thread: option fe_groups = 6 / 7)
+constexpr int kFeGroupEnd6[] = {3, 10, 28, 48, 64}, kFeGroupEnd7[] = {3, 10, 28, 44, 56, 64};
 inline const int *fe_group_ends(int n) {
-  return n >= 9 ? kFeGroupEnd9 : n >= 5 ? kFeGroupEnd5 : n == 4 ? kFeGroupEnd4 : n == 3 ? kFeGroupEnd3 : kFeGroupEnd2;
+  return n >= 9 ? kFeGroupEnd9 : n == 7 ? kFeGroupEnd7 : n == 6 ? kFeGroupEnd6 : n >= 5 ? kFeGroupEnd5 : n == 4 ? kFeGroupEnd4 : n == 3 ? kFeGroupEnd3 : kFeGroupEnd2;
 }
 
 // the frame's description and its fragment words, written into the staging buffer (caller's thread)

@@ -148,7 +148,12 @@ __device__ __forceinline__ uint4 tf_fetch_unit(const uint8_t *src, uint32_t ep, 
   // WHICH launch it was goes into one of eight words behind the flag (fault_id = the launch's serial number, 0x1000 added by
   // k_recon_lf_sb, whose buffer counts on its own): the host decodes a frame again only if every launch that reports a failed
   // wait is the frame it can still repeat -- a frame launched on top of a failed one is not made right by repeating it.
+  // (Eight words, ids modulo eight: two failing launches eight serial numbers apart -- eight frames decoded without a synchronising
+  //  call -- share a word.  Whoever finds another launch's id in its word says so in word 10, and the host then repeats nothing:
+  //  ADVICE r05.)
   if (!ok && fault) {
+    const uint32_t before = __hip_atomic_load(fault + 1 + (fault_id & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (before != 0u && before != fault_id) __hip_atomic_store(fault + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(fault + 1 + (fault_id & 7u), fault_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }

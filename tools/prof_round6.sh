@@ -39,4 +39,20 @@ ab2)
   AB_ROUNDS=2 bash tools/ab.sh base=tools/_build/ab/base.so pitch152=tools/_build/ab/pitch152.so 2>&1 | tee $o/ab_pitch.txt
   AB_ROUNDS=2 AB_STEPS=20 bash tools/ab.sh base=tools/_build/ab/base.so pitch152=tools/_build/ab/pitch152.so 2>&1 | tee $o/ab_pitch20.txt
   E2E_LOOPS=6 python tools/native_lookahead.py 720p,1080p dense 1 0,8 0,1 > $o/native_1stream.jsonl 2>$o/native.err; cut -c1-250 $o/native_1stream.jsonl ;;
+ab3)
+  timeout 1500 python -m pytest tests/test_gpu_frames.py tests/test_gpu_levels.py -m gpu -q -x > $o/pytest_kernels.txt 2>&1; tail -3 $o/pytest_kernels.txt
+  python bench.py --mode enc > $o/bench_enc.jsonl 2> $o/bench_enc.err; tail -5 $o/bench_enc.err
+  python - $o/bench_enc.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    d = json.loads(l)
+    print("%-22s %9.1f %-22s %7.2f us  hbm %.3f" % (d["key"], d["value"], d["unit"], 1e3 * d["ms_per_call"], d["roofline"]["frac"]))
+PY
+  for round in 1 2; do for g in 4 6 7; do
+    echo "== fe_groups $g (round $round)"
+    THIP_FE_GROUPS=$g E2E_LOOPS=6 python tools/native_lookahead.py 720p,1080p dense 1 0 0 2>>$o/native.err | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('   ', d.get('size_name'), d.get('frames_per_s'))"
+  done; done 2>&1 | tee $o/plain_loop_groups.txt ;;
 esac
