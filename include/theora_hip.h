@@ -621,9 +621,15 @@ const char *thip_version_string(void);
  *                the levels form (THIP_COEFFS_LEVELS: int8 units, wide tiles where a level needs more; the reconstruction kernel
  *                dequantises); 0: dequantised int16 slots, as in round 3
  *   fe_groups    th_decode_*, token-list path: how many groups of zig-zag indices a frame's lists go to the device in WHILE the packet is
- *                being decoded (thip_state_token_lists_open / _append; boundaries in thip_frontend.cpp, kFeGroupEnd*): 4 (default), 9, 5,
- *                3, 2; 1: in one piece after the packet's last bit (thip_state_token_lists_begin).  More groups start the device
- *                earlier and cost a pair of launches each
+ *                being decoded (thip_state_token_lists_open / _append; boundaries in thip_frontend.cpp, kFeGroupEnd*): 6 (default since round 6:
+ *                {3, 10, 28, 48, 64}: what the device still walks behind the packet's last bit is sixteen indices instead of thirty-six,
+ *                + 6 % at 1080p, the same at 720p), 4 ({3, 10, 28, 64}), 7 ({3, 10, 28, 44, 56, 64}), 9, 5, 3, 2; 1: in one piece after
+ *                the packet's last bit (thip_state_token_lists_begin).  More groups start the device earlier and cost a pair of
+ *                launches each
+ *   fe_pair_tail th_decode_*, token-list path in groups: 1 (default, round 6): the context's second thread also walks the token lists as
+ *                the caller decodes them and pairs the LAST group's tokens with their fragments -- thip_state_token_lists_append_assigned,
+ *                k_tok_scatter instead of the device's walk of that group behind the packet's last bit; the thread then runs at every frame
+ *                size (fe_worker notwithstanding); 0: the device walks every group.  fe_tails_paired: (counter) such frames
  *   fe_worker    th_decode_*, token-list path: 1: the context has a second thread that undoes the DC prediction (spec 7.8;
  *                decode.c:1392-1500) while th_decode_packetin's caller decodes the tokens of indices 1..63; 0: the caller does it
  *                behind the tokens, while the device still walks the last group of indices (it needs the values last); 2 (default):

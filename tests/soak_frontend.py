@@ -19,7 +19,7 @@ while time.time() - t0 < limit:
     # the DC chain on the caller's thread or on the context's second one), or the library's choice
     lists = [False, True, True, None][int(rng.integers(4))]
     L = theora_amd._lib.load()
-    L.thip_set_option(b"fe_groups", int(rng.choice([1, 2, 3, 4, 5, 9])))
+    L.thip_set_option(b"fe_groups", int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9])))
     L.thip_set_option(b"fe_worker", int(rng.integers(2)))
     L.thip_set_option(b"tl_levels", int(rng.integers(2)))
     L.thip_set_option(b"tl_algo", int(rng.integers(0, 3)))

@@ -264,7 +264,7 @@ def test_packets_decode_bit_exact_with_the_token_lists_on_the_gpu(hip, w, h, fmt
                       device_dc=device_dc) >= 3
 
 
-@pytest.mark.parametrize("groups,worker,levels,algo", [(1, 0, 1, 2), (1, 1, 0, 1), (4, 0, 0, 2), (9, 1, 1, 1), (2, 1, 1, 2), (4, 1, 1, 1)])
+@pytest.mark.parametrize("groups,worker,levels,algo", [(1, 0, 1, 2), (1, 1, 0, 1), (4, 0, 0, 2), (9, 1, 1, 1), (2, 1, 1, 2), (4, 1, 1, 1), (7, 0, 1, 1)])
 @pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 0), (48, 64, 3), (336, 32, 0), (1280, 720, 0), (1920, 1088, 0)])
 def test_packets_decode_bit_exact_with_the_token_lists_in_groups(hip, w, h, fmt, groups, worker, levels, algo):
     """The token-list path's options.  tl_levels: the device writes the coefficient slots as dequantised int16 (0, round 3's
@@ -272,7 +272,7 @@ def test_packets_decode_bit_exact_with_the_token_lists_in_groups(hip, w, h, fmt,
     the generator's streams have both kinds of tile --, k_recon_lf<LEVELS> dequantises).  fe_groups: the lists go to the device in one piece after the packet's last bit
     (1: thip_state_token_lists_begin) or in groups of zig-zag indices while the caller still decodes
     (thip_state_token_lists_staging / _open / _append, k_tok_assign launched once per group, the fragments' positions kept
-    between the launches; the default of 4 is what the other tests run).  fe_worker: the DC prediction undone by the caller
+    between the launches; the default of 6 -- {3, 10, 28, 48, 64} -- is what the other tests run).  fe_worker: the DC prediction undone by the caller
     behind the tokens (0) or by the context's second thread beside them."""
     L = hip._lib.load()
     L.thip_set_option(b"fe_groups", groups)
@@ -282,7 +282,7 @@ def test_packets_decode_bit_exact_with_the_token_lists_in_groups(hip, w, h, fmt,
     try:
         assert run_stream(hip, w, h, fmt, seed=w + 3 * h + fmt, nframes=9 if w < 1000 else 4, device_lists=True) >= 3
     finally:
-        L.thip_set_option(b"fe_groups", 4)
+        L.thip_set_option(b"fe_groups", 6)
         L.thip_set_option(b"fe_worker", 2)
         L.thip_set_option(b"tl_levels", 1)
         L.thip_set_option(b"tl_algo", 0)
@@ -436,6 +436,29 @@ def test_contexts_on_concurrent_host_threads(hip):
                 assert all(np.array_equal(a, b) for a, b in zip(fa, fb)), i
 
 
+@pytest.mark.parametrize("groups", [6, 4, 2, 9])
+@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 2), (48, 64, 3), (1280, 720, 0), (1920, 1088, 0)])
+def test_last_group_paired_by_the_second_thread(hip, w, h, fmt, groups):
+    """Option fe_pair_tail (default since round 6): the context's second thread walks the token lists beside the entropy decoder and
+    pairs the LAST group's tokens with their fragments (decode.c:1540-1581), so that group goes to the device through
+    thip_state_token_lists_append_assigned -- k_tok_scatter -- instead of being walked there behind the packet's last bit.  Every
+    frame against the oracle, with the option on and off, at every grouping; the counter says the paired path was the one taken."""
+    import ctypes as C
+    L = hip._lib.load()
+
+    def counter(name):
+        v = C.c_int()
+        assert L.thip_get_option(name, C.byref(v)) == 0
+        return v.value
+    n = 9 if w < 1000 else 4
+    for on in (1, 0):
+        before = counter(b"fe_tails_paired")
+        with util.options(L, fe_pair_tail=on, fe_groups=groups, fe_device_lists=1):
+            assert run_stream(hip, w, h, fmt, seed=5 * w + h + fmt, nframes=n, device_lists=True, trees="matched") >= 3
+        got = counter(b"fe_tails_paired") - before
+        assert (got >= n - 3) if on else (got == 0), (on, got)
+
+
 @pytest.mark.parametrize("algo,groups", [(0, 4), (2, 4), (2, 1), (1, 9)])
 def test_mutated_packets_through_the_device_path(hip, algo, groups):
     """The same kind of damage tests/test_frontend_fuzz.py applies on the host, through the real
@@ -453,7 +476,7 @@ def test_mutated_packets_through_the_device_path(hip, algo, groups):
         _mutated_packets(hip)
     finally:
         L.thip_set_option(b"tl_algo", 0)
-        L.thip_set_option(b"fe_groups", 4)
+        L.thip_set_option(b"fe_groups", 6)
 
 
 def _mutated_packets(hip):

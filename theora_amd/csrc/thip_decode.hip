@@ -92,8 +92,10 @@ Option g_options[] = {
     {"tl_algo", 0, "token lists on the device: 1: k_tok_assign (rank -> fragment map in LDS, or in memory for planes beyond 36 864 coded fragments); 2: k_tok_rank + k_tok_walk (every fragment looked after by one thread, one barrier per index, one byte of LDS per fragment); 0 (default): 2 where 1 would keep its map in memory (4K), 1 otherwise"},
     {"tl_walk_threads", 0, "k_tok_walk: threads of the work group (256, 512, 1024); 0 (default): by plane size"},
     {"tl_levels", 1, "token lists on the device (thip_state_token_lists_*): 1 (default): the device writes the coefficient slots in the levels form (int8 units, the reconstruction kernel dequantises); 0: dequantised int16 slots"},
-    {"fe_groups", 4, "th_decode_*, token-list path: the groups of zig-zag indices a frame's lists are handed over in while the packet is still being decoded: 4 (default: {3, 10, 28, 64}), 9, 5, 3, 2, 6 ({3, 10, 28, 48, 64}) or 7 ({3, 10, 28, 44, 56, 64}): a shorter last group for one or two more pairs of launches, or 1: in one piece after the packet's last bit"},
+    {"fe_groups", 6, "th_decode_*, token-list path: the groups of zig-zag indices a frame's lists are handed over in while the packet is still being decoded: 6 (default since round 6: {3, 10, 28, 48, 64} -- what the device walks behind the packet's last bit is sixteen indices instead of thirty-six), 4 ({3, 10, 28, 64}, rounds 4-5), 7 ({3, 10, 28, 44, 56, 64}), 9, 5, 3, 2, or 1: in one piece after the packet's last bit"},
     {"fe_worker", 2, "th_decode_*, token-list path: 1: a second thread per context undoes the DC prediction while the caller decodes the tokens of indices 1..63; 0: the caller does it behind the tokens, while the device walks the last indices; 2 (default): 1 for frames of more than 32 768 fragments (beyond 720p), 0 otherwise"},
+    {"fe_pair_tail", 1, "th_decode_*, token-list path in groups: 1 (default, round 6): the context's second thread walks the token lists beside the entropy decoder and pairs the LAST group's tokens with their fragments, so that the device's walk of that group behind the packet's last bit becomes one launch of k_tok_scatter (thip_state_token_lists_append_assigned); the thread then runs at every frame size; 0: the device walks every group"},
+    {"fe_tails_paired", 0, "(counter) frames whose last group of token lists went to the device paired by the second thread (fe_pair_tail)"},
     {"fe_worker_pin", 1, "th_decode_*, fe_worker on: 1 (default): the second thread is kept on the CPUs that share a last-level cache with the caller's; 0: left to the scheduler"},
     {"fe_lookahead", 8, "th_decode_*: packets a caller may announce ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), each parsed by a thread of its own on a parser context: 8 (default), up to 16; 0: announcements are not taken"},
     {"fe_assign", 2, "th_decode_*, announced packets on the token-list path: 1: the parser pairs tokens and fragments while it decodes the tokens and the frame goes to thip_state_token_lists_begin_assigned (k_tok_scatter: the device pairs nothing); 0: the device walks the lists (thip_state_token_lists_begin); 2 (default): whichever measures faster for this stream (24 frames each way, the better for 1024, and again)"},

@@ -8,7 +8,7 @@ mkdir -p $o
 : > $o/pmc_$content.txt
 for grp in "VALUBusy" "SQ_INSTS_VALU SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "MemUnitStalled" "SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE"; do
   d=$o/pmc_${content}_$(echo $grp | tr ' ' '_')
-  THIP_LANES=${LANES:-1} timeout 300 rocprofv3 --pmc $grp --output-format csv -d $d -- python bench.py --content $content --steps 24 --warmup 4 --repeats 1 --min-time 0 --no-cpu-baseline --no-parity --no-profile --no-pmc --no-1080p --no-e2e --no-wide --no-enc --second-content "" > $d.log 2>&1
+  THIP_LANES=${LANES:-1} timeout 300 rocprofv3 --pmc $grp --output-format csv -d $d -- python bench.py --content $content --steps 24 --warmup 4 --repeats 1 --min-time 0 --no-cpu-baseline --no-parity --no-profile --no-pmc --no-1080p --no-e2e --no-wide --no-enc --no-form16 --second-content "" > $d.log 2>&1
   python - "$d" >> $o/pmc_$content.txt <<'PY'
 import csv, glob, sys, os
 files = glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True)

@@ -55,4 +55,34 @@ import sys, json
 for l in sys.stdin:
     d = json.loads(l); print('   ', d.get('size_name'), d.get('frames_per_s'))"
   done; done 2>&1 | tee $o/plain_loop_groups.txt ;;
+ab4)
+  timeout 1800 python -m pytest tests/test_gpu_frontend.py -m gpu -q -x > $o/pytest_frontend.txt 2>&1; tail -3 $o/pytest_frontend.txt
+  for round in 1 2; do for t in 0 1; do
+    echo "== fe_pair_tail $t (round $round)"
+    THIP_FE_PAIR_TAIL=$t E2E_LOOPS=6 python tools/native_lookahead.py 720p,1080p,4k dense,typical 1 0 0 2>>$o/native.err | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('   ', d.get('size_name'), d.get('packets'), d.get('frames_per_s'))"
+  done; done 2>&1 | tee $o/plain_loop_pair_tail.txt
+  python tools/make_clip720.py > /dev/null 2>&1
+  for t in 0 1; do echo "== stage table 720p plain loop, fe_pair_tail $t" >> $o/stage_tables.txt; THIP_FE_PAIR_TAIL=$t THIP_FE_PROF=1 examples/decode_bench gpurun_out/clip720.ogv 1 3 >> $o/stage_tables.txt 2>&1; done
+  tail -60 $o/stage_tables.txt ;;
+final)
+  Q2="--no-cpu-baseline --no-parity --no-profile --no-pmc --no-1080p --no-e2e --no-wide --no-enc --no-form16 --second-content ''"
+  timeout 2400 python -m pytest tests -m gpu -q > $o/pytest_gpu.txt 2>&1; tail -3 $o/pytest_gpu.txt
+  python bench.py --detail $o/bench_detail.json > $o/bench_default.json 2> $o/bench_default.err; wc -c $o/bench_default.json
+  python bench.py --steps 20 --detail $o/bench_detail_steps20.json > $o/bench_steps20.json 2>/dev/null; wc -c $o/bench_steps20.json
+  THIP_FUSE=0 python bench.py --no-cpu-baseline --no-1080p --no-e2e --no-wide --no-enc --no-form16 --detail $o/bench_detail_twopass.json > $o/bench_twopass.json 2>/dev/null
+  python bench.py --mode enc > $o/bench_enc.jsonl 2>$o/bench_enc.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_enc -- python bench.py --mode enc > $o/bench_enc_under_rocprof.jsonl 2>$o/stats_enc.log
+  THIP_LANES=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_lanes1 -- bash -c "python bench.py --steps 64 --repeats 2 --min-time 0 $Q2" > $o/stats_lanes1.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_default -- bash -c "python bench.py --steps 64 --repeats 2 --min-time 0 $Q2" > $o/stats_default.log 2>&1
+  THIP_LANES=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_int16_lanes1 -- bash -c "python bench.py --form dequant16 --steps 64 --repeats 2 --min-time 0 $Q2" > $o/stats_int16_lanes1.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_1080p_single -- bash -c "python bench.py --size 1080p --streams-per-gpu 1 --steps 128 --repeats 2 --min-time 0 $Q2" > $o/stats_1080p_single.log 2>&1
+  LANES=2 bash tools/pmc_r4.sh dense > /dev/null 2>&1; cp gpurun_out/r04/pmc_dense.txt $o/pmc_counters_dense_lanes2.txt 2>/dev/null
+  LANES=2 bash tools/pmc_r4.sh smooth > /dev/null 2>&1; cp gpurun_out/r04/pmc_smooth.txt $o/pmc_counters_smooth_lanes2.txt 2>/dev/null
+  MASTER_ADDR=127.0.0.1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --no-1080p --no-e2e --no-wide --no-enc --no-form16 --no-pmc --cpu-frames 32 --detail $o/bench_detail_torchrun.json > $o/torchrun_world1.log 2>&1
+  E2E_LOOPS=6 python tools/native_lookahead.py 720p,1080p,4k dense 1 0,8,16 0,1 > $o/native_1stream.jsonl 2>$o/native.err
+  E2E_LOOPS=6 python tools/native_lookahead.py 720p,4k dense 4 0,8 0,1 > $o/native_4streams.jsonl 2>>$o/native.err
+  tail -c 600 $o/bench_default.json ;;
 esac
