@@ -383,15 +383,6 @@ int thip_state_token_lists_staging(thip_state *st, thip_token_staging *out);
 int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t *tokens, int64_t ntokens,
                                   const uint32_t (*list_off)[64], const uint32_t (*list_len)[64],
                                   const uint32_t (*eob_carry)[64], const uint32_t (*arrivals)[64]);
-/* The LAST group of an opened frame, [z0, 64), for a caller that has walked these lists itself (round 6: th_decode_*'s plain loop
-   pairs the high indices on its second thread while the packet is still being decoded, so that the device's walk of the last
-   group -- 3 us an index, 110-160 us at 720p, all of it behind the packet's last bit -- is replaced by one launch over the
-   tokens): `tokens` as for _append (the group's tokens, device format), `assign` one word per token and `last_zzi` one byte per
-   coded fragment of the FRAME, both as for thip_state_token_lists_begin_assigned (the last index of a fragment that ended in an
-   earlier group is what the device found itself).  THIP_EIMPL when tokens, words and bytes do not fit the staging buffer's token
-   area behind what the frame has used (the caller hands the group to _append then); the other checks are _append's. */
-int thip_state_token_lists_append_assigned(thip_state *st, int z0, const uint32_t *tokens, const uint32_t *assign, int64_t ntokens,
-                                           const uint8_t *last_zzi);
 int thip_state_token_lists_abort(thip_state *st);
 /* on != 0: the DC coefficient handed to thip_state_frag_recon (dct_coeffs[0]) is the value decoded from
    the tokens, NOT yet un-predicted: the caller skips its oc_dec_dc_unpredict_mcu_plane calls
@@ -626,10 +617,6 @@ const char *thip_version_string(void);
  *                + 6 % at 1080p, the same at 720p), 4 ({3, 10, 28, 64}), 7 ({3, 10, 28, 44, 56, 64}), 9, 5, 3, 2; 1: in one piece after
  *                the packet's last bit (thip_state_token_lists_begin).  More groups start the device earlier and cost a pair of
  *                launches each
- *   fe_pair_tail th_decode_*, token-list path in groups: 1 (default, round 6): the context's second thread also walks the token lists as
- *                the caller decodes them and pairs the LAST group's tokens with their fragments -- thip_state_token_lists_append_assigned,
- *                k_tok_scatter instead of the device's walk of that group behind the packet's last bit; the thread then runs at every frame
- *                size (fe_worker notwithstanding); 0: the device walks every group.  fe_tails_paired: (counter) such frames
  *   fe_worker    th_decode_*, token-list path: 1: the context has a second thread that undoes the DC prediction (spec 7.8;
  *                decode.c:1392-1500) while th_decode_packetin's caller decodes the tokens of indices 1..63; 0: the caller does it
  *                behind the tokens, while the device still walks the last group of indices (it needs the values last); 2 (default):

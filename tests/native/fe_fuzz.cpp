@@ -37,7 +37,6 @@ int thip_state_token_lists_finish(thip_state *, const int16_t *) { return -1; }
 int thip_state_token_lists_open(thip_state *, const thip_token_lists *) { return -1; }
 int thip_state_token_lists_append(thip_state *, int, int, const uint32_t *, int64_t, const uint32_t (*)[64], const uint32_t (*)[64],
                                   const uint32_t (*)[64], const uint32_t (*)[64]) { return -1; }
-int thip_state_token_lists_append_assigned(thip_state *, int, const uint32_t *, const uint32_t *, int64_t, const uint8_t *) { return -1; }
 int thip_state_token_lists_abort(thip_state *) { return -1; }
 int thip_state_ring_mark(thip_state *, int64_t *) { return -1; }
 int thip_state_ring_rewind(thip_state *, const int64_t *) { return -1; }

@@ -436,29 +436,6 @@ def test_contexts_on_concurrent_host_threads(hip):
                 assert all(np.array_equal(a, b) for a, b in zip(fa, fb)), i
 
 
-@pytest.mark.parametrize("groups", [6, 4, 2, 9])
-@pytest.mark.parametrize("w,h,fmt", [(64, 48, 0), (176, 144, 2), (48, 64, 3), (1280, 720, 0), (1920, 1088, 0)])
-def test_last_group_paired_by_the_second_thread(hip, w, h, fmt, groups):
-    """Option fe_pair_tail (default since round 6): the context's second thread walks the token lists beside the entropy decoder and
-    pairs the LAST group's tokens with their fragments (decode.c:1540-1581), so that group goes to the device through
-    thip_state_token_lists_append_assigned -- k_tok_scatter -- instead of being walked there behind the packet's last bit.  Every
-    frame against the oracle, with the option on and off, at every grouping; the counter says the paired path was the one taken."""
-    import ctypes as C
-    L = hip._lib.load()
-
-    def counter(name):
-        v = C.c_int()
-        assert L.thip_get_option(name, C.byref(v)) == 0
-        return v.value
-    n = 9 if w < 1000 else 4
-    for on in (1, 0):
-        before = counter(b"fe_tails_paired")
-        with util.options(L, fe_pair_tail=on, fe_groups=groups, fe_device_lists=1):
-            assert run_stream(hip, w, h, fmt, seed=5 * w + h + fmt, nframes=n, device_lists=True, trees="matched") >= 3
-        got = counter(b"fe_tails_paired") - before
-        assert (got >= n - 3) if on else (got == 0), (on, got)
-
-
 @pytest.mark.parametrize("algo,groups", [(0, 4), (2, 4), (2, 1), (1, 9)])
 def test_mutated_packets_through_the_device_path(hip, algo, groups):
     """The same kind of damage tests/test_frontend_fuzz.py applies on the host, through the real

@@ -76,7 +76,6 @@ SYMBOLS = [
     ("thip_state_token_lists_finish", _I, [_P, _P]),
     ("thip_state_token_lists_open", _I, [_P, _P]),
     ("thip_state_token_lists_append", _I, [_P, _I, _I, _P, C.c_int64, _P, _P, _P, _P]),
-    ("thip_state_token_lists_append_assigned", _I, [_P, _I, _P, _P, C.c_int64, _P]),
     ("thip_state_token_lists_abort", _I, [_P]),
     ("thip_state_token_lists_staging", _I, [_P, _P]),
     ("thip_state_read_pp_plane", _I, [_P, _I, _P]),

@@ -94,8 +94,6 @@ Option g_options[] = {
     {"tl_levels", 1, "token lists on the device (thip_state_token_lists_*): 1 (default): the device writes the coefficient slots in the levels form (int8 units, the reconstruction kernel dequantises); 0: dequantised int16 slots"},
     {"fe_groups", 6, "th_decode_*, token-list path: the groups of zig-zag indices a frame's lists are handed over in while the packet is still being decoded: 6 (default since round 6: {3, 10, 28, 48, 64} -- what the device walks behind the packet's last bit is sixteen indices instead of thirty-six), 4 ({3, 10, 28, 64}, rounds 4-5), 7 ({3, 10, 28, 44, 56, 64}), 9, 5, 3, 2, or 1: in one piece after the packet's last bit"},
     {"fe_worker", 2, "th_decode_*, token-list path: 1: a second thread per context undoes the DC prediction while the caller decodes the tokens of indices 1..63; 0: the caller does it behind the tokens, while the device walks the last indices; 2 (default): 1 for frames of more than 32 768 fragments (beyond 720p), 0 otherwise"},
-    {"fe_pair_tail", 1, "th_decode_*, token-list path in groups: 1 (default, round 6): the context's second thread walks the token lists beside the entropy decoder and pairs the LAST group's tokens with their fragments, so that the device's walk of that group behind the packet's last bit becomes one launch of k_tok_scatter (thip_state_token_lists_append_assigned); the thread then runs at every frame size; 0: the device walks every group"},
-    {"fe_tails_paired", 0, "(counter) frames whose last group of token lists went to the device paired by the second thread (fe_pair_tail)"},
     {"fe_worker_pin", 1, "th_decode_*, fe_worker on: 1 (default): the second thread is kept on the CPUs that share a last-level cache with the caller's; 0: left to the scheduler"},
     {"fe_lookahead", 8, "th_decode_*: packets a caller may announce ahead of their th_decode_packetin (TH_DECCTL_THIP_PREFETCH_PACKET), each parsed by a thread of its own on a parser context: 8 (default), up to 16; 0: announcements are not taken"},
     {"fe_assign", 2, "th_decode_*, announced packets on the token-list path: 1: the parser pairs tokens and fragments while it decodes the tokens and the frame goes to thip_state_token_lists_begin_assigned (k_tok_scatter: the device pairs nothing); 0: the device walks the lists (thip_state_token_lists_begin); 2 (default): whichever measures faster for this stream (24 frames each way, the better for 1024, and again)"},
@@ -2493,62 +2491,6 @@ int thip_state_token_lists_append(thip_state *st, int z0, int z1, const uint32_t
   st->tl_z = z1;
   st->tl_ntok = (int64_t)at + ntokens;
   mark_dirty(st->device, s);   // (behind the launches as well as in front of them: see launch_frame_out)
-  return THIP_OK;
-}
-
-// The last group [z0, 64) of an opened frame, walked by the caller (include/theora_hip.h): tokens, one word per token, the frame's
-// last indices -- k_tok_scatter instead of k_tok_assign / k_tok_walk, then what follows a frame's last group.
-int thip_state_token_lists_append_assigned(thip_state *st, int z0, const uint32_t *tokens, const uint32_t *assign, int64_t ntokens,
-                                           const uint8_t *last_zzi) {
-  if (!st) return THIP_EFAULT;
-  if (!st->tl_pending || z0 != st->tl_z || z0 < 0 || z0 >= 64 || ntokens < 0) return THIP_EINVAL;
-  const int64_t ncoded = st->tl_ncoded;
-  if (!ncoded) {
-    st->tl_z = 64;
-    return THIP_OK;
-  }
-  if (!last_zzi || (ntokens && (!tokens || !assign))) return THIP_EFAULT;
-  if (ncoded > 0x3FFFF) return THIP_EIMPL;   // (eighteen bits of fragment index)
-  const int64_t at = ((int64_t)st->tl_ntok + 3) & ~(int64_t)3;   // the group starts on a 16-byte unit of the token area
-  const int64_t a_asg = (ntokens + 3) & ~(int64_t)3, a_lz = a_asg + ((ntokens + 3) & ~(int64_t)3), a_end = a_lz + ((ncoded + 15) / 16) * 4;
-  if (at + a_end > tl_token_capacity(st)) return THIP_EIMPL;
-  DeviceGuard dg(st->device);
-  hipStream_t s = st->tl_stream;
-  uint32_t *h = st->h_tl + st->tl_o_tok + at;
-  if (ntokens && tokens != h) memcpy(h, tokens, (size_t)ntokens * 4);   // (not if the caller wrote them there)
-  if (ntokens) memcpy(h + a_asg, assign, (size_t)ntokens * 4);
-  memcpy(h + a_lz, last_zzi, (size_t)ncoded);
-  TlCopyK C;   // (the header travels with every group, thip_state_token_lists_append; this group's kernels read none of its tables)
-  C.src[0] = reinterpret_cast<const int4 *>(st->h_tl);
-  C.dst[0] = reinterpret_cast<int4 *>(st->d_tl);
-  C.n[0] = THIP_TL_HDR / 4;
-  C.src[1] = reinterpret_cast<const int4 *>(h);
-  C.dst[1] = reinterpret_cast<int4 *>(st->d_tl + st->tl_o_tok + at);
-  C.n[1] = (size_t)a_end / 4;
-  const unsigned cgroups = (unsigned)std::min<size_t>(256, (C.n[1] + 255) / 256 + 1);
-  hipLaunchKernelGGL(k_tok_copy, dim3(cgroups), dim3(256), 0, s, C);
-  TlK K = st->tl_K;
-  K.z0 = z0;
-  K.z1 = 64;
-  const uint32_t *d_tok = st->d_tl + st->tl_o_tok + at;
-  K.tok = d_tok;   // (k_tok_scatter counts its tokens from the group's first)
-  const int64_t nthreads = std::max<int64_t>(ntokens, ncoded);
-  hipLaunchKernelGGL(k_tok_scatter, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, K, d_tok + a_asg,
-                     reinterpret_cast<const uint8_t *>(d_tok + a_lz), (int)ntokens);
-  K.tok = st->tl_K.tok;
-  if (K.levels) hipLaunchKernelGGL(k_tok_widths, dim3((unsigned)((ncoded + 255) / 256)), dim3(256), 0, s, K);
-  if (ncoded <= 4 * kTlSlotChunk) {
-    hipLaunchKernelGGL(k_tok_slots, dim3(1), dim3(1024), 0, s, K);
-  } else {   // (large frames: many groups, two launches)
-    const unsigned ng = (unsigned)((ncoded + kTlSlotChunk - 1) / kTlSlotChunk);
-    uint32_t *part = st->d_tl_wide + (((size_t)st->tiles.ntiles + 3) & ~(size_t)3);   // (behind the tiles' words)
-    hipLaunchKernelGGL(k_tok_slots_count, dim3(ng), dim3(1024), 0, s, K, part);
-    hipLaunchKernelGGL(k_tok_slots_assign, dim3(ng), dim3(1024), 0, s, K, (const uint32_t *)part);
-  }
-  HIP_TRY(hipGetLastError());
-  st->tl_z = 64;
-  st->tl_ntok = at + a_end;
-  mark_dirty(st->device, s);
   return THIP_OK;
 }
 

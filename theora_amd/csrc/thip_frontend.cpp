@@ -224,20 +224,6 @@ struct FeWorker {
   bool go = false, quit = false;   // a frame to work on / the context is going away (both under mu)
   std::atomic<int> z0_ready{0};    // the three lists of index 0 are complete
   std::atomic<int> done{0};        // the DC values of the frame are there
-  // Option fe_pair_tail (round 6): behind the DC chain the thread WALKS the frame's token lists as the caller completes them -- which
-  // fragment arrives at which index, decode.c:1540-1581 -- and from index z_tail on (the last group the frame is handed over in)
-  // writes down which token is whose, one word per token as thip_state_token_lists_begin_assigned takes them, so that the device's
-  // walk of the last group (3 us an index, all of it behind the packet's last bit) becomes one launch of k_tok_scatter
-  // (thip_state_token_lists_append_assigned).  The caller publishes its progress in lists_done (lists complete, in (index, plane) order).
-  bool pair_tail = false;
-  int z_tail = 64;
-  std::atomic<int> lists_done{0};
-  std::vector<uint8_t> pos[3];     // the index every coded fragment of a plane arrives at next (0xFF: padding)
-  std::vector<uint32_t> arr;       // the arrivals of the list at hand
-  std::vector<uint32_t> words;     // one per token of the lists [z_tail, 64), in (index, plane, token) order
-  std::vector<uint8_t> lastz;      // the last index of every coded fragment (coded order)
-  size_t nwords = 0;
-  bool tail_ok = false;
   // Where it runs: on the CPUs that share a last-level cache with the caller's (option fe_worker_pin).  What the two threads hand each
   // other -- the coded flags, reference indices and index-0 lists one way, the DC values the other -- crosses between their cores
   // every frame; through a shared L3 that is tens of nanoseconds a line, across sockets several hundred (4K: the stages that
@@ -1295,93 +1281,6 @@ void fe_worker_place(FeWorker &w) {
   w.placed = true;
 }
 
-// The walk of the token lists on the worker (FeWorker::pair_tail): list after list in the order the caller completes them, the
-// arrivals of a list found as decode_token_list<true>'s caller finds them (the bytes of `pos` equal to the index), every token given
-// the next of them -- an EOB token as many as it ends.  Positions only below z_tail; words from there on.
-void fe_worker_pair(th_dec_ctx *d) {
-  FeWorker &w = *d->worker;
-  const int z_tail = w.z_tail;
-  size_t nmax = 0;
-  for (int p = 0; p < 3; p++) {
-    const size_t np = d->cl_start[p + 1] - d->cl_start[p], np16 = (np + 15) & ~(size_t)15;
-    w.pos[p].assign(np16 + 16, 0xFF);
-    if (np) memset(w.pos[p].data(), 0, np);   // every coded fragment arrives at index 0
-    nmax = np16 > nmax ? np16 : nmax;
-  }
-  w.arr.resize(nmax + 32);
-  w.lastz.assign(d->cl_start[3] + 1 + 16, 0);
-  size_t wi = 0;
-  bool ok = true;
-  for (int z = 0; z < 64; z++)
-    for (int p = 0; p < 3; p++) {
-      const int idx = z * 3 + p;
-      for (unsigned spins = 0; w.lists_done.load(std::memory_order_acquire) <= idx; spins++) {
-        if (spins < 4096) cpu_relax();
-        else std::this_thread::yield();
-      }
-      const size_t n_arr = d->arrivals[p][z], ntk = d->ntoks[p][z];
-      if (z >= z_tail && w.words.size() < wi + ntk + 8) w.words.resize((wi + ntk + 8) * 2);
-      if (!n_arr) {   // (nobody arrives: no tokens -- a list that has some all the same gets words nobody reads)
-        if (z >= z_tail)
-          for (size_t k = 0; k < ntk; k++) w.words[wi++] = 0xFFFFFFFFu;
-        continue;
-      }
-      const size_t c0 = d->cl_start[p], np = d->cl_start[p + 1] - c0, np16 = (np + 15) & ~(size_t)15;
-      uint8_t *const pos = w.pos[p].data();
-      uint32_t *const arr = w.arr.data();
-      uint8_t *const lastz = w.lastz.data() + c0;
-      size_t na = 0;
-#if defined(__SSE2__)
-      {
-        const __m128i zz = _mm_set1_epi8((char)z), zero = _mm_setzero_si128();
-        for (size_t i = 0; i < np16; i += 16) {
-          const __m128i eq = _mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(pos + i)), zz);
-          const unsigned m = (unsigned)_mm_movemask_epi8(eq);
-          if (!m) continue;
-          __m128i *const lzp = reinterpret_cast<__m128i *>(lastz + i);
-          _mm_storeu_si128(lzp, _mm_or_si128(_mm_andnot_si128(eq, _mm_loadu_si128(lzp)), _mm_and_si128(eq, zz)));
-          for (int half = 0; half < 2; half++) {
-            const unsigned m8 = (m >> (8 * half)) & 0xFFu;
-            const __m128i b = _mm_unpacklo_epi8(_mm_loadl_epi64(reinterpret_cast<const __m128i *>(kBitIndex.idx[m8])), zero);
-            const __m128i base = _mm_set1_epi32((int)(i + 8 * (size_t)half));
-            _mm_storeu_si128(reinterpret_cast<__m128i *>(arr + na), _mm_add_epi32(_mm_unpacklo_epi16(b, zero), base));
-            _mm_storeu_si128(reinterpret_cast<__m128i *>(arr + na + 4), _mm_add_epi32(_mm_unpackhi_epi16(b, zero), base));
-            na += kBitIndex.count[m8];
-          }
-        }
-      }
-#else
-      for (size_t k = 0; k < np; k++)
-        if (pos[k] == z) {
-          arr[na++] = (uint32_t)k;
-          lastz[k] = (uint8_t)z;
-        }
-#endif
-      if (na != n_arr) ok = false;   // (cannot happen: the caller counted the same fragments as it decoded the lists before)
-      const size_t carry = d->eob_carry[p][z] < na ? d->eob_carry[p][z] : na;   // ended by a run from an earlier list
-      const uint32_t *a = arr + carry;
-      size_t n = na - carry;
-      const Tok *t = d->toks[p][z].data();
-      const uint32_t zword = (uint32_t)z << 18;
-      const bool tail = z >= z_tail;
-      for (size_t k = 0; k < ntk; k++) {
-        if (!n) {   // (a token nobody consumes: the caller stops decoding a list when its blocks are used up, so there is none)
-          if (tail) w.words[wi++] = 0xFFFFFFFFu;
-          continue;
-        }
-        const size_t want = t[k].eob ? t[k].eob : 1u;
-        const size_t take = want < n ? want : n;
-        const uint32_t f = *a;
-        a += take;
-        n -= take;
-        pos[f] = (uint8_t)(z + t[k].adv);
-        if (tail) w.words[wi++] = ((uint32_t)c0 + f) | (zword + ((uint32_t)t[k].skip << 18));
-      }
-    }
-  w.nwords = wi;
-  w.tail_ok = ok;
-}
-
 // the worker's side of a frame
 void fe_worker_frame(th_dec_ctx *d) {
   FeWorker &w = *d->worker;
@@ -1394,7 +1293,6 @@ void fe_worker_frame(th_dec_ctx *d) {
   const size_t nc = d->cl_start[3];
   d->tl_dc.resize(nc + 1);
   for (size_t ci = 0; ci < nc; ci++) d->tl_dc[ci] = d->dc[d->clist[ci]];
-  if (w.pair_tail) fe_worker_pair(d);
 }
 
 void fe_worker_main(th_dec_ctx *d) {
@@ -1788,8 +1686,6 @@ double th_granule_time(void *encdec, int64_t granpos) {
 // packets a caller has announced run on parser contexts of their own (FeLookahead), th_decode_packetin adopts the result.
 struct FeRun {
   bool lists_now = false, streaming = false, with_worker = false, dc_done = false;
-  bool pair_tail = false;       // the context's second thread pairs the last group's tokens and fragments (FeWorker::pair_tail)
-  bool tail_deferred = false;   // ... and that group has not been handed over yet: fe_back does, with the thread's words
   int stream_rc = 0;   // (inline hand-over: the first failure)
 };
 constexpr int kFeContinue = 0x7F00;   // fe_front: the frame goes on to fe_back (anything else is th_decode_packetin's return value)
@@ -2075,10 +1971,7 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
   // while that walk runs (0.16 ms at 720p) and a second thread only adds its hand-overs (measured: + 5 % without it at 720p, - 10 %
   // at 1080p, where the chain is 0.36 ms); fe_worker = 2 (default) draws the line at 32 768 fragments, 1 / 0: always / never
   const int fe_worker = thip_option("fe_worker");
-  // (option fe_pair_tail, round 6: the second thread also walks the lists and pairs the LAST group's tokens with their fragments,
-  //  FeWorker -- then it runs at every size: what it takes off the device's walk behind the packet's last bit is worth a thread)
-  const bool want_tail = streaming && !d->device_dc && thip_option("fe_pair_tail") != 0;
-  with_worker = lists_now && !d->device_dc && (want_tail || fe_worker == 1 || (fe_worker == 2 && d->nfrags > 32768));
+  with_worker = lists_now && !d->device_dc && (fe_worker == 1 || (fe_worker == 2 && d->nfrags > 32768));
   if (with_worker && !d->worker) {
     d->worker = new (std::nothrow) FeWorker();
     if (d->worker) {
@@ -2096,19 +1989,8 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
     if (thip_option("fe_worker_pin") != 0) fe_worker_place(w);
     if (w.solo) with_worker = false;
   }
-  const bool pair_tail = r.pair_tail = want_tail && with_worker;
   if (with_worker) {
     FeWorker &w = *d->worker;
-    w.pair_tail = pair_tail;
-    w.tail_ok = false;
-    w.nwords = 0;
-    w.z_tail = 64;
-    if (pair_tail) {   // the last group's first index
-      int zt = 0;
-      for (int g = 0; d->fs.ends[g] != 64; g++) zt = d->fs.ends[g];
-      w.z_tail = zt;
-    }
-    w.lists_done.store(0, std::memory_order_relaxed);
     w.z0_ready.store(0, std::memory_order_relaxed);
     w.done.store(0, std::memory_order_relaxed);
     {
@@ -2218,15 +2100,10 @@ static int fe_front(th_dec_ctx *d, const ogg_packet *op, int64_t *granpos, FeRun
         // (a malformed stream that asks for more tokens than the list has finds its blocks ended)
         out->value = 0; out->skip = 0; out->adv = 0; out->eob = 0xFFFFFFFFu;
         d->prof.tokens += (long)d->ntoks[p][z];
-        if (pair_tail) d->worker->lists_done.store(z * 3 + p + 1, std::memory_order_release);   // the second thread may walk this list
       }
       if (z == 0 && with_worker) d->worker->z0_ready.store(1, std::memory_order_release);   // the DC chain can start
-      // the three lists of index z are complete; with them maybe a group (the last one stays here when the second thread pairs it:
-      // fe_back hands it over with the thread's words)
-      if (streaming && fe_stream_pack_index(d, z) && stream_rc >= 0) {
-        if (pair_tail && z == 63) r.tail_deferred = true;
-        else stream_rc = fe_stream_append(d, d->fs.gi - 1);
-      }
+      // the three lists of index z are complete; with them maybe a group
+      if (streaming && fe_stream_pack_index(d, z) && stream_rc >= 0) stream_rc = fe_stream_append(d, d->fs.gi - 1);
     }
   }
   d->prof.lap(FE_TOKENS);
@@ -2370,20 +2247,6 @@ static int fe_back(th_dec_ctx *d, int64_t *granpos, FeRun &r) {
     if (lrc >= 0 && d->fs.overflow) {
       (void)thip_state_token_lists_abort(d->hip);
       lrc = THIP_EINVAL;
-    }
-    if (lrc >= 0 && r.tail_deferred) {
-      // the last group: with the second thread's words the device pairs nothing (k_tok_scatter); without them -- the walk disagreed
-      // with the caller's counts, or the words do not fit behind the tokens -- the device walks the group as it walks the others
-      const int g = d->fs.gi - 1;
-      FeWorker &w = *d->worker;
-      int arc = THIP_EIMPL;
-      if (w.tail_ok && (int64_t)w.nwords == d->fs.grp_ntok[g])
-        arc = thip_state_token_lists_append_assigned(d->hip, d->fs.grp_z0[g], d->fs.stg.tokens + d->fs.grp_start[g], w.words.data(), d->fs.grp_ntok[g],
-                                                     w.lastz.data());
-      if (arc == THIP_EIMPL) arc = fe_stream_append(d, g);
-      else if (arc >= 0) thip_option_add("fe_tails_paired", 1);
-      lrc = arc;
-      if (lrc < 0) (void)thip_state_token_lists_abort(d->hip);
     }
     d->prof.lap(FE_LBEGIN);
     if (lrc >= 0) {
