@@ -722,7 +722,7 @@ def main_enc(emit=True, subset=False, calls_only=False, pmc=None):
             assert np.array_equal(want_v.cpu().numpy()[:ncpu].view(np.uint32), wv)
             return ncpu / tc
         case(op + "_search", "oc_enc_frag_%s, motion-search form (thip_enc_frag_metric_sites_batch)" % op, call_sites, npairs, "(block,candidate)", bpu,
-             ["k_enc_sites<%d>" % _lib.ENC_OPS[op]], chk_sites, unique_bytes=frame_bytes + nblk * 8 + npairs * (4 if op == "sad" else 8))
+             (["k_enc_sites_satd"] if op == "satd" else []) + ["k_enc_sites<%d>" % _lib.ENC_OPS[op]], chk_sites, unique_bytes=frame_bytes + nblk * 8 + npairs * (4 if op == "sad" else 8))
     # --- the half-pel refinement around each block's whole-pel vector: eight sites (thip_enc_frag_metric_halfpel_batch; what the
     #     reference does with eight oc_enc_frag_satd2 / oc_enc_frag_sad2_thresh calls per block, mcenc.c:551-657) -----------------------
     hp_sites = [(-1, -1), (0, -1), (1, -1), (-1, 0), (1, 0), (-1, 1), (0, 1), (1, 1)]
@@ -770,7 +770,7 @@ def main_enc(emit=True, subset=False, calls_only=False, pmc=None):
                     assert np.array_equal(v.reshape(len(sites), -1)[si].cpu().numpy()[sel].view(np.uint32), wv)
                 return 3 * ncpu / tc
             case("%s_search_x%d" % (op, F), "oc_enc_frag_%s, motion-search form, %d frames per call" % (op, F), call_sitesF, baseF.size * len(sites),
-                 "(block,candidate)", bpu, ["k_enc_sites<%d>" % _lib.ENC_OPS[op]], chk_sitesF,
+                 "(block,candidate)", bpu, (["k_enc_sites_satd"] if op == "satd" else []) + ["k_enc_sites<%d>" % _lib.ENC_OPS[op]], chk_sitesF,
                  unique_bytes=2 * baseF.size * 64 + baseF.size * 8 + baseF.size * len(sites) * (4 if op == "sad" else 8), frames=F)
         if F == 4:
             vecsF = ((rng.integers(-2, 3, baseF.size) & 0xFF) | (rng.integers(-2, 3, baseF.size) << 8)).astype(np.int16)

@@ -593,6 +593,7 @@ const char *thip_version_string(void);
  *   faults_recovered   (counter) frames decoded a second time with the two passes because a bounded wait of k_recon_lf ran out
  *   tl_dc_copy     thip_state_token_lists_finish: 0 (default) a kernel copies the DC values out of the pinned staging buffer, 1 a copy engine
  *   spec_coeffs    k_recon_lf, levels form: 1 (default) frames with a unit for every block get their coefficients asked for at wave start (address from the tile number, checked later), 0 never
+ *   enc_sites_lds  thip_enc_frag_metric_sites_batch, SATD: 1 (default) the source block shared by a block's three lanes through LDS, 0 every lane its own
  *   enc_fdct_lanes thip_enc_fdct8x8_batch: 4 (default) four lanes per block, 1 one block per lane
  *   enc_fq_lanes   thip_enc_fdct_quantize_batch: 4 (default) four lanes per block, 1 one block per lane
  *   enc_halfpel_lanes  thip_enc_frag_metric_halfpel_batch: 2 (default) a lane per side with four sites each, 3 a lane per dx

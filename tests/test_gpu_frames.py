@@ -788,3 +788,86 @@ def test_a_failed_hand_over_on_the_callers_descriptors(hip, capfd):
     finally:
         L.thip_set_option(b"debug", 0)
         L.thip_set_option(b"redo_descs", 0)
+
+
+@pytest.mark.parametrize("content,skip_static,ahead_is_key", [("mixed", 1, False), ("static_bg", 2, False), ("smooth", 2, True)])
+def test_a_frame_decoded_ahead_is_taken_back_at_the_c_abi(hip, content, skip_static, ahead_is_key):
+    """thip_state_ring_mark / thip_state_ring_rewind (round 6; what th_decode_packetin does when, with option fe_pipeline, another
+    packet comes than the one th_decode_ycbcr_out decoded ahead): a frame -- an inter frame, or a key frame, which also moves the
+    golden reference (decode.c:2947-2955) -- decoded after the mark never happened once the ring is put back: the references are
+    the marked ones, the marked frame is the picture again, the next frames decode bit-exactly against an oracle that never saw
+    the discarded one, and no static-block shortcut is taken on what the discarded frame left in its buffer (skip_static = 2
+    applies the shortcut wherever it is allowed)."""
+    import ctypes as C
+    from theora_amd import _lib
+    L = _lib.load()
+    w, h = 336, 176
+    geom = synth.Geometry(w, h)
+    rng = np.random.default_rng(4711)
+    ost, gst = oracle.State(w, h), hip.State(w, h)
+    keep = []
+
+    def both(fr, oracle_too=True):
+        if oracle_too:
+            assert util.oracle_apply(ost, fr) == 0
+        d, ka = synth.upload_frame(synth.pack_frame(geom, fr))
+        keep.append(ka)
+        assert hip.decode_frames([gst], [d])[0] == 0
+    with util.options(L, skip_static=skip_static):
+        both(synth.gen_frame(geom, rng, hip.INTRA_FRAME, content, flimit=3))
+        for _ in range(2):
+            both(synth.gen_frame(geom, rng, hip.INTER_FRAME, content, flimit=3))
+        assert not util.planes_equal(ost, gst)
+        ring = [gst.ref_idx(k) for k in range(3)]
+        mark = (C.c_int64 * 8)()
+        assert L.thip_state_ring_mark(gst.handle, mark) == 0
+        assert L.thip_state_ring_rewind(gst.handle, mark) == 0                      # nothing decoded since: nothing happens
+        both(synth.gen_frame(geom, rng, hip.INTRA_FRAME if ahead_is_key else hip.INTER_FRAME, content, flimit=3), oracle_too=False)
+        assert [gst.ref_idx(k) for k in range(3)] != ring
+        assert L.thip_state_ring_rewind(gst.handle, mark) == 0
+        assert [gst.ref_idx(k) for k in range(3)] == ring
+        assert not util.planes_equal(ost, gst)                                    # the marked frame is the newest again
+        got = gst.ycbcr_out()
+        for pli in range(3):
+            assert np.array_equal(got[pli], ost.get_plane(oracle.FRAME_PREV, pli)[::-1]), pli
+        for _ in range(4):
+            both(synth.gen_frame(geom, rng, hip.INTER_FRAME, content, flimit=3))
+            assert not util.planes_equal(ost, gst)
+            assert ost.ref_frame_idx == [gst.ref_idx(k) for k in range(3)]
+        bad = (C.c_int64 * 8)()
+        assert L.thip_state_ring_rewind(gst.handle, bad) == _lib.EINVAL              # not a mark
+        assert L.thip_state_ring_mark(None, mark) == _lib.EFAULT
+    gst.close()
+    ost.close()
+
+
+def test_check_fault_repairs_for_a_caller_that_only_synchronises(hip, capfd):
+    """thip_state_check_fault: a caller that keeps its frames on the device and brackets its work with thip_synchronize
+    only never reaches the calls that repair a failed hand-over -- thip_synchronize REPORTS (THIP_EFAULT while a state's word is
+    set) and leaves the state to its owner.  The owner's thip_state_check_fault waits for the state's stream and does the repair: 1
+    = the newest frame was decoded again (bit-exact), after which thip_synchronize is quiet; 0 when nothing was wrong."""
+    L = hip._lib.load()
+    w, h = 512, 256
+    geom = synth.Geometry(w, h, PF_420)
+    rng = np.random.default_rng(99)
+    ost, gst = oracle.State(w, h, PF_420), hip.State(w, h, PF_420)
+    try:
+        for f in range(3):
+            fr = synth.gen_frame(geom, rng, hip.INTRA_FRAME if f == 0 else hip.INTER_FRAME, "dense", flimit=3)
+            util.oracle_apply(ost, fr)
+            L.thip_set_option(b"debug", 512 if f == 1 else 0)
+            util.enqueue_frame(hip, gst, geom, fr)
+            if f == 1:
+                L.thip_set_option(b"debug", 0)
+                with pytest.raises(hip.TheoraHipError):
+                    hip.synchronize()                 # reports, repairs nothing
+                assert gst.check_fault() == 1         # the owner's call: decoded again with the two passes
+                hip.synchronize()
+                assert "decoding the frame again" in capfd.readouterr().err
+            else:
+                assert gst.check_fault() == 0
+            assert not util.planes_equal(ost, gst), f
+    finally:
+        L.thip_set_option(b"debug", 0)
+    gst.close()
+    ost.close()

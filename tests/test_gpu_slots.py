@@ -177,7 +177,7 @@ def test_enc_metrics(hip, op):
             assert np.array_equal(want_dc, got_dc.cpu().numpy()), op
 
 
-@pytest.mark.parametrize("op", ["sad", "satd"])
+@pytest.mark.parametrize("op", ["sad", "satd", "satd_every_lane_its_own_source_block"])
 def test_enc_metric_sites(hip, op):
     """The motion-search form (thip_enc_frag_metric_sites_batch): every block against candidate positions in {-1,0,1}^2 around
     one reference position, results candidate-major -- against the oracle called once per (block, candidate) as the
@@ -185,6 +185,11 @@ def test_enc_metric_sites(hip, op):
     order, a subset in another order, a single candidate; reference positions of every byte alignment; flat, saturated and
     random pictures (the largest coefficients a block can have)."""
     from theora_amd import _lib
+    # (SATD: k_enc_sites_satd, the source block shared by a block's three lanes through LDS, is the default since round 6; option
+    #  enc_sites_lds = 0 is k_enc_sites<SATD>.  Block counts that end inside a wave's 21 blocks and inside a work group's 84.)
+    lds = 0 if op.startswith("satd_") else 1
+    op = op.split("_")[0]
+    _lib.load().thip_set_option(b"enc_sites_lds", lds)
     rng = np.random.default_rng(11 + len(op))
     stride, H = 272, 136
     src = rng.integers(0, 256, (H, stride)).astype(np.uint8)
@@ -205,6 +210,12 @@ def test_enc_metric_sites(hip, op):
             assert np.array_equal(want, got[c].cpu().numpy().view(np.uint32)), (op, sites, c)
             if op == "satd":
                 assert np.array_equal(want_dc, got_dc[c].cpu().numpy()), (op, sites, c)
+    for m in (1, 20, 22, 83, 85):
+        got, got_dc = hip.enc_metric_sites_batch(op, dev(src), dev(ref), stride, dev(so[:m]), dev(ro[:m]), full)
+        for c, (dx, dy) in enumerate(full):
+            want, want_dc = oracle.enc_metric_batch(op, src, ref, stride, so[:m], (ro[:m] + dy * stride + dx).astype(np.int32), ro[:m], 0)
+            assert np.array_equal(want, got[c].cpu().numpy().view(np.uint32)), (op, m, c)
+    _lib.load().thip_set_option(b"enc_sites_lds", 1)
     # argument errors: a position outside the pattern, a position twice, too many candidates, an operation without this form
     L = _lib.load()
     o = dev(np.zeros(9 * n, np.int32))

@@ -114,6 +114,7 @@ Option g_options[] = {
     {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
     {"sb_tiles", 600, "k_recon_lf_sb (one super block per wave, four lanes per block) instead of k_recon_lf for launches of fewer tiles than this (0: never)"},
     {"enc_halfpel_lanes", 2, "thip_enc_frag_metric_halfpel_batch: 2 (default): a lane per side (dx = -1 / +1), four sites each; 3: a lane per dx (two or three sites)"},
+    {"enc_sites_lds", 1, "thip_enc_frag_metric_sites_batch, SATD: 1 (default, round 6): k_enc_sites_satd, the source block shared by a block's three lanes through LDS; 0: k_enc_sites<SATD> (rounds 4-5)"},
     {"enc_fdct_lanes", 4, "thip_enc_fdct8x8_batch: 4 (default): four lanes per block (k_enc_fdct4); 1: one block per lane (k_enc_fdct, rounds 1-5)"},
     {"enc_fq_lanes", 4, "thip_enc_fdct_quantize_batch: 4 (default): four lanes per block (k_enc_fdct_quantize4); 1: one block per lane (round 4's kernel)"},
     {"redo_descs", 0, "thip_decode_frames on the caller's descriptors: 1: the caller promises that the buffers a descriptor points to stay as they are until the state's next synchronising call, so a frame whose hand-over failed can be decoded again like a th_decode_* frame; 0 (default): such a frame gets THIP_EFAULT"},

@@ -271,6 +271,91 @@ __global__ __launch_bounds__(256) void k_enc_sites(uint32_t *out, int32_t *dc_ou
   }
 }
 
+// The SATD search with the source block SHARED by the three lanes of a block (round 6; option enc_sites_lds = 0: k_enc_sites<SATD>).
+// k_enc_sites<SATD> keeps three things per lane -- the source block's 32 registers of horizontal levels, the ten reference rows'
+// 40, the difference block's 32: 109 registers, four waves per SIMD, and a 1080p 4:4:4 frame is 4 590 waves on 4 096 slots: a second
+// round of waves for an eighth of the work.  Here a wave takes 21 blocks (63 lanes: lane 3b + dxi), the three lanes of a block
+// prepare its eight source rows BETWEEN them (rows dxi, dxi + 3, dxi + 6: three row preparations a lane instead of eight) into the
+// wave's LDS (36 dwords a block: 32 + 4 of padding, so that sixteen blocks' reads fall on different banks), and the vertical levels
+// run one register column at a time straight off LDS and the prepared reference rows (d[r] = S[r][j] - E[r + dy][j]: the vertical
+// levels mix rows of ONE column only), so that neither the source block nor the difference block ever sits in registers.
+constexpr int kSiteBlocks = 21, kSitePitch = 36;
+#ifndef THIP_ENC_SITES_LDS_WAVES
+#define THIP_ENC_SITES_LDS_WAVES 6
+#endif
+__global__ __launch_bounds__(256, THIP_ENC_SITES_LDS_WAVES) void k_enc_sites_satd(uint32_t *out, int32_t *dc_out, const uint8_t *src_plane,
+                                                                               const uint8_t *ref_plane, int ystride, const int32_t *src_offs,
+                                                                               const int32_t *ref_offs, const SitesK K, int64_t nblocks) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_S[4][kSiteBlocks * kSitePitch];
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  uint32_t *const S = s_S[wave];
+  const int lb = lane / 3, dxi = lane - 3 * lb;   // (lane 63: block 21, idle)
+  const int64_t i = ((int64_t)blockIdx.x * 4 + wave) * kSiteBlocks + lb;
+  const bool live = lb < kSiteBlocks && i < nblocks;
+  int c[3];
+#pragma unroll
+  for (int dyi = 0; dyi < 3; dyi++) c[dyi] = K.site_of[dyi * 3 + dxi];
+  const bool mine = live && (c[0] & c[1] & c[2]) >= 0;   // some position of this lane's column is a candidate
+  uint2 srow[3], e[10];
+  if (live) {
+    const uint8_t *sp = src_plane + src_offs[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) srow[k] = load_row8(sp + (ptrdiff_t)min(dxi + 3 * k, 7) * ystride);
+  }
+  if (mine) {
+    const uint8_t *rp = ref_plane + ref_offs[i] - ystride + (dxi - 1);
+#pragma unroll
+    for (int r = 0; r < 10; r++) e[r] = load_row8(rp + (ptrdiff_t)r * ystride);
+  }
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int r = dxi + 3 * k;
+      pk16 R[4];
+      row_sd(R, srow[k]);
+      row_h12(R);
+      if (r < 8) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) S[lb * kSitePitch + j * 8 + r] = as_u32(R[j]);
+      }
+    }
+  }
+  if (!mine) return;   // (its share of the source block is in LDS: the wave's loads and stores are issued in order, nobody waits for this lane)
+  pk16 E[10][4];
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    row_sd(E[r], e[r]);
+    row_h12(E[r]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int dyi = 0; dyi < 3; dyi++) {
+    if (c[dyi] < 0) continue;
+    uint32_t acc = 0;
+    int dc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint4 s0 = *reinterpret_cast<const uint4 *>(S + lb * kSitePitch + j * 8), s1 = *reinterpret_cast<const uint4 *>(S + lb * kSitePitch + j * 8 + 4);
+      pk16 d[8] = {as_pk(s0.x) - E[dyi + 0][j], as_pk(s0.y) - E[dyi + 1][j], as_pk(s0.z) - E[dyi + 2][j], as_pk(s0.w) - E[dyi + 3][j],
+                   as_pk(s1.x) - E[dyi + 4][j], as_pk(s1.y) - E[dyi + 5][j], as_pk(s1.z) - E[dyi + 6][j], as_pk(s1.w) - E[dyi + 7][j]};
+#pragma unroll
+      for (int r = 0; r < 4; r++) bfly(d[r], d[r + 4]);   // r2, r1 (satd_vert)
+      bfly(d[0], d[2]);
+      bfly(d[1], d[3]);
+      bfly(d[4], d[6]);
+      bfly(d[5], d[7]);
+      if (j == 0) dc = (int)d[0].x + (int)d[1].x;
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) {
+        const pk16 p = d[r], q = d[r + 1], z = {0, 0};
+        acc = sum2_u16(__builtin_elementwise_max(__builtin_elementwise_max(p, q), z - __builtin_elementwise_min(p, q)), acc);
+      }
+    }
+    out[(int64_t)c[dyi] * nblocks + i] = 2u * acc - (uint32_t)(dc < 0 ? -dc : dc);
+    if (dc_out) dc_out[(int64_t)c[dyi] * nblocks + i] = dc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // half-pel refinement: every block against the half-pel positions around ONE whole-pel vector (mcenc.c:596-657)
 // ---------------------------------------------------------------------------------------------------------------

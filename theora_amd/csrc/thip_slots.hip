@@ -832,9 +832,12 @@ int thip_enc_frag_metric_sites_batch(int op, uint32_t *out, int32_t *dc_out, con
   if (op == THIP_ENC_SAD)
     hipLaunchKernelGGL(k_enc_sites<THIP_ENC_SAD>, grid_for(3 * nblocks), dim3(256), 0, g_batch_stream, out, dc_out, src_plane, ref_plane,
                        ystride, src_offs, ref_offs, K, nblocks);
-  else
+  else if (thip_option("enc_sites_lds") == 0)
     hipLaunchKernelGGL(k_enc_sites<THIP_ENC_SATD>, grid_for(3 * nblocks), dim3(256), 0, g_batch_stream, out, dc_out, src_plane, ref_plane,
                        ystride, src_offs, ref_offs, K, nblocks);
+  else   // the source block shared by a block's three lanes through LDS (thip_enc.h)
+    hipLaunchKernelGGL(k_enc_sites_satd, dim3((unsigned)((nblocks + 4 * kSiteBlocks - 1) / (4 * kSiteBlocks))), dim3(256), 0, g_batch_stream, out, dc_out,
+                       src_plane, ref_plane, ystride, src_offs, ref_offs, K, nblocks);
   HIP_TRY(hipGetLastError());
   if (g_batch_sync) HIP_TRY(hipStreamSynchronize(g_batch_stream));
   return THIP_OK;

@@ -67,6 +67,14 @@ for l in sys.stdin:
   python tools/make_clip720.py > /dev/null 2>&1
   for t in 0 1; do echo "== stage table 720p plain loop, fe_pair_tail $t" >> $o/stage_tables.txt; THIP_FE_PAIR_TAIL=$t THIP_FE_PROF=1 examples/decode_bench gpurun_out/clip720.ogv 1 3 >> $o/stage_tables.txt 2>&1; done
   tail -60 $o/stage_tables.txt ;;
+ab5)
+  timeout 1500 python -m pytest tests/test_gpu_slots.py tests/test_gpu_frames.py -m gpu -q > $o/pytest_slots_frames.txt 2>&1; tail -5 $o/pytest_slots_frames.txt
+  for round in 1 2; do for l in 1 0; do echo "== enc_sites_lds $l (round $round)"; THIP_ENC_SITES_LDS=$l python bench.py --mode enc 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    if 'satd_search' in d['key'] or d['key'] in ('fdct', 'cost_maps'): print('   %-18s %9.1f M/s %7.2f us' % (d['key'], d['value'], 1e3 * d['ms_per_call']))"
+  done; done 2>&1 | tee $o/enc_sites_lds.txt ;;
 final)
   Q2="--no-cpu-baseline --no-parity --no-profile --no-pmc --no-1080p --no-e2e --no-wide --no-enc --no-form16 --second-content ''"
   timeout 2400 python -m pytest tests -m gpu -q > $o/pytest_gpu.txt 2>&1; tail -3 $o/pytest_gpu.txt
