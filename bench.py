@@ -660,7 +660,7 @@ def main_enc(emit=True, subset=False, calls_only=False, pmc=None):
         assert np.array_equal(got[:ncpu_blk], want)
         memo["fdct_out"], memo["tc_fdct"] = got, tc
         return ncpu_blk / tc
-    case("fdct", "oc_enc_fdct8x8", lambda: theora_amd.fdct8x8_batch(d_res), nblk, "blocks", 256, ["k_enc_fdct"], chk_fdct)
+    case("fdct", "oc_enc_fdct8x8", lambda: theora_amd.fdct8x8_batch(d_res), nblk, "blocks", 256, ["k_enc_fdct4", "k_enc_fdct"], chk_fdct)
     # --- quantiser (enquant.c:219) on the fDCT output ------------------------------------------
     d_dct = theora_amd.fdct8x8_batch(d_res)
     dq = np.clip(np.arange(64) * 3 + 16, 8, 4096).astype(np.uint16)
