@@ -75,6 +75,10 @@ for l in sys.stdin:
     d = json.loads(l)
     if 'satd_search' in d['key'] or d['key'] in ('fdct', 'cost_maps'): print('   %-18s %9.1f M/s %7.2f us' % (d['key'], d['value'], 1e3 * d['ms_per_call']))"
   done; done 2>&1 | tee $o/enc_sites_lds.txt ;;
+soak)
+  timeout 400 python tests/soak_take_back.py 7 150 2>&1 | tail -3 | tee $o/soak_take_back.txt
+  timeout 400 python tests/soak_frontend.py 11 120 2>&1 | tail -2 | tee $o/soak_frontend.txt
+  python bench.py --detail $o/bench_detail.json > $o/bench_default.json 2> $o/bench_default.err; tail -c 300 $o/bench_default.json ;;
 final)
   Q2="--no-cpu-baseline --no-parity --no-profile --no-pmc --no-1080p --no-e2e --no-wide --no-enc --no-form16 --second-content ''"
   timeout 2400 python -m pytest tests -m gpu -q > $o/pytest_gpu.txt 2>&1; tail -3 $o/pytest_gpu.txt
