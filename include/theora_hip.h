@@ -99,7 +99,7 @@ int thip_state_ycbcr_map(thip_state *st, const uint8_t *planes[3], int32_t strid
 int thip_state_ycbcr_map_begin(thip_state *st);
 int thip_state_ycbcr_map_end(thip_state *st, const uint8_t *planes[3], int32_t strides[3]);
 /* A frame decoded AHEAD of its turn can be taken back: _mark notes the reference ring (which buffer is GOLD / PREV / the frame
-   decoded last: oc_theora_state.ref_frame_idx, state.h:404) before such a frame is handed over, _rewind puts the ring back --
+   decoded last: oc_theora_state.ref_frame_idx, state.h:433; rotated at decode.c:2947-2962) before such a frame is handed over, _rewind puts the ring back --
    the frames decoded since the mark never happened as far as references and pictures go: the next frame is decoded against the
    marked references, thip_state_ycbcr_map shows the marked frame again (the picture a _map_begin named before the mark stays
    valid).  What the discarded frame left in its buffer, its half of the coded map and the host image it went to is treated as
