@@ -292,15 +292,19 @@ __global__ __launch_bounds__(256) void k_enc_fdct(int16_t *y, const int16_t *x, 
   store_block16_wave(y, i, n, o, lds);
 }
 
+// zig-zag index of natural position (the inverse of kFZigZag), a byte each: k_enc_fdct4's lanes read the eight of a row at once
+__device__ __attribute__((aligned(8))) constexpr uint8_t kIZigZag8[64] = {
+    0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+    10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
 // oc_enc_fdct8x8 with FOUR lanes per block (round 6; the layout of k_enc_fdct_quantize4 below, without its second half): one block per
 // lane is 700 dependent instructions a wave on 1.5 waves per SIMD behind one exposed round trip, 105 registers and 32 KB of LDS a
 // work group -- 10.4 us for the 25 MB of a 1080p 4:4:4 frame.  Lane 4b + j takes columns 2j, 2j + 1 of block b for the first pass
 // (fdct.c:143), the block is transposed through the wave's 2 KB of LDS as int16 pairs, the lane takes rows 2j, 2j + 1 for the
 // second (fdct.c:145); the zig-zag order (fdct.c:149) happens on the way out through the same 2 KB, so that loads and stores are
 // whole 16-byte pieces.
+
 __global__ __launch_bounds__(256) void k_enc_fdct4(int16_t *y, const int16_t *x, int64_t n) {
-  __shared__ __attribute__((aligned(8))) uint8_t s_zz[64];   // zig-zag index of a natural position
-  if (threadIdx.x < 64) s_zz[kFZigZag[threadIdx.x]] = (uint8_t)threadIdx.x;
   __shared__ int4 s_x[4 * 128];                          // 2 KB a wave: 16 blocks of eight 16-byte pieces (piece r = row r)
   int4 *lds = s_x + (threadIdx.x >> 6) * 128;
   const int lane = (int)threadIdx.x & 63, b = lane >> 2, j = lane & 3;
@@ -314,7 +318,10 @@ __global__ __launch_bounds__(256) void k_enc_fdct4(int16_t *y, const int16_t *x,
       if (b0 + bb < n) lds[bb * 8 + ((pc + bb) & 7)] = g[idx];
     }
   }
-  __syncthreads();   // (the table too)
+  // (the wave's own 2 KB: no other wave reads them, the wave's LDS operations are issued in order -- no barrier; the zig-zag
+  //  indices of the lane's two rows come out of a 64-byte table in memory, asked for now)
+  const uint2 zz0 = reinterpret_cast<const uint2 *>(kIZigZag8)[2 * j], zz1 = reinterpret_cast<const uint2 *>(kIZigZag8)[2 * j + 1];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int *ldw = reinterpret_cast<const int *>(lds);
   int c0[8], c1[8];   // columns 2j and 2j + 1
 #pragma unroll
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256) void k_enc_fdct4(int16_t *y, const int16_t *x,
   for (int h = 0; h < 2; h++) {
     const int r = 2 * j + h;
     const int4 w = lds[b * 8 + ((r + b) & 7)];
-    zz[h] = *reinterpret_cast<const uint2 *>(s_zz + r * 8);
+    zz[h] = h ? zz1 : zz0;
     int v[8] = {sx16(w.x), w.x >> 16, sx16(w.y), w.y >> 16, sx16(w.z), w.z >> 16, sx16(w.w), w.w >> 16};
     fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll

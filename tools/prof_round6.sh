@@ -75,6 +75,14 @@ for l in sys.stdin:
     d = json.loads(l)
     if 'satd_search' in d['key'] or d['key'] in ('fdct', 'cost_maps'): print('   %-18s %9.1f M/s %7.2f us' % (d['key'], d['value'], 1e3 * d['ms_per_call']))"
   done; done 2>&1 | tee $o/enc_sites_lds.txt ;;
+ab6)
+  timeout 600 python -m pytest tests/test_gpu_slots.py -m gpu -q -k "fdct" 2>&1 | tail -2
+  for round in 1 2 3; do for lib in theora_amd/libtheora_hip.so tools/_build/ab/fdct4_lds_zz.so; do echo "== $lib (round $round)"; THIP_LIB=$lib python bench.py --mode enc 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    if d['key'] in ('fdct',): print('   %-18s %9.1f M/s %7.2f us' % (d['key'], d['value'], 1e3 * d['ms_per_call']))"
+  done; done 2>&1 | tee $o/fdct4_barrier.txt ;;
 soak)
   timeout 400 python tests/soak_take_back.py 7 150 2>&1 | tail -3 | tee $o/soak_take_back.txt
   timeout 400 python tests/soak_frontend.py 11 120 2>&1 | tail -2 | tee $o/soak_frontend.txt
