@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_enc_fdct(int16_t *y, const int16_t *x, 
 }
 
 // zig-zag index of natural position (the inverse of kFZigZag), a byte each: k_enc_fdct4's lanes read the eight of a row at once
-__device__ __attribute__((aligned(8))) constexpr uint8_t kIZigZag8[64] = {
+__device__ __attribute__((aligned(8), unused)) constexpr uint8_t kIZigZag8[64] = {
     0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
     10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
