@@ -47,3 +47,21 @@ def test_fuse_option_switches_paths_inside_one_process(hip):
                 assert not util.planes_equal(ost, gst), (w, h, f)
     finally:
         L.thip_set_option(b"fuse", old)
+
+
+def test_half_tile_variant(hip):
+    """k_recon_lf_h (round 6: two super blocks a wave, two lanes a block -- the launches between k_recon_lf_sb's and k_recon_lf's)
+    forced for EVERY fused launch (THIP_SB_TILES=0 THIP_HALF_TILES=huge): the sequence tests of test_gpu_frames.py -- all formats
+    and sizes from 16x16 to 8K, ragged tiles, plane widths that end inside a half tile, batches, the grey start, four 4K streams in
+    one call, the loop filter's row ranges -- the levels-form tests, and the forced failure of a tile hand-over with its recovery."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, THIP_SB_TILES="0", THIP_HALF_TILES="100000000")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sel = ("sequence or enqueue or batched or grey or dup or lane_shared or static_background or four_concurrent "
+           "or dc_unprediction or beyond_4k or frame_calls or hand_over or failed or taken_back or config3")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "tests/test_gpu_levels.py", "-m", "gpu", "-x", "-q", "-k",
+                        sel + " or levels or wide or form"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -112,6 +112,7 @@ Option g_options[] = {
     {"fe_trace_backend", 0, "th_decode_*: record the slot calls instead of running them (tests)"},
     {"fe_prof", 0, "th_decode_*: per-stage host timing"},
     {"device", -1, "th_decode_alloc: -1 the current device, n that device, -2 round robin over the node's devices (THIP_DEVICE=rr)"},
+    {"half_tiles", 0, "k_recon_lf_h (two super blocks per wave, two lanes per block) for launches of at least sb_tiles and fewer tiles than this (0: never)"},
     {"sb_tiles", 600, "k_recon_lf_sb (one super block per wave, four lanes per block) instead of k_recon_lf for launches of fewer tiles than this (0: never)"},
     {"enc_halfpel_lanes", 2, "thip_enc_frag_metric_halfpel_batch: 2 (default): a lane per side (dx = -1 / +1), four sites each; 3: a lane per dx (two or three sites)"},
     {"enc_sites_lds", 1, "thip_enc_frag_metric_sites_batch, SATD: 1 (default, round 6): k_enc_sites_satd, the source block shared by a block's three lanes through LDS; 0: k_enc_sites<SATD> (rounds 4-5)"},
@@ -245,6 +246,8 @@ struct thip_state {
   int redo_owned;       // set by the callers whose descriptors point into the state's own buffers, around their thip_decode_frames call
   uint8_t *d_edge;      // device, k_recon_lf: kTfRec bytes per tile (the tiles' edges for their neighbours)
   uint32_t edge_epoch;  // serial number of the last k_recon_lf launch for this state (0 = never: the records are zero); 12 bits
+  uint8_t *d_edge_h;    // ... k_recon_lf_h's (a record per half tile; 12-bit serial numbers of its own like the other two)
+  uint32_t edge_epoch_h;
   uint8_t *d_edge_sb;   // ... and k_recon_lf_sb's: a record per super block (a buffer and a serial number of its own: a tag vouches for
   uint32_t edge_epoch_sb;   //  the bytes in front of it only while every launch that uses the buffer rewrites every unit of it)
   int device_dc, enq_device_dc;
@@ -728,6 +731,7 @@ void thip_state_free(thip_state *st) {
   if (st->ev_order) (void)hipEventDestroy(st->ev_order);
   if (st->d_edge) (void)hipFree(st->d_edge);
   if (st->d_edge_sb) (void)hipFree(st->d_edge_sb);
+  if (st->d_edge_h) (void)hipFree(st->d_edge_h);
   for (int k = 0; k < 2; k++)
     if (st->h_tl_buf[k]) (void)hipHostFree(st->h_tl_buf[k]);
   if (st->d_tl) (void)hipFree(st->d_tl);
@@ -1314,8 +1318,9 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     // the chip empty, one wave per super block (thip_fused_sb.h)
     int longest = 1, total_tiles = 0;
     for (int j = 0; j < nlive; j++) total_tiles += B.s[j].tile_end[2];
-    const int sb_tiles = THIP_OPT("sb_tiles");
+    const int sb_tiles = THIP_OPT("sb_tiles"), half_tiles = THIP_OPT("half_tiles");
     const bool small = sb_tiles > 0 && total_tiles < sb_tiles;
+    const bool half = !small && half_tiles > 0 && total_tiles < half_tiles;   // two super blocks a wave, two lanes a block (k_recon_lf_h)
     for (int j = 0; j < nlive; j++) {
       thip_state *st = states[live_state[j]];
       StreamK &K = B.s[j];
@@ -1332,6 +1337,17 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
         st->redo.launch_id = K.epoch | 0x1000u;
         continue;
       }
+      if (half) {
+        if (!st->d_edge_h) {
+          HIP_TRY(hipMalloc((void **)&st->d_edge_h, (size_t)2 * K.tile_end[2] * Tf8::kRec));
+          HIP_TRY(hipMemsetAsync(st->d_edge_h, 0, (size_t)2 * K.tile_end[2] * Tf8::kRec, s));
+        }
+        K.edge = st->d_edge_h;
+        st->edge_epoch_h = st->edge_epoch_h % 4095u + 1u;
+        K.epoch = st->edge_epoch_h;
+        st->redo.launch_id = K.epoch | 0x2000u;
+        continue;
+      }
       if (!st->d_edge) {
         HIP_TRY(hipMalloc((void **)&st->d_edge, (size_t)K.tile_end[2] * kTfRec));
         HIP_TRY(hipMemsetAsync(st->d_edge, 0, (size_t)K.tile_end[2] * kTfRec, s));
@@ -1345,6 +1361,9 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     if (small) {
       if (levels) hipLaunchKernelGGL(k_recon_lf_sb<true>, dim3(8 * longest, nlive), dim3(256), 0, s, B);
       else hipLaunchKernelGGL(k_recon_lf_sb<false>, dim3(8 * longest, nlive), dim3(256), 0, s, B);
+    } else if (half) {
+      if (levels) hipLaunchKernelGGL(k_recon_lf_h<true>, dim3(8 * longest, nlive), dim3(128), 0, s, B);
+      else hipLaunchKernelGGL(k_recon_lf_h<false>, dim3(8 * longest, nlive), dim3(128), 0, s, B);
     } else if (levels) hipLaunchKernelGGL(k_recon_lf<true>, dim3(8 * longest, nlive), dim3(64), 0, s, B);
     else hipLaunchKernelGGL(k_recon_lf<false>, dim3(8 * longest, nlive), dim3(64), 0, s, B);
   } else {

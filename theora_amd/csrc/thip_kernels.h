@@ -705,7 +705,8 @@ __device__ __forceinline__ void residual_shared_load(const int4 *coeffs, const C
 // COMPACT: the results go where the exchange was (4 KB of LDS instead of 8 for LPB = 2): every lane
 // collects all its column pairs first, the wave's LDS traffic settles, then results are written.
 // OUT = 32: the owner lane collects its whole block (Y[32]); OUT = 8 (k_recon_lf_sb, four lanes per block of the PICTURE too):
-// lane 4b + p collects rows 2p, 2p+1 of block b, whose owner rank is `prefix` (Y[8]).  tab16: where the tables are (levels form).
+// lane 4b + p collects rows 2p, 2p+1 of block b, whose owner rank is `prefix` (Y[8]); OUT = 16 (k_recon_lf_h, two lanes per block):
+// lane 2b + p collects rows 4p .. 4p + 3 (Y[16]).  tab16: where the tables are (levels form).
 template <int LPB, bool COMPACT = false, int OUT = 32>
 __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], const CoefForm &F, uint32_t *lds, uint32_t *meta, int lane,
                                                 const ReconLane &L, uint32_t prefix, uint32_t *Y, int tab16 = kLdsTabOff / 16) {
@@ -802,7 +803,8 @@ __device__ __forceinline__ void residual_shared(const int4 W[4 / LPB][2], const 
     for (int r = 0; r < 8; r++) res[g * 32 + r * 4 + cp] = as_u32(pk_descale(Qc[n][r]));   // Y[r*4+k] layout of the owner
   }
   if (L.has_coeff) {
-    const uint4 *y4 = reinterpret_cast<const uint4 *>(res + prefix * 32) + (OUT == 8 ? 2 * (lane & 3) : 0);
+    // (OUT < 32: the block belongs to 32 / OUT lanes of the picture too, each collects its rows)
+    const uint4 *y4 = reinterpret_cast<const uint4 *>(res + prefix * 32) + (OUT == 8 ? 2 * (lane & 3) : (OUT == 16 ? 4 * (lane & 1) : 0));
 #pragma unroll
     for (int q = 0; q < OUT / 4; q++) {
       const uint4 w = y4[q];

@@ -83,6 +83,20 @@ for l in sys.stdin:
     d = json.loads(l)
     if d['key'] in ('fdct',): print('   %-18s %9.1f M/s %7.2f us' % (d['key'], d['value'], 1e3 * d['ms_per_call']))"
   done; done 2>&1 | tee $o/fdct4_barrier.txt ;;
+half)
+  timeout 2400 python -m pytest tests/test_gpu_zz_launch_variants.py -m gpu -q -x -k half > $o/pytest_half.txt 2>&1; tail -25 $o/pytest_half.txt
+  for round in 1 2; do
+    for ht in 0 1600; do
+      THIP_HALF_TILES=$ht bash -c "python bench.py --size 1080p --streams-per-gpu 1 --steps 256 $Q" 2>/dev/null | show "1080p_1stream half_tiles=$ht"
+      THIP_HALF_TILES=$ht bash -c "python bench.py --size 720p --streams-per-gpu 2 --steps 256 $Q" 2>/dev/null | show "720p_2streams half_tiles=$ht"
+    done
+    THIP_HALF_TILES=4000 bash -c "python bench.py --size 1080p --streams-per-gpu 2 --steps 256 $Q" 2>/dev/null | show "1080p_2streams half_tiles=4000"
+    THIP_HALF_TILES=0 bash -c "python bench.py --size 1080p --streams-per-gpu 2 --steps 256 $Q" 2>/dev/null | show "1080p_2streams half_tiles=0"
+    THIP_HALF_TILES=4000 bash -c "python bench.py --size 1080p --streams-per-gpu 4 --steps 256 $Q" 2>/dev/null | show "1080p_4streams half_tiles=4000"
+    THIP_HALF_TILES=0 bash -c "python bench.py --size 1080p --streams-per-gpu 4 --steps 256 $Q" 2>/dev/null | show "1080p_4streams half_tiles=0"
+    THIP_SB_TILES=0 THIP_HALF_TILES=600 bash -c "python bench.py --size 720p --streams-per-gpu 1 --steps 256 $Q" 2>/dev/null | show "720p_1stream half instead of sb"
+    bash -c "python bench.py --size 720p --streams-per-gpu 1 --steps 256 $Q" 2>/dev/null | show "720p_1stream sb"
+  done 2>&1 | tee $o/ab_half.txt ;;
 soak)
   timeout 400 python tests/soak_take_back.py 7 150 2>&1 | tail -3 | tee $o/soak_take_back.txt
   timeout 400 python tests/soak_frontend.py 11 120 2>&1 | tail -2 | tee $o/soak_frontend.txt
