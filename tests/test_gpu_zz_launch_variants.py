@@ -62,6 +62,6 @@ def test_half_tile_variant(hip):
     sel = ("sequence or enqueue or batched or grey or dup or lane_shared or static_background or four_concurrent "
            "or dc_unprediction or beyond_4k or frame_calls or hand_over or failed or taken_back or config3")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_frames.py", "tests/test_gpu_levels.py", "-m", "gpu", "-x", "-q", "-k",
-                        sel + " or levels or wide or form"],
+                        "(" + sel + " or levels or wide or form) and not one_tile_per_wave"],   # (that test sets sb_tiles itself)
                        cwd=root, env=env, capture_output=True, text=True, timeout=2400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
