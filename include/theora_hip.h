@@ -580,6 +580,8 @@ const char *thip_version_string(void);
  *   sb_tiles     launches of fewer tiles than this (all their streams together; default 600: a 720p frame has 345, a 1080p frame 782 and
  *                gains nothing) take k_recon_lf_sb -- one
  *                super block per wave, four lanes per block -- instead of k_recon_lf's one tile per wave (0: never)
+ *   half_tiles   launches of at least sb_tiles and fewer tiles than this take k_recon_lf_h -- two super blocks per wave, two lanes per
+ *                block (round 6) -- instead of k_recon_lf (default 0: never; measured: nothing for one 1080p stream, slower elsewhere)
  *   lanes        library-owned HIP streams per device for thip_decode_frames (default 2)
  *   ctx_lanes    HIP streams shared by the enqueue-fed states, i.e. th_decode_* contexts (default 8; 0 = the lanes)
  *   chunk        streams per kernel launch (default THIP_MAX_BATCH)
