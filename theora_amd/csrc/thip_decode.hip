@@ -88,7 +88,7 @@ Option g_options[] = {
     {"fe_device_tokens", 0, "th_decode_*: token expansion + dequantisation on the device (host-delimited tokens)"},
     {"fe_device_lists", -1, "th_decode_*: the token lists themselves on the device (1 on, 0 off, -1 on while at most four decoder contexts are alive)"},
     {"tl_dc_copy", 0, "token lists on the device, thip_state_token_lists_finish: 0 (default): a kernel copies the caller's DC values out of the pinned staging buffer (k_tok_copy); 1: a copy engine does (rounds 3-4)"},
-    {"spec_coeffs", 1, "k_recon_lf, levels form: 1 (default): for a frame with a coefficient unit for every block (nslots == its fragments) the waves ask for their tile's units when they start, at the address that follows from the tile's number, and check it against the first-slot word; 0: always after the command words"},
+    {"spec_coeffs", 1, "k_recon_lf, levels form: 1 (default): for a frame with a coefficient unit for every block (nslots == its fragments) the waves of whole tile rows ask for their tile's units when they start, at the address that follows from the tile's place in its plane, and check it against the first-slot word; 0: always after the command words"},
     {"tl_algo", 0, "token lists on the device: 1: k_tok_assign (rank -> fragment map in LDS, or in memory for planes beyond 36 864 coded fragments); 2: k_tok_rank + k_tok_walk (every fragment looked after by one thread, one barrier per index, one byte of LDS per fragment); 0 (default): 2 where 1 would keep its map in memory (4K), 1 otherwise"},
     {"tl_walk_threads", 0, "k_tok_walk: threads of the work group (256, 512, 1024); 0 (default): by plane size"},
     {"tl_levels", 1, "token lists on the device (thip_state_token_lists_*): 1 (default): the device writes the coefficient slots in the levels form (int8 units, the reconstruction kernel dequantises); 0: dequantised int16 slots"},
@@ -1220,16 +1220,17 @@ static int launch_chunk(thip_state *const *states, const thip_frame_desc *descs,
     st->buf_serial[bufi] = serial;
     K.flimit2 = 2 * d.flimit;
     K.debug = THIP_OPT("debug");
-    // a unit for every block of the frame, every plane a whole number of tiles wide: the first unit of a tile in the whole tile
-    // rows of a plane is the plane's first + 64 * the tile's number in the plane (StreamK::spec_*)
-    K.spec_on = 0;
-    if (d.coeff_format == THIP_COEFFS_LEVELS && d.nslots == st->nfrags && d.ncoded == st->nfrags && THIP_OPT("spec_coeffs") != 0 &&
-        st->geom[0].nhfrags % 16 == 0 && st->geom[1].nhfrags % 16 == 0 && st->geom[2].nhfrags % 16 == 0) {
-      K.spec_on = 1;
+    // a unit for every block of the frame: the first unit of a tile in the whole tile rows of a plane is the plane's first +
+    // 4 nhfrags * its tile row + 64 * its place in the row (StreamK::spec_*)
+    K.spec_on = d.coeff_format == THIP_COEFFS_LEVELS && d.nslots == st->nfrags && d.ncoded == st->nfrags && THIP_OPT("spec_coeffs") != 0;
+    K.spec_last = d.nslots > 0 ? (uint32_t)d.nslots - 1u : 0u;
+    {
       uint32_t base = 0;
       for (int pli = 0; pli < 3; pli++) {
         K.spec_base[pli] = base;
-        K.spec_full[pli] = (st->geom[pli].nhfrags / 16) * (st->geom[pli].nvfrags / 4);
+        K.spec_rows[pli] = st->geom[pli].nvfrags / 4;
+        K.spec_rowunits[pli] = 4 * st->geom[pli].nhfrags;
+        K.spec_tx[pli] = st->tiles.tiles_x[pli];
         base += (uint32_t)st->geom[pli].nhfrags * (uint32_t)st->geom[pli].nvfrags;
       }
     }

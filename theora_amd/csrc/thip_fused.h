@@ -331,19 +331,23 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
                "s"(te0), "s"(te1), "s"(sqpx), "s"(sqpy), "s"(L2), "s"(ep), "s"(bu0), "s"(bu1), "s"(fault_p));
   const int u = bu0 + jb;
   if (u >= bu1) return;
+  // the tile's plane and its place in it (tiles across from StreamK::spec_tx: the plane's record is not at hand yet)
+  const int pli = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
+  const int rel = u - (pli == 0 ? 0 : (pli == 1 ? te0 : te1));
+  const int tiles_x = S.spec_tx[pli];
+  const int sby = rel / tiles_x, t = rel - sby * tiles_x;
   // ---- 0. (levels form, a frame with a unit for every block) the coefficients asked for NOW: the tile's first unit follows from
-  //      its number where every tile before it is whole, and what comes back is checked against the first-slot word when that
-  //      arrives -- a wave's second round trip, 3 of its 15 us, is gone for every tile the guess is right for; a wrong guess costs
-  //      its 4 KB and nothing else (the real loads land behind it, in order, in the same place)
+  //      its place in the plane wherever its tile row is whole, and what comes back is checked against the first-slot word when that
+  //      arrives -- a wave's second round trip, 3 of its 15 us, is gone for every tile the guess is right for; a wrong guess (and
+  //      the ragged tile at the end of a row, whose blocks do not all own a unit) costs its 4 KB and nothing else: the real loads
+  //      land behind it, in order, in the same place
   bool spec = false;
   uint32_t spec_slot0 = 0;
   if (LEVELS && S.spec_on) {
-    const int pl0 = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
-    const int rel0 = u - (pl0 == 0 ? 0 : (pl0 == 1 ? te0 : te1));
-    if (rel0 < S.spec_full[pl0]) {
+    if (sby < S.spec_rows[pli]) {
       spec = true;
-      spec_slot0 = S.spec_base[pl0] + 64u * (uint32_t)rel0;
-      const uint32_t unit = spec_slot0 + (uint32_t)lane;
+      spec_slot0 = S.spec_base[pli] + (uint32_t)(sby * S.spec_rowunits[pli]) + 64u * (uint32_t)t;
+      const uint32_t unit = min(spec_slot0 + (uint32_t)lane, S.spec_last);
 #pragma unroll
       for (int q = 0; q < 4; q++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)unit_piece(coeffs_p, unit, q),
@@ -362,15 +366,12 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
 #endif
   THIP_TR(tr, 0);
   THIP_PRIO_AT(0);
-  const int pli = (u >= te0 ? 1 : 0) + (u >= te1 ? 1 : 0);
   constexpr bool levels = LEVELS;   // (one kernel per coefficient form: each is straight-line code for its own)
   if (levels) tables_to_lds(dq_p, pli, lane, s_tf);   // (first: whoever has its command word has the tables)
   const PlaneK G = S.pl[pli];
   const int fy0 = S.lf_y0[pli], fy1 = S.lf_y1[pli];
   asm volatile("" ::"s"(G.nh), "s"(G.nv), "s"(G.stride), "s"(G.off), "s"(G.tiles_x), "s"(G.tiles_y), "s"(G.fro), "s"(fy0), "s"(fy1));
-  const int nh = G.nh, nv = G.nv, tiles_x = G.tiles_x;
-  const int rel = u - (pli == 0 ? 0 : (pli == 1 ? te0 : te1));
-  const int sby = rel / tiles_x, t = rel - sby * tiles_x;
+  const int nh = G.nh, nv = G.nv;
   // neighbours: inside the plane, and inside this band (bands are whole tile rows, so left / right always are)
   const bool has_left = t > 0, row_end = t == tiles_x - 1;
   const bool has_up = sby > 0, has_dn = sby < G.tiles_y - 1;

@@ -72,11 +72,16 @@ struct StreamK {
   uint32_t *fault;        // pinned host word of the stream's state: set by a kernel whose bounded wait ran out (k_recon_lf's hand-over)
   // k_recon_lf, levels form: the frame has one coefficient unit for every block (nslots == the frame's fragments: the dense class, an
   // intra frame at a high bit rate), so a tile's first unit is known without its first-slot word wherever the tile rows before it
-  // are whole -- spec_base[plane] + 64 * (tile within the plane), for the plane's first spec_full[plane] tiles -- and the wave asks
+  // are whole -- spec_base[plane] + 4 nhfrags * (tile row) + 64 * (tile in its row), in the plane's whole tile rows: only the LAST tile of a
+  // row can be ragged, so every tile's first unit is known and every tile of 64 blocks is a hit (round 6; round 5's patch asked for
+  // planes a whole number of tiles wide, which left 1080p -- chroma 120 blocks across -- out) -- and the wave asks
   // for its coefficients when it starts, beside the command words, instead of a round trip later
   int spec_on;
-  uint32_t spec_base[3];
-  int spec_full[3];
+  uint32_t spec_base[3];   // the plane's first unit
+  int spec_rows[3];        // its whole tile rows (nvfrags / 4)
+  int spec_rowunits[3];    // units a whole tile row holds (4 nhfrags)
+  uint32_t spec_last;      // the frame's last unit (a ragged tile's guess reaches past its own units: never past the array)
+  int spec_tx[3];          // tiles across (PlaneK::tiles_x, at hand before the plane's record is)
   PlaneK pl[3];
 };
 

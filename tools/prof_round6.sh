@@ -97,6 +97,17 @@ half)
     THIP_SB_TILES=0 THIP_HALF_TILES=600 bash -c "python bench.py --size 720p --streams-per-gpu 1 --steps 256 $Q" 2>/dev/null | show "720p_1stream half instead of sb"
     bash -c "python bench.py --size 720p --streams-per-gpu 1 --steps 256 $Q" 2>/dev/null | show "720p_1stream sb"
   done 2>&1 | tee $o/ab_half.txt ;;
+spec2)
+  timeout 1500 python -m pytest tests/test_gpu_frames.py tests/test_gpu_levels.py -m gpu -q -x > $o/pytest_kernels.txt 2>&1; tail -3 $o/pytest_kernels.txt
+  for round in 1 2 3; do
+    for spec in 0 1; do
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --size 1080p --streams-per-gpu 1 --steps 256 $Q" 2>/dev/null | show "1080p_1stream spec=$spec"
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --size 1080p --streams-per-gpu 4 --steps 256 $Q" 2>/dev/null | show "1080p_4streams spec=$spec"
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --steps 256 $Q" 2>/dev/null | show "4k_dense spec=$spec"
+      THIP_SPEC_COEFFS=$spec bash -c "python bench.py --steps 20 $Q" 2>/dev/null | show "4k_dense steps20 spec=$spec"
+    done
+  done 2>&1 | tee $o/ab_spec2.txt
+  python tools/lf_trace.py --size 1080p --streams 1 2>&1 | grep -v amdgpu.ids > $o/lf_trace_1080p_single.txt; head -13 $o/lf_trace_1080p_single.txt ;;
 soak)
   timeout 400 python tests/soak_take_back.py 7 150 2>&1 | tail -3 | tee $o/soak_take_back.txt
   timeout 400 python tests/soak_frontend.py 11 120 2>&1 | tail -2 | tee $o/soak_frontend.txt
