@@ -453,7 +453,10 @@ __global__ __launch_bounds__(64, THIP_TF_WAVES_PER_EU) void k_recon_lf(const Bat
     if (!spec_hit) dense_issue<7>(coeffs_p, F, L.has_coeff, prefix, s_tf, w7);
     if (valid) recon_issue(R, L, Q, inter, ref);
     THIP_PRIO_AT(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA data has landed (see k_recon)
+    // LDS-DMA data has landed (see k_recon) -- on a hit it has landed already: the guess was asked for before the command words, loads
+    // come back in order, and the command words are here; the transform then runs UNDER the predictor windows' round trip instead
+    // of behind it (what the guess is worth where the chip is nearly empty and that round trip is as long as the coefficients')
+    if (!spec_hit) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dense_finish<7>(coeffs_p, F, L.has_coeff, prefix, s_tf, lane, L, w7, Y);
   }
   if (!L.has_coeff) {
